@@ -1,0 +1,226 @@
+/*
+ * recattend.h — C ABI of librecattend.so: the MI355X (gfx950) implementation of the
+ * recurrent-attention decode loop of renmengye/rec-attend-public.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes (no torch / TF
+ * types) and returns an int:
+ *     0   success
+ *    <0   invalid argument (RA_E_*), nothing was launched / written
+ *    >0   a hipError_t raised by the runtime (see ra_last_error_string()), or for the
+ *         Hungarian entry points the documented positive status 1
+ * The library never allocates memory that crosses the boundary and keeps no global
+ * state besides a thread-local last-error string; every buffer (inputs, outputs,
+ * workspaces) is owned by the caller.  Device pointers are HIP device pointers on the
+ * current device; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All tensors are float32, NHWC, densely packed unless a stride is stated.
+ *
+ * Reference interfaces each entry point replaces are cited as file:line of the
+ * reference checkout (renmengye/rec-attend-public).
+ */
+#ifndef RECATTEND_H_
+#define RECATTEND_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RA_E_INVALID (-1)   /* null pointer / non-positive dim */
+#define RA_E_SHAPE (-2)     /* unsupported shape (alignment / divisibility) */
+#define RA_E_WORKSPACE (-3) /* workspace too small */
+#define RA_E_HUNG_BFS (-12)      /* hungarian.cc:124-127 LOG(FATAL) */
+#define RA_E_HUNG_PATH (-13)     /* hungarian.cc:146-150,156-160 */
+#define RA_E_HUNG_FLOW (-14)     /* hungarian.cc:184-188 */
+#define RA_E_HUNG_EQUALIZE (-15) /* hungarian.cc:446-450 */
+
+int ra_version(void);
+/* Human-readable description of the last non-zero return on this thread. */
+const char *ra_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------
+ * Hungarian matching — replaces the TF custom op
+ *   REGISTER_OP("Hungarian").Input("weights: float").Output("matching: float")
+ *     .Output("cover_x: float").Output("cover_y: float")          hungarian.cc:26-30
+ *   HungarianOp::Compute                                           hungarian.cc:36-85
+ * weights [B,N,M] -> matching [B,N,M], cover_x [B,N] (op shape [B,N,1]), cover_y [B,M]
+ * (op shape [B,1,M]).  The op's 2-D form (hungarian.cc:58-60,490-504) is B == 1.
+ * Bit-exact with the reference's float32 control flow.  Returns 0, or 1 when any example
+ * hit the outer 1000-iteration cap (the reference logs an error and returns the partial
+ * matching, hungarian.cc:363-377 — so does this), or RA_E_HUNG_* where the reference
+ * would LOG(FATAL).  Host pointers; runs on the calling thread; re-entrant.
+ * ---------------------------------------------------------------------------------- */
+int ra_hungarian_f32(const float *weights, int B, int N, int M, float *matching,
+                     float *cover_x, float *cover_y);
+
+/* Same contract on DEVICE pointers (one workgroup per example), so the training step
+ * needs no device->host sync.  status_dev (nullable): int[B] per-example codes as above
+ * (the return value only reports launch errors).  ws: device scratch of at least
+ * ra_hungarian_dev_workspace_bytes(B, N, M) bytes. */
+size_t ra_hungarian_dev_workspace_bytes(int B, int N, int M);
+int ra_hungarian_f32_dev(const float *weights, int B, int N, int M, float *matching,
+                         float *cover_x, float *cover_y, int *status_dev, void *ws,
+                         size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1  conv3x3 (+bias+BatchNorm(eval)+ReLU+maxpool) as an f32-MFMA implicit GEMM.
+ * Replaces one layer of nnlib.cnn's run_cnn (nnlib.py:229-253: conv2d :6-12 + b,
+ * batch_norm :65-128 in eval mode, act, max_pool :15-25) and — with RA_CONV_TRANSPOSED
+ * packing + `upsample` — one layer of nnlib.dcnn's run_dcnn (nnlib.py:362-400:
+ * concat(prev, skip), conv2d_transpose SAME stride 1|2, + b, BN, act).
+ *
+ * Input = channel-concat of src0 [B,Hs,Ws,C0] and (optional) src1 [B,Hs,Ws,C1];
+ * C0 % 4 == 0, C1 % 4 == 0.  With upsample == 1 the conv runs over the zero-stuffed
+ * image U[2i+1,2j+1] = src[i,j] of size [2Hs,2Ws] (the stride-2 transposed conv).
+ * Output y [B,Ho,Wo,Cout], Ho = H/pool, Wo = W/pool, pool in {1,2} (H, W even if 2).
+ * scale/shift [CoutP] fold the conv bias and BN:  y = max?(relu?(conv*scale + shift)).
+ * wpacked comes from ra_conv_pack_weights (device copy of it).
+ * ---------------------------------------------------------------------------------- */
+#define RA_CONV_TRANSPOSED 1 /* w is a conv2d_transpose filter [3,3,Cout,Cin] (nnlib.py:320-325) */
+
+/* Padded channel counts the kernel works in: CinP = roundup(Cin,4), CoutP in {16,32,64,128,...}. */
+int ra_conv_cout_padded(int Cout);
+/* Number of floats in the packed weight buffer for a [3,3,Cin,Cout] filter (Cin % 4 == 0). */
+size_t ra_conv_packed_floats(int Cin, int Cout);
+/* Host-side repack of a TF-layout filter into the kernel's B-operand order.
+ * w: [3,3,Cin_w,Cout] (or [3,3,Cout,Cin_w] with RA_CONV_TRANSPOSED), host pointer.
+ * chan_map (nullable): int[Cin] giving, for every kernel input channel, the filter's
+ * input-channel index it multiplies, or -1 for a zero (padding) channel; NULL = identity
+ * with Cin_w == Cin.  out: host buffer of ra_conv_packed_floats(Cin, Cout) floats. */
+int ra_conv_pack_weights(const float *w, int Cin_w, int Cout, int Cin, const int *chan_map,
+                         int flags, float *out);
+/* Host-side fold of bias + BN(eval) into scale/shift [CoutP] (nnlib.py:119: eps = 1e-3).
+ * beta/gamma/mean/var nullable together (no BN: scale = 1, shift = bias). */
+int ra_conv_fold_bn(const float *bias, const float *beta, const float *gamma, const float *mean,
+                    const float *var, int Cout, float eps, float *scale, float *shift);
+
+int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws,
+                   int upsample, const float *wpacked, const float *scale, const float *shift,
+                   int Cout, int relu, int pool, float *y, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  controller: glimpse read-out + LSTM + glimpse MLP (x iters) + controller MLP +
+ * attention-parameter decode.  Replaces full_model.py:668-722 (= box_model.py:416-468):
+ * nnlib.lstm unroll (nnlib.py:637-649, state = [c|h], zeroed every call
+ * full_model.py:674), nnlib.mlp run_mlp (nnlib.py:476-493) for glimpse_mlp (relu..,
+ * softmax) and ctrl_mlp, modellib.get_unnormalized_attn (modellib.py:843-847),
+ * get_normalized_var (:782-793).
+ * One workgroup per example.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ra_ctrl_desc {
+  int G;        /* glimpse map size gh*gw (full_model.py:311) */
+  int Cf;       /* feature depth (full_model.py:312), % 4 == 0 */
+  int hid;      /* ctrl_rnn_hid_dim, % 4 == 0, <= 256 */
+  int iters;    /* num_ctrl_rnn_iter */
+  int n_gmlp;   /* num_glimpse_mlp_layers (>= 1); dims hid,..,hid,G */
+  int n_cmlp;   /* num_ctrl_mlp_layers (>= 1); dims hid, mlp_dim.., 9 */
+  int mlp_dim;  /* ctrl_mlp_dim, % 4 == 0 */
+  int H, W;     /* image size, for the un-normalisation */
+  int Fh, Fw;   /* filter (patch) size */
+  int squash;       /* squash_ctrl_params (full_model.py:695-697) */
+  int fixed_var;    /* full_model.py:702-706 */
+  int dynamic_var;  /* full_model.py:708-709 */
+  int fixed_gamma;  /* full_model.py:711-716 */
+} ra_ctrl_desc;
+
+/* Packed controller weights (device), produced on the host by ra_ctrl_pack_weights:
+ *   lstm  [(Cf+hid)][4*hid]   rows = [x ; h], columns gate-major i,f,o,u ; + bias [4*hid]
+ *   gmlp  layer l: [hid][NoutP_l] + bias[NoutP_l]   (last layer NoutP = roundup(G,4))
+ *   cmlp  layer l: [..][NoutP_l] + bias            (last layer 9 -> 12)
+ * Layout offsets are internal; both sides use ra_ctrl_packed_floats. */
+size_t ra_ctrl_packed_floats(const ra_ctrl_desc *d);
+/* lstm_w: 12 host pointers in the order w_xi,w_hi,b_i, w_xf,w_hf,b_f, w_xu,w_hu,b_u,
+ * w_xo,w_ho,b_o (nnlib.py:532-609); gmlp_w / cmlp_w: {w_0,b_0,w_1,b_1,...}. */
+int ra_ctrl_pack_weights(const ra_ctrl_desc *d, const float *const *lstm_w,
+                         const float *const *gmlp_w, const float *const *cmlp_w, float *out);
+
+#define RA_ATTN_STRIDE 16
+/* attn record [B][RA_ATTN_STRIDE]: 0 ctr_y, 1 ctr_x, 2 size_y, 3 size_x, 4 lg_var_y,
+ * 5 lg_var_x, 6 attn_gamma = exp(lg_gamma), 7 box_gamma = exp(box_lg_gamma),
+ * 8 y_out_lg_gamma, 9 ctr_norm_y, 10 ctr_norm_x, 11 lg_size_y, 12 lg_size_x. */
+int ra_controller_f32(const ra_ctrl_desc *d, const float *feat /*[B,G,Cf]*/, const float *wpacked,
+                      int B, float *h_last /*[B,hid]*/, float *ctrl_out /*[B,9]*/,
+                      float *glimpse_maps /*[B,iters,G] nullable*/,
+                      float *attn /*[B,RA_ATTN_STRIDE]*/, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3/K5  Gaussian attention.  Replaces modellib.get_gaussian_filter (modellib.py:581-612),
+ * modellib.extract_patch (modellib.py:615-641) and their uses full_model.py:778-789
+ * (read) and :810-818,:843-845 (write + canvas), :738-741 (attention box).
+ * ---------------------------------------------------------------------------------- */
+/* Dense filter bank, the literal operator: out[b,l,f] (modellib.py:610-611). */
+int ra_gaussian_filter_f32(const float *center, const float *size, const float *lg_var, int B,
+                           int L, int F, float *out, void *stream);
+
+/* Filter banks + band limits for both axes from the attn records.
+ *   fy [B,H,Fh], fx [B,W,Fw]  (same values as ra_gaussian_filter_f32)
+ *   band [B][2*(Fh+Fw) + 2*(H+W)] ints: for every filter tap j its pixel range [lo,hi)
+ *   outside of which the weight is < exp(-30) of its peak, then for every pixel l the tap
+ *   range [jlo,jhi) covering it (y axis first, then x). */
+size_t ra_attn_band_ints(int H, int W, int Fh, int Fw);
+int ra_attn_filters_f32(const float *attn, int B, int H, int W, int Fh, int Fw, float *fy,
+                        float *fx, int *band, void *stream);
+
+/* patch[b,j,i,c] = attn_gamma_b * sum_{l,w} fy[b,l,j] * img[b,l,w,chan0+c] * fx[b,w,i]
+ * img [B,H,W,Ci] (Ci % 4 == 0), patch [B,Fh,Fw,Cp] (Cp % 4 == 0, Cp <= Ci - chan0;
+ * chan0 % 4 == 0).  use_gamma = 0 skips the attn_gamma factor. */
+int ra_extract_patch_f32(const float *img, int Ci, int chan0, const float *attn, const float *fy,
+                         const float *fx, const int *band, int B, int H, int W, int Fh, int Fw,
+                         int Cp, int use_gamma, float *patch, void *stream);
+
+/* Paste + canvas update (full_model.py:810-818,843-845):
+ *   y = sigmoid(exp(y_out_lg_gamma) * (fy P fx^T) + beta);  if disable_overwrite:
+ *   y *= (1 - canvas);  y_out[b, :, :] = y;  canvas = max(canvas, y).
+ * P = patch[b,:,:,pc] with channel stride Cp.  canvas is channel `canvas_chan` of
+ * img [B,H,W,Ci] (updated in place; pass canvas_chan < 0 for no canvas).  y_out points
+ * at the [H,W] plane of example 0 and y_stride_b floats separate examples (so a
+ * [B,T,H,W] tensor is written in place, full_model.py:855).  u_ws: workspace of
+ * B*Fh*W floats. */
+int ra_paste_canvas_f32(const float *patch, int Cp, int pc, const float *attn, const float *fy,
+                        const float *fx, const int *band, int B, int H, int W, int Fh, int Fw,
+                        float beta, int disable_overwrite, float *img, int Ci, int canvas_chan,
+                        float *y_out, size_t y_stride_b, float *u_ws, void *stream);
+
+/* Attention box (full_model.py:738-741, box_model.py:479-482):
+ *   box = sigmoid(box_gamma * (fy 1 fx^T) + beta) written like y_out above. */
+int ra_attn_box_f32(const float *attn, const float *fy, const float *fx, const int *band, int B,
+                    int H, int W, int Fh, int Fw, float beta, float *box_out, size_t stride_b,
+                    void *stream);
+
+/* Generic dense extract_patch with caller-supplied filters (the operator surface of
+ * modellib.extract_patch for arbitrary f_y [B,H,FH], f_x [B,W,FW]; x [B,H,W,D]). */
+int ra_extract_patch_dense_f32(const float *x, const float *f_y, const float *f_x, int B, int H,
+                               int W, int D, int FH, int FW, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6  small dense layers (nnlib.mlp run_mlp, nnlib.py:476-493): out = act(x W + b).
+ * x = concat(x0 [B,K0], x1 [B,K1]) (x1 nullable) — the score MLP's
+ * concat([h_crnn, h_core]) of full_model.py:821-822.  W [K0+K1, N] row-major.
+ * act: 0 none, 1 relu, 2 sigmoid, 3 softmax (over N), 4 tanh.
+ * ---------------------------------------------------------------------------------- */
+int ra_dense_f32(const float *x0, int K0, const float *x1, int K1, const float *W, const float *b,
+                 int B, int N, int act, float *out, size_t out_stride_b, void *stream);
+
+/* Elementwise helpers on the path. */
+/* packed[b,h,w,:] = [x (D) | canvas=0 | d_in (Dd) | y_in (Dy) | zero pad] -> Cp channels
+ * (full_model.py:239,640-661; the canvas lives as channel D of the packed image). */
+int ra_pack_input_f32(const float *x, int D, const float *d_in, int Dd, const float *y_in, int Dy,
+                      int B, int H, int W, int Cp, float *packed, void *stream);
+/* canvas channel update used by box_model (box_model.py:500-504):
+ * canvas = max(canvas, ysel - ysel*noise). ysel,noise [B,H,W]. */
+int ra_canvas_max_f32(float *img, int Ci, int canvas_chan, const float *ysel, const float *noise,
+                      int B, int H, int W, void *stream);
+
+/* Stand-alone eval BatchNorm / affine (nnlib.batch_norm with phase_train=False,
+ * nnlib.py:113-119): y[p,c] = relu?(x[p,c]*scale[c] + shift[c]), p < npix. */
+int ra_affine_act_f32(const float *x, const float *scale, const float *shift, size_t npix, int C,
+                      int relu, float *y, void *stream);
+/* Stand-alone nnlib.max_pool (nnlib.py:15-25): ksize = stride = ratio, 'SAME' (-inf pad).
+ * x [B,H,W,C] -> y [B,ceil(H/ratio),ceil(W/ratio),C]. */
+int ra_max_pool_f32(const float *x, int B, int H, int W, int C, int ratio, float *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECATTEND_H_ */

@@ -1,0 +1,302 @@
+// Hungarian matching for librecattend.so — host (CPU) and device (gfx950) entry points built
+// from ONE solver source so both are the same arithmetic.
+//
+// Behavioural contract = the reference TF op `Hungarian` (hungarian.cc:26-30,36-85): max-weight
+// bipartite matching by primal-dual vertex-cover updates where every matching phase is a
+// max-flow recomputed from scratch with the reference's non-textbook BFS (nodes marked when
+// popped, parents overwritten by later pushers; hungarian.cc:107-177).  float32 state,
+// double-typed comparisons against 1e-6 and 1.0 (hungarian.cc:18,292,302,318,428), ordered
+// sets (std::set<int> -> bitmaps scanned in ascending order).  Only add / sub / min /
+// compare touch the data, so host and device results are bit-identical.
+#include <cfloat>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ra_common.h"
+
+namespace ra {
+namespace hung {
+
+constexpr int kMaxIter = 1000;  // MAX_NUM_ITERATION, hungarian.cc:20
+#define RA_HUNG_EPS 1e-6        // EPSILON (a double), hungarian.cc:18
+
+// Flow network + scratch for one [nx, ny] problem, carved out of a caller buffer.
+struct Scratch {
+  int n;  // nx + ny + 2 nodes: s = 0, X = 1..nx, Y = nx+1..nx+ny, t = n-1 (hungarian.cc:197-202)
+  float *cap, *flow, *res, *eq;
+  int *queue, *parent;
+  unsigned char *mark, *inS, *inT, *inN;
+};
+
+__host__ __device__ inline size_t scratch_bytes(int nx, int ny) {
+  size_t n = (size_t)nx + ny + 2;
+  size_t f = 3 * n * n + (size_t)nx * ny;
+  size_t i = (size_t)(kMaxIter + 2) * n + n;
+  size_t b = n + nx + 2 * (size_t)ny;
+  return ((f + i) * 4 + b + 15) / 16 * 16;
+}
+
+__host__ __device__ inline Scratch carve(void *buf, int nx, int ny) {
+  Scratch s;
+  s.n = nx + ny + 2;
+  size_t nn = (size_t)s.n * s.n;
+  float *f = reinterpret_cast<float *>(buf);
+  s.cap = f;
+  s.flow = f + nn;
+  s.res = f + 2 * nn;
+  s.eq = f + 3 * nn;
+  int *ip = reinterpret_cast<int *>(s.eq + (size_t)nx * ny);
+  s.queue = ip;
+  s.parent = ip + (size_t)(kMaxIter + 2) * s.n;
+  unsigned char *bp = reinterpret_cast<unsigned char *>(s.parent + s.n);
+  s.mark = bp;
+  s.inS = bp + s.n;
+  s.inT = s.inS + nx;
+  s.inN = s.inT + ny;
+  return s;
+}
+
+// One augmenting-path search + push.  1 = augmented, 0 = no path, <0 = reference LOG(FATAL).
+__host__ __device__ inline int augment(Scratch &g) {
+  const int n = g.n, src = 0, dst = n - 1;
+  int qh = 0, qt = 0;
+  g.queue[qt++] = src;
+  for (int v = 0; v < n; ++v) {
+    g.mark[v] = 0;
+    g.parent[v] = -1;
+  }
+  bool reached = false;
+  for (int it = 0; qt > qh && it <= kMaxIter; ++it) {
+    if (it == kMaxIter) return RA_E_HUNG_BFS;
+    const int v = g.queue[qh++];
+    g.mark[v] = 1;  // marked on pop, not on push
+    if (v == dst) {
+      reached = true;
+      break;
+    }
+    const float *row = g.res + (size_t)v * n;
+    for (int u = 0; u < n; ++u)
+      if (!g.mark[u] && row[u] > 0) {
+        g.queue[qt++] = u;
+        g.parent[u] = v;  // later pushers overwrite
+      }
+  }
+  if (!reached) return 0;
+
+  float bottleneck = g.cap[0];  // capacity.maxCoeff(), hungarian.cc:144
+  for (int k = 1; k < n * n; ++k) bottleneck = (g.cap[k] > bottleneck) ? g.cap[k] : bottleneck;
+  int v = dst;
+  for (int it = 0; g.parent[v] != -1 && it <= kMaxIter; ++it) {
+    if (it == kMaxIter) return RA_E_HUNG_PATH;
+    const float r = g.res[(size_t)g.parent[v] * n + v];
+    bottleneck = (bottleneck < r) ? bottleneck : r;  // MIN macro
+    v = g.parent[v];
+  }
+  v = dst;
+  for (int it = 0; g.parent[v] != -1 && it <= kMaxIter; ++it) {
+    if (it == kMaxIter) return RA_E_HUNG_PATH;
+    const int p = g.parent[v];
+    if (g.cap[(size_t)p * n + v] > 0)
+      g.flow[(size_t)p * n + v] += bottleneck;
+    else
+      g.flow[(size_t)v * n + p] -= bottleneck;
+    g.res[(size_t)p * n + v] -= bottleneck;
+    g.res[(size_t)v * n + p] += bottleneck;
+    v = p;
+  }
+  return 1;
+}
+
+// Max bipartite matching of the 0/1 graph g.eq via max-flow from scratch (hungarian.cc:179-217).
+__host__ __device__ inline int rematch(Scratch &g, int nx, int ny, float *M) {
+  const int n = g.n, dst = n - 1;
+  for (size_t k = 0; k < (size_t)n * n; ++k) g.cap[k] = 0.0f;
+  for (int x = 0; x < nx; ++x) {
+    g.cap[1 + x] = 1.0f;  // s -> x
+    for (int y = 0; y < ny; ++y) g.cap[(size_t)(1 + x) * n + (1 + nx + y)] = g.eq[x * ny + y];
+  }
+  for (int y = 0; y < ny; ++y) g.cap[(size_t)(1 + nx + y) * n + dst] = 1.0f;  // y -> t
+  for (size_t k = 0; k < (size_t)n * n; ++k) {
+    g.flow[k] = 0.0f;
+    g.res[k] = g.cap[k];
+  }
+  for (int it = 0;; ++it) {
+    const int r = augment(g);
+    if (r < 0) return r;
+    if (r == 0 || it > kMaxIter) break;
+    if (it == kMaxIter) return RA_E_HUNG_FLOW;
+  }
+  for (int x = 0; x < nx; ++x)
+    for (int y = 0; y < ny; ++y) M[x * ny + y] = g.flow[(size_t)(1 + x) * n + (1 + nx + y)];
+  return 0;
+}
+
+// hungarian.cc:219-248: every vertex of the smaller side is matched.
+__host__ __device__ inline bool saturating(const float *M, int nx, int ny) {
+  const bool by_col = nx >= ny;
+  const int outer = by_col ? ny : nx, inner = by_col ? nx : ny;
+  for (int a = 0; a < outer; ++a) {
+    float sum = 0;
+    for (int b = 0; b < inner; ++b) sum += by_col ? M[b * ny + a] : M[a * ny + b];
+    if (sum == 0) return false;
+  }
+  return true;
+}
+
+// hungarian.cc:335-488.  0 solved, 1 outer cap (partial result kept), <0 fatal.
+__host__ __device__ inline int solve(const float *w, int nx, int ny, float *M, float *cx,
+                                     float *cy, void *scratch_buf) {
+  Scratch g = carve(scratch_buf, nx, ny);
+  for (int x = 0; x < nx; ++x) {
+    float top = w[x * ny];
+    for (int y = 1; y < ny; ++y) top = (w[x * ny + y] > top) ? w[x * ny + y] : top;
+    cx[x] = top;
+    g.inS[x] = 0;
+  }
+  for (int y = 0; y < ny; ++y) {
+    cy[y] = 0.0f;
+    g.inT[y] = 0;
+  }
+  for (int k = 0; k < nx * ny; ++k) M[k] = 0.0f;
+  int cntT = 0;
+  bool need_match = true;
+
+  for (int it = 0; it <= kMaxIter; ++it) {
+    if (it == kMaxIter) return 1;
+    // equality graph (hungarian.cc:309-325): float expression, double comparison
+    for (int x = 0; x < nx; ++x)
+      for (int y = 0; y < ny; ++y) {
+        const float slack = cx[x] + cy[y] - w[x * ny + y];
+        const float mag = (slack > 0) ? slack : -slack;
+        g.eq[x * ny + y] = (mag <= RA_HUNG_EPS && (cx[x] > 0 || cy[y] > 0)) ? 1.0f : 0.0f;
+      }
+    if (need_match) {
+      const int r = rematch(g, nx, ny, M);
+      if (r < 0) return r;
+      if (saturating(M, nx, ny)) return 0;
+      for (int x = 0; x < nx; ++x) {  // first exposed x seeds S (hungarian.cc:394-403)
+        bool exposed = true;
+        for (int y = 0; y < ny && exposed; ++y) exposed = !(M[x * ny + y] == 1.0);
+        if (exposed) {
+          for (int a = 0; a < nx; ++a) g.inS[a] = 0;
+          for (int b = 0; b < ny; ++b) g.inT[b] = 0;
+          g.inS[x] = 1;
+          cntT = 0;
+          break;
+        }
+      }
+    }
+    int cntN = 0;  // N(S) in the equality graph
+    for (int y = 0; y < ny; ++y) g.inN[y] = 0;
+    for (int x = 0; x < nx; ++x)
+      if (g.inS[x])
+        for (int y = 0; y < ny; ++y)
+          if (g.eq[x * ny + y] > 0 && !g.inN[y]) {
+            g.inN[y] = 1;
+            ++cntN;
+          }
+    bool same = cntN == cntT;
+    for (int y = 0; y < ny && same; ++y) same = !(g.inN[y] && !g.inT[y]);
+
+    if (same) {  // cover update (hungarian.cc:415-443)
+      float a = FLT_MAX;
+      for (int x = 0; x < nx; ++x)
+        if (g.inS[x])
+          for (int y = 0; y < ny; ++y)
+            if (!g.inT[y]) {
+              const float slack = cx[x] + cy[y] - w[x * ny + y];
+              a = (a < slack) ? a : slack;
+            }
+      if (a < RA_HUNG_EPS) {
+        need_match = true;
+        continue;
+      }
+      for (int x = 0; x < nx; ++x)
+        if (g.inS[x]) cx[x] -= a;
+      for (int y = 0; y < ny; ++y)
+        if (g.inT[y]) cy[y] += a;
+    } else {  // grow the alternating tree (hungarian.cc:444-483)
+      for (int j = 0; cntN > cntT && j <= kMaxIter; ++j) {
+        if (j == kMaxIter) return RA_E_HUNG_EQUALIZE;
+        int y = 0;
+        while (!(g.inN[y] && !g.inT[y])) ++y;  // smallest y in N(S) \ T
+        int z = -1;
+        for (int x = 0; x < nx; ++x)
+          if (M[x * ny + y] == 1.0) {
+            z = x;
+            break;
+          }
+        if (z < 0) {
+          need_match = true;
+          break;
+        }
+        need_match = false;
+        g.inS[z] = 1;
+        for (int v = 0; v < ny; ++v)
+          if (g.eq[z * ny + v] > 0.0 && !g.inN[v]) {
+            g.inN[v] = 1;
+            ++cntN;
+          }
+        g.inT[y] = 1;
+        ++cntT;
+      }
+    }
+  }
+  return 1;
+}
+
+__global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, int ny, float *M,
+                                                        float *cx, float *cy, int *status,
+                                                        char *ws, size_t ws_per_ex) {
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    const int rc = solve(w + (size_t)b * nx * ny, nx, ny, M + (size_t)b * nx * ny,
+                         cx + (size_t)b * nx, cy + (size_t)b * ny, ws + (size_t)b * ws_per_ex);
+    if (status) status[b] = rc;
+  }
+}
+
+inline int merge(int worst, int rc) {
+  if (rc < 0) return (worst >= 0 || rc < worst) ? rc : worst;
+  return (worst >= 0 && rc > worst) ? rc : worst;
+}
+
+}  // namespace hung
+}  // namespace ra
+
+extern "C" int ra_hungarian_f32(const float *weights, int B, int N, int M, float *matching,
+                                float *cover_x, float *cover_y) {
+  if (!weights || !matching || !cover_x || !cover_y || B < 0 || N <= 0 || M <= 0)
+    return ra::fail(RA_E_INVALID, "ra_hungarian_f32: bad argument");
+  std::vector<char> scratch(ra::hung::scratch_bytes(N, M));
+  int worst = 0;
+  for (int b = 0; b < B; ++b) {
+    const int rc = ra::hung::solve(weights + (size_t)b * N * M, N, M, matching + (size_t)b * N * M,
+                                   cover_x + (size_t)b * N, cover_y + (size_t)b * M, scratch.data());
+    worst = ra::hung::merge(worst, rc);
+  }
+  if (worst) ra::set_error("ra_hungarian_f32: status %d", worst);
+  return worst;
+}
+
+extern "C" size_t ra_hungarian_dev_workspace_bytes(int B, int N, int M) {
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  return (size_t)B * ra::hung::scratch_bytes(N, M);
+}
+
+extern "C" int ra_hungarian_f32_dev(const float *weights, int B, int N, int M, float *matching,
+                                    float *cover_x, float *cover_y, int *status_dev, void *ws,
+                                    size_t ws_bytes, void *stream) {
+  if (!weights || !matching || !cover_x || !cover_y || !ws || B < 0 || N <= 0 || M <= 0)
+    return ra::fail(RA_E_INVALID, "ra_hungarian_f32_dev: bad argument");
+  if (B == 0) return 0;
+  const size_t per = ra::hung::scratch_bytes(N, M);
+  if (ws_bytes < per * (size_t)B)
+    return ra::fail(RA_E_WORKSPACE, "ra_hungarian_f32_dev: workspace %zu < %zu", ws_bytes,
+                    per * (size_t)B);
+  hipLaunchKernelGGL(ra::hung::hungarian_kernel, dim3(B), dim3(64), 0, ra::as_stream(stream),
+                     weights, N, M, matching, cover_x, cover_y, status_dev,
+                     reinterpret_cast<char *>(ws), per);
+  return ra::launch_status("ra_hungarian_f32_dev");
+}

@@ -1,0 +1,105 @@
+"""ctypes binding of librecattend.so (the C ABI declared in include/recattend.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import
+of the product path fails loudly.  Device pointers are taken from torch tensors
+(`tensor.data_ptr()`), the stream from `torch.cuda.current_stream()`; torch is plumbing
+(memory + streams) only.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librecattend.so')
+
+RA_CONV_TRANSPOSED = 1
+RA_ATTN_STRIDE = 16
+
+
+class RecAttendError(RuntimeError):
+  pass
+
+
+class CtrlDesc(C.Structure):
+  """struct ra_ctrl_desc (include/recattend.h)."""
+  _fields_ = [(n, C.c_int) for n in ('G', 'Cf', 'hid', 'iters', 'n_gmlp', 'n_cmlp', 'mlp_dim',
+                                      'H', 'W', 'Fh', 'Fw', 'squash', 'fixed_var',
+                                      'dynamic_var', 'fixed_gamma')]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/recattend.h
+SIGNATURES = {
+    'ra_version': (_I, []),
+    'ra_last_error_string': (C.c_char_p, []),
+    'ra_hungarian_f32': (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    'ra_hungarian_dev_workspace_bytes': (_Z, [_I, _I, _I]),
+    'ra_hungarian_f32_dev': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'ra_conv_cout_padded': (_I, [_I]),
+    'ra_conv_packed_floats': (_Z, [_I, _I]),
+    'ra_conv_pack_weights': (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    'ra_conv_fold_bn': (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _P]),
+    'ra_conv3x3_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'ra_ctrl_packed_floats': (_Z, [C.POINTER(CtrlDesc)]),
+    'ra_ctrl_pack_weights': (_I, [C.POINTER(CtrlDesc), _P, _P, _P, _P]),
+    'ra_controller_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P]),
+    'ra_gaussian_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'ra_attn_band_ints': (_Z, [_I, _I, _I, _I]),
+    'ra_attn_filters_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'ra_extract_patch_f32': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_paste_canvas_f32': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I,
+                                 _I, _P, _Z, _P, _P]),
+    'ra_attn_box_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    'ra_extract_patch_dense_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_dense_f32': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    'ra_pack_input_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_canvas_max_f32': (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    'ra_affine_act_f32': (_I, [_P, _P, _P, _Z, _I, _I, _P, _P]),
+    'ra_max_pool_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+  """The loaded library; raises RecAttendError if it (or any symbol) is missing."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise RecAttendError(
+          'librecattend.so not found at %s — build it with `python -c "import '
+          '__graft_entry__ as g; g.build()"` (no CPU fallback exists)' % LIB_PATH)
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      try:
+        fn = getattr(handle, name)
+      except AttributeError:
+        raise RecAttendError('librecattend.so lacks symbol %s' % name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = handle
+  return _lib
+
+
+def check(rc, what):
+  """Turn a non-zero return code into an exception carrying ra_last_error_string()."""
+  if rc != 0:
+    msg = lib().ra_last_error_string()
+    raise RecAttendError('%s failed with code %d: %s' % (what, rc, (msg or b'').decode()))
+
+
+def ptr(t):
+  """Raw data pointer of a torch tensor / numpy array / None."""
+  if t is None:
+    return None
+  if hasattr(t, 'data_ptr'):
+    return t.data_ptr()
+  return t.ctypes.data
+
+
+def stream_ptr():
+  import torch
+  return torch.cuda.current_stream().cuda_stream
