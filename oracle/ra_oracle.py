@@ -429,6 +429,12 @@ def random_params(opt, seed, box_model=False, w_scale=None):
       s = w_scale if w_scale is not None else 1.3 / np.sqrt(fan_in)
       v = rng.normal(0.0, s, shp)
     P[k] = v.astype(np.float32)
+  d_ = derive(opt, box_model)
+  if not box_model:  # make the decoder's last layer swing, so masks are not all sigma(-5)
+    last = d_['adcnn_nlayers'] - 1
+    for t in range(d_['T']):
+      P['attn_dcnn_%d_%d_beta' % (last, t)] = rng.normal(0.4, 0.2, (1,)).astype(np.float32)
+      P['attn_dcnn_%d_%d_gamma' % (last, t)] = rng.uniform(1.5, 3.0, (1,)).astype(np.float32)
   # keep the predicted box inside the image and a sensible size
   P['ctrl_mlp_w_%d' % (derive(opt, box_model)['n_cmlp'] - 1)] *= 0.5
   b = P['ctrl_mlp_b_%d' % (derive(opt, box_model)['n_cmlp'] - 1)]

@@ -1,0 +1,310 @@
+"""`full_model.get_model` of the reference (full_model.py:13-1099) on MI355X kernels.
+
+get_model(opt, is_training=True) takes the reference's `model_opt` dict
+(full_model_train.py:581-658) and returns a dict-like `Model`:
+  * every weight registered under the reference's key (`ctrl_cnn_w_0`,
+    `ctrl_cnn_0_3_beta`, `ctrl_lstm_w_xi`, `glimpse_mlp_w_0`, `ctrl_mlp_w_0`,
+    `attn_cnn_*`, `attn_dcnn_*`, `score_mlp_w_0`; nnlib.py:120-127,206-211,333-335,
+    471-474,611-623) as a float32 device tensor;
+  * `model.run(outputs, feed)` — the counterpart of the harness contract
+    `sess.run([model[k] for k in outputs], feed_dict)` (runner.py:91-105): feed keys `x`
+    [B,H,W,3], `phase_train`, optional `d_in` [B,H,W,8], `y_in` [B,H,W,nc]; outputs are the
+    reference's output keys (full_model.py:853-907): `y_out` [B,T,H,W], `s_out` [B,T],
+    `x_patch`, `y_out_patch`, `attn_box`, `attn_ctr`, `attn_size`, `attn_top_left`,
+    `attn_bot_right`, `attn_ctr_norm`, `attn_lg_size`, `ctrl_rnn_glimpse_map`.
+The forward is the eval graph (phase_train=False; use_knob does not act at eval,
+full_model.py:744-773,826-841).  Losses / train_step (full_model.py:913-1057) are the
+training step, SURVEY.md §8(f) rank 2, not built yet: requesting them raises.
+"""
+import numpy as np
+import torch
+
+import modellib
+import nnlib as nn
+import ra_engine
+from ra_native import RecAttendError
+
+
+def _get(opt, key, default):
+  return opt[key] if key in opt else default
+
+
+def derive_dims(opt, box_model=False):
+  """Shape / flag bookkeeping of the graph builder (full_model.py:18-160,239-258,305-313,
+  455-459,494-502; box_model.py:16-82,343-352)."""
+  d = {'T': opt['timespan'], 'H': opt['inp_height'], 'W': opt['inp_width'],
+       'D': opt['inp_depth'], 'Fh': opt['filter_height'], 'Fw': opt['filter_width']}
+  if d['H'] % 4 or d['W'] % 4:
+    raise RecAttendError('inp_height / inp_width must be multiples of 4')
+  if 'add_d_out' in opt:
+    add_d, add_y = bool(opt['add_d_out']), bool(opt['add_y_out'])
+  else:
+    add_d = add_y = False
+  assert (add_d and add_y) or (not add_d and not add_y)  # full_model.py:206
+  nsc = _get(opt, 'num_semantic_classes', 1)
+  d.update(add_d_out=add_d, add_y_out=add_y, nsc=nsc)
+  if box_model:
+    ctrl = (True, True, add_d, add_y)
+    attn = ctrl
+  else:
+    if 'attn_add_d_out' in opt:
+      attn = (opt['attn_add_inp'], opt['attn_add_canvas'], opt['attn_add_d_out'],
+              opt['attn_add_y_out'])
+    else:
+      attn = (True, True, add_d, add_y)
+    if 'ctrl_add_d_out' in opt:
+      ctrl = (opt['ctrl_add_inp'], opt['ctrl_add_canvas'], opt['ctrl_add_d_out'],
+              opt['ctrl_add_y_out'])
+    else:
+      ctrl = (not add_d, not add_d, add_d, add_y)
+  ctrl, attn = tuple(bool(v) for v in ctrl), tuple(bool(v) for v in attn)
+  depth = lambda fl: (d['D'] if fl[0] else 0) + (1 if fl[1] else 0) + (8 if fl[2] else 0) + (
+      nsc if fl[3] else 0)
+  d['ctrl_in'], d['attn_in'] = ctrl, attn
+  d['C0p'] = -(-(d['D'] + 1 + (8 if add_d else 0) + (nsc if add_y else 0)) // 4) * 4
+  d['ccnn_nlayers'] = len(opt['ctrl_cnn_filter_size'])
+  d['ccnn_filters'] = list(opt['ctrl_cnn_filter_size'])
+  d['ccnn_channels'] = [depth(ctrl)] + list(opt['ctrl_cnn_depth'])
+  d['ccnn_pool'] = list(opt['ctrl_cnn_pool'])
+  sub = int(np.prod(d['ccnn_pool']))
+  d['gh'], d['gw'] = d['H'] // sub, d['W'] // sub
+  d['G'] = d['gh'] * d['gw']
+  d['hid'] = opt['ctrl_rnn_hid_dim']
+  d['iters'] = opt['num_ctrl_rnn_iter']
+  d['n_gmlp'] = opt['num_glimpse_mlp_layers']
+  d['n_cmlp'] = opt['num_ctrl_mlp_layers']
+  d['mlp_dim'] = opt['ctrl_mlp_dim']
+  d['squash'] = bool(opt['squash_ctrl_params'])
+  d['fixed_var'] = bool(_get(opt, 'fixed_var', True if box_model else False))
+  d['dynamic_var'] = bool(_get(opt, 'dynamic_var', False))
+  d['use_bn'] = bool(opt['use_bn'])
+  d['attn_box_padding_ratio'] = opt['attn_box_padding_ratio']
+  if box_model:
+    d['fixed_gamma'] = True
+    return d
+  d['fixed_gamma'] = bool(opt['fixed_gamma'])
+  d['disable_overwrite'] = bool(_get(opt, 'disable_overwrite', True))
+  d['acnn_nlayers'] = len(opt['attn_cnn_filter_size'])
+  d['acnn_filters'] = list(opt['attn_cnn_filter_size'])
+  d['acnn_channels'] = [depth(attn)] + list(opt['attn_cnn_depth'])
+  d['acnn_pool'] = list(opt['attn_cnn_pool'])
+  asub = int(np.prod(d['acnn_pool']))
+  d['core_depth'] = d['acnn_channels'][-1]
+  d['core_dim'] = (d['Fh'] // asub) * (d['Fw'] // asub) * d['core_depth']
+  d['adcnn_nlayers'] = len(opt['attn_dcnn_filter_size'])
+  d['adcnn_filters'] = list(opt['attn_dcnn_filter_size'])
+  d['adcnn_unpool'] = list(opt['attn_dcnn_pool'])
+  d['adcnn_channels'] = [d['core_depth']] + list(opt['attn_dcnn_depth'])
+  add_skip = bool(_get(opt, 'add_skip_conn', True))
+  d['add_skip_conn'] = add_skip
+  skip_flags = _get(opt, 'attn_cnn_skip', [add_skip] * d['acnn_nlayers'])
+  # NB: the reference's CLI leaves the raw flag string here ('1,0,1,..'), whose characters are
+  # all truthy; iterating it reproduces "all skips on".
+  skip_rev = list(skip_flags[::-1])
+  if add_skip:
+    ch_rev = d['acnn_channels'][::-1][1:] + [d['acnn_channels'][0]]
+    d['skip_ch'] = [0] + [ch if sk else 0 for sk, ch in zip(skip_rev, ch_rev)]
+    d['skip_ch'] = (d['skip_ch'] + [0] * d['adcnn_nlayers'])[:d['adcnn_nlayers']]
+  else:
+    d['skip_ch'] = None
+  return d
+
+
+class Model(dict):
+  """The reference's `model` dict plus run().  Tensor-valued entries are weights."""
+
+  OUTPUTS = ('y_out', 's_out', 'x_patch', 'y_out_patch', 'attn_box', 'attn_ctr', 'attn_size',
+             'attn_top_left', 'attn_bot_right', 'attn_ctr_norm', 'attn_lg_size',
+             'ctrl_rnn_glimpse_map', 'ctrl_out', 'h_core', 'canvas')
+  TRAIN_ONLY = ('loss', 'train_step', 'box_loss', 'segm_loss', 'conf_loss', 'iou_soft',
+                'iou_hard', 'wt_cov_soft', 'wt_cov_hard', 'unwt_cov_soft', 'unwt_cov_hard',
+                'dice', 'dic', 'dic_abs', 'count_acc', 'match', 'match_box', 'learn_rate')
+
+  def __init__(self, opt, dims, box_model=False):
+    dict.__init__(self)
+    self.opt = dict(opt)
+    self.dims = dims
+    self.box_model = box_model
+    self.engine = None
+
+  def weight_keys(self):
+    return sorted(k for k, v in self.items() if isinstance(v, torch.Tensor))
+
+  def load_weights(self, weights):
+    """weights: mapping name -> array (e.g. an .npz of the reference's weights.h5 keys,
+    full_model_read.py:33-71, plus the BN EMA statistics)."""
+    for k, v in weights.items():
+      if k not in self or not isinstance(self[k], torch.Tensor):
+        continue
+      v = torch.as_tensor(np.asarray(v, dtype=np.float32))
+      if tuple(v.shape) != tuple(self[k].shape):
+        raise RecAttendError('weight %s: shape %r != %r' % (k, tuple(v.shape),
+                                                           tuple(self[k].shape)))
+      self[k].copy_(v)
+    return self
+
+  def state_dict_numpy(self):
+    return {k: self[k].detach().cpu().numpy() for k in self.weight_keys()}
+
+  def run(self, outputs, feed, as_numpy=False):
+    single = isinstance(outputs, str)
+    names = [outputs] if single else list(outputs)
+    for n in names:
+      if n in self.TRAIN_ONLY:
+        raise NotImplementedError(
+            'output %r needs the training step (SURVEY.md §8f rank 2), not built yet' % n)
+      if n not in self.OUTPUTS:
+        raise KeyError(n)
+    if nn._is_train(feed.get('phase_train', False)):
+      raise NotImplementedError('phase_train=True is the training step (not built yet)')
+    d = self.dims
+    b = self.engine.forward(feed['x'], d_in=feed.get('d_in'), y_in=feed.get('y_in'),
+                            y_gt=feed.get('y_gt'), noise=feed.get('noise'),
+                            want_box='attn_box' in names)
+    res = [self._fetch(n, b) for n in names]
+    if as_numpy:
+      torch.cuda.synchronize()
+      res = [r.detach().cpu().numpy() for r in res]
+    return res[0] if single else res
+
+  def _fetch(self, name, b):
+    d = self.dims
+    a = b['attn']  # [T,B,16]
+    tb = lambda t: t.transpose(0, 1).contiguous()
+    if name in ('y_out', 's_out', 'attn_box'):
+      return b[name].clone()
+    if name == 'x_patch':
+      xp = tb(b['x_patch'])
+      sel = self.engine.attn_sel
+      if sel != list(range(xp.shape[-1])):
+        xp = xp[..., sel].contiguous()
+      return xp
+    if name == 'y_out_patch':
+      return tb(b['y_out_patch'])
+    if name == 'ctrl_rnn_glimpse_map':
+      g = tb(b['gmaps'])
+      return g.view(g.shape[0], d['T'], d['iters'], d['gh'], d['gw'])
+    if name == 'ctrl_out':
+      return tb(b['ctrl_out'])
+    if name == 'attn_ctr':
+      return tb(a[:, :, 0:2])
+    if name == 'attn_size':
+      return tb(a[:, :, 2:4])
+    if name == 'attn_ctr_norm':
+      return tb(a[:, :, 9:11])
+    if name == 'attn_lg_size':
+      return tb(a[:, :, 11:13])
+    if name == 'attn_top_left':
+      return tb(a[:, :, 0:2] - a[:, :, 2:4] / 2.0)  # modellib.py:850-852
+    if name == 'attn_bot_right':
+      return tb(a[:, :, 0:2] + a[:, :, 2:4] / 2.0)
+    if name == 'h_core':
+      raise KeyError('h_core is only available per step; fetch x_patch / y_out_patch instead')
+    if name == 'canvas':
+      return b['img'][..., d['D']:d['D'] + 1].contiguous()
+    raise KeyError(name)
+
+
+def _register_controller(model, opt, d, pt_ctrl=None):
+  """Controller CNN, LSTM, glimpse MLP, controller MLP (full_model.py:263-409)."""
+  T = d['T']
+  relu = nn.relu
+  ccnn = nn.cnn(d['ccnn_filters'], d['ccnn_channels'], d['ccnn_pool'],
+                [relu] * d['ccnn_nlayers'], [d['use_bn']] * d['ccnn_nlayers'],
+                phase_train=model.get('phase_train'), wd=opt['weight_decay'], scope='ctrl_cnn',
+                model=model, init_weights=pt_ctrl and pt_ctrl.get('ccnn'))
+  ccnn.declare_copies(T)
+  Cf = d['ccnn_channels'][-1]
+  cell = nn.lstm(Cf, d['hid'], wd=opt['weight_decay'], scope='ctrl_lstm', model=model,
+                 init_weights=pt_ctrl and pt_ctrl.get('crnn'))
+  gdims = [d['hid']] * d['n_gmlp'] + [d['G']]
+  gmlp = nn.mlp(gdims, [relu] * (d['n_gmlp'] - 1) + [nn.softmax], add_bias=True,
+                wd=opt['weight_decay'], scope='glimpse_mlp', model=model,
+                init_weights=pt_ctrl and pt_ctrl.get('gmlp'))
+  cdims = [d['hid']] + [d['mlp_dim']] * (d['n_cmlp'] - 1) + [9]
+  cmlp = nn.mlp(cdims, [relu] * (d['n_cmlp'] - 1) + [None], add_bias=True,
+                wd=opt['weight_decay'], scope='ctrl_mlp', model=model,
+                init_weights=pt_ctrl and pt_ctrl.get('cmlp'))
+  return ccnn, cell, gmlp, cmlp
+
+
+def _load_pretrained(path):
+  """The reference reads weights.h5 (full_model.py:271-284,...); h5py is not part of this
+  stack, so the same key/value schema is read from an .npz archive."""
+  if path is None:
+    return None
+  if str(path).endswith('.h5'):
+    raise RecAttendError('HDF5 weight files are not readable here; convert to .npz with the '
+                         'same keys (full_model_read.py:33-71)')
+  return dict(np.load(path))
+
+
+def _pretrained_groups(w, d, scopes):
+  """Reshape a flat weight archive into nnlib's init_weights structures."""
+  if w is None:
+    return None
+  T = d['T']
+
+  def cnn_group(scope, nl):
+    out = []
+    for i in range(nl):
+      g = {'w': w['%s_w_%d' % (scope, i)], 'b': w['%s_b_%d' % (scope, i)]}
+      for t in range(T):
+        for n in ('beta', 'gamma'):
+          k = '%s_%d_%d_%s' % (scope, i, t, n)
+          if k in w:
+            g['%s_%d' % (n, t)] = w[k]
+      out.append(g)
+    return out
+
+  res = {}
+  if 'ctrl' in scopes:
+    res['ccnn'] = cnn_group('ctrl_cnn', d['ccnn_nlayers'])
+    res['crnn'] = {k: w['ctrl_lstm_' + k] for k in ('w_xi', 'w_hi', 'b_i', 'w_xf', 'w_hf', 'b_f',
+                                                    'w_xu', 'w_hu', 'b_u', 'w_xo', 'w_ho', 'b_o')}
+    res['gmlp'] = [{'w': w['glimpse_mlp_w_%d' % i], 'b': w['glimpse_mlp_b_%d' % i]}
+                   for i in range(d['n_gmlp'])]
+    res['cmlp'] = [{'w': w['ctrl_mlp_w_%d' % i], 'b': w['ctrl_mlp_b_%d' % i]}
+                   for i in range(d['n_cmlp'])]
+  if 'attn' in scopes:
+    res['acnn'] = cnn_group('attn_cnn', d['acnn_nlayers'])
+    res['adcnn'] = cnn_group('attn_dcnn', d['adcnn_nlayers'])
+  if 'score' in scopes and 'score_mlp_w_0' in w:
+    res['smlp'] = [{'w': w['score_mlp_w_0'], 'b': w['score_mlp_b_0']}]
+  return res
+
+
+def get_model(opt, is_training=True):
+  """The attention model (full_model.py:13)."""
+  d = derive_dims(opt)
+  model = Model(opt, d)
+  model['phase_train'] = {'value': False}
+  pt_net = _get(opt, 'pretrain_net', None)
+  w_ctrl = _load_pretrained(pt_net or _get(opt, 'pretrain_ctrl_net', None))
+  w_attn = _load_pretrained(pt_net or _get(opt, 'pretrain_attn_net', None))
+  w_all = _load_pretrained(pt_net)
+  pt_ctrl = _pretrained_groups(w_ctrl, d, ('ctrl',))
+  pt_attn = _pretrained_groups(w_attn, d, ('attn',))
+  pt_score = _pretrained_groups(w_all, d, ('score',))
+  relu = nn.relu
+  wd = opt['weight_decay']
+
+  ccnn, cell, gmlp, cmlp = _register_controller(model, opt, d, pt_ctrl)
+  acnn = nn.cnn(d['acnn_filters'], d['acnn_channels'], d['acnn_pool'],
+                [relu] * d['acnn_nlayers'], [d['use_bn']] * d['acnn_nlayers'],
+                phase_train=model['phase_train'], wd=wd, scope='attn_cnn', model=model,
+                init_weights=pt_attn and pt_attn['acnn'])
+  acnn.declare_copies(d['T'])
+  smlp = nn.mlp([d['hid'] + d['core_dim'], 1], [nn.sigmoid], wd=wd, scope='score_mlp',
+                model=model, init_weights=pt_score and pt_score.get('smlp'))
+  adcnn = nn.dcnn(d['adcnn_filters'], d['adcnn_channels'], d['adcnn_unpool'],
+                  [relu] * d['adcnn_nlayers'], use_bn=[d['use_bn']] * d['adcnn_nlayers'],
+                  skip_ch=d['skip_ch'], phase_train=model['phase_train'], wd=wd, model=model,
+                  init_weights=pt_attn and pt_attn['adcnn'], scope='attn_dcnn')
+  adcnn.declare_copies(d['T'])
+  model.closures = dict(ccnn=ccnn, crnn_cell=cell, gmlp=gmlp, cmlp=cmlp, acnn=acnn, smlp=smlp,
+                        adcnn=adcnn)
+  model['global_step'] = 0.0
+  model.engine = ra_engine.DecodeEngine(d, model)
+  model.is_training = is_training
+  return model

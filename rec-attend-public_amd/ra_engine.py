@@ -1,0 +1,343 @@
+"""The decode-loop engine: the T-step recurrent-attention forward of full_model / box_model
+driven through the C ABI, with every buffer pre-allocated and the whole launch sequence
+replayable as one HIP graph.
+
+Per output timestep tt (full_model.py:638-848), all on one stream:
+   K1 x L   ctrl CNN   conv3x3+bias+BN(tt)+ReLU+pool  (f32 MFMA)      img -> feat [B,G,Cf]
+   K2       controller glimpse/LSTM/gMLP x iters, cMLP, attn decode  feat -> attn record
+   K3a      filter banks + band limits                               attn -> fy, fx, band
+   K3       extract    gamma * fy^T X fx                             img -> x_patch
+   K4 x ..  attn CNN / DCNN (same MFMA conv kernel; transposed packing + zero-stuffing + skip)
+   K6       score      sigmoid([h, h_core] w + b)                    -> s_out[:, tt]
+   K5       paste      sigmoid(e^g fy P fx^T - 5)(1-canvas), canvas = max -> y_out[:, tt], img
+The canvas is channel D of the packed NHWC image `img` = [x | canvas | d_in | y_in | 0-pad], so
+both the controller CNN and the extract kernel stream one 16-byte-aligned pixel record.
+"""
+import numpy as np
+import torch
+
+import ra_native as rn
+import ra_ops as ops
+
+
+def _dev(a, device):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _r4(n):
+  return -(-n // 4) * 4
+
+
+class DecodeEngine(object):
+  """dims: the derived shape/flag dict (full_model.derive_dims); model: name -> tensor."""
+
+  def __init__(self, dims, model, box_model=False):
+    self.d = dims
+    self.model = model
+    self.box = box_model
+    self._stamp = None
+    self._B = None
+    self._graphs = {}
+    self.use_graph = True
+    self.timing = None  # set to a list to collect (stage, start_event, end_event)
+
+  # ------------------------------------------------------------------ weights
+  def _weights_stamp(self):
+    return tuple((k, v.data_ptr(), v._version) for k, v in sorted(self.model.items())
+                 if isinstance(v, torch.Tensor) and '_' in k and not k.startswith('__'))
+
+  def _chan_map(self, flags):
+    """packed channel -> index in the reference's concat order (full_model.py:640-661) or -1."""
+    d = self.d
+    groups = [(d['D'], True, flags[0]), (1, True, flags[1]), (8, d['add_d_out'], flags[2]),
+              (d['nsc'], d['add_y_out'], flags[3])]
+    cmap, idx = [], 0
+    for n, present, used in groups:
+      if not present:
+        if used:
+          raise rn.RecAttendError('input group used by the model but not fed')
+        continue
+      for _ in range(n):
+        if used:
+          cmap.append(idx)
+          idx += 1
+        else:
+          cmap.append(-1)
+    cmap += [-1] * (d['C0p'] - len(cmap))
+    return cmap, idx
+
+  def prepare(self, device):
+    stamp = self._weights_stamp()
+    if stamp == self._stamp:
+      return
+    d, M, T = self.d, self.model, self.d['T']
+    bn = lambda scope, i, t: tuple(M['%s_%d_%d_%s' % (scope, i, t, n)]
+                                   for n in ('beta', 'gamma', 'ema_mean', 'ema_var'))
+
+    def fold_all(scope, i, cout):
+      sc, sh = [], []
+      for t in range(T):
+        a, b = ops.fold_bn(M['%s_b_%d' % (scope, i)], cout, bn(scope, i, t) if d['use_bn'] else None)
+        sc.append(a)
+        sh.append(b)
+      return _dev(np.stack(sc), device), _dev(np.stack(sh), device)
+
+    W = {}
+    cmap_c, n_c = self._chan_map(d['ctrl_in'])
+    assert n_c == d['ccnn_channels'][0]
+    W['ccnn'] = []
+    for i in range(d['ccnn_nlayers']):
+      cin, cout = d['ccnn_channels'][i], d['ccnn_channels'][i + 1]
+      if i == 0:
+        wp = ops.pack_conv_weights(M['ctrl_cnn_w_0'], cin_kernel=d['C0p'], chan_map=cmap_c)
+      else:
+        wp = ops.pack_conv_weights(M['ctrl_cnn_w_%d' % i], cin_kernel=_r4(cin))
+      sc, sh = fold_all('ctrl_cnn', i, cout)
+      W['ccnn'].append((_dev(wp, device), sc, sh, cout, d['ccnn_pool'][i]))
+    Cf = d['ccnn_channels'][-1]
+    self.desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
+                                   d['mlp_dim'], d['H'], d['W'], d['Fh'], d['Fw'], d['squash'],
+                                   d['fixed_var'], d['dynamic_var'],
+                                   d.get('fixed_gamma', True))
+    lstm = {k: M['ctrl_lstm_' + k] for k in ('w_xi', 'w_hi', 'b_i', 'w_xf', 'w_hf', 'b_f', 'w_xu',
+                                             'w_hu', 'b_u', 'w_xo', 'w_ho', 'b_o')}
+    gm = [(M['glimpse_mlp_w_%d' % i], M['glimpse_mlp_b_%d' % i]) for i in range(d['n_gmlp'])]
+    cm = [(M['ctrl_mlp_w_%d' % i], M['ctrl_mlp_b_%d' % i]) for i in range(d['n_cmlp'])]
+    W['ctrl'] = _dev(ops.pack_ctrl_weights(self.desc, lstm, gm, cm), device)
+    W['smlp_w'] = M['score_mlp_w_0']
+    W['smlp_b'] = M['score_mlp_b_0']
+    if not self.box:
+      cmap_a, n_a = self._chan_map(d['attn_in'])
+      assert n_a == d['acnn_channels'][0]
+      self.attn_sel = [c for c, m in enumerate(cmap_a) if m >= 0]
+      W['acnn'] = []
+      for i in range(d['acnn_nlayers']):
+        cin, cout = d['acnn_channels'][i], d['acnn_channels'][i + 1]
+        if i == 0:
+          wp = ops.pack_conv_weights(M['attn_cnn_w_0'], cin_kernel=d['C0p'], chan_map=cmap_a)
+        else:
+          wp = ops.pack_conv_weights(M['attn_cnn_w_%d' % i], cin_kernel=_r4(cin))
+        sc, sh = fold_all('attn_cnn', i, cout)
+        W['acnn'].append((_dev(wp, device), sc, sh, cout, d['acnn_pool'][i]))
+      # DCNN: filter input channels = [prev | skip] (nnlib.py:365); skip sources are
+      # [None, h_acnn[L-2], ..., h_acnn[0], x_patch] gated by the reversed skip flags
+      # (full_model.py:494-499,798-803)
+      W['adcnn'] = []
+      L = d['acnn_nlayers']
+      prev_c = d['adcnn_channels'][0]
+      for i in range(d['adcnn_nlayers']):
+        cout = d['adcnn_channels'][i + 1]
+        n_skip = d['skip_ch'][i] if d['skip_ch'] is not None else 0
+        src = None  # index into the skip source list
+        if n_skip:
+          src = i - 1  # 0 -> h_acnn[L-2], ..., L-1 -> x_patch
+        c_prev = _r4(prev_c)
+        cmap = [k if k < prev_c else -1 for k in range(c_prev)]
+        c_skip = 0
+        if src is not None:
+          if src == L - 1:  # x_patch: packed channel order
+            cmap += [prev_c + m if m >= 0 else -1 for m in cmap_a]
+            c_skip = d['C0p']
+          else:
+            sc_real = d['acnn_channels'][L - 1 - src]
+            c_skip = _r4(sc_real)
+            cmap += [prev_c + k if k < sc_real else -1 for k in range(c_skip)]
+        wp = ops.pack_conv_weights(M['attn_dcnn_w_%d' % i], cin_kernel=c_prev + c_skip,
+                                   chan_map=cmap, transposed=True)
+        sc, sh = fold_all('attn_dcnn', i, cout)
+        W['adcnn'].append((_dev(wp, device), sc, sh, cout, d['adcnn_unpool'][i], src))
+        prev_c = cout
+    self.W = W
+    self._stamp = stamp
+    self._graphs = {}
+
+  # ------------------------------------------------------------------ buffers
+  def alloc(self, B, device):
+    if self._B == B:
+      return
+    d, T = self.d, self.d['T']
+    f = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+    H, W, Fh, Fw = d['H'], d['W'], d['Fh'], d['Fw']
+    b = {}
+    b['x'] = f(B, H, W, d['D'])
+    if d['add_d_out']:
+      b['d_in'] = f(B, H, W, 8)
+    if d['add_y_out']:
+      b['y_in'] = f(B, H, W, d['nsc'])
+    b['img'] = f(B, H, W, d['C0p'])
+    hh, ww = H, W
+    b['ccnn'] = []
+    for i in range(d['ccnn_nlayers']):
+      hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
+      b['ccnn'].append(f(B, hh, ww, d['ccnn_channels'][i + 1]))
+    b['h_last'] = f(T, B, d['hid'])
+    b['ctrl_out'] = f(T, B, 9)
+    b['gmaps'] = f(T, B, d['iters'], d['G'])
+    b['attn'] = f(T, B, rn.RA_ATTN_STRIDE)
+    b['fy'] = f(B, H, Fh)
+    b['fx'] = f(B, W, Fw)
+    b['band'] = torch.zeros((B, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32, device=device)
+    b['s_out'] = f(B, T) if (self.box is False or d['nsc'] == 1) else f(B, T, d['nsc'])
+    b['attn_box'] = f(B, T, H, W)
+    if self.box:
+      b['y_gt'] = f(B, T, H, W)
+      b['noise'] = f(T, B, H, W)
+      b['ysel'] = f(B, H, W)
+    else:
+      b['x_patch'] = f(T, B, Fh, Fw, d['C0p'])
+      hh, ww = Fh, Fw
+      b['acnn'] = []
+      for i in range(d['acnn_nlayers']):
+        hh, ww = hh // d['acnn_pool'][i], ww // d['acnn_pool'][i]
+        b['acnn'].append(f(B, hh, ww, d['acnn_channels'][i + 1]))
+      b['adcnn'] = []
+      for i in range(d['adcnn_nlayers']):
+        hh, ww = hh * d['adcnn_unpool'][i], ww * d['adcnn_unpool'][i]
+        if i == d['adcnn_nlayers'] - 1:
+          b['y_out_patch'] = f(T, B, hh, ww, d['adcnn_channels'][i + 1])
+          b['adcnn'].append(None)
+        else:
+          b['adcnn'].append(f(B, hh, ww, d['adcnn_channels'][i + 1]))
+      b['y_out'] = f(B, T, H, W)
+      b['u_ws'] = f(B, Fh, W)
+    self.buf = b
+    self._B = B
+    self._graphs = {}
+
+  # ------------------------------------------------------------------ launch sequence
+  def _mark(self, name):
+    if self.timing is not None:
+      ev = torch.cuda.Event(enable_timing=True)
+      ev.record()
+      self.timing.append((name, ev))
+
+  def _launch_all(self, want_box):
+    d, b, Wt, T = self.d, self.buf, self.W, self.d['T']
+    H, W, Fh, Fw = d['H'], d['W'], d['Fh'], d['Fw']
+    ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), d['C0p'], b['img'])
+    self._mark('pack')
+    for tt in range(T):
+      src = b['img']
+      for i, (wp, sc, sh, cout, pool) in enumerate(Wt['ccnn']):
+        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=b['ccnn'][i])
+        src = b['ccnn'][i]
+      self._mark('ctrl_cnn')
+      ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
+                     b['gmaps'][tt], b['attn'][tt])
+      self._mark('controller')
+      ops.attn_filters(b['attn'][tt], H, W, Fh, Fw, b['fy'], b['fx'], b['band'])
+      self._mark('filters')
+      if want_box or self.box:
+        ops.attn_box(b['attn'][tt], b['fy'], b['fx'], b['band'], H, W, Fh, Fw, -5.0,
+                     b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
+        self._mark('attn_box')
+      if self.box:
+        self._box_step(tt)
+        continue
+      xp = b['x_patch'][tt]
+      ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
+                        d['C0p'], True, xp)
+      self._mark('extract')
+      src = xp
+      for i, (wp, sc, sh, cout, pool) in enumerate(Wt['acnn']):
+        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=b['acnn'][i])
+        src = b['acnn'][i]
+      self._mark('attn_cnn')
+      core = src
+      L = d['acnn_nlayers']
+      skips = [b['acnn'][L - 2 - k] for k in range(L - 1)] + [xp]
+      for i, (wp, sc, sh, cout, unpool, sidx) in enumerate(Wt['adcnn']):
+        out = b['y_out_patch'][tt] if b['adcnn'][i] is None else b['adcnn'][i]
+        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=1,
+                    src1=None if sidx is None else skips[sidx], upsample=(unpool == 2), out=out)
+        src = out
+      self._mark('attn_dcnn')
+      ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
+                b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
+      self._mark('score')
+      ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
+                       d['disable_overwrite'], b['img'], d['D'],
+                       b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
+      self._mark('paste')
+
+  def _box_step(self, tt):
+    """box_model.py:484-513: greedy GT match (never accumulated), canvas from noisy GT, score.
+    The [B,T] IoU / arg-max bookkeeping on the GT side uses torch reductions (plumbing for the
+    teacher-forcing input; not on the eval path)."""
+    d, b, T = self.d, self.buf, self.d['T']
+    box = b['attn_box'][:, tt:tt + 1]
+    gt = self.box_gt
+    inter = (box * gt).sum(dim=(2, 3))
+    union = (box + gt - box * gt + 1e-5).sum(dim=(2, 3))
+    iou = inter / union
+    mx = iou.max(dim=1, keepdim=True)[0]
+    match = (iou == mx).to(torch.float32)
+    match = match / match.sum(dim=1, keepdim=True)
+    torch.sum(match[:, :, None, None] * b['y_gt'], dim=1, out=b['ysel'])
+    ops.canvas_max(b['img'], d['D'], b['ysel'], b['noise'][tt])
+    nsc = d['nsc']
+    ops.dense(b['h_last'][tt], self.W['smlp_w'], self.W['smlp_b'],
+              'sigmoid' if nsc == 1 else 'softmax', b['s_out'].data_ptr() + tt * nsc * 4,
+              T * nsc)
+    self._mark('box_step')
+
+  # ------------------------------------------------------------------ public
+  def forward(self, x, d_in=None, y_in=None, y_gt=None, noise=None, want_box=False):
+    if not torch.cuda.is_available():
+      raise rn.RecAttendError('the decode loop needs an MI355X (HIP device); no CPU fallback')
+    device = torch.device('cuda')
+    as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(
+        np.ascontiguousarray(a, dtype=np.float32))).to(device=device, dtype=torch.float32)
+    x = as_t(x)
+    B = x.shape[0]
+    self.prepare(device)
+    self.alloc(B, device)
+    b = self.buf
+    b['x'].copy_(x)
+    if 'd_in' in b:
+      b['d_in'].copy_(as_t(d_in))
+    if 'y_in' in b:
+      b['y_in'].copy_(as_t(y_in))
+    if self.box:
+      b['y_gt'].copy_(as_t(y_gt))
+      if noise is None:
+        b['noise'].uniform_(0.0, 0.3)  # box_model.py:500-502
+      else:
+        b['noise'].copy_(as_t(noise).reshape(b['noise'].shape))
+      self.box_gt = _gt_box_mask(b['y_gt'], self.d['attn_box_padding_ratio'])
+    graphable = self.use_graph and self.timing is None and not self.box
+    if not graphable:
+      self._launch_all(want_box)
+      return b
+    key = bool(want_box)
+    g = self._graphs.get(key)
+    if g is None:
+      self._launch_all(want_box)  # warm-up (also sets kernel attributes)
+      torch.cuda.synchronize()
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        self._launch_all(want_box)
+      self._graphs[key] = g
+    g.replay()
+    return b
+
+
+def _gt_box_mask(y_gt, padding_ratio, min_padding=10.0):
+  """modellib.get_gt_box (modellib.py:663-701) 'box' output, for box_model's greedy match."""
+  B, T, H, W = y_gt.shape
+  dev = y_gt.device
+  iy = torch.arange(H, dtype=torch.float32, device=dev).view(1, 1, H, 1)
+  ix = torch.arange(W, dtype=torch.float32, device=dev).view(1, 1, 1, W)
+  big = float(H * W)
+  tl_y = (iy + (1.0 - y_gt) * big).amin(dim=(2, 3))
+  tl_x = (ix + (1.0 - y_gt) * big).amin(dim=(2, 3))
+  br_y = (iy * y_gt).amax(dim=(2, 3))
+  br_x = (ix * y_gt).amax(dim=(2, 3))
+  out = []
+  for tl, br, idx in ((tl_y, br_y, iy), (tl_x, br_x, ix)):
+    size = br - tl
+    pad = torch.clamp(padding_ratio * size, min=min_padding)
+    lo = (tl - pad)[:, :, None, None]
+    hi = (br + pad)[:, :, None, None]
+    out.append(((idx >= lo) & (idx <= hi)).to(torch.float32))
+  return out[0] * out[1]

@@ -95,6 +95,8 @@ def ptr(t):
   """Raw data pointer of a torch tensor / numpy array / None."""
   if t is None:
     return None
+  if isinstance(t, int):
+    return t
   if hasattr(t, 'data_ptr'):
     return t.data_ptr()
   return t.ctypes.data

@@ -1,0 +1,276 @@
+"""Thin torch-tensor wrappers over the C ABI (include/recattend.h).
+
+Every function here launches hand-written HIP kernels from librecattend.so on the current
+torch stream.  Inputs must be float32 CUDA tensors (contiguous); there is no CPU path —
+calling with CPU tensors raises.  Host-side weight repacking (ra_conv_pack_weights,
+ra_conv_fold_bn, ra_ctrl_pack_weights) runs in the library's C++ and works without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import ra_native as rn
+from ra_native import check, ptr
+
+BN_EPS = 1e-3  # nnlib.py:119
+
+
+def _need_cuda(*ts):
+  for t in ts:
+    if t is not None and not t.is_cuda:
+      raise rn.RecAttendError('recattend kernels need CUDA (HIP) tensors; got a CPU tensor. '
+                              'There is no CPU fallback.')
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+      raise rn.RecAttendError('recattend kernels need contiguous float32 tensors')
+
+
+def _np32(a):
+  if isinstance(a, torch.Tensor):
+    a = a.detach().cpu().numpy()
+  return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------- host packing
+
+
+def cout_padded(cout):
+  return rn.lib().ra_conv_cout_padded(int(cout))
+
+
+def pack_conv_weights(w, cin_kernel=None, chan_map=None, transposed=False):
+  """TF-layout filter -> packed B-operand order (numpy, host).  w [3,3,Ci,Co] or, when
+  transposed, the conv2d_transpose filter [3,3,Co,Ci]."""
+  w = _np32(w)
+  if w.shape[0] != 3 or w.shape[1] != 3:
+    raise rn.RecAttendError('only 3x3 filters are supported, got %r' % (w.shape,))
+  cin_w, cout = (w.shape[3], w.shape[2]) if transposed else (w.shape[2], w.shape[3])
+  cin = cin_w if cin_kernel is None else int(cin_kernel)
+  if chan_map is None and cin != cin_w:
+    chan_map = list(range(cin_w)) + [-1] * (cin - cin_w)
+  n = rn.lib().ra_conv_packed_floats(cin, cout)
+  if n == 0:
+    raise rn.RecAttendError('unsupported conv shape Cin=%d Cout=%d' % (cin, cout))
+  out = np.empty(n, dtype=np.float32)
+  cm = None
+  if chan_map is not None:
+    cm = np.ascontiguousarray(chan_map, dtype=np.int32)
+    assert cm.shape[0] == cin
+  check(rn.lib().ra_conv_pack_weights(ptr(w), cin_w, cout, cin, ptr(cm),
+                                      rn.RA_CONV_TRANSPOSED if transposed else 0, ptr(out)),
+        'ra_conv_pack_weights')
+  return out
+
+
+def fold_bn(bias, cout, bn=None):
+  """(scale, shift) [CoutP] numpy.  bn = (beta, gamma, ema_mean, ema_var) or None."""
+  cp = cout_padded(cout)
+  scale = np.empty(cp, dtype=np.float32)
+  shift = np.empty(cp, dtype=np.float32)
+  b = None if bias is None else _np32(bias)
+  if bn is None:
+    args = (None, None, None, None)
+  else:
+    args = tuple(_np32(a) for a in bn)
+  keep = (b,) + args
+  check(rn.lib().ra_conv_fold_bn(ptr(b), ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]),
+                                 int(cout), C.c_float(BN_EPS), ptr(scale), ptr(shift)),
+        'ra_conv_fold_bn')
+  del keep
+  return scale, shift
+
+
+def make_ctrl_desc(G, Cf, hid, iters, n_gmlp, n_cmlp, mlp_dim, H, W, Fh, Fw, squash, fixed_var,
+                   dynamic_var, fixed_gamma):
+  return rn.CtrlDesc(int(G), int(Cf), int(hid), int(iters), int(n_gmlp), int(n_cmlp),
+                     int(mlp_dim), int(H), int(W), int(Fh), int(Fw), int(bool(squash)),
+                     int(bool(fixed_var)), int(bool(dynamic_var)), int(bool(fixed_gamma)))
+
+
+def pack_ctrl_weights(desc, lstm, gmlp, cmlp):
+  """lstm: dict with keys w_xi,w_hi,b_i,...; gmlp/cmlp: lists [(w,b),...].  -> numpy."""
+  n = rn.lib().ra_ctrl_packed_floats(C.byref(desc))
+  if n == 0:
+    raise rn.RecAttendError('unsupported controller descriptor')
+  order = ['w_xi', 'w_hi', 'b_i', 'w_xf', 'w_hf', 'b_f', 'w_xu', 'w_hu', 'b_u', 'w_xo', 'w_ho',
+           'b_o']
+  la = [_np32(lstm[k]) for k in order]
+  ga = [_np32(a) for wb in gmlp for a in wb]
+  ca = [_np32(a) for wb in cmlp for a in wb]
+  arr = lambda xs: (C.c_void_p * len(xs))(*[x.ctypes.data for x in xs])
+  out = np.empty(n, dtype=np.float32)
+  check(rn.lib().ra_ctrl_pack_weights(C.byref(desc), arr(la), arr(ga), arr(ca), ptr(out)),
+        'ra_ctrl_pack_weights')
+  return out
+
+
+# ---------------------------------------------------------------------------- device ops
+
+
+def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample=False,
+            out=None):
+  """One fused conv layer.  src0 [B,Hs,Ws,C0] (+ src1 [B,Hs,Ws,C1]) -> [B,Ho,Wo,cout]."""
+  _need_cuda(src0, src1, wp, scale, shift, out)
+  B, Hs, Ws, C0 = src0.shape
+  C1 = 0 if src1 is None else src1.shape[3]
+  up = 2 if upsample else 1
+  Ho, Wo = Hs * up // pool, Ws * up // pool
+  if out is None:
+    out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=src0.device)
+  check(rn.lib().ra_conv3x3_f32(ptr(src0), C0, ptr(src1), C1, B, Hs, Ws, int(upsample), ptr(wp),
+                                ptr(scale), ptr(shift), int(cout), int(relu), int(pool),
+                                ptr(out), rn.stream_ptr()), 'ra_conv3x3_f32')
+  return out
+
+
+def controller(desc, feat, wp, h_last, ctrl_out, gmaps, attn):
+  _need_cuda(feat, wp, h_last, ctrl_out, gmaps, attn)
+  B = feat.shape[0]
+  check(rn.lib().ra_controller_f32(C.byref(desc), ptr(feat), ptr(wp), B, ptr(h_last),
+                                   ptr(ctrl_out), ptr(gmaps), ptr(attn), rn.stream_ptr()),
+        'ra_controller_f32')
+
+
+def band_ints(H, W, Fh, Fw):
+  return rn.lib().ra_attn_band_ints(H, W, Fh, Fw)
+
+
+def attn_filters(attn, H, W, Fh, Fw, fy, fx, band):
+  _need_cuda(attn, fy, fx)
+  check(rn.lib().ra_attn_filters_f32(ptr(attn), attn.shape[0], H, W, Fh, Fw, ptr(fy), ptr(fx),
+                                     ptr(band), rn.stream_ptr()), 'ra_attn_filters_f32')
+
+
+def extract_patch(img, chan0, attn, fy, fx, band, Fh, Fw, Cp, use_gamma, patch):
+  _need_cuda(img, attn, fy, fx, patch)
+  B, H, W, Ci = img.shape
+  check(rn.lib().ra_extract_patch_f32(ptr(img), Ci, chan0, ptr(attn), ptr(fy), ptr(fx),
+                                      ptr(band), B, H, W, Fh, Fw, Cp, int(use_gamma), ptr(patch),
+                                      rn.stream_ptr()), 'ra_extract_patch_f32')
+
+
+def paste_canvas(patch, pc, attn, fy, fx, band, beta, disable_overwrite, img, canvas_chan, y_out,
+                 y_stride_b, u_ws, H, W):
+  _need_cuda(patch, attn, fy, fx, img, u_ws)
+  B, Fh, Fw, Cp = patch.shape
+  Ci = 0 if img is None else img.shape[3]
+  check(rn.lib().ra_paste_canvas_f32(ptr(patch), Cp, pc, ptr(attn), ptr(fy), ptr(fx), ptr(band),
+                                     B, H, W, Fh, Fw, C.c_float(beta), int(disable_overwrite),
+                                     ptr(img), Ci, canvas_chan, ptr(y_out), y_stride_b,
+                                     ptr(u_ws), rn.stream_ptr()), 'ra_paste_canvas_f32')
+
+
+def attn_box(attn, fy, fx, band, H, W, Fh, Fw, beta, out, stride_b):
+  _need_cuda(attn, fy, fx)
+  check(rn.lib().ra_attn_box_f32(ptr(attn), ptr(fy), ptr(fx), ptr(band), attn.shape[0], H, W,
+                                 Fh, Fw, C.c_float(beta), ptr(out), stride_b, rn.stream_ptr()),
+        'ra_attn_box_f32')
+
+
+def dense(x0, W, b, act, out, out_stride_b, x1=None):
+  """act: None/'relu'/'sigmoid'/'softmax'/'tanh'.  out may be a view; pass its data ptr."""
+  _need_cuda(x0, x1, W, b)
+  code = {None: 0, 'relu': 1, 'sigmoid': 2, 'softmax': 3, 'tanh': 4}[act]
+  K1 = 0 if x1 is None else x1.shape[1]
+  check(rn.lib().ra_dense_f32(ptr(x0), x0.shape[1], ptr(x1), K1, ptr(W), ptr(b), x0.shape[0],
+                              W.shape[1], code, ptr(out), out_stride_b, rn.stream_ptr()),
+        'ra_dense_f32')
+
+
+def pack_input(x, d_in, y_in, Cp, packed):
+  _need_cuda(x, d_in, y_in, packed)
+  B, H, W, D = x.shape
+  Dd = 0 if d_in is None else d_in.shape[3]
+  Dy = 0 if y_in is None else y_in.shape[3]
+  check(rn.lib().ra_pack_input_f32(ptr(x), D, ptr(d_in), Dd, ptr(y_in), Dy, B, H, W, Cp,
+                                   ptr(packed), rn.stream_ptr()), 'ra_pack_input_f32')
+
+
+def canvas_max(img, canvas_chan, ysel, noise):
+  _need_cuda(img, ysel, noise)
+  B, H, W, Ci = img.shape
+  check(rn.lib().ra_canvas_max_f32(ptr(img), Ci, canvas_chan, ptr(ysel), ptr(noise), B, H, W,
+                                   rn.stream_ptr()), 'ra_canvas_max_f32')
+
+
+def gaussian_filter(center, size, lg_var, L, F):
+  _need_cuda(center, size, lg_var)
+  B = center.shape[0]
+  out = torch.empty((B, L, F), dtype=torch.float32, device=center.device)
+  check(rn.lib().ra_gaussian_filter_f32(ptr(center), ptr(size), ptr(lg_var), B, L, F, ptr(out),
+                                        rn.stream_ptr()), 'ra_gaussian_filter_f32')
+  return out
+
+
+def extract_patch_dense(x, f_y, f_x):
+  _need_cuda(x, f_y, f_x)
+  B, H, W, D = x.shape
+  FH, FW = f_y.shape[2], f_x.shape[2]
+  out = torch.empty((B, FH, FW, D), dtype=torch.float32, device=x.device)
+  check(rn.lib().ra_extract_patch_dense_f32(ptr(x), ptr(f_y), ptr(f_x), B, H, W, D, FH, FW,
+                                            ptr(out), rn.stream_ptr()),
+        'ra_extract_patch_dense_f32')
+  return out
+
+
+def affine_act(x, scale, shift, relu=False):
+  _need_cuda(x, scale, shift)
+  Cc = x.shape[-1]
+  out = torch.empty_like(x)
+  check(rn.lib().ra_affine_act_f32(ptr(x), ptr(scale), ptr(shift), x.numel() // Cc, Cc,
+                                   int(relu), ptr(out), rn.stream_ptr()), 'ra_affine_act_f32')
+  return out
+
+
+def max_pool(x, ratio):
+  _need_cuda(x)
+  B, H, W, Cc = x.shape
+  out = torch.empty((B, -(-H // ratio), -(-W // ratio), Cc), dtype=torch.float32,
+                    device=x.device)
+  check(rn.lib().ra_max_pool_f32(ptr(x), B, H, W, Cc, int(ratio), ptr(out), rn.stream_ptr()),
+        'ra_max_pool_f32')
+  return out
+
+
+def hungarian(weights):
+  """Drop-in for hungarian_module.hungarian (modellib.py:406): weights [B,N,M] or [N,M] ->
+  (matching, cover_x [...,N,1], cover_y [...,1,M]).  CPU tensors/arrays run the host entry
+  point (like the reference's CPU op); CUDA tensors run the device kernel."""
+  is_t = isinstance(weights, torch.Tensor)
+  two_d = (weights.ndim == 2)
+  if weights.ndim not in (2, 3):
+    raise rn.RecAttendError('Must have dimension 3 or 2.')  # hungarian.cc:62
+  if is_t and weights.is_cuda:
+    w = weights.detach().to(torch.float32).contiguous()
+    w3 = w[None] if two_d else w
+    B, N, M = w3.shape
+    m = torch.empty_like(w3)
+    cx = torch.empty((B, N), dtype=torch.float32, device=w.device)
+    cy = torch.empty((B, M), dtype=torch.float32, device=w.device)
+    st = torch.zeros((max(B, 1),), dtype=torch.int32, device=w.device)
+    nb = rn.lib().ra_hungarian_dev_workspace_bytes(max(B, 1), N, M)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=w.device)
+    check(rn.lib().ra_hungarian_f32_dev(ptr(w3), B, N, M, ptr(m), ptr(cx), ptr(cy), ptr(st),
+                                        ptr(ws), nb, rn.stream_ptr()), 'ra_hungarian_f32_dev')
+    hungarian.last_status = st
+    cx, cy = cx[:, :, None], cy[:, None, :]
+    return (m[0], cx[0], cy[0]) if two_d else (m, cx, cy)
+  w = _np32(weights)
+  w3 = w[None] if two_d else w
+  B, N, M = w3.shape
+  m = np.zeros_like(w3)
+  cx = np.zeros((B, N), np.float32)
+  cy = np.zeros((B, M), np.float32)
+  rc = rn.lib().ra_hungarian_f32(ptr(w3), B, N, M, ptr(m), ptr(cx), ptr(cy))
+  if rc < 0:
+    check(rc, 'ra_hungarian_f32')
+  hungarian.last_status = rc
+  cx, cy = cx[:, :, None], cy[:, None, :]
+  if two_d:
+    m, cx, cy = m[0], cx[0], cy[0]
+  if is_t:
+    return torch.from_numpy(m), torch.from_numpy(cx), torch.from_numpy(cy)
+  return m, cx, cy
+
+
+hungarian.last_status = 0

@@ -1,0 +1,152 @@
+"""End-to-end parity of the decode loop (full_model / box_model forward on MI355X, through
+the C ABI) against the float64 NumPy oracle on the same seeded inputs and weights.
+Bar: masks within 1e-3 max-abs (BASELINE.json north_star); observed ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+import ra_oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+MASK_TOL = 1e-3  # the north star's tolerance on masks
+
+
+def _inputs(opt, B, seed):
+  rng = np.random.RandomState(seed)
+  H, W = opt['inp_height'], opt['inp_width']
+  x = rng.rand(B, H, W, 3).astype(np.float32)
+  d_in = y_in = None
+  if opt.get('add_d_out'):
+    lab = rng.randint(0, 8, (B, H, W))
+    d_in = np.eye(8, dtype=np.float32)[lab]
+    logits = rng.randn(B, H, W, opt['num_semantic_classes'])
+    y_in = ora.softmax(logits).astype(np.float32)
+  return x, d_in, y_in
+
+
+def _check(opt, B, seed, use_graph):
+  import full_model
+  P = ora.random_params(opt, seed)
+  x, d_in, y_in = _inputs(opt, B, seed + 1)
+  ref = ora.full_model_forward(opt, P, x, d_in, y_in)
+  m = full_model.get_model(opt).load_weights(P)
+  m.engine.use_graph = use_graph
+  feed = {'x': x, 'phase_train': False, 'd_in': d_in, 'y_in': y_in}
+  names = ['y_out', 's_out', 'x_patch', 'y_out_patch', 'attn_ctr', 'attn_size',
+           'ctrl_rnn_glimpse_map', 'attn_box', 'canvas']
+  for rep in range(2 if use_graph else 1):  # second pass = graph replay
+    out = dict(zip(names, m.run(names, feed, as_numpy=True)))
+    assert out['y_out'].shape == ref['y_out'].shape
+    assert np.abs(out['attn_ctr'] - ref['attn_ctr']).max() < 2e-3
+    assert np.abs(out['attn_size'] - ref['attn_size']).max() < 2e-3
+    assert np.abs(out['ctrl_rnn_glimpse_map'] - ref['ctrl_rnn_glimpse_map']).max() < 1e-4
+    assert np.abs(out['x_patch'] - ref['x_patch']).max() < 1e-3
+    assert np.abs(out['y_out_patch'] - ref['y_out_patch']).max() < 1e-3
+    assert np.abs(out['y_out'] - ref['y_out']).max() < MASK_TOL
+    assert np.abs(out['s_out'] - ref['s_out']).max() < MASK_TOL
+    assert np.abs(out['attn_box'] - ref['attn_box']).max() < MASK_TOL
+    assert np.abs(out['canvas'] - ref['canvas']).max() < MASK_TOL
+  return out, ref
+
+
+def test_cfg1_cvppp_128(cuda):
+  """BASELINE.json configs[0]: CVPPP full_model 128x128, 5 timesteps, batch 1."""
+  out, ref = _check(ora.make_opt('cvppp', 128, 128, 5), 1, 16, use_graph=False)
+  assert ref['y_out'].max() > 0.5  # the fixture is not a trivial all-sigma(-5) mask
+  print('max |dy|', np.abs(out['y_out'] - ref['y_out']).max())
+
+
+def test_cvppp_graph_replay_batch3(cuda):
+  _check(ora.make_opt('cvppp', 128, 160, 3), 3, 14, use_graph=True)
+
+
+def test_cvppp_disable_overwrite_and_no_fixed_gamma(cuda):
+  _check(ora.make_opt('cvppp', 96, 96, 3, disable_overwrite=True, fixed_gamma=False), 2, 31, False)
+
+
+def test_kitti_arch_skip_dynamic_var(cuda):
+  """KITTI-style flags: skip connections, dynamic_var, 13 input channels."""
+  _check(ora.make_opt('kitti', 64, 96, 3), 2, 41, use_graph=False)
+
+
+def test_cityscapes_arch(cuda):
+  _check(ora.make_opt('cityscapes', 64, 128, 2), 1, 51, use_graph=True)
+
+
+def test_weights_reload_invalidates_packing(cuda):
+  import full_model
+  opt = ora.make_opt('cvppp', 64, 64, 2)
+  x, _, _ = _inputs(opt, 1, 5)
+  m = full_model.get_model(opt)
+  for seed in (1, 2):
+    P = ora.random_params(opt, seed)
+    m.load_weights(P)
+    y = m.run('y_out', {'x': x, 'phase_train': False}, as_numpy=True)
+    ref = ora.full_model_forward(opt, P, x)
+    assert np.abs(y - ref['y_out']).max() < MASK_TOL
+
+
+def test_box_model(cuda):
+  import box_model
+  opt = ora.make_opt('cvppp', 96, 96, 3)
+  B = 2
+  P = ora.random_params(opt, 7, box_model=True)
+  rng = np.random.RandomState(8)
+  x = rng.rand(B, 96, 96, 3).astype(np.float32)
+  y_gt = np.zeros((B, 3, 96, 96), np.float32)
+  y_gt[:, 0, 10:40, 15:50] = 1
+  y_gt[:, 1, 50:80, 40:90] = 1
+  noise = rng.uniform(0, 0.3, (3, B, 96, 96, 1)).astype(np.float32)
+  ref = ora.box_model_forward(opt, P, x, y_gt, noise)
+  m = box_model.get_model(opt).load_weights(P)
+  names = ['s_out', 'attn_box', 'attn_ctr', 'attn_size', 'canvas']
+  out = dict(zip(names, m.run(names, {'x': x, 'y_gt': y_gt, 'noise': noise[..., 0],
+                                      'phase_train': False}, as_numpy=True)))
+  for k in names:
+    assert np.abs(out[k] - ref[k]).max() < (2e-3 if k.startswith('attn_c') or k == 'attn_size'
+                                            else MASK_TOL), k
+
+
+def test_operator_surface_closures(cuda):
+  """The nnlib-shaped closures (cnn / dcnn / mlp / lstm) against the oracle, layer by layer."""
+  import nnlib as nn
+  import modellib
+  rng = np.random.RandomState(3)
+  model = {}
+  run = nn.cnn([3, 3], [4, 8, 16], [1, 2], [nn.relu, nn.relu], [True, True], phase_train=False,
+               scope='t_cnn', model=model)
+  run.declare_copies(2)
+  P = {}
+  for k, v in model.items():
+    a = rng.uniform(0.5, 1.5, tuple(v.shape)) if ('gamma' in k or 'var' in k) else \
+        rng.randn(*v.shape) * 0.3
+    v.copy_(torch.from_numpy(a.astype(np.float32)))
+    P[k] = a.astype(np.float32).astype(np.float64)
+  x = rng.randn(2, 16, 16, 4).astype(np.float32)
+  xd = torch.from_numpy(x).to(cuda)
+  for cp in range(2):
+    h = run(xd)
+    ref = ora.run_cnn(x.astype(np.float64), P, 't_cnn', 2, [1, 2], cp)
+    for a, b in zip(h, ref):
+      assert np.abs(a.cpu().numpy() - b).max() < 1e-4
+  assert sorted(model) == sorted(['t_cnn_w_0', 't_cnn_b_0', 't_cnn_w_1', 't_cnn_b_1'] + [
+      't_cnn_%d_%d_%s' % (i, c, n) for i in range(2) for c in range(2)
+      for n in ('beta', 'gamma', 'ema_mean', 'ema_var')])
+  # conv2d / max_pool / gaussian filter / extract_patch stand-alone operators
+  w = rng.randn(3, 3, 4, 8).astype(np.float32)
+  y = nn.conv2d(xd, torch.from_numpy(w).to(cuda)).cpu().numpy()
+  assert np.abs(y - ora.conv2d(x.astype(np.float64), w.astype(np.float64))).max() < 1e-4
+  assert (nn.max_pool(xd, 2).cpu().numpy() == ora.max_pool(x, 2)).all()
+  cell = nn.lstm(8, 16, scope='t_lstm', model=model)
+  PL = {k: model[k].cpu().numpy().astype(np.float64) for k in model if k.startswith('t_lstm')}
+  inp, st = rng.randn(3, 8).astype(np.float32), rng.randn(3, 32).astype(np.float32)
+  s2, gi, gf, go = cell(torch.from_numpy(inp).to(cuda), torch.from_numpy(st).to(cuda))
+  r2, ri, rf, ro = ora.lstm_step(inp.astype(np.float64), st.astype(np.float64), PL, 't_lstm', 16)
+  assert np.abs(s2.cpu().numpy() - r2).max() < 1e-5 and np.abs(go.cpu().numpy() - ro).max() < 1e-5
+  f = modellib.get_gaussian_filter(torch.tensor([20.0, 30.0], device=cuda),
+                                   torch.tensor([25.0, 40.0], device=cuda),
+                                   torch.tensor([0.1, 0.5], device=cuda), 64, 48)
+  fr = ora.get_gaussian_filter(np.array([20.0, 30.0]), np.array([25.0, 40.0]),
+                               np.array([0.1, 0.5]), 64, 48)
+  assert np.abs(f.cpu().numpy() - fr).max() < 1e-5

@@ -1,0 +1,259 @@
+"""Per-kernel parity: every HIP kernel (through the C ABI) against the NumPy oracle on the same
+seeded inputs.  Tolerances are float32 round-off class (the north star's bar is 1e-3 on masks)."""
+import numpy as np
+import pytest
+import torch
+
+import ra_oracle as ora
+import ra_ops as ops
+import ra_native as rn
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, cuda):
+  return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+
+
+def relerr(a, b):
+  return np.abs(a - b).max() / max(1e-6, np.abs(b).max())
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, pool, relu
+    (2, 32, 32, 4, 8, 1, True),
+    (2, 32, 32, 8, 8, 2, True),
+    (1, 64, 48, 8, 16, 1, True),
+    (1, 16, 16, 16, 16, 2, False),
+    (3, 48, 48, 16, 32, 1, True),
+    (2, 24, 24, 32, 32, 2, True),
+    (2, 16, 16, 32, 64, 2, True),
+    (2, 8, 8, 64, 64, 2, True),
+    (1, 128, 128, 4, 8, 1, True),
+    (8, 64, 64, 16, 16, 2, True),   # many workgroups -> big tile geometry
+    (1, 12, 12, 64, 96, 2, True),   # KITTI attn cnn last layer (Cout 96 -> 128 padded)
+    (1, 20, 36, 24, 16, 2, True),   # Cityscapes packed input (24 ch), ragged tiles
+    (1, 6, 10, 4, 1, 1, True),      # Cout = 1, tiny
+]
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,pool,relu', CONV_CASES)
+def test_conv3x3(cuda, B, H, W, Ci, Co, pool, relu):
+  rng = np.random.RandomState(B * 1000 + H + Ci + Co)
+  x = rng.randn(B, H, W, Ci).astype(np.float32)
+  w = (rng.randn(3, 3, Ci, Co) / np.sqrt(9 * Ci)).astype(np.float32)
+  b = rng.randn(Co).astype(np.float32) * 0.1
+  bn = (rng.randn(Co) * 0.2, rng.uniform(0.5, 1.5, Co) * rng.choice([-1, 1], Co),
+        rng.randn(Co) * 0.2, rng.uniform(0.5, 1.5, Co))
+  bn = tuple(a.astype(np.float32) for a in bn)
+  ref = ora.conv2d(x.astype(np.float64), w.astype(np.float64)) + b
+  ref = ora.batch_norm_eval(ref, *[a.astype(np.float64) for a in bn])
+  if relu:
+    ref = ora.relu(ref)
+  if pool > 1:
+    ref = ora.max_pool(ref, pool)
+  wp = dev(ops.pack_conv_weights(w), cuda)
+  sc, sh = ops.fold_bn(b, Co, bn)
+  y = ops.conv3x3(dev(x, cuda), wp, dev(sc, cuda), dev(sh, cuda), Co, relu=relu, pool=pool)
+  torch.cuda.synchronize()
+  y = y.cpu().numpy()
+  assert y.shape == ref.shape
+  assert relerr(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cx,Cs,Co,stride', [
+    (2, 6, 6, 32, 0, 32, 2),
+    (2, 12, 12, 32, 0, 32, 1),
+    (1, 12, 12, 16, 16, 8, 2),
+    (2, 24, 24, 16, 16, 16, 1),
+    (1, 48, 48, 8, 0, 1, 1),
+    (1, 6, 6, 96, 0, 64, 2),
+    (1, 12, 12, 64, 64, 64, 1),
+    (1, 48, 48, 16, 13, 1, 1),  # skip with 13 real channels padded to 16
+])
+def test_conv_transpose(cuda, B, H, W, Cx, Cs, Co, stride):
+  rng = np.random.RandomState(H * 7 + Cx + Cs + Co + stride)
+  x = rng.randn(B, H, W, Cx).astype(np.float32)
+  s = rng.randn(B, H, W, Cs).astype(np.float32) if Cs else None
+  Cin = Cx + Cs
+  w = (rng.randn(3, 3, Co, Cin) / np.sqrt(9 * Cin)).astype(np.float32)
+  b = rng.randn(Co).astype(np.float32) * 0.1
+  xin = x if s is None else np.concatenate([x, s], axis=3)
+  ref = ora.relu(ora.conv2d_transpose(xin.astype(np.float64), w.astype(np.float64), stride) + b)
+  cs_k = -(-Cs // 4) * 4
+  cmap = list(range(Cx)) + [Cx + k if k < Cs else -1 for k in range(cs_k)]
+  wp = dev(ops.pack_conv_weights(w, cin_kernel=Cx + cs_k, chan_map=cmap, transposed=True), cuda)
+  sc, sh = ops.fold_bn(b, Co, None)
+  sk = None
+  if s is not None:
+    sk = dev(np.pad(s, ((0, 0), (0, 0), (0, 0), (0, cs_k - Cs))), cuda)
+  y = ops.conv3x3(dev(x, cuda), wp, dev(sc, cuda), dev(sh, cuda), Co, relu=True, pool=1, src1=sk,
+                  upsample=(stride == 2))
+  torch.cuda.synchronize()
+  y = y.cpu().numpy()
+  assert y.shape == ref.shape
+  assert relerr(y, ref) < 2e-5
+
+
+def _ctrl_setup(opt, seed):
+  d = ora.derive(opt)
+  P = ora.random_params(opt, seed)
+  return d, P
+
+
+@pytest.mark.parametrize('arch,H,W,flags', [
+    ('cvppp', 128, 128, {}),
+    ('cvppp', 224, 224, {'squash_ctrl_params': True}),   # G = 49: not a multiple of 4
+    ('kitti', 128, 448, {}),
+    ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2, 'num_glimpse_mlp_layers': 3}),
+])
+def test_controller(cuda, arch, H, W, flags):
+  opt = ora.make_opt(arch, H, W, 2, **flags)
+  d, P = _ctrl_setup(opt, 3)
+  B = 3
+  rng = np.random.RandomState(5)
+  Cf = d['ccnn_channels'][-1]
+  feat = np.maximum(rng.randn(B, d['G'], Cf), 0).astype(np.float32)
+  P64 = {k: v.astype(np.float64) for k, v in P.items()}
+  h, co, gm = ora._controller(d, P64, feat.astype(np.float64), np.dtype(np.float64))
+  cn, ls, ctr, size, lv = ora._decode_ctrl(d, co, np.dtype(np.float64))
+  desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
+                            opt['ctrl_mlp_dim'], H, W, 48, 48, d['squash'], d['fixed_var'],
+                            d['dynamic_var'], d['fixed_gamma'])
+  lstm = {k[len('ctrl_lstm_'):]: v for k, v in P.items() if k.startswith('ctrl_lstm_')}
+  gmw = [(P['glimpse_mlp_w_%d' % i], P['glimpse_mlp_b_%d' % i]) for i in range(d['n_gmlp'])]
+  cmw = [(P['ctrl_mlp_w_%d' % i], P['ctrl_mlp_b_%d' % i]) for i in range(d['n_cmlp'])]
+  wp = dev(ops.pack_ctrl_weights(desc, lstm, gmw, cmw), cuda)
+  z = lambda *s: torch.zeros(s, dtype=torch.float32, device=cuda)
+  h_last, ctrl_out, gmaps, attn = z(B, d['hid']), z(B, 9), z(B, d['iters'], d['G']), z(B, 16)
+  ops.controller(desc, dev(feat, cuda), wp, h_last, ctrl_out, gmaps, attn)
+  torch.cuda.synchronize()
+  assert relerr(h_last.cpu().numpy(), h) < 5e-5
+  assert np.abs(ctrl_out.cpu().numpy() - co).max() < 5e-5
+  assert np.abs(gmaps.cpu().numpy() - gm).max() < 1e-5
+  a = attn.cpu().numpy()
+  assert np.abs(a[:, 0:2] - ctr).max() < 1e-3 * max(H, W) / 100
+  assert relerr(a[:, 2:4], size) < 1e-4
+  assert np.abs(a[:, 4:6] - lv).max() < 1e-4
+  assert np.abs(a[:, 9:11] - cn).max() < 1e-4 and np.abs(a[:, 11:13] - ls).max() < 1e-4
+  if d['fixed_gamma']:
+    assert (a[:, 6] == 1.0).all() and (a[:, 8] == 2.0).all()
+  else:
+    assert relerr(a[:, 6], np.exp(co[:, 6])) < 1e-4 and np.abs(a[:, 8] - co[:, 8]).max() < 1e-4
+  assert relerr(a[:, 7], np.exp(co[:, 7])) < 1e-4
+
+
+def _attn_rec(B, H, W, rng, big_var=False):
+  rec = np.zeros((B, 16), np.float32)
+  rec[:, 0] = rng.uniform(0.1, 0.9, B) * H
+  rec[:, 1] = rng.uniform(0.1, 0.9, B) * W
+  rec[:, 2] = rng.uniform(0.15, 0.7, B) * H
+  rec[:, 3] = rng.uniform(0.15, 0.7, B) * W
+  rec[:, 4] = np.log(rec[:, 2] / 48.0)
+  rec[:, 5] = np.log(rec[:, 3] / 48.0)
+  if big_var:
+    rec[:, 4:6] += 4.0  # very wide taps: bands cover (almost) the whole image
+  rec[:, 6] = rng.uniform(0.5, 2.0, B)
+  rec[:, 7] = rng.uniform(0.5, 2.0, B)
+  rec[:, 8] = rng.uniform(0.5, 2.5, B)
+  return rec
+
+
+def _filters(cuda, rec, H, W, Fh=48, Fw=48):
+  B = rec.shape[0]
+  fy = torch.zeros((B, H, Fh), dtype=torch.float32, device=cuda)
+  fx = torch.zeros((B, W, Fw), dtype=torch.float32, device=cuda)
+  band = torch.zeros((B, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32, device=cuda)
+  ops.attn_filters(dev(rec, cuda), H, W, Fh, Fw, fy, fx, band)
+  return fy, fx, band
+
+
+@pytest.mark.parametrize('H,W,big', [(128, 128, False), (96, 160, True), (512, 512, False)])
+def test_filters_extract_paste(cuda, H, W, big):
+  rng = np.random.RandomState(H + W)
+  B, C = 3, 8
+  rec = _attn_rec(B, H, W, rng, big)
+  # box partly outside the image
+  rec[0, 0], rec[0, 1] = 0.02 * H, 0.97 * W
+  fy, fx, band = _filters(cuda, rec, H, W)
+  r64 = rec.astype(np.float64)
+  fy_ref = ora.get_gaussian_filter(r64[:, 0], r64[:, 2], r64[:, 4], H, 48)
+  fx_ref = ora.get_gaussian_filter(r64[:, 1], r64[:, 3], r64[:, 5], W, 48)
+  torch.cuda.synchronize()
+  assert relerr(fy.cpu().numpy(), fy_ref) < 1e-4 and relerr(fx.cpu().numpy(), fx_ref) < 1e-4
+  # dense operator too
+  g = ops.gaussian_filter(dev(rec[:, 0], cuda), dev(rec[:, 2], cuda), dev(rec[:, 4], cuda), H, 48)
+  assert relerr(g.cpu().numpy(), fy_ref) < 1e-4
+  # extract
+  img = rng.rand(B, H, W, C).astype(np.float32)
+  patch = torch.zeros((B, 48, 48, C), dtype=torch.float32, device=cuda)
+  ops.extract_patch(dev(img, cuda), 0, dev(rec, cuda), fy, fx, band, 48, 48, C, True, patch)
+  ref = r64[:, 6].reshape(-1, 1, 1, 1) * ora.extract_patch(img.astype(np.float64), fy_ref, fx_ref, C)
+  torch.cuda.synchronize()
+  assert np.abs(patch.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+  # generic dense operator with the same filters
+  pd = ops.extract_patch_dense(dev(img, cuda), fy, fx)
+  assert np.abs(pd.cpu().numpy() * r64[:, 6].reshape(-1, 1, 1, 1) - ref).max() < \
+      2e-5 * max(1.0, np.abs(ref).max())
+  # paste + canvas, two consecutive steps on the same canvas
+  P = rng.randn(B, 48, 48, 1).astype(np.float32)
+  canvas0 = rng.uniform(0, 0.6, (B, H, W, 1)).astype(np.float32)
+  for overwrite in (True, False):
+    imgc = img.copy()
+    imgc[..., 3:4] = canvas0
+    dimg = dev(imgc, cuda)
+    y_out = torch.zeros((B, 2, H, W), dtype=torch.float32, device=cuda)
+    u_ws = torch.zeros((B, 48, W), dtype=torch.float32, device=cuda)
+    ops.paste_canvas(dev(P, cuda), 0, dev(rec, cuda), fy, fx, band, -5.0, overwrite, dimg, 3,
+                     y_out.data_ptr() + H * W * 4, 2 * H * W, u_ws, H, W)
+    torch.cuda.synchronize()
+    yy = ora.extract_patch(P.astype(np.float64), np.transpose(fy_ref, (0, 2, 1)),
+                           np.transpose(fx_ref, (0, 2, 1)), 1)
+    yy = ora.sigmoid(np.exp(r64[:, 8]).reshape(-1, 1, 1, 1) * yy - 5.0)
+    if overwrite:
+      yy = yy * (1 - canvas0.astype(np.float64))
+    cref = np.maximum(yy, canvas0)
+    got = y_out.cpu().numpy()
+    assert (got[:, 0] == 0).all()
+    assert np.abs(got[:, 1] - yy[..., 0]).max() < 1e-5
+    gimg = dimg.cpu().numpy()
+    assert np.abs(gimg[..., 3] - cref[..., 0]).max() < 1e-5
+    assert (gimg[..., [0, 1, 2, 4, 5, 6, 7]] == imgc[..., [0, 1, 2, 4, 5, 6, 7]]).all()
+  # attention box
+  box = torch.zeros((B, H, W), dtype=torch.float32, device=cuda)
+  ops.attn_box(dev(rec, cuda), fy, fx, band, H, W, 48, 48, -5.0, box, H * W)
+  ones = np.ones((B, 48, 48, 1))
+  bref = ora.sigmoid(ora.extract_patch(ones * r64[:, 7].reshape(-1, 1, 1, 1),
+                                       np.transpose(fy_ref, (0, 2, 1)),
+                                       np.transpose(fx_ref, (0, 2, 1)), 1) - 5.0)
+  torch.cuda.synchronize()
+  assert np.abs(box.cpu().numpy() - bref[..., 0]).max() < 2e-5
+
+
+def test_dense_pool_affine_pack(cuda):
+  rng = np.random.RandomState(0)
+  B = 5
+  x0, x1 = rng.randn(B, 256).astype(np.float32), rng.randn(B, 1152).astype(np.float32)
+  W = (rng.randn(1408, 3) / 30).astype(np.float32)
+  b = rng.randn(3).astype(np.float32)
+  z = np.concatenate([x0, x1], 1).astype(np.float64) @ W + b
+  for act, f in (('sigmoid', ora.sigmoid), ('softmax', ora.softmax), (None, lambda v: v),
+                 ('relu', ora.relu), ('tanh', np.tanh)):
+    out = torch.zeros((B, 3), dtype=torch.float32, device=cuda)
+    ops.dense(dev(x0, cuda), dev(W, cuda), dev(b, cuda), act, out, 3, x1=dev(x1, cuda))
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - f(z)).max() < 2e-5
+  x = rng.randn(2, 7, 9, 5).astype(np.float32)
+  for r in (2, 3):
+    y = ops.max_pool(dev(x, cuda), r).cpu().numpy()
+    assert (y == ora.max_pool(x, r)).all()
+  sc, sh = rng.randn(5).astype(np.float32), rng.randn(5).astype(np.float32)
+  y = ops.affine_act(dev(x, cuda), dev(sc, cuda), dev(sh, cuda), relu=True).cpu().numpy()
+  assert np.abs(y - np.maximum(x * sc + sh, 0)).max() < 1e-6
+  xi = rng.rand(2, 8, 8, 3).astype(np.float32)
+  di, yi = rng.rand(2, 8, 8, 8).astype(np.float32), rng.rand(2, 8, 8, 1).astype(np.float32)
+  packed = torch.full((2, 8, 8, 16), 7.0, dtype=torch.float32, device=cuda)
+  ops.pack_input(dev(xi, cuda), dev(di, cuda), dev(yi, cuda), 16, packed)
+  ref = np.concatenate([xi, np.zeros((2, 8, 8, 1), np.float32), di, yi,
+                        np.zeros((2, 8, 8, 3), np.float32)], 3)
+  assert (packed.cpu().numpy() == ref).all()
