@@ -208,8 +208,17 @@ class DecodeEngine(object):
   def _mark(self, name):
     if self.timing is not None:
       ev = torch.cuda.Event(enable_timing=True)
-      ev.record()
+      ev.record()  # on the current stream = the stream every kernel here is launched on
       self.timing.append((name, ev))
+
+  def stage_times_ms(self):
+    """After a forward with self.timing = [] and a synchronize: {stage: (total ms, launches)}
+    from the HIP events recorded between stages."""
+    out = {}
+    for (_, e0), (name, e1) in zip(self.timing[:-1], self.timing[1:]):
+      tot, n = out.get(name, (0.0, 0))
+      out[name] = (tot + e0.elapsed_time(e1), n + 1)
+    return out
 
   def _launch_all(self, want_box):
     d, b, Wt, T = self.d, self.buf, self.W, self.d['T']
@@ -221,7 +230,7 @@ class DecodeEngine(object):
       for i, (wp, sc, sh, cout, pool) in enumerate(Wt['ccnn']):
         ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=b['ccnn'][i])
         src = b['ccnn'][i]
-      self._mark('ctrl_cnn')
+        self._mark('ctrl_cnn_L%d' % i)
       ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
                      b['gmaps'][tt], b['attn'][tt])
       self._mark('controller')
