@@ -122,22 +122,14 @@ def main():
   ap.add_argument('--timespan', type=int, default=16)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-graph', action='store_true')
-  ap.add_argument('--profile-steps', type=int, default=3,
-                  help='instrumented (HIP-event per stage) forwards for the roofline objects')
+  ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
   args = ap.parse_args()
 
-  rank = int(os.environ.get('RANK', '0'))
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
-  torch.cuda.set_device(local_rank)
-  dist = None
-  if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world)
+  import ra_dist
+  if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus > 1:
+    raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+  torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+  rank, world, local_rank = ra_dist.init('nccl')  # 'nccl' is RCCL on ROCm
 
   import full_model
   B, T, S = args.batch, args.timespan, args.size
@@ -146,15 +138,12 @@ def main():
   seed_weights(model, 1234 + rank)
   eng = model.engine
   eng.use_graph = not args.no_graph
+  eng.nsub = args.nsub
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
   feed = {'x': x, 'phase_train': False}
 
-  def barrier():
-    torch.cuda.synchronize()
-    if dist is not None:
-      dist.barrier()
-    torch.cuda.synchronize()
+  barrier = ra_dist.barrier
 
   for _ in range(max(args.warmup, 1)):
     eng.forward(feed['x'])
@@ -163,11 +152,7 @@ def main():
   for _ in range(args.steps):
     eng.forward(feed['x'])
   barrier()
-  elapsed = time.perf_counter() - t0
-  if dist is not None:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+  elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
   value = world * B * T * args.steps / elapsed
 
   out = {
@@ -184,51 +169,77 @@ def main():
   }
 
   if rank == 0:
-    # ---- roofline objects: instrumented forwards (HIP events between stages, same stream) ----
-    eng.use_graph = False
-    acc = {}
-    for _ in range(max(args.profile_steps, 1)):
-      eng.timing = []
-      eng._mark('start')
-      eng.forward(feed['x'])
+    # ---- roofline objects: the launch groups exactly as the product issues them (one
+    # sub-batch of Bs images), each captured alone in a HIP graph and replayed between two HIP
+    # events on the launch stream, so host launch overhead does not pollute kernel time ----
+    import ra_ops as ops
+    d, Wt, sb = model.dims, eng.W, eng.subs[0]
+    Bs = sb['img'].shape[0]
+    Fh, Fw = d['Fh'], d['Fw']
+
+    def graph_time_us(fn, reps=30):
+      fn()
       torch.cuda.synchronize()
-      for k, (ms, n) in eng.stage_times_ms().items():
-        a = acc.setdefault(k, [0.0, 0])
-        a[0] += ms
-        a[1] += n
-    eng.timing = None
-    d = model.dims
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        fn()
+      for _ in range(3):
+        g.replay()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      torch.cuda.synchronize()
+      e0.record()
+      for _ in range(reps):
+        g.replay()
+      e1.record()
+      torch.cuda.synchronize()
+      return 1e3 * e0.elapsed_time(e1) / reps
+
+    def enc_layer(i):
+      wp, sc, sh, cout, pool = Wt['ccnn'][i]
+      src = sb['img'] if i == 0 else sb['ccnn'][i - 1]
+      ops.conv3x3(src, wp, sc[0], sh[0], cout, relu=True, pool=pool, out=sb['ccnn'][i])
+
     tot_f, per_f = encoder_flops_per_image(d)
     layers = []
-    enc_ms_per_ts = 0.0
     for i in range(d['ccnn_nlayers']):
-      ms, n = acc['ctrl_cnn_L%d' % i]
-      avg = ms / n
-      enc_ms_per_ts += avg
-      layers.append({'layer': i, 'avg_us': 1e3 * avg, 'gflop': per_f[i] * B / 1e9,
-                     'tflops': per_f[i] * B / (avg * 1e-3) / 1e12})
-    achieved = tot_f * B / (enc_ms_per_ts * 1e-3) / 1e12
+      us = graph_time_us(lambda: [enc_layer(i) for _ in range(4)]) / 4.0
+      layers.append({'layer': i, 'avg_us': us, 'gflop': per_f[i] * Bs / 1e9,
+                     'tflops': per_f[i] * Bs / (us * 1e-6) / 1e12})
+    enc_us = graph_time_us(lambda: [enc_layer(i) for i in range(d['ccnn_nlayers'])])
+    achieved = tot_f * Bs / (enc_us * 1e-6) / 1e12
     out['roofline'] = {
-        'kernel': 'ra::conv::conv3x3_mfma (controller CNN, %d launches per timestep)' % d['ccnn_nlayers'],
+        'kernel': 'ra::conv::conv3x3_mfma (controller CNN: %d launches per timestep per sub-batch '
+                  'of %d images)' % (d['ccnn_nlayers'], Bs),
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
         'peak_note': 'dense f32-input MFMA (v_mfma_f32_16x16x4_f32); the kernel computes in exact f32',
-        'flop_per_launch_group': tot_f * B, 'avg_us_per_launch_group': 1e3 * enc_ms_per_ts,
+        'flop_per_launch_group': tot_f * Bs, 'avg_us_per_launch_group': enc_us,
         'layers': layers}
-    attn_ms = sum(acc[k][0] / acc[k][1] for k in ('extract', 'paste') if k in acc)
-    attn_bytes = float(S * S * (d['acnn_channels'][0] + 3) * 4) * B
+
+    def attn_group():
+      ops.extract_patch(sb['img'], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], Fh, Fw,
+                        d['C0p'], True, sb['x_patch'][0])
+      ops.paste_canvas(sb['y_out_patch'][0], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], -5.0,
+                       d['disable_overwrite'], sb['img'], d['D'], sb['y_out'].data_ptr(),
+                       T * S * S, sb['u_ws'], S, S)
+
+    attn_us = graph_time_us(attn_group)
+    attn_bytes = float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs
     out['roofline_attn'] = {
-        'kernel': 'extract_patch + paste_u + paste (attention resample)', 'bound': 'hbm',
-        'achieved': attn_bytes / (attn_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-        'frac': attn_bytes / (attn_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 'traffic': None,
-        'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': 1e3 * attn_ms}
-    out['stage_us_per_timestep'] = {k: 1e3 * v[0] / v[1] for k, v in sorted(acc.items())}
+        'kernel': 'extract_patch + paste_u + paste (attention resample, one sub-batch)', 'bound': 'hbm',
+        'achieved': attn_bytes / (attn_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+        'frac': attn_bytes / (attn_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': None,
+        'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': attn_us}
+    out['controller_us'] = graph_time_us(lambda: ops.controller(
+        eng.desc, sb['ccnn'][-1], Wt['ctrl'], sb['h_last'][0], sb['ctrl_out'][0], sb['gmaps'][0],
+        sb['attn'][0]))
+    out['config']['sub_batches'] = len(eng.subs)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(opt, 1234)
     print(json.dumps(out))
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  if world > 1:
+    ra_dist.barrier()
+    torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

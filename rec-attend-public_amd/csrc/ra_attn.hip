@@ -42,9 +42,26 @@ __host__ __device__ inline size_t band_ints(int H, int W, int Fh, int Fw) {
   return 2 * (size_t)(Fh + Fw) + 2 * (size_t)(H + W);
 }
 
-__device__ void axis_filters(float ctr, float size, float lg_var, int L, int F, float *tab, int *lo,
-                             int *hi, int *jlo, int *jhi, int *s_lo, int *s_hi) {
-  const float var = expf(lg_var);
+constexpr int kFiltRows = 64;  // pixels of one axis per workgroup
+
+// One workgroup = kFiltRows pixels of one axis of one example: their dense filter rows, the
+// tap range covering each of them, and (chunk 0 only) the per-tap pixel band.
+__global__ __launch_bounds__(256) void attn_filters_kernel(const float *attn, int H, int W, int Fh,
+                                                            int Fw, float *fy, float *fx, int *band) {
+  extern __shared__ int s_band[];  // [F lo][F hi]
+  const int b = blockIdx.z, axis = blockIdx.y;
+  const int L = axis ? W : H, F = axis ? Fw : Fh;
+  const int l0 = blockIdx.x * kFiltRows;
+  if (l0 >= L) return;
+  const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
+  const float ctr = rec[0 + axis], size = rec[2 + axis], var = expf(rec[4 + axis]);
+  int *bd = band + (size_t)b * band_ints(H, W, Fh, Fw);
+  int *lo = axis ? bd + 2 * Fh : bd;
+  int *hi = lo + F;
+  int *jlo = bd + 2 * (Fh + Fw) + (axis ? 2 * H : 0);
+  int *jhi = jlo + L;
+  float *tab = axis ? fx + (size_t)b * W * Fw : fy + (size_t)b * H * Fh;
+  int *s_lo = s_band, *s_hi = s_band + F;
   const float R = sqrtf(2.0f * kBandLog * var);
   for (int j = threadIdx.x; j < F; j += blockDim.x) {
     const float mu = tap_mu(ctr, size, F, j);
@@ -56,18 +73,21 @@ __device__ void axis_filters(float ctr, float size, float lg_var, int L, int F, 
       c = (float)L;
     }
     const int ia = (int)a, ic = (int)c;
-    lo[j] = ia;
-    hi[j] = ic > ia ? ic : ia;
-    s_lo[j] = lo[j];
-    s_hi[j] = hi[j];
+    s_lo[j] = ia;
+    s_hi[j] = ic > ia ? ic : ia;
+    if (blockIdx.x == 0) {
+      lo[j] = s_lo[j];
+      hi[j] = s_hi[j];
+    }
   }
-  for (int e = threadIdx.x; e < L * F; e += blockDim.x) {
-    const int j = e % F, l = e / F;
-    tab[e] = gauss((float)l, tap_mu(ctr, size, F, j), var);
+  const int nl = (L - l0) < kFiltRows ? (L - l0) : kFiltRows;
+  for (int e = threadIdx.x; e < nl * F; e += blockDim.x) {
+    const int j = e % F, l = l0 + e / F;
+    tab[(size_t)l * F + j] = gauss((float)l, tap_mu(ctr, size, F, j), var);
   }
   __syncthreads();
   // taps covering pixel l: lo/hi are non-decreasing in j, so the set is one contiguous range
-  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+  for (int l = l0 + threadIdx.x; l < l0 + nl; l += blockDim.x) {
     int a = 0;
     while (a < F && s_hi[a] <= l) ++a;
     int c = a;
@@ -75,24 +95,10 @@ __device__ void axis_filters(float ctr, float size, float lg_var, int L, int F, 
     jlo[l] = a;
     jhi[l] = c;
   }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void attn_filters_kernel(const float *attn, int H, int W, int Fh,
-                                                            int Fw, float *fy, float *fx, int *band) {
-  extern __shared__ int s_band[];  // 2 * max(Fh, Fw)
-  const int b = blockIdx.x;
-  const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
-  int *bd = band + (size_t)b * band_ints(H, W, Fh, Fw);
-  const int Fm = Fh > Fw ? Fh : Fw;
-  axis_filters(rec[0], rec[2], rec[4], H, Fh, fy + (size_t)b * H * Fh, bd, bd + Fh,
-               bd + 2 * (Fh + Fw), bd + 2 * (Fh + Fw) + H, s_band, s_band + Fm);
-  axis_filters(rec[1], rec[3], rec[5], W, Fw, fx + (size_t)b * W * Fw, bd + 2 * Fh, bd + 2 * Fh + Fw,
-               bd + 2 * (Fh + Fw) + 2 * H, bd + 2 * (Fh + Fw) + 2 * H + W, s_band, s_band + Fm);
 }
 
 // ---- read: patch[b,j,i,c] = gamma * sum_l sum_w fy[l,j] img[l,w,c] fx[w,i] -------------------
-constexpr int kJB = 8;     // filter rows (j) per workgroup
+constexpr int kJB = 4;     // filter rows (j) per workgroup
 constexpr int kWC = 256;   // image columns per pass (= threads)
 
 __global__ __launch_bounds__(256) void extract_patch_kernel(const float *img, int Ci, int chan0,
@@ -124,13 +130,24 @@ __global__ __launch_bounds__(256) void extract_patch_kernel(const float *img, in
 #pragma unroll
     for (int jj = 0; jj < kJB; ++jj) T[jj] = f32x4{0, 0, 0, 0};
     if (w < w1) {
-      for (int l = l0; l < l1; ++l) {
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(imb + ((size_t)l * W + w) * Ci);
-        const float *wrow = fyb + (size_t)l * Fh + j0;
+      constexpr int U = 8;  // rows in flight per thread: the loop is latency-, not ALU-bound
+      for (int l = l0; l < l1; l += U) {
+        f32x4 xv[U];
 #pragma unroll
-        for (int jj = 0; jj < kJB; ++jj) {
-          const float wt = (jj < nj) ? wrow[jj] : 0.0f;
-          T[jj] += wt * xv;
+        for (int u = 0; u < U; ++u) {
+          const int ll = (l + u < l1) ? l + u : l1 - 1;
+          xv[u] = *reinterpret_cast<const f32x4 *>(imb + ((size_t)ll * W + w) * Ci);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (l + u < l1) {
+            const float *wrow = fyb + (size_t)(l + u) * Fh + j0;
+#pragma unroll
+            for (int jj = 0; jj < kJB; ++jj) {
+              const float wt = (jj < nj) ? wrow[jj] : 0.0f;
+              T[jj] += wt * xv[u];
+            }
+          }
         }
       }
     }
@@ -216,7 +233,36 @@ __global__ __launch_bounds__(128) void paste_kernel(const float *u, const float 
   float *yrow = y_out + (size_t)b * y_stride_b + (size_t)l * W;
   float *crow = (canvas_chan >= 0) ? img + ((size_t)b * H + l) * W * Ci + canvas_chan : nullptr;
   const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(yrow) & 15) == 0);
-  if (vec) {
+  if (vec && crow && Ci == 4) {
+    // 16-byte pixel records: read-modify-write the whole record, 4 pixels per thread
+    float *prow = img + ((size_t)b * H + l) * W * 4;
+    for (int w4 = threadIdx.x * 4; w4 < W; w4 += blockDim.x * 4) {
+      f32x4 px[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) px[k] = *reinterpret_cast<const f32x4 *>(prow + (size_t)(w4 + k) * 4);
+      f32x4 s = f32x4{0, 0, 0, 0};
+      for (int j = a; j < c; ++j)
+        s += fyl[j] * *reinterpret_cast<const f32x4 *>(ub + (size_t)j * W + w4);
+      f32x4 y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = sigmoidf(gy * s[k] + beta);
+        // select, not a runtime vector index (that would spill the record to scratch)
+        const float cv = canvas_chan == 0 ? px[k].x : canvas_chan == 1 ? px[k].y
+                       : canvas_chan == 2 ? px[k].z : px[k].w;
+        if (disable_overwrite) v *= (1.0f - cv);
+        const float nv = fmaxf(cv, v);
+        px[k].x = canvas_chan == 0 ? nv : px[k].x;
+        px[k].y = canvas_chan == 1 ? nv : px[k].y;
+        px[k].z = canvas_chan == 2 ? nv : px[k].z;
+        px[k].w = canvas_chan == 3 ? nv : px[k].w;
+        y[k] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(prow + (size_t)(w4 + k) * 4) = px[k];
+      *reinterpret_cast<f32x4 *>(yrow + w4) = y;
+    }
+  } else if (vec) {
     for (int w4 = threadIdx.x * 4; w4 < W; w4 += blockDim.x * 4) {
       f32x4 s = f32x4{0, 0, 0, 0};
       for (int j = a; j < c; ++j)
@@ -396,9 +442,9 @@ extern "C" int ra_attn_filters_f32(const float *attn_rec, int B, int H, int W, i
                                    float *fy, float *fx, int *band, void *stream) {
   if (!attn_rec || !fy || !fx || !band || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0)
     return fail(RA_E_INVALID, "ra_attn_filters_f32: bad argument");
-  const int Fm = Fh > Fw ? Fh : Fw;
-  hipLaunchKernelGGL(attn::attn_filters_kernel, dim3(B), dim3(256), 2 * Fm * sizeof(int),
-                     as_stream(stream), attn_rec, H, W, Fh, Fw, fy, fx, band);
+  const int Fm = Fh > Fw ? Fh : Fw, Lm = H > W ? H : W;
+  hipLaunchKernelGGL(attn::attn_filters_kernel, dim3(ceil_div(Lm, attn::kFiltRows), 2, B), dim3(256),
+                     2 * Fm * sizeof(int), as_stream(stream), attn_rec, H, W, Fh, Fw, fy, fx, band);
   return launch_status("ra_attn_filters_f32");
 }
 

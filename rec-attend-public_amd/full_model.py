@@ -167,12 +167,19 @@ class Model(dict):
       res = [r.detach().cpu().numpy() for r in res]
     return res[0] if single else res
 
-  def _fetch(self, name, b):
+  def _fetch(self, name, eng):
     d = self.dims
-    a = b['attn']  # [T,B,16]
     tb = lambda t: t.transpose(0, 1).contiguous()
     if name in ('y_out', 's_out', 'attn_box'):
-      return b[name].clone()
+      return eng.fetch(name).clone()
+    b = {k: eng.fetch(k) for k in ('attn',)}
+    if name in ('x_patch', 'y_out_patch', 'gmaps', 'ctrl_out', 'img'):
+      b[name] = eng.fetch(name)
+    if name == 'ctrl_rnn_glimpse_map':
+      b['gmaps'] = eng.fetch('gmaps')
+    if name == 'canvas':
+      b['img'] = eng.fetch('img')
+    a = b['attn']  # [T,B,16]
     if name == 'x_patch':
       xp = tb(b['x_patch'])
       sel = self.engine.attn_sel

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Entry point with the flag surface of the reference's full_model_eval.py (:180-222).
+
+Restores results/<model_id>/{model_opt.yaml, weights.npz}, forces `use_knob=False`
+(full_model_eval.py:172-174), feeds {x, phase_train=False[, d_in, y_in]} and fetches
+['y_out', 's_out'] (full_model_eval.py:35; runner.py:91-105) batch by batch on the MI355X
+kernels, sharding the images over the ranks when launched with torch.distributed.run.  Inputs
+come from --input (an .npz with x [N,H,W,3] and optionally d_in / y_in) or are synthetic; the
+reference's HDF5 datasets, post-processing and analyzers are out of scope — the
+raw outputs are written to <output>/output_<split>/pred_rank<r>.npz."""
+import argparse
+import os
+import time
+
+import numpy as np
+import yaml
+
+import cmd_args_parser as cap
+import full_model
+import ra_dist
+
+
+def build_parser():
+  p = argparse.ArgumentParser(description='Evaluate output')
+  for table in (cap.EVAL_FLAGS, cap.DATA_FLAGS):
+    cap.add_flags(p, table)
+  p.add_argument('--input', default=None, help='.npz with x [N,H,W,3] (+ d_in, y_in)')
+  p.add_argument('--num_synthetic', type=int, default=8)
+  return p
+
+
+def main(argv=None):
+  import torch
+  args = build_parser().parse_args(argv)
+  if args.model_id is None:
+    raise Exception('You must provide model ID')  # cmd_args_parser.py:154-155
+  restore = os.path.join(args.results, args.model_id)
+  with open(os.path.join(restore, 'model_opt.yaml')) as f:
+    model_opt = yaml.safe_load(f)
+  model_opt['use_knob'] = False
+  rank, world, local_rank = ra_dist.init()
+  if torch.cuda.is_available():
+    torch.cuda.set_device(local_rank)
+  model = full_model.get_model(model_opt).load_weights(dict(np.load(os.path.join(restore, 'weights.npz'))))
+  H, W = model_opt['inp_height'], model_opt['inp_width']
+  if args.input:
+    data = dict(np.load(args.input))
+  else:
+    rng = np.random.RandomState(1234)
+    data = {'x': rng.rand(args.num_synthetic, H, W, 3).astype(np.float32)}
+    if model.dims['add_d_out']:
+      n = args.num_synthetic
+      data['d_in'] = np.eye(8, dtype=np.float32)[rng.randint(0, 8, (n, H, W))]
+      lg = rng.randn(n, H, W, model.dims['nsc']).astype(np.float32)
+      data['y_in'] = np.exp(lg) / np.exp(lg).sum(-1, keepdims=True)
+  lo, hi = ra_dist.shard_range(rank, world, data['x'].shape[0])
+  ys, ss, t0 = [], [], time.time()
+  for b0 in range(lo, hi, args.batch_size):
+    b1 = min(hi, b0 + args.batch_size)
+    feed = {k: v[b0:b1] for k, v in data.items() if k in ('x', 'd_in', 'y_in')}
+    feed['phase_train'] = False
+    y, s = model.run(['y_out', 's_out'], feed, as_numpy=True)
+    ys.append(y)
+    ss.append(s)
+  out_dir = os.path.join(args.output or restore, 'output_' + args.split.split(',')[0])
+  os.makedirs(out_dir, exist_ok=True)
+  path = os.path.join(out_dir, 'pred_rank%d.npz' % rank)
+  np.savez_compressed(path, y_out=np.concatenate(ys), s_out=np.concatenate(ss), first_index=lo)
+  print('rank %d: images [%d, %d) -> %s (%.2f s)' % (rank, lo, hi, path, time.time() - t0))
+  ra_dist.barrier()
+
+
+if __name__ == '__main__':
+  main()

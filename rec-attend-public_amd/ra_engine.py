@@ -38,6 +38,7 @@ class DecodeEngine(object):
     self._stamp = None
     self._B = None
     self._graphs = {}
+    self.nsub = 0  # sub-batches decoded on parallel streams; 0 = choose from the batch size
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
 
@@ -153,56 +154,85 @@ class DecodeEngine(object):
 
   # ------------------------------------------------------------------ buffers
   def alloc(self, B, device):
-    if self._B == B:
+    """Buffers for a batch of B split into `nsub` independent sub-batches (each decoded on its
+    own HIP stream: the latency-bound controller / patch kernels of one sub-batch overlap the
+    other's conv launches).  Batch-leading tensors are shared and sliced; the rest is per
+    sub-batch."""
+    nsub = self.nsub if self.nsub else (2 if (B % 2 == 0 and B >= 4) else 1)
+    if B % nsub:
+      nsub = 1
+    if self._B == (B, nsub):
       return
     d, T = self.d, self.d['T']
     f = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
     H, W, Fh, Fw = d['H'], d['W'], d['Fh'], d['Fw']
-    b = {}
-    b['x'] = f(B, H, W, d['D'])
+    g = {}
+    g['x'] = f(B, H, W, d['D'])
     if d['add_d_out']:
-      b['d_in'] = f(B, H, W, 8)
+      g['d_in'] = f(B, H, W, 8)
     if d['add_y_out']:
-      b['y_in'] = f(B, H, W, d['nsc'])
-    b['img'] = f(B, H, W, d['C0p'])
-    hh, ww = H, W
-    b['ccnn'] = []
-    for i in range(d['ccnn_nlayers']):
-      hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
-      b['ccnn'].append(f(B, hh, ww, d['ccnn_channels'][i + 1]))
-    b['h_last'] = f(T, B, d['hid'])
-    b['ctrl_out'] = f(T, B, 9)
-    b['gmaps'] = f(T, B, d['iters'], d['G'])
-    b['attn'] = f(T, B, rn.RA_ATTN_STRIDE)
-    b['fy'] = f(B, H, Fh)
-    b['fx'] = f(B, W, Fw)
-    b['band'] = torch.zeros((B, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32, device=device)
-    b['s_out'] = f(B, T) if (self.box is False or d['nsc'] == 1) else f(B, T, d['nsc'])
-    b['attn_box'] = f(B, T, H, W)
+      g['y_in'] = f(B, H, W, d['nsc'])
+    g['s_out'] = f(B, T) if (self.box is False or d['nsc'] == 1) else f(B, T, d['nsc'])
+    g['attn_box'] = f(B, T, H, W)
     if self.box:
-      b['y_gt'] = f(B, T, H, W)
-      b['noise'] = f(T, B, H, W)
-      b['ysel'] = f(B, H, W)
+      g['y_gt'] = f(B, T, H, W)
+      g['noise'] = f(T, B, H, W)
     else:
-      b['x_patch'] = f(T, B, Fh, Fw, d['C0p'])
-      hh, ww = Fh, Fw
-      b['acnn'] = []
-      for i in range(d['acnn_nlayers']):
-        hh, ww = hh // d['acnn_pool'][i], ww // d['acnn_pool'][i]
-        b['acnn'].append(f(B, hh, ww, d['acnn_channels'][i + 1]))
-      b['adcnn'] = []
-      for i in range(d['adcnn_nlayers']):
-        hh, ww = hh * d['adcnn_unpool'][i], ww * d['adcnn_unpool'][i]
-        if i == d['adcnn_nlayers'] - 1:
-          b['y_out_patch'] = f(T, B, hh, ww, d['adcnn_channels'][i + 1])
-          b['adcnn'].append(None)
-        else:
-          b['adcnn'].append(f(B, hh, ww, d['adcnn_channels'][i + 1]))
-      b['y_out'] = f(B, T, H, W)
-      b['u_ws'] = f(B, Fh, W)
-    self.buf = b
-    self._B = B
+      g['y_out'] = f(B, T, H, W)
+    Bs = B // nsub
+    subs = []
+    for k in range(nsub):
+      b = {kk: v[k * Bs:(k + 1) * Bs] for kk, v in g.items() if kk != 'noise'}
+      b['img'] = f(Bs, H, W, d['C0p'])
+      hh, ww = H, W
+      b['ccnn'] = []
+      for i in range(d['ccnn_nlayers']):
+        hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
+        b['ccnn'].append(f(Bs, hh, ww, d['ccnn_channels'][i + 1]))
+      b['h_last'] = f(T, Bs, d['hid'])
+      b['ctrl_out'] = f(T, Bs, 9)
+      b['gmaps'] = f(T, Bs, d['iters'], d['G'])
+      b['attn'] = f(T, Bs, rn.RA_ATTN_STRIDE)
+      b['fy'] = f(Bs, H, Fh)
+      b['fx'] = f(Bs, W, Fw)
+      b['band'] = torch.zeros((Bs, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32,
+                              device=device)
+      if self.box:
+        b['noise'] = f(T, Bs, H, W)
+        b['ysel'] = f(Bs, H, W)
+      else:
+        b['x_patch'] = f(T, Bs, Fh, Fw, d['C0p'])
+        hh, ww = Fh, Fw
+        b['acnn'] = []
+        for i in range(d['acnn_nlayers']):
+          hh, ww = hh // d['acnn_pool'][i], ww // d['acnn_pool'][i]
+          b['acnn'].append(f(Bs, hh, ww, d['acnn_channels'][i + 1]))
+        b['adcnn'] = []
+        for i in range(d['adcnn_nlayers']):
+          hh, ww = hh * d['adcnn_unpool'][i], ww * d['adcnn_unpool'][i]
+          if i == d['adcnn_nlayers'] - 1:
+            b['y_out_patch'] = f(T, Bs, hh, ww, d['adcnn_channels'][i + 1])
+            b['adcnn'].append(None)
+          else:
+            b['adcnn'].append(f(Bs, hh, ww, d['adcnn_channels'][i + 1]))
+        b['u_ws'] = f(Bs, Fh, W)
+      subs.append(b)
+    self.glob = g
+    self.subs = subs
+    self.streams = [torch.cuda.Stream(device=device) for _ in range(nsub)] if nsub > 1 else []
+    self._B = (B, nsub)
     self._graphs = {}
+
+  def fetch(self, name):
+    """A result buffer for the whole batch: shared tensors directly, per-sub-batch [T,Bs,...]
+    buffers concatenated along their batch dimension."""
+    if name in self.glob:
+      return self.glob[name]
+    parts = [sb[name] for sb in self.subs]
+    if len(parts) == 1:
+      return parts[0]
+    dim = 0 if name in ('img', 'fy', 'fx') else 1
+    return torch.cat(parts, dim=dim)
 
   # ------------------------------------------------------------------ launch sequence
   def _mark(self, name):
@@ -221,7 +251,21 @@ class DecodeEngine(object):
     return out
 
   def _launch_all(self, want_box):
-    d, b, Wt, T = self.d, self.buf, self.W, self.d['T']
+    """All sub-batches; with more than one, each on its own stream forked from / joined to the
+    current stream (inside a graph capture this becomes parallel branches)."""
+    if len(self.subs) == 1:
+      self._launch_sub(self.subs[0], want_box)
+      return
+    main = torch.cuda.current_stream()
+    for sb, st in zip(self.subs, self.streams):
+      st.wait_stream(main)
+      with torch.cuda.stream(st):
+        self._launch_sub(sb, want_box)
+    for st in self.streams:
+      main.wait_stream(st)
+
+  def _launch_sub(self, b, want_box):
+    d, Wt, T = self.d, self.W, self.d['T']
     H, W, Fh, Fw = d['H'], d['W'], d['Fh'], d['Fw']
     ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), d['C0p'], b['img'])
     self._mark('pack')
@@ -241,7 +285,7 @@ class DecodeEngine(object):
                      b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
         self._mark('attn_box')
       if self.box:
-        self._box_step(tt)
+        self._box_step(b, tt)
         continue
       xp = b['x_patch'][tt]
       ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
@@ -269,13 +313,13 @@ class DecodeEngine(object):
                        b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
       self._mark('paste')
 
-  def _box_step(self, tt):
+  def _box_step(self, b, tt):
     """box_model.py:484-513: greedy GT match (never accumulated), canvas from noisy GT, score.
     The [B,T] IoU / arg-max bookkeeping on the GT side uses torch reductions (plumbing for the
     teacher-forcing input; not on the eval path)."""
-    d, b, T = self.d, self.buf, self.d['T']
+    d, T = self.d, self.d['T']
     box = b['attn_box'][:, tt:tt + 1]
-    gt = self.box_gt
+    gt = b['box_gt']
     inter = (box * gt).sum(dim=(2, 3))
     union = (box + gt - box * gt + 1e-5).sum(dim=(2, 3))
     iou = inter / union
@@ -301,7 +345,7 @@ class DecodeEngine(object):
     B = x.shape[0]
     self.prepare(device)
     self.alloc(B, device)
-    b = self.buf
+    b = self.glob
     b['x'].copy_(x)
     if 'd_in' in b:
       b['d_in'].copy_(as_t(d_in))
@@ -313,11 +357,14 @@ class DecodeEngine(object):
         b['noise'].uniform_(0.0, 0.3)  # box_model.py:500-502
       else:
         b['noise'].copy_(as_t(noise).reshape(b['noise'].shape))
-      self.box_gt = _gt_box_mask(b['y_gt'], self.d['attn_box_padding_ratio'])
+      Bs = B // len(self.subs)
+      for k, sb in enumerate(self.subs):
+        sb['noise'].copy_(b['noise'][:, k * Bs:(k + 1) * Bs])
+        sb['box_gt'] = _gt_box_mask(sb['y_gt'], self.d['attn_box_padding_ratio'])
     graphable = self.use_graph and self.timing is None and not self.box
     if not graphable:
       self._launch_all(want_box)
-      return b
+      return self
     key = bool(want_box)
     g = self._graphs.get(key)
     if g is None:
@@ -328,7 +375,7 @@ class DecodeEngine(object):
         self._launch_all(want_box)
       self._graphs[key] = g
     g.replay()
-    return b
+    return self
 
 
 def _gt_box_mask(y_gt, padding_ratio, min_padding=10.0):

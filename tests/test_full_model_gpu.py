@@ -150,3 +150,48 @@ def test_operator_surface_closures(cuda):
   fr = ora.get_gaussian_filter(np.array([20.0, 30.0]), np.array([25.0, 40.0]),
                                np.array([0.1, 0.5]), 64, 48)
   assert np.abs(f.cpu().numpy() - fr).max() < 1e-5
+
+
+@pytest.mark.parametrize('name', ['full_model_cvppp_128', 'full_model_kitti_64x96'])
+def test_golden_fixture(cuda, name):
+  """The committed vectors (tests/golden/*.npz: seeded inputs -> oracle outputs)."""
+  import os
+  import full_model
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'),
+               allow_pickle=True)
+  opt = fx['opt'].item()
+  P = ora.random_params(opt, int(fx['seed']))
+  feed = {'x': fx['x'], 'phase_train': False}
+  for k in ('d_in', 'y_in'):
+    if k in fx.files:
+      feed[k] = fx[k]
+  m = full_model.get_model(opt).load_weights(P)
+  names = ['y_out', 's_out', 'attn_ctr', 'attn_size', 'x_patch', 'ctrl_rnn_glimpse_map']
+  out = dict(zip(names, m.run(names, feed, as_numpy=True)))
+  assert np.abs(out['y_out'] - fx['y_out']).max() < MASK_TOL
+  assert np.abs(out['s_out'] - fx['s_out']).max() < MASK_TOL
+  assert np.abs(out['x_patch'] - fx['x_patch']).max() < 1e-3
+  assert np.abs(out['attn_ctr'] - fx['attn_ctr']).max() < 2e-3
+  assert np.abs(out['ctrl_rnn_glimpse_map'] - fx['ctrl_rnn_glimpse_map']).max() < 1e-4
+
+
+def test_full_size_properties(cuda):
+  """BASELINE.json configs[1] shape (512x512, T=16, B=8): size-independent properties — canvas
+  monotone = running max of the masks, masks in (0,1), glimpse maps sum to one, batch rows
+  independent of their neighbours (same image alone == same image inside a batch)."""
+  import bench
+  import full_model
+  opt = bench.make_opt('cvppp', 512, 512, 16)
+  m = full_model.get_model(opt)
+  bench.seed_weights(m, 3)
+  g = torch.Generator().manual_seed(0)
+  x = torch.rand((8, 512, 512, 3), generator=g)
+  y, s, gm, cv = m.run(['y_out', 's_out', 'ctrl_rnn_glimpse_map', 'canvas'],
+                       {'x': x, 'phase_train': False})
+  assert y.shape == (8, 16, 512, 512) and s.shape == (8, 16)
+  assert bool(((y > 0) & (y < 1)).all()) and bool(((s > 0) & (s < 1)).all())
+  assert float((gm.sum(dim=(3, 4)) - 1).abs().max()) < 1e-5
+  assert float((y.max(dim=1)[0] - cv[..., 0]).abs().max()) < 1e-6
+  m.engine.nsub = 1
+  y1 = m.run('y_out', {'x': x[2:3], 'phase_train': False})
+  assert float((y1 - y[2:3]).abs().max()) < 1e-5

@@ -1,0 +1,122 @@
+"""Host-side logic that needs no GPU: the model_opt -> shape bookkeeping, the weight-key schema,
+the kernel weight packing (checked by index arithmetic), error behaviour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import full_model
+import box_model
+import nnlib as nn
+import modellib
+import ra_ops as ops
+import ra_native as rn
+import ra_oracle as ora
+
+
+def test_dims_match_oracle_bookkeeping():
+  for arch, H, W, T, over in (('cvppp', 128, 128, 5, {}), ('kitti', 128, 448, 20, {}),
+                              ('cityscapes', 256, 512, 20, {}),
+                              ('cvppp', 512, 512, 16, {'fixed_var': True})):
+    opt = ora.make_opt(arch, H, W, T, **over)
+    d, o = full_model.derive_dims(opt), ora.derive(opt)
+    for k in ('G', 'gh', 'gw', 'core_dim', 'ccnn_channels', 'acnn_channels', 'adcnn_channels',
+              'ctrl_in', 'attn_in', 'fixed_var', 'dynamic_var', 'fixed_gamma', 'disable_overwrite'):
+      assert d[k] == o[k], (arch, k)
+    assert (d['skip_ch'] or [])[:d['adcnn_nlayers']] == (o['skip_ch'] or [])[:d['adcnn_nlayers']]
+  assert full_model.derive_dims(ora.make_opt('kitti', 128, 448, 20))['C0p'] == 16
+  assert full_model.derive_dims(ora.make_opt('cityscapes', 256, 512, 20))['C0p'] == 24
+
+
+def test_weight_key_schema_is_the_reference_one():
+  opt = ora.make_opt('cvppp', 64, 64, 3)
+  m = full_model.get_model(opt)
+  S = ora.param_shapes(opt)
+  assert set(m.weight_keys()) == set(S)
+  assert all(tuple(m[k].shape) == tuple(S[k]) for k in S)
+  # spot-check the literal key forms (nnlib.py:124,208,334,472,612-623)
+  for k in ('ctrl_cnn_w_0', 'ctrl_cnn_b_7', 'ctrl_cnn_0_2_beta', 'ctrl_cnn_7_0_ema_var',
+            'ctrl_lstm_w_xi', 'ctrl_lstm_b_o', 'glimpse_mlp_w_1', 'ctrl_mlp_b_0', 'attn_cnn_w_5',
+            'attn_cnn_5_2_gamma', 'attn_dcnn_w_6', 'attn_dcnn_6_1_ema_mean', 'score_mlp_w_0'):
+    assert k in m
+  assert tuple(m['attn_dcnn_w_0'].shape) == (3, 3, 32, 32)   # [f, f, out, in] (nnlib.py:321)
+  assert tuple(m['score_mlp_w_0'].shape) == (256 + 6 * 6 * 32, 1)
+  # reference initial values: BN gamma 1 / beta 0 / EMA 0, LSTM forget bias 1 (nnlib.py:89-91,567)
+  assert float(m['ctrl_cnn_3_1_gamma'].mean()) == 1 and float(m['ctrl_cnn_3_1_ema_var'].sum()) == 0
+  assert float(m['ctrl_lstm_b_f'].mean()) == 1 and float(m['ctrl_lstm_b_i'].abs().sum()) == 0
+  assert float(m['ctrl_cnn_w_0'].abs().max()) <= 0.02 + 1e-6  # truncated normal, 2 sigma
+  b = box_model.get_model(opt)
+  assert set(b.weight_keys()) == set(ora.param_shapes(opt, box_model=True))
+  # round trip through the weight archive form
+  m2 = full_model.get_model(opt).load_weights(m.state_dict_numpy())
+  assert all(torch.equal(m[k].cpu(), m2[k].cpu()) for k in S)
+
+
+def test_conv_weight_packing_layout():
+  rng = np.random.RandomState(0)
+  for Ci, Co in ((4, 8), (8, 16), (16, 32), (32, 64), (24, 16)):
+    w = rng.randn(3, 3, Ci, Co).astype(np.float32)
+    p = ops.pack_conv_weights(w)
+    cp = ops.cout_padded(Co)
+    CK = 16 if Ci % 16 == 0 else 8 if Ci % 8 == 0 else 4
+    p = p.reshape(Ci // CK, 9, CK // 4, 4, cp)
+    for c in range(Ci):
+      got = p[c // CK, :, (c % CK) // 4, c % 4, :Co]
+      assert (got == w[:, :, c, :].reshape(9, Co)).all()
+    assert (p[..., Co:] == 0).all()
+  # transposed-conv filter [3,3,Cout,Cin]: taps flipped, in/out swapped, padded channels zero
+  wt = rng.randn(3, 3, 8, 20).astype(np.float32)
+  cmap = list(range(16)) + [16, 17, 18, 19] + [-1] * 4
+  p = ops.pack_conv_weights(wt, cin_kernel=24, chan_map=cmap, transposed=True).reshape(3, 9, 2, 4, 16)
+  for c in range(24):
+    got = p[c // 8, :, (c % 8) // 4, c % 4, :8]
+    exp = wt[::-1, ::-1, :, cmap[c]].reshape(9, 8) if cmap[c] >= 0 else np.zeros((9, 8))
+    assert (got == exp).all()
+
+
+def test_bn_fold_and_controller_packing():
+  rng = np.random.RandomState(1)
+  b, beta, gamma, mean, var = [rng.randn(8).astype(np.float32) for _ in range(5)]
+  var = np.abs(var) + 0.1
+  sc, sh = ops.fold_bn(b, 8, (beta, gamma, mean, var))
+  x = rng.randn(5, 8).astype(np.float32)
+  ref = ora.batch_norm_eval(x.astype(np.float64) + b, beta, gamma, mean, var)
+  assert np.abs(x * sc[:8] + sh[:8] - ref).max() < 1e-5 and (sc[8:] == 1).all() and (sh[8:] == 0).all()
+  sc, sh = ops.fold_bn(b, 8, None)
+  assert (sc == 1).all() and (sh[:8] == b).all()
+  desc = ops.make_ctrl_desc(49, 8, 16, 5, 2, 1, 16, 224, 224, 48, 48, 0, 0, 0, 1)
+  lstm = {k + g: rng.randn(*s).astype(np.float32) for g in 'ifuo'
+          for k, s in (('w_x', (8, 16)), ('w_h', (16, 16)))}
+  lstm.update({'b_' + g: rng.randn(16).astype(np.float32) for g in 'ifuo'})
+  gm = [(rng.randn(16, 16).astype(np.float32), rng.randn(16).astype(np.float32)),
+        (rng.randn(16, 49).astype(np.float32), rng.randn(49).astype(np.float32))]
+  cm = [(rng.randn(16, 9).astype(np.float32), rng.randn(9).astype(np.float32))]
+  p = ops.pack_ctrl_weights(desc, lstm, gm, cm)
+  W = p[:24 * 64].reshape(24, 64)
+  for gi, g in enumerate('ifou'):  # packed gate order i, f, o, u
+    assert (W[:8, gi * 16:(gi + 1) * 16] == lstm['w_x' + g]).all()
+    assert (W[8:, gi * 16:(gi + 1) * 16] == lstm['w_h' + g]).all()
+  off = 24 * 64 + 64 + 16 * 16 + 16
+  g2 = p[off:off + 16 * 52].reshape(16, 52)  # G = 49 padded to 52 columns
+  assert (g2[:, :49] == gm[1][0]).all() and (g2[:, 49:] == 0).all()
+
+
+def test_unbuilt_parts_fail_loudly():
+  opt = ora.make_opt('cvppp', 64, 64, 2)
+  m = full_model.get_model(opt)
+  with pytest.raises(NotImplementedError):
+    m.run(['loss', 'train_step'], {'x': np.zeros((1, 64, 64, 3), np.float32), 'phase_train': True})
+  with pytest.raises(NotImplementedError):
+    m.run('y_out', {'x': np.zeros((1, 64, 64, 3), np.float32), 'phase_train': True})
+  with pytest.raises(KeyError):
+    m.run('nonsense', {'x': None})
+  with pytest.raises(NotImplementedError):
+    modellib.f_iou(None, None)
+  if not torch.cuda.is_available():
+    with pytest.raises(rn.RecAttendError):   # no silent CPU fallback
+      m.run('y_out', {'x': np.zeros((1, 64, 64, 3), np.float32), 'phase_train': False})
+    with pytest.raises(rn.RecAttendError):
+      nn.max_pool(torch.zeros(1, 4, 4, 4), 2)
+  with pytest.raises(Exception):
+    full_model.derive_dims(ora.make_opt('cvppp', 66, 64, 2))

@@ -1,0 +1,132 @@
+"""Hungarian matching: the C oracle and the product (host + device entry points) against the
+reference's own known-answer tests (hungarian_tf_tests.py:9-90, fixture
+tests/golden/hungarian_kats.json), its termination set (:92-275), and each other (bit-exact)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ra_ops as ops
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, 'golden', 'hungarian_kats.json')))['cases']
+_ora = ctypes.CDLL(os.path.join(os.path.dirname(HERE), 'oracle', 'libhungarian_oracle.so'))
+_ora.ora_hungarian_f32.restype = ctypes.c_int
+
+
+def oracle(W):
+  W = np.ascontiguousarray(W, np.float32)
+  two_d = W.ndim == 2
+  W3 = W[None] if two_d else W
+  B, N, M = W3.shape
+  m, cx, cy = np.zeros_like(W3), np.zeros((B, N), np.float32), np.zeros((B, M), np.float32)
+  p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+  rc = _ora.ora_hungarian_f32(p(W3), B, N, M, p(m), p(cx), p(cy))
+  return rc, m, cx, cy
+
+
+def _weights(case):
+  W = np.array(case['W'], dtype=np.float64)
+  if case['round_1e6']:
+    W = np.round(W * 1e6) / 1e6  # hungarian_tf_tests.py:200-201
+  return W.astype(np.float32)  # the op's input is float32 (hungarian.cc:27)
+
+
+@pytest.mark.parametrize('case', KATS, ids=[c['name'] for c in KATS])
+def test_reference_vectors_oracle_and_host(case):
+  W = _weights(case)
+  rc, m, cx, cy = oracle(W)
+  M2, cx2, cy2 = ops.hungarian(W)
+  assert rc == 0 and ops.hungarian.last_status == 0  # terminates without hitting a cap
+  if W.ndim == 2:
+    m, cx, cy = m[0], cx[0], cy[0]
+  # product == oracle, bit for bit
+  assert (M2 == m).all() and (cx2[..., 0] == cx).all() and (cy2[..., 0, :] == cy).all()
+  # and both == the reference's asserted answers where it asserts them
+  if 'matching' in case:
+    assert (m == np.array(case['matching'], np.float32)).all()
+  if 'cover_x' in case:
+    assert (cx == np.array(case['cover_x'], np.float32)).all()
+    assert (cy == np.array(case['cover_y'], np.float32)).all()
+  # a matching: at most one 1 per row/column, entries exactly 0/1
+  assert set(np.unique(m)) <= {0.0, 1.0}
+  assert (m.sum(-1) <= 1).all() and (m.sum(-2) <= 1).all()
+
+
+def _random_cases(seed, n):
+  rng = np.random.RandomState(seed)
+  for it in range(n):
+    nx = rng.randint(1, 24)
+    ny = nx if rng.rand() < 0.6 else rng.randint(1, 24)
+    W = rng.rand(rng.randint(1, 4), nx, ny).astype(np.float32)
+    kind = it % 5
+    if kind == 1:   # the f_segm_match conditioning (modellib.py:395-406)
+      W = (np.floor(W * 1e6 + 0.5) / 1e6 + 1e-5).astype(np.float32)
+    elif kind == 2:  # masked-out GT columns
+      W[:, :, ny // 2:] = 1e-5
+    elif kind == 3:  # ties
+      W = np.round(W * 4) / 4
+    elif kind == 4:  # zeros
+      W[W < 0.5] = 0
+    yield W
+
+
+def test_host_equals_oracle_random():
+  for W in _random_cases(0, 250):
+    a = oracle(W)
+    M, cx, cy = ops.hungarian(W)
+    assert a[0] == ops.hungarian.last_status
+    assert (a[1] == M).all() and (a[2] == cx[..., 0]).all() and (a[3] == cy[:, 0, :]).all()
+
+
+def test_optimality_small():
+  """The matching maximises total weight (brute force over permutations, n <= 6)."""
+  import itertools
+  rng = np.random.RandomState(3)
+  for _ in range(40):
+    n = rng.randint(2, 7)
+    W = (rng.randint(1, 50, (n, n))).astype(np.float32)
+    M, _, _ = ops.hungarian(W)
+    best = max(sum(W[i, p[i]] for i in range(n)) for p in itertools.permutations(range(n)))
+    assert (M * W).sum() == best
+
+
+def test_shape_and_rank_errors():
+  with pytest.raises(Exception):
+    ops.hungarian(np.zeros((2, 2, 2, 2), np.float32))
+  M, cx, cy = ops.hungarian(np.ones((3, 4), np.float32))
+  assert M.shape == (3, 4) and cx.shape == (3, 1) and cy.shape == (1, 4)
+  M, cx, cy = ops.hungarian(np.ones((2, 3, 4), np.float32))
+  assert M.shape == (2, 3, 4) and cx.shape == (2, 3, 1) and cy.shape == (2, 1, 4)
+
+
+def test_f_segm_match_conditioning():
+  """modellib.f_segm_match (modellib.py:382-415) on CPU tensors: masks + quantisation."""
+  import torch
+  import modellib
+  rng = np.random.RandomState(1)
+  iou = torch.from_numpy(rng.rand(2, 5, 5).astype(np.float32))
+  s_gt = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]], dtype=torch.float32)
+  m = modellib.f_segm_match(iou, s_gt).numpy()
+  assert (m[0, 3:, :] == 0).all() and (m[0, :, 3:] == 0).all()
+  assert m[0].sum() == 3 and m[1].sum() == 5
+
+
+@pytest.mark.gpu
+def test_device_equals_host(cuda):
+  import torch
+  for W in list(_random_cases(5, 60)) + [_weights(c) for c in KATS]:
+    Mh, cxh, cyh = ops.hungarian(W)
+    st_h = ops.hungarian.last_status
+    Md, cxd, cyd = ops.hungarian(torch.from_numpy(W).to(cuda))
+    torch.cuda.synchronize()
+    assert (Md.cpu().numpy() == Mh).all()
+    assert (cxd.cpu().numpy() == cxh).all() and (cyd.cpu().numpy() == cyh).all()
+    assert int(ops.hungarian.last_status.max()) == st_h
+  # cfg5-sized problem: T = 32
+  W = np.random.RandomState(9).rand(4, 32, 32).astype(np.float32)
+  Mh, _, _ = ops.hungarian(W)
+  Md, _, _ = ops.hungarian(torch.from_numpy(W).to(cuda))
+  assert (Md.cpu().numpy() == Mh).all()

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Per-kernel timing on the GPU box (HIP events on the launch stream, many back-to-back
+launches).  Usage: python tools/microbench.py [--batch 8] [--size 512] [names...]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'rec-attend-public_amd'))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import bench
+import full_model
+import ra_ops as ops
+
+
+def timeit(fn, reps=50, warm=5):
+  for _ in range(warm):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return 1e3 * e0.elapsed_time(e1) / reps
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--batch', type=int, default=8)
+  ap.add_argument('--size', type=int, default=512)
+  ap.add_argument('names', nargs='*')
+  args = ap.parse_args()
+  B, S, T = args.batch, args.size, 2
+  opt = bench.make_opt('cvppp', S, S, T)
+  m = full_model.get_model(opt, is_training=False)
+  bench.seed_weights(m, 1)
+  eng = m.engine
+  eng.use_graph = False
+  eng.nsub = 1
+  x = torch.rand((B, S, S, 3)).cuda()
+  eng.forward(x)
+  torch.cuda.synchronize()
+  d, b, Wt = eng.d, eng.subs[0], eng.W
+  H = W = S
+  res = {}
+
+  def want(n):
+    return not args.names or any(n.startswith(a) for a in args.names)
+
+  src = b['img']
+  tot_f, per_f = bench.encoder_flops_per_image(d)
+  for i, (wp, sc, sh, cout, pool) in enumerate(Wt['ccnn']):
+    if want('conv'):
+      s_ = src
+      us = timeit(lambda: ops.conv3x3(s_, wp, sc[0], sh[0], cout, relu=True, pool=pool, out=b['ccnn'][i]))
+      res['conv_L%d' % i] = (us, per_f[i] * B / us / 1e6)
+    src = b['ccnn'][i]
+  if want('controller'):
+    res['controller'] = (timeit(lambda: ops.controller(eng.desc, src, Wt['ctrl'], b['h_last'][0],
+                                                       b['ctrl_out'][0], b['gmaps'][0], b['attn'][0])), 0)
+  if want('filters'):
+    res['filters'] = (timeit(lambda: ops.attn_filters(b['attn'][0], H, W, 48, 48, b['fy'], b['fx'], b['band'])), 0)
+  if want('extract'):
+    us = timeit(lambda: ops.extract_patch(b['img'], 0, b['attn'][0], b['fy'], b['fx'], b['band'], 48, 48,
+                                          d['C0p'], True, b['x_patch'][0]))
+    res['extract'] = (us, 0)
+  if want('paste'):
+    pt = b['y_out_patch'][0]
+    us = timeit(lambda: ops.paste_canvas(pt, 0, b['attn'][0], b['fy'], b['fx'], b['band'], -5.0, False,
+                                         b['img'], d['D'], b['y_out'].data_ptr(), T * H * W, b['u_ws'], H, W))
+    res['paste'] = (us, (S * S * 12.0 * B) / us / 1e3)
+  if want('acnn'):
+    def chain():
+      s2 = b['x_patch'][0]
+      for i, (wp, sc, sh, cout, pool) in enumerate(Wt['acnn']):
+        ops.conv3x3(s2, wp, sc[0], sh[0], cout, relu=True, pool=pool, out=b['acnn'][i])
+        s2 = b['acnn'][i]
+      for i, (wp, sc, sh, cout, unpool, sidx) in enumerate(Wt['adcnn']):
+        out = b['y_out_patch'][0] if b['adcnn'][i] is None else b['adcnn'][i]
+        ops.conv3x3(s2, wp, sc[0], sh[0], cout, relu=True, pool=1, upsample=(unpool == 2), out=out)
+        s2 = out
+    res['acnn+adcnn(13 launches)'] = (timeit(chain), 0)
+  if want('score'):
+    core = b['acnn'][-1]
+    res['score'] = (timeit(lambda: ops.dense(b['h_last'][0], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
+                                             b['s_out'].data_ptr(), T, x1=core.view(B, -1))), 0)
+  for k, (us, rate) in res.items():
+    print('%-28s %9.2f us   %s' % (k, us, ('%.1f TF/s|GB/s' % rate) if rate else ''))
+
+
+if __name__ == '__main__':
+  main()
