@@ -194,22 +194,24 @@ def main():
       torch.cuda.synchronize()
       return 1e3 * e0.elapsed_time(e1) / reps
 
-    def enc_layer(i):
-      wp, sc, sh, cout, pool = Wt['ccnn'][i]
-      src = sb['img'] if i == 0 else sb['ccnn'][i - 1]
-      ops.conv3x3(src, wp, sc[0], sh[0], cout, relu=True, pool=pool, out=sb['ccnn'][i])
+    def enc_step(step):
+      first = step[1]
+      src = sb['img'] if first == 0 else sb['ccnn'][first - 1]
+      eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], 0, 'ctrl_cnn')
 
     tot_f, per_f = encoder_flops_per_image(d)
     layers = []
-    for i in range(d['ccnn_nlayers']):
-      us = graph_time_us(lambda: [enc_layer(i) for _ in range(4)]) / 4.0
-      layers.append({'layer': i, 'avg_us': us, 'gflop': per_f[i] * Bs / 1e9,
-                     'tflops': per_f[i] * Bs / (us * 1e-6) / 1e12})
-    enc_us = graph_time_us(lambda: [enc_layer(i) for i in range(d['ccnn_nlayers'])])
+    for step in eng.plan['ccnn']:
+      us = graph_time_us(lambda: [enc_step(step) for _ in range(4)]) / 4.0
+      fl = sum(per_f[i] for i in step[1:])
+      layers.append({'layers': list(step[1:]), 'fused': step[0] == 'pair', 'avg_us': us,
+                     'gflop': fl * Bs / 1e9, 'tflops': fl * Bs / (us * 1e-6) / 1e12})
+    enc_us = graph_time_us(lambda: [enc_step(st_) for st_ in eng.plan['ccnn']])
     achieved = tot_f * Bs / (enc_us * 1e-6) / 1e12
     out['roofline'] = {
-        'kernel': 'ra::conv::conv3x3_mfma (controller CNN: %d launches per timestep per sub-batch '
-                  'of %d images)' % (d['ccnn_nlayers'], Bs),
+        'kernel': 'ra::cpair::conv_pair_mfma + ra::conv::conv3x3_mfma (controller CNN: %d layers in %d '
+                  'launches per timestep per sub-batch of %d images)' % (d['ccnn_nlayers'],
+                                                                       len(eng.plan['ccnn']), Bs),
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
         'peak_note': 'dense f32-input MFMA (v_mfma_f32_16x16x4_f32); the kernel computes in exact f32',
@@ -230,9 +232,15 @@ def main():
         'achieved': attn_bytes / (attn_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
         'frac': attn_bytes / (attn_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': None,
         'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': attn_us}
-    out['controller_us'] = graph_time_us(lambda: ops.controller(
-        eng.desc, sb['ccnn'][-1], Wt['ctrl'], sb['h_last'][0], sb['ctrl_out'][0], sb['gmaps'][0],
-        sb['attn'][0]))
+    if 'ctrl_ws' in sb:
+      out['controller_us'] = graph_time_us(lambda: ops.controller_split(
+          eng.desc, sb['ccnn'][-1], Wt['ctrl_split'], sb['h_last'][0], sb['ctrl_out'][0],
+          sb['gmaps'][0], sb['attn'][0], sb['ctrl_ws'], sb['ctrl_status']))
+      out['controller_status'] = int(sb['ctrl_status'].item())
+    else:
+      out['controller_us'] = graph_time_us(lambda: ops.controller(
+          eng.desc, sb['ccnn'][-1], Wt['ctrl'], sb['h_last'][0], sb['ctrl_out'][0], sb['gmaps'][0],
+          sb['attn'][0]))
     out['config']['sub_batches'] = len(eng.subs)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(opt, 1234)

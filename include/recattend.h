@@ -99,6 +99,17 @@ int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, 
                    int upsample, const float *wpacked, const float *scale, const float *shift,
                    int Cout, int relu, int pool, float *y, void *stream);
 
+/* Two consecutive layers fused in one launch (the intermediate activation stays in LDS):
+ *   A: conv3x3 + scale/shift [+ReLU], no pool, optional zero-stuffed (stride-2 transposed) input
+ *   B: conv3x3 + scale/shift [+ReLU] + max-pool poolB
+ * src [B,Hs,Ws,Cin] single source, Cin in {4,8,16,32}; CoutA in {8,16,32}; CoutB <= 32.
+ * wpA / wpB from ra_conv_pack_weights with Cin resp. CoutA input channels. */
+int ra_conv_pair_supported(int Cin, int CoutA, int CoutB);
+int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsampleA,
+                     const float *wpA, const float *scaleA, const float *shiftA, int CoutA, int reluA,
+                     const float *wpB, const float *scaleB, const float *shiftB, int CoutB, int reluB,
+                     int poolB, float *y, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * K2  controller: glimpse read-out + LSTM + glimpse MLP (x iters) + controller MLP +
  * attention-parameter decode.  Replaces full_model.py:668-722 (= box_model.py:416-468):
@@ -143,6 +154,21 @@ int ra_controller_f32(const ra_ctrl_desc *d, const float *feat /*[B,G,Cf]*/, con
                       int B, float *h_last /*[B,hid]*/, float *ctrl_out /*[B,9]*/,
                       float *glimpse_maps /*[B,iters,G] nullable*/,
                       float *attn /*[B,RA_ATTN_STRIDE]*/, void *stream);
+
+/* Split form of the same controller: 16 workgroups per example, each keeping its slice of
+ * the LSTM / glimpse-MLP weights in LDS for the whole launch and exchanging only the small
+ * activation vectors through 8-byte {tag, value} granules in `ws` (device, must be zero-filled
+ * ONCE when allocated; generation-tagged, so graph replays need no memset; one workspace per
+ * concurrently running launch).  Same results up to float32 summation order.  B <= 14.
+ * status_dev (nullable): set to 1 if a peer workgroup timed out. */
+int ra_ctrl_split_supported(const ra_ctrl_desc *d);
+size_t ra_ctrl_split_packed_floats(const ra_ctrl_desc *d);
+size_t ra_ctrl_split_workspace_bytes(const ra_ctrl_desc *d, int B);
+int ra_ctrl_split_pack_weights(const ra_ctrl_desc *d, const float *const *lstm_w,
+                               const float *const *gmlp_w, const float *const *cmlp_w, float *out);
+int ra_controller_split_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
+                            float *h_last, float *ctrl_out, float *glimpse_maps, float *attn,
+                            void *ws, size_t ws_bytes, int *status_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * K3/K5  Gaussian attention.  Replaces modellib.get_gaussian_filter (modellib.py:581-612),

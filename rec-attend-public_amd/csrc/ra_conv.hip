@@ -16,12 +16,26 @@
 // Workgroup = 4 waves.  WN waves split the cout groups, 4/WN waves split pixel rows.  Each wave
 // owns PM = GX*GY pixel groups (2 rows x 8 cols each) x NC cout groups of 16.
 // LDS holds one Cin chunk (CK channels) of the input tile + halo as [CK/4][rows][cols][4].
+#include <cstdlib>
+
 #include "ra_common.h"
 
 namespace ra {
 namespace conv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+inline int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
 
 struct Args {
   const float *src0;
@@ -37,7 +51,19 @@ struct Args {
   int Cout, CoutP;
   int relu, pool;
   int Ho, Wo;
+  int ablate;  // tuning aid (RA_CONV_ABLATE): 1 skip epilogue, 2 skip staging, 4 skip MFMA loop
+  int bytes0, bytes1, bytes_y;  // tensor sizes for the buffer descriptors (each < 2 GiB)
 };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kOOB = 0x7fffffff;  // a buffer offset past every tensor: loads return 0, stores drop
+template <int CTRL>
+__device__ inline float quad_swap(float v) {  // DPP quad permute: VALU rate, no LDS crossbar
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
 
 template <int CK, int NC, int WN, int GX, int GY>
 struct Geo {
@@ -49,140 +75,312 @@ struct Geo {
   static constexpr int LW = TW + 2;            // LDS cols (halo)
   static constexpr int LH = TH + 2;            // LDS rows
   static constexpr int NCG = CK / 4;           // channel groups per chunk
-  static constexpr int PLANE0 = LH * LW * 4;   // floats per channel-group plane
-  // pad the plane stride to == 8 (mod 32) dwords so the 16-B staging writes of the NCG planes
-  // land on different bank quads
-  static constexpr int PLANE = PLANE0 + ((8 - (PLANE0 % 32)) + 32) % 32;
+  // LDS record of one pixel: [ksub 0..3][cg 0..NCG-1] (channel = 4*cg + ksub), so ONE wide
+  // ds_read (b128 for CK=16, b64 for CK=8) fetches a lane's A operands of all NCG k-steps of a
+  // tap.
+  static constexpr int PIX = CK;  // unpadded: modelled b128/b64 conflicts are lowest at 16 / 8
   static constexpr int KS = 9 * NCG;           // MFMA k-steps per chunk
-  static constexpr int LDS_FLOATS = NCG * PLANE;
+  static constexpr int LDS_FLOATS = LH * LW * PIX;
 };
 
-template <int CK, int NC, int WN, int GX, int GY>
-__global__ __launch_bounds__(256) void conv3x3_mfma(const Args a) {
+// Persistent, software-pipelined form: a workgroup walks tiles t = blockIdx.x, +gridDim.x, ...;
+// the work items are (tile, Cin chunk).  While the MFMAs of item i run out of LDS buffer i&1, the
+// global loads of item i+1 are already in flight into registers; they are written to the other LDS
+// buffer after the MFMA loop, followed by the only barrier of the item.  Single-chunk layers keep
+// their B operand in registers for the whole launch.
+// SWAP = false: pixels are the MFMA A operand -> a lane's 4 accumulators are the 2x2 pool window of
+//   one channel (pool layers: in-register max, one 4-byte store per lane).
+// SWAP = true : weights are the A operand -> a lane's 4 accumulators are 4 consecutive channels of
+//   one pixel (no-pool layers: one 16-byte store per lane instead of four 4-byte stores).
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
   using G = Geo<CK, NC, WN, GX, GY>;
-  __shared__ __attribute__((aligned(16))) float tile[G::LDS_FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // 2 * G::LDS_FLOATS
+  constexpr int NPIX = G::LH * G::LW;        // pixel records of one staged chunk
+  constexpr int NST = (NPIX + 255) / 256;    // pixels per thread
+  typedef float avec __attribute__((ext_vector_type(G::NCG)));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wn = wave % WN;
   const int wm = wave / WN;
-  const int b = blockIdx.z;
-  const int ty0 = blockIdx.y * G::TH;
-  const int tx0 = blockIdx.x * G::TW;
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / CK;
 
   // A-operand lane geometry: m = lane & 15 -> (q, dy, dx); ksub = lane >> 4.
   const int m = lane & 15, ksub = lane >> 4;
   const int q = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
-  const int a_base = ((wm * G::WR + dy) * G::LW + 2 * q + dx) * 4 + ksub;  // floats
+  const int a_base = ((wm * G::WR + dy) * G::LW + 2 * q + dx) * G::PIX + ksub * G::NCG;  // floats
+  const int co_lane = lane & 15;
+  const int qo = lane >> 4;  // D rows 4*qo + r -> pooled x position qo, window element r
 
   f32x4 acc[G::PM][NC];
+  float breg[G::KS][NC];
+  // The MFMA is issued as D = W^T-slice x pixels (weights are the A operand), so a lane holds
+  // pixel (lane & 15) and, in its 4 accumulator registers, output channels 4*(lane>>4)..+3:
+  // the epilogue stores one float4 per lane.  Per-lane epilogue constants, loaded once:
+  f32x4 sc4[NC], sh4[NC];
 #pragma unroll
-  for (int g = 0; g < G::PM; ++g)
-#pragma unroll
-    for (int n = 0; n < NC; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NC; ++n) {
+    if constexpr (SWAP) {
+      sc4[n] = *reinterpret_cast<const f32x4 *>(a.scale + 16 * (wn * NC + n) + 4 * ksub);
+      sh4[n] = *reinterpret_cast<const f32x4 *>(a.shift + 16 * (wn * NC + n) + 4 * ksub);
+    } else {
+      const float sc = a.scale[16 * (wn * NC + n) + co_lane], sh = a.shift[16 * (wn * NC + n) + co_lane];
+      sc4[n] = f32x4{sc, sc, sc, sc};
+      sh4[n] = f32x4{sh, sh, sh, sh};
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src0, a.bytes0);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src1 ? a.src1 : a.src0, a.src1 ? a.bytes1 : 0);
+  const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.y, a.bytes_y);
+  f32x4 st[NST][G::NCG];
 
-  const int co_lane = lane & 15;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    // ---- B operand for this chunk -> registers (L2-resident packed weights) ----
-    float breg[G::KS][NC];
-    {
-      const float *wrow = a.wp + ((size_t)ch * G::KS * 4 + ksub) * a.CoutP + 16 * (wn * NC) + co_lane;
+  auto zero_acc = [&]() {
 #pragma unroll
-      for (int s = 0; s < G::KS; ++s)
+    for (int g = 0; g < G::PM; ++g)
 #pragma unroll
-        for (int n = 0; n < NC; ++n) breg[s][n] = wrow[(size_t)s * 4 * a.CoutP + 16 * n];
-    }
-    // ---- stage the input tile (+halo) of this chunk into LDS ----
-    if (ch > 0) __syncthreads();
-    for (int e = tid; e < G::NCG * G::LH * G::LW; e += 256) {
-      const int cg = e % G::NCG;
-      const int c = (e / G::NCG) % G::LW;
-      const int r = e / (G::NCG * G::LW);
-      const int Y = ty0 + r - 1, X = tx0 + c - 1;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-      int ys = Y, xs = X;
-      if (a.ups) {
-        ok = ok & (Y & 1) & (X & 1);
-        ys = Y >> 1;
-        xs = X >> 1;
+      for (int n = 0; n < NC; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto load_b = [&](int ch) {  // B operand of one chunk -> registers (L2-resident packed weights)
+    const float *wrow = a.wp + ((size_t)ch * G::KS * 4 + ksub) * a.CoutP + 16 * (wn * NC) + co_lane;
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) breg[s][n] = wrow[(size_t)s * 4 * a.CoutP + 16 * n];
+  };
+  auto tile_origin = [&](int T, int &b, int &ty0, int &tx0) {  // wave-uniform (scalar ALU)
+    const int per = tiles_x * tiles_y;
+    b = T / per;
+    const int r = T - b * per;
+    ty0 = (r / tiles_x) * G::TH;
+    tx0 = (r % tiles_x) * G::TW;
+  };
+  // Tile-independent part of every staged pixel's source offset, computed ONCE: the per-item
+  // address arithmetic is then one add + four compares per pixel (32-bit; 64-bit multiplies per
+  // load cost as much VALU time as the MFMAs they feed).  Tile origins are even, so for the
+  // zero-stuffed (stride-2 transposed) input  (ty0 + r - 1) >> 1 == ty0/2 + ((r - 1) >> 1).
+  int rel_r[NST], rel_c[NST], off0[NST], off1[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = tid + 256 * i;
+    rel_r[i] = e / G::LW - 1;
+    rel_c[i] = e % G::LW - 1;
+    const int ys = a.ups ? (rel_r[i] >> 1) : rel_r[i];
+    const int xs = a.ups ? (rel_c[i] >> 1) : rel_c[i];
+    off0[i] = (ys * a.Ws + xs) * a.C0;
+    off1[i] = (ys * a.Ws + xs) * a.C1;
+    if (e >= NPIX) rel_r[i] = -(1 << 28);  // never in range
+    if (a.ups && !((rel_r[i] & 1) && (rel_c[i] & 1))) rel_r[i] = -(1 << 28);  // stuffed zero
+  }
+  auto load_item = [&](int T, int ch) {  // global -> registers (input tile + halo of one chunk)
+    int b, ty0, tx0;
+    tile_origin(T, b, ty0, tx0);
+    const int sy0 = a.ups ? (ty0 >> 1) : ty0, sx0 = a.ups ? (tx0 >> 1) : tx0;
+    const int pbase = (b * a.Hs + sy0) * a.Ws + sx0;  // scalar: source pixel index of the origin
+    const int ylo = -ty0, yhi = a.H - ty0, xlo = -tx0, xhi = a.W - tx0;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const bool ok = (rel_r[i] >= ylo) & (rel_r[i] < yhi) & (rel_c[i] >= xlo) & (rel_c[i] < xhi);
+#pragma unroll
+      for (int cg = 0; cg < G::NCG; ++cg) {
+        const int chan = ch * CK + cg * 4;  // uniform
+        // out-of-image / zero-stuffed pixels read past the descriptor's range: the buffer unit
+        // returns zeros, so the SAME padding costs no branch
+        if (chan < a.C0) {
+          const int off = ok ? (pbase * a.C0 + off0[i] + chan) * 4 : kOOB;
+          st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+        } else {
+          const int off = ok ? (pbase * a.C1 + off1[i] + chan - a.C0) * 4 : kOOB;
+          st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+        }
       }
-      if (ok) {
-        const int chan = ch * CK + cg * 4;
-        const float *p = (chan < a.C0)
-                             ? a.src0 + (((size_t)b * a.Hs + ys) * a.Ws + xs) * a.C0 + chan
-                             : a.src1 + (((size_t)b * a.Hs + ys) * a.Ws + xs) * a.C1 + (chan - a.C0);
-        v = *reinterpret_cast<const f32x4 *>(p);
-      }
-      *reinterpret_cast<f32x4 *>(&tile[cg * G::PLANE + (r * G::LW + c) * 4]) = v;
     }
-    __syncthreads();
-    // ---- MFMA main loop: 9 taps x NCG channel groups ----
+  };
+  auto store_item = [&](int buf) {  // registers -> LDS buffer, transposed to [ksub][cg]
+    float *tb = tile + buf * G::LDS_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NPIX) {
+        float *rec = tb + e * G::PIX;
+        if constexpr (G::NCG == 1) {
+          *reinterpret_cast<f32x4 *>(rec) = st[i][0];
+        } else if constexpr (G::NCG == 2) {
+          *reinterpret_cast<f32x4 *>(rec) = f32x4{st[i][0].x, st[i][1].x, st[i][0].y, st[i][1].y};
+          *reinterpret_cast<f32x4 *>(rec + 4) = f32x4{st[i][0].z, st[i][1].z, st[i][0].w, st[i][1].w};
+        } else {
+          *reinterpret_cast<f32x4 *>(rec) = f32x4{st[i][0].x, st[i][1].x, st[i][2].x, st[i][3].x};
+          *reinterpret_cast<f32x4 *>(rec + 4) = f32x4{st[i][0].y, st[i][1].y, st[i][2].y, st[i][3].y};
+          *reinterpret_cast<f32x4 *>(rec + 8) = f32x4{st[i][0].z, st[i][1].z, st[i][2].z, st[i][3].z};
+          *reinterpret_cast<f32x4 *>(rec + 12) = f32x4{st[i][0].w, st[i][1].w, st[i][2].w, st[i][3].w};
+        }
+      }
+    }
+  };
+  auto compute = [&](int buf) {  // MFMA main loop: 9 taps, one wide A read per (tap, group)
+    const float *tb = tile + buf * G::LDS_FLOATS;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap % 3;
+      avec av[G::PM];
+#pragma unroll
+      for (int g = 0; g < G::PM; ++g) {
+        const int gx = g % GX, gy = g / GX;
+        av[g] = *reinterpret_cast<const avec *>(
+            &tb[a_base + ((2 * gy + ky) * G::LW + 8 * gx + kx) * G::PIX]);
+      }
 #pragma unroll
       for (int cg = 0; cg < G::NCG; ++cg) {
         const int s = tap * G::NCG + cg;
-        float av[G::PM];
+#pragma unroll
+        for (int g = 0; g < G::PM; ++g) {
+          const float aval = av[g][cg];
+#pragma unroll
+          for (int n = 0; n < NC; ++n)
+            if constexpr (SWAP)
+              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[s][n], aval, acc[g][n], 0, 0, 0);
+            else
+              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aval, breg[s][n], acc[g][n], 0, 0, 0);
+        }
+      }
+    }
+  };
+  const int opool = a.pool;  // 1 or 2
+  const bool vec_ok = (a.Cout & 3) == 0;
+  auto epilogue = [&](int T) {  // scale/shift (bias + BN), ReLU, 2x2 max-pool, store
+    int b, ty0, tx0;
+    tile_origin(T, b, ty0, tx0);
+    if constexpr (!SWAP) {  // lane = channel co_lane; registers r = window element (dy,dx) of pixel group qo
+      const int wrow0 = ty0 + wm * G::WR, lcol0 = tx0 + 2 * qo;
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const int co = 16 * (wn * NC + n) + co_lane;
+        const bool co_ok = co < a.Cout;
+        const int obase = ((b * a.Ho + wrow0 / opool) * a.Wo + lcol0 / opool) * a.Cout + co;
 #pragma unroll
         for (int g = 0; g < G::PM; ++g) {
           const int gx = g % GX, gy = g / GX;
-          av[g] = tile[a_base + cg * G::PLANE + ((2 * gy + ky) * G::LW + 8 * gx + kx) * 4];
+          const int row0 = wrow0 + 2 * gy, col0 = lcol0 + 8 * gx;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[g][n][r] * sc4[n].x + sh4[n].x;
+            if (a.relu) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (opool == 2) {
+            const float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            const bool ok = co_ok & ((row0 >> 1) < a.Ho) & ((col0 >> 1) < a.Wo);
+            const int boff = ok ? (obase + (gy * a.Wo + 4 * gx) * a.Cout) * 4 : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, boff, 0, 0);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = co_ok & (row0 + (r >> 1) < a.Ho) & (col0 + (r & 1) < a.Wo);
+              const int boff = ok ? (obase + ((2 * gy + (r >> 1)) * a.Wo + 8 * gx + (r & 1)) * a.Cout) * 4 : kOOB;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsy, boff, 0, 0);
+            }
+          }
         }
+      }
+      return;
+    }
+    const int lrow = ty0 + wm * G::WR + dy;  // conv row / col of this lane's pixel in group 0
+    const int lcol = tx0 + 2 * q + dx;
+    const bool pool_lane = (opool == 1) | ((dy | dx) == 0);  // after pooling one lane of 4 stores
 #pragma unroll
-        for (int g = 0; g < G::PM; ++g)
+    for (int n = 0; n < NC; ++n) {
+      const int co0 = 16 * (wn * NC + n) + 4 * ksub;
+      const int obase = ((b * a.Ho + lrow / opool) * a.Wo + lcol / opool) * a.Cout + co0;
 #pragma unroll
-          for (int n = 0; n < NC; ++n)
-            acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g], breg[s][n], acc[g][n], 0, 0, 0);
+      for (int g = 0; g < G::PM; ++g) {
+        const int gx = g % GX, gy = g / GX;
+        f32x4 v = acc[g][n] * sc4[n] + sh4[n];
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (opool == 2) {  // the 2x2 window = lanes 4q..4q+3
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = fmaxf(v[r], quad_swap<0xB1>(v[r]));  // lanes ^1  (quad_perm [1,0,3,2])
+            v[r] = fmaxf(v[r], quad_swap<0x4E>(v[r]));  // lanes ^2  (quad_perm [2,3,0,1])
+          }
+        }
+        const int prow = (lrow + 2 * gy) / opool, pcol = (lcol + 8 * gx) / opool;
+        const bool ok = pool_lane & (prow < a.Ho) & (pcol < a.Wo);
+        const int off = obase + ((2 / opool) * gy * a.Wo + (8 / opool) * gx) * a.Cout;
+        if (vec_ok) {
+          const int boff = (ok & (co0 < a.Cout)) ? off * 4 : kOOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, boff, 0, 0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int boff = (ok & (co0 + r < a.Cout)) ? (off + r) * 4 : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsy, boff, 0, 0);
+          }
+        }
       }
     }
-  }
+  };
 
-  // ---- epilogue: scale/shift (bias + BN), ReLU, 2x2 max-pool, store ----
-  const int qo = lane >> 4;  // D rows 4*qo + r  ->  pooled x position qo, window element r
-#pragma unroll
-  for (int n = 0; n < NC; ++n) {
-    const int co = 16 * (wn * NC + n) + co_lane;
-    const float sc = a.scale[co], sh = a.shift[co];
-    const bool co_ok = co < a.Cout;
-#pragma unroll
-    for (int g = 0; g < G::PM; ++g) {
-      const int gx = g % GX, gy = g / GX;
-      const int row0 = ty0 + wm * G::WR + 2 * gy;
-      const int col0 = tx0 + 8 * gx + 2 * qo;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[g][n][r] * sc + sh;
-        if (a.relu) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (a.pool == 2) {
-        const float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        const int pr = row0 >> 1, pc = col0 >> 1;
-        if (co_ok && pr < a.Ho && pc < a.Wo)
-          a.y[(((size_t)b * a.Ho + pr) * a.Wo + pc) * a.Cout + co] = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pr = row0 + (r >> 1), pc = col0 + (r & 1);
-          if (co_ok && pr < a.Ho && pc < a.Wo)
-            a.y[(((size_t)b * a.Ho + pr) * a.Wo + pc) * a.Cout + co] = v[r];
-        }
-      }
+  int T = blockIdx.x, ch = 0, buf = 0;
+  if (T >= ntiles) return;
+  load_b(0);
+  load_item(T, 0);
+  store_item(0);
+  zero_acc();
+  __syncthreads();
+  while (true) {
+    int nT = T, nch = ch + 1;
+    if (nch == nchunks) {
+      nch = 0;
+      nT = T + gridDim.x;
     }
+    const bool has_next = nT < ntiles;
+    if (has_next && !(a.ablate & 2)) load_item(nT, nch);  // in flight across the MFMA loop
+    if (!(a.ablate & 4)) compute(buf);
+    if (ch == nchunks - 1) {
+      if (!(a.ablate & 1)) epilogue(T);
+      zero_acc();
+    }
+    if (!has_next) break;
+    if (nchunks > 1) load_b(nch);
+    if (!(a.ablate & 2)) store_item(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    T = nT;
+    ch = nch;
   }
+}
+
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP>
+int launch_s(const Args &a, int B, hipStream_t st) {
+  using G = Geo<CK, NC, WN, GX, GY>;
+  auto kern = conv3x3_mfma<CK, NC, WN, GX, GY, SWAP>;
+  constexpr size_t lds = 2 * G::LDS_FLOATS * sizeof(float);
+  static int wgs_per_cu = 0;  // idempotent lazy init
+  if (!wgs_per_cu) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, lds) != hipSuccess || n < 1) n = 1;
+    wgs_per_cu = n > 4 ? 4 : n;
+  }
+  const int tiles_x = ceil_div(a.W, G::TW), tiles_y = ceil_div(a.H, G::TH);
+  const int ntiles = tiles_x * tiles_y * B;
+  const int cap = wgs_per_cu * num_cus();
+  const int grid = ntiles < cap ? ntiles : cap;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  return launch_status("ra_conv3x3_f32");
 }
 
 template <int CK, int NC, int WN, int GX, int GY>
 int launch(const Args &a, int B, hipStream_t st) {
-  using G = Geo<CK, NC, WN, GX, GY>;
-  dim3 grid(ceil_div(a.W, G::TW), ceil_div(a.H, G::TH), B);
-  hipLaunchKernelGGL((conv3x3_mfma<CK, NC, WN, GX, GY>), grid, dim3(256), 0, st, a);
-  return launch_status("ra_conv3x3_f32");
+  // channel-vector stores pay off when there is no pooling and the channel count allows float4
+  if (a.pool == 1 && (a.Cout & 3) == 0) return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
+  return launch_s<CK, NC, WN, GX, GY, false>(a, B, st);
 }
 
 // Tile geometry choice: the biggest tile that still yields >= ~2 workgroups per CU, narrow
@@ -195,6 +393,15 @@ int dispatch_geo(const Args &a, int B, hipStream_t st) {
   };
   const bool narrow = (a.W % 32 != 0) && (a.W % 32 <= 16);
   const long want = 512;
+  static int force = -1;  // RA_CONV_GEO=<gx><gy> (e.g. 41) forces a geometry: tuning aid only
+  if (force < 0) {
+    const char *e = getenv("RA_CONV_GEO");
+    force = e ? atoi(e) : 0;
+  }
+  if (force == 42) return launch<CK, NC, WN, 4, 2>(a, B, st);
+  if (force == 41) return launch<CK, NC, WN, 4, 1>(a, B, st);
+  if (force == 22) return launch<CK, NC, WN, 2, 2>(a, B, st);
+  if (force == 21) return launch<CK, NC, WN, 2, 1>(a, B, st);
   if (!narrow) {
     if (wgs(4, 2) >= want) return launch<CK, NC, WN, 4, 2>(a, B, st);
     if (wgs(4, 1) >= want) return launch<CK, NC, WN, 4, 1>(a, B, st);
@@ -203,12 +410,16 @@ int dispatch_geo(const Args &a, int B, hipStream_t st) {
   return launch<CK, NC, WN, 2, 1>(a, B, st);
 }
 
+// Cout groups per wave (NC) x waves along cout (WN).  Small problems (few tiles) split the cout
+// groups over more waves so that each wave's serial MFMA chain is shorter.
 template <int CK>
 int dispatch_cout(const Args &a, int B, hipStream_t st) {
+  const long tiles_big = (long)ceil_div(a.W, 16) * ceil_div(a.H, 8) * B;  // 8x16 tiles, WN = 1
+  const bool small = tiles_big < 256;
   switch (a.CoutP) {
     case 16: return dispatch_geo<CK, 1, 1>(a, B, st);
-    case 32: return dispatch_geo<CK, 2, 1>(a, B, st);
-    case 64: return dispatch_geo<CK, 2, 2>(a, B, st);
+    case 32: return small ? dispatch_geo<CK, 1, 2>(a, B, st) : dispatch_geo<CK, 2, 1>(a, B, st);
+    case 64: return small ? dispatch_geo<CK, 1, 4>(a, B, st) : dispatch_geo<CK, 2, 2>(a, B, st);
     case 128: return dispatch_geo<CK, 2, 4>(a, B, st);
     default: return fail(RA_E_SHAPE, "ra_conv3x3_f32: CoutP %d unsupported", a.CoutP);
   }
@@ -315,11 +526,28 @@ extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int 
   a.CoutP = ra_conv_cout_padded(Cout);
   a.relu = relu;
   a.pool = pool;
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char *e = getenv("RA_CONV_ABLATE");
+      abl = e ? atoi(e) : 0;
+    }
+    a.ablate = abl;
+  }
   if (!a.CoutP) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: Cout %d", Cout);
   if (pool != 1 && pool != 2) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: pool %d", pool);
   if (pool == 2 && ((a.H | a.W) & 1)) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: odd size with pool 2");
   a.Ho = a.H / pool;
   a.Wo = a.W / pool;
+  {
+    const size_t n0 = (size_t)B * Hs * Ws * C0 * 4, n1 = (size_t)B * Hs * Ws * C1 * 4,
+                 ny = (size_t)B * a.Ho * a.Wo * Cout * 4;
+    if (n0 >= (1ull << 31) || n1 >= (1ull << 31) || ny >= (1ull << 31))
+      return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: a tensor exceeds 2 GiB (32-bit buffer offsets)");
+    a.bytes0 = (int)n0;
+    a.bytes1 = (int)n1;
+    a.bytes_y = (int)ny;
+  }
   const int Cin = C0 + C1;
   const int CK = ra::conv::chunk_of(Cin);
   // a chunk may not straddle the src0/src1 boundary at finer than 4 channels (always true) but

@@ -1,0 +1,364 @@
+// K1 (pair form) — TWO consecutive 3x3 SAME conv layers fused in one launch:
+//   A: conv3x3 (+bias+BN+ReLU, no pool; optionally the zero-stuffed stride-2 transposed conv)
+//   B: conv3x3 (+bias+BN+ReLU, max-pool 1|2)
+// The A output of a tile (+1-pixel halo, recomputed) never leaves LDS, which removes the
+// HBM write+read of the intermediate activation — the dominant cost of the first controller-CNN
+// layers (L0 writes 8 MiB per 512x512 image that L1 reads straight back) — and halves the number
+// of launches of the patch-sized attention CNN / DCNN.  Same f32 MFMA implicit-GEMM machinery as
+// ra_conv.hip (v_mfma_f32_16x16x4_f32, 2x2-window row mapping, [pixel][ksub][cg] LDS records
+// read with one wide ds_read per tap).  nnlib.py:229-253 (cnn) / :362-400 (dcnn), two layers.
+#include <cstdlib>
+
+#include "ra_common.h"
+
+namespace ra {
+namespace cpair {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PArgs {
+  const float *src;
+  float *y;
+  const float *wpA, *scA, *shA, *wpB, *scB, *shB;
+  int C0, Hs, Ws, H, W, ups;
+  int CoutAP, CoutB, CoutBP, poolB, Ho, Wo, reluA, reluB;
+  int ablate;  // tuning aid (RA_PAIR_ABLATE): 1 no stores, 2 no input loads, 4 no phase A, 8 no phase B MFMA
+};
+
+template <int CINA, int CMID, int NCB, int GX, int GYB>
+struct PGeo {
+  static constexpr int NCA = (CMID + 15) / 16;
+  static constexpr int TWB = 8 * GX, THB = 8 * GYB, PMB = GX * GYB;
+  static constexpr int GXA = GX + 1, GRA = THB / 2 + 1, NGA = GXA * GRA;
+  static constexpr int AW = 8 * GXA, AH = 2 * GRA;     // A-out tile (B tile + halo, padded)
+  static constexpr int LWA = AW + 2, LHA = AH + 2;     // input tile of A
+  static constexpr int NCGA = CINA / 4, CKA = CINA < 16 ? CINA : 16, NCHA = CINA / CKA, NCGAC = CKA / 4;
+  static constexpr int NCGB = CMID / 4, CKB = CMID < 16 ? CMID : 16, NCHB = CMID / CKB, NCGBC = CKB / 4;
+  static constexpr int KSA = 9 * NCGAC, KSB = 9 * NCGBC;
+  static constexpr int IN_FLOATS = LHA * LWA * CINA;
+  static constexpr int MID_FLOATS = AH * AW * CMID;
+  static constexpr int RA = 4;                          // A groups per wave per round
+  static constexpr int GPW = (NGA + 3) / 4;             // A groups per wave
+  static constexpr int ROUNDS = (GPW + RA - 1) / RA;
+};
+
+template <int N>
+struct vec_of {
+  typedef float type __attribute__((ext_vector_type(N)));
+};
+
+template <int CINA, int CMID, int NCB, int GX, int GYB>
+__global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x, int tiles_y) {
+  using G = PGeo<CINA, CMID, NCB, GX, GYB>;
+  constexpr int NCA = G::NCA;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tin = lds;                  // [LHA][LWA][CINA]  records [ksub][cg]
+  float *tmid = lds + G::IN_FLOATS;  // [AH][AW][CMID]    records [ksub][cg]
+  typedef typename vec_of<G::NCGAC>::type avecA;
+  typedef typename vec_of<G::NCGBC>::type avecB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, ksub = lane >> 4;
+  const int q = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
+  const int co_lane = lane & 15, qo = lane >> 4;
+  const int per = tiles_x * tiles_y;
+  const int b = blockIdx.x / per;
+  const int trem = blockIdx.x - b * per;
+  const int ty0 = (trem / tiles_x) * G::THB, tx0 = (trem % tiles_x) * G::TWB;
+
+  // ---------------- phase 0: stage A's input tile (+2-pixel halo) ----------------
+  {
+    const int sy0 = a.ups ? (ty0 >> 1) : ty0, sx0 = a.ups ? (tx0 >> 1) : tx0;
+    const float *base = a.src + ((size_t)(b * a.Hs + sy0) * a.Ws + sx0) * a.C0;
+    for (int e = tid; e < G::LHA * G::LWA; e += 256) {
+      const int rr = e / G::LWA - 2, cc = e % G::LWA - 2;  // relative to the B-tile origin
+      const int Y = ty0 + rr, X = tx0 + cc;
+      bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+      int ys = rr, xs = cc;
+      if (a.ups) {
+        ok = ok & (rr & 1) & (cc & 1);  // origins are even: parity of Y == parity of rr
+        ys = rr >> 1;
+        xs = cc >> 1;
+      }
+      f32x4 v[G::NCGA];
+#pragma unroll
+      for (int cg = 0; cg < G::NCGA; ++cg) {
+        v[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && !(a.ablate & 2)) v[cg] = *reinterpret_cast<const f32x4 *>(base + (ys * a.Ws + xs) * a.C0 + 4 * cg);
+      }
+      float *rec = tin + e * CINA;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if constexpr (G::NCGA == 1) {
+          rec[ks] = v[0][ks];
+        } else if constexpr (G::NCGA == 2) {
+          rec[ks * 2] = v[0][ks];
+          rec[ks * 2 + 1] = v[1][ks];
+        } else {
+#pragma unroll
+          for (int c4 = 0; c4 < G::NCGA / 4; ++c4)
+            *reinterpret_cast<f32x4 *>(rec + ks * G::NCGA + 4 * c4) =
+                f32x4{v[4 * c4][ks], v[4 * c4 + 1][ks], v[4 * c4 + 2][ks], v[4 * c4 + 3][ks]};
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase A: conv A over the B tile + halo, result -> LDS ----------------
+  if (!(a.ablate & 4)) {
+    float scA[NCA], shA[NCA];
+#pragma unroll
+    for (int n = 0; n < NCA; ++n) {
+      scA[n] = a.scA[16 * n + co_lane];
+      shA[n] = a.shA[16 * n + co_lane];
+    }
+    const int lane_in = (dy * G::LWA + 2 * q + dx) * CINA + ksub * G::NCGA;
+    float bregA[G::KSA][NCA];
+    auto load_bA = [&](int ch) {
+      const float *wrow = a.wpA + ((size_t)ch * G::KSA * 4 + ksub) * a.CoutAP + co_lane;
+#pragma unroll
+      for (int s = 0; s < G::KSA; ++s)
+#pragma unroll
+        for (int n = 0; n < NCA; ++n) bregA[s][n] = wrow[(size_t)s * 4 * a.CoutAP + 16 * n];
+    };
+    if (G::NCHA == 1) load_bA(0);
+    for (int rd = 0; rd < G::ROUNDS; ++rd) {
+      f32x4 acc[G::RA][NCA];
+      int gbase[G::RA], gr[G::RA], gc[G::RA];
+#pragma unroll
+      for (int j = 0; j < G::RA; ++j) {
+        int gi = wave + 4 * (rd * G::RA + j);
+        if (gi >= G::NGA) gi = G::NGA - 1;  // duplicate work, masked at the store
+        gr[j] = gi / G::GXA;
+        gc[j] = gi % G::GXA;
+        gbase[j] = (2 * gr[j] * G::LWA + 8 * gc[j]) * CINA + lane_in;
+#pragma unroll
+        for (int n = 0; n < NCA; ++n) acc[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      for (int ch = 0; ch < G::NCHA; ++ch) {
+        if (G::NCHA > 1) load_bA(ch);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          avecA av[G::RA];
+#pragma unroll
+          for (int j = 0; j < G::RA; ++j)
+            av[j] = *reinterpret_cast<const avecA *>(
+                &tin[gbase[j] + (ky * G::LWA + kx) * CINA + ch * G::NCGAC]);
+#pragma unroll
+          for (int cg = 0; cg < G::NCGAC; ++cg)
+#pragma unroll
+            for (int j = 0; j < G::RA; ++j)
+#pragma unroll
+              for (int n = 0; n < NCA; ++n)
+                acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][cg], bregA[tap * G::NCGAC + cg][n],
+                                                                 acc[j][n], 0, 0, 0);
+        }
+      }
+      // A epilogue -> tmid (zero outside the image: it is B's SAME padding)
+#pragma unroll
+      for (int j = 0; j < G::RA; ++j) {
+        const bool live = (wave + 4 * (rd * G::RA + j)) < G::NGA;
+#pragma unroll
+        for (int n = 0; n < NCA; ++n) {
+          const int co = 16 * n + co_lane;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ar = 2 * gr[j] + (r >> 1), ac = 8 * gc[j] + 2 * qo + (r & 1);
+            const int Y = ty0 - 1 + ar, X = tx0 - 1 + ac;
+            float v = acc[j][n][r] * scA[n] + shA[n];
+            if (a.reluA) v = fmaxf(v, 0.f);
+            if (!((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W))) v = 0.f;
+            if (live && co < CMID) tmid[(ar * G::AW + ac) * CMID + (co & 3) * G::NCGB + (co >> 2)] = v;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase B: conv B out of tmid, epilogue -> global ----------------
+  {
+    f32x4 acc[G::PMB][NCB];
+#pragma unroll
+    for (int g = 0; g < G::PMB; ++g)
+#pragma unroll
+      for (int n = 0; n < NCB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_base = ((wave * 2 * GYB + dy) * G::AW + 2 * q + dx) * CMID + ksub * G::NCGB;
+    float bregB[G::KSB][NCB];
+    for (int ch = 0; ch < ((a.ablate & 8) ? 0 : G::NCHB); ++ch) {
+      {
+        const float *wrow = a.wpB + ((size_t)ch * G::KSB * 4 + ksub) * a.CoutBP + co_lane;
+#pragma unroll
+        for (int s = 0; s < G::KSB; ++s)
+#pragma unroll
+          for (int n = 0; n < NCB; ++n) bregB[s][n] = wrow[(size_t)s * 4 * a.CoutBP + 16 * n];
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        avecB av[G::PMB];
+#pragma unroll
+        for (int g = 0; g < G::PMB; ++g) {
+          const int gx = g % GX, gy = g / GX;
+          av[g] = *reinterpret_cast<const avecB *>(
+              &tmid[a_base + ((2 * gy + ky) * G::AW + 8 * gx + kx) * CMID + ch * G::NCGBC]);
+        }
+#pragma unroll
+        for (int cg = 0; cg < G::NCGBC; ++cg)
+#pragma unroll
+          for (int g = 0; g < G::PMB; ++g)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n)
+              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][cg], bregB[tap * G::NCGBC + cg][n],
+                                                               acc[g][n], 0, 0, 0);
+      }
+    }
+    const int opool = a.poolB;
+    const int wrow0 = ty0 + wave * 2 * GYB, lcol0 = tx0 + 2 * qo;
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) {
+      const int co = 16 * n + co_lane;
+      const float sc = a.scB[co], sh = a.shB[co];
+      const bool co_ok = co < a.CoutB;
+      const int obase = ((b * a.Ho + wrow0 / opool) * a.Wo + lcol0 / opool) * a.CoutB + co;
+#pragma unroll
+      for (int g = 0; g < G::PMB; ++g) {
+        const int gx = g % GX, gy = g / GX;
+        const int row0 = wrow0 + 2 * gy, col0 = lcol0 + 8 * gx;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[g][n][r] * sc + sh;
+          if (a.reluB) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (opool == 2) {
+          const float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+          if (co_ok && (row0 >> 1) < a.Ho && (col0 >> 1) < a.Wo && !(a.ablate & 1))
+            a.y[obase + (gy * a.Wo + 4 * gx) * a.CoutB] = o;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co_ok && row0 + (r >> 1) < a.Ho && col0 + (r & 1) < a.Wo)
+              a.y[obase + ((2 * gy + (r >> 1)) * a.Wo + 8 * gx + (r & 1)) * a.CoutB] = v[r];
+        }
+      }
+    }
+  }
+}
+
+template <int CINA, int CMID, int NCB, int GX, int GYB>
+int launch(const PArgs &a, int B, hipStream_t st) {
+  using G = PGeo<CINA, CMID, NCB, GX, GYB>;
+  auto kern = conv_pair_mfma<CINA, CMID, NCB, GX, GYB>;
+  constexpr size_t lds = (size_t)(G::IN_FLOATS + G::MID_FLOATS) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "pair tile does not fit LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int tiles_x = ceil_div(a.W, G::TWB), tiles_y = ceil_div(a.H, G::THB);
+  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * B), dim3(256), lds, st, a, tiles_x, tiles_y);
+  return launch_status("ra_conv_pair_f32");
+}
+
+template <int CINA, int CMID, int NCB>
+int dispatch_geo(const PArgs &a, int B, hipStream_t st) {
+  using Big = PGeo<CINA, CMID, NCB, 4, 2>;
+  constexpr bool big_fits = (size_t)(Big::IN_FLOATS + Big::MID_FLOATS) * 4 <= 80 * 1024;
+  const bool narrow = (a.W % 32 != 0) && (a.W % 32 <= 16);
+  auto wgs = [&](int gx, int gyb) { return (long)ceil_div(a.W, 8 * gx) * ceil_div(a.H, 8 * gyb) * B; };
+  static int force = -1;  // RA_PAIR_GEO=<gx><gyb>: tuning aid
+  if (force < 0) {
+    const char *e = getenv("RA_PAIR_GEO");
+    force = e ? atoi(e) : 0;
+  }
+  if constexpr (big_fits) {
+    if (force == 42 || (!force && !narrow && wgs(4, 2) >= 512)) return launch<CINA, CMID, NCB, 4, 2>(a, B, st);
+  }
+  if (force == 41 || (!force && !narrow)) return launch<CINA, CMID, NCB, 4, 1>(a, B, st);
+  if (force == 22 || (!force && wgs(2, 2) >= 512)) return launch<CINA, CMID, NCB, 2, 2>(a, B, st);
+  return launch<CINA, CMID, NCB, 2, 1>(a, B, st);
+}
+
+template <int CINA, int CMID>
+int dispatch_b(const PArgs &a, int B, hipStream_t st) {
+  if (a.CoutBP == 16) return dispatch_geo<CINA, CMID, 1>(a, B, st);
+  if (a.CoutBP == 32) return dispatch_geo<CINA, CMID, 2>(a, B, st);
+  return fail(RA_E_SHAPE, "ra_conv_pair_f32: CoutB %d unsupported", a.CoutB);
+}
+
+template <int CINA>
+int dispatch_mid(const PArgs &a, int cmid, int B, hipStream_t st) {
+  switch (cmid) {
+    case 8: return dispatch_b<CINA, 8>(a, B, st);
+    case 16: return dispatch_b<CINA, 16>(a, B, st);
+    case 32: return dispatch_b<CINA, 32>(a, B, st);
+    default: return fail(RA_E_SHAPE, "ra_conv_pair_f32: CoutA %d unsupported", cmid);
+  }
+}
+
+}  // namespace cpair
+}  // namespace ra
+
+using namespace ra;
+
+extern "C" int ra_conv_pair_supported(int Cin, int CoutA, int CoutB) {
+  const bool cin_ok = Cin == 4 || Cin == 8 || Cin == 16 || Cin == 32;
+  const bool mid_ok = CoutA == 8 || CoutA == 16 || CoutA == 32;
+  return cin_ok && mid_ok && CoutB >= 1 && CoutB <= 32;
+}
+
+extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsampleA,
+                                const float *wpA, const float *scaleA, const float *shiftA, int CoutA,
+                                int reluA, const float *wpB, const float *scaleB, const float *shiftB,
+                                int CoutB, int reluB, int poolB, float *y, void *stream) {
+  if (!src || !wpA || !scaleA || !shiftA || !wpB || !scaleB || !shiftB || !y || B <= 0 || Hs <= 0 ||
+      Ws <= 0)
+    return fail(RA_E_INVALID, "ra_conv_pair_f32: bad argument");
+  if (!ra_conv_pair_supported(Cin, CoutA, CoutB))
+    return fail(RA_E_SHAPE, "ra_conv_pair_f32: Cin=%d CoutA=%d CoutB=%d", Cin, CoutA, CoutB);
+  if (poolB != 1 && poolB != 2) return fail(RA_E_SHAPE, "ra_conv_pair_f32: pool %d", poolB);
+  cpair::PArgs a;
+  a.src = src;
+  a.y = y;
+  a.wpA = wpA;
+  a.scA = scaleA;
+  a.shA = shiftA;
+  a.wpB = wpB;
+  a.scB = scaleB;
+  a.shB = shiftB;
+  a.C0 = Cin;
+  a.Hs = Hs;
+  a.Ws = Ws;
+  a.ups = upsampleA ? 1 : 0;
+  a.H = Hs * (1 + a.ups);
+  a.W = Ws * (1 + a.ups);
+  if (poolB == 2 && ((a.H | a.W) & 1)) return fail(RA_E_SHAPE, "ra_conv_pair_f32: odd size with pool 2");
+  a.CoutAP = ra_conv_cout_padded(CoutA);
+  a.CoutB = CoutB;
+  a.CoutBP = ra_conv_cout_padded(CoutB);
+  a.poolB = poolB;
+  a.Ho = a.H / poolB;
+  a.Wo = a.W / poolB;
+  a.reluA = reluA;
+  a.reluB = reluB;
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char *e = getenv("RA_PAIR_ABLATE");
+      abl = e ? atoi(e) : 0;
+    }
+    a.ablate = abl;
+  }
+  hipStream_t st = as_stream(stream);
+  switch (Cin) {
+    case 4: return cpair::dispatch_mid<4>(a, CoutA, B, st);
+    case 8: return cpair::dispatch_mid<8>(a, CoutA, B, st);
+    case 16: return cpair::dispatch_mid<16>(a, CoutA, B, st);
+    default: return cpair::dispatch_mid<32>(a, CoutA, B, st);
+  }
+}

@@ -38,6 +38,9 @@ class DecodeEngine(object):
     self._stamp = None
     self._B = None
     self._graphs = {}
+    self.fuse_pairs = True  # fused two-layer conv launches in the controller CNN where it pays
+    self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
+    self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = choose from the batch size
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -105,6 +108,9 @@ class DecodeEngine(object):
     gm = [(M['glimpse_mlp_w_%d' % i], M['glimpse_mlp_b_%d' % i]) for i in range(d['n_gmlp'])]
     cm = [(M['ctrl_mlp_w_%d' % i], M['ctrl_mlp_b_%d' % i]) for i in range(d['n_cmlp'])]
     W['ctrl'] = _dev(ops.pack_ctrl_weights(self.desc, lstm, gm, cm), device)
+    self.split_ok = self.ctrl_split and ops.ctrl_split_supported(self.desc)
+    if self.split_ok:
+      W['ctrl_split'] = _dev(ops.pack_ctrl_split_weights(self.desc, lstm, gm, cm), device)
     W['smlp_w'] = M['score_mlp_w_0']
     W['smlp_b'] = M['score_mlp_b_0']
     if not self.box:
@@ -149,8 +155,48 @@ class DecodeEngine(object):
         W['adcnn'].append((_dev(wp, device), sc, sh, cout, d['adcnn_unpool'][i], src))
         prev_c = cout
     self.W = W
+    self.plan = self._make_plan(W)
     self._stamp = stamp
     self._graphs = {}
+
+  def _make_plan(self, W):
+    """Greedy pairing of consecutive conv layers into fused launches (ra_conv_pair_f32): A must
+    not pool (cnn) / B must not upsample (dcnn), single source, channel counts supported."""
+    d = self.d
+    plan = {}
+
+    def pair_up(n, cin, cout, a_ok, b_ok):
+      steps, i = [], 0
+      while i < n:
+        # measured on MI355X: fusion pays while the intermediate has <= 16 channels (LDS tile
+        # small enough for a 16x32 tile); wider pairs recompute too much halo
+        if (self.fuse_pairs and i + 1 < n and a_ok(i) and b_ok(i + 1) and cout(i) <= 16 and
+            ops.conv_pair_supported(cin(i), cout(i), cout(i + 1))):
+          steps.append(('pair', i, i + 1))
+          i += 2
+        else:
+          steps.append(('single', i))
+          i += 1
+      return steps
+
+    cc = d['ccnn_channels']
+    plan['ccnn'] = pair_up(d['ccnn_nlayers'], lambda i: d['C0p'] if i == 0 else _r4(cc[i]),
+                           lambda i: cc[i + 1], lambda i: d['ccnn_pool'][i] == 1, lambda i: True)
+    if not self.box:
+      ac = d['acnn_channels']
+      L = d['acnn_nlayers']
+      # attn-CNN outputs that feed DCNN skip connections must be materialised (not fused away)
+      skip_used = set(L - 2 - lay_[5] for lay_ in W['adcnn'] if lay_[5] is not None and lay_[5] < L - 1)
+      fuse_patch = self.fuse_patch_pairs
+      plan['acnn'] = pair_up(L, lambda i: d['C0p'] if i == 0 else _r4(ac[i]), lambda i: ac[i + 1],
+                             lambda i: fuse_patch and d['acnn_pool'][i] == 1 and i not in skip_used,
+                             lambda i: True)
+      dc = d['adcnn_channels']
+      lay = W['adcnn']
+      plan['adcnn'] = pair_up(d['adcnn_nlayers'], lambda i: _r4(dc[i]), lambda i: dc[i + 1],
+                              lambda i: fuse_patch and lay[i][5] is None,
+                              lambda i: lay[i][5] is None and lay[i][4] == 1)
+    return plan
 
   # ------------------------------------------------------------------ buffers
   def alloc(self, B, device):
@@ -197,6 +243,8 @@ class DecodeEngine(object):
       b['fx'] = f(Bs, W, Fw)
       b['band'] = torch.zeros((Bs, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32,
                               device=device)
+      if self.split_ok and Bs <= 14:
+        b['ctrl_ws'], b['ctrl_status'] = ops.ctrl_split_workspace(self.desc, Bs, device)
       if self.box:
         b['noise'] = f(T, Bs, H, W)
         b['ysel'] = f(Bs, H, W)
@@ -270,13 +318,13 @@ class DecodeEngine(object):
     ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), d['C0p'], b['img'])
     self._mark('pack')
     for tt in range(T):
-      src = b['img']
-      for i, (wp, sc, sh, cout, pool) in enumerate(Wt['ccnn']):
-        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=b['ccnn'][i])
-        src = b['ccnn'][i]
-        self._mark('ctrl_cnn_L%d' % i)
-      ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
-                     b['gmaps'][tt], b['attn'][tt])
+      src = self._run_cnn(self.plan['ccnn'], Wt['ccnn'], b['img'], b['ccnn'], tt, 'ctrl_cnn')
+      if 'ctrl_ws' in b:
+        ops.controller_split(self.desc, src, Wt['ctrl_split'], b['h_last'][tt], b['ctrl_out'][tt],
+                             b['gmaps'][tt], b['attn'][tt], b['ctrl_ws'], b['ctrl_status'])
+      else:
+        ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
+                       b['gmaps'][tt], b['attn'][tt])
       self._mark('controller')
       ops.attn_filters(b['attn'][tt], H, W, Fh, Fw, b['fy'], b['fx'], b['band'])
       self._mark('filters')
@@ -291,18 +339,22 @@ class DecodeEngine(object):
       ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
                         d['C0p'], True, xp)
       self._mark('extract')
-      src = xp
-      for i, (wp, sc, sh, cout, pool) in enumerate(Wt['acnn']):
-        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=b['acnn'][i])
-        src = b['acnn'][i]
-      self._mark('attn_cnn')
+      src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
       core = src
       L = d['acnn_nlayers']
       skips = [b['acnn'][L - 2 - k] for k in range(L - 1)] + [xp]
-      for i, (wp, sc, sh, cout, unpool, sidx) in enumerate(Wt['adcnn']):
-        out = b['y_out_patch'][tt] if b['adcnn'][i] is None else b['adcnn'][i]
-        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=1,
-                    src1=None if sidx is None else skips[sidx], upsample=(unpool == 2), out=out)
+      for step in self.plan['adcnn']:
+        if step[0] == 'pair':
+          (wpa, sca, sha, ca, upa, _), (wpb, scb, shb, cb, _, _) = Wt['adcnn'][step[1]], Wt['adcnn'][step[2]]
+          out = b['y_out_patch'][tt] if b['adcnn'][step[2]] is None else b['adcnn'][step[2]]
+          ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=1,
+                        upsampleA=(upa == 2), out=out)
+        else:
+          i = step[1]
+          wp, sc, sh, cout, unpool, sidx = Wt['adcnn'][i]
+          out = b['y_out_patch'][tt] if b['adcnn'][i] is None else b['adcnn'][i]
+          ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=1,
+                      src1=None if sidx is None else skips[sidx], upsample=(unpool == 2), out=out)
         src = out
       self._mark('attn_dcnn')
       ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
@@ -312,6 +364,22 @@ class DecodeEngine(object):
                        d['disable_overwrite'], b['img'], d['D'],
                        b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
       self._mark('paste')
+
+  def _run_cnn(self, steps, layers, src, bufs, tt, name):
+    for step in steps:
+      if step[0] == 'pair':
+        (wpa, sca, sha, ca, _), (wpb, scb, shb, cb, poolb) = layers[step[1]], layers[step[2]]
+        ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=poolb,
+                      out=bufs[step[2]])
+        src = bufs[step[2]]
+        self._mark('%s_L%d+%d' % (name, step[1], step[2]))
+      else:
+        i = step[1]
+        wp, sc, sh, cout, pool = layers[i]
+        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i])
+        src = bufs[i]
+        self._mark('%s_L%d' % (name, i))
+    return src
 
   def _box_step(self, b, tt):
     """box_model.py:484-513: greedy GT match (never accumulated), canvas from noisy GT, score.

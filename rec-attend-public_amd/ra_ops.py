@@ -104,6 +104,41 @@ def pack_ctrl_weights(desc, lstm, gmlp, cmlp):
   return out
 
 
+def ctrl_split_supported(desc):
+  return bool(rn.lib().ra_ctrl_split_supported(C.byref(desc)))
+
+
+def pack_ctrl_split_weights(desc, lstm, gmlp, cmlp):
+  n = rn.lib().ra_ctrl_split_packed_floats(C.byref(desc))
+  if n == 0:
+    raise rn.RecAttendError('descriptor not supported by the split controller')
+  order = ['w_xi', 'w_hi', 'b_i', 'w_xf', 'w_hf', 'b_f', 'w_xu', 'w_hu', 'b_u', 'w_xo', 'w_ho',
+           'b_o']
+  la = [_np32(lstm[k]) for k in order]
+  ga = [_np32(a) for wb in gmlp for a in wb]
+  ca = [_np32(a) for wb in cmlp for a in wb]
+  arr = lambda xs: (C.c_void_p * len(xs))(*[x.ctypes.data for x in xs])
+  out = np.empty(n, dtype=np.float32)
+  check(rn.lib().ra_ctrl_split_pack_weights(C.byref(desc), arr(la), arr(ga), arr(ca), ptr(out)),
+        'ra_ctrl_split_pack_weights')
+  return out
+
+
+def ctrl_split_workspace(desc, B, device):
+  """Zero-filled exchange workspace (+ status word) for ONE stream of launches."""
+  nb = rn.lib().ra_ctrl_split_workspace_bytes(C.byref(desc), B)
+  return (torch.zeros((nb + 7) // 8, dtype=torch.int64, device=device),
+          torch.zeros(1, dtype=torch.int32, device=device))
+
+
+def controller_split(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
+  _need_cuda(feat, wp, h_last, ctrl_out, gmaps, attn)
+  check(rn.lib().ra_controller_split_f32(C.byref(desc), ptr(feat), ptr(wp), feat.shape[0],
+                                         ptr(h_last), ptr(ctrl_out), ptr(gmaps), ptr(attn),
+                                         ptr(ws), ws.numel() * 8, ptr(status), rn.stream_ptr()),
+        'ra_controller_split_f32')
+
+
 # ---------------------------------------------------------------------------- device ops
 
 
@@ -120,6 +155,26 @@ def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample
   check(rn.lib().ra_conv3x3_f32(ptr(src0), C0, ptr(src1), C1, B, Hs, Ws, int(upsample), ptr(wp),
                                 ptr(scale), ptr(shift), int(cout), int(relu), int(pool),
                                 ptr(out), rn.stream_ptr()), 'ra_conv3x3_f32')
+  return out
+
+
+def conv_pair_supported(cin, cout_a, cout_b):
+  return bool(rn.lib().ra_conv_pair_supported(int(cin), int(cout_a), int(cout_b)))
+
+
+def conv_pair(src, wpA, scA, shA, coutA, wpB, scB, shB, coutB, poolB=1, upsampleA=False,
+              reluA=True, reluB=True, out=None):
+  """Two fused conv layers (A: no pool / optional stride-2 transposed; B: pool 1|2)."""
+  _need_cuda(src, wpA, scA, shA, wpB, scB, shB, out)
+  B, Hs, Ws, C0 = src.shape
+  up = 2 if upsampleA else 1
+  Ho, Wo = Hs * up // poolB, Ws * up // poolB
+  if out is None:
+    out = torch.empty((B, Ho, Wo, coutB), dtype=torch.float32, device=src.device)
+  check(rn.lib().ra_conv_pair_f32(ptr(src), C0, B, Hs, Ws, int(upsampleA), ptr(wpA), ptr(scA),
+                                  ptr(shA), int(coutA), int(reluA), ptr(wpB), ptr(scB), ptr(shB),
+                                  int(coutB), int(reluB), int(poolB), ptr(out), rn.stream_ptr()),
+        'ra_conv_pair_f32')
   return out
 
 

@@ -95,6 +95,60 @@ def test_conv_transpose(cuda, B, H, W, Cx, Cs, Co, stride):
   assert relerr(y, ref) < 2e-5
 
 
+PAIR_CASES = [
+    # B, H, W, Cin, CoutA, CoutB, poolB, upsA
+    (2, 64, 64, 4, 8, 8, 2, False),     # ctrl L0+L1
+    (1, 48, 80, 8, 16, 16, 2, False),   # ctrl L2+L3
+    (2, 32, 32, 16, 32, 32, 2, False),  # ctrl L4+L5
+    (3, 48, 48, 4, 8, 8, 2, False),     # attn a0+a1 (narrow tiles)
+    (2, 24, 24, 8, 16, 16, 2, False),   # a2+a3
+    (2, 12, 12, 16, 32, 32, 2, False),  # a4+a5
+    (2, 6, 6, 32, 32, 32, 1, True),     # dcnn d0 (stride-2 transposed) + d1
+    (2, 12, 12, 32, 16, 16, 1, True),   # d2+d3
+    (1, 24, 24, 16, 8, 8, 1, True),     # d4+d5
+    (1, 20, 36, 8, 8, 1, 1, False),     # CoutB = 1, ragged tiles
+    (8, 128, 128, 4, 8, 8, 2, False),   # many tiles -> big geometry
+]
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Ca,Cb,poolB,ups', PAIR_CASES)
+def test_conv_pair(cuda, B, H, W, Ci, Ca, Cb, poolB, ups):
+  assert ops.conv_pair_supported(Ci, Ca, Cb)
+  rng = np.random.RandomState(H * 3 + Ci + Ca + Cb)
+  x = rng.randn(B, H, W, Ci).astype(np.float32)
+  mk_bn = lambda c: tuple(a.astype(np.float32) for a in (
+      rng.randn(c) * 0.2, rng.uniform(0.5, 1.5, c) * rng.choice([-1, 1], c), rng.randn(c) * 0.2,
+      rng.uniform(0.5, 1.5, c)))
+  bA, bB, bnA, bnB = rng.randn(Ca).astype(np.float32) * 0.1, rng.randn(Cb).astype(np.float32) * 0.1, \
+      mk_bn(Ca), mk_bn(Cb)
+  f64 = lambda t: tuple(a.astype(np.float64) for a in t)
+  if ups:
+    wA = (rng.randn(3, 3, Ca, Ci) / np.sqrt(9 * Ci)).astype(np.float32)
+    wB = (rng.randn(3, 3, Cb, Ca) / np.sqrt(9 * Ca)).astype(np.float32)
+    h = ora.conv2d_transpose(x.astype(np.float64), wA.astype(np.float64), 2) + bA
+    h = ora.relu(ora.batch_norm_eval(h, *f64(bnA)))
+    ref = ora.conv2d_transpose(h, wB.astype(np.float64), 1) + bB
+  else:
+    wA = (rng.randn(3, 3, Ci, Ca) / np.sqrt(9 * Ci)).astype(np.float32)
+    wB = (rng.randn(3, 3, Ca, Cb) / np.sqrt(9 * Ca)).astype(np.float32)
+    h = ora.relu(ora.batch_norm_eval(ora.conv2d(x.astype(np.float64), wA.astype(np.float64)) + bA,
+                                     *f64(bnA)))
+    ref = ora.conv2d(h, wB.astype(np.float64)) + bB
+  ref = ora.relu(ora.batch_norm_eval(ref, *f64(bnB)))
+  if poolB > 1:
+    ref = ora.max_pool(ref, poolB)
+  wpA = dev(ops.pack_conv_weights(wA, transposed=ups), cuda)
+  wpB = dev(ops.pack_conv_weights(wB, transposed=ups), cuda)
+  scA, shA = ops.fold_bn(bA, Ca, bnA)
+  scB, shB = ops.fold_bn(bB, Cb, bnB)
+  y = ops.conv_pair(dev(x, cuda), wpA, dev(scA, cuda), dev(shA, cuda), Ca, wpB, dev(scB, cuda),
+                    dev(shB, cuda), Cb, poolB=poolB, upsampleA=ups)
+  torch.cuda.synchronize()
+  y = y.cpu().numpy()
+  assert y.shape == ref.shape
+  assert relerr(y, ref) < 3e-5
+
+
 def _ctrl_setup(opt, seed):
   d = ora.derive(opt)
   P = ora.random_params(opt, seed)
@@ -141,6 +195,48 @@ def test_controller(cuda, arch, H, W, flags):
   else:
     assert relerr(a[:, 6], np.exp(co[:, 6])) < 1e-4 and np.abs(a[:, 8] - co[:, 8]).max() < 1e-4
   assert relerr(a[:, 7], np.exp(co[:, 7])) < 1e-4
+
+
+@pytest.mark.parametrize('arch,H,W,flags', [
+    ('cvppp', 128, 128, {}),
+    ('cvppp', 224, 224, {'squash_ctrl_params': True}),   # G = 49 -> gs = 4, padded logits
+    ('kitti', 128, 448, {}),
+    ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2, 'num_glimpse_mlp_layers': 3}),
+    ('cvppp', 512, 512, {'num_glimpse_mlp_layers': 1}),
+])
+def test_controller_split(cuda, arch, H, W, flags):
+  """The 16-workgroup LDS-stationary controller: same maths, exchanged through tagged granules;
+  launched three times on the same workspace (generation tags, as under HIP-graph replay)."""
+  opt = ora.make_opt(arch, H, W, 2, **flags)
+  d, P = _ctrl_setup(opt, 4)
+  B = 5
+  Cf = d['ccnn_channels'][-1]
+  desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
+                            opt['ctrl_mlp_dim'], H, W, 48, 48, d['squash'], d['fixed_var'],
+                            d['dynamic_var'], d['fixed_gamma'])
+  assert ops.ctrl_split_supported(desc)
+  lstm = {k[len('ctrl_lstm_'):]: v for k, v in P.items() if k.startswith('ctrl_lstm_')}
+  gmw = [(P['glimpse_mlp_w_%d' % i], P['glimpse_mlp_b_%d' % i]) for i in range(d['n_gmlp'])]
+  cmw = [(P['ctrl_mlp_w_%d' % i], P['ctrl_mlp_b_%d' % i]) for i in range(d['n_cmlp'])]
+  wp = dev(ops.pack_ctrl_split_weights(desc, lstm, gmw, cmw), cuda)
+  ws, status = ops.ctrl_split_workspace(desc, B, cuda)
+  P64 = {k: v.astype(np.float64) for k, v in P.items()}
+  z = lambda *s: torch.full(s, 7.0, dtype=torch.float32, device=cuda)
+  for rep in range(3):
+    rng = np.random.RandomState(50 + rep)
+    feat = np.maximum(rng.randn(B, d['G'], Cf), 0).astype(np.float32)
+    h, co, gm = ora._controller(d, P64, feat.astype(np.float64), np.dtype(np.float64))
+    cn, ls, ctr, size, lv = ora._decode_ctrl(d, co, np.dtype(np.float64))
+    h_last, ctrl_out, gmaps, attn = z(B, d['hid']), z(B, 9), z(B, d['iters'], d['G']), z(B, 16)
+    ops.controller_split(desc, dev(feat, cuda), wp, h_last, ctrl_out, gmaps, attn, ws, status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    assert relerr(h_last.cpu().numpy(), h) < 5e-5
+    assert np.abs(ctrl_out.cpu().numpy() - co).max() < 5e-5
+    assert np.abs(gmaps.cpu().numpy() - gm).max() < 1e-5
+    a = attn.cpu().numpy()
+    assert np.abs(a[:, 0:2] - ctr).max() < 1e-3 * max(H, W) / 100
+    assert relerr(a[:, 2:4], size) < 1e-4 and np.abs(a[:, 4:6] - lv).max() < 1e-4
 
 
 def _attn_rec(B, H, W, rng, big_var=False):

@@ -55,11 +55,18 @@ def main():
   src = b['img']
   tot_f, per_f = bench.encoder_flops_per_image(d)
   for i, (wp, sc, sh, cout, pool) in enumerate(Wt['ccnn']):
-    if want('conv'):
+    if want('conv_L'):
       s_ = src
       us = timeit(lambda: ops.conv3x3(s_, wp, sc[0], sh[0], cout, relu=True, pool=pool, out=b['ccnn'][i]))
       res['conv_L%d' % i] = (us, per_f[i] * B / us / 1e6)
     src = b['ccnn'][i]
+  if want('pair'):
+    for step in eng.plan['ccnn']:
+      first = step[1]
+      s0 = b['img'] if first == 0 else b['ccnn'][first - 1]
+      fl = sum(per_f[i] for i in step[1:])
+      us = timeit(lambda: eng._run_cnn([step], Wt['ccnn'], s0, b['ccnn'], 0, 'x'))
+      res['pair_' + '+'.join(str(i) for i in step[1:])] = (us, fl * B / us / 1e6)
   if want('controller'):
     res['controller'] = (timeit(lambda: ops.controller(eng.desc, src, Wt['ctrl'], b['h_last'][0],
                                                        b['ctrl_out'][0], b['gmaps'][0], b['attn'][0])), 0)
