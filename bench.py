@@ -123,6 +123,7 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
+  ap.add_argument('--stagger-us', type=float, default=None)
   args = ap.parse_args()
 
   import ra_dist
@@ -139,6 +140,8 @@ def main():
   eng = model.engine
   eng.use_graph = not args.no_graph
   eng.nsub = args.nsub
+  if args.stagger_us is not None:
+    eng.stagger_us = args.stagger_us
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
   feed = {'x': x, 'phase_train': False}
@@ -177,12 +180,16 @@ def main():
     Bs = sb['img'].shape[0]
     Fh, Fw = d['Fh'], d['Fw']
 
-    def graph_time_us(fn, reps=30):
+    def graph_time_us(fn, reps=20, inner=8):
+      """Average duration of one `fn` launch group: `inner` copies are captured in one HIP graph
+      (a replay has a fixed ~10 us cost that must not be charged to the kernels) and the graph is
+      replayed `reps` times between two HIP events on the launch stream."""
       fn()
       torch.cuda.synchronize()
       g = torch.cuda.CUDAGraph()
       with torch.cuda.graph(g):
-        fn()
+        for _ in range(inner):
+          fn()
       for _ in range(3):
         g.replay()
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -192,17 +199,17 @@ def main():
         g.replay()
       e1.record()
       torch.cuda.synchronize()
-      return 1e3 * e0.elapsed_time(e1) / reps
+      return 1e3 * e0.elapsed_time(e1) / (reps * inner)
 
     def enc_step(step):
       first = step[1]
       src = sb['img'] if first == 0 else sb['ccnn'][first - 1]
-      eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], 0, 'ctrl_cnn')
+      eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], 0, 'ctrl_cnn', plane=sb.get('canvas'))
 
     tot_f, per_f = encoder_flops_per_image(d)
     layers = []
     for step in eng.plan['ccnn']:
-      us = graph_time_us(lambda: [enc_step(step) for _ in range(4)]) / 4.0
+      us = graph_time_us(lambda: enc_step(step))
       fl = sum(per_f[i] for i in step[1:])
       layers.append({'layers': list(step[1:]), 'fused': step[0] == 'pair', 'avg_us': us,
                      'gflop': fl * Bs / 1e9, 'tflops': fl * Bs / (us * 1e-6) / 1e12})
@@ -219,16 +226,23 @@ def main():
         'layers': layers}
 
     def attn_group():
-      ops.extract_patch(sb['img'], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], Fh, Fw,
-                        d['C0p'], True, sb['x_patch'][0])
-      ops.paste_canvas(sb['y_out_patch'][0], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], -5.0,
-                       d['disable_overwrite'], sb['img'], d['D'], sb['y_out'].data_ptr(),
-                       T * S * S, sb['u_ws'], S, S)
+      if eng.direct_attn:
+        ops.extract_direct(sb['img'], 0, sb['attn'][0], Fh, Fw, d['C0p'], True, sb['x_patch'][0],
+                           canvas=sb['canvas'], canvas_chan=d['D'])
+        ops.paste_direct(sb['y_out_patch'][0], 0, sb['attn'][0], -5.0, d['disable_overwrite'],
+                         sb['y_out'].data_ptr(), T * S * S, S, S, canvas=sb['canvas'])
+      else:
+        ops.extract_patch(sb['img'], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], Fh, Fw,
+                          d['C0p'], True, sb['x_patch'][0])
+        ops.paste_canvas(sb['y_out_patch'][0], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], -5.0,
+                         d['disable_overwrite'], sb['img'], d['D'], sb['y_out'].data_ptr(),
+                         T * S * S, sb['u_ws'], S, S)
 
     attn_us = graph_time_us(attn_group)
     attn_bytes = float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs
     out['roofline_attn'] = {
-        'kernel': 'extract_patch + paste_u + paste (attention resample, one sub-batch)', 'bound': 'hbm',
+        'kernel': 'ra::attnd::extract_direct_kernel + paste_direct_kernel (attention resample, one '
+                  'sub-batch)', 'bound': 'hbm',
         'achieved': attn_bytes / (attn_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
         'frac': attn_bytes / (attn_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': None,
         'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': attn_us}

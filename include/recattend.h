@@ -95,9 +95,12 @@ int ra_conv_pack_weights(const float *w, int Cin_w, int Cout, int Cin, const int
 int ra_conv_fold_bn(const float *bias, const float *beta, const float *gamma, const float *mean,
                     const float *var, int Cout, float eps, float *scale, float *shift);
 
+/* plane (nullable): a [B,Hs,Ws] tensor that REPLACES input channel plane_chan of src0 — the
+ * canvas kept outside the packed image (full_model.py:648: canvas is one channel of ccnn_inp). */
 int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws,
                    int upsample, const float *wpacked, const float *scale, const float *shift,
-                   int Cout, int relu, int pool, float *y, void *stream);
+                   int Cout, int relu, int pool, const float *plane, int plane_chan, float *y,
+                   void *stream);
 
 /* Two consecutive layers fused in one launch (the intermediate activation stays in LDS):
  *   A: conv3x3 + scale/shift [+ReLU], no pool, optional zero-stuffed (stride-2 transposed) input
@@ -108,7 +111,7 @@ int ra_conv_pair_supported(int Cin, int CoutA, int CoutB);
 int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsampleA,
                      const float *wpA, const float *scaleA, const float *shiftA, int CoutA, int reluA,
                      const float *wpB, const float *scaleB, const float *shiftB, int CoutB, int reluB,
-                     int poolB, float *y, void *stream);
+                     int poolB, const float *plane, int plane_chan, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * K2  controller: glimpse read-out + LSTM + glimpse MLP (x iters) + controller MLP +
@@ -214,6 +217,19 @@ int ra_attn_box_f32(const float *attn, const float *fy, const float *fx, const i
                     int H, int W, int Fh, int Fw, float beta, float *box_out, size_t stride_b,
                     void *stream);
 
+/* Direct forms of the same three operators: the filter weights are computed on the fly from the
+ * attention records (no fy/fx/band tables, no u_ws), so a timestep needs two launches, and the
+ * canvas may live in its own plane `canvas` [B,H,W] (then channel canvas_chan of img is ignored /
+ * untouched); with canvas == NULL the canvas is channel canvas_chan of img as above. */
+int ra_extract_direct_f32(const float *img, int Ci, int chan0, const float *canvas, int canvas_chan,
+                          const float *attn, int B, int H, int W, int Fh, int Fw, int Cp,
+                          int use_gamma, float *patch, void *stream);
+int ra_paste_direct_f32(const float *patch, int Cp, int pc, const float *attn, int B, int H, int W,
+                        int Fh, int Fw, float beta, int disable_overwrite, float *canvas, float *img,
+                        int Ci, int canvas_chan, float *y_out, size_t y_stride_b, void *stream);
+int ra_attn_box_direct_f32(const float *attn, int B, int H, int W, int Fh, int Fw, float beta,
+                           float *box_out, size_t stride_b, void *stream);
+
 /* Generic dense extract_patch with caller-supplied filters (the operator surface of
  * modellib.extract_patch for arbitrary f_y [B,H,FH], f_x [B,W,FW]; x [B,H,W,D]). */
 int ra_extract_patch_dense_f32(const float *x, const float *f_y, const float *f_x, int B, int H,
@@ -245,6 +261,11 @@ int ra_affine_act_f32(const float *x, const float *scale, const float *shift, si
 /* Stand-alone nnlib.max_pool (nnlib.py:15-25): ksize = stride = ratio, 'SAME' (-inf pad).
  * x [B,H,W,C] -> y [B,ceil(H/ratio),ceil(W/ratio),C]. */
 int ra_max_pool_f32(const float *x, int B, int H, int W, int C, int ratio, float *y, void *stream);
+
+/* Scheduling aid: one idle wave that occupies `stream` for the given time (100 MHz realtime
+ * clock).  The decode engine uses it once per forward to phase-shift its sub-batch streams so
+ * their latency-bound tails overlap the other sub-batch's convolutions. */
+int ra_delay_us_f32(float microseconds, void *stream);
 
 #ifdef __cplusplus
 }

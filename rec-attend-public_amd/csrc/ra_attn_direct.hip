@@ -1,0 +1,293 @@
+// K3 / K5 (direct form) — Gaussian attention read and write driven straight from the attention
+// record: the separable filter weights are computed on the fly (one v_exp per tap-pixel pair)
+// instead of being read back from dense [L,48] tables, so one timestep needs TWO launches
+// (extract, paste) instead of four (filters, extract, paste_u, paste), and the canvas can live in
+// its own [B,H,W] plane: the paste then moves exactly its algorithmic bytes (read canvas, write
+// canvas, write y_out: 12 B per pixel) instead of read-modify-writing 16-byte packed pixel records.
+//   modellib.get_gaussian_filter modellib.py:581-612, extract_patch :615-641,
+//   full_model.py:778-789 (read), :810-818,:843-845 (write + canvas), :738-741 (attention box).
+// Same banding rule as ra_attn.hip: taps whose weight is below exp(-30) of the peak are skipped.
+#include "ra_common.h"
+
+namespace ra {
+namespace attnd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float kBandLog = 30.0f;
+constexpr float kInvSqrt2Pi = 0.3989422804014327f;
+
+struct Axis {  // one axis of one example's filter bank
+  float ctr, step, inv_step, half, inv2var, norm, R;
+  int L, F;
+  __device__ inline float mu(int j) const { return ctr + step * ((float)j - half); }
+  __device__ inline float w(float l, int j) const {  // modellib.py:610-611
+    const float d = l - mu(j);
+    return norm * __expf(-d * d * inv2var);
+  }
+  // pixel band [lo, hi) of tap j
+  __device__ inline void band(int j, int &lo, int &hi) const {
+    const float m = mu(j);
+    float a = ceilf(m - R), c = floorf(m + R) + 1.0f;
+    a = fminf(fmaxf(a, 0.0f), (float)L);
+    c = fminf(fmaxf(c, 0.0f), (float)L);
+    if (!(a == a) || !(c == c)) {
+      a = 0.0f;
+      c = (float)L;
+    }
+    lo = (int)a;
+    hi = (int)c > lo ? (int)c : lo;
+  }
+  // tap range [jlo, jhi) whose band contains pixel l (widened by one tap each side: extra terms
+  // are harmless, missing ones are not)
+  __device__ inline void taps(int l, int &jlo, int &jhi) const {
+    float a = ((float)l - R - ctr) * inv_step + half, c = ((float)l + R - ctr) * inv_step + half;
+    if (!(a == a) || !(c == c) || !(step > 0.0f)) {
+      jlo = 0;
+      jhi = F;
+      return;
+    }
+    a = fminf(fmaxf(floorf(a) - 1.0f, 0.0f), (float)F);
+    c = fminf(fmaxf(ceilf(c) + 2.0f, 0.0f), (float)F);
+    jlo = (int)a;
+    jhi = (int)c;
+  }
+};
+
+__device__ inline Axis make_axis(const float *rec, int axis, int L, int F) {
+  Axis A;
+  const float var = __expf(rec[4 + axis]);
+  A.ctr = rec[0 + axis];
+  A.step = (rec[2 + axis] + 1.0f) / (float)F;       // modellib.py:599
+  A.inv_step = 1.0f / A.step;
+  A.half = ((float)F - 1.0f) / 2.0f;
+  A.inv2var = 0.5f / var;
+  A.norm = kInvSqrt2Pi / sqrtf(var);                // 1/sqrt(var)/sqrt(2 pi)
+  A.R = sqrtf(2.0f * kBandLog * var);
+  A.L = L;
+  A.F = F;
+  return A;
+}
+
+constexpr int kColPass = 512;  // image columns per pass of the extract kernel
+
+// patch[b,j,i,4cg..] = gamma * sum_l sum_w fy(l,j) X[b,l,w,4cg..] fx(w,i); workgroup = (tap j, cg, b)
+__global__ __launch_bounds__(256) void extract_direct_kernel(const float *img, int Ci, int chan0,
+                                                              const float *canvas, int canvas_chan,
+                                                              const float *attn, int H, int W, int Fh,
+                                                              int Fw, int Cp, int use_gamma,
+                                                              float *patch) {
+  __shared__ f32x4 tl[4][kColPass];
+  __shared__ float fyw[256];
+  __shared__ f32x4 part[256];
+  const int t = threadIdx.x, j = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
+  const Axis Ay = make_axis(rec, 0, H, Fh), Ax = make_axis(rec, 1, W, Fw);
+  int l0, l1, w0, w1, tmp;
+  Ay.band(j, l0, l1);
+  Ax.band(0, w0, tmp);
+  Ax.band(Fw - 1, tmp, w1);
+  const float *imb = img + (size_t)b * H * W * Ci + chan0 + 4 * cg;
+  const bool use_canvas = canvas != nullptr && (canvas_chan >= chan0 + 4 * cg) && (canvas_chan < chan0 + 4 * cg + 4);
+  const int cslot = canvas_chan - (chan0 + 4 * cg);
+  const float *cvb = canvas ? canvas + (size_t)b * H * W : nullptr;
+  const int lane = t & 63, rph = t >> 6;
+
+  // stage-2 ownership: output i = t % Fw, k-part = t / Fw  (Fw * nparts <= 256)
+  const int nparts = 256 / Fw;
+  const int oi = t % Fw, op = t / Fw;
+  int bi_lo = 0, bi_hi = 0;
+  if (op < nparts) Ax.band(oi, bi_lo, bi_hi);
+  f32x4 P = f32x4{0, 0, 0, 0};
+
+  for (int wp = w0; wp < w1; wp += kColPass) {
+    const int wend = (wp + kColPass < w1) ? wp + kColPass : w1;
+    const int ncol = wend - wp;
+    // zero the per-phase column sums
+    for (int e = t; e < 4 * kColPass; e += 256) tl[e / kColPass][e % kColPass] = f32x4{0, 0, 0, 0};
+    __syncthreads();
+    for (int lr = l0; lr < l1; lr += 256) {  // rows in chunks of 256 (weights staged in LDS)
+      const int nrow = (l1 - lr) < 256 ? (l1 - lr) : 256;
+      if (t < nrow) fyw[t] = Ay.w((float)(lr + t), j);
+      __syncthreads();
+      // each thread: columns lane + 64*c (c < NCC), rows rph + 4*r; all NCC x U loads of a row
+      // batch are issued before the first FMA (the kernel is latency-, not bandwidth-bound)
+      constexpr int NCC = kColPass / 64, U = 2;
+      f32x4 acc[NCC];
+#pragma unroll
+      for (int c = 0; c < NCC; ++c) acc[c] = f32x4{0, 0, 0, 0};
+      for (int r0 = rph; r0 < nrow; r0 += 4 * U) {
+        f32x4 xv[U][NCC];
+        float cv[U][NCC];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c = 0; c < NCC; ++c) {
+            const int r = r0 + 4 * u, w = wp + 64 * c + lane;
+            const bool ok = (r < nrow) & (w < wend);
+            const int rr = ok ? r : 0, ww = ok ? w : wp;
+            xv[u][c] = *reinterpret_cast<const f32x4 *>(imb + ((size_t)(lr + rr) * W + ww) * Ci);
+            cv[u][c] = use_canvas ? cvb[(size_t)(lr + rr) * W + ww] : 0.0f;
+          }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c = 0; c < NCC; ++c) {
+            const int r = r0 + 4 * u, w = wp + 64 * c + lane;
+            if ((r < nrow) & (w < wend)) {
+              f32x4 x = xv[u][c];
+              if (use_canvas) {
+                x.x = cslot == 0 ? cv[u][c] : x.x;
+                x.y = cslot == 1 ? cv[u][c] : x.y;
+                x.z = cslot == 2 ? cv[u][c] : x.z;
+                x.w = cslot == 3 ? cv[u][c] : x.w;
+              }
+              acc[c] += fyw[r] * x;
+            }
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < NCC; ++c)
+        if (wp + 64 * c + lane < wend) tl[rph][64 * c + lane] += acc[c];
+      __syncthreads();
+    }
+    // stage 2: P[i] += sum_{w in pass and band(i)} (sum_ph tl[ph][w]) * fx(w, i)
+    if (op < nparts) {
+      const int a = bi_lo > wp ? bi_lo : wp, c = bi_hi < wend ? bi_hi : wend;
+      for (int w = a + op; w < c; w += nparts) {
+        const f32x4 T = tl[0][w - wp] + tl[1][w - wp] + tl[2][w - wp] + tl[3][w - wp];
+        P += Ax.w((float)w, oi) * T;
+      }
+    }
+    __syncthreads();
+  }
+  part[t] = P;
+  __syncthreads();
+  if (t < Fw) {
+    f32x4 s = f32x4{0, 0, 0, 0};
+    for (int p = 0; p < nparts; ++p) s += part[p * Fw + t];
+    const float gamma = use_gamma ? rec[6] : 1.0f;
+    *reinterpret_cast<f32x4 *>(patch + (((size_t)b * Fh + j) * Fw + t) * Cp + 4 * cg) = gamma * s;
+  }
+}
+
+__device__ inline float sigmoidf(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+// y[b,l,w] = sigmoid(e^g * sum_j sum_i fy(l,j) P[j,i] fx(w,i) + beta) [* (1 - canvas)];
+// canvas = max(canvas, y).  One workgroup per image row.  MODE 0: paste, 1: attention box.
+template <int MODE>
+__global__ __launch_bounds__(128) void paste_direct_kernel(const float *patch, int Cp, int pc,
+                                                            const float *attn, int H, int W, int Fh,
+                                                            int Fw, float beta, int disable_overwrite,
+                                                            float *canvas, float *img, int Ci,
+                                                            int canvas_chan, float *y_out,
+                                                            size_t y_stride_b) {
+  extern __shared__ float V[];  // [Fw]:  V[i] = sum_j fy(l,j) P[j,i]
+  const int l = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
+  const Axis Ay = make_axis(rec, 0, H, Fh), Ax = make_axis(rec, 1, W, Fw);
+  int jlo, jhi;
+  Ay.taps(l, jlo, jhi);
+  for (int i = t; i < Fw; i += blockDim.x) {
+    float s = 0.0f;
+    if (MODE == 0) {
+      const float *pb = patch + ((size_t)b * Fh * Fw + i) * Cp + pc;
+      for (int j = jlo; j < jhi; ++j) s += Ay.w((float)l, j) * pb[(size_t)j * Fw * Cp];
+    } else {
+      for (int j = jlo; j < jhi; ++j) s += Ay.w((float)l, j);  // P == 1 (const_ones)
+    }
+    V[i] = s;
+  }
+  __syncthreads();
+  const float gain = (MODE == 0) ? __expf(rec[8]) : rec[7];
+  float *yrow = y_out + (size_t)b * y_stride_b + (size_t)l * W;
+  float *crow = canvas ? canvas + ((size_t)b * H + l) * W : nullptr;
+  float *prow = (!canvas && img && canvas_chan >= 0) ? img + ((size_t)b * H + l) * W * Ci + canvas_chan : nullptr;
+  const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(yrow) & 15) == 0) &&
+                   (!crow || (reinterpret_cast<uintptr_t>(crow) & 15) == 0);
+  const bool row_live = jlo < jhi;  // uniform: does any tap reach this row at all?
+  const float y_dead = sigmoidf(beta);
+  for (int w4 = t * 4; w4 < W; w4 += blockDim.x * 4) {
+    f32x4 cv = f32x4{0, 0, 0, 0};
+    if (MODE == 0) {
+      if (crow && vec) cv = *reinterpret_cast<const f32x4 *>(crow + w4);
+      else
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (w4 + k < W) cv[k] = crow ? crow[w4 + k] : (prow ? prow[(size_t)(w4 + k) * Ci] : 0.0f);
+    }
+    f32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int w = w4 + k;
+      float v = y_dead;
+      if (row_live) {
+        int ilo, ihi;
+        Ax.taps(w, ilo, ihi);
+        if (ilo < ihi) {
+          float s = 0.0f;
+          for (int i = ilo; i < ihi; ++i) s += V[i] * Ax.w((float)w, i);
+          v = sigmoidf(gain * s + beta);
+        }
+      }
+      if (MODE == 0 && disable_overwrite) v *= (1.0f - cv[k]);
+      y[k] = v;
+      cv[k] = fmaxf(cv[k], v);
+    }
+    if (vec) {
+      *reinterpret_cast<f32x4 *>(yrow + w4) = y;
+      if (MODE == 0 && crow) *reinterpret_cast<f32x4 *>(crow + w4) = cv;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (w4 + k < W) {
+          yrow[w4 + k] = y[k];
+          if (MODE == 0 && crow) crow[w4 + k] = cv[k];
+        }
+    }
+    if (MODE == 0 && prow) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (w4 + k < W) prow[(size_t)(w4 + k) * Ci] = cv[k];
+    }
+  }
+}
+
+}  // namespace attnd
+}  // namespace ra
+
+using namespace ra;
+
+extern "C" int ra_extract_direct_f32(const float *img, int Ci, int chan0, const float *canvas,
+                                     int canvas_chan, const float *attn_rec, int B, int H, int W, int Fh,
+                                     int Fw, int Cp, int use_gamma, float *patch, void *stream) {
+  if (!img || !attn_rec || !patch || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0)
+    return fail(RA_E_INVALID, "ra_extract_direct_f32: bad argument");
+  if (Ci % 4 || Cp % 4 || chan0 % 4 || chan0 + Cp > Ci || Cp <= 0 || Fw > 256)
+    return fail(RA_E_SHAPE, "ra_extract_direct_f32: Ci=%d chan0=%d Cp=%d Fw=%d", Ci, chan0, Cp, Fw);
+  hipLaunchKernelGGL(attnd::extract_direct_kernel, dim3(Fh, Cp / 4, B), dim3(256), 0, as_stream(stream), img,
+                     Ci, chan0, canvas, canvas_chan, attn_rec, H, W, Fh, Fw, Cp, use_gamma, patch);
+  return launch_status("ra_extract_direct_f32");
+}
+
+extern "C" int ra_paste_direct_f32(const float *patch, int Cp, int pc, const float *attn_rec, int B, int H,
+                                   int W, int Fh, int Fw, float beta, int disable_overwrite,
+                                   float *canvas, float *img, int Ci, int canvas_chan, float *y_out,
+                                   size_t y_stride_b, void *stream) {
+  if (!patch || !attn_rec || !y_out || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0 || Cp <= 0 ||
+      pc < 0 || pc >= Cp)
+    return fail(RA_E_INVALID, "ra_paste_direct_f32: bad argument");
+  hipLaunchKernelGGL(attnd::paste_direct_kernel<0>, dim3(H, B), dim3(128), Fw * sizeof(float),
+                     as_stream(stream), patch, Cp, pc, attn_rec, H, W, Fh, Fw, beta, disable_overwrite, canvas,
+                     img, Ci, canvas_chan, y_out, y_stride_b);
+  return launch_status("ra_paste_direct_f32");
+}
+
+extern "C" int ra_attn_box_direct_f32(const float *attn_rec, int B, int H, int W, int Fh, int Fw, float beta,
+                                      float *box_out, size_t stride_b, void *stream) {
+  if (!attn_rec || !box_out || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0)
+    return fail(RA_E_INVALID, "ra_attn_box_direct_f32: bad argument");
+  hipLaunchKernelGGL(attnd::paste_direct_kernel<1>, dim3(H, B), dim3(128), Fw * sizeof(float),
+                     as_stream(stream), nullptr, 1, 0, attn_rec, H, W, Fh, Fw, beta, 0, nullptr, nullptr, 0, -1,
+                     box_out, stride_b);
+  return launch_status("ra_attn_box_direct_f32");
+}

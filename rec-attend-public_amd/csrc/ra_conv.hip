@@ -53,6 +53,8 @@ struct Args {
   int Ho, Wo;
   int ablate;  // tuning aid (RA_CONV_ABLATE): 1 skip epilogue, 2 skip staging, 4 skip MFMA loop
   int bytes0, bytes1, bytes_y;  // tensor sizes for the buffer descriptors (each < 2 GiB)
+  const float *plane;           // optional [B,Hs,Ws] plane that REPLACES input channel plane_chan
+  int plane_chan, bytes_p;      // (the canvas, kept outside the packed image)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +95,7 @@ struct Geo {
 // SWAP = true : weights are the A operand -> a lane's 4 accumulators are 4 consecutive channels of
 //   one pixel (no-pool layers: one 16-byte store per lane instead of four 4-byte stores).
 template <int CK, int NC, int WN, int GX, int GY, bool SWAP>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
   using G = Geo<CK, NC, WN, GX, GY>;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // 2 * G::LDS_FLOATS
   constexpr int NPIX = G::LH * G::LW;        // pixel records of one staged chunk
@@ -115,8 +117,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x
   const int co_lane = lane & 15;
   const int qo = lane >> 4;  // D rows 4*qo + r -> pooled x position qo, window element r
 
+  // multi-chunk layers with one cout group per wave prefetch the NEXT chunk's B operand into a
+  // second register set while the MFMAs of the current chunk run (36 more VGPRs); otherwise the
+  // weight reload between chunks is an exposed L2 round trip on every item
+  constexpr bool BDB = (NC == 1) && (G::PM <= 4) && (CK == 16);
   f32x4 acc[G::PM][NC];
   float breg[G::KS][NC];
+  float bnext[BDB ? G::KS : 1][NC];
   // The MFMA is issued as D = W^T-slice x pixels (weights are the A operand), so a lane holds
   // pixel (lane & 15) and, in its 4 accumulator registers, output channels 4*(lane>>4)..+3:
   // the epilogue stores one float4 per lane.  Per-lane epilogue constants, loaded once:
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x
   const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src0, a.bytes0);
   const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src1 ? a.src1 : a.src0, a.src1 ? a.bytes1 : 0);
   const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.y, a.bytes_y);
+  const __amdgpu_buffer_rsrc_t rsp = make_rsrc(a.plane ? a.plane : a.src0, a.plane ? a.bytes_p : 0);
   f32x4 st[NST][G::NCG];
 
   auto zero_acc = [&]() {
@@ -150,6 +158,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x
 #pragma unroll
       for (int n = 0; n < NC; ++n) breg[s][n] = wrow[(size_t)s * 4 * a.CoutP + 16 * n];
   };
+  auto load_b_next = [&](int ch) {
+    if constexpr (BDB) {
+      const float *wrow = a.wp + ((size_t)ch * G::KS * 4 + ksub) * a.CoutP + 16 * (wn * NC) + co_lane;
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) bnext[s][n] = wrow[(size_t)s * 4 * a.CoutP + 16 * n];
+    }
+  };
+  auto swap_b = [&]() {
+    if constexpr (BDB) {
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) breg[s][n] = bnext[s][n];
+    }
+  };
   auto tile_origin = [&](int T, int &b, int &ty0, int &tx0) {  // wave-uniform (scalar ALU)
     const int per = tiles_x * tiles_y;
     b = T / per;
@@ -161,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x
   // address arithmetic is then one add + four compares per pixel (32-bit; 64-bit multiplies per
   // load cost as much VALU time as the MFMAs they feed).  Tile origins are even, so for the
   // zero-stuffed (stride-2 transposed) input  (ty0 + r - 1) >> 1 == ty0/2 + ((r - 1) >> 1).
-  int rel_r[NST], rel_c[NST], off0[NST], off1[NST];
+  int rel_r[NST], rel_c[NST], off0[NST], off1[NST], offp[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
     const int e = tid + 256 * i;
@@ -171,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x
     const int xs = a.ups ? (rel_c[i] >> 1) : rel_c[i];
     off0[i] = (ys * a.Ws + xs) * a.C0;
     off1[i] = (ys * a.Ws + xs) * a.C1;
+    offp[i] = ys * a.Ws + xs;
     if (e >= NPIX) rel_r[i] = -(1 << 28);  // never in range
     if (a.ups && !((rel_r[i] & 1) && (rel_c[i] & 1))) rel_r[i] = -(1 << 28);  // stuffed zero
   }
@@ -191,6 +217,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x
         if (chan < a.C0) {
           const int off = ok ? (pbase * a.C0 + off0[i] + chan) * 4 : kOOB;
           st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+          if (a.plane && chan == (a.plane_chan & ~3)) {  // uniform: the canvas lives in its own plane
+            const float pv = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsp, ok ? (pbase + offp[i]) * 4 : kOOB, 0, 0));
+            const int slot = a.plane_chan & 3;
+            st[i][cg].x = slot == 0 ? pv : st[i][cg].x;
+            st[i][cg].y = slot == 1 ? pv : st[i][cg].y;
+            st[i][cg].z = slot == 2 ? pv : st[i][cg].z;
+            st[i][cg].w = slot == 3 ? pv : st[i][cg].w;
+          }
         } else {
           const int off = ok ? (pbase * a.C1 + off1[i] + chan - a.C0) * 4 : kOOB;
           st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
@@ -340,13 +375,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const Args a, int tiles_x
     }
     const bool has_next = nT < ntiles;
     if (has_next && !(a.ablate & 2)) load_item(nT, nch);  // in flight across the MFMA loop
+    if (BDB && has_next && nchunks > 1) load_b_next(nch);
     if (!(a.ablate & 4)) compute(buf);
     if (ch == nchunks - 1) {
       if (!(a.ablate & 1)) epilogue(T);
       zero_acc();
     }
     if (!has_next) break;
-    if (nchunks > 1) load_b(nch);
+    if (nchunks > 1) {
+      if constexpr (BDB) swap_b();
+      else load_b(nch);
+    }
     if (!(a.ablate & 2)) store_item(buf ^ 1);
     __syncthreads();
     buf ^= 1;
@@ -502,8 +541,8 @@ extern "C" int ra_conv_fold_bn(const float *bias, const float *beta, const float
 
 extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs,
                               int Ws, int upsample, const float *wpacked, const float *scale,
-                              const float *shift, int Cout, int relu, int pool, float *y,
-                              void *stream) {
+                              const float *shift, int Cout, int relu, int pool, const float *plane,
+                              int plane_chan, float *y, void *stream) {
   if (!src0 || !wpacked || !scale || !shift || !y || B <= 0 || Hs <= 0 || Ws <= 0 || C0 <= 0 ||
       C1 < 0 || (C1 > 0 && !src1))
     return ra::fail(RA_E_INVALID, "ra_conv3x3_f32: bad argument");
@@ -547,6 +586,11 @@ extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int 
     a.bytes0 = (int)n0;
     a.bytes1 = (int)n1;
     a.bytes_y = (int)ny;
+    a.plane = plane;
+    a.plane_chan = plane_chan;
+    a.bytes_p = (int)((size_t)B * Hs * Ws * 4);
+    if (plane && (plane_chan < 0 || plane_chan >= C0))
+      return ra::fail(RA_E_INVALID, "ra_conv3x3_f32: plane channel %d of %d", plane_chan, C0);
   }
   const int Cin = C0 + C1;
   const int CK = ra::conv::chunk_of(Cin);

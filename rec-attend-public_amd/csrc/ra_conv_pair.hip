@@ -22,6 +22,8 @@ struct PArgs {
   const float *wpA, *scA, *shA, *wpB, *scB, *shB;
   int C0, Hs, Ws, H, W, ups;
   int CoutAP, CoutB, CoutBP, poolB, Ho, Wo, reluA, reluB;
+  const float *plane;  // optional [B,Hs,Ws] plane replacing input channel plane_chan (the canvas)
+  int plane_chan;
   int ablate;  // tuning aid (RA_PAIR_ABLATE): 1 no stores, 2 no input loads, 4 no phase A, 8 no phase B MFMA
 };
 
@@ -85,6 +87,17 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
       for (int cg = 0; cg < G::NCGA; ++cg) {
         v[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok && !(a.ablate & 2)) v[cg] = *reinterpret_cast<const f32x4 *>(base + (ys * a.Ws + xs) * a.C0 + 4 * cg);
+      }
+      if (a.plane && ok) {
+        const float pv = a.plane[(size_t)(b * a.Hs + sy0 + ys) * a.Ws + sx0 + xs];
+        const int pg = a.plane_chan >> 2, slot = a.plane_chan & 3;
+#pragma unroll
+        for (int cg = 0; cg < G::NCGA; ++cg) {  // selects, not runtime register indexing
+          v[cg].x = (cg == pg && slot == 0) ? pv : v[cg].x;
+          v[cg].y = (cg == pg && slot == 1) ? pv : v[cg].y;
+          v[cg].z = (cg == pg && slot == 2) ? pv : v[cg].z;
+          v[cg].w = (cg == pg && slot == 3) ? pv : v[cg].w;
+        }
       }
       float *rec = tin + e * CINA;
 #pragma unroll
@@ -315,7 +328,8 @@ extern "C" int ra_conv_pair_supported(int Cin, int CoutA, int CoutB) {
 extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsampleA,
                                 const float *wpA, const float *scaleA, const float *shiftA, int CoutA,
                                 int reluA, const float *wpB, const float *scaleB, const float *shiftB,
-                                int CoutB, int reluB, int poolB, float *y, void *stream) {
+                                int CoutB, int reluB, int poolB, const float *plane, int plane_chan,
+                                float *y, void *stream) {
   if (!src || !wpA || !scaleA || !shiftA || !wpB || !scaleB || !shiftB || !y || B <= 0 || Hs <= 0 ||
       Ws <= 0)
     return fail(RA_E_INVALID, "ra_conv_pair_f32: bad argument");
@@ -346,6 +360,9 @@ extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws
   a.Wo = a.W / poolB;
   a.reluA = reluA;
   a.reluB = reluB;
+  a.plane = plane;
+  a.plane_chan = plane_chan;
+  if (plane && (plane_chan < 0 || plane_chan >= Cin)) return fail(RA_E_INVALID, "ra_conv_pair_f32: plane channel");
   {
     static int abl = -1;
     if (abl < 0) {

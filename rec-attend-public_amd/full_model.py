@@ -178,6 +178,8 @@ class Model(dict):
     if name == 'ctrl_rnn_glimpse_map':
       b['gmaps'] = eng.fetch('gmaps')
     if name == 'canvas':
+      if eng.direct_attn:
+        return eng.fetch('canvas').unsqueeze(-1).contiguous()
       b['img'] = eng.fetch('img')
     a = b['attn']  # [T,B,16]
     if name == 'x_patch':

@@ -38,9 +38,11 @@ class DecodeEngine(object):
     self._stamp = None
     self._B = None
     self._graphs = {}
+    self.direct_attn = True   # table-free extract / paste kernels + the canvas in its own plane
     self.fuse_pairs = True  # fused two-layer conv launches in the controller CNN where it pays
     self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
+    self.stagger_us = 0.0  # start sub-batch k this many microseconds * k late (phase shift)
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = choose from the batch size
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -230,6 +232,8 @@ class DecodeEngine(object):
     for k in range(nsub):
       b = {kk: v[k * Bs:(k + 1) * Bs] for kk, v in g.items() if kk != 'noise'}
       b['img'] = f(Bs, H, W, d['C0p'])
+      if self.direct_attn:
+        b['canvas'] = f(Bs, H, W)
       hh, ww = H, W
       b['ccnn'] = []
       for i in range(d['ccnn_nlayers']):
@@ -279,7 +283,7 @@ class DecodeEngine(object):
     parts = [sb[name] for sb in self.subs]
     if len(parts) == 1:
       return parts[0]
-    dim = 0 if name in ('img', 'fy', 'fx') else 1
+    dim = 0 if name in ('img', 'fy', 'fx', 'canvas') else 1
     return torch.cat(parts, dim=dim)
 
   # ------------------------------------------------------------------ launch sequence
@@ -308,17 +312,42 @@ class DecodeEngine(object):
     for sb, st in zip(self.subs, self.streams):
       st.wait_stream(main)
       with torch.cuda.stream(st):
-        self._launch_sub(sb, want_box)
+        self._launch_pack(sb)
+    # Stagger the streams: the chip-filling controller-CNN phases of the sub-batches are chained
+    # by events (enc(k,t) after enc(k-1,t); enc(0,t) after enc(last,t-1)), so one sub-batch's
+    # latency-bound tail (controller, patch convs, paste: a few dozen workgroups) runs UNDER the
+    # next sub-batch's convolutions instead of all sub-batches idling the chip in lockstep.
+    # Phase-shift the streams once: sub-batch k starts k * stagger_us late, so its latency-bound
+    # tail (controller, patch convs, paste: a few dozen workgroups) runs under another
+    # sub-batch's chip-filling convolutions instead of all sub-batches idling in lockstep.
+    for k, (sb, st) in enumerate(zip(self.subs, self.streams)):
+      with torch.cuda.stream(st):
+        if self.stagger_us and k:
+          ops.delay_us(self.stagger_us * k)
+        for tt in range(self.d['T']):
+          self._launch_tail(sb, tt, want_box, self._launch_encoder(sb, tt))
     for st in self.streams:
       main.wait_stream(st)
 
   def _launch_sub(self, b, want_box):
+    self._launch_pack(b)
+    for tt in range(self.d['T']):
+      self._launch_tail(b, tt, want_box, self._launch_encoder(b, tt))
+
+  def _launch_encoder(self, b, tt):
+    return self._run_cnn(self.plan['ccnn'], self.W['ccnn'], b['img'], b['ccnn'], tt, 'ctrl_cnn',
+                         plane=b.get('canvas'))
+
+  def _launch_pack(self, b):
+    ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), self.d['C0p'], b['img'])
+    if 'canvas' in b:
+      b['canvas'].zero_()  # full_model.py:239
+    self._mark('pack')
+
+  def _launch_tail(self, b, tt, want_box, src):
     d, Wt, T = self.d, self.W, self.d['T']
     H, W, Fh, Fw = d['H'], d['W'], d['Fh'], d['Fw']
-    ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), d['C0p'], b['img'])
-    self._mark('pack')
-    for tt in range(T):
-      src = self._run_cnn(self.plan['ccnn'], Wt['ccnn'], b['img'], b['ccnn'], tt, 'ctrl_cnn')
+    if True:
       if 'ctrl_ws' in b:
         ops.controller_split(self.desc, src, Wt['ctrl_split'], b['h_last'][tt], b['ctrl_out'][tt],
                              b['gmaps'][tt], b['attn'][tt], b['ctrl_ws'], b['ctrl_status'])
@@ -326,18 +355,28 @@ class DecodeEngine(object):
         ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
                        b['gmaps'][tt], b['attn'][tt])
       self._mark('controller')
-      ops.attn_filters(b['attn'][tt], H, W, Fh, Fw, b['fy'], b['fx'], b['band'])
-      self._mark('filters')
+      direct = self.direct_attn
+      if not direct:
+        ops.attn_filters(b['attn'][tt], H, W, Fh, Fw, b['fy'], b['fx'], b['band'])
+        self._mark('filters')
       if want_box or self.box:
-        ops.attn_box(b['attn'][tt], b['fy'], b['fx'], b['band'], H, W, Fh, Fw, -5.0,
-                     b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
+        if direct:
+          ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0,
+                              b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
+        else:
+          ops.attn_box(b['attn'][tt], b['fy'], b['fx'], b['band'], H, W, Fh, Fw, -5.0,
+                       b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
         self._mark('attn_box')
       if self.box:
         self._box_step(b, tt)
-        continue
+        return
       xp = b['x_patch'][tt]
-      ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
-                        d['C0p'], True, xp)
+      if direct:
+        ops.extract_direct(b['img'], 0, b['attn'][tt], Fh, Fw, d['C0p'], True, xp,
+                           canvas=b['canvas'], canvas_chan=d['D'])
+      else:
+        ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
+                          d['C0p'], True, xp)
       self._mark('extract')
       src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
       core = src
@@ -360,23 +399,31 @@ class DecodeEngine(object):
       ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
                 b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
       self._mark('score')
-      ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
-                       d['disable_overwrite'], b['img'], d['D'],
-                       b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
+      if direct:
+        ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'])
+      else:
+        ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
+                         d['disable_overwrite'], b['img'], d['D'],
+                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
       self._mark('paste')
 
-  def _run_cnn(self, steps, layers, src, bufs, tt, name):
+  def _run_cnn(self, steps, layers, src, bufs, tt, name, plane=None):
+    """plane: the canvas plane standing in for channel D of the FIRST layer's packed input."""
+    pc = self.d['D'] if plane is not None else -1
     for step in steps:
+      pl = plane if step[1] == 0 else None
       if step[0] == 'pair':
         (wpa, sca, sha, ca, _), (wpb, scb, shb, cb, poolb) = layers[step[1]], layers[step[2]]
         ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=poolb,
-                      out=bufs[step[2]])
+                      out=bufs[step[2]], plane=pl, plane_chan=pc if pl is not None else -1)
         src = bufs[step[2]]
         self._mark('%s_L%d+%d' % (name, step[1], step[2]))
       else:
         i = step[1]
         wp, sc, sh, cout, pool = layers[i]
-        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i])
+        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i], plane=pl,
+                    plane_chan=pc if pl is not None else -1)
         src = bufs[i]
         self._mark('%s_L%d' % (name, i))
     return src
@@ -395,7 +442,10 @@ class DecodeEngine(object):
     match = (iou == mx).to(torch.float32)
     match = match / match.sum(dim=1, keepdim=True)
     torch.sum(match[:, :, None, None] * b['y_gt'], dim=1, out=b['ysel'])
-    ops.canvas_max(b['img'], d['D'], b['ysel'], b['noise'][tt])
+    if 'canvas' in b:
+      ops.canvas_max(b['canvas'].view(b['canvas'].shape + (1,)), 0, b['ysel'], b['noise'][tt])
+    else:
+      ops.canvas_max(b['img'], d['D'], b['ysel'], b['noise'][tt])
     nsc = d['nsc']
     ops.dense(b['h_last'][tt], self.W['smlp_w'], self.W['smlp_b'],
               'sigmoid' if nsc == 1 else 'softmax', b['s_out'].data_ptr() + tt * nsc * 4,

@@ -42,9 +42,9 @@ SIGNATURES = {
     'ra_conv_packed_floats': (_Z, [_I, _I]),
     'ra_conv_pack_weights': (_I, [_P, _I, _I, _I, _P, _I, _P]),
     'ra_conv_fold_bn': (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _P]),
-    'ra_conv3x3_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'ra_conv3x3_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_conv_pair_supported': (_I, [_I, _I, _I]),
-    'ra_conv_pair_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'ra_conv_pair_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_ctrl_packed_floats': (_Z, [C.POINTER(CtrlDesc)]),
     'ra_ctrl_pack_weights': (_I, [C.POINTER(CtrlDesc), _P, _P, _P, _P]),
     'ra_controller_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P]),
@@ -60,10 +60,14 @@ SIGNATURES = {
     'ra_paste_canvas_f32': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I,
                                  _I, _P, _Z, _P, _P]),
     'ra_attn_box_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    'ra_extract_direct_f32': (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_paste_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _I, _P, _Z, _P]),
+    'ra_attn_box_direct_f32': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     'ra_extract_patch_dense_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_dense_f32': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _P]),
     'ra_pack_input_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ra_canvas_max_f32': (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    'ra_delay_us_f32': (_I, [_F, _P]),
     'ra_affine_act_f32': (_I, [_P, _P, _P, _Z, _I, _I, _P, _P]),
     'ra_max_pool_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
 }

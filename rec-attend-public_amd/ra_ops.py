@@ -143,7 +143,7 @@ def controller_split(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
 
 
 def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample=False,
-            out=None):
+            out=None, plane=None, plane_chan=-1):
   """One fused conv layer.  src0 [B,Hs,Ws,C0] (+ src1 [B,Hs,Ws,C1]) -> [B,Ho,Wo,cout]."""
   _need_cuda(src0, src1, wp, scale, shift, out)
   B, Hs, Ws, C0 = src0.shape
@@ -154,7 +154,8 @@ def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=src0.device)
   check(rn.lib().ra_conv3x3_f32(ptr(src0), C0, ptr(src1), C1, B, Hs, Ws, int(upsample), ptr(wp),
                                 ptr(scale), ptr(shift), int(cout), int(relu), int(pool),
-                                ptr(out), rn.stream_ptr()), 'ra_conv3x3_f32')
+                                ptr(plane), int(plane_chan), ptr(out), rn.stream_ptr()),
+        'ra_conv3x3_f32')
   return out
 
 
@@ -163,7 +164,7 @@ def conv_pair_supported(cin, cout_a, cout_b):
 
 
 def conv_pair(src, wpA, scA, shA, coutA, wpB, scB, shB, coutB, poolB=1, upsampleA=False,
-              reluA=True, reluB=True, out=None):
+              reluA=True, reluB=True, out=None, plane=None, plane_chan=-1):
   """Two fused conv layers (A: no pool / optional stride-2 transposed; B: pool 1|2)."""
   _need_cuda(src, wpA, scA, shA, wpB, scB, shB, out)
   B, Hs, Ws, C0 = src.shape
@@ -173,7 +174,8 @@ def conv_pair(src, wpA, scA, shA, coutA, wpB, scB, shB, coutB, poolB=1, upsample
     out = torch.empty((B, Ho, Wo, coutB), dtype=torch.float32, device=src.device)
   check(rn.lib().ra_conv_pair_f32(ptr(src), C0, B, Hs, Ws, int(upsampleA), ptr(wpA), ptr(scA),
                                   ptr(shA), int(coutA), int(reluA), ptr(wpB), ptr(scB), ptr(shB),
-                                  int(coutB), int(reluB), int(poolB), ptr(out), rn.stream_ptr()),
+                                  int(coutB), int(reluB), int(poolB), ptr(plane), int(plane_chan),
+                                  ptr(out), rn.stream_ptr()),
         'ra_conv_pair_f32')
   return out
 
@@ -222,6 +224,32 @@ def attn_box(attn, fy, fx, band, H, W, Fh, Fw, beta, out, stride_b):
         'ra_attn_box_f32')
 
 
+def extract_direct(img, chan0, attn, Fh, Fw, Cp, use_gamma, patch, canvas=None, canvas_chan=-1):
+  _need_cuda(img, attn, patch, canvas)
+  B, H, W, Ci = img.shape
+  check(rn.lib().ra_extract_direct_f32(ptr(img), Ci, chan0, ptr(canvas), int(canvas_chan), ptr(attn),
+                                       B, H, W, Fh, Fw, Cp, int(use_gamma), ptr(patch),
+                                       rn.stream_ptr()), 'ra_extract_direct_f32')
+
+
+def paste_direct(patch, pc, attn, beta, disable_overwrite, y_out, y_stride_b, H, W, canvas=None,
+                 img=None, canvas_chan=-1):
+  _need_cuda(patch, attn, canvas, img)
+  B, Fh, Fw, Cp = patch.shape
+  Ci = 0 if img is None else img.shape[3]
+  check(rn.lib().ra_paste_direct_f32(ptr(patch), Cp, pc, ptr(attn), B, H, W, Fh, Fw, C.c_float(beta),
+                                     int(disable_overwrite), ptr(canvas), ptr(img), Ci,
+                                     int(canvas_chan), ptr(y_out), y_stride_b, rn.stream_ptr()),
+        'ra_paste_direct_f32')
+
+
+def attn_box_direct(attn, H, W, Fh, Fw, beta, out, stride_b):
+  _need_cuda(attn)
+  check(rn.lib().ra_attn_box_direct_f32(ptr(attn), attn.shape[0], H, W, Fh, Fw, C.c_float(beta),
+                                        ptr(out), stride_b, rn.stream_ptr()),
+        'ra_attn_box_direct_f32')
+
+
 def dense(x0, W, b, act, out, out_stride_b, x1=None):
   """act: None/'relu'/'sigmoid'/'softmax'/'tanh'.  out may be a view; pass its data ptr."""
   _need_cuda(x0, x1, W, b)
@@ -246,6 +274,10 @@ def canvas_max(img, canvas_chan, ysel, noise):
   B, H, W, Ci = img.shape
   check(rn.lib().ra_canvas_max_f32(ptr(img), Ci, canvas_chan, ptr(ysel), ptr(noise), B, H, W,
                                    rn.stream_ptr()), 'ra_canvas_max_f32')
+
+
+def delay_us(us):
+  check(rn.lib().ra_delay_us_f32(C.c_float(us), rn.stream_ptr()), 'ra_delay_us_f32')
 
 
 def gaussian_filter(center, size, lg_var, L, F):

@@ -326,6 +326,81 @@ def test_filters_extract_paste(cuda, H, W, big):
   assert np.abs(box.cpu().numpy() - bref[..., 0]).max() < 2e-5
 
 
+@pytest.mark.parametrize('H,W,big', [(128, 128, False), (96, 160, True), (512, 512, False)])
+def test_direct_extract_paste_box(cuda, H, W, big):
+  """The table-free attention kernels (weights computed on the fly), with the canvas either as a
+  channel of the packed image or as its own plane."""
+  rng = np.random.RandomState(H * 2 + W)
+  B, C = 3, 8
+  rec = _attn_rec(B, H, W, rng, big)
+  rec[0, 0], rec[0, 1] = 0.02 * H, 0.97 * W  # box partly outside the image
+  r64 = rec.astype(np.float64)
+  fy_ref = ora.get_gaussian_filter(r64[:, 0], r64[:, 2], r64[:, 4], H, 48)
+  fx_ref = ora.get_gaussian_filter(r64[:, 1], r64[:, 3], r64[:, 5], W, 48)
+  img = rng.rand(B, H, W, C).astype(np.float32)
+  canvas0 = rng.uniform(0, 0.6, (B, H, W)).astype(np.float32)
+  img_ref = img.copy()
+  img_ref[..., 3] = canvas0
+  ref = r64[:, 6].reshape(-1, 1, 1, 1) * ora.extract_patch(img_ref.astype(np.float64), fy_ref, fx_ref, C)
+  tol = 3e-5 * max(1.0, np.abs(ref).max())
+  for plane in (False, True):
+    dimg = dev(img if plane else img_ref, cuda)  # with a plane, channel 3 of img is ignored
+    dcv = dev(canvas0, cuda) if plane else None
+    patch = torch.zeros((B, 48, 48, C), dtype=torch.float32, device=cuda)
+    ops.extract_direct(dimg, 0, dev(rec, cuda), 48, 48, C, True, patch, canvas=dcv, canvas_chan=3)
+    torch.cuda.synchronize()
+    assert np.abs(patch.cpu().numpy() - ref).max() < tol
+    P = rng.randn(B, 48, 48, 1).astype(np.float32)
+    yy = ora.extract_patch(P.astype(np.float64), np.transpose(fy_ref, (0, 2, 1)),
+                           np.transpose(fx_ref, (0, 2, 1)), 1)[..., 0]
+    yy = ora.sigmoid(np.exp(r64[:, 8]).reshape(-1, 1, 1) * yy - 5.0)
+    for overwrite in (True, False):
+      dimg = dev(img if plane else img_ref, cuda)
+      dcv = dev(canvas0, cuda) if plane else None
+      y_out = torch.zeros((B, 2, H, W), dtype=torch.float32, device=cuda)
+      ops.paste_direct(dev(P, cuda), 0, dev(rec, cuda), -5.0, overwrite,
+                       y_out.data_ptr() + H * W * 4, 2 * H * W, H, W, canvas=dcv,
+                       img=None if plane else dimg, canvas_chan=-1 if plane else 3)
+      torch.cuda.synchronize()
+      yo = yy * (1 - canvas0.astype(np.float64)) if overwrite else yy
+      got = y_out.cpu().numpy()
+      assert (got[:, 0] == 0).all() and np.abs(got[:, 1] - yo).max() < 2e-5
+      cv = dcv.cpu().numpy() if plane else dimg.cpu().numpy()[..., 3]
+      assert np.abs(cv - np.maximum(yo, canvas0)).max() < 2e-5
+      if not plane:
+        gi = dimg.cpu().numpy()
+        assert (gi[..., [0, 1, 2, 4, 5, 6, 7]] == img_ref[..., [0, 1, 2, 4, 5, 6, 7]]).all()
+  box = torch.zeros((B, H, W), dtype=torch.float32, device=cuda)
+  ops.attn_box_direct(dev(rec, cuda), H, W, 48, 48, -5.0, box, H * W)
+  ones = np.ones((B, 48, 48, 1))
+  bref = ora.sigmoid(ora.extract_patch(ones * r64[:, 7].reshape(-1, 1, 1, 1),
+                                       np.transpose(fy_ref, (0, 2, 1)),
+                                       np.transpose(fx_ref, (0, 2, 1)), 1) - 5.0)
+  torch.cuda.synchronize()
+  assert np.abs(box.cpu().numpy() - bref[..., 0]).max() < 3e-5
+
+
+def test_conv_with_canvas_plane(cuda):
+  """Input channel 3 supplied by a separate [B,H,W] plane (single and fused-pair kernels)."""
+  rng = np.random.RandomState(12)
+  B, H, W = 2, 40, 56
+  x = rng.randn(B, H, W, 4).astype(np.float32)
+  plane = rng.randn(B, H, W).astype(np.float32)
+  xr = x.copy()
+  xr[..., 3] = plane
+  wA = (rng.randn(3, 3, 4, 8) / 6).astype(np.float32)
+  wB = (rng.randn(3, 3, 8, 8) / 8).astype(np.float32)
+  hA = ora.relu(ora.conv2d(xr.astype(np.float64), wA.astype(np.float64)))
+  refB = ora.max_pool(ora.relu(ora.conv2d(hA, wB.astype(np.float64))), 2)
+  wpA, wpB = dev(ops.pack_conv_weights(wA), cuda), dev(ops.pack_conv_weights(wB), cuda)
+  sc, sh = [dev(a, cuda) for a in ops.fold_bn(None, 8)]
+  y = ops.conv3x3(dev(x, cuda), wpA, sc, sh, 8, relu=True, pool=1, plane=dev(plane, cuda), plane_chan=3)
+  assert relerr(y.cpu().numpy(), hA) < 2e-5
+  y2 = ops.conv_pair(dev(x, cuda), wpA, sc, sh, 8, wpB, sc, sh, 8, poolB=2, plane=dev(plane, cuda),
+                     plane_chan=3)
+  assert relerr(y2.cpu().numpy(), refB) < 3e-5
+
+
 def test_dense_pool_affine_pack(cuda):
   rng = np.random.RandomState(0)
   B = 5

@@ -16,17 +16,24 @@ import full_model
 import ra_ops as ops
 
 
-def timeit(fn, reps=50, warm=5):
-  for _ in range(warm):
-    fn()
+def timeit(fn, reps=20, inner=8):
+  """In-graph timing: `inner` copies captured in one HIP graph (amortises the ~10 us replay cost)."""
+  fn()
   torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    for _ in range(inner):
+      fn()
+  for _ in range(3):
+    g.replay()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize()
   e0.record()
   for _ in range(reps):
-    fn()
+    g.replay()
   e1.record()
   torch.cuda.synchronize()
-  return 1e3 * e0.elapsed_time(e1) / reps
+  return 1e3 * e0.elapsed_time(e1) / (reps * inner)
 
 
 def main():
@@ -81,6 +88,17 @@ def main():
     us = timeit(lambda: ops.paste_canvas(pt, 0, b['attn'][0], b['fy'], b['fx'], b['band'], -5.0, False,
                                          b['img'], d['D'], b['y_out'].data_ptr(), T * H * W, b['u_ws'], H, W))
     res['paste'] = (us, (S * S * 12.0 * B) / us / 1e3)
+  if want('patch'):
+    s2 = b['x_patch'][0]
+    for i, (wp, sc, sh, cout, pool) in enumerate(Wt['acnn']):
+      s_ = s2
+      res['acnn_L%d' % i] = (timeit(lambda: ops.conv3x3(s_, wp, sc[0], sh[0], cout, relu=True, pool=pool, out=b['acnn'][i])), 0)
+      s2 = b['acnn'][i]
+    for i, (wp, sc, sh, cout, unpool, sidx) in enumerate(Wt['adcnn']):
+      out = b['y_out_patch'][0] if b['adcnn'][i] is None else b['adcnn'][i]
+      s_ = s2
+      res['adcnn_L%d' % i] = (timeit(lambda: ops.conv3x3(s_, wp, sc[0], sh[0], cout, relu=True, pool=1, upsample=(unpool == 2), out=out)), 0)
+      s2 = out
   if want('acnn'):
     def chain():
       s2 = b['x_patch'][0]
