@@ -123,7 +123,6 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
-  ap.add_argument('--stagger-us', type=float, default=None)
   args = ap.parse_args()
 
   import ra_dist
@@ -140,8 +139,6 @@ def main():
   eng = model.engine
   eng.use_graph = not args.no_graph
   eng.nsub = args.nsub
-  if args.stagger_us is not None:
-    eng.stagger_us = args.stagger_us
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
   feed = {'x': x, 'phase_train': False}

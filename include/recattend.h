@@ -262,11 +262,6 @@ int ra_affine_act_f32(const float *x, const float *scale, const float *shift, si
  * x [B,H,W,C] -> y [B,ceil(H/ratio),ceil(W/ratio),C]. */
 int ra_max_pool_f32(const float *x, int B, int H, int W, int C, int ratio, float *y, void *stream);
 
-/* Scheduling aid: one idle wave that occupies `stream` for the given time (100 MHz realtime
- * clock).  The decode engine uses it once per forward to phase-shift its sub-batch streams so
- * their latency-bound tails overlap the other sub-batch's convolutions. */
-int ra_delay_us_f32(float microseconds, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -415,12 +415,6 @@ __global__ void max_pool_kernel(const float *x, int B, int H, int W, int C, int 
   }
 }
 
-// One wave that just waits: used to phase-shift a stream (see ra_engine: staggered sub-batches).
-__global__ void delay_kernel(unsigned long long ticks) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock
-  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
 inline int grid_for(size_t n, int block) {
   size_t g = (n + block - 1) / block;
   return (int)(g < 2048 ? (g ? g : 1) : 2048);
@@ -552,9 +546,3 @@ extern "C" int ra_max_pool_f32(const float *x, int B, int H, int W, int C, int r
   return launch_status("ra_max_pool_f32");
 }
 
-extern "C" int ra_delay_us_f32(float microseconds, void *stream) {
-  if (!(microseconds >= 0.0f) || microseconds > 1.0e5f) return fail(RA_E_INVALID, "ra_delay_us_f32: bad argument");
-  hipLaunchKernelGGL(attn::delay_kernel, dim3(1), dim3(64), 0, as_stream(stream),
-                     (unsigned long long)(microseconds * 100.0f));
-  return launch_status("ra_delay_us_f32");
-}

@@ -42,7 +42,6 @@ class DecodeEngine(object):
     self.fuse_pairs = True  # fused two-layer conv launches in the controller CNN where it pays
     self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
-    self.stagger_us = 0.0  # start sub-batch k this many microseconds * k late (phase shift)
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = choose from the batch size
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -312,20 +311,10 @@ class DecodeEngine(object):
     for sb, st in zip(self.subs, self.streams):
       st.wait_stream(main)
       with torch.cuda.stream(st):
-        self._launch_pack(sb)
-    # Stagger the streams: the chip-filling controller-CNN phases of the sub-batches are chained
-    # by events (enc(k,t) after enc(k-1,t); enc(0,t) after enc(last,t-1)), so one sub-batch's
-    # latency-bound tail (controller, patch convs, paste: a few dozen workgroups) runs UNDER the
-    # next sub-batch's convolutions instead of all sub-batches idling the chip in lockstep.
-    # Phase-shift the streams once: sub-batch k starts k * stagger_us late, so its latency-bound
-    # tail (controller, patch convs, paste: a few dozen workgroups) runs under another
-    # sub-batch's chip-filling convolutions instead of all sub-batches idling in lockstep.
-    for k, (sb, st) in enumerate(zip(self.subs, self.streams)):
-      with torch.cuda.stream(st):
-        if self.stagger_us and k:
-          ops.delay_us(self.stagger_us * k)
-        for tt in range(self.d['T']):
-          self._launch_tail(sb, tt, want_box, self._launch_encoder(sb, tt))
+        self._launch_sub(sb, want_box)
+    # (Measured: forcing the sub-batches out of lockstep — an initial delay, or chaining their
+    #  conv phases through device counters — does not pay under hipGraph on ROCm 7.2; cross-stream
+    #  event edges between the forked branches crash hipStreamEndCapture.  See DESIGN.md §5.)
     for st in self.streams:
       main.wait_stream(st)
 

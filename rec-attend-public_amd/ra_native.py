@@ -67,7 +67,6 @@ SIGNATURES = {
     'ra_dense_f32': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _P]),
     'ra_pack_input_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ra_canvas_max_f32': (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
-    'ra_delay_us_f32': (_I, [_F, _P]),
     'ra_affine_act_f32': (_I, [_P, _P, _P, _Z, _I, _I, _P, _P]),
     'ra_max_pool_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
 }

@@ -276,10 +276,6 @@ def canvas_max(img, canvas_chan, ysel, noise):
                                    rn.stream_ptr()), 'ra_canvas_max_f32')
 
 
-def delay_us(us):
-  check(rn.lib().ra_delay_us_f32(C.c_float(us), rn.stream_ptr()), 'ra_delay_us_f32')
-
-
 def gaussian_filter(center, size, lg_var, L, F):
   _need_cuda(center, size, lg_var)
   B = center.shape[0]
