@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
   assert lib.ra_conv_packed_floats(6, 8) == 0          # Cin % 4
   assert lib.ra_conv_packed_floats(8, 8) == 9 * 8 * 16
   # null pointers are rejected before any launch
-  rc = lib.ra_conv3x3_f32(None, 4, None, 0, 1, 8, 8, 0, None, None, None, 8, 1, 1, None, None)
+  rc = lib.ra_conv3x3_f32(None, 4, None, 0, 1, 8, 8, 0, None, None, None, 8, 1, 1, None, -1, None, None)
   assert rc == -1 and b'bad argument' in lib.ra_last_error_string()
   rc = lib.ra_hungarian_f32(None, 1, 2, 2, None, None, None)
   assert rc == -1
