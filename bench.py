@@ -83,6 +83,18 @@ def seed_weights(model, seed):
   model['ctrl_mlp_b_0'].copy_(b)
 
 
+def pmc_traffic(images, size):
+  """HBM bytes per encoder launch group measured with rocprofv3 --pmc (separate FETCH_SIZE and
+  WRITE_SIZE passes over `bench.py --pmc-group`, summarised by tools/pmc_traffic.py)."""
+  path = os.path.join(ROOT, 'profiles', 'r01_pmc_encoder_traffic.json')
+  if not os.path.exists(path):
+    return None
+  rec = json.load(open(path))
+  if rec.get('images') != images or rec.get('size') != size:
+    return None
+  return rec['hbm_bytes_per_launch_group']
+
+
 def cpu_baseline(opt, seed, budget_s=20.0):
   """NumPy oracle (oracle/ra_oracle.py, float32) on the host cores: B=1, as many timesteps
   as fit the budget (each timestep costs the same)."""
@@ -123,6 +135,9 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
+  ap.add_argument('--pmc-group', type=int, default=0, metavar='REPS',
+                  help='profiling aid: after one forward, launch only the encoder group REPS times '
+                       'eagerly and exit (run under rocprofv3 --pmc; see tools/pmc_traffic.py)')
   args = ap.parse_args()
 
   import ra_dist
@@ -144,6 +159,16 @@ def main():
   feed = {'x': x, 'phase_train': False}
 
   barrier = ra_dist.barrier
+
+  if args.pmc_group:
+    eng.forward(feed['x'])
+    sb = eng.subs[0]
+    for _ in range(args.pmc_group):
+      eng._run_cnn(eng.plan['ccnn'], eng.W['ccnn'], sb['img'], sb['ccnn'], 0, 'ctrl_cnn',
+                   plane=sb.get('canvas'))
+    torch.cuda.synchronize()
+    print(json.dumps({'pmc_group': args.pmc_group, 'images': int(sb['img'].shape[0]), 'size': S}))
+    return
 
   for _ in range(max(args.warmup, 1)):
     eng.forward(feed['x'])
@@ -211,13 +236,23 @@ def main():
       layers.append({'layers': list(step[1:]), 'fused': step[0] == 'pair', 'avg_us': us,
                      'gflop': fl * Bs / 1e9, 'tflops': fl * Bs / (us * 1e-6) / 1e12})
     enc_us = graph_time_us(lambda: [enc_step(st_) for st_ in eng.plan['ccnn']])
+    # compulsory HBM bytes of the group as launched: every launch reads its source once and
+    # writes its (pooled) output once; the first also reads the canvas plane
+    enc_bytes = 4.0 * sb['canvas'].numel() if 'canvas' in sb else 0.0
+    for st_ in eng.plan['ccnn']:
+      src_ = sb['img'] if st_[1] == 0 else sb['ccnn'][st_[1] - 1]
+      enc_bytes += 4.0 * (src_.numel() + sb['ccnn'][st_[-1]].numel())
     achieved = tot_f * Bs / (enc_us * 1e-6) / 1e12
     out['roofline'] = {
         'kernel': 'ra::cpair::conv_pair_mfma + ra::conv::conv3x3_mfma (controller CNN: %d layers in %d '
                   'launches per timestep per sub-batch of %d images)' % (d['ccnn_nlayers'],
                                                                        len(eng.plan['ccnn']), Bs),
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(Bs, S),
+        'traffic_note': 'HBM bytes per launch group from committed rocprofv3 --pmc passes '
+                        '(profiles/r01_pmc_encoder_traffic.json; FETCH_SIZE x2 gfx950 correction + '
+                        'WRITE_SIZE); null if no pass matches this shape',
+        'algorithmic_bytes_per_launch_group': enc_bytes,
         'peak_note': 'dense f32-input MFMA (v_mfma_f32_16x16x4_f32); the kernel computes in exact f32',
         'flop_per_launch_group': tot_f * Bs, 'avg_us_per_launch_group': enc_us,
         'layers': layers}
