@@ -24,6 +24,7 @@ struct PArgs {
   int CoutAP, CoutB, CoutBP, poolB, Ho, Wo, reluA, reluB;
   const float *plane;  // optional [B,Hs,Ws] plane replacing input channel plane_chan (the canvas)
   int plane_chan;
+  int bytes0, bytes_p;  // tensor sizes for the buffer descriptors (each < 2 GiB)
   int ablate;  // tuning aid (RA_PAIR_ABLATE): 1 no stores, 2 no input loads, 4 no phase A, 8 no phase B MFMA
 };
 
@@ -261,6 +262,246 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// N-packed form for the full-resolution 8-channel pairs (controller CNN L0+L1: Cin -> 8 -> <=8,
+// pool 2).  A 16x16x4 MFMA has 16 output columns; with 8 output channels half of them would
+// multiply zeros.  Here the 16 columns are 2 horizontally adjacent pixels x 8 channels,
+//   n = p*8 + co,  D[m][n] = sum_{ky, kx' in 0..3, ci} in[y+ky-1][x_even-1+kx'][ci] * W'[ky][kx'][ci][n],
+//   W'[ky][kx'][ci][p*8+co] = W[ky][kx'-p][ci][co]  (0 outside 0 <= kx'-p <= 2),
+// so one MFMA row is a pixel PAIR: 12 k-steps per 32 pixels instead of 2 x 9.  W' is built in
+// registers from the standard packed filter (predicated loads), the interface does not change.
+// Tile = 16 x 32 conv pixels (8 x 16 pooled).  Row mappings:
+//   phase A (no pool): m -> (row m>>2, pair m&3), groups of 4 rows x 8 cols, 5 x 5 groups cover
+//                      the 18 x 36 (even-aligned) region layer B needs; result -> LDS tile `tmid`
+//   phase B (pool 2):  m -> (pair m>>1, row m&1), groups of 2 rows x 16 cols; the pool window of a
+//                      pair is registers (2j, 2j+1) of lanes n and n^8 -> v_max + one DPP row_ror:8.
+// Both LDS tiles use odd row strides (43 / 41 pixels) so the strided operand reads are 2-way
+// instead of 4-way bank-conflicted (MI355X_MICROARCH.md, LDS: bank = dword address mod 32 / 64).
+template <int CINA>
+struct NGeo {
+  static constexpr int TH = 16, TW = 32;
+  static constexpr int NCGA = CINA / 4;
+  static constexpr int AGX = 5, AGY = 5, NGA = AGX * AGY, GPW = (NGA + 3) / 4;
+  static constexpr int AW = 41, AHS = TH + 2;  // tmid: row stride (pixels), rows stored
+  static constexpr int LW = 43, LH = 4 * AGY + 2;  // tin: row stride, rows addressable
+  static constexpr int LHL = TH + 4, LWL = TW + 5;  // tin rows / cols actually loaded (20 x 37)
+  static constexpr int IN_FLOATS = LH * LW * CINA;
+  static constexpr int MID_FLOATS = AHS * AW * 8;
+};
+
+template <int CINA>
+__global__ __launch_bounds__(256, 4) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y) {
+  using G = NGeo<CINA>;
+  constexpr int NCGA = G::NCGA;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tin = lds;                  // [LH][LW] records [ksub][cg]  (channel = 4*cg + ksub)
+  float *tmid = lds + G::IN_FLOATS;  // [AHS][AW] records [ksub][cg], 8 channels
+  typedef typename vec_of<NCGA>::type avecA;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, ksub = lane >> 4;  // A-operand side
+  const int n = lane & 15, qo = lane >> 4;    // D side: column n = (p, co), rows 4*qo + r
+  const int p = n >> 3, co = n & 7;
+  const int per = tiles_x * tiles_y;
+  const int b = blockIdx.x / per;
+  const int trem = blockIdx.x - b * per;
+  const int ty0 = (trem / tiles_x) * G::TH, tx0 = (trem % tiles_x) * G::TW;
+
+  // W' of both layers: one dword per (tap', cg) per lane, zero where the tap misses pixel p
+  float bA[12][NCGA], bB[12][2];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kxp = 0; kxp < 4; ++kxp) {
+      const int kx = kxp - p;
+      const bool ok = (kx >= 0) & (kx <= 2);
+      const int tap = ok ? ky * 3 + kx : 0;
+#pragma unroll
+      for (int cg = 0; cg < NCGA; ++cg) {
+        const float w = a.wpA[((tap * NCGA + cg) * 4 + ksub) * a.CoutAP + co];
+        bA[ky * 4 + kxp][cg] = ok ? w : 0.f;
+      }
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        const float w = a.wpB[((tap * 2 + cg) * 4 + ksub) * a.CoutBP + co];
+        bB[ky * 4 + kxp][cg] = ok ? w : 0.f;
+      }
+    }
+  const float scA = a.scA[co], shA = a.shA[co], scB = a.scB[co], shB = a.shB[co];
+
+  // ---------------- phase 0: stage layer A's input (tile + halo), zeros outside the image ----------
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src), 0, a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.plane ? a.plane : a.src), 0, a.plane ? a.bytes_p : 0, 0x00020000);
+    constexpr int NE = G::LHL * G::LWL, NIT = (NE + 255) / 256;
+    f32x4 v[NIT][NCGA];
+    float pv[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tid + 256 * i;
+      const int rr = e / G::LWL, cc = e - rr * G::LWL;
+      const int Y = ty0 - 2 + rr, X = tx0 - 3 + cc;
+      const bool ok = (e < NE) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+      const int pix = (b * a.H + Y) * a.W + X;
+#pragma unroll
+      for (int cg = 0; cg < NCGA; ++cg)
+        v[i][cg] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (pix * CINA + 4 * cg) * 4 : 0x7fffffff, 0, 0));
+      pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ok ? pix * 4 : 0x7fffffff, 0, 0));
+    }
+    const int pg = a.plane_chan >> 2, slot = a.plane_chan & 3;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tid + 256 * i;
+      const int rr = e / G::LWL, cc = e - rr * G::LWL;
+      if (a.plane) {
+#pragma unroll
+        for (int cg = 0; cg < NCGA; ++cg) {  // selects, not runtime register indexing
+          v[i][cg].x = (cg == pg && slot == 0) ? pv[i] : v[i][cg].x;
+          v[i][cg].y = (cg == pg && slot == 1) ? pv[i] : v[i][cg].y;
+          v[i][cg].z = (cg == pg && slot == 2) ? pv[i] : v[i][cg].z;
+          v[i][cg].w = (cg == pg && slot == 3) ? pv[i] : v[i][cg].w;
+        }
+      }
+      if (e < NE) {
+        float *rec = tin + (rr * G::LW + cc) * CINA;
+        if constexpr (NCGA == 1) {
+          *reinterpret_cast<f32x4 *>(rec) = v[i][0];
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int cg = 0; cg < NCGA; ++cg) rec[ks * NCGA + cg] = v[i][cg][ks];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase A: layer A on the 18 x 36 region -> tmid ----------------
+  {
+    const bool interior = (ty0 >= 1) & (ty0 + G::TH + 1 <= a.H) & (tx0 >= 2) & (tx0 + G::TW + 1 <= a.W);
+    const int lane_in = ((m >> 2) * G::LW + 2 * (m & 3)) * CINA + ksub * NCGA;
+    const int chpos = (co & 3) * 2 + (co >> 2);
+    const int lane_mid = (qo * G::AW + p) * 8 + chpos;
+    f32x4 acc[G::GPW];
+    int gin[G::GPW];
+#pragma unroll
+    for (int s = 0; s < G::GPW; ++s) {
+      int gi = wave + 4 * s;
+      if (gi >= G::NGA) gi = G::NGA - 1;  // duplicate work, masked at the store
+      const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
+      gin[s] = (4 * gr * G::LW + 8 * gc) * CINA + lane_in;
+      acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kxp = 0; kxp < 4; ++kxp) {
+        avecA av[G::GPW];
+#pragma unroll
+        for (int s = 0; s < G::GPW; ++s)
+          av[s] = *reinterpret_cast<const avecA *>(&tin[gin[s] + (ky * G::LW + kxp) * CINA]);
+#pragma unroll
+        for (int cg = 0; cg < NCGA; ++cg)
+#pragma unroll
+          for (int s = 0; s < G::GPW; ++s)
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[ky * 4 + kxp][cg], acc[s], 0, 0, 0);
+      }
+#pragma unroll
+    for (int s = 0; s < G::GPW; ++s) {
+      const int gi = wave + 4 * s;
+      const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
+      const bool live = (gi < G::NGA) & (4 * gr + qo < G::AHS);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[s][r] * scA + shA;
+        if (a.reluA) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (!interior) {  // outside the image the intermediate is layer B's SAME padding: zero
+        const int Y = ty0 - 1 + 4 * gr + qo;
+        const bool yok = (Y >= 0) & (Y < a.H);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int X = tx0 - 2 + 8 * gc + 2 * r + p;
+          v[r] = (yok & (X >= 0) & (X < a.W)) ? v[r] : 0.f;
+        }
+      }
+      if (live) {
+        float *dst = tmid + (4 * gr * G::AW + 8 * gc) * 8 + lane_mid;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r * 16] = v[r];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase B: layer B out of tmid, BN + ReLU + 2x2 max-pool -> global ----------------
+  {
+    f32x4 acc[4];
+    int gmid[4];
+    const int lane_b = ((m & 1) * G::AW + 2 * (m >> 1) + 1) * 8 + ksub * 2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int gy = 2 * wave + (g >> 1), gx = g & 1;
+      gmid[g] = (2 * gy * G::AW + 16 * gx) * 8 + lane_b;
+      acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kxp = 0; kxp < 4; ++kxp) {
+        f32x2 av[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          av[g] = *reinterpret_cast<const f32x2 *>(&tmid[gmid[g] + (ky * G::AW + kxp) * 8]);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][cg], bB[ky * 4 + kxp][cg], acc[g], 0, 0, 0);
+      }
+    const int prow0 = (ty0 >> 1) + wave * 2, pcol0 = (tx0 >> 1) + 2 * qo + p;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[g][r] * scB + shB;
+        if (a.reluB) v[r] = fmaxf(v[r], 0.f);
+      }
+      // registers (2j, 2j+1) = rows (0, 1) of pair 2*qo + j; lane n^8 holds the pair's other pixel
+      const float t0 = fmaxf(v[0], v[1]), t1 = fmaxf(v[2], v[3]);
+      const float u0 = fmaxf(t0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0x128, 0xf, 0xf, true)));
+      const float u1 = fmaxf(t1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x128, 0xf, 0xf, true)));
+      const float o = p ? u1 : u0;  // lane (p, co) stores pooled pixel 2*qo + p
+      const int prow = prow0 + (g >> 1), pcol = pcol0 + 8 * (g & 1);
+      if ((co < a.CoutB) & (prow < a.Ho) & (pcol < a.Wo) & !(a.ablate & 1))
+        a.y[((size_t)(b * a.Ho + prow) * a.Wo + pcol) * a.CoutB + co] = o;
+    }
+  }
+}
+
+template <int CINA>
+int launch8(const PArgs &a, int B, hipStream_t st) {
+  using G = NGeo<CINA>;
+  auto kern = conv_pair8_mfma<CINA>;
+  constexpr size_t lds = (size_t)(G::IN_FLOATS + G::MID_FLOATS) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int tiles_x = ceil_div(a.W, G::TW), tiles_y = ceil_div(a.H, G::TH);
+  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * B), dim3(256), lds, st, a, tiles_x, tiles_y);
+  return launch_status("ra_conv_pair_f32");
+}
+
 template <int CINA, int CMID, int NCB, int GX, int GYB>
 int launch(const PArgs &a, int B, hipStream_t st) {
   using G = PGeo<CINA, CMID, NCB, GX, GYB>;
@@ -372,6 +613,15 @@ extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws
     a.ablate = abl;
   }
   hipStream_t st = as_stream(stream);
+  const size_t bytes0 = (size_t)B * Hs * Ws * Cin * 4;
+  a.bytes0 = (int)bytes0;
+  a.bytes_p = (int)((size_t)B * Hs * Ws * 4);
+  static int no8 = -1;  // RA_PAIR_NO8=1: tuning aid, disables the N-packed kernel
+  if (no8 < 0) no8 = getenv("RA_PAIR_NO8") ? 1 : 0;
+  if (!no8 && CoutA == 8 && CoutB <= 8 && poolB == 2 && !a.ups && bytes0 < (1u << 31) && a.W > 16) {
+    if (Cin == 4) return cpair::launch8<4>(a, B, st);
+    if (Cin == 8) return cpair::launch8<8>(a, B, st);
+  }
   switch (Cin) {
     case 4: return cpair::dispatch_mid<4>(a, CoutA, B, st);
     case 8: return cpair::dispatch_mid<8>(a, CoutA, B, st);

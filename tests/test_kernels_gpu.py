@@ -108,6 +108,9 @@ PAIR_CASES = [
     (1, 24, 24, 16, 8, 8, 1, True),     # d4+d5
     (1, 20, 36, 8, 8, 1, 1, False),     # CoutB = 1, ragged tiles
     (8, 128, 128, 4, 8, 8, 2, False),   # many tiles -> big geometry
+    (2, 50, 70, 4, 8, 8, 2, False),     # N-packed kernel, ragged tiles on both edges
+    (1, 18, 34, 8, 8, 5, 2, False),     # N-packed kernel, Cin = 8, CoutB < 8
+    (1, 16, 32, 4, 8, 8, 2, False),     # N-packed kernel, exactly one tile
 ]
 
 
