@@ -42,7 +42,7 @@ class DecodeEngine(object):
     self.fuse_pairs = True  # fused two-layer conv launches in the controller CNN where it pays
     self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
-    self.nsub = 0  # sub-batches decoded on parallel streams; 0 = choose from the batch size
+    self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
 
@@ -205,7 +205,7 @@ class DecodeEngine(object):
     own HIP stream: the latency-bound controller / patch kernels of one sub-batch overlap the
     other's conv launches).  Batch-leading tensors are shared and sliced; the rest is per
     sub-batch."""
-    nsub = self.nsub if self.nsub else (2 if (B % 2 == 0 and B >= 4) else 1)
+    nsub = self.nsub if self.nsub else 1
     if B % nsub:
       nsub = 1
     if self._B == (B, nsub):
@@ -312,9 +312,11 @@ class DecodeEngine(object):
       st.wait_stream(main)
       with torch.cuda.stream(st):
         self._launch_sub(sb, want_box)
-    # (Measured: forcing the sub-batches out of lockstep — an initial delay, or chaining their
-    #  conv phases through device counters — does not pay under hipGraph on ROCm 7.2; cross-stream
-    #  event edges between the forked branches crash hipStreamEndCapture.  See DESIGN.md §5.)
+    # (Measured, DESIGN.md §5: the branches run in lockstep, so two sub-batches are within 1 % of
+    #  one; making their conv phases mutually exclusive — graph edges added after capture,
+    #  per-timestep graphs chained by events, or linear graphs with device-side semaphores — was
+    #  slower every time on ROCm 7.2, and a branched graph costs the host ~2 ms per replay against
+    #  0.15 ms for the linear one.  Hence nsub defaults to 1.)
     for st in self.streams:
       main.wait_stream(st)
 
