@@ -262,7 +262,8 @@ def main():
         ops.extract_direct(sb['img'], 0, sb['attn'][0], Fh, Fw, d['C0p'], True, sb['x_patch'][0],
                            canvas=sb['canvas'], canvas_chan=d['D'])
         ops.paste_direct(sb['y_out_patch'][0], 0, sb['attn'][0], -5.0, d['disable_overwrite'],
-                         sb['y_out'].data_ptr(), T * S * S, S, S, canvas=sb['canvas'])
+                         sb['y_out'].data_ptr(), T * S * S, S, S, canvas=sb['canvas'],
+                         flags=ops.PASTE_Y_PREFILLED | ops.PASTE_CANVAS_FLOORED)
       else:
         ops.extract_patch(sb['img'], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], Fh, Fw,
                           d['C0p'], True, sb['x_patch'][0])

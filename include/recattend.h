@@ -39,6 +39,10 @@ int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
 
+/* Test aid (no reference counterpart): fills the LDS of every CU with NaN, so a kernel that
+ * reads shared memory it never wrote fails the parity tests deterministically. */
+int ra_debug_poison_lds(void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Hungarian matching — replaces the TF custom op
  *   REGISTER_OP("Hungarian").Input("weights: float").Output("matching: float")
@@ -224,9 +228,17 @@ int ra_attn_box_f32(const float *attn, const float *fy, const float *fx, const i
 int ra_extract_direct_f32(const float *img, int Ci, int chan0, const float *canvas, int canvas_chan,
                           const float *attn, int B, int H, int W, int Fh, int Fw, int Cp,
                           int use_gamma, float *patch, void *stream);
+/* flags (promises by the caller that let the paste touch only the attention window):
+ *   RA_PASTE_Y_PREFILLED     y_out already holds sigmoid(beta) everywhere (ignored with
+ *                            disable_overwrite, where untouched pixels are sigmoid(beta)*(1-canvas))
+ *   RA_PASTE_CANVAS_FLOORED  canvas >= sigmoid(beta) everywhere already (true after the first
+ *                            paste of a sequence that started from canvas = 0) */
+#define RA_PASTE_Y_PREFILLED 1
+#define RA_PASTE_CANVAS_FLOORED 2
 int ra_paste_direct_f32(const float *patch, int Cp, int pc, const float *attn, int B, int H, int W,
                         int Fh, int Fw, float beta, int disable_overwrite, float *canvas, float *img,
-                        int Ci, int canvas_chan, float *y_out, size_t y_stride_b, void *stream);
+                        int Ci, int canvas_chan, float *y_out, size_t y_stride_b, int flags,
+                        void *stream);
 int ra_attn_box_direct_f32(const float *attn, int B, int H, int W, int Fh, int Fw, float beta,
                            float *box_out, size_t stride_b, void *stream);
 

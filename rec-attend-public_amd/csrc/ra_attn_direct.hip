@@ -180,13 +180,27 @@ __global__ __launch_bounds__(128) void paste_direct_kernel(const float *patch, i
                                                             int Fw, float beta, int disable_overwrite,
                                                             float *canvas, float *img, int Ci,
                                                             int canvas_chan, float *y_out,
-                                                            size_t y_stride_b) {
+                                                            size_t y_stride_b, int flags) {
   extern __shared__ float V[];  // [Fw]:  V[i] = sum_j fy(l,j) P[j,i]
   const int l = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
   const Axis Ay = make_axis(rec, 0, H, Fh), Ax = make_axis(rec, 1, W, Fw);
   int jlo, jhi;
   Ay.taps(l, jlo, jhi);
+  // Pixels no tap reaches have y = sigmoid(beta) and leave a canvas that is already >= sigmoid(beta)
+  // unchanged: with both promises from the caller (flags) only the window is touched.
+  const bool skip_dead = (flags & RA_PASTE_Y_PREFILLED) && (MODE != 0 || !canvas || (flags & RA_PASTE_CANVAS_FLOORED)) &&
+                         (MODE != 0 || canvas || !img);
+  if (skip_dead && jlo >= jhi) return;
+  int wbeg = 0, wend = W;
+  if (skip_dead) {
+    int w0, w1, tmp;
+    Ax.band(0, w0, tmp);
+    Ax.band(Fw - 1, tmp, w1);
+    wbeg = w0 & ~3;
+    wend = (w1 + 3) & ~3;
+    wend = wend < W ? wend : W;
+  }
   for (int i = t; i < Fw; i += blockDim.x) {
     float s = 0.0f;
     if (MODE == 0) {
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(128) void paste_direct_kernel(const float *patch, i
                    (!crow || (reinterpret_cast<uintptr_t>(crow) & 15) == 0);
   const bool row_live = jlo < jhi;  // uniform: does any tap reach this row at all?
   const float y_dead = sigmoidf(beta);
-  for (int w4 = t * 4; w4 < W; w4 += blockDim.x * 4) {
+  for (int w4 = wbeg + t * 4; w4 < wend; w4 += blockDim.x * 4) {
     f32x4 cv = f32x4{0, 0, 0, 0};
     if (MODE == 0) {
       if (crow && vec) cv = *reinterpret_cast<const f32x4 *>(crow + w4);
@@ -272,13 +286,13 @@ extern "C" int ra_extract_direct_f32(const float *img, int Ci, int chan0, const 
 extern "C" int ra_paste_direct_f32(const float *patch, int Cp, int pc, const float *attn_rec, int B, int H,
                                    int W, int Fh, int Fw, float beta, int disable_overwrite,
                                    float *canvas, float *img, int Ci, int canvas_chan, float *y_out,
-                                   size_t y_stride_b, void *stream) {
+                                   size_t y_stride_b, int flags, void *stream) {
   if (!patch || !attn_rec || !y_out || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0 || Cp <= 0 ||
       pc < 0 || pc >= Cp)
     return fail(RA_E_INVALID, "ra_paste_direct_f32: bad argument");
   hipLaunchKernelGGL(attnd::paste_direct_kernel<0>, dim3(H, B), dim3(128), Fw * sizeof(float),
                      as_stream(stream), patch, Cp, pc, attn_rec, H, W, Fh, Fw, beta, disable_overwrite, canvas,
-                     img, Ci, canvas_chan, y_out, y_stride_b);
+                     img, Ci, canvas_chan, y_out, y_stride_b, disable_overwrite ? (flags & ~RA_PASTE_Y_PREFILLED) : flags);
   return launch_status("ra_paste_direct_f32");
 }
 
@@ -288,6 +302,6 @@ extern "C" int ra_attn_box_direct_f32(const float *attn_rec, int B, int H, int W
     return fail(RA_E_INVALID, "ra_attn_box_direct_f32: bad argument");
   hipLaunchKernelGGL(attnd::paste_direct_kernel<1>, dim3(H, B), dim3(128), Fw * sizeof(float),
                      as_stream(stream), nullptr, 1, 0, attn_rec, H, W, Fh, Fw, beta, 0, nullptr, nullptr, 0, -1,
-                     box_out, stride_b);
+                     box_out, stride_b, 0);
   return launch_status("ra_attn_box_direct_f32");
 }

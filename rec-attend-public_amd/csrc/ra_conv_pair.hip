@@ -284,13 +284,19 @@ struct NGeo {
   static constexpr int AGX = 5, AGY = 5, NGA = AGX * AGY, GPW = (NGA + 3) / 4;
   static constexpr int AW = 41, AHS = TH + 2;  // tmid: row stride (pixels), rows stored
   static constexpr int LW = 43, LH = 4 * AGY + 2;  // tin: row stride, rows addressable
-  static constexpr int LHL = TH + 4, LWL = TW + 5;  // tin rows / cols actually loaded (20 x 37)
+  // tin rows / cols actually loaded (20 x 38): every value that shares an MFMA row with a needed
+  // output must be finite even where its weight is zero (pair 17 = columns 34|35 reads tin
+  // columns 34..37; 0 * NaN would poison column 34)
+  static constexpr int LHL = TH + 4, LWL = TW + 6;
   static constexpr int IN_FLOATS = LH * LW * CINA;
   static constexpr int MID_FLOATS = AHS * AW * 8;
 };
 
+#ifndef RA_PAIR8_OCC
+#define RA_PAIR8_OCC 3  // workgroups per CU: 3 x 38.7 KB LDS, <= 168 VGPRs (4 spills)
+#endif
 template <int CINA>
-__global__ __launch_bounds__(256, 4) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = NGeo<CINA>;
   constexpr int NCGA = G::NCGA;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -305,11 +311,14 @@ __global__ __launch_bounds__(256, 4) void conv_pair8_mfma(const PArgs a, int til
   const int n = lane & 15, qo = lane >> 4;    // D side: column n = (p, co), rows 4*qo + r
   const int p = n >> 3, co = n & 7;
   const int per = tiles_x * tiles_y;
-  const int b = blockIdx.x / per;
-  const int trem = blockIdx.x - b * per;
-  const int ty0 = (trem / tiles_x) * G::TH, tx0 = (trem % tiles_x) * G::TW;
 
-  // W' of both layers: one dword per (tap', cg) per lane, zero where the tap misses pixel p
+  // BN scale is folded into the weights and the shift into the accumulator's initial value, so
+  // the epilogue of a value is one v_max (ReLU); FP32 MFMA shares the FP32 VALU lanes on gfx950
+  // (tools/mfma_valu.hip: their times add), so every VALU instruction here costs MFMA time.
+  const float scA = a.scA[co], shA = a.shA[co], scB = a.scB[co], shB = a.shB[co];
+  const float loA = a.reluA ? 0.f : -__builtin_inff(), loB = a.reluB ? 0.f : -__builtin_inff();
+  // W' of both layers, once per workgroup: one dword per (tap', cg) per lane, zero where the
+  // tap misses pixel p
   float bA[12][NCGA], bB[12][2];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
@@ -321,42 +330,67 @@ __global__ __launch_bounds__(256, 4) void conv_pair8_mfma(const PArgs a, int til
 #pragma unroll
       for (int cg = 0; cg < NCGA; ++cg) {
         const float w = a.wpA[((tap * NCGA + cg) * 4 + ksub) * a.CoutAP + co];
-        bA[ky * 4 + kxp][cg] = ok ? w : 0.f;
+        bA[ky * 4 + kxp][cg] = ok ? w * scA : 0.f;
       }
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
         const float w = a.wpB[((tap * 2 + cg) * 4 + ksub) * a.CoutBP + co];
-        bB[ky * 4 + kxp][cg] = ok ? w : 0.f;
+        bB[ky * 4 + kxp][cg] = ok ? w * scB : 0.f;
       }
     }
-  const float scA = a.scA[co], shA = a.shA[co], scB = a.scB[co], shB = a.shB[co];
 
-  // ---------------- phase 0: stage layer A's input (tile + halo), zeros outside the image ----------
-  {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src), 0, a.bytes0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.plane ? a.plane : a.src), 0, a.plane ? a.bytes_p : 0, 0x00020000);
-    constexpr int NE = G::LHL * G::LWL, NIT = (NE + 255) / 256;
-    f32x4 v[NIT][NCGA];
-    float pv[NIT];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src), 0, a.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(a.plane ? a.plane : a.src), 0, a.plane ? a.bytes_p : 0, 0x00020000);
+  constexpr int NE = G::LHL * G::LWL, NIT = (NE + 255) / 256;
+  // this thread's staged pixels (tile-independent): position in the loaded window and LDS record
+  int e_rr[NIT], e_cc[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int e = tid + 256 * i;
+    e_rr[i] = e / G::LWL;
+    e_cc[i] = e - e_rr[i] * G::LWL;
+    if (e >= NE) e_rr[i] = -(1 << 20);  // never inside the image
+  }
+  f32x4 v[NIT][NCGA];
+  float pv[NIT];
+  // global loads of one tile's input window (tile + halo) into registers; zeros outside the image
+  auto fetch = [&](int tile) {
+    const int fb = tile / per, frem = tile - fb * per;
+    const int fy0 = (frem / tiles_x) * G::TH - 2, fx0 = (frem % tiles_x) * G::TW - 3;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = tid + 256 * i;
-      const int rr = e / G::LWL, cc = e - rr * G::LWL;
-      const int Y = ty0 - 2 + rr, X = tx0 - 3 + cc;
-      const bool ok = (e < NE) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-      const int pix = (b * a.H + Y) * a.W + X;
+      const int Y = fy0 + e_rr[i], X = fx0 + e_cc[i];
+      const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W) & !(a.ablate & 2);
+      const int pix = (fb * a.H + Y) * a.W + X;
 #pragma unroll
       for (int cg = 0; cg < NCGA; ++cg)
         v[i][cg] = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (pix * CINA + 4 * cg) * 4 : 0x7fffffff, 0, 0));
       pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ok ? pix * 4 : 0x7fffffff, 0, 0));
     }
-    const int pg = a.plane_chan >> 2, slot = a.plane_chan & 3;
+  };
+
+  const int lane_in = ((m >> 2) * G::LW + 2 * (m & 3)) * CINA + ksub * NCGA;
+  const int chpos = (co & 3) * 2 + (co >> 2);
+  const int lane_mid = (qo * G::AW + p) * 8 + chpos;
+  const int lane_b = ((m & 1) * G::AW + 2 * (m >> 1) + 1) * 8 + ksub * 2;
+  const int pg = a.plane_chan >> 2, slot = a.plane_chan & 3;
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  // the padded groups read LDS this kernel never writes; whatever an earlier kernel left there
+  // must not be NaN/Inf (their results are discarded, but keep the arithmetic clean)
+  for (int e = tid; e < (G::IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
+    reinterpret_cast<f32x4 *>(lds)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / per, trem = tile - b * per;
+    const int ty0 = (trem / tiles_x) * G::TH, tx0 = (trem % tiles_x) * G::TW;
+
+    // ---------------- stage layer A's input window (prefetched registers -> LDS) ----------------
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = tid + 256 * i;
-      const int rr = e / G::LWL, cc = e - rr * G::LWL;
       if (a.plane) {
 #pragma unroll
         for (int cg = 0; cg < NCGA; ++cg) {  // selects, not runtime register indexing
@@ -366,8 +400,8 @@ __global__ __launch_bounds__(256, 4) void conv_pair8_mfma(const PArgs a, int til
           v[i][cg].w = (cg == pg && slot == 3) ? pv[i] : v[i][cg].w;
         }
       }
-      if (e < NE) {
-        float *rec = tin + (rr * G::LW + cc) * CINA;
+      if (e_rr[i] >= 0) {
+        float *rec = tin + (e_rr[i] * G::LW + e_cc[i]) * CINA;
         if constexpr (NCGA == 1) {
           *reinterpret_cast<f32x4 *>(rec) = v[i][0];
         } else {
@@ -378,110 +412,102 @@ __global__ __launch_bounds__(256, 4) void conv_pair8_mfma(const PArgs a, int til
         }
       }
     }
-  }
-  __syncthreads();
-
-  // ---------------- phase A: layer A on the 18 x 36 region -> tmid ----------------
-  {
-    const bool interior = (ty0 >= 1) & (ty0 + G::TH + 1 <= a.H) & (tx0 >= 2) & (tx0 + G::TW + 1 <= a.W);
-    const int lane_in = ((m >> 2) * G::LW + 2 * (m & 3)) * CINA + ksub * NCGA;
-    const int chpos = (co & 3) * 2 + (co >> 2);
-    const int lane_mid = (qo * G::AW + p) * 8 + chpos;
-    f32x4 acc[G::GPW];
-    int gin[G::GPW];
-#pragma unroll
-    for (int s = 0; s < G::GPW; ++s) {
-      int gi = wave + 4 * s;
-      if (gi >= G::NGA) gi = G::NGA - 1;  // duplicate work, masked at the store
-      const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
-      gin[s] = (4 * gr * G::LW + 8 * gc) * CINA + lane_in;
-      acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    {  // the next tile's loads fly while this one is computed
+      const int next = tile + gridDim.x;
+      if (next < ntiles) fetch(next);
     }
+
+    // ---------------- phase A: layer A on the 18 x 36 region -> tmid ----------------
+    {
+      const bool interior = (ty0 >= 1) & (ty0 + G::TH + 1 <= a.H) & (tx0 >= 2) & (tx0 + G::TW + 1 <= a.W);
+      f32x4 acc[G::GPW];
+      int gin[G::GPW];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int s = 0; s < G::GPW; ++s) {
+        int gi = wave + 4 * s;
+        if (gi >= G::NGA) gi = G::NGA - 1;  // duplicate work, masked at the store
+        const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
+        gin[s] = (4 * gr * G::LW + 8 * gc) * CINA + lane_in;
+        acc[s] = f32x4{shA, shA, shA, shA};
+      }
 #pragma unroll
-      for (int kxp = 0; kxp < 4; ++kxp) {
-        avecA av[G::GPW];
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int s = 0; s < G::GPW; ++s)
-          av[s] = *reinterpret_cast<const avecA *>(&tin[gin[s] + (ky * G::LW + kxp) * CINA]);
-#pragma unroll
-        for (int cg = 0; cg < NCGA; ++cg)
+        for (int kxp = 0; kxp < 4; ++kxp) {
+          avecA av[G::GPW];
 #pragma unroll
           for (int s = 0; s < G::GPW; ++s)
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[ky * 4 + kxp][cg], acc[s], 0, 0, 0);
-      }
+            av[s] = *reinterpret_cast<const avecA *>(&tin[gin[s] + (ky * G::LW + kxp) * CINA]);
 #pragma unroll
-    for (int s = 0; s < G::GPW; ++s) {
-      const int gi = wave + 4 * s;
-      const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
-      const bool live = (gi < G::NGA) & (4 * gr + qo < G::AHS);
-      float v[4];
+          for (int cg = 0; cg < NCGA; ++cg)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[s][r] * scA + shA;
-        if (a.reluA) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (!interior) {  // outside the image the intermediate is layer B's SAME padding: zero
-        const int Y = ty0 - 1 + 4 * gr + qo;
-        const bool yok = (Y >= 0) & (Y < a.H);
+            for (int s = 0; s < G::GPW; ++s)
+              acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[ky * 4 + kxp][cg], acc[s], 0, 0, 0);
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int X = tx0 - 2 + 8 * gc + 2 * r + p;
-          v[r] = (yok & (X >= 0) & (X < a.W)) ? v[r] : 0.f;
+      for (int s = 0; s < G::GPW; ++s) {
+        const int gi = wave + 4 * s;
+        const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
+        const bool live = (gi < G::NGA) & (4 * gr + qo < G::AHS);
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[s][r], loA);
+        if (!interior) {  // outside the image the intermediate is layer B's SAME padding: zero
+          const int Y = ty0 - 1 + 4 * gr + qo;
+          const bool yok = (Y >= 0) & (Y < a.H);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int X = tx0 - 2 + 8 * gc + 2 * r + p;
+            o[r] = (yok & (X >= 0) & (X < a.W)) ? o[r] : 0.f;
+          }
+        }
+        if (live) {
+          float *dst = tmid + (4 * gr * G::AW + 8 * gc) * 8 + lane_mid;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[r * 16] = o[r];
         }
       }
-      if (live) {
-        float *dst = tmid + (4 * gr * G::AW + 8 * gc) * 8 + lane_mid;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[r * 16] = v[r];
-      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---------------- phase B: layer B out of tmid, BN + ReLU + 2x2 max-pool -> global ----------------
-  {
-    f32x4 acc[4];
-    int gmid[4];
-    const int lane_b = ((m & 1) * G::AW + 2 * (m >> 1) + 1) * 8 + ksub * 2;
+    // ---------------- phase B: layer B out of tmid, BN + ReLU + 2x2 max-pool -> global ----------------
+    {
+      f32x4 acc[4];
+      int gmid[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int gy = 2 * wave + (g >> 1), gx = g & 1;
-      gmid[g] = (2 * gy * G::AW + 16 * gx) * 8 + lane_b;
-      acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int gy = 2 * wave + (g >> 1), gx = g & 1;
+        gmid[g] = (2 * gy * G::AW + 16 * gx) * 8 + lane_b;
+        acc[g] = f32x4{shB, shB, shB, shB};
+      }
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kxp = 0; kxp < 4; ++kxp) {
-        f32x2 av[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          av[g] = *reinterpret_cast<const f32x2 *>(&tmid[gmid[g] + (ky * G::AW + kxp) * 8]);
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg)
+        for (int kxp = 0; kxp < 4; ++kxp) {
+          f32x2 av[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][cg], bB[ky * 4 + kxp][cg], acc[g], 0, 0, 0);
-      }
-    const int prow0 = (ty0 >> 1) + wave * 2, pcol0 = (tx0 >> 1) + 2 * qo + p;
+            av[g] = *reinterpret_cast<const f32x2 *>(&tmid[gmid[g] + (ky * G::AW + kxp) * 8]);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v[4];
+          for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[g][r] * scB + shB;
-        if (a.reluB) v[r] = fmaxf(v[r], 0.f);
+            for (int g = 0; g < 4; ++g)
+              acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][cg], bB[ky * 4 + kxp][cg], acc[g], 0, 0, 0);
+        }
+      const int prow0 = (ty0 >> 1) + wave * 2, pcol0 = (tx0 >> 1) + 2 * qo + p;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // ReLU commutes with max: pool first.  registers (2j, 2j+1) = rows (0, 1) of pair
+        // 2*qo + j; lane n^8 holds the pair's other pixel
+        const float t0 = fmaxf(fmaxf(acc[g][0], acc[g][1]), loB), t1 = fmaxf(fmaxf(acc[g][2], acc[g][3]), loB);
+        const float u0 = fmaxf(t0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0x128, 0xf, 0xf, true)));
+        const float u1 = fmaxf(t1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x128, 0xf, 0xf, true)));
+        const float ov = p ? u1 : u0;  // lane (p, co) stores pooled pixel 2*qo + p
+        const int prow = prow0 + (g >> 1), pcol = pcol0 + 8 * (g & 1);
+        if ((co < a.CoutB) & (prow < a.Ho) & (pcol < a.Wo) & !(a.ablate & 1))
+          a.y[((size_t)(b * a.Ho + prow) * a.Wo + pcol) * a.CoutB + co] = ov;
       }
-      // registers (2j, 2j+1) = rows (0, 1) of pair 2*qo + j; lane n^8 holds the pair's other pixel
-      const float t0 = fmaxf(v[0], v[1]), t1 = fmaxf(v[2], v[3]);
-      const float u0 = fmaxf(t0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0x128, 0xf, 0xf, true)));
-      const float u1 = fmaxf(t1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x128, 0xf, 0xf, true)));
-      const float o = p ? u1 : u0;  // lane (p, co) stores pooled pixel 2*qo + p
-      const int prow = prow0 + (g >> 1), pcol = pcol0 + 8 * (g & 1);
-      if ((co < a.CoutB) & (prow < a.Ho) & (pcol < a.Wo) & !(a.ablate & 1))
-        a.y[((size_t)(b * a.Ho + prow) * a.Wo + pcol) * a.CoutB + co] = o;
     }
   }
 }
@@ -498,7 +524,13 @@ int launch8(const PArgs &a, int B, hipStream_t st) {
     attr = true;
   }
   const int tiles_x = ceil_div(a.W, G::TW), tiles_y = ceil_div(a.H, G::TH);
-  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * B), dim3(256), lds, st, a, tiles_x, tiles_y);
+  const int ntiles = tiles_x * tiles_y * B;
+  static int wgs = -1;  // RA_PAIR8_WGS: tuning aid, persistent workgroups (default 3 per CU)
+  if (wgs < 0) {
+    const char *e = getenv("RA_PAIR8_WGS");
+    wgs = e ? atoi(e) : 768;
+  }
+  hipLaunchKernelGGL(kern, dim3(ntiles < wgs ? ntiles : wgs), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_f32");
 }
 

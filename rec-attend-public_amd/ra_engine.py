@@ -14,6 +14,8 @@ The canvas is channel D of the packed NHWC image `img` = [x | canvas | d_in | y_
 both the controller CNN and the extract kernel stream one 16-byte-aligned pixel record.
 """
 import numpy as np
+import math
+
 import torch
 
 import ra_native as rn
@@ -333,6 +335,10 @@ class DecodeEngine(object):
     ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), self.d['C0p'], b['img'])
     if 'canvas' in b:
       b['canvas'].zero_()  # full_model.py:239
+      if not self.box and not self.d['disable_overwrite']:
+        # every pixel outside an attention window is sigmoid(0 - 5) (full_model.py:813-818): fill
+        # once per forward at memset speed, the per-timestep paste then writes windows only
+        b['y_out'].fill_(1.0 / (1.0 + math.exp(5.0)))
     self._mark('pack')
 
   def _launch_tail(self, b, tt, want_box, src):
@@ -391,8 +397,13 @@ class DecodeEngine(object):
                 b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
       self._mark('score')
       if direct:
+        # y_out was prefilled with sigmoid(beta) (_launch_pack) and after the first paste the canvas
+        # is >= sigmoid(beta) everywhere, so only the attention window is touched
+        flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | \
+            (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
         ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
-                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'])
+                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
+                         flags=flags)
       else:
         ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
                          d['disable_overwrite'], b['img'], d['D'],

@@ -35,6 +35,7 @@ _Z = C.c_size_t
 SIGNATURES = {
     'ra_version': (_I, []),
     'ra_last_error_string': (C.c_char_p, []),
+    'ra_debug_poison_lds': (_I, [_P]),
     'ra_hungarian_f32': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'ra_hungarian_dev_workspace_bytes': (_Z, [_I, _I, _I]),
     'ra_hungarian_f32_dev': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
@@ -61,7 +62,7 @@ SIGNATURES = {
                                  _I, _P, _Z, _P, _P]),
     'ra_attn_box_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     'ra_extract_direct_f32': (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'ra_paste_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _I, _P, _Z, _P]),
+    'ra_paste_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _I, _P, _Z, _I, _P]),
     'ra_attn_box_direct_f32': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     'ra_extract_patch_dense_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_dense_f32': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _P]),

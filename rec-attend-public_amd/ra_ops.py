@@ -159,6 +159,11 @@ def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample
   return out
 
 
+def poison_lds():
+  """Test aid: leave NaN in every CU's LDS (see ra_debug_poison_lds)."""
+  check(rn.lib().ra_debug_poison_lds(rn.stream_ptr()), 'ra_debug_poison_lds')
+
+
 def conv_pair_supported(cin, cout_a, cout_b):
   return bool(rn.lib().ra_conv_pair_supported(int(cin), int(cout_a), int(cout_b)))
 
@@ -232,14 +237,18 @@ def extract_direct(img, chan0, attn, Fh, Fw, Cp, use_gamma, patch, canvas=None, 
                                        rn.stream_ptr()), 'ra_extract_direct_f32')
 
 
+PASTE_Y_PREFILLED, PASTE_CANVAS_FLOORED = 1, 2
+
+
 def paste_direct(patch, pc, attn, beta, disable_overwrite, y_out, y_stride_b, H, W, canvas=None,
-                 img=None, canvas_chan=-1):
+                 img=None, canvas_chan=-1, flags=0):
   _need_cuda(patch, attn, canvas, img)
   B, Fh, Fw, Cp = patch.shape
   Ci = 0 if img is None else img.shape[3]
   check(rn.lib().ra_paste_direct_f32(ptr(patch), Cp, pc, ptr(attn), B, H, W, Fh, Fw, C.c_float(beta),
                                      int(disable_overwrite), ptr(canvas), ptr(img), Ci,
-                                     int(canvas_chan), ptr(y_out), y_stride_b, rn.stream_ptr()),
+                                     int(canvas_chan), ptr(y_out), y_stride_b, int(flags),
+                                     rn.stream_ptr()),
         'ra_paste_direct_f32')
 
 

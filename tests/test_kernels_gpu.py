@@ -373,6 +373,18 @@ def test_direct_extract_paste_box(cuda, H, W, big):
       if not plane:
         gi = dimg.cpu().numpy()
         assert (gi[..., [0, 1, 2, 4, 5, 6, 7]] == img_ref[..., [0, 1, 2, 4, 5, 6, 7]]).all()
+  # window-only paste: y_out prefilled with sigmoid(beta), canvas already >= sigmoid(beta)
+  y_dead = 1.0 / (1.0 + np.exp(5.0))
+  cfl = np.maximum(canvas0, np.float32(y_dead))
+  dcv = dev(cfl, cuda)
+  y_out = torch.full((B, 2, H, W), y_dead, dtype=torch.float32, device=cuda)
+  ops.paste_direct(dev(P, cuda), 0, dev(rec, cuda), -5.0, False, y_out.data_ptr() + H * W * 4,
+                   2 * H * W, H, W, canvas=dcv,
+                   flags=ops.PASTE_Y_PREFILLED | ops.PASTE_CANVAS_FLOORED)
+  torch.cuda.synchronize()
+  got = y_out.cpu().numpy()
+  assert (got[:, 0] == np.float32(y_dead)).all() and np.abs(got[:, 1] - yy).max() < 2e-5
+  assert np.abs(dcv.cpu().numpy() - np.maximum(yy, cfl)).max() < 2e-5
   box = torch.zeros((B, H, W), dtype=torch.float32, device=cuda)
   ops.attn_box_direct(dev(rec, cuda), H, W, 48, 48, -5.0, box, H * W)
   ones = np.ones((B, 48, 48, 1))
