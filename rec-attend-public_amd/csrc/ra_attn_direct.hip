@@ -7,6 +7,8 @@
 //   modellib.get_gaussian_filter modellib.py:581-612, extract_patch :615-641,
 //   full_model.py:778-789 (read), :810-818,:843-845 (write + canvas), :738-741 (attention box).
 // Same banding rule as ra_attn.hip: taps whose weight is below exp(-30) of the peak are skipped.
+#include <cstdlib>
+
 #include "ra_common.h"
 
 namespace ra {
@@ -173,25 +175,38 @@ __global__ __launch_bounds__(256) void extract_direct_kernel(const float *img, i
 __device__ inline float sigmoidf(float z) { return 1.0f / (1.0f + __expf(-z)); }
 
 // y[b,l,w] = sigmoid(e^g * sum_j sum_i fy(l,j) P[j,i] fx(w,i) + beta) [* (1 - canvas)];
-// canvas = max(canvas, y).  One workgroup per image row.  MODE 0: paste, 1: attention box.
+// canvas = max(canvas, y).  One workgroup per kPasteRows image rows.  MODE 0: paste, 1: attention box.
+struct PasteGeo {
+  int rows, threads;
+};
+inline PasteGeo paste_geo() {  // RA_PASTE_GEO=<rows>,<threads>: tuning aid
+  static PasteGeo g = {0, 0};
+  if (!g.rows) {
+    g = PasteGeo{4, 256};
+    if (const char *e = getenv("RA_PASTE_GEO")) sscanf(e, "%d,%d", &g.rows, &g.threads);
+  }
+  return g;
+}
 template <int MODE>
-__global__ __launch_bounds__(128) void paste_direct_kernel(const float *patch, int Cp, int pc,
+__global__ __launch_bounds__(256) void paste_direct_kernel(const float *patch, int Cp, int pc,
                                                             const float *attn, int H, int W, int Fh,
                                                             int Fw, float beta, int disable_overwrite,
                                                             float *canvas, float *img, int Ci,
                                                             int canvas_chan, float *y_out,
-                                                            size_t y_stride_b, int flags) {
-  extern __shared__ float V[];  // [Fw]:  V[i] = sum_j fy(l,j) P[j,i]
-  const int l = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+                                                            size_t y_stride_b, int flags, int kPasteRows) {
+  extern __shared__ float V[];  // [kPasteRows][Fw]:  V[r][i] = sum_j fy(l0 + r, j) P[j,i]
+  const int l0 = blockIdx.x * kPasteRows, b = blockIdx.y, t = threadIdx.x;
   const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
   const Axis Ay = make_axis(rec, 0, H, Fh), Ax = make_axis(rec, 1, W, Fw);
-  int jlo, jhi;
-  Ay.taps(l, jlo, jhi);
+  const int nrow = (H - l0) < kPasteRows ? (H - l0) : kPasteRows;
   // Pixels no tap reaches have y = sigmoid(beta) and leave a canvas that is already >= sigmoid(beta)
   // unchanged: with both promises from the caller (flags) only the window is touched.
   const bool skip_dead = (flags & RA_PASTE_Y_PREFILLED) && (MODE != 0 || !canvas || (flags & RA_PASTE_CANVAS_FLOORED)) &&
                          (MODE != 0 || canvas || !img);
-  if (skip_dead && jlo >= jhi) return;
+  int jall_lo, jall_hi, jtmp;
+  Ay.taps(l0, jall_lo, jtmp);
+  Ay.taps(l0 + nrow - 1, jtmp, jall_hi);  // tap ranges are monotone in l: union over the rows
+  if (skip_dead && jall_lo >= jall_hi) return;
   int wbeg = 0, wend = W;
   if (skip_dead) {
     int w0, w1, tmp;
@@ -201,26 +216,47 @@ __global__ __launch_bounds__(128) void paste_direct_kernel(const float *patch, i
     wend = (w1 + 3) & ~3;
     wend = wend < W ? wend : W;
   }
-  for (int i = t; i < Fw; i += blockDim.x) {
+  for (int e = t; e < nrow * Fw; e += blockDim.x) {
+    const int r = e / Fw, i = e - r * Fw, l = l0 + r;
+    int jlo, jhi;
+    Ay.taps(l, jlo, jhi);
     float s = 0.0f;
     if (MODE == 0) {
+      // batches of 8 independent loads: a dependent load-FMA chain would cost one L2 round trip
+      // per tap, and the taps of a row are the whole critical path of this kernel
       const float *pb = patch + ((size_t)b * Fh * Fw + i) * Cp + pc;
-      for (int j = jlo; j < jhi; ++j) s += Ay.w((float)l, j) * pb[(size_t)j * Fw * Cp];
+      for (int j0 = jlo; j0 < jhi; j0 += 8) {
+        float pvv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = (j0 + u < jhi) ? j0 + u : jhi - 1;
+          pvv[u] = pb[(size_t)j * Fw * Cp];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < jhi) s += Ay.w((float)l, j0 + u) * pvv[u];
+      }
     } else {
       for (int j = jlo; j < jhi; ++j) s += Ay.w((float)l, j);  // P == 1 (const_ones)
     }
-    V[i] = s;
+    V[e] = s;
   }
   __syncthreads();
   const float gain = (MODE == 0) ? __expf(rec[8]) : rec[7];
-  float *yrow = y_out + (size_t)b * y_stride_b + (size_t)l * W;
-  float *crow = canvas ? canvas + ((size_t)b * H + l) * W : nullptr;
-  float *prow = (!canvas && img && canvas_chan >= 0) ? img + ((size_t)b * H + l) * W * Ci + canvas_chan : nullptr;
-  const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(yrow) & 15) == 0) &&
-                   (!crow || (reinterpret_cast<uintptr_t>(crow) & 15) == 0);
-  const bool row_live = jlo < jhi;  // uniform: does any tap reach this row at all?
   const float y_dead = sigmoidf(beta);
-  for (int w4 = wbeg + t * 4; w4 < wend; w4 += blockDim.x * 4) {
+  const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(y_out) & 15) == 0) && ((y_stride_b & 3) == 0) &&
+                   (!canvas || (reinterpret_cast<uintptr_t>(canvas) & 15) == 0);
+  const int ngrp = (wend - wbeg + 3) >> 2;  // float4 column groups of the window
+  for (int e = t; e < nrow * ngrp; e += blockDim.x) {
+    const int r = e / ngrp, w4 = wbeg + 4 * (e - r * ngrp), l = l0 + r;
+    int jlo, jhi;
+    Ay.taps(l, jlo, jhi);
+    const bool row_live = jlo < jhi;
+    if (skip_dead && !row_live) continue;
+    float *yrow = y_out + (size_t)b * y_stride_b + (size_t)l * W;
+    float *crow = canvas ? canvas + ((size_t)b * H + l) * W : nullptr;
+    float *prow = (!canvas && img && canvas_chan >= 0) ? img + ((size_t)b * H + l) * W * Ci + canvas_chan : nullptr;
+    const float *Vr = V + r * Fw;
     f32x4 cv = f32x4{0, 0, 0, 0};
     if (MODE == 0) {
       if (crow && vec) cv = *reinterpret_cast<const f32x4 *>(crow + w4);
@@ -239,7 +275,7 @@ __global__ __launch_bounds__(128) void paste_direct_kernel(const float *patch, i
         Ax.taps(w, ilo, ihi);
         if (ilo < ihi) {
           float s = 0.0f;
-          for (int i = ilo; i < ihi; ++i) s += V[i] * Ax.w((float)w, i);
+          for (int i = ilo; i < ihi; ++i) s += Vr[i] * Ax.w((float)w, i);
           v = sigmoidf(gain * s + beta);
         }
       }
@@ -290,9 +326,12 @@ extern "C" int ra_paste_direct_f32(const float *patch, int Cp, int pc, const flo
   if (!patch || !attn_rec || !y_out || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0 || Cp <= 0 ||
       pc < 0 || pc >= Cp)
     return fail(RA_E_INVALID, "ra_paste_direct_f32: bad argument");
-  hipLaunchKernelGGL(attnd::paste_direct_kernel<0>, dim3(H, B), dim3(128), Fw * sizeof(float),
+  const attnd::PasteGeo pg = attnd::paste_geo();
+  hipLaunchKernelGGL(attnd::paste_direct_kernel<0>, dim3(ceil_div(H, pg.rows), B), dim3(pg.threads),
+                     pg.rows * Fw * sizeof(float),
                      as_stream(stream), patch, Cp, pc, attn_rec, H, W, Fh, Fw, beta, disable_overwrite, canvas,
-                     img, Ci, canvas_chan, y_out, y_stride_b, disable_overwrite ? (flags & ~RA_PASTE_Y_PREFILLED) : flags);
+                     img, Ci, canvas_chan, y_out, y_stride_b, disable_overwrite ? (flags & ~RA_PASTE_Y_PREFILLED) : flags,
+                     pg.rows);
   return launch_status("ra_paste_direct_f32");
 }
 
@@ -300,8 +339,10 @@ extern "C" int ra_attn_box_direct_f32(const float *attn_rec, int B, int H, int W
                                       float *box_out, size_t stride_b, void *stream) {
   if (!attn_rec || !box_out || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0)
     return fail(RA_E_INVALID, "ra_attn_box_direct_f32: bad argument");
-  hipLaunchKernelGGL(attnd::paste_direct_kernel<1>, dim3(H, B), dim3(128), Fw * sizeof(float),
+  const attnd::PasteGeo pg = attnd::paste_geo();
+  hipLaunchKernelGGL(attnd::paste_direct_kernel<1>, dim3(ceil_div(H, pg.rows), B), dim3(pg.threads),
+                     pg.rows * Fw * sizeof(float),
                      as_stream(stream), nullptr, 1, 0, attn_rec, H, W, Fh, Fw, beta, 0, nullptr, nullptr, 0, -1,
-                     box_out, stride_b, 0);
+                     box_out, stride_b, 0, pg.rows);
   return launch_status("ra_attn_box_direct_f32");
 }

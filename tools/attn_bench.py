@@ -25,7 +25,9 @@ eng.forward(torch.rand(B, S, S, 3).cuda()); torch.cuda.synchronize()
 sb, d = eng.subs[0], eng.d
 print('attn rec', sb['attn'][0][0, :6].tolist())
 ex = lambda: ops.extract_direct(sb['img'], 0, sb['attn'][0], 48, 48, 4, True, sb['x_patch'][0], canvas=sb['canvas'], canvas_chan=3)
-pa = lambda: ops.paste_direct(sb['y_out_patch'][0], 0, sb['attn'][0], -5.0, False, sb['y_out'].data_ptr(), T * S * S, S, S, canvas=sb['canvas'])
+import os
+PF = int(os.environ.get('PASTE_FLAGS', '3'))
+pa = lambda: ops.paste_direct(sb['y_out_patch'][0], 0, sb['attn'][0], -5.0, False, sb['y_out'].data_ptr(), T * S * S, S, S, canvas=sb['canvas'], flags=PF)
 print('B=%d extract_direct %.1f us   paste_direct %.1f us  (%.0f GB/s on 12 B/px)' % (B, gtime(ex), gtime(pa), B * S * S * 12 / gtime(pa) / 1e3))
 rec0 = sb['attn'][0].clone()
 for name, mod in (('box off-image', lambda r: r.__setitem__((slice(None), 0), -5000.0)),
