@@ -273,6 +273,171 @@ def f_segm_match_precondition(iou, s_gt):
 
 
 # --------------------------------------------------------------------------------------
+# loss / statistics head of the training graph (forward only), full_model.py:913-1097
+# --------------------------------------------------------------------------------------
+
+_HUNG = None
+
+
+def hungarian_c(w):
+  """The plain-C Hungarian oracle (oracle/hungarian_oracle.c, restating hungarian.cc) on a
+  float32 [B,N,M] weight tensor -> matching [B,N,M]."""
+  global _HUNG
+  import ctypes
+  import os
+  if _HUNG is None:
+    _HUNG = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                     'libhungarian_oracle.so'))
+    _HUNG.ora_hungarian_f32.restype = ctypes.c_int
+  w = np.ascontiguousarray(w, np.float32)
+  B, N, M = w.shape
+  m, cx, cy = np.zeros_like(w), np.zeros((B, N), np.float32), np.zeros((B, M), np.float32)
+  p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+  rc = _HUNG.ora_hungarian_f32(p(w), B, N, M, p(m), p(cx), p(cy))
+  if rc < 0:
+    raise RuntimeError('hungarian oracle failed: %d' % rc)
+  return m
+
+
+def f_iou_pairwise(a, b):
+  """modellib.py:124-155 pairwise=True — a [B,N,H,W], b [B,M,H,W] -> [B,N,M];
+  f_inter :113-116, f_union :119-122 (the 1e-5 is summed over every pixel)."""
+  inter = np.einsum('bnhw,bmhw->bnm', a, b)
+  sa = a.sum(axis=(2, 3))[:, :, None]
+  sb = b.sum(axis=(2, 3))[:, None, :]
+  hw = a.shape[2] * a.shape[3]
+  return inter / (sa + sb - inter + 1e-5 * hw)
+
+
+def f_dice_pairwise(a, b):
+  """modellib.py:71-104 pairwise=True — 2 * inter / (sum(a + 1e-5) + sum(b + 1e-5))."""
+  inter = np.einsum('bnhw,bmhw->bnm', a, b)
+  hw = a.shape[2] * a.shape[3]
+  ca = a.sum(axis=(2, 3))[:, :, None] + 1e-5 * hw
+  cb = b.sum(axis=(2, 3))[:, None, :] + 1e-5 * hw
+  return 2 * inter / (ca + cb)
+
+
+def get_identity_match(s_gt):
+  """modellib.py:28-37."""
+  T = s_gt.shape[1]
+  return np.eye(T, dtype=s_gt.dtype)[None] * s_gt[:, None, :] * s_gt[:, :, None]
+
+
+def f_segm_match(iou, s_gt):
+  """modellib.py:382-415 (Hungarian on the masked, quantised IoU, masked again)."""
+  w, mask_x, mask_y = f_segm_match_precondition(iou, s_gt)
+  return hungarian_c(w).astype(iou.dtype) * mask_x * mask_y
+
+
+def f_coverage_weight(y_gt):
+  """modellib.py:277-289."""
+  s = y_gt.sum(axis=(2, 3))
+  tot = s.sum(axis=1, keepdims=True) + (s == 0).astype(s.dtype)
+  return s / tot
+
+
+def f_weighted_coverage(iou, y_gt):
+  """modellib.py:292-302 (coverage = max over the output axis, :265-274)."""
+  return (iou.max(axis=1) * f_coverage_weight(y_gt)).sum() / y_gt.shape[0]
+
+
+def f_unweighted_coverage(iou, count):
+  """modellib.py:305-313."""
+  return (iou.max(axis=1).sum(axis=1) / count).sum() / iou.shape[0]
+
+
+def f_conf_loss(s_out, match):
+  """modellib.py:316-339 with use_cum_min=True; f_cum_min :40-53, f_cum_max :56-68,
+  f_bce_minmax :430-437."""
+  B, T = s_out.shape
+  match_sum = match.sum(axis=2)
+  s_min = np.minimum.accumulate(s_out, axis=1)
+  s_max = np.maximum.accumulate(s_out[:, ::-1], axis=1)[:, ::-1]
+  eps = 1e-5
+  bce = -match_sum * np.log(s_min + eps) - (1 - match_sum) * np.log(1 - s_max + eps)
+  return bce.sum() / B / T
+
+
+def f_count_stats(s_out, s_gt):
+  """f_count_acc modellib.py:482-494, f_dic :497-511 (abs False / True)."""
+  B = s_out.shape[0]
+  cout = (s_out > 0.5).astype(s_out.dtype).sum(axis=1)
+  cgt = s_gt.sum(axis=1)
+  return (cout == cgt).astype(s_out.dtype).sum() / B, (cout - cgt).sum() / B, \
+      np.abs(cout - cgt).sum() / B
+
+
+def loss_head(opt, fwd, y_gt, s_gt):
+  """The loss and statistics part of the training graph, full_model.py:913-1097, evaluated on
+  the outputs `fwd` of full_model_forward (phase_train False: the GT knobs are off, :762-769,
+  :839-841, and the per-timestep iou_soft_box of the use_knob branch, :756-758, equals the
+  pairwise f_iou).  box_loss_fn / segm_loss_fn in {'iou', 'wt_cov'}."""
+  dt = fwd['y_out'].dtype
+  y_gt, s_gt = y_gt.astype(dt), s_gt.astype(dt)
+  B, T = s_gt.shape
+  y_out, s_out, attn_box = fwd['y_out'], fwd['s_out'], fwd['attn_box']
+  fixed_order = bool(_opt(opt, 'fixed_order', False))
+  # get_gt_attn -> get_gt_box, full_model.py:561-566 (min_padding = padding + 4)
+  _, _, attn_box_gt = get_gt_box(y_gt, padding_ratio=opt['attn_box_padding_ratio'],
+                                 center_shift_ratio=0.0, min_padding=opt['padding'] + 4.0)
+  out = {'attn_box_gt': attn_box_gt}
+  identity = get_identity_match(s_gt)
+  iou_box_pair = f_iou_pairwise(attn_box, attn_box_gt)
+  if fixed_order:
+    match_box = identity
+    iou_box_mask = np.einsum('bii->bi', iou_box_pair)  # f_iou(pairwise=False), :924
+  else:
+    match_box = f_segm_match(iou_box_pair, s_gt)
+    iou_box_mask = (iou_box_pair * match_box).sum(axis=1)
+  out['match_box'] = match_box
+  cnt_box = np.maximum(1.0, match_box.sum(axis=(1, 2)))
+  iou_soft_box = (iou_box_mask.sum(axis=1) / cnt_box).sum() / B
+  box_fn = _opt(opt, 'box_loss_fn', 'iou')
+  if box_fn == 'iou':
+    box_loss = -iou_soft_box
+  elif box_fn == 'wt_cov':  # :967-968 passes the SCALAR iou_soft_box; not restatable -> pairwise
+    raise NotImplementedError('box_loss_fn wt_cov feeds a scalar to f_weighted_coverage (:968)')
+  else:
+    raise NotImplementedError(box_fn)
+  out['iou_soft_box'], out['box_loss'] = iou_soft_box, box_loss
+
+  iou_pair = f_iou_pairwise(y_out, y_gt)
+  real_match = f_segm_match(iou_pair, s_gt)
+  match = identity if fixed_order else real_match
+  out['match'] = match
+  cnt = np.maximum(1.0, match.sum(axis=(1, 2)))
+  out['wt_cov_soft'] = f_weighted_coverage(iou_pair, y_gt)
+  out['unwt_cov_soft'] = f_unweighted_coverage(iou_pair, cnt)
+  if fixed_order:
+    iou_mask = np.einsum('bii->bi', iou_pair)
+  else:
+    iou_mask = (iou_pair * match).sum(axis=1)
+  out['iou_soft'] = (iou_mask.sum(axis=1) / cnt).sum() / B
+  segm_fn = _opt(opt, 'segm_loss_fn', 'iou')
+  if segm_fn == 'iou':
+    segm_loss = -out['iou_soft']
+  elif segm_fn == 'wt_cov':
+    segm_loss = -out['wt_cov_soft']
+  else:
+    raise NotImplementedError(segm_fn)
+  out['segm_loss'] = segm_loss
+  out['conf_loss'] = f_conf_loss(s_out, match)
+  out['loss'] = box_loss + segm_loss + _opt(opt, 'loss_mix_ratio', 1.0) * out['conf_loss']
+
+  y_hard = (y_out > 0.5).astype(dt)
+  iou_hard = f_iou_pairwise(y_hard, y_gt)
+  out['wt_cov_hard'] = f_weighted_coverage(iou_hard, y_gt)
+  out['unwt_cov_hard'] = f_unweighted_coverage(iou_hard, cnt)
+  out['iou_hard'] = ((iou_hard * real_match).sum(axis=(1, 2)) / cnt).sum() / B
+  dice = f_dice_pairwise(y_hard, y_gt)
+  out['dice'] = ((dice * real_match).sum(axis=(1, 2)) / cnt).sum() / B
+  out['count_acc'], out['dic'], out['dic_abs'] = f_count_stats(s_out, s_gt)
+  out['iou_soft_pairwise'], out['iou_hard_pairwise'], out['dice_pairwise'] = iou_pair, iou_hard, dice
+  return out
+
+
+# --------------------------------------------------------------------------------------
 # model option handling shared by both graphs
 # --------------------------------------------------------------------------------------
 

@@ -29,36 +29,44 @@ struct Scratch {
   unsigned char *mark, *inS, *inT, *inN;
 };
 
-__host__ __device__ inline size_t scratch_bytes(int nx, int ny) {
+// The scratch has a HOT part (flow network, equality graph, marks: a few n^2 floats, touched by
+// every step of the serial solver) and the BFS QUEUE ((kMaxIter + 2) * n ints, touched
+// sequentially).  On the device the hot part lives in LDS when it fits — a dependent access costs
+// ~60 cycles there against most of a microsecond in global memory — and the queue stays in the
+// caller's workspace.
+__host__ __device__ inline size_t hot_bytes(int nx, int ny) {
   size_t n = (size_t)nx + ny + 2;
   size_t f = 3 * n * n + (size_t)nx * ny;
-  size_t i = (size_t)(kMaxIter + 2) * n + n;
   size_t b = n + nx + 2 * (size_t)ny;
-  return ((f + i) * 4 + b + 15) / 16 * 16;
+  return ((f + n) * 4 + b + 15) / 16 * 16;
 }
+__host__ __device__ inline size_t queue_bytes(int nx, int ny) {
+  size_t n = (size_t)nx + ny + 2;
+  return ((size_t)(kMaxIter + 2) * n * 4 + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t scratch_bytes(int nx, int ny) { return hot_bytes(nx, ny) + queue_bytes(nx, ny); }
 
-__host__ __device__ inline Scratch carve(void *buf, int nx, int ny) {
+__host__ __device__ inline Scratch carve(void *hot, void *queue, int nx, int ny) {
   Scratch s;
   s.n = nx + ny + 2;
   size_t nn = (size_t)s.n * s.n;
-  float *f = reinterpret_cast<float *>(buf);
+  float *f = reinterpret_cast<float *>(hot);
   s.cap = f;
   s.flow = f + nn;
   s.res = f + 2 * nn;
   s.eq = f + 3 * nn;
-  int *ip = reinterpret_cast<int *>(s.eq + (size_t)nx * ny);
-  s.queue = ip;
-  s.parent = ip + (size_t)(kMaxIter + 2) * s.n;
+  s.parent = reinterpret_cast<int *>(s.eq + (size_t)nx * ny);
   unsigned char *bp = reinterpret_cast<unsigned char *>(s.parent + s.n);
   s.mark = bp;
   s.inS = bp + s.n;
   s.inT = s.inS + nx;
   s.inN = s.inT + ny;
+  s.queue = reinterpret_cast<int *>(queue);
   return s;
 }
 
 // One augmenting-path search + push.  1 = augmented, 0 = no path, <0 = reference LOG(FATAL).
-__host__ __device__ inline int augment(Scratch &g) {
+__host__ __device__ inline int augment(Scratch &g, float cap_max) {
   const int n = g.n, src = 0, dst = n - 1;
   int qh = 0, qt = 0;
   g.queue[qt++] = src;
@@ -84,8 +92,7 @@ __host__ __device__ inline int augment(Scratch &g) {
   }
   if (!reached) return 0;
 
-  float bottleneck = g.cap[0];  // capacity.maxCoeff(), hungarian.cc:144
-  for (int k = 1; k < n * n; ++k) bottleneck = (g.cap[k] > bottleneck) ? g.cap[k] : bottleneck;
+  float bottleneck = cap_max;  // capacity.maxCoeff(), hungarian.cc:144 (constant within a max-flow)
   int v = dst;
   for (int it = 0; g.parent[v] != -1 && it <= kMaxIter; ++it) {
     if (it == kMaxIter) return RA_E_HUNG_PATH;
@@ -121,8 +128,10 @@ __host__ __device__ inline int rematch(Scratch &g, int nx, int ny, float *M) {
     g.flow[k] = 0.0f;
     g.res[k] = g.cap[k];
   }
+  float cap_max = g.cap[0];
+  for (int k = 1; k < n * n; ++k) cap_max = (g.cap[k] > cap_max) ? g.cap[k] : cap_max;
   for (int it = 0;; ++it) {
-    const int r = augment(g);
+    const int r = augment(g, cap_max);
     if (r < 0) return r;
     if (r == 0 || it > kMaxIter) break;
     if (it == kMaxIter) return RA_E_HUNG_FLOW;
@@ -146,8 +155,8 @@ __host__ __device__ inline bool saturating(const float *M, int nx, int ny) {
 
 // hungarian.cc:335-488.  0 solved, 1 outer cap (partial result kept), <0 fatal.
 __host__ __device__ inline int solve(const float *w, int nx, int ny, float *M, float *cx,
-                                     float *cy, void *scratch_buf) {
-  Scratch g = carve(scratch_buf, nx, ny);
+                                     float *cy, void *hot_buf, void *queue_buf) {
+  Scratch g = carve(hot_buf, queue_buf, nx, ny);
   for (int x = 0; x < nx; ++x) {
     float top = w[x * ny];
     for (int y = 1; y < ny; ++y) top = (w[x * ny + y] > top) ? w[x * ny + y] : top;
@@ -246,15 +255,35 @@ __host__ __device__ inline int solve(const float *w, int nx, int ny, float *M, f
   return 1;
 }
 
+// One workgroup (one wave) per example; lane 0 runs the serial solver.  use_lds: the hot scratch and
+// private copies of w / M / cx / cy live in LDS (all 64 lanes stage them in and out).
 __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, int ny, float *M,
                                                         float *cx, float *cy, int *status,
-                                                        char *ws, size_t ws_per_ex) {
-  const int b = blockIdx.x;
-  if (threadIdx.x == 0) {
-    const int rc = solve(w + (size_t)b * nx * ny, nx, ny, M + (size_t)b * nx * ny,
-                         cx + (size_t)b * nx, cy + (size_t)b * ny, ws + (size_t)b * ws_per_ex);
+                                                        char *ws, size_t ws_per_ex, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float *wb = w + (size_t)b * nx * ny;
+  float *Mb = M + (size_t)b * nx * ny, *cxb = cx + (size_t)b * nx, *cyb = cy + (size_t)b * ny;
+  char *wsb = ws + (size_t)b * ws_per_ex;
+  if (!use_lds) {
+    if (t == 0) {
+      const int rc = solve(wb, nx, ny, Mb, cxb, cyb, wsb, wsb + hot_bytes(nx, ny));
+      if (status) status[b] = rc;
+    }
+    return;
+  }
+  float *lw = reinterpret_cast<float *>(lds + hot_bytes(nx, ny));
+  float *lM = lw + nx * ny, *lcx = lM + nx * ny, *lcy = lcx + nx;
+  for (int e = t; e < nx * ny; e += 64) lw[e] = wb[e];
+  __syncthreads();
+  if (t == 0) {
+    const int rc = solve(lw, nx, ny, lM, lcx, lcy, lds, wsb + hot_bytes(nx, ny));
     if (status) status[b] = rc;
   }
+  __syncthreads();
+  for (int e = t; e < nx * ny; e += 64) Mb[e] = lM[e];
+  for (int e = t; e < nx; e += 64) cxb[e] = lcx[e];
+  for (int e = t; e < ny; e += 64) cyb[e] = lcy[e];
 }
 
 inline int merge(int worst, int rc) {
@@ -273,7 +302,8 @@ extern "C" int ra_hungarian_f32(const float *weights, int B, int N, int M, float
   int worst = 0;
   for (int b = 0; b < B; ++b) {
     const int rc = ra::hung::solve(weights + (size_t)b * N * M, N, M, matching + (size_t)b * N * M,
-                                   cover_x + (size_t)b * N, cover_y + (size_t)b * M, scratch.data());
+                                   cover_x + (size_t)b * N, cover_y + (size_t)b * M, scratch.data(),
+                                   scratch.data() + ra::hung::hot_bytes(N, M));
     worst = ra::hung::merge(worst, rc);
   }
   if (worst) ra::set_error("ra_hungarian_f32: status %d", worst);
@@ -295,8 +325,16 @@ extern "C" int ra_hungarian_f32_dev(const float *weights, int B, int N, int M, f
   if (ws_bytes < per * (size_t)B)
     return ra::fail(RA_E_WORKSPACE, "ra_hungarian_f32_dev: workspace %zu < %zu", ws_bytes,
                     per * (size_t)B);
-  hipLaunchKernelGGL(ra::hung::hungarian_kernel, dim3(B), dim3(64), 0, ra::as_stream(stream),
+  const size_t lds = ra::hung::hot_bytes(N, M) + ((size_t)2 * N * M + N + M) * sizeof(float);
+  const int use_lds = lds <= 150 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra::hung::hungarian_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(ra::hung::hungarian_kernel, dim3(B), dim3(64), use_lds ? lds : 0, ra::as_stream(stream),
                      weights, N, M, matching, cover_x, cover_y, status_dev,
-                     reinterpret_cast<char *>(ws), per);
+                     reinterpret_cast<char *>(ws), per, use_lds);
   return ra::launch_status("ra_hungarian_f32_dev");
 }

@@ -1,0 +1,491 @@
+// K8..K10 — the loss / statistics head of the training graph, forward only
+// (full_model.py:913-1097; modellib.py:28-37,71-155,265-339,382-415,482-511,663-701).
+//
+//   K8  pair_stats:  one streaming pass over a [B,N,H,W] and b [B,M,H,W] produces the pairwise
+//       soft IoU, the pairwise IoU and DICE of (a > 0.5), and the per-instance sums — the
+//       reference makes three passes (f_iou soft :981, f_iou hard :1065, f_dice :1073).  The
+//       [N,HW] x [HW,M] contraction runs on v_mfma_f32_16x16x4_f32 with the pixel axis as K;
+//       at 4 FLOP/B it is HBM-bound (32 MiB per image at cfg2), the MFMA only keeps the VALU
+//       out of the way.  Partials per pixel chunk are reduced in a fixed order by a finishing
+//       kernel, so results do not depend on scheduling.
+//   K9  gt_box:      get_gt_box — bounding box of every GT instance by min/max reductions, then
+//       the filled, padded rectangle mask.
+//   K10 segm_match pre/post-processing around the device Hungarian solver, and the scalar
+//       statistics (coverage, matched IoU, DICE, confidence loss, counting) in one workgroup.
+#include <cmath>
+
+#include "ra_common.h"
+
+namespace ra {
+namespace loss {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxT = 32;        // instances per image supported (two 16-row MFMA blocks)
+constexpr int kChunkPx = 4096;   // pixels per workgroup of the streaming pass
+constexpr int kPartFloats = 2 * kMaxT * kMaxT + 3 * kMaxT;  // per-(image, chunk) partial record
+
+// partial record layout: [soft inter NxM (32x32)][hard inter][sum a (32)][sum a>0.5][sum b]
+template <int NI, int NJ>
+__global__ __launch_bounds__(256) void pair_stats_kernel(const float *a, const float *b, int N, int M,
+                                                          int HW, int nchunks, float *part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int chunk = blockIdx.x, img = blockIdx.y;
+  const float *ab = a + (size_t)img * N * HW, *bb = b + (size_t)img * M * HW;
+  f32x4 accs[NI][NJ], acch[NI][NJ];
+  float sa[NI], sah[NI], sb[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    sa[i] = sah[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) accs[i][j] = acch[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sb[j] = 0.f;
+  // a wave streams 64 pixels per step: lane (row r, quad q) loads float4s at 16u + 4q, so a row is
+  // read in 256-byte runs; MFMA step e pairs element e of the a- and b-float4 of the same lane
+  // (A[m=r][k=q] = a[r][px], B[k=q][n=r] = b[r][px]: any pixel order works if both use it)
+  const int px_begin = chunk * kChunkPx + wave * (kChunkPx / 4), px_end = px_begin + kChunkPx / 4;
+  f32x4 av[NI][4], bv[NJ][4], an[NI][4], bn[NJ][4];
+  auto fetch = [&](int p0, f32x4 (&xa)[NI][4], f32x4 (&xb)[NJ][4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int px = p0 + 16 * u + 4 * q;
+      const bool ok = (px < HW) & (p0 < px_end);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        xa[i][u] = (ok && 16 * i + r < N) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(16 * i + r) * HW + px)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        xb[j][u] = (ok && 16 * j + r < M) ? *reinterpret_cast<const f32x4 *>(bb + (size_t)(16 * j + r) * HW + px)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(px_begin, an, bn);
+  for (int p0 = px_begin; p0 < px_end; p0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) av[i][u] = an[i][u];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[j][u] = bn[j][u];
+    }
+    fetch(p0 + 64, an, bn);  // the next step's loads fly while this step is computed
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f32x4 ah[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ah[i][e] = av[i][u][e] > 0.5f ? 1.f : 0.f;  // full_model.py:1064
+        sa[i] += (av[i][u][0] + av[i][u][1]) + (av[i][u][2] + av[i][u][3]);
+        sah[i] += (ah[i][0] + ah[i][1]) + (ah[i][2] + ah[i][3]);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sb[j] += (bv[j][u][0] + bv[j][u][1]) + (bv[j][u][2] + bv[j][u][3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            accs[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u][e], bv[j][u][e], accs[i][j], 0, 0, 0);
+            acch[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][e], bv[j][u][e], acch[i][j], 0, 0, 0);
+          }
+    }
+  }
+  // reduce the 4 waves through LDS in a fixed order, then one record per (image, chunk)
+  __shared__ float red[4][kPartFloats];
+  float *mine = red[wave];
+  for (int e = lane; e < kPartFloats; e += 64) mine[e] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // D[m = 4*(lane>>4) + k][n = lane & 15]
+        const int m = 16 * i + 4 * q + k, n = 16 * j + r;
+        mine[m * kMaxT + n] = accs[i][j][k];
+        mine[kMaxT * kMaxT + m * kMaxT + n] = acch[i][j][k];
+      }
+  // row sums: lanes (r, q = 0..3) hold partials of the same row
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float s = sa[i], h = sah[i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    h += __shfl_xor(h, 16);
+    h += __shfl_xor(h, 32);
+    if (q == 0) {
+      mine[2 * kMaxT * kMaxT + 16 * i + r] = s;
+      mine[2 * kMaxT * kMaxT + kMaxT + 16 * i + r] = h;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float s = sb[j];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (q == 0) mine[2 * kMaxT * kMaxT + 2 * kMaxT + 16 * j + r] = s;
+  }
+  __syncthreads();
+  float *dst = part + ((size_t)img * nchunks + chunk) * kPartFloats;
+  for (int e = tid; e < kPartFloats; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// sum the chunk records of one image in a fixed order: block (x = 256-element slice, y = image)
+__global__ __launch_bounds__(256) void pair_stats_reduce_kernel(const float *part, int nchunks, float *tot) {
+  const int img = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kPartFloats) return;
+  const float *src = part + (size_t)img * nchunks * kPartFloats + e;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 8 <= nchunks; c += 8)  // 8 independent loads in flight
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] += src[(size_t)(c + k) * kPartFloats];
+  for (; c < nchunks; ++c) s[0] += src[(size_t)c * kPartFloats];
+  tot[(size_t)img * kPartFloats + e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+// one workgroup per image: the ratios
+__global__ __launch_bounds__(256) void pair_stats_finish_kernel(const float *totals, int N, int M, int HW,
+                                                                 float *iou_soft, float *iou_hard,
+                                                                 float *dice_hard, float *sum_a, float *sum_b) {
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const float *tot = totals + (size_t)img * kPartFloats;
+  const float eps_hw = 1e-5f * (float)HW;  // modellib.py:119-122: the eps is summed per pixel
+  const float *sa = tot + 2 * kMaxT * kMaxT, *sah = sa + kMaxT, *sb = sah + kMaxT;
+  for (int e = tid; e < N * M; e += 256) {
+    const int i = e / M, j = e - i * M;
+    const float is = tot[i * kMaxT + j], ih = tot[kMaxT * kMaxT + i * kMaxT + j];
+    const size_t o = ((size_t)img * N + i) * M + j;
+    if (iou_soft) iou_soft[o] = is / (sa[i] + sb[j] - is + eps_hw);
+    if (iou_hard) iou_hard[o] = ih / (sah[i] + sb[j] - ih + eps_hw);
+    if (dice_hard) dice_hard[o] = 2.f * ih / ((sah[i] + eps_hw) + (sb[j] + eps_hw));  // modellib.py:92-98
+  }
+  if (sum_a)
+    for (int i = tid; i < N; i += 256) sum_a[(size_t)img * N + i] = sa[i];
+  if (sum_b)
+    for (int j = tid; j < M; j += 256) sum_b[(size_t)img * M + j] = sb[j];
+}
+
+// ---- K9: get_gt_box (modellib.py:663-701) ----
+// params record per (b, t): [0..1] top_left (y, x), [2..3] bot_right after the empty-instance
+// fix-up, [4..7] the padded rectangle the mask is filled with (tl_y, tl_x, br_y, br_x)
+__global__ __launch_bounds__(256) void gt_box_reduce_kernel(const float *y_gt, int H, int W, float pad_ratio,
+                                                             float min_pad, float *params) {
+  __shared__ float red[5][256];
+  const int inst = blockIdx.x, tid = threadIdx.x;
+  const float *y = y_gt + (size_t)inst * H * W;
+  const float big = (float)(H * W);
+  float mny = 3.0e38f, mnx = 3.0e38f, mxy = -3.0e38f, mxx = -3.0e38f, sum = 0.f;
+  for (int e = tid * 4; e < H * W; e += 256 * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(y + e);  // H*W % 4 == 0 checked by the host
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = (e + k) / W, xx = (e + k) - yy * W;
+      const float g = v[k];
+      mny = fminf(mny, (float)yy + (1.f - g) * big);
+      mnx = fminf(mnx, (float)xx + (1.f - g) * big);
+      mxy = fmaxf(mxy, (float)yy * g);
+      mxx = fmaxf(mxx, (float)xx * g);
+      sum += g;
+    }
+  }
+  red[0][tid] = mny;
+  red[1][tid] = mnx;
+  red[2][tid] = mxy;
+  red[3][tid] = mxx;
+  red[4][tid] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      red[0][tid] = fminf(red[0][tid], red[0][tid + s]);
+      red[1][tid] = fminf(red[1][tid], red[1][tid + s]);
+      red[2][tid] = fmaxf(red[2][tid], red[2][tid + s]);
+      red[3][tid] = fmaxf(red[3][tid], red[3][tid + s]);
+      red[4][tid] += red[4][tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float tl[2] = {red[0][0], red[1][0]}, br[2] = {red[2][0], red[3][0]};
+    const float nz = red[4][0] > 0.f ? 1.f : 0.f;
+    float *p = params + (size_t)inst * 8;
+    for (int k = 0; k < 2; ++k) {
+      const float size = br[k] - tl[k];
+      const float pad = fmaxf(pad_ratio * size, min_pad);
+      tl[k] -= pad;
+      br[k] += pad;
+      p[4 + k] = tl[k];
+      p[6 + k] = br[k];
+      p[k] = tl[k] * nz;
+      p[2 + k] = nz * br[k] + (1.f - nz) * (2.f * min_pad);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gt_box_fill_kernel(const float *params, int H, int W, float *box) {
+  const int inst = blockIdx.y;
+  const float *p = params + (size_t)inst * 8;
+  const float ty = p[4], tx = p[5], by = p[6], bx = p[7];
+  float *o = box + (size_t)inst * H * W;
+  for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < H * W; e += gridDim.x * 256 * 4) {
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = (e + k) / W, xx = (e + k) - yy * W;
+      v[k] = ((float)yy >= ty && (float)xx >= tx && (float)yy <= by && (float)xx <= bx) ? 1.f : 0.f;
+    }
+    *reinterpret_cast<f32x4 *>(o + e) = v;
+  }
+}
+
+// ---- K10: f_segm_match pre/post (modellib.py:395-413) ----
+__global__ void match_pre_kernel(const float *iou, const float *s_gt, int N, int total, float *w) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int j = e % N, i = (e / N) % N, b = e / (N * N);
+  const float m = iou[e] * s_gt[b * N + j] * s_gt[b * N + i];
+  // tf.round(x * 1e6) / 1e6 taken as floor(x + 0.5), then + eps
+  w[e] = floorf(m * 1e6f + 0.5f) / 1e6f + 1e-5f;
+}
+
+__global__ void match_post_kernel(float *match, const float *s_gt, int N, int total) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int j = e % N, i = (e / N) % N, b = e / (N * N);
+  match[e] = match[e] * s_gt[b * N + j] * s_gt[b * N + i];
+}
+
+__device__ inline float block_sum(float v, float *scratch) {
+  const int tid = threadIdx.x;
+  scratch[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) scratch[tid] += scratch[tid + s];
+    __syncthreads();
+  }
+  const float r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
+// All scalar statistics in one workgroup; thread t owns images t, t+256, ... (B is small).
+// out: see RA_STAT_* in recattend.h.
+__global__ __launch_bounds__(256) void loss_stats_kernel(
+    const float *iou_soft, const float *iou_hard, const float *dice, const float *match_real,
+    const float *iou_box, const float *match_box, const float *s_out, const float *s_gt,
+    const float *sum_gt, int B, int T, int fixed_order, int segm_fn, float mix, float *out) {
+  __shared__ float scratch[256];
+  float v_iou_soft = 0, v_iou_box = 0, v_wt_soft = 0, v_unwt_soft = 0, v_wt_hard = 0, v_unwt_hard = 0,
+        v_iou_hard = 0, v_dice = 0, v_conf = 0, v_cacc = 0, v_dic = 0, v_dica = 0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float *sg = s_gt + (size_t)b * T, *so = s_out + (size_t)b * T;
+    const float *is = iou_soft + (size_t)b * T * T, *ih = iou_hard + (size_t)b * T * T;
+    const float *dc = dice + (size_t)b * T * T, *mr = match_real + (size_t)b * T * T;
+    const float *ib = iou_box + (size_t)b * T * T, *mb = match_box + (size_t)b * T * T;
+    // identity match (modellib.py:28-37) when fixed_order, else the Hungarian matches
+    float cnt = 0.f, cnt_box = 0.f, m_is = 0.f, m_ib = 0.f, m_ih = 0.f, m_dc = 0.f;
+    for (int i = 0; i < T; ++i)
+      for (int j = 0; j < T; ++j) {
+        const float ident = (i == j) ? sg[i] * sg[j] : 0.f;
+        const float m = fixed_order ? ident : mr[i * T + j];
+        const float mbx = fixed_order ? ident : mb[i * T + j];
+        cnt += m;
+        cnt_box += mbx;
+        m_is += is[i * T + j] * m;
+        m_ib += ib[i * T + j] * mbx;
+        m_ih += ih[i * T + j] * mr[i * T + j];  // hard statistics always use the real match (:1062)
+        m_dc += dc[i * T + j] * mr[i * T + j];
+      }
+    cnt = fmaxf(1.f, cnt);
+    cnt_box = fmaxf(1.f, cnt_box);
+    v_iou_soft += m_is / cnt;
+    v_iou_box += m_ib / cnt_box;
+    v_iou_hard += m_ih / cnt;
+    v_dice += m_dc / cnt;
+    // coverage: max over the output axis per GT instance (modellib.py:265-313)
+    float tot_gt = 0.f;
+    for (int j = 0; j < T; ++j) tot_gt += sum_gt[(size_t)b * T + j];
+    float cs = 0.f, ch = 0.f, ws = 0.f, wh = 0.f;
+    for (int j = 0; j < T; ++j) {
+      float mxs = -3.0e38f, mxh = -3.0e38f;
+      for (int i = 0; i < T; ++i) {
+        mxs = fmaxf(mxs, is[i * T + j]);
+        mxh = fmaxf(mxh, ih[i * T + j]);
+      }
+      const float g = sum_gt[(size_t)b * T + j];
+      const float wt = g / (tot_gt + (g == 0.f ? 1.f : 0.f));
+      cs += mxs;
+      ch += mxh;
+      ws += mxs * wt;
+      wh += mxh * wt;
+    }
+    v_wt_soft += ws;
+    v_wt_hard += wh;
+    v_unwt_soft += cs / cnt;
+    v_unwt_hard += ch / cnt;
+    // confidence loss with cumulative min / max (modellib.py:316-339,430-437)
+    float cmax[kMaxT];
+    float run = -3.0e38f;
+    for (int i = T - 1; i >= 0; --i) {
+      run = fmaxf(run, so[i]);
+      cmax[i] = run;
+    }
+    float cmin = 3.0e38f, cout = 0.f, cgt = 0.f;
+    for (int i = 0; i < T; ++i) {
+      cmin = fminf(cmin, so[i]);
+      float msum = 0.f;
+      for (int j = 0; j < T; ++j)
+        msum += fixed_order ? ((i == j) ? sg[i] * sg[j] : 0.f) : mr[i * T + j];
+      v_conf += -msum * logf(cmin + 1e-5f) - (1.f - msum) * logf(1.f - cmax[i] + 1e-5f);
+      cout += so[i] > 0.5f ? 1.f : 0.f;
+      cgt += sg[i];
+    }
+    v_cacc += (cout == cgt) ? 1.f : 0.f;
+    v_dic += cout - cgt;
+    v_dica += fabsf(cout - cgt);
+  }
+  const float nb = (float)B;
+  const float iou_soft_s = block_sum(v_iou_soft, scratch) / nb;
+  const float iou_box_s = block_sum(v_iou_box, scratch) / nb;
+  const float wt_soft = block_sum(v_wt_soft, scratch) / nb;
+  const float unwt_soft = block_sum(v_unwt_soft, scratch) / nb;
+  const float wt_hard = block_sum(v_wt_hard, scratch) / nb;
+  const float unwt_hard = block_sum(v_unwt_hard, scratch) / nb;
+  const float iou_hard_s = block_sum(v_iou_hard, scratch) / nb;
+  const float dice_s = block_sum(v_dice, scratch) / nb;
+  const float conf = block_sum(v_conf, scratch) / nb / (float)T;
+  const float cacc = block_sum(v_cacc, scratch) / nb;
+  const float dic = block_sum(v_dic, scratch) / nb;
+  const float dica = block_sum(v_dica, scratch) / nb;
+  if (threadIdx.x == 0) {
+    const float box_loss = -iou_box_s;  // box_loss_fn 'iou' (full_model.py:965-966)
+    const float segm_loss = segm_fn == 1 ? -wt_soft : -iou_soft_s;  // :1013-1016
+    out[RA_STAT_LOSS] = box_loss + segm_loss + mix * conf;
+    out[RA_STAT_BOX_LOSS] = box_loss;
+    out[RA_STAT_SEGM_LOSS] = segm_loss;
+    out[RA_STAT_CONF_LOSS] = conf;
+    out[RA_STAT_IOU_SOFT] = iou_soft_s;
+    out[RA_STAT_IOU_SOFT_BOX] = iou_box_s;
+    out[RA_STAT_WT_COV_SOFT] = wt_soft;
+    out[RA_STAT_UNWT_COV_SOFT] = unwt_soft;
+    out[RA_STAT_IOU_HARD] = iou_hard_s;
+    out[RA_STAT_WT_COV_HARD] = wt_hard;
+    out[RA_STAT_UNWT_COV_HARD] = unwt_hard;
+    out[RA_STAT_DICE] = dice_s;
+    out[RA_STAT_COUNT_ACC] = cacc;
+    out[RA_STAT_DIC] = dic;
+    out[RA_STAT_DIC_ABS] = dica;
+  }
+}
+
+inline int nchunks_for(int HW) { return ceil_div(HW, kChunkPx); }
+
+}  // namespace loss
+}  // namespace ra
+
+using namespace ra;
+
+extern "C" size_t ra_pair_stats_workspace_floats(int B, int HW) {
+  if (B <= 0 || HW <= 0) return 0;
+  return (size_t)B * (loss::nchunks_for(HW) + 1) * loss::kPartFloats;  // chunk records + totals
+}
+
+extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
+                                 size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
+                                 float *sum_a, float *sum_b, void *stream) {
+  if (!a || !b || !ws || B <= 0 || N <= 0 || M <= 0 || HW <= 0)
+    return fail(RA_E_INVALID, "ra_pair_stats_f32: bad argument");
+  if (N > loss::kMaxT || M > loss::kMaxT || HW % 4)
+    return fail(RA_E_SHAPE, "ra_pair_stats_f32: N=%d M=%d (max %d), HW=%d (multiple of 4)", N, M, loss::kMaxT, HW);
+  if (ws_floats < ra_pair_stats_workspace_floats(B, HW))
+    return fail(RA_E_WORKSPACE, "ra_pair_stats_f32: workspace of %zu floats, need %zu", ws_floats,
+                ra_pair_stats_workspace_floats(B, HW));
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15)
+    return fail(RA_E_INVALID, "ra_pair_stats_f32: inputs must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const int nch = loss::nchunks_for(HW);
+  const dim3 grid(nch, B);
+  const int ni = N > 16 ? 2 : 1, nj = M > 16 ? 2 : 1;
+  if (ni == 1 && nj == 1)
+    hipLaunchKernelGGL((loss::pair_stats_kernel<1, 1>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+  else if (ni == 2 && nj == 2)
+    hipLaunchKernelGGL((loss::pair_stats_kernel<2, 2>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+  else if (ni == 1)
+    hipLaunchKernelGGL((loss::pair_stats_kernel<1, 2>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+  else
+    hipLaunchKernelGGL((loss::pair_stats_kernel<2, 1>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+  int rc = launch_status("ra_pair_stats_f32");
+  if (rc) return rc;
+  float *tot = ws + (size_t)B * nch * loss::kPartFloats;
+  hipLaunchKernelGGL(loss::pair_stats_reduce_kernel, dim3(ceil_div(loss::kPartFloats, 256), B), dim3(256), 0, st, ws,
+                     nch, tot);
+  hipLaunchKernelGGL(loss::pair_stats_finish_kernel, dim3(B), dim3(256), 0, st, tot, N, M, HW, iou_soft, iou_hard,
+                     dice_hard, sum_a, sum_b);
+  return launch_status("ra_pair_stats_f32");
+}
+
+extern "C" int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, float padding_ratio,
+                             float min_padding, float *params, float *box, void *stream) {
+  if (!y_gt || !params || B <= 0 || T <= 0 || H <= 0 || W <= 0)
+    return fail(RA_E_INVALID, "ra_gt_box_f32: bad argument");
+  if ((H * W) % 4 || (reinterpret_cast<uintptr_t>(y_gt) & 15) || (box && (reinterpret_cast<uintptr_t>(box) & 15)))
+    return fail(RA_E_SHAPE, "ra_gt_box_f32: H*W must be a multiple of 4 and the tensors 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(loss::gt_box_reduce_kernel, dim3(B * T), dim3(256), 0, st, y_gt, H, W, padding_ratio,
+                     min_padding, params);
+  int rc = launch_status("ra_gt_box_f32");
+  if (rc || !box) return rc;
+  const int gx = ceil_div(H * W, 256 * 4 * 4);
+  hipLaunchKernelGGL(loss::gt_box_fill_kernel, dim3(gx, B * T), dim3(256), 0, st, params, H, W, box);
+  return launch_status("ra_gt_box_f32");
+}
+
+extern "C" size_t ra_segm_match_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  const size_t w = (size_t)B * N * N * sizeof(float);                         // quantised weights
+  const size_t cov = (size_t)B * 2 * N * sizeof(float);                       // covers (discarded)
+  return ((w + cov + 255) / 256) * 256 + ra_hungarian_dev_workspace_bytes(B, N, N);
+}
+
+extern "C" int ra_segm_match_f32(const float *iou, const float *s_gt, int B, int N, void *ws, size_t ws_bytes,
+                                 float *match, int *status, void *stream) {
+  if (!iou || !s_gt || !ws || !match || !status || B <= 0 || N <= 0)
+    return fail(RA_E_INVALID, "ra_segm_match_f32: bad argument");
+  if (ws_bytes < ra_segm_match_workspace_bytes(B, N))
+    return fail(RA_E_WORKSPACE, "ra_segm_match_f32: workspace of %zu bytes, need %zu", ws_bytes,
+                ra_segm_match_workspace_bytes(B, N));
+  hipStream_t st = as_stream(stream);
+  float *w = static_cast<float *>(ws);
+  float *cx = w + (size_t)B * N * N, *cy = cx + (size_t)B * N;
+  const size_t head = (((size_t)B * N * N + (size_t)B * 2 * N) * sizeof(float) + 255) / 256 * 256;
+  char *hws = static_cast<char *>(ws) + head;
+  const int total = B * N * N;
+  hipLaunchKernelGGL(loss::match_pre_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, iou, s_gt, N, total, w);
+  int rc = launch_status("ra_segm_match_f32");
+  if (rc) return rc;
+  rc = ra_hungarian_f32_dev(w, B, N, N, match, cx, cy, status, hws, ws_bytes - head, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss::match_post_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, match, s_gt, N, total);
+  return launch_status("ra_segm_match_f32");
+}
+
+extern "C" int ra_loss_stats_f32(const float *iou_soft, const float *iou_hard, const float *dice,
+                                 const float *match_real, const float *iou_box, const float *match_box,
+                                 const float *s_out, const float *s_gt, const float *sum_gt, int B, int T,
+                                 int fixed_order, int segm_loss_fn, float loss_mix_ratio, float *out,
+                                 void *stream) {
+  if (!iou_soft || !iou_hard || !dice || !match_real || !iou_box || !match_box || !s_out || !s_gt || !sum_gt ||
+      !out || B <= 0 || T <= 0)
+    return fail(RA_E_INVALID, "ra_loss_stats_f32: bad argument");
+  if (T > loss::kMaxT) return fail(RA_E_SHAPE, "ra_loss_stats_f32: T=%d (max %d)", T, loss::kMaxT);
+  if (segm_loss_fn != 0 && segm_loss_fn != 1) return fail(RA_E_INVALID, "ra_loss_stats_f32: segm_loss_fn");
+  hipLaunchKernelGGL(loss::loss_stats_kernel, dim3(1), dim3(256), 0, as_stream(stream), iou_soft, iou_hard, dice,
+                     match_real, iou_box, match_box, s_out, s_gt, sum_gt, B, T, fixed_order, segm_loss_fn,
+                     loss_mix_ratio, out);
+  return launch_status("ra_loss_stats_f32");
+}

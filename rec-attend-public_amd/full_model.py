@@ -22,6 +22,7 @@ import torch
 import modellib
 import nnlib as nn
 import ra_engine
+import ra_ops as ops
 from ra_native import RecAttendError
 
 
@@ -116,9 +117,11 @@ class Model(dict):
   OUTPUTS = ('y_out', 's_out', 'x_patch', 'y_out_patch', 'attn_box', 'attn_ctr', 'attn_size',
              'attn_top_left', 'attn_bot_right', 'attn_ctr_norm', 'attn_lg_size',
              'ctrl_rnn_glimpse_map', 'ctrl_out', 'h_core', 'canvas')
-  TRAIN_ONLY = ('loss', 'train_step', 'box_loss', 'segm_loss', 'conf_loss', 'iou_soft',
-                'iou_hard', 'wt_cov_soft', 'wt_cov_hard', 'unwt_cov_soft', 'unwt_cov_hard',
-                'dice', 'dic', 'dic_abs', 'count_acc', 'match', 'match_box', 'learn_rate')
+  # the loss / statistics head of the training graph, forward only (full_model.py:913-1097):
+  # needs y_gt and s_gt in the feed
+  LOSS_OUTPUTS = ops.STAT_NAMES + ('match', 'match_box', 'attn_box_gt', 'attn_top_left_gt',
+                                   'attn_bot_right_gt')
+  TRAIN_ONLY = ('train_step', 'learn_rate', 'gt_knob_prob_box', 'gt_knob_prob_segm')
 
   def __init__(self, opt, dims, box_model=False):
     dict.__init__(self)
@@ -153,19 +156,61 @@ class Model(dict):
       if n in self.TRAIN_ONLY:
         raise NotImplementedError(
             'output %r needs the training step (SURVEY.md §8f rank 2), not built yet' % n)
-      if n not in self.OUTPUTS:
+      if n not in self.OUTPUTS and n not in self.LOSS_OUTPUTS:
         raise KeyError(n)
     if nn._is_train(feed.get('phase_train', False)):
       raise NotImplementedError('phase_train=True is the training step (not built yet)')
     d = self.dims
+    want_loss = any(n in self.LOSS_OUTPUTS for n in names)
+    if want_loss and self.box_model:
+      raise NotImplementedError('the loss head is built for full_model only')
     b = self.engine.forward(feed['x'], d_in=feed.get('d_in'), y_in=feed.get('y_in'),
-                            y_gt=feed.get('y_gt'), noise=feed.get('noise'),
-                            want_box='attn_box' in names)
-    res = [self._fetch(n, b) for n in names]
+                            y_gt=feed.get('y_gt') if self.box_model else None,
+                            noise=feed.get('noise'),
+                            want_box=want_loss or 'attn_box' in names)
+    head = self._loss_head(b, feed) if want_loss else {}
+    res = [head[n] if n in head else self._fetch(n, b) for n in names]
     if as_numpy:
       torch.cuda.synchronize()
       res = [r.detach().cpu().numpy() for r in res]
     return res[0] if single else res
+
+  def _loss_head(self, eng, feed):
+    """full_model.py:913-1097 on the decoded batch (phase_train False: the GT knobs are off and
+    the per-timestep iou_soft_box of the use_knob branch, :756-758, equals the pairwise f_iou)."""
+    opt = self.opt
+    if 'y_gt' not in feed or 's_gt' not in feed:
+      raise RecAttendError('loss / statistics outputs need y_gt and s_gt in the feed')
+    if opt.get('box_loss_fn', 'iou') != 'iou' or opt.get('segm_loss_fn', 'iou') not in ('iou', 'wt_cov'):
+      raise NotImplementedError('box_loss_fn %r / segm_loss_fn %r (built: iou; iou, wt_cov)' %
+                                (opt.get('box_loss_fn'), opt.get('segm_loss_fn')))
+    dev = eng.fetch('y_out').device
+    as_t = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32)).to(dev) \
+        if not isinstance(v, torch.Tensor) else v.to(device=dev, dtype=torch.float32)
+    y_gt, s_gt = as_t(feed['y_gt']).contiguous(), as_t(feed['s_gt']).contiguous()
+    y_out, s_out, attn_box = eng.fetch('y_out'), eng.fetch('s_out'), eng.fetch('attn_box')
+    # get_gt_attn -> get_gt_box with min_padding = padding + 4 (full_model.py:561-566)
+    params, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0)
+    segm = ops.pair_stats(y_out, y_gt, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_b'))
+    boxs = ops.pair_stats(attn_box, box_gt, want=('iou_soft',))
+    fixed = bool(opt.get('fixed_order', False))
+    match_real, st1 = ops.segm_match(segm['iou_soft'], s_gt)
+    match_box, st2 = ops.segm_match(boxs['iou_soft'], s_gt)
+    stats = ops.loss_stats(segm['iou_soft'], segm['iou_hard'], segm['dice_hard'], match_real,
+                           boxs['iou_soft'], match_box, s_out, s_gt, segm['sum_b'], fixed_order=fixed,
+                           segm_loss_fn=opt.get('segm_loss_fn', 'iou'),
+                           loss_mix_ratio=float(opt.get('loss_mix_ratio', 1.0)))
+    self.match_status = (st1, st2)
+    head = {n: stats[i] for i, n in enumerate(ops.STAT_NAMES)}
+    if fixed:
+      ident = modellib.get_identity_match(s_gt.shape[0], s_gt.shape[1], s_gt)
+      head['match'], head['match_box'] = ident, ident
+    else:
+      head['match'], head['match_box'] = match_real, match_box
+    head['attn_box_gt'] = box_gt
+    head['attn_top_left_gt'] = params[:, :, 0:2].contiguous()
+    head['attn_bot_right_gt'] = params[:, :, 2:4].contiguous()
+    return head
 
   def _fetch(self, name, eng):
     d = self.dims

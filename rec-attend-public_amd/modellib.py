@@ -92,6 +92,159 @@ def f_segm_match(iou, s_gt):
   return match_eps.to(iou.device) * mask_x * mask_y
 
 
+# --------------------------------------------------------------------------------------
+# Loss / statistics operators (forward).  The pixel-sized contractions and reductions run in
+# csrc/ra_loss.hip (one streaming pass, ops.pair_stats / ops.gt_box); what is left here is
+# [B,T]- and [B,T,T]-sized bookkeeping with the reference's names and argument lists.
+# full_model.get_model(...).run(['loss', 'iou_soft', ...]) uses the fused ra_loss_stats_f32.
+# --------------------------------------------------------------------------------------
+def _pair(a, b):
+  """a [B,N,H,W], b [B,M,H,W] -> (inter [B,N,M], sum_a [B,N,1], sum_b [B,1,M], eps*HW)."""
+  st = ops.pair_stats(a, b, want=('iou_soft', 'sum_a', 'sum_b'))
+  e = 1e-5 * a.shape[2] * a.shape[3]
+  sa, sb = st['sum_a'][:, :, None], st['sum_b'][:, None, :]
+  iou = st['iou_soft']
+  inter = iou * (sa + sb + e) / (1.0 + iou)  # iou = I / (sa + sb - I + e)
+  return iou, inter, sa, sb, e
+
+
+def _as4(t):
+  """[H,W] / [N,H,W] / [B,N,H,W] -> [B,N,H,W] (the reference accepts all three)."""
+  return t.reshape((1,) * (4 - t.dim()) + tuple(t.shape))
+
+
+def f_inter(a, b):
+  """modellib.py:107-110 for aligned [B,N,H,W] inputs -> [B,N]."""
+  a, b = _as4(a), _as4(b)
+  return torch.diagonal(_pair(a, b)[1], dim1=1, dim2=2).reshape(a.shape[:2])
+
+
+def f_union(a, b, eps=1e-5):
+  """modellib.py:113-117 (eps summed over every pixel) for aligned inputs -> [B,N]."""
+  a, b = _as4(a), _as4(b)
+  _, inter, sa, sb, e = _pair(a, b)
+  u = sa + sb - inter + eps * a.shape[2] * a.shape[3]
+  return torch.diagonal(u, dim1=1, dim2=2).reshape(a.shape[:2])
+
+
+def f_iou(a, b, timespan=None, pairwise=False):
+  """modellib.py:124-155: pairwise -> [B,N,M]; aligned -> [B,N]."""
+  a, b = _as4(a), _as4(b)
+  iou = _pair(a, b)[0]
+  return iou if pairwise else torch.diagonal(iou, dim1=1, dim2=2).reshape(a.shape[:2])
+
+
+def f_dice(a, b, timespan=None, pairwise=False):
+  """modellib.py:71-104."""
+  a, b = _as4(a), _as4(b)
+  _, inter, sa, sb, e = _pair(a, b)
+  d = 2.0 * inter / ((sa + e) + (sb + e))
+  return d if pairwise else torch.diagonal(d, dim1=1, dim2=2).reshape(a.shape[:2])
+
+
+def get_identity_match(num_ex, timespan, s_gt):
+  """modellib.py:28-37."""
+  eye = torch.eye(timespan, dtype=s_gt.dtype, device=s_gt.device)[None]
+  return eye * s_gt[:, None, :] * s_gt[:, :, None]
+
+
+def f_cum_min(s, d):
+  """modellib.py:40-53."""
+  return torch.cummin(s, dim=1)[0]
+
+
+def f_cum_max(s, d):
+  """modellib.py:56-68 (cumulative maximum from the END)."""
+  return torch.flip(torch.cummax(torch.flip(s, [1]), dim=1)[0], [1])
+
+
+def f_bce(y_out, y_gt):
+  """modellib.py:424-427."""
+  eps = 1e-5
+  return -y_gt * torch.log(y_out + eps) - (1 - y_gt) * torch.log(1 - y_out + eps)
+
+
+def f_bce_minmax(y_out_min, y_out_max, y_gt):
+  """modellib.py:430-437."""
+  eps = 1e-5
+  return -y_gt * torch.log(y_out_min + eps) - (1 - y_gt) * torch.log(1 - y_out_max + eps)
+
+
+def f_coverage(iou):
+  """modellib.py:265-274."""
+  return iou.max(dim=1)[0]
+
+
+def f_coverage_weight(y_gt):
+  """modellib.py:277-289."""
+  s = ops.pair_stats(y_gt, y_gt, want=('sum_b',))['sum_b']
+  return s / (s.sum(dim=1, keepdim=True) + (s == 0).to(s.dtype))
+
+
+def f_weighted_coverage(iou, y_gt):
+  """modellib.py:292-302."""
+  return (f_coverage(iou) * f_coverage_weight(y_gt)).sum() / float(y_gt.shape[0])
+
+
+def f_unweighted_coverage(iou, count):
+  """modellib.py:305-313."""
+  return (f_coverage(iou).sum(dim=1) / count).sum() / float(iou.shape[0])
+
+
+def f_conf_loss(s_out, match, timespan, use_cum_min=True):
+  """modellib.py:316-339."""
+  match_sum = match.sum(dim=2)
+  if use_cum_min:
+    s_bce = f_bce_minmax(f_cum_min(s_out, timespan), f_cum_max(s_out, timespan), match_sum)
+  else:
+    s_bce = f_bce(s_out, match_sum)
+  return s_bce.sum() / float(s_out.shape[0]) / float(s_out.shape[1])
+
+
+def f_greedy_match(score, matched):
+  """modellib.py:365-379."""
+  score = score * (1.0 - matched)
+  mx = score.max(dim=1, keepdim=True)[0]
+  match = (score == mx).to(score.dtype)
+  return match / match.sum(dim=1, keepdim=True)
+
+
+def f_count_acc(s_out, s_gt):
+  """modellib.py:482-494."""
+  cout = (s_out > 0.5).to(s_out.dtype).sum(dim=1)
+  return (cout == s_gt.sum(dim=1)).to(s_out.dtype).sum() / float(s_out.shape[0])
+
+
+def f_dic(s_out, s_gt, abs=False):
+  """modellib.py:497-511."""
+  diff = (s_out > 0.5).to(s_out.dtype).sum(dim=1) - s_gt.sum(dim=1)
+  if abs:
+    diff = diff.abs()
+  return diff.sum() / float(s_out.shape[0])
+
+
+def get_gt_box(y_gt, padding_ratio=0.0, center_shift_ratio=0.0, min_padding=10.0):
+  """modellib.py:663-701 -> top_left [B,T,2], bot_right [B,T,2], box [B,T,H,W]."""
+  if not isinstance(center_shift_ratio, (int, float)) or center_shift_ratio != 0.0 or \
+      not isinstance(padding_ratio, (int, float)):
+    raise NotImplementedError('noisy GT boxes (tensor padding / centre shift, full_model.py:567-577) '
+                              'belong to the training step (SURVEY.md §8f rank 2)')
+  params, box = ops.gt_box(y_gt, float(padding_ratio), float(min_padding))
+  return params[:, :, 0:2].contiguous(), params[:, :, 2:4].contiguous(), box
+
+
+def get_gt_attn(y_gt, filter_height, filter_width, padding_ratio=0.0, center_shift_ratio=0.0,
+                min_padding=10.0):
+  """modellib.py:644-660."""
+  top_left, bot_right, box = get_gt_box(y_gt, padding_ratio=padding_ratio,
+                                        center_shift_ratio=center_shift_ratio,
+                                        min_padding=min_padding)
+  ctr, size = get_box_ctr_size(top_left, bot_right)
+  lg_var = get_normalized_var(size, filter_height, filter_width)
+  lg_gamma = get_normalized_gamma(size, filter_height, filter_width)
+  return ctr, size, lg_var, lg_gamma, box, top_left, bot_right
+
+
 def _not_built(name):
   def fn(*a, **k):
     raise NotImplementedError('modellib.%s belongs to the training step (SURVEY.md §8f rank 2) '
@@ -100,8 +253,5 @@ def _not_built(name):
   return fn
 
 
-for _n in ('f_iou', 'f_dice', 'f_inter', 'f_union', 'f_iou_box', 'f_weighted_coverage',
-           'f_unweighted_coverage', 'f_conf_loss', 'f_greedy_match', 'f_match_loss', 'f_bce',
-           'f_bce_minmax', 'f_cum_min', 'f_cum_max', 'f_count_acc', 'f_dic', 'get_gt_attn',
-           'get_gt_box', 'get_identity_match'):
+for _n in ('f_iou_box', 'f_match_loss', 'f_huber', 'f_squared_err', 'f_sem_loss'):
   globals()[_n] = _not_built(_n)

@@ -70,6 +70,12 @@ SIGNATURES = {
     'ra_canvas_max_f32': (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
     'ra_affine_act_f32': (_I, [_P, _P, _P, _Z, _I, _I, _P, _P]),
     'ra_max_pool_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_pair_stats_workspace_floats': (_Z, [_I, _I]),
+    'ra_pair_stats_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _P]),
+    'ra_gt_box_f32': (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    'ra_segm_match_workspace_bytes': (_Z, [_I, _I]),
+    'ra_segm_match_f32': (_I, [_P, _P, _I, _I, _P, _Z, _P, _P, _P]),
+    'ra_loss_stats_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
 }
 
 _lib = None

@@ -366,3 +366,73 @@ def hungarian(weights):
 
 
 hungarian.last_status = 0
+
+
+# --------------------------------------------------------------------------------------
+# loss / statistics head (csrc/ra_loss.hip)
+# --------------------------------------------------------------------------------------
+STAT_NAMES = ('loss', 'box_loss', 'segm_loss', 'conf_loss', 'iou_soft', 'iou_soft_box',
+              'wt_cov_soft', 'unwt_cov_soft', 'iou_hard', 'wt_cov_hard', 'unwt_cov_hard', 'dice',
+              'count_acc', 'dic', 'dic_abs')  # RA_STAT_* order
+
+
+def pair_stats(a, b, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_a', 'sum_b')):
+  """One pass over a [B,N,H,W] and b [B,M,H,W]: pairwise soft IoU, IoU / DICE of (a > 0.5), and
+  the per-instance sums (modellib.f_iou / f_dice pairwise=True, full_model.py:981,1064-1073)."""
+  _need_cuda(a, b)
+  a, b = a.contiguous(), b.contiguous()
+  B, N, H, W = a.shape
+  M = b.shape[1]
+  dev = a.device
+  n = rn.lib().ra_pair_stats_workspace_floats(B, H * W)
+  ws = torch.empty((n,), dtype=torch.float32, device=dev)
+  out = {}
+  for k, shp in (('iou_soft', (B, N, M)), ('iou_hard', (B, N, M)), ('dice_hard', (B, N, M)),
+                 ('sum_a', (B, N)), ('sum_b', (B, M))):
+    out[k] = torch.empty(shp, dtype=torch.float32, device=dev) if k in want else None
+  check(rn.lib().ra_pair_stats_f32(ptr(a), ptr(b), B, N, M, H * W, ptr(ws), n, ptr(out['iou_soft']),
+                                   ptr(out['iou_hard']), ptr(out['dice_hard']), ptr(out['sum_a']),
+                                   ptr(out['sum_b']), rn.stream_ptr()), 'ra_pair_stats_f32')
+  return out
+
+
+def gt_box(y_gt, padding_ratio, min_padding, want_box=True):
+  """modellib.get_gt_box (modellib.py:663-701), center_shift_ratio = 0: params [B,T,8], box."""
+  _need_cuda(y_gt)
+  y_gt = y_gt.contiguous()
+  B, T, H, W = y_gt.shape
+  params = torch.empty((B, T, 8), dtype=torch.float32, device=y_gt.device)
+  box = torch.empty((B, T, H, W), dtype=torch.float32, device=y_gt.device) if want_box else None
+  check(rn.lib().ra_gt_box_f32(ptr(y_gt), B, T, H, W, C.c_float(padding_ratio),
+                               C.c_float(min_padding), ptr(params), ptr(box), rn.stream_ptr()),
+        'ra_gt_box_f32')
+  return params, box
+
+
+def segm_match(iou, s_gt):
+  """modellib.f_segm_match (modellib.py:382-415) on device; returns (match [B,N,N], status [B])."""
+  _need_cuda(iou, s_gt)
+  iou, s_gt = iou.contiguous(), s_gt.contiguous()
+  B, N, _ = iou.shape
+  nb = rn.lib().ra_segm_match_workspace_bytes(B, N)
+  ws = torch.empty((nb,), dtype=torch.uint8, device=iou.device)
+  match = torch.empty_like(iou)
+  status = torch.zeros((B,), dtype=torch.int32, device=iou.device)
+  check(rn.lib().ra_segm_match_f32(ptr(iou), ptr(s_gt), B, N, ptr(ws), nb, ptr(match), ptr(status),
+                                   rn.stream_ptr()), 'ra_segm_match_f32')
+  return match, status
+
+
+def loss_stats(iou_soft, iou_hard, dice, match_real, iou_box, match_box, s_out, s_gt, sum_gt,
+               fixed_order=False, segm_loss_fn='iou', loss_mix_ratio=1.0):
+  """Every scalar of full_model.py:941-1081 -> float32 [len(STAT_NAMES)] on the device."""
+  ts = [t.contiguous() for t in (iou_soft, iou_hard, dice, match_real, iou_box, match_box, s_out,
+                                 s_gt, sum_gt)]
+  _need_cuda(*ts)
+  B, T = s_gt.shape
+  out = torch.empty((len(STAT_NAMES),), dtype=torch.float32, device=s_gt.device)
+  fn = {'iou': 0, 'wt_cov': 1}[segm_loss_fn]
+  check(rn.lib().ra_loss_stats_f32(*[ptr(t) for t in ts], B, T, int(bool(fixed_order)), fn,
+                                   C.c_float(loss_mix_ratio), ptr(out), rn.stream_ptr()),
+        'ra_loss_stats_f32')
+  return out
