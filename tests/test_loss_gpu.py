@@ -204,3 +204,26 @@ def test_loss_head_full_size_properties(cuda):
   named = dict(zip(ops.STAT_NAMES, stats))
   assert named['iou_soft'] > 0.99 and named['iou_hard'] > 0.99 and named['dice'] > 0.99
   assert named['wt_cov_hard'] > 0.99 and named['count_acc'] == 1.0 and named['dic'] == 0.0
+
+
+def _load_loss_fixture():
+  import os
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loss_head_cvppp_128.npz'),
+               allow_pickle=True)
+  shape = tuple(int(v) for v in fx['y_gt_shape'])
+  y_gt = np.unpackbits(fx['y_gt_bits'])[:int(np.prod(shape))].reshape(shape).astype(np.float32)
+  return fx, y_gt
+
+
+def test_loss_head_golden_fixture(cuda):
+  """The committed vector tests/golden/loss_head_cvppp_128.npz (make_fixtures.py)."""
+  import full_model
+  fx, y_gt = _load_loss_fixture()
+  opt = fx['opt'].item()
+  m = full_model.get_model(opt).load_weights(ora.random_params(opt, int(fx['seed'])))
+  names = list(SCALARS) + ['match', 'match_box']
+  out = dict(zip(names, m.run(names, {'x': fx['x'], 'phase_train': False, 'y_gt': y_gt, 's_gt': fx['s_gt']},
+                              as_numpy=True)))
+  assert (out['match'] == fx['match']).all() and (out['match_box'] == fx['match_box']).all()
+  for k in SCALARS:
+    assert abs(float(out[k]) - float(fx[k])) < 2e-4 * max(1.0, abs(float(fx[k]))), k
