@@ -135,6 +135,8 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
+  ap.add_argument('--host-input', action='store_true',
+                  help='hand x over as a pinned HOST buffer each step (PCIe-inclusive rate; never the headline value)')
   ap.add_argument('--pmc-group', type=int, default=0, metavar='REPS',
                   help='profiling aid: after one forward, launch only the encoder group REPS times '
                        'eagerly and exit (run under rocprofv3 --pmc; see tools/pmc_traffic.py)')
@@ -156,6 +158,8 @@ def main():
   eng.nsub = args.nsub
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
+  if args.host_input:
+    x = x.cpu().pin_memory()
   feed = {'x': x, 'phase_train': False}
 
   barrier = ra_dist.barrier
@@ -190,7 +194,7 @@ def main():
                              'y_out+s_out' % (S, S, T, B),
                  'arch': 'cvppp', 'H': S, 'W': S, 'T': T, 'batch_per_gpu': B,
                  'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no collective' % world,
-                 'hip_graph': bool(eng.use_graph)},
+                 'hip_graph': bool(eng.use_graph), 'input': 'host (PCIe inclusive)' if args.host_input else 'resident in HBM'},
   }
 
   if rank == 0:
