@@ -281,7 +281,9 @@ int ra_max_pool_f32(const float *x, int B, int H, int W, int C, int ratio, float
  *   f_iou(a > 0.5, b, pairwise=True) (full_model.py:1064-1065) and f_dice(a > 0.5, b,
  *   pairwise=True) (modellib.py:71-104) in ONE pass over a [B,N,H*W] and b [B,M,H*W]
  *   (N, M <= 32, H*W % 4 == 0, 16-byte aligned).  Outputs (each nullable): iou_soft,
- *   iou_hard, dice_hard [B,N,M]; sum_a [B,N], sum_b [B,M] = per-instance pixel sums.
+ *   iou_hard, dice_hard [B,N,M]; sum_a [B,N], sum_b [B,M] = per-instance pixel sums; inter
+ *   [B,N,M] = the raw intersections sum(a*b) (exact integers for binary masks up to 2^24
+ *   pixels); sum_a_hard [B,N] = pixel counts of (a > 0.5).
  *   ws: device scratch of ra_pair_stats_workspace_floats(B, H*W) floats.
  * ra_gt_box_f32 — modellib.get_gt_box (modellib.py:663-701) with center_shift_ratio 0:
  *   params [B,T,8] = top_left (y,x), bot_right (y,x) as returned by the reference, then the
@@ -302,7 +304,7 @@ enum {
 size_t ra_pair_stats_workspace_floats(int B, int HW);
 int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
                       size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
-                      float *sum_a, float *sum_b, void *stream);
+                      float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream);
 int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, float padding_ratio,
                   float min_padding, float *params, float *box, void *stream);
 size_t ra_segm_match_workspace_bytes(int B, int N);
@@ -313,6 +315,42 @@ int ra_loss_stats_f32(const float *iou_soft, const float *iou_hard, const float 
                       const float *s_out, const float *s_gt, const float *sum_gt, int B, int T,
                       int fixed_order, int segm_loss_fn, float loss_mix_ratio, float *out,
                       void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Evaluation post-processing and metrics (utils/postprocess.py, analysis.py:314-760).
+ *
+ * ra_postprocess_f32 — apply_confidence (postprocess.py:15-29), apply_one_label (:32-52),
+ *   apply_threshold (:5-12) and, with fg [B,H,W] != NULL, mask_foreground (:139-147) in one
+ *   pass: y_bin[b,t,p] = (t == argmax_t' y*s) && (max_t' y*s > thresh) [* fg]; s_hard
+ *   (nullable) [B,T] = s_out > 0.5; union_out (nullable) [B,H,W] = max_t y_bin.
+ * ra_union_f32 — y.max(axis=0) per image (analysis.py:547,570).
+ * ra_remove_tiny_f32 — remove_tiny (postprocess.py:109-136): instance planes whose size
+ *   (sizes [B,T], e.g. sum_a of ra_pair_stats_f32) is <= threshold are zeroed, conf too.
+ * ra_eval_metrics_f32 — from inter [B,T,T] / sum_a / sum_b of the BINARY masks (outputs = a,
+ *   ground truth = b) and s_gt: iou_pairwise (nullable) [B,T,T] (analysis.py:314-334); stats
+ *   [B,RA_EVAL_COUNT]; inst (nullable) [B,RA_EVALI_COUNT,T].  fg_inter/fg_a/fg_b [B]
+ *   (nullable together) = |union_a & union_b|, |union_a|, |union_b|; a_in_fgb [B,T] =
+ *   |a_i & union_b|, b_in_fga [B,T] = |b_j & union_a| (both nullable).
+ * ---------------------------------------------------------------------------------- */
+enum {
+  RA_EVAL_SBD = 0, RA_EVAL_WT_COV, RA_EVAL_UNWT_COV, RA_EVAL_FG_IOU, RA_EVAL_FG_DICE, RA_EVAL_FP,
+  RA_EVAL_FN, RA_EVAL_COUNT_ACC, RA_EVAL_COUNT_MSE, RA_EVAL_DIC, RA_EVAL_DIC_ABS, RA_EVAL_NUM_OBJ,
+  RA_EVAL_COUNT_OUT, RA_EVAL_COUNT
+};
+enum {
+  RA_EVALI_OBJ_PR = 0, RA_EVALI_OBJ_RE, RA_EVALI_PIX_PR, RA_EVALI_PIX_RE, RA_EVALI_HAS_OUT,
+  RA_EVALI_IS_GT, RA_EVALI_COUNT
+};
+int ra_postprocess_f32(const float *y_out, const float *s_out, int B, int T, int H, int W,
+                       float thresh, const float *fg, float *y_bin, float *s_hard,
+                       float *union_out, void *stream);
+int ra_union_f32(const float *y, int B, int T, int HW, float *union_out, void *stream);
+int ra_remove_tiny_f32(float *y_bin, const float *sizes, float *conf, int B, int T, int HW,
+                       float threshold, void *stream);
+int ra_eval_metrics_f32(const float *inter, const float *sum_a, const float *sum_b,
+                        const float *s_gt, const float *fg_inter, const float *fg_a,
+                        const float *fg_b, const float *a_in_fgb, const float *b_in_fga, int B,
+                        int T, float *iou_pairwise, float *stats, float *inst, void *stream);
 
 #ifdef __cplusplus
 }

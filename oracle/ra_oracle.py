@@ -438,6 +438,118 @@ def loss_head(opt, fwd, y_gt, s_gt):
 
 
 # --------------------------------------------------------------------------------------
+# evaluation post-processing (utils/postprocess.py) and metrics (analysis.py:314-787)
+# --------------------------------------------------------------------------------------
+def pp_apply_confidence(y_out, s_out):
+  """postprocess.py:15-29."""
+  return y_out * s_out[:, :, None, None], (s_out > 0.5).astype('float')
+
+
+def pp_apply_one_label(y_out):
+  """postprocess.py:32-52 (numpy argmax: first maximum)."""
+  out = np.zeros(y_out.shape)
+  for ii in range(y_out.shape[0]):
+    am = np.argmax(y_out[ii], axis=0)
+    for jj in range(y_out.shape[1]):
+      out[ii, jj] = (am == jj).astype('float32') * y_out[ii, jj]
+  return out
+
+
+def pp_apply_threshold(y_out, thresh):
+  """postprocess.py:5-12."""
+  return (y_out > thresh).astype('float32')
+
+
+def pp_remove_tiny(y_out, conf, threshold=200):
+  """postprocess.py:109-136."""
+  if threshold == 0:
+    return y_out, conf
+  size = y_out.sum(axis=(2, 3), keepdims=True)
+  keep = (size > threshold).astype('float32')
+  return y_out * keep, conf * keep.reshape(conf.shape)
+
+
+def postprocess(y_out, s_out, thresh, fg=None, remove_tiny_threshold=0):
+  """full_model_eval.py:112-124 without upsample / morph (cv2)."""
+  y, s = pp_apply_confidence(y_out, s_out)
+  y = pp_apply_threshold(pp_apply_one_label(y), thresh)
+  if fg is not None:
+    y = y * fg[:, None]  # mask_foreground, postprocess.py:139-147
+    y, s = pp_remove_tiny(y, s, remove_tiny_threshold)
+  return y, s
+
+
+def an_f_iou(a, b):
+  """analysis.py:314-326."""
+  inter = (a * b).sum(axis=-1).sum(axis=-1)
+  union = (a + b).sum(axis=-1).sum(axis=-1) - inter
+  return inter / (union + np.equal(union, 0).astype('float32'))
+
+
+def an_f_iou_pairwise(a, b):
+  """analysis.py:329-334 (one example: a [N,H,W], b [M,H,W])."""
+  return an_f_iou(np.expand_dims(a, 1), np.expand_dims(b, 0))
+
+
+def _an_f_pr(a, b):
+  """analysis.py:337-349."""
+  inter = (a * b).sum(axis=-1).sum(axis=-1)
+  asum = a.sum(axis=-1).sum(axis=-1)
+  return inter / (asum + np.equal(asum, 0).astype('float32'))
+
+
+def _an_f_dice(a, b):
+  """analysis.py:352-367."""
+  ca, cb = a.sum(axis=-1).sum(axis=-1), b.sum(axis=-1).sum(axis=-1)
+  cs = ca + cb
+  return 2 * (a * b).sum(axis=-1).sum(axis=-1) / (cs + np.equal(cs, 0).astype('float32'))
+
+
+def eval_metrics(y_out, y_gt, s_gt):
+  """analysis.py:370-787 per image, for binary y_out / y_gt [B,T,H,W]: dict of [B] arrays and
+  the variable-length per-instance lists (avg_pr, avg_re, obj_pr, obj_re)."""
+  B, T = s_gt.shape
+  num_obj = np.maximum(s_gt.sum(axis=1), 1)           # :773-787
+  count_out = (y_out.sum(axis=(2, 3)) > 0).astype('float32')  # :766-770
+  count_gt = s_gt.sum(axis=1)
+  out = {k: np.zeros(B) for k in ('sbd', 'wt_cov', 'unwt_cov', 'fg_iou', 'fg_dice', 'avg_fp', 'avg_fn')}
+  lists = {k: [] for k in ('avg_pr', 'avg_re', 'obj_pr', 'obj_re')}
+  ious = []
+  for ii in range(B):
+    a, b, no = y_out[ii], y_gt[ii], int(num_obj[ii])
+    iou = an_f_iou_pairwise(a, b)
+    ious.append(iou)
+    bd_a = np.array([_an_f_dice(a[k:k + 1], b).max(axis=0) for k in range(T)])   # :370-386
+    bd_b = np.array([_an_f_dice(b[k:k + 1], a).max(axis=0) for k in range(T)])
+    out['sbd'][ii] = min(bd_a[:no].mean(), bd_b[:no].mean())                       # :434-460
+    cov = iou.max(axis=0)                                                          # :463-464
+    tot = b.sum()
+    w_wt = b.sum(axis=(1, 2)) / (tot + np.equal(tot, 0).astype('float32'))         # :467-478
+    out['wt_cov'][ii] = (cov * w_wt)[:no].sum()
+    out['unwt_cov'][ii] = (cov * (1 / num_obj[ii]))[:no].sum()
+    out['fg_iou'][ii] = an_f_iou(a.max(axis=0), b.max(axis=0))                     # :533-553
+    out['fg_dice'][ii] = _an_f_dice(a.max(axis=0), b.max(axis=0))                  # :556-576
+    out['avg_fp'][ii] = (count_out[ii] * np.equal(iou.sum(axis=1), 0)).sum()       # :579-592
+    out['avg_fn'][ii] = (s_gt[ii] * np.equal(iou.sum(axis=0), 0)).sum()            # :595-605
+    pr = _an_f_pr(a, b.max(axis=0, keepdims=True))                                 # :608-627
+    re = _an_f_pr(b, a.max(axis=0, keepdims=True))                                 # :630-650
+    m_out = (iou.max(axis=1) >= 0.5).astype('float32')                             # :653-671
+    m_gt = (iou.max(axis=0) >= 0.5).astype('float32')                              # :674-690
+    for jj in range(T):
+      if count_out[ii, jj] > 0:
+        lists['avg_pr'].append(pr[jj])
+        lists['obj_pr'].append(m_out[jj])
+    for jj in range(int(count_gt[ii])):
+      lists['avg_re'].append(re[jj])
+      lists['obj_re'].append(m_gt[jj])
+  d = count_out.sum(axis=1) - count_gt
+  out.update(count_mse=d.astype('float') ** 2, count_acc=(d == 0).astype('float'), dic=d,   # :693-763
+             dic_abs=np.abs(d), iou_pairwise=np.array(ious))
+  out.update({k: np.array(v) for k, v in lists.items()})
+  return out
+
+
+# --------------------------------------------------------------------------------------
 # model option handling shared by both graphs
 # --------------------------------------------------------------------------------------
 

@@ -1,0 +1,229 @@
+// K11..K12 — evaluation post-processing and metrics on the device:
+//   K11 postprocess: utils/postprocess.py apply_confidence (:15-29) -> apply_one_label (:32-52) ->
+//       apply_threshold (:5-12) [-> mask_foreground (:139-147)] fused into one pass over
+//       y_out [B,T,H,W]; remove_tiny (:109-136) zeroes whole instance planes afterwards.  The cv2
+//       steps (upsample + bilateral filter :75-106, morph :55-72) are not built.
+//   K12 eval_metrics: the per-image statistics of analysis.py:314-760 from the pairwise
+//       intersections and instance sizes of the binary masks (one ra_pair_stats_f32 pass):
+//       pairwise IoU, symmetric best DICE, weighted / unweighted coverage, false positives /
+//       negatives, object precision / recall flags, counting.
+#include <cmath>
+
+#include "ra_common.h"
+
+namespace ra {
+namespace eval {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxT = 32;
+
+// One thread per 4 pixels: weight by the confidence, keep only the arg-max instance (first
+// maximum, like numpy.argmax), threshold, optional foreground mask; also the union plane.
+__global__ __launch_bounds__(256) void postprocess_kernel(const float *y, const float *s, int T, int HW,
+                                                           float thresh, const float *fg, float *y_bin,
+                                                           float *s_hard, float *uni) {
+  const int b = blockIdx.y;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (blockIdx.x == 0 && threadIdx.x < T && s_hard)
+    s_hard[(size_t)b * T + threadIdx.x] = s[(size_t)b * T + threadIdx.x] > 0.5f ? 1.f : 0.f;  // :28
+  if (e >= HW) return;
+  const float *yb = y + (size_t)b * T * HW + e;
+  f32x4 best = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+  int arg[4] = {0, 0, 0, 0};
+  for (int t = 0; t < T; ++t) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(yb + (size_t)t * HW) * s[(size_t)b * T + t];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (v[k] > best[k]) {  // strict: the first maximum wins
+        best[k] = v[k];
+        arg[k] = t;
+      }
+  }
+  f32x4 keep;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) keep[k] = best[k] > thresh ? 1.f : 0.f;
+  if (fg) keep = keep * *reinterpret_cast<const f32x4 *>(fg + (size_t)b * HW + e);
+  float *ob = y_bin + (size_t)b * T * HW + e;
+  for (int t = 0; t < T; ++t) {
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = arg[k] == t ? keep[k] : 0.f;
+    *reinterpret_cast<f32x4 *>(ob + (size_t)t * HW) = o;
+  }
+  if (uni) *reinterpret_cast<f32x4 *>(uni + (size_t)b * HW + e) = keep;
+}
+
+// uni[b,px] = max_t y[b,t,px]  (analysis.py:547,570: y.max(axis=0))
+__global__ __launch_bounds__(256) void union_kernel(const float *y, int T, int HW, float *uni) {
+  const int b = blockIdx.y;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= HW) return;
+  const float *yb = y + (size_t)b * T * HW + e;
+  f32x4 m = *reinterpret_cast<const f32x4 *>(yb);
+  for (int t = 1; t < T; ++t) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(yb + (size_t)t * HW);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+  }
+  *reinterpret_cast<f32x4 *>(uni + (size_t)b * HW + e) = m;
+}
+
+// remove_tiny_single (postprocess.py:126-136): planes of at most `threshold` pixels vanish
+__global__ __launch_bounds__(256) void remove_tiny_kernel(float *y_bin, const float *sizes, float *conf, int HW,
+                                                           float threshold) {
+  const int inst = blockIdx.y;
+  if (sizes[inst] > threshold) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && conf) conf[inst] = 0.f;
+  float *p = y_bin + (size_t)inst * HW;
+  for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < HW; e += gridDim.x * 256 * 4)
+    *reinterpret_cast<f32x4 *>(p + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// One workgroup per image; everything is T x T sized.  Per-image scalars -> stats[b][RA_EVAL_*],
+// per-instance vectors -> inst[b][RA_EVALI_*][T].
+__global__ __launch_bounds__(256) void eval_metrics_kernel(const float *inter, const float *sa, const float *sb,
+                                                            const float *s_gt, const float *fg_inter,
+                                                            const float *fg_a, const float *fg_b,
+                                                            const float *a_in_fgb, const float *b_in_fga, int T,
+                                                            float *iou_out, float *stats, float *inst) {
+  __shared__ float iou[kMaxT][kMaxT], dice[kMaxT][kMaxT];
+  __shared__ float red[8][kMaxT];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *I = inter + (size_t)b * T * T, *A = sa + (size_t)b * T, *Bs = sb + (size_t)b * T;
+  const float *sg = s_gt + (size_t)b * T;
+  for (int e = tid; e < T * T; e += 256) {
+    const int i = e / T, j = e - i * T;
+    const float in = I[e], uni = A[i] + Bs[j] - in, card = A[i] + Bs[j];
+    const float v = in / (uni + (uni == 0.f ? 1.f : 0.f));  // analysis.py:314-326
+    iou[i][j] = v;
+    dice[i][j] = 2.f * in / (card + (card == 0.f ? 1.f : 0.f));  // :352-367
+    if (iou_out) iou_out[(size_t)b * T * T + e] = v;
+  }
+  __syncthreads();
+  if (tid < T) {
+    const int k = tid;
+    float bd_a = 0.f, bd_b = 0.f, cov = 0.f, rs = 0.f, cs = 0.f, mx_r = 0.f;
+    for (int j = 0; j < T; ++j) {
+      bd_a = fmaxf(bd_a, dice[k][j]);  // best DICE of output k over the GT (:370-386)
+      bd_b = fmaxf(bd_b, dice[j][k]);  // best DICE of GT k over the outputs
+      cov = fmaxf(cov, iou[j][k]);     // coverage of GT k (:463-464, max over axis 0)
+      mx_r = fmaxf(mx_r, iou[k][j]);
+      rs += iou[k][j];
+      cs += iou[j][k];
+    }
+    red[0][k] = bd_a;
+    red[1][k] = bd_b;
+    red[2][k] = cov;
+    red[3][k] = rs;
+    red[4][k] = cs;
+    red[5][k] = mx_r;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float count_gt = 0.f, tot_gt = 0.f, count_out = 0.f;
+    for (int t = 0; t < T; ++t) {
+      count_gt += sg[t];
+      tot_gt += Bs[t];
+      count_out += A[t] > 0.f ? 1.f : 0.f;  // f_count_out :766-770
+    }
+    const float num_obj = fmaxf(count_gt, 1.f);  // _f_num_obj :773-787
+    const int no = (int)num_obj < T ? (int)num_obj : T;
+    float bda = 0.f, bdb = 0.f, wt = 0.f, unwt = 0.f, fp = 0.f, fn = 0.f;
+    for (int t = 0; t < no; ++t) {
+      bda += red[0][t];
+      bdb += red[1][t];
+      wt += red[2][t] * (Bs[t] / (tot_gt + (tot_gt == 0.f ? 1.f : 0.f)));  // :467-478 weighted
+      unwt += red[2][t] * (1.f / num_obj);
+    }
+    for (int t = 0; t < T; ++t) {
+      fp += (A[t] > 0.f ? 1.f : 0.f) * (red[3][t] == 0.f ? 1.f : 0.f);  // :579-592
+      fn += sg[t] * (red[4][t] == 0.f ? 1.f : 0.f);                      // :595-605
+    }
+    float *o = stats + (size_t)b * RA_EVAL_COUNT;
+    o[RA_EVAL_SBD] = fminf(bda / (float)no, bdb / (float)no);  // :434-460
+    o[RA_EVAL_WT_COV] = wt;
+    o[RA_EVAL_UNWT_COV] = unwt;
+    o[RA_EVAL_FP] = fp;
+    o[RA_EVAL_FN] = fn;
+    const float d = count_out - count_gt;
+    o[RA_EVAL_COUNT_ACC] = d == 0.f ? 1.f : 0.f;  // :711-726
+    o[RA_EVAL_COUNT_MSE] = d * d;                 // :693-708
+    o[RA_EVAL_DIC] = d;                           // :729-744
+    o[RA_EVAL_DIC_ABS] = fabsf(d);                // :747-763
+    if (fg_inter) {  // foreground IoU / DICE of the unions (:533-576)
+      const float in = fg_inter[b], fa = fg_a[b], fb = fg_b[b], uni = fa + fb - in, card = fa + fb;
+      o[RA_EVAL_FG_IOU] = in / (uni + (uni == 0.f ? 1.f : 0.f));
+      o[RA_EVAL_FG_DICE] = 2.f * in / (card + (card == 0.f ? 1.f : 0.f));
+    } else {
+      o[RA_EVAL_FG_IOU] = o[RA_EVAL_FG_DICE] = 0.f;
+    }
+    o[RA_EVAL_NUM_OBJ] = num_obj;
+    o[RA_EVAL_COUNT_OUT] = count_out;
+  }
+  if (inst && tid < T) {
+    float *o = inst + (size_t)b * RA_EVALI_COUNT * T;
+    const int k = tid;
+    float cgt = 0.f;
+    for (int t = 0; t < T; ++t) cgt += sg[t];
+    const float has_out = A[k] > 0.f ? 1.f : 0.f, is_gt = (float)k < cgt ? 1.f : 0.f;
+    o[RA_EVALI_OBJ_PR * T + k] = red[5][k] >= 0.5f ? 1.f : 0.f;  // :653-671 (valid where has_out)
+    o[RA_EVALI_OBJ_RE * T + k] = red[2][k] >= 0.5f ? 1.f : 0.f;  // :674-690 (valid where is_gt)
+    o[RA_EVALI_HAS_OUT * T + k] = has_out;
+    o[RA_EVALI_IS_GT * T + k] = is_gt;
+    // pixel precision / recall against the union of the other side (:608-650, _f_pr :337-349)
+    const float pa = a_in_fgb ? a_in_fgb[(size_t)b * T + k] : 0.f, pb = b_in_fga ? b_in_fga[(size_t)b * T + k] : 0.f;
+    o[RA_EVALI_PIX_PR * T + k] = pa / (A[k] + (A[k] == 0.f ? 1.f : 0.f));
+    o[RA_EVALI_PIX_RE * T + k] = pb / (Bs[k] + (Bs[k] == 0.f ? 1.f : 0.f));
+  }
+}
+
+}  // namespace eval
+}  // namespace ra
+
+using namespace ra;
+
+extern "C" int ra_postprocess_f32(const float *y_out, const float *s_out, int B, int T, int H, int W, float thresh,
+                                  const float *fg, float *y_bin, float *s_hard, float *union_out, void *stream) {
+  if (!y_out || !s_out || !y_bin || B <= 0 || T <= 0 || H <= 0 || W <= 0)
+    return fail(RA_E_INVALID, "ra_postprocess_f32: bad argument");
+  const int HW = H * W;
+  if (HW % 4 || T > 256 || ((reinterpret_cast<uintptr_t>(y_out) | reinterpret_cast<uintptr_t>(y_bin)) & 15) ||
+      (fg && (reinterpret_cast<uintptr_t>(fg) & 15)) || (union_out && (reinterpret_cast<uintptr_t>(union_out) & 15)))
+    return fail(RA_E_SHAPE, "ra_postprocess_f32: H*W %% 4, T <= 256 and 16-byte aligned tensors required");
+  hipLaunchKernelGGL(eval::postprocess_kernel, dim3(ceil_div(HW, 1024), B), dim3(256), 0, as_stream(stream), y_out,
+                     s_out, T, HW, thresh, fg, y_bin, s_hard, union_out);
+  return launch_status("ra_postprocess_f32");
+}
+
+extern "C" int ra_union_f32(const float *y, int B, int T, int HW, float *union_out, void *stream) {
+  if (!y || !union_out || B <= 0 || T <= 0 || HW <= 0) return fail(RA_E_INVALID, "ra_union_f32: bad argument");
+  if (HW % 4 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(union_out)) & 15))
+    return fail(RA_E_SHAPE, "ra_union_f32: H*W %% 4 and 16-byte aligned tensors required");
+  hipLaunchKernelGGL(eval::union_kernel, dim3(ceil_div(HW, 1024), B), dim3(256), 0, as_stream(stream), y, T, HW,
+                     union_out);
+  return launch_status("ra_union_f32");
+}
+
+extern "C" int ra_remove_tiny_f32(float *y_bin, const float *sizes, float *conf, int B, int T, int HW,
+                                  float threshold, void *stream) {
+  if (!y_bin || !sizes || B <= 0 || T <= 0 || HW <= 0) return fail(RA_E_INVALID, "ra_remove_tiny_f32: bad argument");
+  if (HW % 4 || (reinterpret_cast<uintptr_t>(y_bin) & 15))
+    return fail(RA_E_SHAPE, "ra_remove_tiny_f32: H*W %% 4 and a 16-byte aligned tensor required");
+  hipLaunchKernelGGL(eval::remove_tiny_kernel, dim3(ceil_div(HW, 256 * 4 * 8), B * T), dim3(256), 0,
+                     as_stream(stream), y_bin, sizes, conf, HW, threshold);
+  return launch_status("ra_remove_tiny_f32");
+}
+
+extern "C" int ra_eval_metrics_f32(const float *inter, const float *sum_a, const float *sum_b, const float *s_gt,
+                                   const float *fg_inter, const float *fg_a, const float *fg_b,
+                                   const float *a_in_fgb, const float *b_in_fga, int B, int T, float *iou_pairwise,
+                                   float *stats, float *inst, void *stream) {
+  if (!inter || !sum_a || !sum_b || !s_gt || !stats || B <= 0 || T <= 0)
+    return fail(RA_E_INVALID, "ra_eval_metrics_f32: bad argument");
+  if (T > eval::kMaxT) return fail(RA_E_SHAPE, "ra_eval_metrics_f32: T=%d (max %d)", T, eval::kMaxT);
+  if ((fg_inter != nullptr) != (fg_a != nullptr) || (fg_inter != nullptr) != (fg_b != nullptr))
+    return fail(RA_E_INVALID, "ra_eval_metrics_f32: fg_inter, fg_a, fg_b go together");
+  hipLaunchKernelGGL(eval::eval_metrics_kernel, dim3(B), dim3(256), 0, as_stream(stream), inter, sum_a, sum_b, s_gt,
+                     fg_inter, fg_a, fg_b, a_in_fgb, b_in_fga, T, iou_pairwise, stats, inst);
+  return launch_status("ra_eval_metrics_f32");
+}

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void pair_stats_reduce_kernel(const float *par
 // one workgroup per image: the ratios
 __global__ __launch_bounds__(256) void pair_stats_finish_kernel(const float *totals, int N, int M, int HW,
                                                                  float *iou_soft, float *iou_hard,
-                                                                 float *dice_hard, float *sum_a, float *sum_b) {
+                                                                 float *dice_hard, float *sum_a, float *sum_b,
+                                                                 float *inter_soft, float *sum_a_hard) {
   const int img = blockIdx.x, tid = threadIdx.x;
   const float *tot = totals + (size_t)img * kPartFloats;
   const float eps_hw = 1e-5f * (float)HW;  // modellib.py:119-122: the eps is summed per pixel
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(256) void pair_stats_finish_kernel(const float *tot
     if (iou_soft) iou_soft[o] = is / (sa[i] + sb[j] - is + eps_hw);
     if (iou_hard) iou_hard[o] = ih / (sah[i] + sb[j] - ih + eps_hw);
     if (dice_hard) dice_hard[o] = 2.f * ih / ((sah[i] + eps_hw) + (sb[j] + eps_hw));  // modellib.py:92-98
+    if (inter_soft) inter_soft[o] = is;
   }
+  if (sum_a_hard)
+    for (int i = tid; i < N; i += 256) sum_a_hard[(size_t)img * N + i] = sah[i];
   if (sum_a)
     for (int i = tid; i < N; i += 256) sum_a[(size_t)img * N + i] = sa[i];
   if (sum_b)
@@ -397,7 +401,7 @@ extern "C" size_t ra_pair_stats_workspace_floats(int B, int HW) {
 
 extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
                                  size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
-                                 float *sum_a, float *sum_b, void *stream) {
+                                 float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream) {
   if (!a || !b || !ws || B <= 0 || N <= 0 || M <= 0 || HW <= 0)
     return fail(RA_E_INVALID, "ra_pair_stats_f32: bad argument");
   if (N > loss::kMaxT || M > loss::kMaxT || HW % 4)
@@ -425,7 +429,7 @@ extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, i
   hipLaunchKernelGGL(loss::pair_stats_reduce_kernel, dim3(ceil_div(loss::kPartFloats, 256), B), dim3(256), 0, st, ws,
                      nch, tot);
   hipLaunchKernelGGL(loss::pair_stats_finish_kernel, dim3(B), dim3(256), 0, st, tot, N, M, HW, iou_soft, iou_hard,
-                     dice_hard, sum_a, sum_b);
+                     dice_hard, sum_a, sum_b, inter, sum_a_hard);
   return launch_status("ra_pair_stats_f32");
 }
 

@@ -66,6 +66,10 @@ def derive_dims(opt, box_model=False):
   d['ccnn_nlayers'] = len(opt['ctrl_cnn_filter_size'])
   d['ccnn_filters'] = list(opt['ctrl_cnn_filter_size'])
   d['ccnn_channels'] = [depth(ctrl)] + list(opt['ctrl_cnn_depth'])
+  if d['ccnn_channels'][0] == 0:
+    raise RecAttendError('the controller CNN has no input: pass at least one of ctrl_add_inp / '
+                         'ctrl_add_canvas / ctrl_add_d_out / ctrl_add_y_out (full_model.py:140-149; '
+                         'the run scripts pass --ctrl_add_inp --ctrl_add_canvas)')
   d['ccnn_pool'] = list(opt['ctrl_cnn_pool'])
   sub = int(np.prod(d['ccnn_pool']))
   d['gh'], d['gw'] = d['H'] // sub, d['W'] // sub

@@ -5,9 +5,14 @@ Restores results/<model_id>/{model_opt.yaml, weights.npz}, forces `use_knob=Fals
 (full_model_eval.py:172-174), feeds {x, phase_train=False[, d_in, y_in]} and fetches
 ['y_out', 's_out'] (full_model_eval.py:35; runner.py:91-105) batch by batch on the MI355X
 kernels, sharding the images over the ranks when launched with torch.distributed.run.  Inputs
-come from --input (an .npz with x [N,H,W,3] and optionally d_in / y_in) or are synthetic; the
-reference's HDF5 datasets, post-processing and analyzers are out of scope — the
-raw outputs are written to <output>/output_<split>/pred_rank<r>.npz."""
+come from --input (an .npz with x [N,H,W,3] and optionally d_in / y_in / y_gt / s_gt / fg) or are
+synthetic; the reference's HDF5 datasets are out of scope.  The raw outputs are
+written to <output>/output_<split>/pred_rank<r>.npz.  With y_gt and s_gt in the input the
+reference's write_log chain (full_model_eval.py:97-139) runs on the device for every threshold of
+--threshold_list (default 0.0 .. 0.9, :39-40): apply_confidence, apply_one_label,
+apply_threshold [, mask_foreground, remove_tiny] and the --analyzers (default list :201-205);
+the per-threshold means go to <output>/output_<split>/metrics_rank<r>.yaml.  The cv2 steps
+(upsample + bilateral filter, morph) are skipped: evaluation is at the network resolution."""
 import argparse
 import os
 import time
@@ -54,19 +59,51 @@ def main(argv=None):
       lg = rng.randn(n, H, W, model.dims['nsc']).astype(np.float32)
       data['y_in'] = np.exp(lg) / np.exp(lg).sum(-1, keepdims=True)
   lo, hi = ra_dist.shard_range(rank, world, data['x'].shape[0])
+  thresholds = [float(t) for t in args.threshold_list.split(',')] if args.threshold_list else \
+      [0.1 * k for k in range(10)]                                    # full_model_eval.py:39-40,193-198
+  if args.analyzers is None:                                          # :199-210
+    names = [] if args.test else ['sbd', 'wt_cov', 'unwt_cov', 'avg_fp', 'avg_fn', 'avg_pr', 'avg_re',
+                                  'obj_pr', 'obj_re', 'count_acc', 'count_mse', 'dic', 'dic_abs']
+  else:
+    names = [n for n in args.analyzers.split(',') if n]
+  analyze = bool(names) and 'y_gt' in data and 's_gt' in data
+  acc = {th: {n: [] for n in names} for th in thresholds}
   ys, ss, t0 = [], [], time.time()
   for b0 in range(lo, hi, args.batch_size):
     b1 = min(hi, b0 + args.batch_size)
     feed = {k: v[b0:b1] for k, v in data.items() if k in ('x', 'd_in', 'y_in')}
     feed['phase_train'] = False
-    y, s = model.run(['y_out', 's_out'], feed, as_numpy=True)
-    ys.append(y)
-    ss.append(s)
+    y_dev, s_dev = model.run(['y_out', 's_out'], feed)
+    if analyze:
+      import analysis
+      from utils import postprocess as pp
+      dev = y_dev.device
+      gt = torch.as_tensor(np.asarray(data['y_gt'][b0:b1], dtype=np.float32)).to(dev)
+      sg = torch.as_tensor(np.asarray(data['s_gt'][b0:b1], dtype=np.float32)).to(dev)
+      fg = torch.as_tensor(np.asarray(data['fg'][b0:b1], dtype=np.float32)).to(dev) if 'fg' in data else None
+      for th in thresholds:
+        y_bin, s_hard, _ = pp.postprocess(y_dev, s_dev, th, fg=fg, remove_tiny_threshold=args.remove_tiny)
+        results = {'y_out': y_bin, 'y_gt': gt, 's_out': s_hard, 's_gt': sg}
+        for n in names:
+          acc[th][n].append(analysis.create_analyzer(n)(results).cpu().numpy())
+    ys.append(y_dev.cpu().numpy())
+    ss.append(s_dev.cpu().numpy())
   out_dir = os.path.join(args.output or restore, 'output_' + args.split.split(',')[0])
   os.makedirs(out_dir, exist_ok=True)
   path = os.path.join(out_dir, 'pred_rank%d.npz' % rank)
   np.savez_compressed(path, y_out=np.concatenate(ys), s_out=np.concatenate(ss), first_index=lo)
   print('rank %d: images [%d, %d) -> %s (%.2f s)' % (rank, lo, hi, path, time.time() - t0))
+  if analyze:
+    summary = {}
+    for th in thresholds:
+      vals = {n: np.concatenate(v) if v else np.zeros(0) for n, v in acc[th].items()}
+      summary['%.2f' % th] = {n: {'mean': float(v.mean()) if v.size else 0.0, 'count': int(v.size)}
+                              for n, v in vals.items()}
+    with open(os.path.join(out_dir, 'metrics_rank%d.yaml' % rank), 'w') as f:
+      yaml.safe_dump(summary, f)
+    best = max(summary, key=lambda k: summary[k].get('sbd', {}).get('mean', 0.0))
+    print('rank %d: threshold %s  %s' % (rank, best, ' '.join(
+        '%s=%.4f' % (n, summary[best][n]['mean']) for n in names)))
   ra_dist.barrier()
 
 

@@ -379,8 +379,8 @@ STAT_NAMES = ('loss', 'box_loss', 'segm_loss', 'conf_loss', 'iou_soft', 'iou_sof
 def pair_stats(a, b, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_a', 'sum_b')):
   """One pass over a [B,N,H,W] and b [B,M,H,W]: pairwise soft IoU, IoU / DICE of (a > 0.5), and
   the per-instance sums (modellib.f_iou / f_dice pairwise=True, full_model.py:981,1064-1073)."""
-  _need_cuda(a, b)
   a, b = a.contiguous(), b.contiguous()
+  _need_cuda(a, b)
   B, N, H, W = a.shape
   M = b.shape[1]
   dev = a.device
@@ -388,18 +388,19 @@ def pair_stats(a, b, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_a', 'sum_b'
   ws = torch.empty((n,), dtype=torch.float32, device=dev)
   out = {}
   for k, shp in (('iou_soft', (B, N, M)), ('iou_hard', (B, N, M)), ('dice_hard', (B, N, M)),
-                 ('sum_a', (B, N)), ('sum_b', (B, M))):
+                 ('sum_a', (B, N)), ('sum_b', (B, M)), ('inter', (B, N, M)), ('sum_a_hard', (B, N))):
     out[k] = torch.empty(shp, dtype=torch.float32, device=dev) if k in want else None
   check(rn.lib().ra_pair_stats_f32(ptr(a), ptr(b), B, N, M, H * W, ptr(ws), n, ptr(out['iou_soft']),
                                    ptr(out['iou_hard']), ptr(out['dice_hard']), ptr(out['sum_a']),
-                                   ptr(out['sum_b']), rn.stream_ptr()), 'ra_pair_stats_f32')
+                                   ptr(out['sum_b']), ptr(out['inter']), ptr(out['sum_a_hard']),
+                                   rn.stream_ptr()), 'ra_pair_stats_f32')
   return out
 
 
 def gt_box(y_gt, padding_ratio, min_padding, want_box=True):
   """modellib.get_gt_box (modellib.py:663-701), center_shift_ratio = 0: params [B,T,8], box."""
-  _need_cuda(y_gt)
   y_gt = y_gt.contiguous()
+  _need_cuda(y_gt)
   B, T, H, W = y_gt.shape
   params = torch.empty((B, T, 8), dtype=torch.float32, device=y_gt.device)
   box = torch.empty((B, T, H, W), dtype=torch.float32, device=y_gt.device) if want_box else None
@@ -411,8 +412,8 @@ def gt_box(y_gt, padding_ratio, min_padding, want_box=True):
 
 def segm_match(iou, s_gt):
   """modellib.f_segm_match (modellib.py:382-415) on device; returns (match [B,N,N], status [B])."""
-  _need_cuda(iou, s_gt)
   iou, s_gt = iou.contiguous(), s_gt.contiguous()
+  _need_cuda(iou, s_gt)
   B, N, _ = iou.shape
   nb = rn.lib().ra_segm_match_workspace_bytes(B, N)
   ws = torch.empty((nb,), dtype=torch.uint8, device=iou.device)
@@ -436,3 +437,71 @@ def loss_stats(iou_soft, iou_hard, dice, match_real, iou_box, match_box, s_out, 
                                    C.c_float(loss_mix_ratio), ptr(out), rn.stream_ptr()),
         'ra_loss_stats_f32')
   return out
+
+
+# --------------------------------------------------------------------------------------
+# evaluation post-processing and metrics (csrc/ra_eval.hip)
+# --------------------------------------------------------------------------------------
+EVAL_NAMES = ('sbd', 'wt_cov', 'unwt_cov', 'fg_iou', 'fg_dice', 'avg_fp', 'avg_fn', 'count_acc',
+              'count_mse', 'dic', 'dic_abs', 'num_obj', 'count_out')  # RA_EVAL_* order
+EVALI_NAMES = ('obj_pr', 'obj_re', 'pix_pr', 'pix_re', 'has_out', 'is_gt')  # RA_EVALI_* order
+
+
+def postprocess(y_out, s_out, thresh, fg=None, want_union=False):
+  """apply_confidence -> apply_one_label -> apply_threshold [-> mask_foreground] in one pass
+  (utils/postprocess.py:5-52,139-147): (y_bin [B,T,H,W], s_hard [B,T], union [B,H,W] | None)."""
+  y_out, s_out = y_out.contiguous(), s_out.contiguous()
+  fg = None if fg is None else fg.contiguous()
+  _need_cuda(y_out, s_out, fg)
+  B, T, H, W = y_out.shape
+  y_bin = torch.empty_like(y_out)
+  s_hard = torch.empty((B, T), dtype=torch.float32, device=y_out.device)
+  uni = torch.empty((B, H, W), dtype=torch.float32, device=y_out.device) if want_union else None
+  check(rn.lib().ra_postprocess_f32(ptr(y_out), ptr(s_out), B, T, H, W, C.c_float(thresh),
+                                    ptr(fg), ptr(y_bin),
+                                    ptr(s_hard), ptr(uni), rn.stream_ptr()), 'ra_postprocess_f32')
+  return y_bin, s_hard, uni
+
+
+def union_over_instances(y):
+  """y [B,T,H,W] -> max over T [B,H,W] (analysis.py:547,570)."""
+  y = y.contiguous()
+  _need_cuda(y)
+  B, T, H, W = y.shape
+  out = torch.empty((B, H, W), dtype=torch.float32, device=y.device)
+  check(rn.lib().ra_union_f32(ptr(y), B, T, H * W, ptr(out), rn.stream_ptr()), 'ra_union_f32')
+  return out
+
+
+def remove_tiny(y_bin, sizes, conf, threshold):
+  """In place: instance planes of at most `threshold` pixels are zeroed, their conf too."""
+  _need_cuda(y_bin, sizes, conf)
+  B, T, H, W = y_bin.shape
+  check(rn.lib().ra_remove_tiny_f32(ptr(y_bin), ptr(sizes.contiguous()), ptr(conf), B, T, H * W,
+                                    C.c_float(threshold), rn.stream_ptr()), 'ra_remove_tiny_f32')
+
+
+def eval_metrics(y_bin, y_gt, s_gt, fg_a=None, fg_b=None):
+  """Every per-image statistic of analysis.py:314-760 for binary outputs y_bin and ground truth
+  y_gt [B,T,H,W]: dict(iou_pairwise [B,T,T], stats [B,len(EVAL_NAMES)], inst [B,len(EVALI_NAMES),T])."""
+  y_bin, y_gt, s_gt = y_bin.contiguous(), y_gt.contiguous(), s_gt.contiguous()
+  _need_cuda(y_bin, y_gt, s_gt)
+  B, T, H, W = y_bin.shape
+  dev = y_bin.device
+  if fg_a is None:
+    fg_a = union_over_instances(y_bin)
+  if fg_b is None:
+    fg_b = union_over_instances(y_gt)
+  main = pair_stats(y_bin, y_gt, want=('inter', 'sum_a', 'sum_b'))
+  ua, ub = fg_a.view(B, 1, H, W), fg_b.view(B, 1, H, W)
+  fg = pair_stats(ua, ub, want=('inter', 'sum_a', 'sum_b'))
+  a_fgb = pair_stats(y_bin, ub, want=('inter',))['inter'].view(B, T).contiguous()
+  b_fga = pair_stats(ua, y_gt, want=('inter',))['inter'].view(B, T).contiguous()
+  iou = torch.empty((B, T, T), dtype=torch.float32, device=dev)
+  stats = torch.empty((B, len(EVAL_NAMES)), dtype=torch.float32, device=dev)
+  inst = torch.empty((B, len(EVALI_NAMES), T), dtype=torch.float32, device=dev)
+  check(rn.lib().ra_eval_metrics_f32(ptr(main['inter']), ptr(main['sum_a']), ptr(main['sum_b']),
+                                     ptr(s_gt.contiguous()), ptr(fg['inter']), ptr(fg['sum_a']),
+                                     ptr(fg['sum_b']), ptr(a_fgb), ptr(b_fga), B, T, ptr(iou), ptr(stats),
+                                     ptr(inst), rn.stream_ptr()), 'ra_eval_metrics_f32')
+  return {'iou_pairwise': iou, 'stats': stats, 'inst': inst, 'sizes': main['sum_a']}

@@ -112,7 +112,7 @@ def test_unbuilt_parts_fail_loudly():
   with pytest.raises(KeyError):
     m.run('nonsense', {'x': None})
   with pytest.raises(NotImplementedError):
-    modellib.f_iou(None, None)
+    modellib.f_match_loss(None, None, None, 2, None)  # the loss variants that only matter with a backward pass
   if not torch.cuda.is_available():
     with pytest.raises(rn.RecAttendError):   # no silent CPU fallback
       m.run('y_out', {'x': np.zeros((1, 64, 64, 3), np.float32), 'phase_train': False})
