@@ -255,8 +255,265 @@ __host__ __device__ inline int solve(const float *w, int nx, int ny, float *M, f
   return 1;
 }
 
-// One workgroup (one wave) per example; lane 0 runs the serial solver.  use_lds: the hot scratch and
-// private copies of w / M / cx / cy live in LDS (all 64 lanes stage them in and out).
+// ---- wave-cooperative form of the same algorithm (device only) ----
+// The 64 lanes of one wave execute solve_wave() together: every data-parallel loop of the serial
+// solver (equality graph, network reset, neighbourhood marks, slack minimum, cover update, ...) is
+// strided over the lanes, every order-dependent step keeps the serial order (BFS pushes go in
+// ascending node order through a ballot, the path walk and the tree growth run on uniform
+// scalars).  min / max / or-reductions are exact and order-independent, so the result is the
+// serial solver's, bit for bit (tests/test_hungarian.py checks it on the reference's vectors and
+// hundreds of random problems).  All lanes hold identical copies of the scalar state.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline void wsync() { __syncthreads(); }  // one wave per workgroup: orders LDS/global traffic
+__device__ inline float wave_min(float v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(v, o);
+    v = (t < v) ? t : v;
+  }
+  return v;
+}
+__device__ inline float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(v, o);
+    v = (t > v) ? t : v;
+  }
+  return v;
+}
+
+__device__ inline int augment_wave(Scratch &g, float cap_max, int lane) {
+  const int n = g.n, src = 0, dst = n - 1;
+  for (int v = lane; v < n; v += 64) {
+    g.mark[v] = 0;
+    g.parent[v] = -1;
+  }
+  if (lane == 0) g.queue[0] = src;
+  __threadfence_block();
+  wsync();
+  int qh = 0, qt = 1;
+  bool reached = false;
+  for (int it = 0; qt > qh && it <= kMaxIter; ++it) {
+    if (it == kMaxIter) return RA_E_HUNG_BFS;
+    const int v = g.queue[qh++];
+    if (lane == 0) g.mark[v] = 1;  // marked on pop, not on push
+    wsync();
+    if (v == dst) {
+      reached = true;
+      break;
+    }
+    const float *row = g.res + (size_t)v * n;
+    for (int base = 0; base < n; base += 64) {
+      const int u = base + lane;
+      const bool push = u < n && !g.mark[u] && row[u] > 0;
+      const unsigned long long m = __ballot(push);
+      if (push) {
+        g.queue[qt + __popcll(m & ((1ull << lane) - 1ull))] = u;  // ascending u, like the serial scan
+        g.parent[u] = v;                                            // later pushers overwrite
+      }
+      qt += __popcll(m);
+    }
+    __threadfence_block();
+    wsync();
+  }
+  if (!reached) return 0;
+  int rc = 1;
+  if (lane == 0) {  // the augmenting path is at most n long: walk it on one lane
+    float bottleneck = cap_max;  // capacity.maxCoeff(), hungarian.cc:144
+    int v = dst;
+    for (int it = 0; g.parent[v] != -1 && it <= kMaxIter; ++it) {
+      if (it == kMaxIter) {
+        rc = RA_E_HUNG_PATH;
+        break;
+      }
+      const float r = g.res[(size_t)g.parent[v] * n + v];
+      bottleneck = (bottleneck < r) ? bottleneck : r;
+      v = g.parent[v];
+    }
+    v = dst;
+    for (int it = 0; rc == 1 && g.parent[v] != -1 && it <= kMaxIter; ++it) {
+      if (it == kMaxIter) {
+        rc = RA_E_HUNG_PATH;
+        break;
+      }
+      const int p = g.parent[v];
+      if (g.cap[(size_t)p * n + v] > 0)
+        g.flow[(size_t)p * n + v] += bottleneck;
+      else
+        g.flow[(size_t)v * n + p] -= bottleneck;
+      g.res[(size_t)p * n + v] -= bottleneck;
+      g.res[(size_t)v * n + p] += bottleneck;
+      v = p;
+    }
+  }
+  rc = __shfl(rc, 0);
+  wsync();
+  return rc;
+}
+
+__device__ inline int rematch_wave(Scratch &g, int nx, int ny, float *M, int lane) {
+  const int n = g.n, dst = n - 1, nn = n * n;
+  for (int k = lane; k < nn; k += 64) g.cap[k] = 0.0f;
+  wsync();
+  for (int k = lane; k < nx * ny; k += 64) {
+    const int x = k / ny, y = k - x * ny;
+    g.cap[(size_t)(1 + x) * n + (1 + nx + y)] = g.eq[k];
+  }
+  for (int x = lane; x < nx; x += 64) g.cap[1 + x] = 1.0f;                                // s -> x
+  for (int y = lane; y < ny; y += 64) g.cap[(size_t)(1 + nx + y) * n + dst] = 1.0f;      // y -> t
+  wsync();
+  float cap_max = -FLT_MAX;
+  for (int k = lane; k < nn; k += 64) {
+    const float c = g.cap[k];
+    g.flow[k] = 0.0f;
+    g.res[k] = c;
+    cap_max = (c > cap_max) ? c : cap_max;
+  }
+  cap_max = wave_max(cap_max);
+  wsync();
+  for (int it = 0;; ++it) {
+    const int r = augment_wave(g, cap_max, lane);
+    if (r < 0) return r;
+    if (r == 0 || it > kMaxIter) break;
+    if (it == kMaxIter) return RA_E_HUNG_FLOW;
+  }
+  for (int k = lane; k < nx * ny; k += 64) {
+    const int x = k / ny, y = k - x * ny;
+    M[k] = g.flow[(size_t)(1 + x) * n + (1 + nx + y)];
+  }
+  wsync();
+  return 0;
+}
+
+__device__ inline int solve_wave(const float *w, int nx, int ny, float *M, float *cx, float *cy,
+                                 void *hot_buf, void *queue_buf, int lane) {
+  Scratch g = carve(hot_buf, queue_buf, nx, ny);
+  for (int x = lane; x < nx; x += 64) {
+    float top = w[x * ny];
+    for (int y = 1; y < ny; ++y) top = (w[x * ny + y] > top) ? w[x * ny + y] : top;
+    cx[x] = top;
+    g.inS[x] = 0;
+  }
+  for (int y = lane; y < ny; y += 64) {
+    cy[y] = 0.0f;
+    g.inT[y] = 0;
+  }
+  for (int k = lane; k < nx * ny; k += 64) M[k] = 0.0f;
+  wsync();
+  int cntT = 0;
+  bool need_match = true;
+
+  for (int it = 0; it <= kMaxIter; ++it) {
+    if (it == kMaxIter) return 1;
+    for (int k = lane; k < nx * ny; k += 64) {  // equality graph (hungarian.cc:309-325)
+      const int x = k / ny, y = k - x * ny;
+      const float slack = cx[x] + cy[y] - w[k];
+      const float mag = (slack > 0) ? slack : -slack;
+      g.eq[k] = (mag <= RA_HUNG_EPS && (cx[x] > 0 || cy[y] > 0)) ? 1.0f : 0.0f;
+    }
+    wsync();
+    if (need_match) {
+      const int r = rematch_wave(g, nx, ny, M, lane);
+      if (r < 0) return r;
+      {  // saturating(): every vertex of the smaller side is matched (hungarian.cc:219-248)
+        const bool by_col = nx >= ny;
+        const int outer = by_col ? ny : nx, inner = by_col ? nx : ny;
+        bool unsat = false;
+        for (int a = lane; a < outer; a += 64) {
+          float sum = 0;
+          for (int b = 0; b < inner; ++b) sum += by_col ? M[b * ny + a] : M[a * ny + b];
+          unsat = unsat || (sum == 0);
+        }
+        if (__ballot(unsat) == 0ull) return 0;
+      }
+      int first = -1;  // first exposed x seeds S (hungarian.cc:394-403)
+      for (int base = 0; base < nx && first < 0; base += 64) {
+        const int x = base + lane;
+        bool exposed = x < nx;
+        if (exposed)
+          for (int y = 0; y < ny && exposed; ++y) exposed = !(M[x * ny + y] == 1.0);
+        const unsigned long long m = __ballot(exposed);
+        if (m) first = base + (int)__builtin_ctzll(m);
+      }
+      if (first >= 0) {
+        for (int a = lane; a < nx; a += 64) g.inS[a] = (a == first) ? 1 : 0;
+        for (int b = lane; b < ny; b += 64) g.inT[b] = 0;
+        cntT = 0;
+      }
+      wsync();
+    }
+    int cntN = 0;  // N(S) in the equality graph
+    bool diff = false;
+    for (int base = 0; base < ny; base += 64) {
+      const int y = base + lane;
+      bool inN = false;
+      if (y < ny)
+        for (int x = 0; x < nx; ++x) inN = inN || (g.inS[x] && g.eq[x * ny + y] > 0);
+      if (y < ny) g.inN[y] = inN ? 1 : 0;
+      cntN += __popcll(__ballot(inN));
+      diff = diff || (inN && !g.inT[y < ny ? y : 0]);
+    }
+    const bool same = (cntN == cntT) && (__ballot(diff) == 0ull);
+    wsync();
+
+    if (same) {  // cover update (hungarian.cc:415-443)
+      float a = FLT_MAX;
+      for (int k = lane; k < nx * ny; k += 64) {
+        const int x = k / ny, y = k - x * ny;
+        if (g.inS[x] && !g.inT[y]) {
+          const float slack = cx[x] + cy[y] - w[k];
+          a = (a < slack) ? a : slack;
+        }
+      }
+      a = wave_min(a);
+      if (a < RA_HUNG_EPS) {
+        need_match = true;
+        continue;
+      }
+      for (int x = lane; x < nx; x += 64)
+        if (g.inS[x]) cx[x] -= a;
+      for (int y = lane; y < ny; y += 64)
+        if (g.inT[y]) cy[y] += a;
+      wsync();
+    } else {  // grow the alternating tree (hungarian.cc:444-483)
+      for (int j = 0; cntN > cntT && j <= kMaxIter; ++j) {
+        if (j == kMaxIter) return RA_E_HUNG_EQUALIZE;
+        int y = -1;  // smallest y in N(S) \ T
+        for (int base = 0; base < ny && y < 0; base += 64) {
+          const int c = base + lane;
+          const unsigned long long m = __ballot(c < ny && g.inN[c] && !g.inT[c]);
+          if (m) y = base + (int)__builtin_ctzll(m);
+        }
+        int z = -1;  // its match
+        for (int base = 0; base < nx && z < 0 && y >= 0; base += 64) {
+          const int x = base + lane;
+          const unsigned long long m = __ballot(x < nx && M[x * ny + y] == 1.0);
+          if (m) z = base + (int)__builtin_ctzll(m);
+        }
+        if (z < 0) {
+          need_match = true;
+          break;
+        }
+        need_match = false;
+        for (int base = 0; base < ny; base += 64) {
+          const int v = base + lane;
+          const bool add = v < ny && g.eq[z * ny + v] > 0.0 && !g.inN[v];
+          if (add) g.inN[v] = 1;
+          cntN += __popcll(__ballot(add));
+        }
+        if (lane == 0) {
+          g.inS[z] = 1;
+          g.inT[y] = 1;
+        }
+        ++cntT;
+        wsync();
+      }
+    }
+  }
+  return 1;
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+// One workgroup (one wave) per example running solve_wave().  use_lds: the hot scratch and private
+// copies of w / M / cx / cy live in LDS (all 64 lanes stage them in and out).
 __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, int ny, float *M,
                                                         float *cx, float *cy, int *status,
                                                         char *ws, size_t ws_per_ex, int use_lds) {
@@ -266,20 +523,22 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, i
   float *Mb = M + (size_t)b * nx * ny, *cxb = cx + (size_t)b * nx, *cyb = cy + (size_t)b * ny;
   char *wsb = ws + (size_t)b * ws_per_ex;
   if (!use_lds) {
-    if (t == 0) {
-      const int rc = solve(wb, nx, ny, Mb, cxb, cyb, wsb, wsb + hot_bytes(nx, ny));
-      if (status) status[b] = rc;
-    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int rc = solve_wave(wb, nx, ny, Mb, cxb, cyb, wsb, wsb + hot_bytes(nx, ny), t);
+    if (t == 0 && status) status[b] = rc;
+#endif
     return;
   }
   float *lw = reinterpret_cast<float *>(lds + hot_bytes(nx, ny));
   float *lM = lw + nx * ny, *lcx = lM + nx * ny, *lcy = lcx + nx;
   for (int e = t; e < nx * ny; e += 64) lw[e] = wb[e];
   __syncthreads();
-  if (t == 0) {
-    const int rc = solve(lw, nx, ny, lM, lcx, lcy, lds, wsb + hot_bytes(nx, ny));
-    if (status) status[b] = rc;
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    const int rc = solve_wave(lw, nx, ny, lM, lcx, lcy, lds, wsb + hot_bytes(nx, ny), t);
+    if (t == 0 && status) status[b] = rc;
   }
+#endif
   __syncthreads();
   for (int e = t; e < nx * ny; e += 64) Mb[e] = lM[e];
   for (int e = t; e < nx; e += 64) cxb[e] = lcx[e];
