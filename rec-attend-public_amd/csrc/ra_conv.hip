@@ -51,7 +51,6 @@ struct Args {
   int Cout, CoutP;
   int relu, pool;
   int Ho, Wo;
-  int ablate;  // tuning aid (RA_CONV_ABLATE): 1 skip epilogue, 2 skip staging, 4 skip MFMA loop
   int bytes0, bytes1, bytes_y;  // tensor sizes for the buffer descriptors (each < 2 GiB)
   const float *plane;           // optional [B,Hs,Ws] plane that REPLACES input channel plane_chan
   int plane_chan, bytes_p;      // (the canvas, kept outside the packed image)
@@ -200,20 +199,35 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
     if (e >= NPIX) rel_r[i] = -(1 << 28);  // never in range
     if (a.ups && !((rel_r[i] & 1) && (rel_c[i] & 1))) rel_r[i] = -(1 << 28);  // stuffed zero
   }
+  // single source, no zero-stuffing, no canvas plane: the common case, kept free of per-element
+  // flag tests (they are wave-uniform, but inside the unrolled loops each becomes a branch)
+  const bool simple = !a.ups && a.C1 == 0 && a.plane == nullptr;
   auto load_item = [&](int T, int ch) {  // global -> registers (input tile + halo of one chunk)
     int b, ty0, tx0;
     tile_origin(T, b, ty0, tx0);
+    const int ylo = -ty0, yhi = a.H - ty0, xlo = -tx0, xhi = a.W - tx0;
+    if (simple) {
+      const int base = ((b * a.Hs + ty0) * a.Ws + tx0) * a.C0 + ch * CK;  // scalar
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        const bool ok = (rel_r[i] >= ylo) & (rel_r[i] < yhi) & (rel_c[i] >= xlo) & (rel_c[i] < xhi);
+        // out-of-image pixels read past the descriptor's range: the buffer unit returns zeros,
+        // so the SAME padding costs no branch
+        const int off = ok ? (base + off0[i]) * 4 : kOOB;
+#pragma unroll
+        for (int cg = 0; cg < G::NCG; ++cg)
+          st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16 * cg, 0));
+      }
+      return;
+    }
     const int sy0 = a.ups ? (ty0 >> 1) : ty0, sx0 = a.ups ? (tx0 >> 1) : tx0;
     const int pbase = (b * a.Hs + sy0) * a.Ws + sx0;  // scalar: source pixel index of the origin
-    const int ylo = -ty0, yhi = a.H - ty0, xlo = -tx0, xhi = a.W - tx0;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const bool ok = (rel_r[i] >= ylo) & (rel_r[i] < yhi) & (rel_c[i] >= xlo) & (rel_c[i] < xhi);
 #pragma unroll
       for (int cg = 0; cg < G::NCG; ++cg) {
         const int chan = ch * CK + cg * 4;  // uniform
-        // out-of-image / zero-stuffed pixels read past the descriptor's range: the buffer unit
-        // returns zeros, so the SAME padding costs no branch
         if (chan < a.C0) {
           const int off = ok ? (pbase * a.C0 + off0[i] + chan) * 4 : kOOB;
           st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
@@ -284,32 +298,43 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   };
   const int opool = a.pool;  // 1 or 2
   const bool vec_ok = (a.Cout & 3) == 0;
+  const float lo = a.relu ? 0.f : -__builtin_inff();  // ReLU as one v_max, no flag test per value
   auto epilogue = [&](int T) {  // scale/shift (bias + BN), ReLU, 2x2 max-pool, store
     int b, ty0, tx0;
     tile_origin(T, b, ty0, tx0);
     if constexpr (!SWAP) {  // lane = channel co_lane; registers r = window element (dy,dx) of pixel group qo
       const int wrow0 = ty0 + wm * G::WR, lcol0 = tx0 + 2 * qo;
+      if (opool == 2) {
 #pragma unroll
-      for (int n = 0; n < NC; ++n) {
-        const int co = 16 * (wn * NC + n) + co_lane;
-        const bool co_ok = co < a.Cout;
-        const int obase = ((b * a.Ho + wrow0 / opool) * a.Wo + lcol0 / opool) * a.Cout + co;
+        for (int n = 0; n < NC; ++n) {
+          const int co = 16 * (wn * NC + n) + co_lane;
+          const bool co_ok = co < a.Cout;
+          const int obase = ((b * a.Ho + (wrow0 >> 1)) * a.Wo + (lcol0 >> 1)) * a.Cout + co;
 #pragma unroll
-        for (int g = 0; g < G::PM; ++g) {
-          const int gx = g % GX, gy = g / GX;
-          const int row0 = wrow0 + 2 * gy, col0 = lcol0 + 8 * gx;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[g][n][r] * sc4[n].x + sh4[n].x;
-            if (a.relu) v[r] = fmaxf(v[r], 0.f);
-          }
-          if (opool == 2) {
-            const float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+          for (int g = 0; g < G::PM; ++g) {
+            const int gx = g % GX, gy = g / GX;
+            const int row0 = wrow0 + 2 * gy, col0 = lcol0 + 8 * gx;
+            // max commutes with the (monotone or not) affine only after it: apply BN first
+            const f32x4 v = acc[g][n] * sc4[n] + sh4[n];
+            const float o = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), lo);
             const bool ok = co_ok & ((row0 >> 1) < a.Ho) & ((col0 >> 1) < a.Wo);
             const int boff = ok ? (obase + (gy * a.Wo + 4 * gx) * a.Cout) * 4 : kOOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, boff, 0, 0);
-          } else {
+          }
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+          const int co = 16 * (wn * NC + n) + co_lane;
+          const bool co_ok = co < a.Cout;
+          const int obase = ((b * a.Ho + wrow0) * a.Wo + lcol0) * a.Cout + co;
+#pragma unroll
+          for (int g = 0; g < G::PM; ++g) {
+            const int gx = g % GX, gy = g / GX;
+            const int row0 = wrow0 + 2 * gy, col0 = lcol0 + 8 * gx;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[g][n][r] * sc4[n].x + sh4[n].x, lo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const bool ok = co_ok & (row0 + (r >> 1) < a.Ho) & (col0 + (r & 1) < a.Wo);
@@ -332,10 +357,8 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       for (int g = 0; g < G::PM; ++g) {
         const int gx = g % GX, gy = g / GX;
         f32x4 v = acc[g][n] * sc4[n] + sh4[n];
-        if (a.relu) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
         if (opool == 2) {  // the 2x2 window = lanes 4q..4q+3
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -374,11 +397,11 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       nT = T + gridDim.x;
     }
     const bool has_next = nT < ntiles;
-    if (has_next && !(a.ablate & 2)) load_item(nT, nch);  // in flight across the MFMA loop
+    if (has_next) load_item(nT, nch);  // in flight across the MFMA loop
     if (BDB && has_next && nchunks > 1) load_b_next(nch);
-    if (!(a.ablate & 4)) compute(buf);
+    compute(buf);
     if (ch == nchunks - 1) {
-      if (!(a.ablate & 1)) epilogue(T);
+      epilogue(T);
       zero_acc();
     }
     if (!has_next) break;
@@ -386,7 +409,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       if constexpr (BDB) swap_b();
       else load_b(nch);
     }
-    if (!(a.ablate & 2)) store_item(buf ^ 1);
+    store_item(buf ^ 1);
     __syncthreads();
     buf ^= 1;
     T = nT;
@@ -565,14 +588,6 @@ extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int 
   a.CoutP = ra_conv_cout_padded(Cout);
   a.relu = relu;
   a.pool = pool;
-  {
-    static int abl = -1;
-    if (abl < 0) {
-      const char *e = getenv("RA_CONV_ABLATE");
-      abl = e ? atoi(e) : 0;
-    }
-    a.ablate = abl;
-  }
   if (!a.CoutP) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: Cout %d", Cout);
   if (pool != 1 && pool != 2) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: pool %d", pool);
   if (pool == 2 && ((a.H | a.W) & 1)) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: odd size with pool 2");
