@@ -352,6 +352,15 @@ int ra_eval_metrics_f32(const float *inter, const float *sum_a, const float *sum
                         const float *fg_b, const float *a_in_fgb, const float *b_in_fga, int B,
                         int T, float *iou_pairwise, float *stats, float *inst, void *stream);
 
+/* In-graph augmentation, image_ops.random_transformation (image_ops.py:9-113) for given random
+ * draws: zero-pad by `padding`, crop H x W at (off_y, off_x) in [0, 2*padding] (one offset per
+ * batch), reverse along H (flip_v) / W (flip_h), then transpose H <-> W (needs H == W).
+ * x, out: [N,H,W,C]; instance masks [B,T,H,W] go in as N = B*T, C = 1.  out != x.
+ * The colour jitter (:99-103) is not built. */
+int ra_random_transform_f32(const float *x, int N, int H, int W, int C, int padding, int off_y,
+                            int off_x, int flip_v, int flip_h, int transpose, float *out,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -549,6 +549,22 @@ def eval_metrics(y_out, y_gt, s_gt):
   return out
 
 
+def random_transformation(x, padding, off_y, off_x, flip_v=False, flip_h=False, transpose=False):
+  """image_ops.py:9-113 with phase_train true, for GIVEN draws, on x [N,H,W,C] (use C = 1 planes
+  for the instance masks): zero-pad (:37), crop at the offset (:53-55), tf.reverse along H / W
+  (:88-91), tf.transpose of H and W (:95-97)."""
+  N, H, W = x.shape[:3]
+  pad = [(0, 0), (padding, padding), (padding, padding)] + [(0, 0)] * (x.ndim - 3)
+  r = np.pad(x, pad)[:, off_y:off_y + H, off_x:off_x + W]
+  if flip_v:
+    r = r[:, ::-1]
+  if flip_h:
+    r = r[:, :, ::-1]
+  if transpose:
+    r = np.swapaxes(r, 1, 2)
+  return np.ascontiguousarray(r)
+
+
 # --------------------------------------------------------------------------------------
 # model option handling shared by both graphs
 # --------------------------------------------------------------------------------------

@@ -227,3 +227,44 @@ extern "C" int ra_eval_metrics_f32(const float *inter, const float *sum_a, const
                      fg_inter, fg_a, fg_b, a_in_fgb, b_in_fga, T, iou_pairwise, stats, inst);
   return launch_status("ra_eval_metrics_f32");
 }
+
+// ---- K13: in-graph augmentation, image_ops.random_transformation (image_ops.py:9-113) ----
+// Zero-pad by `padding`, crop H x W at (off_y, off_x) (one offset per batch, :52), reverse along
+// H / W (:85-91), transpose H <-> W (:93-97): one gather.  x is [N, H, W, C] (images, d, c) or,
+// with C == 1, any stack of planes ([B*T, H, W] instance masks, :57-59).
+namespace ra {
+namespace eval {
+__global__ __launch_bounds__(256) void random_transform_kernel(const float *x, int H, int W, int C, int padding,
+                                                                int off_y, int off_x, int flip_v, int flip_h,
+                                                                int transpose, float *out) {
+  const int n = blockIdx.y;
+  const size_t plane = (size_t)H * W * C;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < plane; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int j = (int)((e / C) % W), i = (int)(e / ((size_t)C * W));  // output pixel (i, j)
+    // undo transpose, then the flips, then the crop offset
+    int ri = transpose ? j : i, rj = transpose ? i : j;
+    if (flip_v) ri = H - 1 - ri;
+    if (flip_h) rj = W - 1 - rj;
+    const int sy = ri + off_y - padding, sx = rj + off_x - padding;
+    float v = 0.f;
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[(size_t)n * plane + ((size_t)sy * W + sx) * C + c];
+    out[(size_t)n * plane + e] = v;
+  }
+}
+}  // namespace eval
+}  // namespace ra
+
+extern "C" int ra_random_transform_f32(const float *x, int N, int H, int W, int C, int padding, int off_y, int off_x,
+                                       int flip_v, int flip_h, int transpose, float *out, void *stream) {
+  if (!x || !out || x == out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || padding < 0)
+    return fail(RA_E_INVALID, "ra_random_transform_f32: bad argument");
+  if (off_y < 0 || off_x < 0 || off_y > 2 * padding || off_x > 2 * padding)
+    return fail(RA_E_INVALID, "ra_random_transform_f32: offset (%d, %d) outside [0, 2*padding]", off_y, off_x);
+  if (transpose && H != W) return fail(RA_E_SHAPE, "ra_random_transform_f32: transpose needs H == W");
+  const size_t plane = (size_t)H * W * C;
+  const int gx = (int)((plane + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(eval::random_transform_kernel, dim3(gx < 1 ? 1 : gx, N), dim3(256), 0, as_stream(stream), x, H, W,
+                     C, padding, off_y, off_x, flip_v, flip_h, transpose, out);
+  return launch_status("ra_random_transform_f32");
+}

@@ -1,0 +1,47 @@
+"""image_ops.py of the reference: the in-graph augmentation (random_transformation, :9-113).
+
+At evaluation (phase_train false) it is pad-then-centre-crop = the identity (:70-82,106), which is
+why the decode loop never calls it.  With phase_train true it draws ONE crop offset per batch (:52)
+and one flip / transpose decision per batch (:85-97) and applies them to x, y, d, c alike; the
+gather runs in one HIP kernel per tensor (ra_random_transform_f32).  The draws come from a
+torch.Generator so that ranks can offset their streams deterministically.
+The colour jitter (random hue / saturation / brightness / contrast, :99-103) is not built."""
+import torch
+
+import nnlib as nn
+import ra_ops as ops
+
+
+def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=True, rnd_transpose=True,
+                          rnd_colour=False, y=None, d=None, c=None, generator=None):
+  """x [B,H,W,3], y [B,T,H,W], d [B,H,W,8], c [B,H,W,1] -> dict with the same keys (x, y, d, c)."""
+  results = {'x': x}
+  for k, v in (('y', y), ('d', d), ('c', c)):
+    if v is not None:
+      results[k] = v
+  if not nn._is_train(phase_train):
+    return results  # centre slices of the padded tensors: the inputs themselves
+  if rnd_colour:
+    raise NotImplementedError('colour jitter (image_ops.py:99-103, :116-230) is not built')
+  if d is not None:  # image_ops.py:42-45
+    assert not rnd_vflip, 'Orientation mode is on, no random flips'
+    assert not rnd_hflip, 'Orientation mode is on, no random flips'
+    assert not rnd_transpose, 'Orientation mode is on, no random transpose'
+  g = generator
+  off = torch.randint(0, max(2 * padding, 1), (2,), generator=g) if padding > 0 else torch.zeros(2, dtype=torch.long)
+  u = torch.rand(3, generator=g)
+  # tf.random_uniform([1], 1.0 - float(flag), 1.0) < 0.5: never true when the flag is off (:85-94)
+  flip_h = bool(rnd_hflip) and float(u[0]) < 0.5 and d is None
+  flip_v = bool(rnd_vflip) and float(u[1]) < 0.5 and d is None
+  do_tr = bool(rnd_transpose) and float(u[2]) < 0.5 and d is None
+  kw = dict(padding=padding, off_y=int(off[0]), off_x=int(off[1]), flip_v=flip_v, flip_h=flip_h, transpose=do_tr)
+  results['x'] = ops.random_transform(x, **kw)
+  if y is not None:
+    B, T, H, W = y.shape
+    results['y'] = ops.random_transform(y.reshape(B * T, H, W), **kw).reshape(B, T, H, W)
+  if d is not None:
+    results['d'] = ops.random_transform(d, **kw)
+  if c is not None:
+    results['c'] = ops.random_transform(c, **kw)
+  results['_draws'] = kw
+  return results

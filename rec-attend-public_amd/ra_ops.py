@@ -505,3 +505,17 @@ def eval_metrics(y_bin, y_gt, s_gt, fg_a=None, fg_b=None):
                                      ptr(fg['sum_b']), ptr(a_fgb), ptr(b_fga), B, T, ptr(iou), ptr(stats),
                                      ptr(inst), rn.stream_ptr()), 'ra_eval_metrics_f32')
   return {'iou_pairwise': iou, 'stats': stats, 'inst': inst, 'sizes': main['sum_a']}
+
+
+def random_transform(x, padding, off_y, off_x, flip_v=False, flip_h=False, transpose=False):
+  """image_ops.random_transformation for given draws on x [N,H,W,C] (or [N,H,W] planes)."""
+  x = x.contiguous()
+  _need_cuda(x)
+  shape = x.shape
+  N, H, W = shape[0], shape[1], shape[2]
+  Cc = shape[3] if x.dim() == 4 else 1
+  out = torch.empty_like(x)
+  check(rn.lib().ra_random_transform_f32(ptr(x), N, H, W, Cc, int(padding), int(off_y), int(off_x),
+                                         int(bool(flip_v)), int(bool(flip_h)), int(bool(transpose)),
+                                         ptr(out), rn.stream_ptr()), 'ra_random_transform_f32')
+  return out

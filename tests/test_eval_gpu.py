@@ -163,3 +163,31 @@ def test_eval_driver_writes_predictions_and_metrics(cuda, tmp_path):
   r = {'y_out': y_bin, 'y_gt': dev(y_gt, cuda), 's_out': s_hard, 's_gt': dev(s_gt, cuda)}
   assert abs(summary['0.50']['sbd']['mean'] - float(analysis.f_symmetric_best_dice(r).mean())) < 1e-6
   assert summary['0.50']['dic']['count'] == 3
+
+
+@pytest.mark.parametrize('H,W,C,pad', [(32, 32, 3, 8), (24, 40, 8, 5), (16, 16, 1, 0)])
+def test_random_transformation(cuda, H, W, C, pad):
+  """image_ops.random_transformation: every combination of the draws against the oracle, the
+  identity at evaluation, and the reference-named wrapper applying the same draws to x and y."""
+  import image_ops
+  import ra_ops as ops
+  rng = np.random.RandomState(H + C)
+  x = rng.rand(2, H, W, C).astype(np.float32)
+  for off_y, off_x in ((0, 0), (pad, pad), (2 * pad, max(2 * pad - 1, 0))):
+    for fv in (False, True):
+      for fh in (False, True):
+        for tr in ((False, True) if H == W else (False,)):
+          got = ops.random_transform(dev(x, cuda), pad, off_y, off_x, fv, fh, tr).cpu().numpy()
+          assert (got == ora.random_transformation(x, pad, off_y, off_x, fv, fh, tr)).all()
+  xd = dev(x[..., :3] if C >= 3 else np.repeat(x, 3, axis=3), cuda)
+  y = dev(rng.rand(2, 4, H, W), cuda)
+  same = image_ops.random_transformation(xd, pad, False, y=y)
+  assert same['x'] is xd and same['y'] is y
+  g = torch.Generator().manual_seed(5)
+  r = image_ops.random_transformation(xd, pad, True, rnd_transpose=(H == W), y=y, generator=g)
+  kw = r['_draws']
+  assert (r['x'].cpu().numpy() == ora.random_transformation(xd.cpu().numpy(), **kw)).all()
+  yr = ora.random_transformation(y.cpu().numpy().reshape(8, H, W), **kw).reshape(2, 4, H, W)
+  assert (r['y'].cpu().numpy() == yr).all()
+  with pytest.raises(NotImplementedError):
+    image_ops.random_transformation(xd, pad, True, rnd_colour=True)
