@@ -361,6 +361,11 @@ int ra_random_transform_f32(const float *x, int N, int H, int W, int C, int padd
                             int off_x, int flip_v, int flip_h, int transpose, float *out,
                             void *stream);
 
+/* out[b,p] = sum_t w[b,t] * y[b,t,p]: the ground-truth instance box_model's greedy match picks
+ * (box_model.py:487-499).  Terms with w == 0 are skipped (0 * x is not evaluated). */
+int ra_weighted_sum_f32(const float *w, const float *y, int B, int T, int HW, float *out,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,3 +268,32 @@ extern "C" int ra_random_transform_f32(const float *x, int N, int H, int W, int 
                      C, padding, off_y, off_x, flip_v, flip_h, transpose, out);
   return launch_status("ra_random_transform_f32");
 }
+
+// out[b,p] = sum_t w[b,t] * y[b,t,p] — the ground-truth instance picked by box_model's greedy match
+// (box_model.py:487-499: reduce_sum(grd_match * y_gt, 1)).
+namespace ra {
+namespace eval {
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float *w, const float *y, int T, int HW,
+                                                            float *out) {
+  const int b = blockIdx.y;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= HW) return;
+  const float *yb = y + (size_t)b * T * HW + e;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t) {
+    const float wt = w[(size_t)b * T + t];
+    if (wt != 0.f) acc += wt * *reinterpret_cast<const f32x4 *>(yb + (size_t)t * HW);  // uniform per image
+  }
+  *reinterpret_cast<f32x4 *>(out + (size_t)b * HW + e) = acc;
+}
+}  // namespace eval
+}  // namespace ra
+
+extern "C" int ra_weighted_sum_f32(const float *w, const float *y, int B, int T, int HW, float *out, void *stream) {
+  if (!w || !y || !out || B <= 0 || T <= 0 || HW <= 0) return fail(RA_E_INVALID, "ra_weighted_sum_f32: bad argument");
+  if (HW % 4 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return fail(RA_E_SHAPE, "ra_weighted_sum_f32: H*W %% 4 and 16-byte aligned tensors required");
+  hipLaunchKernelGGL(eval::weighted_sum_kernel, dim3(ceil_div(HW, 1024), B), dim3(256), 0, as_stream(stream), w, y, T,
+                     HW, out);
+  return launch_status("ra_weighted_sum_f32");
+}

@@ -432,18 +432,16 @@ class DecodeEngine(object):
 
   def _box_step(self, b, tt):
     """box_model.py:484-513: greedy GT match (never accumulated), canvas from noisy GT, score.
-    The [B,T] IoU / arg-max bookkeeping on the GT side uses torch reductions (plumbing for the
-    teacher-forcing input; not on the eval path)."""
+    The pixel-sized parts run in HIP (pairwise IoU of the box against the GT boxes on the streaming
+    K8 kernel, the picked instance as a weighted sum); the arg-max over T values per image is
+    [B,T]-sized bookkeeping."""
     d, T = self.d, self.d['T']
     box = b['attn_box'][:, tt:tt + 1]
-    gt = b['box_gt']
-    inter = (box * gt).sum(dim=(2, 3))
-    union = (box + gt - box * gt + 1e-5).sum(dim=(2, 3))
-    iou = inter / union
+    iou = ops.pair_stats(box, b['box_gt'], want=('iou_soft',))['iou_soft'][:, 0]  # f_inter / f_union, [B,T]
     mx = iou.max(dim=1, keepdim=True)[0]
-    match = (iou == mx).to(torch.float32)
+    match = (iou == mx).to(torch.float32)       # f_greedy_match with matched = 0, modellib.py:365-379
     match = match / match.sum(dim=1, keepdim=True)
-    torch.sum(match[:, :, None, None] * b['y_gt'], dim=1, out=b['ysel'])
+    ops.weighted_sum(match, b['y_gt'], b['ysel'])
     if 'canvas' in b:
       ops.canvas_max(b['canvas'].view(b['canvas'].shape + (1,)), 0, b['ysel'], b['noise'][tt])
     else:
@@ -480,7 +478,7 @@ class DecodeEngine(object):
       Bs = B // len(self.subs)
       for k, sb in enumerate(self.subs):
         sb['noise'].copy_(b['noise'][:, k * Bs:(k + 1) * Bs])
-        sb['box_gt'] = _gt_box_mask(sb['y_gt'], self.d['attn_box_padding_ratio'])
+        sb['box_gt'] = ops.gt_box(sb['y_gt'].contiguous(), float(self.d['attn_box_padding_ratio']), 10.0)[1]
     graphable = self.use_graph and self.timing is None and not self.box
     if not graphable:
       self._launch_all(want_box)
@@ -496,24 +494,3 @@ class DecodeEngine(object):
       self._graphs[key] = g
     g.replay()
     return self
-
-
-def _gt_box_mask(y_gt, padding_ratio, min_padding=10.0):
-  """modellib.get_gt_box (modellib.py:663-701) 'box' output, for box_model's greedy match."""
-  B, T, H, W = y_gt.shape
-  dev = y_gt.device
-  iy = torch.arange(H, dtype=torch.float32, device=dev).view(1, 1, H, 1)
-  ix = torch.arange(W, dtype=torch.float32, device=dev).view(1, 1, 1, W)
-  big = float(H * W)
-  tl_y = (iy + (1.0 - y_gt) * big).amin(dim=(2, 3))
-  tl_x = (ix + (1.0 - y_gt) * big).amin(dim=(2, 3))
-  br_y = (iy * y_gt).amax(dim=(2, 3))
-  br_x = (ix * y_gt).amax(dim=(2, 3))
-  out = []
-  for tl, br, idx in ((tl_y, br_y, iy), (tl_x, br_x, ix)):
-    size = br - tl
-    pad = torch.clamp(padding_ratio * size, min=min_padding)
-    lo = (tl - pad)[:, :, None, None]
-    hi = (br + pad)[:, :, None, None]
-    out.append(((idx >= lo) & (idx <= hi)).to(torch.float32))
-  return out[0] * out[1]

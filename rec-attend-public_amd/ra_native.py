@@ -81,6 +81,7 @@ SIGNATURES = {
     'ra_remove_tiny_f32': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     'ra_eval_metrics_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     'ra_random_transform_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
 }
 
 _lib = None

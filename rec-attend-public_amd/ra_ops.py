@@ -519,3 +519,12 @@ def random_transform(x, padding, off_y, off_x, flip_v=False, flip_h=False, trans
                                          int(bool(flip_v)), int(bool(flip_h)), int(bool(transpose)),
                                          ptr(out), rn.stream_ptr()), 'ra_random_transform_f32')
   return out
+
+
+def weighted_sum(w, y, out):
+  """out[b] = sum_t w[b,t] * y[b,t] for y [B,T,H,W] (box_model.py:487-499)."""
+  w = w.contiguous()
+  _need_cuda(w, y, out)
+  B, T, H, W = y.shape
+  check(rn.lib().ra_weighted_sum_f32(ptr(w), ptr(y), B, T, H * W, ptr(out), rn.stream_ptr()),
+        'ra_weighted_sum_f32')
