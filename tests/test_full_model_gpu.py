@@ -74,6 +74,28 @@ def test_cityscapes_arch(cuda):
   _check(ora.make_opt('cityscapes', 64, 128, 2), 1, 51, use_graph=True)
 
 
+def test_cfg3_kitti_native_size(cuda):
+  """BASELINE.json configs[2] at the size the reference feeds the model (KITTI images
+  are resized to 128x448, T=20): parity at B=2, then the configured B=16 (more images than the
+  16-workgroup controller takes: the single-workgroup controller path) row-independent of it."""
+  import full_model
+  opt = ora.make_opt('kitti', 128, 448, 20)
+  out, ref = _check(opt, 2, 61, use_graph=True)
+  P = ora.random_params(opt, 61)
+  x, d_in, y_in = _inputs(opt, 2, 62)
+  rep = lambda a: np.concatenate([a] * 8)
+  m = full_model.get_model(opt).load_weights(P)
+  y16 = m.run('y_out', {'x': rep(x), 'd_in': rep(d_in), 'y_in': rep(y_in), 'phase_train': False}, as_numpy=True)
+  assert y16.shape == (16, 20, 128, 448)
+  assert np.abs(y16[:2] - out['y_out']).max() < 1e-4 and np.abs(y16[14:] - out['y_out']).max() < 1e-4
+
+
+def test_cfg5_cityscapes_native_size(cuda):
+  """BASELINE.json configs[4] at the model's native 256x512, T=20 (9 semantic classes, 21 input
+  channels, skip connections, dynamic_var), one image against the oracle."""
+  _check(ora.make_opt('cityscapes', 256, 512, 20), 1, 71, use_graph=True)
+
+
 def test_weights_reload_invalidates_packing(cuda):
   import full_model
   opt = ora.make_opt('cvppp', 64, 64, 2)
