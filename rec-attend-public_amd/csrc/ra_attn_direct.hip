@@ -70,105 +70,103 @@ __device__ inline Axis make_axis(const float *rec, int axis, int L, int F) {
   return A;
 }
 
-constexpr int kColPass = 512;  // image columns per pass of the extract kernel
+constexpr int kColPass = 256;  // image columns per pass of the extract kernel (one per thread)
 
-// patch[b,j,i,4cg..] = gamma * sum_l sum_w fy(l,j) X[b,l,w,4cg..] fx(w,i); workgroup = (tap j, cg, b)
+// patch[b,j,i,4cg..] = gamma * sum_l sum_w fy(l,j) X[b,l,w,4cg..] fx(w,i)
+// Workgroup = (TJ consecutive taps j, channel group cg, image b); thread = image column.
+// Stage 1: every thread streams its column over the union of the TJ taps' row bands (adjacent taps
+// share most of their rows: one load feeds TJ accumulators) with 16 independent 16-byte loads in
+// flight — the kernel is bounded by its dependent load chain, not by bytes.  Stage 2: the TJ x Fw
+// outputs contract the column sums with fx through LDS.
+template <int TJ>
 __global__ __launch_bounds__(256) void extract_direct_kernel(const float *img, int Ci, int chan0,
                                                               const float *canvas, int canvas_chan,
                                                               const float *attn, int H, int W, int Fh,
                                                               int Fw, int Cp, int use_gamma,
                                                               float *patch) {
-  __shared__ f32x4 tl[4][kColPass];
-  __shared__ float fyw[256];
-  __shared__ f32x4 part[256];
-  const int t = threadIdx.x, j = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  __shared__ f32x4 tl[TJ][kColPass];
+  __shared__ float fyw[TJ][256];
+  const int t = threadIdx.x, j0 = blockIdx.x * TJ, cg = blockIdx.y, b = blockIdx.z;
   const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
   const Axis Ay = make_axis(rec, 0, H, Fh), Ax = make_axis(rec, 1, W, Fw);
   int l0, l1, w0, w1, tmp;
-  Ay.band(j, l0, l1);
+  Ay.band(j0, l0, tmp);
+  Ay.band(j0 + TJ - 1, tmp, l1);  // tap centres are monotone in j: the union is one interval
+  if (l1 < l0) l1 = l0;
   Ax.band(0, w0, tmp);
   Ax.band(Fw - 1, tmp, w1);
   const float *imb = img + (size_t)b * H * W * Ci + chan0 + 4 * cg;
   const bool use_canvas = canvas != nullptr && (canvas_chan >= chan0 + 4 * cg) && (canvas_chan < chan0 + 4 * cg + 4);
   const int cslot = canvas_chan - (chan0 + 4 * cg);
   const float *cvb = canvas ? canvas + (size_t)b * H * W : nullptr;
-  const int lane = t & 63, rph = t >> 6;
 
-  // stage-2 ownership: output i = t % Fw, k-part = t / Fw  (Fw * nparts <= 256)
-  const int nparts = 256 / Fw;
-  const int oi = t % Fw, op = t / Fw;
+  // stage-2 ownership: output (tap tj2, column i) for t < TJ * Fw
+  const int tj2 = t / Fw, oi = t - tj2 * Fw;
+  const bool owner = t < TJ * Fw;
   int bi_lo = 0, bi_hi = 0;
-  if (op < nparts) Ax.band(oi, bi_lo, bi_hi);
+  if (owner) Ax.band(oi, bi_lo, bi_hi);
   f32x4 P = f32x4{0, 0, 0, 0};
 
   for (int wp = w0; wp < w1; wp += kColPass) {
     const int wend = (wp + kColPass < w1) ? wp + kColPass : w1;
-    const int ncol = wend - wp;
-    // zero the per-phase column sums
-    for (int e = t; e < 4 * kColPass; e += 256) tl[e / kColPass][e % kColPass] = f32x4{0, 0, 0, 0};
-    __syncthreads();
+    const int w = wp + t;
+    const bool col_ok = w < wend;
+    f32x4 acc[TJ];
+#pragma unroll
+    for (int k = 0; k < TJ; ++k) acc[k] = f32x4{0, 0, 0, 0};
     for (int lr = l0; lr < l1; lr += 256) {  // rows in chunks of 256 (weights staged in LDS)
       const int nrow = (l1 - lr) < 256 ? (l1 - lr) : 256;
-      if (t < nrow) fyw[t] = Ay.w((float)(lr + t), j);
+      __syncthreads();  // previous chunk's weights fully consumed
+      if (t < nrow) {
+#pragma unroll
+        for (int k = 0; k < TJ; ++k) {
+          int a, c;
+          Ay.band(j0 + k, a, c);
+          const int l = lr + t;
+          fyw[k][t] = (l >= a && l < c) ? Ay.w((float)l, j0 + k) : 0.0f;  // outside tap k's own band
+        }
+      }
       __syncthreads();
-      // each thread: columns lane + 64*c (c < NCC), rows rph + 4*r; all NCC x U loads of a row
-      // batch are issued before the first FMA (the kernel is latency-, not bandwidth-bound)
-      constexpr int NCC = kColPass / 64, U = 2;
-      f32x4 acc[NCC];
+      constexpr int U = 16;
+      for (int r0 = 0; r0 < nrow; r0 += U) {
+        f32x4 xv[U];
+        float cv[U];
 #pragma unroll
-      for (int c = 0; c < NCC; ++c) acc[c] = f32x4{0, 0, 0, 0};
-      for (int r0 = rph; r0 < nrow; r0 += 4 * U) {
-        f32x4 xv[U][NCC];
-        float cv[U][NCC];
+        for (int u = 0; u < U; ++u) {
+          const bool ok = col_ok & (r0 + u < nrow);
+          const int rr = ok ? r0 + u : 0, ww = ok ? w : wp;
+          xv[u] = *reinterpret_cast<const f32x4 *>(imb + ((size_t)(lr + rr) * W + ww) * Ci);
+          cv[u] = use_canvas ? cvb[(size_t)(lr + rr) * W + ww] : 0.0f;
+        }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int c = 0; c < NCC; ++c) {
-            const int r = r0 + 4 * u, w = wp + 64 * c + lane;
-            const bool ok = (r < nrow) & (w < wend);
-            const int rr = ok ? r : 0, ww = ok ? w : wp;
-            xv[u][c] = *reinterpret_cast<const f32x4 *>(imb + ((size_t)(lr + rr) * W + ww) * Ci);
-            cv[u][c] = use_canvas ? cvb[(size_t)(lr + rr) * W + ww] : 0.0f;
-          }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int c = 0; c < NCC; ++c) {
-            const int r = r0 + 4 * u, w = wp + 64 * c + lane;
-            if ((r < nrow) & (w < wend)) {
-              f32x4 x = xv[u][c];
-              if (use_canvas) {
-                x.x = cslot == 0 ? cv[u][c] : x.x;
-                x.y = cslot == 1 ? cv[u][c] : x.y;
-                x.z = cslot == 2 ? cv[u][c] : x.z;
-                x.w = cslot == 3 ? cv[u][c] : x.w;
-              }
-              acc[c] += fyw[r] * x;
+        for (int u = 0; u < U; ++u) {
+          if (col_ok & (r0 + u < nrow)) {
+            f32x4 x = xv[u];
+            if (use_canvas) {
+              x.x = cslot == 0 ? cv[u] : x.x;
+              x.y = cslot == 1 ? cv[u] : x.y;
+              x.z = cslot == 2 ? cv[u] : x.z;
+              x.w = cslot == 3 ? cv[u] : x.w;
             }
-          }
-      }
 #pragma unroll
-      for (int c = 0; c < NCC; ++c)
-        if (wp + 64 * c + lane < wend) tl[rph][64 * c + lane] += acc[c];
-      __syncthreads();
-    }
-    // stage 2: P[i] += sum_{w in pass and band(i)} (sum_ph tl[ph][w]) * fx(w, i)
-    if (op < nparts) {
-      const int a = bi_lo > wp ? bi_lo : wp, c = bi_hi < wend ? bi_hi : wend;
-      for (int w = a + op; w < c; w += nparts) {
-        const f32x4 T = tl[0][w - wp] + tl[1][w - wp] + tl[2][w - wp] + tl[3][w - wp];
-        P += Ax.w((float)w, oi) * T;
+            for (int k = 0; k < TJ; ++k) acc[k] += fyw[k][r0 + u] * x;
+          }
+        }
       }
     }
+    __syncthreads();  // previous pass's stage 2 done with tl
+#pragma unroll
+    for (int k = 0; k < TJ; ++k) tl[k][t] = acc[k];
     __syncthreads();
+    // stage 2: P[tj2, oi] += sum_{w in pass and band(oi)} tl[tj2][w] * fx(w, oi)
+    if (owner) {
+      const int a = bi_lo > wp ? bi_lo : wp, c = bi_hi < wend ? bi_hi : wend;
+      for (int ww = a; ww < c; ++ww) P += Ax.w((float)ww, oi) * tl[tj2][ww - wp];
+    }
   }
-  part[t] = P;
-  __syncthreads();
-  if (t < Fw) {
-    f32x4 s = f32x4{0, 0, 0, 0};
-    for (int p = 0; p < nparts; ++p) s += part[p * Fw + t];
+  if (owner && j0 + tj2 < Fh) {
     const float gamma = use_gamma ? rec[6] : 1.0f;
-    *reinterpret_cast<f32x4 *>(patch + (((size_t)b * Fh + j) * Fw + t) * Cp + 4 * cg) = gamma * s;
+    *reinterpret_cast<f32x4 *>(patch + (((size_t)b * Fh + j0 + tj2) * Fw + oi) * Cp + 4 * cg) = gamma * P;
   }
 }
 
@@ -314,8 +312,12 @@ extern "C" int ra_extract_direct_f32(const float *img, int Ci, int chan0, const 
     return fail(RA_E_INVALID, "ra_extract_direct_f32: bad argument");
   if (Ci % 4 || Cp % 4 || chan0 % 4 || chan0 + Cp > Ci || Cp <= 0 || Fw > 256)
     return fail(RA_E_SHAPE, "ra_extract_direct_f32: Ci=%d chan0=%d Cp=%d Fw=%d", Ci, chan0, Cp, Fw);
-  hipLaunchKernelGGL(attnd::extract_direct_kernel, dim3(Fh, Cp / 4, B), dim3(256), 0, as_stream(stream), img,
-                     Ci, chan0, canvas, canvas_chan, attn_rec, H, W, Fh, Fw, Cp, use_gamma, patch);
+  if (Fh % 4 == 0 && 4 * Fw <= 256)
+    hipLaunchKernelGGL(attnd::extract_direct_kernel<4>, dim3(Fh / 4, Cp / 4, B), dim3(256), 0, as_stream(stream),
+                       img, Ci, chan0, canvas, canvas_chan, attn_rec, H, W, Fh, Fw, Cp, use_gamma, patch);
+  else
+    hipLaunchKernelGGL(attnd::extract_direct_kernel<1>, dim3(Fh, Cp / 4, B), dim3(256), 0, as_stream(stream),
+                       img, Ci, chan0, canvas, canvas_chan, attn_rec, H, W, Fh, Fw, Cp, use_gamma, patch);
   return launch_status("ra_extract_direct_f32");
 }
 

@@ -25,7 +25,6 @@ struct PArgs {
   const float *plane;  // optional [B,Hs,Ws] plane replacing input channel plane_chan (the canvas)
   int plane_chan;
   int bytes0, bytes_p;  // tensor sizes for the buffer descriptors (each < 2 GiB)
-  int ablate;  // tuning aid (RA_PAIR_ABLATE): 1 no stores, 2 no input loads, 4 no phase A, 8 no phase B MFMA
 };
 
 template <int CINA, int CMID, int NCB, int GX, int GYB>
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
 #pragma unroll
       for (int cg = 0; cg < G::NCGA; ++cg) {
         v[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok && !(a.ablate & 2)) v[cg] = *reinterpret_cast<const f32x4 *>(base + (ys * a.Ws + xs) * a.C0 + 4 * cg);
+        if (ok) v[cg] = *reinterpret_cast<const f32x4 *>(base + (ys * a.Ws + xs) * a.C0 + 4 * cg);
       }
       if (a.plane && ok) {
         const float pv = a.plane[(size_t)(b * a.Hs + sy0 + ys) * a.Ws + sx0 + xs];
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
   __syncthreads();
 
   // ---------------- phase A: conv A over the B tile + halo, result -> LDS ----------------
-  if (!(a.ablate & 4)) {
+  {
     float scA[NCA], shA[NCA];
 #pragma unroll
     for (int n = 0; n < NCA; ++n) {
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
       for (int n = 0; n < NCB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int a_base = ((wave * 2 * GYB + dy) * G::AW + 2 * q + dx) * CMID + ksub * G::NCGB;
     float bregB[G::KSB][NCB];
-    for (int ch = 0; ch < ((a.ablate & 8) ? 0 : G::NCHB); ++ch) {
+    for (int ch = 0; ch < G::NCHB; ++ch) {
       {
         const float *wrow = a.wpB + ((size_t)ch * G::KSB * 4 + ksub) * a.CoutBP + co_lane;
 #pragma unroll
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
         }
         if (opool == 2) {
           const float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-          if (co_ok && (row0 >> 1) < a.Ho && (col0 >> 1) < a.Wo && !(a.ablate & 1))
+          if (co_ok && (row0 >> 1) < a.Ho && (col0 >> 1) < a.Wo)
             a.y[obase + (gy * a.Wo + 4 * gx) * a.CoutB] = o;
         } else {
 #pragma unroll
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int Y = fy0 + e_rr[i], X = fx0 + e_cc[i];
-      const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W) & !(a.ablate & 2);
+      const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
       const int pix = (fb * a.H + Y) * a.W + X;
 #pragma unroll
       for (int cg = 0; cg < NCGA; ++cg)
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
         const float u1 = fmaxf(t1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x128, 0xf, 0xf, true)));
         const float ov = p ? u1 : u0;  // lane (p, co) stores pooled pixel 2*qo + p
         const int prow = prow0 + (g >> 1), pcol = pcol0 + 8 * (g & 1);
-        if ((co < a.CoutB) & (prow < a.Ho) & (pcol < a.Wo) & !(a.ablate & 1))
+        if ((co < a.CoutB) & (prow < a.Ho) & (pcol < a.Wo))
           a.y[((size_t)(b * a.Ho + prow) * a.Wo + pcol) * a.CoutB + co] = ov;
       }
     }
@@ -636,14 +635,6 @@ extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws
   a.plane = plane;
   a.plane_chan = plane_chan;
   if (plane && (plane_chan < 0 || plane_chan >= Cin)) return fail(RA_E_INVALID, "ra_conv_pair_f32: plane channel");
-  {
-    static int abl = -1;
-    if (abl < 0) {
-      const char *e = getenv("RA_PAIR_ABLATE");
-      abl = e ? atoi(e) : 0;
-    }
-    a.ablate = abl;
-  }
   hipStream_t st = as_stream(stream);
   const size_t bytes0 = (size_t)B * Hs * Ws * Cin * 4;
   a.bytes0 = (int)bytes0;
