@@ -214,6 +214,16 @@ __global__ __launch_bounds__(256) void paste_direct_kernel(const float *patch, i
     wend = (w1 + 3) & ~3;
     wend = wend < W ? wend : W;
   }
+  const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(y_out) & 15) == 0) && ((y_stride_b & 3) == 0) &&
+                   (!canvas || (reinterpret_cast<uintptr_t>(canvas) & 15) == 0);
+  const int ngrp = (wend - wbeg + 3) >> 2;  // float4 column groups of the window
+  // the canvas values of this thread's first item are fetched before the V phase, so that the two
+  // global round trips of the kernel (patch, canvas) overlap
+  f32x4 cv_pre = f32x4{0, 0, 0, 0};
+  if (MODE == 0 && canvas && vec && t < nrow * ngrp) {
+    const int r = t / ngrp, w4 = wbeg + 4 * (t - r * ngrp);
+    cv_pre = *reinterpret_cast<const f32x4 *>(canvas + ((size_t)b * H + l0 + r) * W + w4);
+  }
   for (int e = t; e < nrow * Fw; e += blockDim.x) {
     const int r = e / Fw, i = e - r * Fw, l = l0 + r;
     int jlo, jhi;
@@ -242,9 +252,6 @@ __global__ __launch_bounds__(256) void paste_direct_kernel(const float *patch, i
   __syncthreads();
   const float gain = (MODE == 0) ? __expf(rec[8]) : rec[7];
   const float y_dead = sigmoidf(beta);
-  const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(y_out) & 15) == 0) && ((y_stride_b & 3) == 0) &&
-                   (!canvas || (reinterpret_cast<uintptr_t>(canvas) & 15) == 0);
-  const int ngrp = (wend - wbeg + 3) >> 2;  // float4 column groups of the window
   for (int e = t; e < nrow * ngrp; e += blockDim.x) {
     const int r = e / ngrp, w4 = wbeg + 4 * (e - r * ngrp), l = l0 + r;
     int jlo, jhi;
@@ -257,29 +264,35 @@ __global__ __launch_bounds__(256) void paste_direct_kernel(const float *patch, i
     const float *Vr = V + r * Fw;
     f32x4 cv = f32x4{0, 0, 0, 0};
     if (MODE == 0) {
-      if (crow && vec) cv = *reinterpret_cast<const f32x4 *>(crow + w4);
+      if (crow && vec) cv = (e == t) ? cv_pre : *reinterpret_cast<const f32x4 *>(crow + w4);
       else
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (w4 + k < W) cv[k] = crow ? crow[w4 + k] : (prow ? prow[(size_t)(w4 + k) * Ci] : 0.0f);
     }
     f32x4 y;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int w = w4 + k;
-      float v = y_dead;
+    {
+      // one tap loop for the 4 pixels (tap ranges are monotone in w: take the union; the extra
+      // terms are below e^-30 of the peak) so that the four exponentials per tap are independent
+      f32x4 sacc = f32x4{0, 0, 0, 0};
+      int ilo = 0, ihi = 0;
       if (row_live) {
-        int ilo, ihi;
-        Ax.taps(w, ilo, ihi);
-        if (ilo < ihi) {
-          float s = 0.0f;
-          for (int i = ilo; i < ihi; ++i) s += Vr[i] * Ax.w((float)w, i);
-          v = sigmoidf(gain * s + beta);
+        int t0, t1;
+        Ax.taps(w4, ilo, t0);
+        Ax.taps(w4 + 3, t1, ihi);
+        for (int i = ilo; i < ihi; ++i) {
+          const float vi = Vr[i];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sacc[k] += vi * Ax.w((float)(w4 + k), i);
         }
       }
-      if (MODE == 0 && disable_overwrite) v *= (1.0f - cv[k]);
-      y[k] = v;
-      cv[k] = fmaxf(cv[k], v);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = (row_live && ilo < ihi) ? sigmoidf(gain * sacc[k] + beta) : y_dead;
+        if (MODE == 0 && disable_overwrite) v *= (1.0f - cv[k]);
+        y[k] = v;
+        cv[k] = fmaxf(cv[k], v);
+      }
     }
     if (vec) {
       *reinterpret_cast<f32x4 *>(yrow + w4) = y;
