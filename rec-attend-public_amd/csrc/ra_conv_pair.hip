@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
   typedef typename vec_of<G::NCGAC>::type avecA;
   typedef typename vec_of<G::NCGBC>::type avecB;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: group bookkeeping on the SALU
   const int m = lane & 15, ksub = lane >> 4;
   const int q = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
   const int co_lane = lane & 15, qo = lane >> 4;
@@ -169,21 +170,30 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
                                                                  acc[j][n], 0, 0, 0);
         }
       }
-      // A epilogue -> tmid (zero outside the image: it is B's SAME padding)
+      // A epilogue -> tmid (zero outside the image: it is B's SAME padding).  Tiles whose whole
+      // A region lies inside the image (uniform test) skip the per-value bounds arithmetic.
+      const bool interior = (ty0 >= 1) & (ty0 - 1 + G::AH <= a.H) & (tx0 >= 1) & (tx0 + G::TWB + 1 <= a.W);
+      const float loA = a.reluA ? 0.f : -__builtin_inff();
 #pragma unroll
       for (int j = 0; j < G::RA; ++j) {
         const bool live = (wave + 4 * (rd * G::RA + j)) < G::NGA;
 #pragma unroll
         for (int n = 0; n < NCA; ++n) {
           const int co = 16 * n + co_lane;
+          float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int ar = 2 * gr[j] + (r >> 1), ac = 8 * gc[j] + 2 * qo + (r & 1);
-            const int Y = ty0 - 1 + ar, X = tx0 - 1 + ac;
-            float v = acc[j][n][r] * scA[n] + shA[n];
-            if (a.reluA) v = fmaxf(v, 0.f);
-            if (!((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W))) v = 0.f;
-            if (live && co < CMID) tmid[(ar * G::AW + ac) * CMID + (co & 3) * G::NCGB + (co >> 2)] = v;
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[j][n][r] * scA[n] + shA[n], loA);
+          if (!interior) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int Y = ty0 - 1 + 2 * gr[j] + (r >> 1), X = tx0 - 1 + 8 * gc[j] + 2 * qo + (r & 1);
+              o[r] = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o[r] : 0.f;
+            }
+          }
+          if (live && co < CMID) {
+            float *dst = tmid + ((2 * gr[j]) * G::AW + 8 * gc[j] + 2 * qo) * CMID + (co & 3) * G::NCGB + (co >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((r >> 1) * G::AW + (r & 1)) * CMID] = o[r];
           }
         }
       }
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
       }
     }
     const int opool = a.poolB;
+    const float loB = a.reluB ? 0.f : -__builtin_inff();
     const int wrow0 = ty0 + wave * 2 * GYB, lcol0 = tx0 + 2 * qo;
 #pragma unroll
     for (int n = 0; n < NCB; ++n) {
@@ -242,10 +253,7 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
         const int row0 = wrow0 + 2 * gy, col0 = lcol0 + 8 * gx;
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[g][n][r] * sc + sh;
-          if (a.reluB) v[r] = fmaxf(v[r], 0.f);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[g][n][r] * sc + sh, loB);
         if (opool == 2) {
           const float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
           if (co_ok && (row0 >> 1) < a.Ho && (col0 >> 1) < a.Wo)
