@@ -288,12 +288,13 @@ int ra_max_pool_f32(const float *x, int B, int H, int W, int C, int ratio, float
  * ra_gt_box_f32 — modellib.get_gt_box (modellib.py:663-701) with center_shift_ratio 0:
  *   params [B,T,8] = top_left (y,x), bot_right (y,x) as returned by the reference, then the
  *   padded rectangle (tl_y, tl_x, br_y, br_x) the mask is filled with; box (nullable)
- *   [B,T,H,W] = the filled rectangle mask.
+ *   [B,T,H,W] = the filled rectangle mask.  ws: ra_gt_box_workspace_floats(B, T) device floats.
  * ra_segm_match_f32 — modellib.f_segm_match (modellib.py:382-415): mask with s_gt, quantise
  *   to 1e-6, + 1e-5, Hungarian (device), mask again.  status: int[B] as ra_hungarian_f32_dev.
  * ra_loss_stats_f32 — every scalar of full_model.py:941-1081 for box_loss_fn = 'iou' and
  *   segm_loss_fn 0 = 'iou' / 1 = 'wt_cov': out[RA_STAT_COUNT] indexed by RA_STAT_*.
- *   sum_gt [B,T] = per-instance sums of y_gt (f_coverage_weight, modellib.py:277-289).
+ *   sum_gt [B,T] = per-instance sums of y_gt (f_coverage_weight, modellib.py:277-289);
+ *   ws: ra_loss_stats_workspace_floats(B) device floats.
  * ---------------------------------------------------------------------------------- */
 enum {
   RA_STAT_LOSS = 0, RA_STAT_BOX_LOSS, RA_STAT_SEGM_LOSS, RA_STAT_CONF_LOSS, RA_STAT_IOU_SOFT,
@@ -305,16 +306,19 @@ size_t ra_pair_stats_workspace_floats(int B, int HW);
 int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
                       size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
                       float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream);
+size_t ra_gt_box_workspace_floats(int B, int T);
 int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, float padding_ratio,
-                  float min_padding, float *params, float *box, void *stream);
+                  float min_padding, float *ws, size_t ws_floats, float *params, float *box,
+                  void *stream);
 size_t ra_segm_match_workspace_bytes(int B, int N);
 int ra_segm_match_f32(const float *iou, const float *s_gt, int B, int N, void *ws, size_t ws_bytes,
                       float *match, int *status, void *stream);
 int ra_loss_stats_f32(const float *iou_soft, const float *iou_hard, const float *dice,
                       const float *match_real, const float *iou_box, const float *match_box,
                       const float *s_out, const float *s_gt, const float *sum_gt, int B, int T,
-                      int fixed_order, int segm_loss_fn, float loss_mix_ratio, float *out,
-                      void *stream);
+                      int fixed_order, int segm_loss_fn, float loss_mix_ratio, float *ws,
+                      size_t ws_floats, float *out, void *stream);
+size_t ra_loss_stats_workspace_floats(int B);
 
 /* ------------------------------------------------------------------------------------
  * Evaluation post-processing and metrics (utils/postprocess.py, analysis.py:314-760).

@@ -178,14 +178,18 @@ __global__ __launch_bounds__(256) void pair_stats_finish_kernel(const float *tot
 // ---- K9: get_gt_box (modellib.py:663-701) ----
 // params record per (b, t): [0..1] top_left (y, x), [2..3] bot_right after the empty-instance
 // fix-up, [4..7] the padded rectangle the mask is filled with (tl_y, tl_x, br_y, br_x)
-__global__ __launch_bounds__(256) void gt_box_reduce_kernel(const float *y_gt, int H, int W, float pad_ratio,
-                                                             float min_pad, float *params) {
+constexpr int kGtSplit = 8;  // workgroups per instance in the min/max/sum reduction
+
+// partial record per (instance, slice): min_y, min_x, max_y, max_x, sum
+__global__ __launch_bounds__(256) void gt_box_reduce_kernel(const float *y_gt, int H, int W, float *partial) {
   __shared__ float red[5][256];
-  const int inst = blockIdx.x, tid = threadIdx.x;
+  const int inst = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
   const float *y = y_gt + (size_t)inst * H * W;
   const float big = (float)(H * W);
+  const int per = ((H * W / 4 + kGtSplit - 1) / kGtSplit) * 4;  // pixels per slice, multiple of 4
+  const int e0 = slice * per, e1 = (e0 + per < H * W) ? e0 + per : H * W;
   float mny = 3.0e38f, mnx = 3.0e38f, mxy = -3.0e38f, mxx = -3.0e38f, sum = 0.f;
-  for (int e = tid * 4; e < H * W; e += 256 * 4) {
+  for (int e = e0 + tid * 4; e < e1; e += 256 * 4) {
     const f32x4 v = *reinterpret_cast<const f32x4 *>(y + e);  // H*W % 4 == 0 checked by the host
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -214,20 +218,34 @@ __global__ __launch_bounds__(256) void gt_box_reduce_kernel(const float *y_gt, i
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    float tl[2] = {red[0][0], red[1][0]}, br[2] = {red[2][0], red[3][0]};
-    const float nz = red[4][0] > 0.f ? 1.f : 0.f;
-    float *p = params + (size_t)inst * 8;
-    for (int k = 0; k < 2; ++k) {
-      const float size = br[k] - tl[k];
-      const float pad = fmaxf(pad_ratio * size, min_pad);
-      tl[k] -= pad;
-      br[k] += pad;
-      p[4 + k] = tl[k];
-      p[6 + k] = br[k];
-      p[k] = tl[k] * nz;
-      p[2 + k] = nz * br[k] + (1.f - nz) * (2.f * min_pad);
-    }
+  if (tid < 5) partial[((size_t)inst * kGtSplit + slice) * 5 + tid] = red[tid][0];
+}
+
+// one thread per instance: combine the slices in order, pad, write the params record
+__global__ void gt_box_finish_kernel(const float *partial, int ninst, float pad_ratio, float min_pad,
+                                     float *params) {
+  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= ninst) return;
+  const float *q = partial + (size_t)inst * kGtSplit * 5;
+  float tl[2] = {q[0], q[1]}, br[2] = {q[2], q[3]}, sum = q[4];
+  for (int s = 1; s < kGtSplit; ++s) {
+    tl[0] = fminf(tl[0], q[s * 5 + 0]);
+    tl[1] = fminf(tl[1], q[s * 5 + 1]);
+    br[0] = fmaxf(br[0], q[s * 5 + 2]);
+    br[1] = fmaxf(br[1], q[s * 5 + 3]);
+    sum += q[s * 5 + 4];
+  }
+  const float nz = sum > 0.f ? 1.f : 0.f;
+  float *p = params + (size_t)inst * 8;
+  for (int k = 0; k < 2; ++k) {
+    const float size = br[k] - tl[k];
+    const float pad = fmaxf(pad_ratio * size, min_pad);
+    tl[k] -= pad;
+    br[k] += pad;
+    p[4 + k] = tl[k];
+    p[6 + k] = br[k];
+    p[k] = tl[k] * nz;
+    p[2 + k] = nz * br[k] + (1.f - nz) * (2.f * min_pad);
   }
 }
 
@@ -264,109 +282,125 @@ __global__ void match_post_kernel(float *match, const float *s_gt, int N, int to
   match[e] = match[e] * s_gt[b * N + j] * s_gt[b * N + i];
 }
 
-__device__ inline float block_sum(float v, float *scratch) {
-  const int tid = threadIdx.x;
-  scratch[tid] = v;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) scratch[tid] += scratch[tid + s];
-    __syncthreads();
-  }
-  const float r = scratch[0];
-  __syncthreads();
-  return r;
-}
-
-// All scalar statistics in one workgroup; thread t owns images t, t+256, ... (B is small).
-// out: see RA_STAT_* in recattend.h.
-__global__ __launch_bounds__(256) void loss_stats_kernel(
+// Scalar statistics, stage 1: one workgroup per image, thread t owns output row t and ground-truth
+// column t of the T x T matrices; the 12 per-image terms go to partial[b][12].
+constexpr int kNTerms = 12;
+__global__ __launch_bounds__(64) void loss_stats_image_kernel(
     const float *iou_soft, const float *iou_hard, const float *dice, const float *match_real,
     const float *iou_box, const float *match_box, const float *s_out, const float *s_gt,
-    const float *sum_gt, int B, int T, int fixed_order, int segm_fn, float mix, float *out) {
-  __shared__ float scratch[256];
-  float v_iou_soft = 0, v_iou_box = 0, v_wt_soft = 0, v_unwt_soft = 0, v_wt_hard = 0, v_unwt_hard = 0,
-        v_iou_hard = 0, v_dice = 0, v_conf = 0, v_cacc = 0, v_dic = 0, v_dica = 0;
-  for (int b = threadIdx.x; b < B; b += 256) {
-    const float *sg = s_gt + (size_t)b * T, *so = s_out + (size_t)b * T;
-    const float *is = iou_soft + (size_t)b * T * T, *ih = iou_hard + (size_t)b * T * T;
-    const float *dc = dice + (size_t)b * T * T, *mr = match_real + (size_t)b * T * T;
-    const float *ib = iou_box + (size_t)b * T * T, *mb = match_box + (size_t)b * T * T;
-    // identity match (modellib.py:28-37) when fixed_order, else the Hungarian matches
-    float cnt = 0.f, cnt_box = 0.f, m_is = 0.f, m_ib = 0.f, m_ih = 0.f, m_dc = 0.f;
-    for (int i = 0; i < T; ++i)
-      for (int j = 0; j < T; ++j) {
-        const float ident = (i == j) ? sg[i] * sg[j] : 0.f;
-        const float m = fixed_order ? ident : mr[i * T + j];
-        const float mbx = fixed_order ? ident : mb[i * T + j];
-        cnt += m;
-        cnt_box += mbx;
-        m_is += is[i * T + j] * m;
-        m_ib += ib[i * T + j] * mbx;
-        m_ih += ih[i * T + j] * mr[i * T + j];  // hard statistics always use the real match (:1062)
-        m_dc += dc[i * T + j] * mr[i * T + j];
-      }
-    cnt = fmaxf(1.f, cnt);
-    cnt_box = fmaxf(1.f, cnt_box);
-    v_iou_soft += m_is / cnt;
-    v_iou_box += m_ib / cnt_box;
-    v_iou_hard += m_ih / cnt;
-    v_dice += m_dc / cnt;
-    // coverage: max over the output axis per GT instance (modellib.py:265-313)
-    float tot_gt = 0.f;
-    for (int j = 0; j < T; ++j) tot_gt += sum_gt[(size_t)b * T + j];
-    float cs = 0.f, ch = 0.f, ws = 0.f, wh = 0.f;
-    for (int j = 0; j < T; ++j) {
-      float mxs = -3.0e38f, mxh = -3.0e38f;
-      for (int i = 0; i < T; ++i) {
-        mxs = fmaxf(mxs, is[i * T + j]);
-        mxh = fmaxf(mxh, ih[i * T + j]);
-      }
-      const float g = sum_gt[(size_t)b * T + j];
-      const float wt = g / (tot_gt + (g == 0.f ? 1.f : 0.f));
-      cs += mxs;
-      ch += mxh;
-      ws += mxs * wt;
-      wh += mxh * wt;
+    const float *sum_gt, int T, int fixed_order, float *partial) {
+  __shared__ float red[16][kMaxT];
+  __shared__ float cmin_s[kMaxT], cmax_s[kMaxT];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float *sg = s_gt + (size_t)b * T, *so = s_out + (size_t)b * T;
+  const float *is = iou_soft + (size_t)b * T * T, *ih = iou_hard + (size_t)b * T * T;
+  const float *dc = dice + (size_t)b * T * T, *mr = match_real + (size_t)b * T * T;
+  const float *ib = iou_box + (size_t)b * T * T, *mb = match_box + (size_t)b * T * T;
+  if (t == 0) {  // cumulative min from the start / max to the end (modellib.py:40-68)
+    float run = 3.0e38f;
+    for (int i = 0; i < T; ++i) {
+      run = fminf(run, so[i]);
+      cmin_s[i] = run;
     }
-    v_wt_soft += ws;
-    v_wt_hard += wh;
-    v_unwt_soft += cs / cnt;
-    v_unwt_hard += ch / cnt;
-    // confidence loss with cumulative min / max (modellib.py:316-339,430-437)
-    float cmax[kMaxT];
-    float run = -3.0e38f;
+    run = -3.0e38f;
     for (int i = T - 1; i >= 0; --i) {
       run = fmaxf(run, so[i]);
-      cmax[i] = run;
+      cmax_s[i] = run;
     }
-    float cmin = 3.0e38f, cout = 0.f, cgt = 0.f;
-    for (int i = 0; i < T; ++i) {
-      cmin = fminf(cmin, so[i]);
-      float msum = 0.f;
-      for (int j = 0; j < T; ++j)
-        msum += fixed_order ? ((i == j) ? sg[i] * sg[j] : 0.f) : mr[i * T + j];
-      v_conf += -msum * logf(cmin + 1e-5f) - (1.f - msum) * logf(1.f - cmax[i] + 1e-5f);
-      cout += so[i] > 0.5f ? 1.f : 0.f;
-      cgt += sg[i];
-    }
-    v_cacc += (cout == cgt) ? 1.f : 0.f;
-    v_dic += cout - cgt;
-    v_dica += fabsf(cout - cgt);
   }
-  const float nb = (float)B;
-  const float iou_soft_s = block_sum(v_iou_soft, scratch) / nb;
-  const float iou_box_s = block_sum(v_iou_box, scratch) / nb;
-  const float wt_soft = block_sum(v_wt_soft, scratch) / nb;
-  const float unwt_soft = block_sum(v_unwt_soft, scratch) / nb;
-  const float wt_hard = block_sum(v_wt_hard, scratch) / nb;
-  const float unwt_hard = block_sum(v_unwt_hard, scratch) / nb;
-  const float iou_hard_s = block_sum(v_iou_hard, scratch) / nb;
-  const float dice_s = block_sum(v_dice, scratch) / nb;
-  const float conf = block_sum(v_conf, scratch) / nb / (float)T;
-  const float cacc = block_sum(v_cacc, scratch) / nb;
-  const float dic = block_sum(v_dic, scratch) / nb;
-  const float dica = block_sum(v_dica, scratch) / nb;
-  if (threadIdx.x == 0) {
+  __syncthreads();
+  float v[16];
+  for (int k = 0; k < 16; ++k) v[k] = 0.f;
+  if (t < T) {
+    const int i = t;
+    float cnt = 0.f, cnt_box = 0.f, m_is = 0.f, m_ib = 0.f, m_ih = 0.f, m_dc = 0.f, msum = 0.f;
+    float mxs = -3.0e38f, mxh = -3.0e38f;
+    for (int j = 0; j < T; ++j) {
+      // identity match (modellib.py:28-37) when fixed_order, else the Hungarian matches
+      const float ident = (i == j) ? sg[i] * sg[j] : 0.f;
+      const float m = fixed_order ? ident : mr[i * T + j];
+      const float mbx = fixed_order ? ident : mb[i * T + j];
+      cnt += m;
+      cnt_box += mbx;
+      msum += m;
+      m_is += is[i * T + j] * m;
+      m_ib += ib[i * T + j] * mbx;
+      m_ih += ih[i * T + j] * mr[i * T + j];  // hard statistics always use the real match (:1062)
+      m_dc += dc[i * T + j] * mr[i * T + j];
+      mxs = fmaxf(mxs, is[j * T + i]);  // coverage of ground-truth instance i: max over outputs j
+      mxh = fmaxf(mxh, ih[j * T + i]);
+    }
+    v[0] = cnt;
+    v[1] = cnt_box;
+    v[2] = m_is;
+    v[3] = m_ib;
+    v[4] = m_ih;
+    v[5] = m_dc;
+    v[6] = mxs;
+    v[7] = mxh;
+    v[8] = sum_gt[(size_t)b * T + i];
+    // confidence loss with cumulative min / max (modellib.py:316-339,430-437)
+    v[9] = -msum * logf(cmin_s[i] + 1e-5f) - (1.f - msum) * logf(1.f - cmax_s[i] + 1e-5f);
+    v[10] = so[i] > 0.5f ? 1.f : 0.f;
+    v[11] = sg[i];
+  }
+  if (t < kMaxT)
+    for (int k = 0; k < 12; ++k) red[k][t] = v[k];
+  __syncthreads();
+  if (t == 0) {  // combine the T rows in order (T <= 32)
+    float cnt = 0, cnt_box = 0, m_is = 0, m_ib = 0, m_ih = 0, m_dc = 0, tot_gt = 0, conf = 0, cout = 0, cgt = 0;
+    for (int i = 0; i < T; ++i) {
+      cnt += red[0][i];
+      cnt_box += red[1][i];
+      m_is += red[2][i];
+      m_ib += red[3][i];
+      m_ih += red[4][i];
+      m_dc += red[5][i];
+      tot_gt += red[8][i];
+      conf += red[9][i];
+      cout += red[10][i];
+      cgt += red[11][i];
+    }
+    cnt = fmaxf(1.f, cnt);
+    cnt_box = fmaxf(1.f, cnt_box);
+    float cs = 0, ch = 0, ws = 0, wh = 0;  // coverage (modellib.py:265-313)
+    for (int j = 0; j < T; ++j) {
+      const float g = red[8][j];
+      const float wt = g / (tot_gt + (g == 0.f ? 1.f : 0.f));
+      cs += red[6][j];
+      ch += red[7][j];
+      ws += red[6][j] * wt;
+      wh += red[7][j] * wt;
+    }
+    float *o = partial + (size_t)b * kNTerms;
+    o[0] = m_is / cnt;      // matched soft IoU
+    o[1] = m_ib / cnt_box;  // matched box IoU
+    o[2] = ws;              // weighted coverage, soft
+    o[3] = cs / cnt;        // unweighted coverage, soft
+    o[4] = wh;
+    o[5] = ch / cnt;
+    o[6] = m_ih / cnt;
+    o[7] = m_dc / cnt;
+    o[8] = conf;
+    o[9] = (cout == cgt) ? 1.f : 0.f;
+    o[10] = cout - cgt;
+    o[11] = fabsf(cout - cgt);
+  }
+}
+
+// stage 2: mean over the batch (fixed order) and the losses.  out: RA_STAT_* in recattend.h.
+__global__ __launch_bounds__(64) void loss_stats_final_kernel(const float *partial, int B, int T, int segm_fn,
+                                                               float mix, float *out) {
+  __shared__ float tot[kNTerms];
+  const int t = threadIdx.x;
+  if (t < kNTerms) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += partial[(size_t)b * kNTerms + t];
+    tot[t] = s / (float)B;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const float iou_soft_s = tot[0], iou_box_s = tot[1], wt_soft = tot[2], conf = tot[8] / (float)T;
     const float box_loss = -iou_box_s;  // box_loss_fn 'iou' (full_model.py:965-966)
     const float segm_loss = segm_fn == 1 ? -wt_soft : -iou_soft_s;  // :1013-1016
     out[RA_STAT_LOSS] = box_loss + segm_loss + mix * conf;
@@ -376,14 +410,14 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(
     out[RA_STAT_IOU_SOFT] = iou_soft_s;
     out[RA_STAT_IOU_SOFT_BOX] = iou_box_s;
     out[RA_STAT_WT_COV_SOFT] = wt_soft;
-    out[RA_STAT_UNWT_COV_SOFT] = unwt_soft;
-    out[RA_STAT_IOU_HARD] = iou_hard_s;
-    out[RA_STAT_WT_COV_HARD] = wt_hard;
-    out[RA_STAT_UNWT_COV_HARD] = unwt_hard;
-    out[RA_STAT_DICE] = dice_s;
-    out[RA_STAT_COUNT_ACC] = cacc;
-    out[RA_STAT_DIC] = dic;
-    out[RA_STAT_DIC_ABS] = dica;
+    out[RA_STAT_UNWT_COV_SOFT] = tot[3];
+    out[RA_STAT_IOU_HARD] = tot[6];
+    out[RA_STAT_WT_COV_HARD] = tot[4];
+    out[RA_STAT_UNWT_COV_HARD] = tot[5];
+    out[RA_STAT_DICE] = tot[7];
+    out[RA_STAT_COUNT_ACC] = tot[9];
+    out[RA_STAT_DIC] = tot[10];
+    out[RA_STAT_DIC_ABS] = tot[11];
   }
 }
 
@@ -433,15 +467,25 @@ extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, i
   return launch_status("ra_pair_stats_f32");
 }
 
+extern "C" size_t ra_gt_box_workspace_floats(int B, int T) {
+  if (B <= 0 || T <= 0) return 0;
+  return (size_t)B * T * loss::kGtSplit * 5;
+}
+
 extern "C" int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, float padding_ratio,
-                             float min_padding, float *params, float *box, void *stream) {
-  if (!y_gt || !params || B <= 0 || T <= 0 || H <= 0 || W <= 0)
+                             float min_padding, float *ws, size_t ws_floats, float *params, float *box,
+                             void *stream) {
+  if (!y_gt || !params || !ws || B <= 0 || T <= 0 || H <= 0 || W <= 0)
     return fail(RA_E_INVALID, "ra_gt_box_f32: bad argument");
+  if (ws_floats < ra_gt_box_workspace_floats(B, T))
+    return fail(RA_E_WORKSPACE, "ra_gt_box_f32: workspace of %zu floats, need %zu", ws_floats,
+                ra_gt_box_workspace_floats(B, T));
   if ((H * W) % 4 || (reinterpret_cast<uintptr_t>(y_gt) & 15) || (box && (reinterpret_cast<uintptr_t>(box) & 15)))
     return fail(RA_E_SHAPE, "ra_gt_box_f32: H*W must be a multiple of 4 and the tensors 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(loss::gt_box_reduce_kernel, dim3(B * T), dim3(256), 0, st, y_gt, H, W, padding_ratio,
-                     min_padding, params);
+  hipLaunchKernelGGL(loss::gt_box_reduce_kernel, dim3(loss::kGtSplit, B * T), dim3(256), 0, st, y_gt, H, W, ws);
+  hipLaunchKernelGGL(loss::gt_box_finish_kernel, dim3(ceil_div(B * T, 64)), dim3(64), 0, st, ws, B * T,
+                     padding_ratio, min_padding, params);
   int rc = launch_status("ra_gt_box_f32");
   if (rc || !box) return rc;
   const int gx = ceil_div(H * W, 256 * 4 * 4);
@@ -478,18 +522,24 @@ extern "C" int ra_segm_match_f32(const float *iou, const float *s_gt, int B, int
   return launch_status("ra_segm_match_f32");
 }
 
+extern "C" size_t ra_loss_stats_workspace_floats(int B) { return B > 0 ? (size_t)B * loss::kNTerms : 0; }
+
 extern "C" int ra_loss_stats_f32(const float *iou_soft, const float *iou_hard, const float *dice,
                                  const float *match_real, const float *iou_box, const float *match_box,
                                  const float *s_out, const float *s_gt, const float *sum_gt, int B, int T,
-                                 int fixed_order, int segm_loss_fn, float loss_mix_ratio, float *out,
-                                 void *stream) {
+                                 int fixed_order, int segm_loss_fn, float loss_mix_ratio, float *ws,
+                                 size_t ws_floats, float *out, void *stream) {
   if (!iou_soft || !iou_hard || !dice || !match_real || !iou_box || !match_box || !s_out || !s_gt || !sum_gt ||
-      !out || B <= 0 || T <= 0)
+      !out || !ws || B <= 0 || T <= 0)
     return fail(RA_E_INVALID, "ra_loss_stats_f32: bad argument");
+  if (ws_floats < ra_loss_stats_workspace_floats(B))
+    return fail(RA_E_WORKSPACE, "ra_loss_stats_f32: workspace of %zu floats, need %zu", ws_floats,
+                ra_loss_stats_workspace_floats(B));
   if (T > loss::kMaxT) return fail(RA_E_SHAPE, "ra_loss_stats_f32: T=%d (max %d)", T, loss::kMaxT);
   if (segm_loss_fn != 0 && segm_loss_fn != 1) return fail(RA_E_INVALID, "ra_loss_stats_f32: segm_loss_fn");
-  hipLaunchKernelGGL(loss::loss_stats_kernel, dim3(1), dim3(256), 0, as_stream(stream), iou_soft, iou_hard, dice,
-                     match_real, iou_box, match_box, s_out, s_gt, sum_gt, B, T, fixed_order, segm_loss_fn,
+  hipLaunchKernelGGL(loss::loss_stats_image_kernel, dim3(B), dim3(64), 0, as_stream(stream), iou_soft, iou_hard,
+                     dice, match_real, iou_box, match_box, s_out, s_gt, sum_gt, T, fixed_order, ws);
+  hipLaunchKernelGGL(loss::loss_stats_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), ws, B, T, segm_loss_fn,
                      loss_mix_ratio, out);
   return launch_status("ra_loss_stats_f32");
 }

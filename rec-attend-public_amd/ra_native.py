@@ -72,10 +72,12 @@ SIGNATURES = {
     'ra_max_pool_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'ra_pair_stats_workspace_floats': (_Z, [_I, _I]),
     'ra_pair_stats_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'ra_gt_box_f32': (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    'ra_gt_box_workspace_floats': (_Z, [_I, _I]),
+    'ra_gt_box_f32': (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _Z, _P, _P, _P]),
     'ra_segm_match_workspace_bytes': (_Z, [_I, _I]),
     'ra_segm_match_f32': (_I, [_P, _P, _I, _I, _P, _Z, _P, _P, _P]),
-    'ra_loss_stats_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
+    'ra_loss_stats_workspace_floats': (_Z, [_I]),
+    'ra_loss_stats_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _Z, _P, _P]),
     'ra_postprocess_f32': (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     'ra_union_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'ra_remove_tiny_f32': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),

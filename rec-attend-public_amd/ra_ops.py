@@ -404,9 +404,11 @@ def gt_box(y_gt, padding_ratio, min_padding, want_box=True):
   B, T, H, W = y_gt.shape
   params = torch.empty((B, T, 8), dtype=torch.float32, device=y_gt.device)
   box = torch.empty((B, T, H, W), dtype=torch.float32, device=y_gt.device) if want_box else None
+  n = rn.lib().ra_gt_box_workspace_floats(B, T)
+  ws = torch.empty((n,), dtype=torch.float32, device=y_gt.device)
   check(rn.lib().ra_gt_box_f32(ptr(y_gt), B, T, H, W, C.c_float(padding_ratio),
-                               C.c_float(min_padding), ptr(params), ptr(box), rn.stream_ptr()),
-        'ra_gt_box_f32')
+                               C.c_float(min_padding), ptr(ws), n, ptr(params), ptr(box),
+                               rn.stream_ptr()), 'ra_gt_box_f32')
   return params, box
 
 
@@ -433,8 +435,10 @@ def loss_stats(iou_soft, iou_hard, dice, match_real, iou_box, match_box, s_out, 
   B, T = s_gt.shape
   out = torch.empty((len(STAT_NAMES),), dtype=torch.float32, device=s_gt.device)
   fn = {'iou': 0, 'wt_cov': 1}[segm_loss_fn]
+  n = rn.lib().ra_loss_stats_workspace_floats(B)
+  ws = torch.empty((n,), dtype=torch.float32, device=s_gt.device)
   check(rn.lib().ra_loss_stats_f32(*[ptr(t) for t in ts], B, T, int(bool(fixed_order)), fn,
-                                   C.c_float(loss_mix_ratio), ptr(out), rn.stream_ptr()),
+                                   C.c_float(loss_mix_ratio), ptr(ws), n, ptr(out), rn.stream_ptr()),
         'ra_loss_stats_f32')
   return out
 
