@@ -120,3 +120,35 @@ def test_unbuilt_parts_fail_loudly():
       nn.max_pool(torch.zeros(1, 4, 4, 4), 2)
   with pytest.raises(Exception):
     full_model.derive_dims(ora.make_opt('cvppp', 66, 64, 2))
+
+
+def test_eval_and_loss_modules_have_no_cpu_fallback():
+  """The reference-named evaluation / loss modules run on the HIP kernels only: CPU tensors are
+  refused loudly, never computed by torch behind the caller's back."""
+  import analysis
+  import image_ops
+  from utils import postprocess as pp
+  y = torch.rand(1, 3, 8, 8)
+  s = torch.rand(1, 3)
+  if not torch.cuda.is_available():
+    for call in (lambda: pp.postprocess(y, s, 0.5), lambda: pp.apply_one_label(y),
+                 lambda: pp.remove_tiny(y, s, 10), lambda: analysis.f_iou_pairwise(y, y),
+                 lambda: analysis.f_symmetric_best_dice({'y_out': y, 'y_gt': y, 's_out': s, 's_gt': s}),
+                 lambda: modellib.f_iou(y, y, 3, pairwise=True), lambda: modellib.get_gt_box(y),
+                 lambda: modellib.f_segm_match(torch.rand(1, 3, 3), s) if False else ops_segm(y, s),
+                 lambda: image_ops.random_transformation(torch.rand(1, 8, 8, 3), 2, True)):
+      with pytest.raises(rn.RecAttendError):
+        call()
+  # evaluation mode of the augmentation is the identity and needs no kernel
+  x = torch.rand(1, 8, 8, 3)
+  r = image_ops.random_transformation(x, 2, False, y=y)
+  assert r['x'] is x and r['y'] is y
+  with pytest.raises(NotImplementedError):
+    pp.morph(y)
+  with pytest.raises(Exception):
+    analysis.create_analyzer('nope')
+
+
+def ops_segm(y, s):
+  import ra_ops
+  return ra_ops.segm_match(torch.rand(1, 3, 3), s)
