@@ -96,6 +96,16 @@ def test_cfg5_cityscapes_native_size(cuda):
   _check(ora.make_opt('cityscapes', 256, 512, 20), 1, 71, use_graph=True)
 
 
+@pytest.mark.parametrize('over', [
+    dict(num_ctrl_mlp_layers=2, ctrl_mlp_dim=64, num_glimpse_mlp_layers=3, num_ctrl_rnn_iter=3, ctrl_rnn_hid_dim=128),
+    dict(filter_height=32, filter_width=32, squash_ctrl_params=True, fixed_var=True),
+    dict(num_ctrl_rnn_iter=1, ctrl_rnn_hid_dim=64, fixed_gamma=False, dynamic_var=True),
+], ids=['deep_mlps_small_lstm', 'patch32_squash_fixed_var', 'one_glimpse_dynamic_var'])
+def test_option_corners(cuda, over):
+  """model_opt values off the run scripts' beaten path: the generic controller / kernel variants."""
+  _check(ora.make_opt('cvppp', 96, 128, 2, **over), 2, 81, use_graph=False)
+
+
 def test_weights_reload_invalidates_packing(cuda):
   import full_model
   opt = ora.make_opt('cvppp', 64, 64, 2)
