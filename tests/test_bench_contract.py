@@ -1,0 +1,49 @@
+"""bench.py's output contract (one JSON line with the driver's fields, the roofline object and the
+CPU baseline), checked on the GPU with a short run; the argument parser on the CPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_flags_parse_without_a_gpu():
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True)
+  assert out.returncode == 0
+  for flag in ('--gpus', '--steps', '--warmup', '--no-cpu-baseline', '--host-input', '--pmc-group'):
+    assert flag in out.stdout
+
+
+@pytest.mark.gpu
+def test_bench_json_line(cuda):
+  env = dict(os.environ)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, env=env, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = [l for l in out.stdout.strip().splitlines() if l.startswith('{')][-1]
+  d = json.loads(line)
+  for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+            'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+    assert k in d, k
+  assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
+  assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+  assert 'workload' in d['config'] and 'model' not in d['config']
+  assert abs(d['value'] - 8 * 16 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
+  r = d['roofline']
+  for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+    assert k in r, k
+  assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+  assert 0.1 < r['frac'] < 1.0
+
+
+@pytest.mark.gpu
+def test_cpu_baseline_object(cuda):
+  sys.path.insert(0, ROOT)
+  import bench
+  opt = bench.make_opt('cvppp', 64, 64, 2)
+  cb = bench.cpu_baseline(opt, 3, budget_s=0.5)
+  assert cb['kind'] == 'port' and cb['unit'] == 'instance-timesteps/s' and cb['value'] > 0 and cb['cores'] >= 1
+  assert 'sample' in cb
