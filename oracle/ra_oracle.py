@@ -5,7 +5,8 @@ A NumPy restatement of the forward (eval-mode) path of the reference's
 operators that path uses.  Every function cites the reference ``file:line`` it follows
 (paths relative to the reference checkout).
 
-PARITY STATUS: **parity unpinned** for the neural path.  The reference ships no test,
+PARITY STATUS: **parity unpinned** for the neural path (cross-checked by a second, independent
+torch restatement, oracle/ra_oracle_torch.py, to 1e-9).  The reference ships no test,
 fixture or golden vector for nnlib/modellib/full_model (its only test file is
 ``hungarian_tf_tests.py``) and its runtime (Python 2.7 + TensorFlow 0.12) is not
 installable here, so this restatement cannot be checked against reference outputs.

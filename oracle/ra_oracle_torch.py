@@ -1,0 +1,238 @@
+"""Second CPU oracle (TEST INFRASTRUCTURE ONLY): the same eval-mode forward and loss head as
+oracle/ra_oracle.py, restated INDEPENDENTLY on torch primitives (float64, CPU) and differentiable.
+
+Why it exists:
+  * the neural path of the reference has no fixture to pin an oracle against ("parity unpinned",
+    see ra_oracle.py); two restatements written against the reference's lines with different
+    primitives (NumPy einsum / explicit loops there, torch.nn.functional here: F.conv2d,
+    F.conv_transpose2d, F.max_pool2d, torch.matmul) that agree to 1e-9 are a stronger pin than
+    either alone (tests/test_oracle_torch.py);
+  * torch autograd through this restatement is the reference gradient the backward kernels of the
+    training step (not built yet) will be checked against.
+
+Only shape bookkeeping (`derive`) and the plain-C Hungarian are shared with ra_oracle.py; every
+tensor operation below is written against the reference source again.  Nothing under
+rec-attend-public_amd/ imports this module.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import ra_oracle as ora
+
+DT = torch.float64
+
+
+def t64(a):
+  return torch.as_tensor(np.asarray(a, dtype=np.float64))
+
+
+def conv_same(x, w, b):
+  """nnlib.conv2d (nnlib.py:6-12): NHWC x, HWIO w, stride 1, SAME -> NHWC (odd kernels)."""
+  k = w.shape[0]
+  y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=k // 2)
+  return y.permute(0, 2, 3, 1) + b
+
+
+def deconv_same(x, w, b, stride):
+  """nnlib.py:372-376 conv2d_transpose, filter [f,f,out,in], SAME, output = input * stride.
+  SURVEY.md §8a trap 2: stride 2, k = 3 is conv_transpose2d(padding=0)[..., :2n, :2n]; stride 1 is
+  padding = 1."""
+  wt = w.permute(3, 2, 0, 1)  # [in, out, kh, kw]
+  xi = x.permute(0, 3, 1, 2)
+  if stride == 1:
+    y = F.conv_transpose2d(xi, wt, stride=1, padding=w.shape[0] // 2)
+  else:
+    n_h, n_w = x.shape[1] * stride, x.shape[2] * stride
+    y = F.conv_transpose2d(xi, wt, stride=stride, padding=0)[:, :, :n_h, :n_w]
+  return y.permute(0, 2, 3, 1) + b
+
+
+def pool(x, r):
+  """nnlib.max_pool (nnlib.py:15-25); all sizes on the path are even."""
+  if r == 1:
+    return x
+  return F.max_pool2d(x.permute(0, 3, 1, 2), r, r).permute(0, 2, 3, 1)
+
+
+def bn_eval(x, P, key):
+  """nnlib.batch_norm, eval branch (nnlib.py:113-119): EMA statistics, eps 1e-3 inside the sqrt."""
+  inv = P[key + '_gamma'] * torch.rsqrt(P[key + '_ema_var'] + 1e-3)
+  return x * inv + (P[key + '_beta'] - P[key + '_ema_mean'] * inv)
+
+
+def cnn(x, P, scope, n, pools, tt, use_bn):
+  """nnlib.cnn / run_cnn (nnlib.py:214-255): conv + b -> BN -> ReLU -> pool, all layers returned."""
+  hs = []
+  for i in range(n):
+    h = conv_same(x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)])
+    if use_bn:
+      h = bn_eval(h, P, '%s_%d_%d' % (scope, i, tt))
+    x = pool(torch.relu(h), pools[i])
+    hs.append(x)
+  return hs
+
+
+def dcnn(x, P, scope, n, unpool, tt, skip, use_bn):
+  """nnlib.dcnn / run_dcnn (nnlib.py:339-402): [concat skip] -> transposed conv + b -> BN -> ReLU."""
+  hs = []
+  for i in range(n):
+    if skip is not None and skip[i] is not None:
+      x = torch.cat([x, skip[i]], dim=3)
+    h = deconv_same(x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)], unpool[i])
+    if use_bn:
+      h = bn_eval(h, P, '%s_%d_%d' % (scope, i, tt))
+    x = torch.relu(h)
+    hs.append(x)
+  return hs
+
+
+def mlp(x, P, scope, acts):
+  """nnlib.mlp / run_mlp (nnlib.py:476-493)."""
+  hs = []
+  for i, act in enumerate(acts):
+    x = x @ P['%s_w_%d' % (scope, i)] + P['%s_b_%d' % (scope, i)]
+    if act is not None:
+      x = act(x)
+    hs.append(x)
+  return hs
+
+
+def lstm(x, state, P, hid):
+  """nnlib.lstm unroll (nnlib.py:637-649): state = [c | h]."""
+  c, h = state[:, :hid], state[:, hid:]
+  gate = lambda g: x @ P['ctrl_lstm_w_x' + g] + h @ P['ctrl_lstm_w_h' + g] + P['ctrl_lstm_b_' + g]
+  gi, gf, go = torch.sigmoid(gate('i')), torch.sigmoid(gate('f')), torch.sigmoid(gate('o'))
+  u = torch.tanh(gate('u'))
+  c = gf * c + gi * u
+  return torch.cat([c, go * torch.tanh(c)], dim=1)
+
+
+def gaussian_filter(ctr, size, lg_var, L, Fn):
+  """modellib.get_gaussian_filter (modellib.py:581-612) -> [B, L, F], not normalised."""
+  j = torch.arange(Fn, dtype=DT)
+  mu = ctr[:, None] + ((size[:, None] + 1.0) / Fn) * (j[None, :] - (Fn - 1) / 2.0)  # [B,F]
+  l = torch.arange(L, dtype=DT)
+  var = torch.exp(lg_var)[:, None, None]
+  dd = l[None, :, None] - mu[:, None, :]
+  return torch.exp(-0.5 * dd * dd / var) / (torch.sqrt(var) * math.sqrt(2 * math.pi))
+
+
+def extract(x, fy, fx):
+  """modellib.extract_patch (modellib.py:615-641): per channel F_y^T X F_x.  x [B,H,W,C]."""
+  t = torch.einsum('blj,blwc->bjwc', fy, x)
+  return torch.einsum('bjwc,bwi->bjic', t, fx)
+
+
+def forward(opt, Pnp, x, d_in=None, y_in=None, requires_grad=()):
+  """Eval-mode forward of full_model.py:638-907.  Returns (outputs dict of torch tensors, P dict);
+  parameters named in `requires_grad` are leaves with gradients enabled."""
+  d = ora.derive(opt)
+  P = {k: t64(v).requires_grad_(k in requires_grad) for k, v in Pnp.items()}
+  x = t64(x)
+  d_in = None if d_in is None else t64(d_in)
+  y_in = None if y_in is None else t64(y_in)
+  B, T, H, W, Fh, Fw, hid, G = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw'], d['hid'], d['G']
+  canvas = torch.zeros((B, H, W, 1), dtype=DT)
+  outs = {k: [] for k in ('y_out', 's_out', 'attn_box', 'attn_ctr', 'attn_size', 'x_patch')}
+
+  def cat(flags):  # full_model.py:640-661: x, canvas, d_in, y_in in that order
+    parts = [p for f, p in zip(flags, (x, canvas, d_in, y_in)) if f]
+    return torch.cat(parts, dim=3)
+
+  for tt in range(T):
+    feat = cnn(cat(d['ctrl_in']), P, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, d['use_bn'])[-1]
+    feat = feat.reshape(B, G, -1)
+    state = torch.zeros((B, 2 * hid), dtype=DT)
+    gmap = torch.full((B, G, 1), 1.0 / G, dtype=DT)
+    for it in range(d['iters']):  # full_model.py:668-689
+      state = lstm((feat * gmap).sum(dim=1), state, P, hid)
+      h = state[:, hid:]
+      if it < d['iters'] - 1:
+        acts = [torch.relu] * (d['n_gmlp'] - 1) + [lambda z: torch.softmax(z, dim=1)]
+        gmap = mlp(h, P, 'glimpse_mlp', acts)[-1][:, :, None]
+    co = mlp(h, P, 'ctrl_mlp', [torch.relu] * (d['n_cmlp'] - 1) + [None])[-1]
+    cn, ls = co[:, 0:2], co[:, 2:4]  # full_model.py:691-722
+    if d['squash']:
+      cn, ls = torch.tanh(cn), -F.softplus(ls)
+    dims = torch.tensor([H, W], dtype=DT)
+    ctr = (cn + 1.0) * dims / 2.0
+    size = torch.exp(ls) * dims
+    lg_var = torch.zeros_like(ctr) if d['fixed_var'] else torch.log(size) - torch.log(torch.tensor([Fh, Fw], dtype=DT))
+    if d['dynamic_var']:
+      lg_var = co[:, 4:6]
+    if d['fixed_gamma']:
+      attn_gamma, y_lg_gamma = torch.ones((B, 1, 1, 1), dtype=DT), torch.full((B, 1, 1, 1), 2.0, dtype=DT)
+    else:
+      attn_gamma, y_lg_gamma = torch.exp(co[:, 6]).reshape(B, 1, 1, 1), co[:, 8].reshape(B, 1, 1, 1)
+    box_gamma = torch.exp(co[:, 7]).reshape(B, 1, 1, 1)
+    fy, fx = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh), \
+        gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+    fyi, fxi = fy.transpose(1, 2), fx.transpose(1, 2)
+    ones = torch.ones((B, Fh, Fw, 1), dtype=DT)
+    attn_box = torch.sigmoid(extract(ones * box_gamma, fyi, fxi) - 5.0).reshape(B, 1, H, W)  # :738-741
+    x_patch = attn_gamma * extract(cat(d['attn_in']), fy, fx)                              # :788-789
+    h_acnn = cnn(x_patch, P, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, d['use_bn'])
+    h_core = h_acnn[-1].reshape(B, -1)                                                        # :794
+    skip = None
+    if d['add_skip_conn']:                                                                    # :798-805
+      rev = h_acnn[::-1][1:] + [x_patch]
+      skip = [None] + [hh if sk else None for sk, hh in zip(d['skip_rev'], rev)]
+    y_patch = dcnn(h_acnn[-1], P, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, skip, d['use_bn'])[-1]
+    y = torch.sigmoid(torch.exp(y_lg_gamma) * extract(y_patch, fyi, fxi) - 5.0).reshape(B, 1, H, W)  # :810-815
+    if d['disable_overwrite']:
+      y = (1 - canvas).reshape(B, 1, H, W) * y
+    s = torch.sigmoid(torch.cat([h, h_core], dim=1) @ P['score_mlp_w_0'] + P['score_mlp_b_0'])  # :821-822
+    canvas = torch.maximum(y.reshape(B, H, W, 1), canvas)                                      # :843-848
+    if ora._opt(opt, 'stop_canvas_grad', True):
+      canvas = canvas.detach()
+    for k, v in (('y_out', y), ('s_out', s), ('attn_box', attn_box), ('attn_ctr', ctr[:, None]),
+                 ('attn_size', size[:, None]), ('x_patch', x_patch[:, None])):
+      outs[k].append(v)
+  res = {k: torch.cat(v, dim=1) for k, v in outs.items()}
+  res['canvas'] = canvas
+  return res, P
+
+
+def iou_pairwise(a, b):
+  """modellib.f_iou pairwise (modellib.py:124-155), eps summed per pixel (:119-122)."""
+  inter = torch.einsum('bnhw,bmhw->bnm', a, b)
+  sa, sb = a.sum(dim=(2, 3))[:, :, None], b.sum(dim=(2, 3))[:, None, :]
+  return inter / (sa + sb - inter + 1e-5 * a.shape[2] * a.shape[3])
+
+
+def loss_head(opt, fwd, y_gt, s_gt):
+  """full_model.py:913-1025 for box_loss_fn = segm_loss_fn = 'iou' (the run scripts' setting): the
+  differentiable total loss plus the pieces.  The matchings are constants (Hungarian,
+  ops.NoGradient, modellib.py:11)."""
+  y_gt, s_gt = t64(y_gt), t64(s_gt)
+  B, T = s_gt.shape
+  _, _, box_gt = ora.get_gt_box(y_gt.numpy(), padding_ratio=opt['attn_box_padding_ratio'],
+                                center_shift_ratio=0.0, min_padding=opt['padding'] + 4.0)
+  box_gt = t64(box_gt)
+
+  def match_of(iou):
+    if ora._opt(opt, 'fixed_order', False):
+      return t64(ora.get_identity_match(s_gt.numpy()))
+    return t64(ora.f_segm_match(iou.detach().numpy(), s_gt.numpy()))
+
+  out = {}
+  iou_box = iou_pairwise(fwd['attn_box'], box_gt)
+  m_box = match_of(iou_box)
+  cnt_box = torch.clamp(m_box.sum(dim=(1, 2)), min=1.0)
+  out['iou_soft_box'] = ((iou_box * m_box).sum(dim=(1, 2)) / cnt_box).sum() / B
+  iou = iou_pairwise(fwd['y_out'], y_gt)
+  m = match_of(iou)
+  cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
+  out['iou_soft'] = ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B
+  s_out = fwd['s_out']
+  s_min = torch.cummin(s_out, dim=1)[0]                                   # modellib.py:40-53
+  s_max = torch.flip(torch.cummax(torch.flip(s_out, [1]), dim=1)[0], [1])  # :56-68
+  ms = m.sum(dim=2)
+  bce = -ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)  # :430-437
+  out['conf_loss'] = bce.sum() / B / T
+  out['loss'] = -out['iou_soft_box'] - out['iou_soft'] + ora._opt(opt, 'loss_mix_ratio', 1.0) * out['conf_loss']
+  out['match'], out['match_box'] = m, m_box
+  return out
