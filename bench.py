@@ -292,6 +292,23 @@ def main():
       out['controller_us'] = graph_time_us(lambda: ops.controller(
           eng.desc, sb['ccnn'][-1], Wt['ctrl'], sb['h_last'][0], sb['ctrl_out'][0], sb['gmaps'][0],
           sb['attn'][0]))
+    # the Hungarian op is not roofline-rated; report us per [T,T] problem (device
+    # solver, one wave per problem, B problems per launch) on matching-shaped weights
+    rng = np.random.RandomState(7)
+    wm = np.zeros((B, T, T), np.float32)
+    for bb in range(B):
+      k = rng.randint(T // 2, T)
+      for i, j in enumerate(rng.permutation(k)):
+        wm[bb, i, j] = rng.uniform(0.5, 0.95)
+      wm[bb, :k, :k] += rng.uniform(0, 0.05, (k, k)).astype(np.float32)
+    wm_d = torch.as_tensor(np.floor(wm * 1e6 + 0.5) / 1e6 + 1e-5).cuda()
+    ops.hungarian(wm_d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+      ops.hungarian(wm_d)
+    torch.cuda.synchronize()
+    out['hungarian_us_per_problem'] = 1e6 * (time.perf_counter() - t0) / (5 * B)
     out['config']['sub_batches'] = len(eng.subs)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(opt, 1234)
