@@ -106,6 +106,30 @@ def test_option_corners(cuda, over):
   _check(ora.make_opt('cvppp', 96, 128, 2, **over), 2, 81, use_graph=False)
 
 
+def test_long_sequence_t32_and_loss_head(cuda):
+  """T = 32 (the cfg5 T=32 variant's sequence length; the loss head's and matching's maximum),
+  small image: decode parity, then the loss head against the oracle with 20 instances."""
+  import full_model
+  opt = ora.make_opt('cvppp', 64, 64, 32)
+  out, ref = _check(opt, 1, 91, use_graph=True)
+  rng = np.random.RandomState(92)
+  yy, xx = np.mgrid[0:64, 0:64]
+  y_gt, s_gt = np.zeros((1, 32, 64, 64), np.float32), np.zeros((1, 32), np.float32)
+  for t in range(20):
+    cy, cx = rng.randint(6, 58), rng.randint(6, 58)
+    y_gt[0, t] = ((yy - cy) ** 2 + (xx - cx) ** 2 < 16)
+    s_gt[0, t] = 1
+  P = ora.random_params(opt, 91)
+  x, _, _ = _inputs(opt, 1, 92)
+  href = ora.loss_head(opt, ora.full_model_forward(opt, P, x), y_gt, s_gt)
+  m = full_model.get_model(opt).load_weights(P)
+  names = ['loss', 'iou_soft', 'conf_loss', 'dice', 'match']
+  got = dict(zip(names, m.run(names, {'x': x, 'phase_train': False, 'y_gt': y_gt, 's_gt': s_gt}, as_numpy=True)))
+  assert (got['match'] == href['match']).all()
+  for k in names[:-1]:
+    assert abs(float(got[k]) - float(href[k])) < 2e-4 * max(1.0, abs(float(href[k]))), k
+
+
 def test_weights_reload_invalidates_packing(cuda):
   import full_model
   opt = ora.make_opt('cvppp', 64, 64, 2)
