@@ -135,6 +135,7 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
+  ap.add_argument('--no-fuse-score', action='store_true', help='tuning aid: score MLP as its own launch')
   ap.add_argument('--host-input', action='store_true',
                   help='hand x over as a pinned HOST buffer each step (PCIe-inclusive rate; never the headline value)')
   ap.add_argument('--pmc-group', type=int, default=0, metavar='REPS',
@@ -156,6 +157,7 @@ def main():
   eng = model.engine
   eng.use_graph = not args.no_graph
   eng.nsub = args.nsub
+  eng.fuse_score = not args.no_fuse_score
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
   if args.host_input:

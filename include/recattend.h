@@ -239,6 +239,14 @@ int ra_paste_direct_f32(const float *patch, int Cp, int pc, const float *attn, i
                         int Fh, int Fw, float beta, int disable_overwrite, float *canvas, float *img,
                         int Ci, int canvas_chan, float *y_out, size_t y_stride_b, int flags,
                         void *stream);
+/* ra_paste_direct_f32 on a canvas plane, with the score MLP of the same timestep
+ * (full_model.py:794,821-822: s = sigmoid([h | h_core] . w + bias), h [B,K0], core [B,K1],
+ * w [K0+K1], bias [1]) riding along as one extra workgroup per image: s_out[b * s_stride_b]. */
+int ra_paste_score_direct_f32(const float *patch, int Cp, int pc, const float *attn, int B, int H,
+                              int W, int Fh, int Fw, float beta, int disable_overwrite,
+                              float *canvas, float *y_out, size_t y_stride_b, int flags,
+                              const float *h, int K0, const float *core, int K1, const float *w,
+                              const float *bias, float *s_out, size_t s_stride_b, void *stream);
 int ra_attn_box_direct_f32(const float *attn, int B, int H, int W, int Fh, int Fw, float beta,
                            float *box_out, size_t stride_b, void *stream);
 

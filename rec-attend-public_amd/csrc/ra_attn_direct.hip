@@ -185,15 +185,43 @@ inline PasteGeo paste_geo() {  // RA_PASTE_GEO=<rows>,<threads>: tuning aid
   }
   return g;
 }
+// Optional rider on the paste launch: the score MLP of the same timestep (full_model.py:794,821-822:
+// s = sigmoid([h | h_core] . w + b)) runs in one extra workgroup per image instead of its own launch.
+struct ScoreArgs {
+  const float *h, *core, *w, *bias;  // h [B,K0], core [B,K1], w [K0+K1], bias [1]
+  float *s_out;                       // element b at s_out[b * stride]
+  int K0, K1;
+  size_t stride;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256) void paste_direct_kernel(const float *patch, int Cp, int pc,
                                                             const float *attn, int H, int W, int Fh,
                                                             int Fw, float beta, int disable_overwrite,
                                                             float *canvas, float *img, int Ci,
                                                             int canvas_chan, float *y_out,
-                                                            size_t y_stride_b, int flags, int kPasteRows) {
+                                                            size_t y_stride_b, int flags, int kPasteRows,
+                                                            ScoreArgs sc) {
   extern __shared__ float V[];  // [kPasteRows][Fw]:  V[r][i] = sum_j fy(l0 + r, j) P[j,i]
   const int l0 = blockIdx.x * kPasteRows, b = blockIdx.y, t = threadIdx.x;
+  if (l0 >= H) {  // the rider workgroup (grid.x is one larger when a score is requested)
+    float s = 0.0f;
+    const int K = sc.K0 + sc.K1;
+    for (int k = t; k < K; k += blockDim.x) {
+      const float xv = (k < sc.K0) ? sc.h[(size_t)b * sc.K0 + k] : sc.core[(size_t)b * sc.K1 + (k - sc.K0)];
+      s += xv * sc.w[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((t & 63) == 0) V[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) {
+      float tot = sc.bias ? sc.bias[0] : 0.0f;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot += V[wv];
+      sc.s_out[(size_t)b * sc.stride] = sigmoidf(tot);
+    }
+    return;
+  }
   const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
   const Axis Ay = make_axis(rec, 0, H, Fh), Ax = make_axis(rec, 1, W, Fw);
   const int nrow = (H - l0) < kPasteRows ? (H - l0) : kPasteRows;
@@ -346,7 +374,7 @@ extern "C" int ra_paste_direct_f32(const float *patch, int Cp, int pc, const flo
                      pg.rows * Fw * sizeof(float),
                      as_stream(stream), patch, Cp, pc, attn_rec, H, W, Fh, Fw, beta, disable_overwrite, canvas,
                      img, Ci, canvas_chan, y_out, y_stride_b, disable_overwrite ? (flags & ~RA_PASTE_Y_PREFILLED) : flags,
-                     pg.rows);
+                     pg.rows, attnd::ScoreArgs{});
   return launch_status("ra_paste_direct_f32");
 }
 
@@ -358,6 +386,24 @@ extern "C" int ra_attn_box_direct_f32(const float *attn_rec, int B, int H, int W
   hipLaunchKernelGGL(attnd::paste_direct_kernel<1>, dim3(ceil_div(H, pg.rows), B), dim3(pg.threads),
                      pg.rows * Fw * sizeof(float),
                      as_stream(stream), nullptr, 1, 0, attn_rec, H, W, Fh, Fw, beta, 0, nullptr, nullptr, 0, -1,
-                     box_out, stride_b, 0, pg.rows);
+                     box_out, stride_b, 0, pg.rows, attnd::ScoreArgs{});
   return launch_status("ra_attn_box_direct_f32");
+}
+
+extern "C" int ra_paste_score_direct_f32(const float *patch, int Cp, int pc, const float *attn_rec, int B, int H,
+                                         int W, int Fh, int Fw, float beta, int disable_overwrite, float *canvas,
+                                         float *y_out, size_t y_stride_b, int flags, const float *h, int K0,
+                                         const float *core, int K1, const float *w, const float *bias,
+                                         float *s_out, size_t s_stride_b, void *stream) {
+  if (!patch || !attn_rec || !y_out || !canvas || !h || !w || !s_out || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 ||
+      Fw <= 0 || Cp <= 0 || pc < 0 || pc >= Cp || K0 <= 0 || K1 < 0 || (K1 > 0 && !core))
+    return fail(RA_E_INVALID, "ra_paste_score_direct_f32: bad argument");
+  const attnd::PasteGeo pg = attnd::paste_geo();
+  attnd::ScoreArgs sc{h, core, w, bias, s_out, K0, K1, s_stride_b};
+  const size_t lds = (size_t)(pg.rows * Fw > 8 ? pg.rows * Fw : 8) * sizeof(float);
+  hipLaunchKernelGGL(attnd::paste_direct_kernel<0>, dim3(ceil_div(H, pg.rows) + 1, B), dim3(pg.threads), lds,
+                     as_stream(stream), patch, Cp, pc, attn_rec, H, W, Fh, Fw, beta, disable_overwrite, canvas,
+                     static_cast<float *>(nullptr), 0, -1, y_out, y_stride_b,
+                     disable_overwrite ? (flags & ~RA_PASTE_Y_PREFILLED) : flags, pg.rows, sc);
+  return launch_status("ra_paste_score_direct_f32");
 }

@@ -44,6 +44,7 @@ class DecodeEngine(object):
     self.fuse_pairs = True  # fused two-layer conv launches in the controller CNN where it pays
     self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
+    self.fuse_score = True  # score MLP as an extra workgroup of the paste launch
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -393,17 +394,25 @@ class DecodeEngine(object):
                       src1=None if sidx is None else skips[sidx], upsample=(unpool == 2), out=out)
         src = out
       self._mark('attn_dcnn')
-      ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
-                b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
-      self._mark('score')
+      fused_score = direct and self.fuse_score and self.timing is None
+      if not fused_score:
+        ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
+                  b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
+        self._mark('score')
       if direct:
         # y_out was prefilled with sigmoid(beta) (_launch_pack) and after the first paste the canvas
         # is >= sigmoid(beta) everywhere, so only the attention window is touched
         flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | \
             (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
-        ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
-                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
-                         flags=flags)
+        if fused_score:  # the score MLP rides on the paste launch (one extra workgroup per image)
+          ops.paste_score_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                                 b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, b['canvas'], flags,
+                                 b['h_last'][tt], core.view(core.shape[0], -1), Wt['smlp_w'], Wt['smlp_b'],
+                                 b['s_out'].data_ptr() + tt * 4, T)
+        else:
+          ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                           b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
+                           flags=flags)
       else:
         ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
                          d['disable_overwrite'], b['img'], d['D'],

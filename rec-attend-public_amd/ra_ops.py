@@ -252,6 +252,19 @@ def paste_direct(patch, pc, attn, beta, disable_overwrite, y_out, y_stride_b, H,
         'ra_paste_direct_f32')
 
 
+def paste_score_direct(patch, pc, attn, beta, disable_overwrite, y_out, y_stride_b, H, W, canvas, flags,
+                       h, core, w, bias, s_out_ptr, s_stride_b):
+  """paste_direct on a canvas plane + the score MLP of the timestep in the same launch."""
+  _need_cuda(patch, attn, canvas, h, core, w, bias)
+  B, Fh, Fw, Cp = patch.shape
+  K1 = 0 if core is None else core.shape[1]
+  check(rn.lib().ra_paste_score_direct_f32(ptr(patch), Cp, pc, ptr(attn), B, H, W, Fh, Fw, C.c_float(beta),
+                                           int(disable_overwrite), ptr(canvas), ptr(y_out), y_stride_b,
+                                           int(flags), ptr(h), h.shape[1], ptr(core), K1, ptr(w), ptr(bias),
+                                           ptr(s_out_ptr), s_stride_b, rn.stream_ptr()),
+        'ra_paste_score_direct_f32')
+
+
 def attn_box_direct(attn, H, W, Fh, Fw, beta, out, stride_b):
   _need_cuda(attn)
   check(rn.lib().ra_attn_box_direct_f32(ptr(attn), attn.shape[0], H, W, Fh, Fw, C.c_float(beta),
