@@ -21,8 +21,11 @@ sb = eng.subs[0]
 REP = 8
 
 
+NSTEPS = int(sys.argv[1]) if len(sys.argv) > 1 else len(eng.plan['ccnn'])  # encoder launches in the probe
+
+
 def enc():
-  eng._run_cnn(eng.plan['ccnn'], eng.W['ccnn'], sb['img'], sb['ccnn'], 1, 'ctrl_cnn', plane=sb.get('canvas'))
+  eng._run_cnn(eng.plan['ccnn'][:NSTEPS], eng.W['ccnn'], sb['img'], sb['ccnn'], 1, 'ctrl_cnn', plane=sb.get('canvas'))
 
 
 def tail():
