@@ -372,7 +372,7 @@ extern "C" int ra_controller_f32(const ra_ctrl_desc *d, const float *feat, const
   if (bytes > 160 * 1024) return fail(RA_E_SHAPE, "ra_controller_f32: %zu B of LDS", bytes);
   static bool attr_set = false;  // idempotent; benign if raced
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(ctrl::controller_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctrl::controller_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }

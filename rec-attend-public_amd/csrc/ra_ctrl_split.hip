@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void controller_split_kernel(
     {
       // e = t + 256*i ; since Cf divides 256, channel c = t % Cf is fixed per thread and
       // g = t / Cf + (256 / Cf) * i
-      const int c = t % Cf, g0 = t / Cf, gstep = kThreads / Cf;
+      const int g0 = t / Cf, gstep = kThreads / Cf;
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < FR; ++i) {

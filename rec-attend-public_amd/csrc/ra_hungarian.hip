@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, i
   const int b = blockIdx.x, t = threadIdx.x;
   const float *wb = w + (size_t)b * nx * ny;
   float *Mb = M + (size_t)b * nx * ny, *cxb = cx + (size_t)b * nx, *cyb = cy + (size_t)b * ny;
-  char *wsb = ws + (size_t)b * ws_per_ex;
+  [[maybe_unused]] char *wsb = ws + (size_t)b * ws_per_ex;  // device pass only
   if (!use_lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int rc = solve_wave(wb, nx, ny, Mb, cxb, cyb, wsb, wsb + hot_bytes(nx, ny), t);
