@@ -345,79 +345,78 @@ class DecodeEngine(object):
   def _launch_tail(self, b, tt, want_box, src):
     d, Wt, T = self.d, self.W, self.d['T']
     H, W, Fh, Fw = d['H'], d['W'], d['Fh'], d['Fw']
-    if True:
-      if 'ctrl_ws' in b:
-        ops.controller_split(self.desc, src, Wt['ctrl_split'], b['h_last'][tt], b['ctrl_out'][tt],
-                             b['gmaps'][tt], b['attn'][tt], b['ctrl_ws'], b['ctrl_status'])
-      else:
-        ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
-                       b['gmaps'][tt], b['attn'][tt])
-      self._mark('controller')
-      direct = self.direct_attn
-      if not direct:
-        ops.attn_filters(b['attn'][tt], H, W, Fh, Fw, b['fy'], b['fx'], b['band'])
-        self._mark('filters')
-      if want_box or self.box:
-        if direct:
-          ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0,
-                              b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
-        else:
-          ops.attn_box(b['attn'][tt], b['fy'], b['fx'], b['band'], H, W, Fh, Fw, -5.0,
-                       b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
-        self._mark('attn_box')
-      if self.box:
-        self._box_step(b, tt)
-        return
-      xp = b['x_patch'][tt]
+    if 'ctrl_ws' in b:
+      ops.controller_split(self.desc, src, Wt['ctrl_split'], b['h_last'][tt], b['ctrl_out'][tt],
+                           b['gmaps'][tt], b['attn'][tt], b['ctrl_ws'], b['ctrl_status'])
+    else:
+      ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
+                     b['gmaps'][tt], b['attn'][tt])
+    self._mark('controller')
+    direct = self.direct_attn
+    if not direct:
+      ops.attn_filters(b['attn'][tt], H, W, Fh, Fw, b['fy'], b['fx'], b['band'])
+      self._mark('filters')
+    if want_box or self.box:
       if direct:
-        ops.extract_direct(b['img'], 0, b['attn'][tt], Fh, Fw, d['C0p'], True, xp,
-                           canvas=b['canvas'], canvas_chan=d['D'])
+        ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0,
+                            b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
       else:
-        ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
-                          d['C0p'], True, xp)
-      self._mark('extract')
-      src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
-      core = src
-      L = d['acnn_nlayers']
-      skips = [b['acnn'][L - 2 - k] for k in range(L - 1)] + [xp]
-      for step in self.plan['adcnn']:
-        if step[0] == 'pair':
-          (wpa, sca, sha, ca, upa, _), (wpb, scb, shb, cb, _, _) = Wt['adcnn'][step[1]], Wt['adcnn'][step[2]]
-          out = b['y_out_patch'][tt] if b['adcnn'][step[2]] is None else b['adcnn'][step[2]]
-          ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=1,
-                        upsampleA=(upa == 2), out=out)
-        else:
-          i = step[1]
-          wp, sc, sh, cout, unpool, sidx = Wt['adcnn'][i]
-          out = b['y_out_patch'][tt] if b['adcnn'][i] is None else b['adcnn'][i]
-          ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=1,
-                      src1=None if sidx is None else skips[sidx], upsample=(unpool == 2), out=out)
-        src = out
-      self._mark('attn_dcnn')
-      fused_score = direct and self.fuse_score and self.timing is None
-      if not fused_score:
-        ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
-                  b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
-        self._mark('score')
-      if direct:
-        # y_out was prefilled with sigmoid(beta) (_launch_pack) and after the first paste the canvas
-        # is >= sigmoid(beta) everywhere, so only the attention window is touched
-        flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | \
-            (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
-        if fused_score:  # the score MLP rides on the paste launch (one extra workgroup per image)
-          ops.paste_score_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
-                                 b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, b['canvas'], flags,
-                                 b['h_last'][tt], core.view(core.shape[0], -1), Wt['smlp_w'], Wt['smlp_b'],
-                                 b['s_out'].data_ptr() + tt * 4, T)
-        else:
-          ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
-                           b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
-                           flags=flags)
+        ops.attn_box(b['attn'][tt], b['fy'], b['fx'], b['band'], H, W, Fh, Fw, -5.0,
+                     b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
+      self._mark('attn_box')
+    if self.box:
+      self._box_step(b, tt)
+      return
+    xp = b['x_patch'][tt]
+    if direct:
+      ops.extract_direct(b['img'], 0, b['attn'][tt], Fh, Fw, d['C0p'], True, xp,
+                         canvas=b['canvas'], canvas_chan=d['D'])
+    else:
+      ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
+                        d['C0p'], True, xp)
+    self._mark('extract')
+    src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
+    core = src
+    L = d['acnn_nlayers']
+    skips = [b['acnn'][L - 2 - k] for k in range(L - 1)] + [xp]
+    for step in self.plan['adcnn']:
+      if step[0] == 'pair':
+        (wpa, sca, sha, ca, upa, _), (wpb, scb, shb, cb, _, _) = Wt['adcnn'][step[1]], Wt['adcnn'][step[2]]
+        out = b['y_out_patch'][tt] if b['adcnn'][step[2]] is None else b['adcnn'][step[2]]
+        ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=1,
+                      upsampleA=(upa == 2), out=out)
       else:
-        ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
-                         d['disable_overwrite'], b['img'], d['D'],
-                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
-      self._mark('paste')
+        i = step[1]
+        wp, sc, sh, cout, unpool, sidx = Wt['adcnn'][i]
+        out = b['y_out_patch'][tt] if b['adcnn'][i] is None else b['adcnn'][i]
+        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=1,
+                    src1=None if sidx is None else skips[sidx], upsample=(unpool == 2), out=out)
+      src = out
+    self._mark('attn_dcnn')
+    fused_score = direct and self.fuse_score and self.timing is None
+    if not fused_score:
+      ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
+                b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
+      self._mark('score')
+    if direct:
+      # y_out was prefilled with sigmoid(beta) (_launch_pack) and after the first paste the canvas
+      # is >= sigmoid(beta) everywhere, so only the attention window is touched
+      flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | \
+          (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
+      if fused_score:  # the score MLP rides on the paste launch (one extra workgroup per image)
+        ops.paste_score_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                               b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, b['canvas'], flags,
+                               b['h_last'][tt], core.view(core.shape[0], -1), Wt['smlp_w'], Wt['smlp_b'],
+                               b['s_out'].data_ptr() + tt * 4, T)
+      else:
+        ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
+                         flags=flags)
+    else:
+      ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
+                       d['disable_overwrite'], b['img'], d['D'],
+                       b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
+    self._mark('paste')
 
   def _run_cnn(self, steps, layers, src, bufs, tt, name, plane=None):
     """plane: the canvas plane standing in for channel D of the FIRST layer's packed input."""
