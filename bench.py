@@ -14,8 +14,9 @@ scaling is weak.
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel group — the controller
 CNN's conv3x3 f32-MFMA launches (1.585 GFLOP per image-timestep at cfg2) —
 timed with HIP events on the launch stream; `roofline_attn` the HBM-bound attention resample
-(extract + paste, 7.0 MiB algorithmic per image-timestep); `cpu_baseline` the NumPy oracle
-timed on this box's host cores over a bounded sample (a reported baseline, not the target).
+(extract + paste, 7.0 MiB algorithmic per image-timestep); `cpu_baseline` the PyTorch-CPU
+restatement (float32, all host cores) timed over a bounded sample (a reported baseline, not the
+target).
 """
 import argparse
 import json
@@ -95,33 +96,41 @@ def pmc_traffic(images, size):
   return rec['hbm_bytes_per_launch_group']
 
 
-def cpu_baseline(opt, seed, budget_s=15.0):
-  """NumPy oracle (oracle/ra_oracle.py, float32) on the host cores: B=1, as many timesteps
-  as fit the budget (each timestep costs the same)."""
+def cpu_baseline(opt, seed, budget_s=15.0, batch=2, steps=4):
+  """CPU stand-in baseline as BASELINE.md §3 / SURVEY.md §8(d) define it: the PyTorch-CPU
+  restatement of the same graph (oracle/ra_oracle_torch.py: F.conv2d / conv_transpose2d /
+  max_pool2d / matmul, i.e. oneDNN + BLAS), float32, every host core, on a bounded sample of the
+  same workload — forwards of `batch` images x `steps` timesteps at the full cfg2 resolution (a
+  timestep costs the same wherever it sits in the sequence).  The reference's own TF-0.12 CPU
+  path cannot run here, hence kind = "port"."""
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import ra_oracle as ora
-  try:
-    from threadpoolctl import threadpool_info
-    threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-  except Exception:
-    threads = os.cpu_count() or 1
+  import ra_oracle_torch as ort
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  ort.set_dtype(torch.float32)
   o1 = dict(opt)
-  o1['timespan'] = 1
+  o1['timespan'] = steps
   P = ora.random_params(o1, seed)
-  x = np.random.RandomState(seed).rand(1, opt['inp_height'], opt['inp_width'], 3).astype(np.float32)
-  ora.full_model_forward(o1, P, x, dtype=np.float32)  # warm-up
-  n, t0 = 0, time.perf_counter()
-  while True:
-    ora.full_model_forward(o1, P, x, dtype=np.float32)
-    n += 1
-    el = time.perf_counter() - t0
-    if el > budget_s or n >= 64:  # bounded: about 10-15 s of CPU work
-      break
-  return {'value': n / el, 'unit': 'instance-timesteps/s', 'cores': int(threads),
-          'kind': 'port',
-          'sample': 'NumPy/BLAS float32 oracle, %d x (B=1, T=1) forwards of the same %dx%d '
-                    'CVPPP-arch graph in %.1f s; stand-in for the TF-0.12 CPU path, which cannot '
-                    'run here' % (n, opt['inp_height'], opt['inp_width'], el)}
+  x = np.random.RandomState(seed).rand(batch, opt['inp_height'], opt['inp_width'], 3).astype(np.float32)
+  try:
+    with torch.no_grad():
+      ort.forward(o1, P, x)  # warm-up (thread pool, oneDNN primitive cache)
+      n, t0 = 0, time.perf_counter()
+      while True:
+        ort.forward(o1, P, x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 128:  # bounded: at most ~15 s of CPU work
+          break
+  finally:
+    ort.set_dtype(torch.float64)
+  return {'value': n * batch * steps / el, 'unit': 'instance-timesteps/s', 'cores': int(cores),
+          'kind': 'port', 'label': 'CPU stand-in (PyTorch-CPU restatement, float32), %d cores' % cores,
+          'sample': 'PyTorch-CPU (oneDNN/BLAS) float32 restatement, %d forwards of B=%d x T=%d of the same '
+                    '%dx%d CVPPP-arch graph in %.1f s on %d threads; stand-in for the TF-0.12 CPU path, '
+                    'which cannot run here' % (n, batch, steps, opt['inp_height'], opt['inp_width'], el,
+                                               torch.get_num_threads())}
 
 
 def main():

@@ -378,6 +378,14 @@ int ra_random_transform_f32(const float *x, int N, int H, int W, int C, int padd
 int ra_weighted_sum_f32(const float *w, const float *y, int B, int T, int HW, float *out,
                         void *stream);
 
+/* p[0..n) = value (p 16-byte aligned): the canvas reset `canvas = zeros` (full_model.py:239) and
+ * the sigmoid(beta) prefill of y_out behind RA_PASTE_Y_PREFILLED, as a library launch so that the
+ * captured forward holds no framework kernel. */
+int ra_fill_f32(float *p, size_t n, float value, void *stream);
+/* modellib.f_greedy_match with matched == 0 (modellib.py:365-379; box_model.py:487-498):
+ * match[b,t] = (score[b,t] == max_t score[b,:]) / #maxima.  score, match [B,T]. */
+int ra_greedy_match_f32(const float *score, int B, int T, float *match, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

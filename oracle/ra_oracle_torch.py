@@ -22,11 +22,20 @@ import torch.nn.functional as F
 
 import ra_oracle as ora
 
-DT = torch.float64
+DT = torch.float64  # the checker's precision; bench.py's cpu_baseline leg times it at float32
+
+
+def set_dtype(dt):
+  """float64 (default: the parity / gradient checker) or float32 (the timed CPU stand-in, the
+  reference's own arithmetic type)."""
+  global DT
+  DT = dt
 
 
 def t64(a):
-  return torch.as_tensor(np.asarray(a, dtype=np.float64))
+  if isinstance(a, torch.Tensor):
+    return a.to(DT)
+  return torch.as_tensor(np.asarray(a, dtype=np.float64)).to(DT)
 
 
 def conv_same(x, w, b):

@@ -44,3 +44,46 @@ extern "C" int ra_debug_poison_lds(void *stream) {
                      static_cast<float *>(nullptr));
   return ra::launch_status("ra_debug_poison_lds");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Small utilities of the decode loop that must not cost a framework kernel inside the HIP graph.
+namespace ra {
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fill_kernel(float *p, size_t n4, size_t n, float v) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const f32x4 vv = f32x4{v, v, v, v};
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += stride)
+    reinterpret_cast<f32x4 *>(p)[e] = vv;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = v;
+}
+// f_greedy_match with matched == 0 (modellib.py:365-379): match = (score == max) / count.
+__global__ __launch_bounds__(64) void greedy_match_kernel(const float *score, int T, float *match) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float mx = -__builtin_inff();
+  for (int t = lane; t < T; t += 64) mx = fmaxf(mx, score[(size_t)b * T + t]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float cnt = 0.f;
+  for (int t = lane; t < T; t += 64) cnt += score[(size_t)b * T + t] == mx ? 1.f : 0.f;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  for (int t = lane; t < T; t += 64) match[(size_t)b * T + t] = (score[(size_t)b * T + t] == mx ? 1.f : 0.f) / cnt;
+}
+}  // namespace
+}  // namespace ra
+
+extern "C" int ra_fill_f32(float *p, size_t n, float value, void *stream) {
+  if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return ra::fail(RA_E_INVALID, "ra_fill_f32: null / unaligned pointer");
+  if (n == 0) return 0;
+  const size_t n4 = n / 4;
+  size_t grid = (n4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  if (grid == 0) grid = 1;
+  hipLaunchKernelGGL(ra::fill_kernel, dim3((unsigned)grid), dim3(256), 0, ra::as_stream(stream), p, n4, n, value);
+  return ra::launch_status("ra_fill_f32");
+}
+
+extern "C" int ra_greedy_match_f32(const float *score, int B, int T, float *match, void *stream) {
+  if (!score || !match || B <= 0 || T <= 0) return ra::fail(RA_E_INVALID, "ra_greedy_match_f32: bad argument");
+  hipLaunchKernelGGL(ra::greedy_match_kernel, dim3(B), dim3(64), 0, ra::as_stream(stream), score, T, match);
+  return ra::launch_status("ra_greedy_match_f32");
+}

@@ -13,8 +13,10 @@ get_model(opt, is_training=True) takes the reference's `model_opt` dict
     `x_patch`, `y_out_patch`, `attn_box`, `attn_ctr`, `attn_size`, `attn_top_left`,
     `attn_bot_right`, `attn_ctr_norm`, `attn_lg_size`, `ctrl_rnn_glimpse_map`.
 The forward is the eval graph (phase_train=False; use_knob does not act at eval,
-full_model.py:744-773,826-841).  Losses / train_step (full_model.py:913-1057) are the
-training step, SURVEY.md §8(f) rank 2, not built yet: requesting them raises.
+full_model.py:744-773,826-841).  With `y_gt` / `s_gt` in the feed the loss / statistics head
+of the training graph (full_model.py:913-1097) is available as outputs too (`loss`, `iou_soft`,
+`match`, ... — Model.LOSS_OUTPUTS; csrc/ra_loss.hip).  `train_step` (backward + Adam,
+full_model.py:1039-1057) lives in ra_train.py.
 """
 import numpy as np
 import torch
@@ -137,11 +139,31 @@ class Model(dict):
   def weight_keys(self):
     return sorted(k for k, v in self.items() if isinstance(v, torch.Tensor))
 
-  def load_weights(self, weights):
+  def load_weights(self, weights, strict=True):
     """weights: mapping name -> array (e.g. an .npz of the reference's weights.h5 keys,
-    full_model_read.py:33-71, plus the BN EMA statistics)."""
+    full_model_read.py:33-71, plus the BN EMA statistics).
+
+    strict (default): every registered tensor must be present in `weights` — in particular the
+    `*_ema_mean` / `*_ema_var` BatchNorm statistics, which the reference's weights.h5 export
+    omits (they live only in the TF checkpoint, nnlib.py:121-127): left at their initial zeros
+    every BN layer would compute gamma * x / sqrt(1e-3).  Keys of `weights` the model does not
+    register are reported with a warning.  strict=False loads what matches and returns quietly
+    (the pre-training hand-off of a sub-network, full_model.py:271-284)."""
+    known = set(self.weight_keys())
+    given = set(weights.keys())
+    if strict:
+      missing = sorted(known - given)
+      if missing:
+        raise RecAttendError(
+            'load_weights: %d registered tensors are missing from the archive (first: %s); BN EMA '
+            'statistics are not part of the reference weights.h5 export — add them or pass '
+            'strict=False' % (len(missing), ', '.join(missing[:4])))
+    extra = sorted(given - known)
+    if extra:
+      import warnings
+      warnings.warn('load_weights: ignoring %d unknown keys (first: %s)' % (len(extra), ', '.join(extra[:4])))
     for k, v in weights.items():
-      if k not in self or not isinstance(self[k], torch.Tensor):
+      if k not in known:
         continue
       v = torch.as_tensor(np.asarray(v, dtype=np.float32))
       if tuple(v.shape) != tuple(self[k].shape):
@@ -205,6 +227,8 @@ class Model(dict):
                            segm_loss_fn=opt.get('segm_loss_fn', 'iou'),
                            loss_mix_ratio=float(opt.get('loss_mix_ratio', 1.0)))
     self.match_status = (st1, st2)
+    ops.check_match_status(st1, 'f_segm_match(y_out, y_gt)')
+    ops.check_match_status(st2, 'f_segm_match(attn_box, attn_box_gt)')
     head = {n: stats[i] for i, n in enumerate(ops.STAT_NAMES)}
     if fixed:
       ident = modellib.get_identity_match(s_gt.shape[0], s_gt.shape[1], s_gt)

@@ -9,7 +9,7 @@ come from --input (an .npz with x [N,H,W,3] and optionally d_in / y_in / y_gt / 
 synthetic; the reference's HDF5 datasets are out of scope.  The raw outputs are
 written to <output>/output_<split>/pred_rank<r>.npz.  With y_gt and s_gt in the input the
 reference's write_log chain (full_model_eval.py:97-139) runs on the device for every threshold of
---threshold_list (default 0.0 .. 0.9, :39-40): apply_confidence, apply_one_label,
+--threshold_list (default 0.3, the reference CLI's default, :193-194): apply_confidence, apply_one_label,
 apply_threshold [, mask_foreground, remove_tiny] and the --analyzers (default list :201-205);
 the per-threshold means go to <output>/output_<split>/metrics_rank<r>.yaml.  The cv2 steps
 (upsample + bilateral filter, morph) are skipped: evaluation is at the network resolution."""
@@ -59,8 +59,9 @@ def main(argv=None):
       lg = rng.randn(n, H, W, model.dims['nsc']).astype(np.float32)
       data['y_in'] = np.exp(lg) / np.exp(lg).sum(-1, keepdims=True)
   lo, hi = ra_dist.shard_range(rank, world, data['x'].shape[0])
-  thresholds = [float(t) for t in args.threshold_list.split(',')] if args.threshold_list else \
-      [0.1 * k for k in range(10)]                                    # full_model_eval.py:39-40,193-198
+  # the reference CLI defaults to [0.3] (MyEvalArgsParser.make_opt, full_model_eval.py:193-198); the
+  # 0.0 .. 0.9 sweep of :39-40 is only EvalRunner's fallback for a caller that hands it None
+  thresholds = [float(t) for t in args.threshold_list.split(',')] if args.threshold_list else [0.3]
   if args.analyzers is None:                                          # :199-210
     names = [] if args.test else ['sbd', 'wt_cov', 'unwt_cov', 'avg_fp', 'avg_fn', 'avg_pr', 'avg_re',
                                   'obj_pr', 'obj_re', 'count_acc', 'count_mse', 'dic', 'dic_abs']
@@ -69,6 +70,14 @@ def main(argv=None):
   analyze = bool(names) and 'y_gt' in data and 's_gt' in data
   acc = {th: {n: [] for n in names} for th in thresholds}
   ys, ss, t0 = [], [], time.time()
+  try:
+    _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, analyze, acc, ys, ss, t0)
+  finally:
+    ra_dist.barrier()  # always reached: a rank that fails must not leave the others hanging
+
+
+def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, analyze, acc, ys, ss, t0):
+  import torch
   for b0 in range(lo, hi, args.batch_size):
     b1 = min(hi, b0 + args.batch_size)
     feed = {k: v[b0:b1] for k, v in data.items() if k in ('x', 'd_in', 'y_in')}
@@ -91,7 +100,11 @@ def main(argv=None):
   out_dir = os.path.join(args.output or restore, 'output_' + args.split.split(',')[0])
   os.makedirs(out_dir, exist_ok=True)
   path = os.path.join(out_dir, 'pred_rank%d.npz' % rank)
-  np.savez_compressed(path, y_out=np.concatenate(ys), s_out=np.concatenate(ss), first_index=lo)
+  T, H, W = model.dims['T'], model.dims['H'], model.dims['W']
+  # an empty shard (more ranks than images) writes empty arrays of the right rank
+  y_all = np.concatenate(ys) if ys else np.zeros((0, T, H, W), np.float32)
+  s_all = np.concatenate(ss) if ss else np.zeros((0, T), np.float32)
+  np.savez_compressed(path, y_out=y_all, s_out=s_all, first_index=lo)
   print('rank %d: images [%d, %d) -> %s (%.2f s)' % (rank, lo, hi, path, time.time() - t0))
   if analyze:
     summary = {}
@@ -101,10 +114,9 @@ def main(argv=None):
                               for n, v in vals.items()}
     with open(os.path.join(out_dir, 'metrics_rank%d.yaml' % rank), 'w') as f:
       yaml.safe_dump(summary, f)
-    best = max(summary, key=lambda k: summary[k].get('sbd', {}).get('mean', 0.0))
-    print('rank %d: threshold %s  %s' % (rank, best, ' '.join(
-        '%s=%.4f' % (n, summary[best][n]['mean']) for n in names)))
-  ra_dist.barrier()
+    for th in sorted(summary):  # every threshold, never a ground-truth-tuned arg-max
+      print('rank %d: threshold %s  %s' % (rank, th, ' '.join(
+          '%s=%.4f' % (n, summary[th][n]['mean']) for n in names)))
 
 
 if __name__ == '__main__':

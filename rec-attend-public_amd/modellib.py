@@ -1,9 +1,10 @@
 """`modellib` surface of the reference on gfx950 kernels (cited as modellib.py:line).
 
 Built: the Gaussian-attention operators of the decode loop (get_gaussian_filter,
-extract_patch and the (un)normalisers), the Hungarian op binding and f_segm_match's
-conditioning around it.  The loss / IoU family (modellib.py:28-531) belongs to the training
-step, SURVEY.md §8(f) rank 2, and is not built yet.
+extract_patch and the (un)normalisers), the Hungarian op binding with f_segm_match's
+conditioning around it, and the loss / IoU family (f_iou, f_dice, f_inter, f_union, coverage,
+f_conf_loss, f_greedy_match, get_gt_box, ...; modellib.py:28-531) on the streaming kernels of
+csrc/ra_loss.hip.
 """
 import math
 
@@ -99,13 +100,12 @@ def f_segm_match(iou, s_gt):
 # full_model.get_model(...).run(['loss', 'iou_soft', ...]) uses the fused ra_loss_stats_f32.
 # --------------------------------------------------------------------------------------
 def _pair(a, b):
-  """a [B,N,H,W], b [B,M,H,W] -> (inter [B,N,M], sum_a [B,N,1], sum_b [B,1,M], eps*HW)."""
-  st = ops.pair_stats(a, b, want=('iou_soft', 'sum_a', 'sum_b'))
+  """a [B,N,H,W], b [B,M,H,W] -> (iou [B,N,M], inter [B,N,M], sum_a [B,N,1], sum_b [B,1,M],
+  eps*HW).  `inter` is the kernel's own sum(a*b), not recovered from the ratio."""
+  st = ops.pair_stats(a, b, want=('iou_soft', 'inter', 'sum_a', 'sum_b'))
   e = 1e-5 * a.shape[2] * a.shape[3]
   sa, sb = st['sum_a'][:, :, None], st['sum_b'][:, None, :]
-  iou = st['iou_soft']
-  inter = iou * (sa + sb + e) / (1.0 + iou)  # iou = I / (sa + sb - I + e)
-  return iou, inter, sa, sb, e
+  return st['iou_soft'], st['inter'], sa, sb, e
 
 
 def _as4(t):
@@ -113,25 +113,40 @@ def _as4(t):
   return t.reshape((1,) * (4 - t.dim()) + tuple(t.shape))
 
 
+def _aligned(m, a, b):
+  """The non-pairwise result of an elementwise-broadcast op from its pairwise matrix m [B,N,M]:
+  N == M -> the diagonal [B,N]; N == 1 or M == 1 -> the broadcast row / column [B,max(N,M)]
+  (the reference multiplies a [B,1,H,W] against b [B,T,H,W], full_model.py:752-754,
+  box_model.py:487-490); anything else is a shape error there too."""
+  N, M = a.shape[1], b.shape[1]
+  if N == M:
+    return torch.diagonal(m, dim1=1, dim2=2).reshape(a.shape[:2])
+  if N == 1:
+    return m[:, 0, :].contiguous()
+  if M == 1:
+    return m[:, :, 0].contiguous()
+  raise RecAttendError('incompatible instance counts %d and %d (broadcast needs equal or 1)' % (N, M))
+
+
 def f_inter(a, b):
-  """modellib.py:107-110 for aligned [B,N,H,W] inputs -> [B,N]."""
+  """modellib.py:107-110 -> [B,N] (broadcast over a singleton instance axis)."""
   a, b = _as4(a), _as4(b)
-  return torch.diagonal(_pair(a, b)[1], dim1=1, dim2=2).reshape(a.shape[:2])
+  return _aligned(_pair(a, b)[1], a, b)
 
 
 def f_union(a, b, eps=1e-5):
-  """modellib.py:113-117 (eps summed over every pixel) for aligned inputs -> [B,N]."""
+  """modellib.py:113-117 (eps summed over every pixel) -> [B,N]."""
   a, b = _as4(a), _as4(b)
   _, inter, sa, sb, e = _pair(a, b)
   u = sa + sb - inter + eps * a.shape[2] * a.shape[3]
-  return torch.diagonal(u, dim1=1, dim2=2).reshape(a.shape[:2])
+  return _aligned(u, a, b)
 
 
 def f_iou(a, b, timespan=None, pairwise=False):
   """modellib.py:124-155: pairwise -> [B,N,M]; aligned -> [B,N]."""
   a, b = _as4(a), _as4(b)
   iou = _pair(a, b)[0]
-  return iou if pairwise else torch.diagonal(iou, dim1=1, dim2=2).reshape(a.shape[:2])
+  return iou if pairwise else _aligned(iou, a, b)
 
 
 def f_dice(a, b, timespan=None, pairwise=False):
@@ -139,7 +154,7 @@ def f_dice(a, b, timespan=None, pairwise=False):
   a, b = _as4(a), _as4(b)
   _, inter, sa, sb, e = _pair(a, b)
   d = 2.0 * inter / ((sa + e) + (sb + e))
-  return d if pairwise else torch.diagonal(d, dim1=1, dim2=2).reshape(a.shape[:2])
+  return d if pairwise else _aligned(d, a, b)
 
 
 def get_identity_match(num_ex, timespan, s_gt):

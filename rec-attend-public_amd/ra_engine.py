@@ -254,6 +254,9 @@ class DecodeEngine(object):
       if self.box:
         b['noise'] = f(T, Bs, H, W)
         b['ysel'] = f(Bs, H, W)
+        b['match'] = f(Bs, T)
+        if self.direct_attn:
+          b['box1'] = f(Bs, 1, H, W)
       else:
         b['x_patch'] = f(T, Bs, Fh, Fw, d['C0p'])
         hh, ww = Fh, Fw
@@ -335,11 +338,11 @@ class DecodeEngine(object):
   def _launch_pack(self, b):
     ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), self.d['C0p'], b['img'])
     if 'canvas' in b:
-      b['canvas'].zero_()  # full_model.py:239
+      ops.fill(b['canvas'], 0.0)  # full_model.py:239
       if not self.box and not self.d['disable_overwrite']:
         # every pixel outside an attention window is sigmoid(0 - 5) (full_model.py:813-818): fill
         # once per forward at memset speed, the per-timestep paste then writes windows only
-        b['y_out'].fill_(1.0 / (1.0 + math.exp(5.0)))
+        ops.fill(b['y_out'], 1.0 / (1.0 + math.exp(5.0)))
     self._mark('pack')
 
   def _launch_tail(self, b, tt, want_box, src):
@@ -360,6 +363,8 @@ class DecodeEngine(object):
       if direct:
         ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0,
                             b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
+        if self.box:  # dense copy of this step's box for the pairwise-IoU kernel
+          ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0, b['box1'].data_ptr(), H * W)
       else:
         ops.attn_box(b['attn'][tt], b['fy'], b['fx'], b['band'], H, W, Fh, Fw, -5.0,
                      b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
@@ -444,12 +449,10 @@ class DecodeEngine(object):
     K8 kernel, the picked instance as a weighted sum); the arg-max over T values per image is
     [B,T]-sized bookkeeping."""
     d, T = self.d, self.d['T']
-    box = b['attn_box'][:, tt:tt + 1]
-    iou = ops.pair_stats(box, b['box_gt'], want=('iou_soft',))['iou_soft'][:, 0]  # f_inter / f_union, [B,T]
-    mx = iou.max(dim=1, keepdim=True)[0]
-    match = (iou == mx).to(torch.float32)       # f_greedy_match with matched = 0, modellib.py:365-379
-    match = match / match.sum(dim=1, keepdim=True)
-    ops.weighted_sum(match, b['y_gt'], b['ysel'])
+    box = b['box1'] if 'box1' in b else b['attn_box'][:, tt:tt + 1].contiguous()
+    iou = ops.pair_stats(box, b['box_gt'], want=('iou_soft',))['iou_soft']  # f_inter / f_union, [B,1,T]
+    ops.greedy_match(iou.view(iou.shape[0], T), out=b['match'])  # matched = 0, modellib.py:365-379
+    ops.weighted_sum(b['match'], b['y_gt'], b['ysel'])
     if 'canvas' in b:
       ops.canvas_max(b['canvas'].view(b['canvas'].shape + (1,)), 0, b['ysel'], b['noise'][tt])
     else:
@@ -487,11 +490,17 @@ class DecodeEngine(object):
       for k, sb in enumerate(self.subs):
         sb['noise'].copy_(b['noise'][:, k * Bs:(k + 1) * Bs])
         sb['box_gt'] = ops.gt_box(sb['y_gt'].contiguous(), float(self.d['attn_box_padding_ratio']), 10.0)[1]
-    graphable = self.use_graph and self.timing is None and not self.box
+    graphable = self.use_graph and self.timing is None
     if not graphable:
       self._launch_all(want_box)
       return self
     key = bool(want_box)
+    if self.box:  # the GT boxes are a fresh tensor per forward: the graph reads a fixed buffer
+      for sb in self.subs:
+        if 'box_gt_buf' not in sb:
+          sb['box_gt_buf'] = torch.empty_like(sb['box_gt'])
+        sb['box_gt_buf'].copy_(sb['box_gt'])
+        sb['box_gt'] = sb['box_gt_buf']
     g = self._graphs.get(key)
     if g is None:
       self._launch_all(want_box)  # warm-up (also sets kernel attributes)

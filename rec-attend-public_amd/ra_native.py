@@ -84,6 +84,8 @@ SIGNATURES = {
     'ra_eval_metrics_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     'ra_random_transform_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    'ra_fill_f32': (_I, [_P, _Z, _F, _P]),
+    'ra_greedy_match_f32': (_I, [_P, _I, _I, _P, _P]),
     'ra_paste_score_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _Z, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _P]),
 }
 

@@ -358,6 +358,7 @@ def hungarian(weights):
     check(rn.lib().ra_hungarian_f32_dev(ptr(w3), B, N, M, ptr(m), ptr(cx), ptr(cy), ptr(st),
                                         ptr(ws), nb, rn.stream_ptr()), 'ra_hungarian_f32_dev')
     hungarian.last_status = st
+    check_match_status(st, 'hungarian')
     cx, cy = cx[:, :, None], cy[:, None, :]
     return (m[0], cx[0], cy[0]) if two_d else (m, cx, cy)
   w = _np32(weights)
@@ -379,6 +380,25 @@ def hungarian(weights):
 
 
 hungarian.last_status = 0
+
+
+def check_match_status(status, what='Hungarian'):
+  """Per-example status of the device solver (int32 [B], include/recattend.h): a negative code is
+  where the reference LOG(FATAL)s (hungarian.cc:124-127,146-160,184-188,446-450) — raise instead of
+  carrying a partial matching into the loss; 1 is the outer 1000-iteration cap, where the
+  reference logs an error and returns the partial matching (hungarian.cc:363-377) — warn."""
+  if status is None or isinstance(status, int):
+    worst, capped = (status or 0), (status == 1)
+  else:
+    worst = int(status.min().item())
+    capped = bool((status == 1).any().item())
+  if worst < 0:
+    raise rn.RecAttendError('%s: the matching solver stopped with code %d (an iteration cap the '
+                            'reference aborts on, hungarian.cc LOG(FATAL))' % (what, worst))
+  if capped:
+    import warnings
+    warnings.warn('%s: outer iteration cap reached, partial matching returned (hungarian.cc:363-377)'
+                  % what)
 
 
 # --------------------------------------------------------------------------------------
@@ -535,6 +555,24 @@ def random_transform(x, padding, off_y, off_x, flip_v=False, flip_h=False, trans
   check(rn.lib().ra_random_transform_f32(ptr(x), N, H, W, Cc, int(padding), int(off_y), int(off_x),
                                          int(bool(flip_v)), int(bool(flip_h)), int(bool(transpose)),
                                          ptr(out), rn.stream_ptr()), 'ra_random_transform_f32')
+  return out
+
+
+def fill(t, value):
+  """t[...] = value as a library launch (keeps framework kernels out of the captured forward)."""
+  _need_cuda(t)
+  check(rn.lib().ra_fill_f32(ptr(t), t.numel(), C.c_float(value), rn.stream_ptr()), 'ra_fill_f32')
+  return t
+
+
+def greedy_match(score, out=None):
+  """modellib.f_greedy_match with matched == 0 (modellib.py:365-379): score [B,T] -> [B,T]."""
+  score = score.contiguous()
+  _need_cuda(score, out)
+  if out is None:
+    out = torch.empty_like(score)
+  check(rn.lib().ra_greedy_match_f32(ptr(score), score.shape[0], score.shape[1], ptr(out),
+                                     rn.stream_ptr()), 'ra_greedy_match_f32')
   return out
 
 

@@ -251,3 +251,54 @@ def test_full_size_properties(cuda):
   m.engine.nsub = 1
   y1 = m.run('y_out', {'x': x[2:3], 'phase_train': False})
   assert float((y1 - y[2:3]).abs().max()) < 1e-5
+
+
+def test_cfg2_full_size_vs_oracle(cuda):
+  """BASELINE.json configs[1] at FULL size — CVPPP arch, 512x512, T=16 — against the float64
+  oracle with oracle-style weights (non-trivial masks), B=2; masks within 1e-3."""
+  opt = ora.make_opt('cvppp', 512, 512, 16)
+  out, ref = _check(opt, 2, 101, use_graph=True)
+  assert ref['y_out'].max() > 0.5
+  print('cfg2 full size: max |dy| = %.2e' % np.abs(out['y_out'] - ref['y_out']).max())
+
+
+def test_cfg5_cityscapes_t32(cuda):
+  """The cfg5 T=32 variant on the Cityscapes arch (9 semantic classes, skips, dynamic_var)."""
+  _check(ora.make_opt('cityscapes', 64, 128, 32), 1, 111, use_graph=True)
+
+
+def _box_case(arch, H, W, T, B, seed, **over):
+  import box_model
+  opt = ora.make_opt(arch, H, W, T, **over)
+  P = ora.random_params(opt, seed, box_model=True)
+  rng = np.random.RandomState(seed + 1)
+  x, d_in, y_in = _inputs(opt, B, seed + 2)
+  y_gt = np.zeros((B, T, H, W), np.float32)
+  for b in range(B):
+    for t in range(min(T, 3)):
+      y0, x0 = rng.randint(0, H // 2), rng.randint(0, W // 2)
+      y_gt[b, t, y0:y0 + rng.randint(8, H // 2), x0:x0 + rng.randint(8, W // 2)] = 1
+  noise = rng.uniform(0, 0.3, (T, B, H, W, 1)).astype(np.float32)
+  ref = ora.box_model_forward(opt, P, x, y_gt, noise, d_in=d_in, y_in=y_in)
+  m = box_model.get_model(opt).load_weights(P)
+  names = ['s_out', 'attn_box', 'attn_ctr', 'attn_size', 'canvas']
+  feed = {'x': x, 'y_gt': y_gt, 'noise': noise[..., 0], 'phase_train': False, 'd_in': d_in, 'y_in': y_in}
+  for rep in range(2):  # second pass = HIP-graph replay
+    out = dict(zip(names, m.run(names, feed, as_numpy=True)))
+    for k in names:
+      assert out[k].shape == ref[k].shape, k
+      assert np.abs(out[k] - ref[k]).max() < (2e-3 if k.startswith('attn_c') or k == 'attn_size'
+                                              else MASK_TOL), k
+  return out, ref
+
+
+def test_box_model_kitti_native_size(cuda):
+  """cfg3's first stage on its own arch: box_model, KITTI arch at 128x448 with d_in / y_in (13
+  input channels packed to 16), fixed_var default True (box_model.py:58-61)."""
+  _box_case('kitti', 128, 448, 4, 2, 121)
+
+
+def test_box_model_softmax_score(cuda):
+  """num_semantic_classes > 1: the score is a softmax over classes (box_model.py:508-513)."""
+  out, ref = _box_case('cityscapes', 64, 128, 3, 2, 131)
+  assert out['s_out'].shape == (2, 3, 9) and abs(float(out['s_out'][0, 0].sum()) - 1.0) < 1e-5

@@ -130,3 +130,42 @@ def test_device_equals_host(cuda):
   Mh, _, _ = ops.hungarian(W)
   Md, _, _ = ops.hungarian(torch.from_numpy(W).to(cuda))
   assert (Md.cpu().numpy() == Mh).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', KATS, ids=[c['name'] for c in KATS])
+def test_reference_vectors_device(cuda, case):
+  """The DEVICE solver against the reference's own asserted answers (hungarian_tf_tests.py:9-90)
+  and, bit for bit, against the C oracle — not only transitively through the host product."""
+  import torch
+  W = _weights(case)
+  rc, m, cx, cy = oracle(W)
+  Md, cxd, cyd = ops.hungarian(torch.from_numpy(W).to(cuda))
+  assert int(ops.hungarian.last_status.max()) == 0 and rc == 0
+  Md, cxd, cyd = Md.cpu().numpy(), cxd.cpu().numpy()[..., 0], cyd.cpu().numpy()[..., 0, :]
+  if W.ndim == 2:
+    m, cx, cy = m[0], cx[0], cy[0]
+  assert (Md == m).all() and (cxd == cx).all() and (cyd == cy).all()
+  if 'matching' in case:
+    assert (Md == np.array(case['matching'], np.float32)).all()
+  if 'cover_x' in case:
+    assert (cxd == np.array(case['cover_x'], np.float32)).all()
+    assert (cyd == np.array(case['cover_y'], np.float32)).all()
+
+
+@pytest.mark.gpu
+def test_status_is_checked_on_device(cuda):
+  """A per-example inner-cap status must surface as an error, as the reference's LOG(FATAL) does
+  (hungarian.cc:124-127): a near-dense equality graph at T = 32 exceeds the BFS pop cap."""
+  import torch
+  from ra_native import RecAttendError
+  W = np.full((1, 32, 32), 1e-5, np.float32)  # one image without any GT object, f_segm_match's eps fill
+  rc, _, _, _ = oracle(W)
+  if rc < 0:  # the reference aborts here; so must the product, host and device alike
+    with pytest.raises(RecAttendError):
+      ops.hungarian(W)
+    with pytest.raises(RecAttendError):
+      ops.hungarian(torch.from_numpy(W).to(cuda))
+  else:
+    M, _, _ = ops.hungarian(torch.from_numpy(W).to(cuda))
+    assert int(ops.hungarian.last_status.max()) == rc
