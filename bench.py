@@ -84,10 +84,12 @@ def seed_weights(model, seed):
   model['ctrl_mlp_b_0'].copy_(b)
 
 
-def pmc_traffic(images, size):
-  """HBM bytes per encoder launch group measured with rocprofv3 --pmc (separate FETCH_SIZE and
-  WRITE_SIZE passes over `bench.py --pmc-group`, summarised by tools/pmc_traffic.py)."""
-  path = os.path.join(ROOT, 'profiles', 'r01_pmc_encoder_traffic.json')
+def pmc_traffic(images, size, name='r02_pmc_encoder_traffic.json'):
+  """HBM bytes per launch group measured with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE
+  passes over `bench.py --pmc-group REPS [--pmc-which attn]`, summarised by tools/pmc_traffic.py)."""
+  path = os.path.join(ROOT, 'profiles', name)
+  if not os.path.exists(path) and name.startswith('r02_pmc_encoder'):
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_encoder_traffic.json')
   if not os.path.exists(path):
     return None
   rec = json.load(open(path))
@@ -96,41 +98,72 @@ def pmc_traffic(images, size):
   return rec['hbm_bytes_per_launch_group']
 
 
-def cpu_baseline(opt, seed, budget_s=15.0, batch=2, steps=4):
+def _cgroup_cpus():
+  """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a
+  container often sees every host core in os.cpu_count() but is scheduled on far fewer)."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+    if quota != 'max':
+      n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+  except Exception:
+    pass
+  return max(1, n)
+
+
+def cpu_baseline(opt, seed, budget_s=12.0, batch=2, steps=4):
   """CPU stand-in baseline as BASELINE.md §3 / SURVEY.md §8(d) define it: the PyTorch-CPU
   restatement of the same graph (oracle/ra_oracle_torch.py: F.conv2d / conv_transpose2d /
-  max_pool2d / matmul, i.e. oneDNN + BLAS), float32, every host core, on a bounded sample of the
-  same workload — forwards of `batch` images x `steps` timesteps at the full cfg2 resolution (a
-  timestep costs the same wherever it sits in the sequence).  The reference's own TF-0.12 CPU
-  path cannot run here, hence kind = "port"."""
+  max_pool2d / matmul, i.e. oneDNN + BLAS), float32, on a bounded sample of the same workload —
+  forwards of `batch` images x `steps` timesteps at the full cfg2 resolution (a timestep costs the
+  same wherever it sits in the sequence).  Thread count: every usable core is tried first on ONE
+  image-timestep; oversubscribed intra-op pools can be orders of magnitude slower than a moderate
+  one on this graph's small tensors, so 32 threads are tried too and the faster setting is the one
+  timed and reported (`cores` = threads actually used).  The reference's own TF-0.12 CPU path
+  cannot run here, hence kind = "port"."""
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import ra_oracle as ora
   import ra_oracle_torch as ort
-  cores = os.cpu_count() or 1
-  torch.set_num_threads(cores)
+  usable = _cgroup_cpus()
   ort.set_dtype(torch.float32)
-  o1 = dict(opt)
-  o1['timespan'] = steps
-  P = ora.random_params(o1, seed)
-  x = np.random.RandomState(seed).rand(batch, opt['inp_height'], opt['inp_width'], 3).astype(np.float32)
+  H, W = opt['inp_height'], opt['inp_width']
+  rng = np.random.RandomState(seed)
   try:
     with torch.no_grad():
-      ort.forward(o1, P, x)  # warm-up (thread pool, oneDNN primitive cache)
+      o1 = dict(opt)
+      o1['timespan'] = 1
+      P1 = ora.random_params(o1, seed)
+      x1 = rng.rand(1, H, W, 3).astype(np.float32)
+      probe = {}
+      for nt in sorted({usable, min(usable, 32)}, reverse=True):
+        torch.set_num_threads(nt)
+        ort.forward(o1, P1, x1)  # warm-up: thread pool, oneDNN primitive cache
+        t0 = time.perf_counter()
+        ort.forward(o1, P1, x1)
+        probe[nt] = time.perf_counter() - t0
+      threads = min(probe, key=probe.get)
+      torch.set_num_threads(threads)
+      o2 = dict(opt)
+      o2['timespan'] = steps
+      P2 = ora.random_params(o2, seed)
+      x2 = rng.rand(batch, H, W, 3).astype(np.float32)
       n, t0 = 0, time.perf_counter()
       while True:
-        ort.forward(o1, P, x)
+        ort.forward(o2, P2, x2)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 128:  # bounded: at most ~15 s of CPU work
+        if el > budget_s or n >= 128:  # bounded sample
           break
   finally:
     ort.set_dtype(torch.float64)
-  return {'value': n * batch * steps / el, 'unit': 'instance-timesteps/s', 'cores': int(cores),
-          'kind': 'port', 'label': 'CPU stand-in (PyTorch-CPU restatement, float32), %d cores' % cores,
+  return {'value': n * batch * steps / el, 'unit': 'instance-timesteps/s', 'cores': int(threads),
+          'kind': 'port', 'label': 'CPU stand-in (PyTorch-CPU restatement, float32), %d threads of %d usable '
+                                   'cores' % (threads, usable),
           'sample': 'PyTorch-CPU (oneDNN/BLAS) float32 restatement, %d forwards of B=%d x T=%d of the same '
-                    '%dx%d CVPPP-arch graph in %.1f s on %d threads; stand-in for the TF-0.12 CPU path, '
-                    'which cannot run here' % (n, batch, steps, opt['inp_height'], opt['inp_width'], el,
-                                               torch.get_num_threads())}
+                    '%dx%d CVPPP-arch graph in %.1f s on %d threads (one image-timestep probe: %s); stand-in '
+                    'for the TF-0.12 CPU path, which cannot run here'
+                    % (n, batch, steps, H, W, el, threads,
+                       ', '.join('%d threads %.2f s' % kv for kv in sorted(probe.items())))}
 
 
 def main():
@@ -150,6 +183,10 @@ def main():
   ap.add_argument('--pmc-group', type=int, default=0, metavar='REPS',
                   help='profiling aid: after one forward, launch only the encoder group REPS times '
                        'eagerly and exit (run under rocprofv3 --pmc; see tools/pmc_traffic.py)')
+  ap.add_argument('--pmc-which', default='enc', choices=['enc', 'attn', 'tail'],
+                  help='which launch group --pmc-group repeats: the encoder, extract+paste, or the whole tail')
+  ap.add_argument('--attn-b32', action='store_true', help='also time extract+paste at B=32 (roofline_attn.at_B32)')
+  ap.add_argument('--no-fuse-patchnet', action='store_true', help='tuning aid: per-layer patch-net launches')
   args = ap.parse_args()
 
   import ra_dist
@@ -167,6 +204,7 @@ def main():
   eng.use_graph = not args.no_graph
   eng.nsub = args.nsub
   eng.fuse_score = not args.no_fuse_score
+  eng.fuse_patchnet = not args.no_fuse_patchnet
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
   if args.host_input:
@@ -178,9 +216,20 @@ def main():
   if args.pmc_group:
     eng.forward(feed['x'])
     sb = eng.subs[0]
+    import ra_ops as ops
+    d = model.dims
     for _ in range(args.pmc_group):
-      eng._run_cnn(eng.plan['ccnn'], eng.W['ccnn'], sb['img'], sb['ccnn'], 0, 'ctrl_cnn',
-                   plane=sb.get('canvas'))
+      if args.pmc_which == 'enc':
+        eng._run_cnn(eng.plan['ccnn'], eng.W['ccnn'], sb['img'], sb['ccnn'], 0, 'ctrl_cnn',
+                     plane=sb.get('canvas'))
+      elif args.pmc_which == 'attn':
+        ops.extract_direct(sb['img'], 0, sb['attn'][0], d['Fh'], d['Fw'], d['C0p'], True, sb['x_patch'][0],
+                           canvas=sb['canvas'], canvas_chan=d['D'])
+        ops.paste_direct(sb['y_out_patch'][0], 0, sb['attn'][0], -5.0, d['disable_overwrite'],
+                         sb['y_out'].data_ptr(), T * S * S, S, S, canvas=sb['canvas'],
+                         flags=ops.PASTE_Y_PREFILLED | ops.PASTE_CANVAS_FLOORED)
+      else:
+        eng._launch_tail(sb, 1, False, sb['ccnn'][-1])
     torch.cuda.synchronize()
     print(json.dumps({'pmc_group': args.pmc_group, 'images': int(sb['img'].shape[0]), 'size': S}))
     return
@@ -265,35 +314,62 @@ def main():
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(Bs, S),
         'traffic_note': 'HBM bytes per launch group from committed rocprofv3 --pmc passes '
-                        '(profiles/r01_pmc_encoder_traffic.json; FETCH_SIZE x2 gfx950 correction + '
+                        '(profiles/r0x_pmc_encoder_traffic.json; FETCH_SIZE x2 gfx950 correction + '
                         'WRITE_SIZE); null if no pass matches this shape',
         'algorithmic_bytes_per_launch_group': enc_bytes,
         'peak_note': 'dense f32-input MFMA (v_mfma_f32_16x16x4_f32); the kernel computes in exact f32',
         'flop_per_launch_group': tot_f * Bs, 'avg_us_per_launch_group': enc_us,
         'layers': layers}
 
-    def attn_group():
-      if eng.direct_attn:
-        ops.extract_direct(sb['img'], 0, sb['attn'][0], Fh, Fw, d['C0p'], True, sb['x_patch'][0],
-                           canvas=sb['canvas'], canvas_chan=d['D'])
-        ops.paste_direct(sb['y_out_patch'][0], 0, sb['attn'][0], -5.0, d['disable_overwrite'],
-                         sb['y_out'].data_ptr(), T * S * S, S, S, canvas=sb['canvas'],
-                         flags=ops.PASTE_Y_PREFILLED | ops.PASTE_CANVAS_FLOORED)
-      else:
-        ops.extract_patch(sb['img'], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], Fh, Fw,
-                          d['C0p'], True, sb['x_patch'][0])
-        ops.paste_canvas(sb['y_out_patch'][0], 0, sb['attn'][0], sb['fy'], sb['fx'], sb['band'], -5.0,
-                         d['disable_overwrite'], sb['img'], d['D'], sb['y_out'].data_ptr(),
-                         T * S * S, sb['u_ws'], S, S)
+    Hh = S
+    prefilled = not d['disable_overwrite']
+    pflags = (ops.PASTE_Y_PREFILLED if prefilled else 0) | ops.PASTE_CANVAS_FLOORED
+
+    def attn_group(bb=sb, n=Bs):
+      ops.extract_direct(bb['img'][:n], 0, bb['attn'][0][:n], Fh, Fw, d['C0p'], True, bb['x_patch'][0][:n],
+                         canvas=bb['canvas'][:n], canvas_chan=d['D'])
+      ops.paste_direct(bb['y_out_patch'][0][:n], 0, bb['attn'][0][:n], -5.0, d['disable_overwrite'],
+                       bb['y_out'].data_ptr(), T * S * S, S, S, canvas=bb['canvas'][:n], flags=pflags)
+
+    def prefill(bb=sb):  # once per forward: y_out = sigmoid(beta) everywhere, canvas = 0
+      ops.fill(bb['canvas'], 0.0)
+      ops.fill(bb['y_out'], 1.0 / (1.0 + np.exp(5.0)))
 
     attn_us = graph_time_us(attn_group)
+    # the window-only paste relies on a once-per-forward prefill of y_out [B,T,H,W] and canvas:
+    # its 1/T share belongs to every timestep's attention-resample time
+    fill_us = graph_time_us(prefill, reps=10, inner=2) if prefilled else 0.0
+    group_us = attn_us + fill_us / T
     attn_bytes = float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs
+    attn_traffic = pmc_traffic(Bs, S, 'r02_pmc_attn_traffic.json')
     out['roofline_attn'] = {
-        'kernel': 'ra::attnd::extract_direct_kernel + paste_direct_kernel (attention resample, one '
-                  'sub-batch)', 'bound': 'hbm',
-        'achieved': attn_bytes / (attn_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-        'frac': attn_bytes / (attn_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': None,
-        'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': attn_us}
+        'kernel': 'ra::attnd::extract_direct_kernel + paste_direct_kernel (+ 1/T of the per-forward '
+                  'prefill) — attention resample, one sub-batch of %d images' % Bs, 'bound': 'hbm',
+        'achieved': attn_bytes / (group_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+        'frac': attn_bytes / (group_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': attn_traffic,
+        'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': group_us,
+        'extract_paste_us': attn_us, 'prefill_us_per_forward': fill_us,
+        'note': 'achieved = ALGORITHMIC bytes (SURVEY 8d: read the attention input once, write y_out, '
+                'read+write the canvas = H*W*(C0+3)*4 B per image-timestep) / time.  The kernels are '
+                'window-only: `traffic` (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_attn_traffic.json) '
+                'is what they really move; each is bounded by a dependent-load latency chain, not by bytes'}
+    if args.attn_b32:  # the same group at a large batch, where latency amortises
+      import full_model as fm2
+      m32 = fm2.get_model(opt, is_training=False)
+      seed_weights(m32, 99)
+      m32.engine.forward(torch.rand((32, S, S, 3), generator=g, dtype=torch.float32).cuda())
+      s32 = m32.engine.subs[0]
+      us32 = graph_time_us(lambda: attn_group(s32, 32))
+      f32us = graph_time_us(lambda: prefill(s32), reps=5, inner=1) if prefilled else 0.0
+      by32 = float(S * S * (d['acnn_channels'][0] + 3) * 4) * 32
+      out['roofline_attn']['at_B32'] = {'avg_us_per_launch_group': us32 + f32us / T, 'extract_paste_us': us32,
+                                        'achieved': by32 / ((us32 + f32us / T) * 1e-6) / 1e9,
+                                        'frac': by32 / ((us32 + f32us / T) * 1e-6) / 1e9 / PEAK_HBM_GBS}
+      del m32, s32
+    # the whole post-encoder tail of one timestep exactly as the forward issues it
+    tail_us = graph_time_us(lambda: eng._launch_tail(sb, 1, False, sb['ccnn'][-1]))
+    out['tail_us'] = tail_us
+    out['tail_launches'] = 3 if 'pnet_ws' in sb else None
     if 'ctrl_ws' in sb:
       out['controller_us'] = graph_time_us(lambda: ops.controller_split(
           eng.desc, sb['ccnn'][-1], Wt['ctrl_split'], sb['h_last'][0], sb['ctrl_out'][0],

@@ -378,6 +378,41 @@ int ra_random_transform_f32(const float *x, int N, int H, int W, int C, int padd
 int ra_weighted_sum_f32(const float *w, const float *y, int B, int T, int HW, float *out,
                         void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * K4  the whole patch-sized network of one timestep in ONE launch: attention CNN
+ * (nnlib.cnn run_cnn, nnlib.py:214-255) -> attention DCNN (nnlib.dcnn run_dcnn,
+ * nnlib.py:339-402, no skip connections) [-> score MLP, full_model.py:794,821-822], i.e.
+ * full_model.py:792-807,821-822.  Layers as ra_conv3x3_f32 takes them (packed weights,
+ * scale/shift [T][CoutP] per timestep; upsample = stride-2 transposed conv).  16 workgroups
+ * per image walk a phase list: layers at one resolution are chained through LDS, phases
+ * exchange activations through L2 (write-through stores + a per-image arrival counter).
+ * Supported: Cin in {4,8,16,32}, Cout <= 32 (multiple of 4 except the last layer), no
+ * second source; B * 16 workgroups must be co-resident (ra_patchnet_supported).  The caller
+ * falls back to per-layer ra_conv3x3_f32 launches otherwise.
+ *   x [B,Hp,Wp,layers[0].Cin] -> y [B,Ho,Wo,Cout_last];  tt = timestep (row of scale/shift).
+ *   score rider (s_out nullable): s_out[b * s_stride_b] = sigmoid([h[b,:K0] | flat(out of layer
+ *   core_layer)[b]] . w + bias[0]); the core layer must end a phase (it pools).
+ *   ws: ra_patchnet_workspace_bytes() device bytes, zero-filled ONCE when allocated (the kernel
+ *   re-arms its counters itself, so HIP-graph replays need no memset); status_dev (nullable)
+ *   is set to 1 if a peer workgroup timed out.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ra_pnet_layer {
+  const float *wpacked; /* ra_conv_pack_weights output, device */
+  const float *scale;   /* [T][CoutP], device */
+  const float *shift;   /* [T][CoutP], device */
+  int Cin;              /* input channels incl. padding to 4 */
+  int Cout;
+  int upsample;         /* 1: conv2d_transpose stride 2 (nnlib.py:372-376) */
+  int pool;             /* 1 | 2 */
+  int relu;
+} ra_pnet_layer;
+int ra_patchnet_supported(const ra_pnet_layer *layers, int n_layers, int B, int Hp, int Wp);
+size_t ra_patchnet_workspace_bytes(const ra_pnet_layer *layers, int n_layers, int B, int Hp, int Wp);
+int ra_patchnet_f32(const ra_pnet_layer *layers, int n_layers, int core_layer, const float *x,
+                    int B, int Hp, int Wp, int tt, float *y, const float *h, int K0,
+                    const float *w, const float *bias, float *s_out, size_t s_stride_b, void *ws,
+                    size_t ws_bytes, int *status_dev, void *stream);
+
 /* p[0..n) = value (p 16-byte aligned): the canvas reset `canvas = zeros` (full_model.py:239) and
  * the sigmoid(beta) prefill of y_out behind RA_PASTE_Y_PREFILLED, as a library launch so that the
  * captured forward holds no framework kernel. */

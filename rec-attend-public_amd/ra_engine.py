@@ -45,6 +45,7 @@ class DecodeEngine(object):
     self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
     self.fuse_score = True  # score MLP as an extra workgroup of the paste launch
+    self.fuse_patchnet = True  # attention CNN + DCNN + score as ONE launch (K4) where supported
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -158,6 +159,17 @@ class DecodeEngine(object):
         sc, sh = fold_all('attn_dcnn', i, cout)
         W['adcnn'].append((_dev(wp, device), sc, sh, cout, d['adcnn_unpool'][i], src))
         prev_c = cout
+    self.pnet = None
+    if not self.box and self.fuse_patchnet and all(lay[5] is None for lay in W['adcnn']) and \
+        all(u in (1, 2) for u in d['adcnn_unpool']):
+      lays = []
+      for i, (wp, sc, sh, cout, pool) in enumerate(W['acnn']):
+        lays.append((wp, sc, sh, d['C0p'] if i == 0 else _r4(d['acnn_channels'][i]), cout, False, pool))
+      for i, (wp, sc, sh, cout, unpool, _) in enumerate(W['adcnn']):
+        lays.append((wp, sc, sh, _r4(d['adcnn_channels'][i]), cout, unpool == 2, 1))
+      meta = [(l[3], l[4], l[5], l[6]) for l in lays]
+      if ops.PatchNet.structurally_supported(meta, d['Fh'], d['Fw'], 1) and d['acnn_pool'][-1] == 2:
+        self.pnet = ops.PatchNet(lays, d['acnn_nlayers'] - 1, d['Fh'], d['Fw'])
     self.W = W
     self.plan = self._make_plan(W)
     self._stamp = stamp
@@ -273,6 +285,8 @@ class DecodeEngine(object):
           else:
             b['adcnn'].append(f(Bs, hh, ww, d['adcnn_channels'][i + 1]))
         b['u_ws'] = f(Bs, Fh, W)
+        if self.pnet is not None and self.direct_attn and self.pnet.supported(Bs):
+          b['pnet_ws'], b['pnet_status'] = self.pnet.workspace(Bs, device)
       subs.append(b)
     self.glob = g
     self.subs = subs
@@ -380,6 +394,18 @@ class DecodeEngine(object):
       ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
                         d['C0p'], True, xp)
     self._mark('extract')
+    if 'pnet_ws' in b:  # K4: attention CNN + DCNN + score in one launch, then the window-only paste
+      src = b['y_out_patch'][tt]
+      self.pnet(xp, tt, src, b['pnet_ws'], b['pnet_status'], h=b['h_last'][tt], sw=Wt['smlp_w'],
+                sb=Wt['smlp_b'], s_out_ptr=b['s_out'].data_ptr() + tt * 4, s_stride_b=T)
+      self._mark('patchnet')
+      flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | \
+          (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
+      ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                       b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
+                       flags=flags)
+      self._mark('paste')
+      return
     src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
     core = src
     L = d['acnn_nlayers']

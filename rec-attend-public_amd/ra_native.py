@@ -26,6 +26,12 @@ class CtrlDesc(C.Structure):
                                       'dynamic_var', 'fixed_gamma')]
 
 
+class PnetLayer(C.Structure):
+  """struct ra_pnet_layer (include/recattend.h)."""
+  _fields_ = [('wpacked', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('Cin', C.c_int),
+              ('Cout', C.c_int), ('upsample', C.c_int), ('pool', C.c_int), ('relu', C.c_int)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -85,6 +91,9 @@ SIGNATURES = {
     'ra_random_transform_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ra_fill_f32': (_I, [_P, _Z, _F, _P]),
+    'ra_patchnet_supported': (_I, [_P, _I, _I, _I, _I]),
+    'ra_patchnet_workspace_bytes': (_Z, [_P, _I, _I, _I, _I]),
+    'ra_patchnet_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _Z, _P, _Z, _P, _P]),
     'ra_greedy_match_f32': (_I, [_P, _I, _I, _P, _P]),
     'ra_paste_score_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _Z, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _P]),
 }

@@ -443,3 +443,32 @@ def test_dense_pool_affine_pack(cuda):
   ref = np.concatenate([xi, np.zeros((2, 8, 8, 1), np.float32), di, yi,
                         np.zeros((2, 8, 8, 3), np.float32)], 3)
   assert (packed.cpu().numpy() == ref).all()
+
+
+@pytest.mark.parametrize('case', [dict(H=96, W=128, T=2, B=3), dict(H=64, W=64, T=2, B=2, filter_height=32, filter_width=32),
+                                  dict(H=64, W=96, T=2, B=16)],
+                         ids=['patch48_b3', 'patch32_b2', 'patch48_b16'])
+def test_patchnet_fused_vs_per_layer(cuda, case):
+  """K4 (attention CNN + DCNN + score in one launch, 16 workgroups per image exchanging through
+  L2) against the per-layer launches of the same kernels' arithmetic, and against the oracle."""
+  import full_model
+  case = dict(case)
+  H, W, T, B = case.pop('H'), case.pop('W'), case.pop('T'), case.pop('B')
+  opt = ora.make_opt('cvppp', H, W, T, **case)
+  P = ora.random_params(opt, 5)
+  x = np.random.RandomState(6).rand(B, H, W, 3).astype(np.float32)
+  names = ['y_out_patch', 's_out', 'y_out']
+  res = {}
+  for fused in (True, False):
+    m = full_model.get_model(opt).load_weights(P)
+    m.engine.fuse_patchnet = fused
+    for rep in range(3):  # replays: the in-kernel counter re-arm
+      res[fused] = m.run(names, {'x': x, 'phase_train': False}, as_numpy=True)
+    assert ('pnet_ws' in m.engine.subs[0]) == fused
+    if fused:
+      assert int(m.engine.subs[0]['pnet_status'].item()) == 0
+  for a, b in zip(res[True], res[False]):
+    assert np.abs(a - b).max() < 1e-5
+  ref = ora.full_model_forward(opt, P, x[:2])
+  assert np.abs(res[True][0][:2] - ref['y_out_patch']).max() < 1e-3
+  assert np.abs(res[True][1][:2] - ref['s_out']).max() < 1e-3

@@ -3,7 +3,9 @@
 profiles/r01_pmc_encoder_traffic.json.
 
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <REPS>
-       <images> <size> <out.json>
+       <images> <size> <out.json> [kernel-substring,kernel-substring,...]
+The optional last argument selects the kernels of the group (default: the controller-CNN kernels
+ra::conv:: / ra::cpair::; e.g. "ra::attnd::" for the extract + paste pair).
 
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  Per MI355X_MICROARCH.md (HBM section) gfx950's
 FETCH_SIZE tallies 128-B requests as 64 B, so it is doubled; WRITE_SIZE is taken as is.  Only the
@@ -14,9 +16,12 @@ last REPS x launches_per_group dispatches of the run.
 import csv, json, sys
 
 
+KEYS = ['ra::conv::', 'ra::cpair::']
+
+
 def tail_sum(path, counter, reps):
   rows = [r for r in csv.DictReader(open(path))
-          if r['Counter_Name'] == counter and ('ra::conv::' in r['Kernel_Name'] or 'ra::cpair::' in r['Kernel_Name'])]
+          if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in KEYS)]
   rows.sort(key=lambda r: int(r['Dispatch_Id']))
   # the eager group launches are the tail of the run; find the group length from the repeating
   # kernel-name pattern at the end
@@ -36,6 +41,8 @@ def tail_sum(path, counter, reps):
 
 def main():
   fcsv, wcsv, reps, images, size, out = sys.argv[1:7]
+  if len(sys.argv) > 7:
+    KEYS[:] = sys.argv[7].split(',')
   reps = int(reps)
   glen, fetch_kib, fk = tail_sum(fcsv, 'FETCH_SIZE', reps)
   glen2, write_kib, wk = tail_sum(wcsv, 'WRITE_SIZE', reps)
