@@ -187,6 +187,7 @@ def main():
                   help='which launch group --pmc-group repeats: the encoder, extract+paste, or the whole tail')
   ap.add_argument('--attn-b32', action='store_true', help='also time extract+paste at B=32 (roofline_attn.at_B32)')
   ap.add_argument('--no-fuse-patchnet', action='store_true', help='tuning aid: per-layer patch-net launches')
+  ap.add_argument('--no-cache-first', action='store_true', help='tuning aid: recompute the whole first layer per timestep')
   args = ap.parse_args()
 
   import ra_dist
@@ -205,6 +206,7 @@ def main():
   eng.nsub = args.nsub
   eng.fuse_score = not args.no_fuse_score
   eng.fuse_patchnet = not args.no_fuse_patchnet
+  eng.cache_first = not args.no_cache_first
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
   if args.host_input:
@@ -221,7 +223,7 @@ def main():
     for _ in range(args.pmc_group):
       if args.pmc_which == 'enc':
         eng._run_cnn(eng.plan['ccnn'], eng.W['ccnn'], sb['img'], sb['ccnn'], 0, 'ctrl_cnn',
-                     plane=sb.get('canvas'))
+                     plane=sb.get('canvas'), cache=sb.get('l0cache'))
       elif args.pmc_which == 'attn':
         ops.extract_direct(sb['img'], 0, sb['attn'][0], d['Fh'], d['Fw'], d['C0p'], True, sb['x_patch'][0],
                            canvas=sb['canvas'], canvas_chan=d['D'])
@@ -290,7 +292,8 @@ def main():
     def enc_step(step):
       first = step[1]
       src = sb['img'] if first == 0 else sb['ccnn'][first - 1]
-      eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], 0, 'ctrl_cnn', plane=sb.get('canvas'))
+      eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], 0, 'ctrl_cnn', plane=sb.get('canvas'),
+                   cache=sb.get('l0cache'))
 
     tot_f, per_f = encoder_flops_per_image(d)
     layers = []
@@ -300,6 +303,11 @@ def main():
       layers.append({'layers': list(step[1:]), 'fused': step[0] == 'pair', 'avg_us': us,
                      'gflop': fl * Bs / 1e9, 'tflops': fl * Bs / (us * 1e-6) / 1e12})
     enc_us = graph_time_us(lambda: [enc_step(st_) for st_ in eng.plan['ccnn']])
+    cache_us = 0.0
+    if 'l0cache' in sb:  # once per forward: its 1/T share belongs to every timestep's encoder time
+      cache_us = graph_time_us(lambda: ops.first_cache(sb['img'], Wt['ccnn'][0][0], d['ccnn_channels'][1], d['D'],
+                                                       sb['l0cache']), reps=10, inner=2)
+      enc_us += cache_us / T
     # compulsory HBM bytes of the group as launched: every launch reads its source once and
     # writes its (pooled) output once; the first also reads the canvas plane
     enc_bytes = 4.0 * sb['canvas'].numel() if 'canvas' in sb else 0.0
@@ -319,6 +327,13 @@ def main():
         'algorithmic_bytes_per_launch_group': enc_bytes,
         'peak_note': 'dense f32-input MFMA (v_mfma_f32_16x16x4_f32); the kernel computes in exact f32',
         'flop_per_launch_group': tot_f * Bs, 'avg_us_per_launch_group': enc_us,
+        'first_layer_cache': None if 'l0cache' not in sb else {
+            'us_per_forward': cache_us,
+            'note': 'the image channels\' share of layer 0 (27 of its 36 multiply-adds per output) is '
+                    'timestep-invariant and computed once per forward (SURVEY.md Appendix A); its 1/T share '
+                    'is included in avg_us_per_launch_group.  flop_per_launch_group stays the ALGORITHMIC '
+                    'count (SURVEY 8d), of which %.1f %% is no longer executed per timestep'
+                    % (100.0 * 0.75 * per_f[0] / tot_f)},
         'layers': layers}
 
     Hh = S

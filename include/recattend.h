@@ -117,6 +117,25 @@ int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsam
                      const float *wpB, const float *scaleB, const float *shiftB, int CoutB, int reluB,
                      int poolB, const float *plane, int plane_chan, float *y, void *stream);
 
+/* The first controller-CNN pair with the image part of layer A cached.  Of layer A's input
+ * concat(x, canvas) (full_model.py:640-661) only the canvas changes between timesteps
+ * (:843-848), and a convolution is linear in its input channels, so
+ *   S = sum_{taps, ci != plane_chan} x * W          (no bias, no BN)
+ * is computed ONCE per forward (ra_conv_first_cache_f32; `cache` holds it in the accumulator
+ * layout of the pair kernel, ra_conv_first_cache_floats() floats) and every timestep computes
+ *   A = relu?((S + conv(canvas, W[:, :, plane_chan, :])) * scaleA(tt) + shiftA(tt)),  B as in
+ * ra_conv_pair_f32 with poolB = 2 — 3 instead of 12 MFMA k-steps for layer A and 4 instead of 20
+ * staged bytes per pixel.  Cin = 4, CoutA = 8, CoutB <= 8 only (ra_conv_first_cache_supported);
+ * src [B,H,W,4] packed image, plane [B,H,W] the canvas, wpA packed for Cin = 4. */
+int ra_conv_first_cache_supported(int Cin, int CoutA, int CoutB, int poolB, int H, int W);
+size_t ra_conv_first_cache_floats(int B, int H, int W);
+int ra_conv_first_cache_f32(const float *src, int B, int H, int W, const float *wpA, int CoutA,
+                            int plane_chan, float *cache, void *stream);
+int ra_conv_pair_cached_f32(const float *cache, const float *plane, int plane_chan, int B, int H,
+                            int W, const float *wpA, const float *scaleA, const float *shiftA,
+                            int reluA, const float *wpB, const float *scaleB, const float *shiftB,
+                            int CoutB, int reluB, float *y, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * K2  controller: glimpse read-out + LSTM + glimpse MLP (x iters) + controller MLP +
  * attention-parameter decode.  Replaces full_model.py:668-722 (= box_model.py:416-468):

@@ -25,6 +25,8 @@ struct PArgs {
   const float *plane;  // optional [B,Hs,Ws] plane replacing input channel plane_chan (the canvas)
   int plane_chan;
   int bytes0, bytes_p;  // tensor sizes for the buffer descriptors (each < 2 GiB)
+  const float *cache;   // conv_pair8 CACHED form: layer A's timestep-invariant partial sums
+  int cache_rows, cache_gx, bytes_c;
 };
 
 template <int CINA, int CMID, int NCB, int GX, int GYB>
@@ -302,13 +304,22 @@ struct NGeo {
 #ifndef RA_PAIR8_OCC
 #define RA_PAIR8_OCC 3  // workgroups per CU: 3 x 38.7 KB LDS, <= 168 VGPRs (4 spills)
 #endif
-template <int CINA>
+// CACHED form (CINA == 4 only): of layer A's input only the canvas channel changes between
+// timesteps (full_model.py:640-661,843-848), so the contribution of the image channels,
+// S[pixel][co] = sum_{tap, ci != canvas} x * W (no bias, no BN), is computed ONCE per forward by
+// first_cache_kernel into the accumulator layout of phase A; per timestep layer A is then
+//   acc = S * scale(tt) + shift(tt)  (+)  3 MFMAs over the 3 x 4 canvas window
+// instead of 12 MFMAs over the 4-channel window, and only the 4-byte canvas plane is staged.
+template <int CINA, bool CACHED>
 __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = NGeo<CINA>;
   constexpr int NCGA = G::NCGA;
+  static_assert(!CACHED || CINA == 4, "cached form: 4 input channels");
+  constexpr int RECA = CACHED ? 1 : CINA;  // floats per staged input pixel
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *tin = lds;                  // [LH][LW] records [ksub][cg]  (channel = 4*cg + ksub)
-  float *tmid = lds + G::IN_FLOATS;  // [AHS][AW] records [ksub][cg], 8 channels
+  constexpr int IN_FLOATS = (G::LH * G::LW * RECA + 3) & ~3;
+  float *tin = lds;              // [LH][LW] records [ksub][cg]  (channel = 4*cg + ksub); CACHED: the canvas only
+  float *tmid = lds + IN_FLOATS;  // [AHS][AW] records [ksub][cg], 8 channels
   typedef typename vec_of<NCGA>::type avecA;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -326,7 +337,16 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
   const float loA = a.reluA ? 0.f : -__builtin_inff(), loB = a.reluB ? 0.f : -__builtin_inff();
   // W' of both layers, once per workgroup: one dword per (tap', cg) per lane, zero where the
   // tap misses pixel p
-  float bA[12][NCGA], bB[12][2];
+  float bA[CACHED ? 1 : 12][NCGA], bB[12][2];
+  float bAc[3];  // CACHED: k = the 4 window columns of row ky of the canvas channel alone
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int kx = ksub - p;
+    const bool ok = (kx >= 0) & (kx <= 2);
+    const int tap = ok ? ky * 3 + kx : 0;
+    const float w = a.wpA[((tap * NCGA + (a.plane_chan >> 2)) * 4 + (a.plane_chan & 3)) * a.CoutAP + co];
+    bAc[ky] = (CACHED && ok) ? w * scA : 0.f;
+  }
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -334,10 +354,12 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
       const int kx = kxp - p;
       const bool ok = (kx >= 0) & (kx <= 2);
       const int tap = ok ? ky * 3 + kx : 0;
+      if constexpr (!CACHED) {
 #pragma unroll
-      for (int cg = 0; cg < NCGA; ++cg) {
-        const float w = a.wpA[((tap * NCGA + cg) * 4 + ksub) * a.CoutAP + co];
-        bA[ky * 4 + kxp][cg] = ok ? w * scA : 0.f;
+        for (int cg = 0; cg < NCGA; ++cg) {
+          const float w = a.wpA[((tap * NCGA + cg) * 4 + ksub) * a.CoutAP + co];
+          bA[ky * 4 + kxp][cg] = ok ? w * scA : 0.f;
+        }
       }
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
@@ -370,15 +392,20 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
       const int Y = fy0 + e_rr[i], X = fx0 + e_cc[i];
       const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
       const int pix = (fb * a.H + Y) * a.W + X;
+      if constexpr (!CACHED) {
 #pragma unroll
-      for (int cg = 0; cg < NCGA; ++cg)
-        v[i][cg] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (pix * CINA + 4 * cg) * 4 : 0x7fffffff, 0, 0));
+        for (int cg = 0; cg < NCGA; ++cg)
+          v[i][cg] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (pix * CINA + 4 * cg) * 4 : 0x7fffffff, 0, 0));
+      }
       pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ok ? pix * 4 : 0x7fffffff, 0, 0));
     }
   };
 
-  const int lane_in = ((m >> 2) * G::LW + 2 * (m & 3)) * CINA + ksub * NCGA;
+  const int lane_in = CACHED ? (m >> 2) * G::LW + 2 * (m & 3) + ksub
+                             : ((m >> 2) * G::LW + 2 * (m & 3)) * CINA + ksub * NCGA;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(CACHED ? a.cache : a.src), 0, CACHED ? a.bytes_c : 0, 0x00020000);
   const int chpos = (co & 3) * 2 + (co >> 2);
   const int lane_mid = (qo * G::AW + p) * 8 + chpos;
   const int lane_b = ((m & 1) * G::AW + 2 * (m >> 1) + 1) * 8 + ksub * 2;
@@ -388,7 +415,7 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
   if (tile < ntiles) fetch(tile);
   // the padded groups read LDS this kernel never writes; whatever an earlier kernel left there
   // must not be NaN/Inf (their results are discarded, but keep the arithmetic clean)
-  for (int e = tid; e < (G::IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
+  for (int e = tid; e < (IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
     reinterpret_cast<f32x4 *>(lds)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
@@ -398,6 +425,10 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
     // ---------------- stage layer A's input window (prefetched registers -> LDS) ----------------
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
+      if constexpr (CACHED) {
+        if (e_rr[i] >= 0) tin[e_rr[i] * G::LW + e_cc[i]] = pv[i];
+        continue;
+      }
       if (a.plane) {
 #pragma unroll
         for (int cg = 0; cg < NCGA; ++cg) {  // selects, not runtime register indexing
@@ -435,9 +466,29 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
         int gi = wave + 4 * s;
         if (gi >= G::NGA) gi = G::NGA - 1;  // duplicate work, masked at the store
         const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
-        gin[s] = (4 * gr * G::LW + 8 * gc) * CINA + lane_in;
-        acc[s] = f32x4{shA, shA, shA, shA};
+        gin[s] = (4 * gr * G::LW + 8 * gc) * RECA + lane_in;
+        if constexpr (CACHED) {
+          // this lane's 4 partial sums (rows 4*qo + r of the group) are one float4 of the cache:
+          // [image][row ty0-1+4gr+qo (+1)][column group tx0/8+gc][n][r]
+          const int crow = ty0 + 4 * gr + qo, cgx = (tx0 >> 3) + gc;
+          const int off = (((b * a.cache_rows + crow) * a.cache_gx + cgx) * 16 + n) * 16;
+          const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0));
+          acc[s] = c * scA + shA;
+        } else {
+          acc[s] = f32x4{shA, shA, shA, shA};
+        }
       }
+      if constexpr (CACHED) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          float av[G::GPW];
+#pragma unroll
+          for (int s = 0; s < G::GPW; ++s) av[s] = tin[gin[s] + ky * G::LW];
+#pragma unroll
+          for (int s = 0; s < G::GPW; ++s)
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bAc[ky], acc[s], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -452,6 +503,7 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
             for (int s = 0; s < G::GPW; ++s)
               acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[ky * 4 + kxp][cg], acc[s], 0, 0, 0);
         }
+      }
 #pragma unroll
       for (int s = 0; s < G::GPW; ++s) {
         const int gi = wave + 4 * s;
@@ -519,11 +571,11 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
   }
 }
 
-template <int CINA>
+template <int CINA, bool CACHED = false>
 int launch8(const PArgs &a, int B, hipStream_t st) {
   using G = NGeo<CINA>;
-  auto kern = conv_pair8_mfma<CINA>;
-  constexpr size_t lds = (size_t)(G::IN_FLOATS + G::MID_FLOATS) * sizeof(float);
+  auto kern = conv_pair8_mfma<CINA, CACHED>;
+  constexpr size_t lds = (size_t)(((G::LH * G::LW * (CACHED ? 1 : CINA) + 3) & ~3) + G::MID_FLOATS) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -539,6 +591,53 @@ int launch8(const PArgs &a, int B, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(ntiles < wgs ? ntiles : wgs), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_f32");
+}
+
+// Timestep-invariant partial sums of the N-packed pair's layer A (see conv_pair8_mfma, CACHED):
+//   S[b][Y+1][gx][n = p*8 + co][r] = sum_{ky,kx} sum_{ci != plane_chan} x[b][Y+ky-1][X+kx-1][ci] * W[ky][kx][ci][co]
+// with X = 8*gx - 2 + 2*r + p (SAME zero padding; 0 for pixels outside the image), i.e. exactly
+// the float4 a lane of phase A initialises its accumulator with.  One thread per (b, row, gx, n).
+__global__ __launch_bounds__(256) void first_cache_kernel(const float *x, const float *wpA, int CoutAP, int plane_chan,
+                                                          int B, int H, int W, int rows, int ngx, float *cache) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * rows * ngx * 16;
+  if (idx >= total) return;
+  const int n = (int)(idx & 15);
+  long rest = idx >> 4;
+  const int gx = (int)(rest % ngx);
+  rest /= ngx;
+  const int row = (int)(rest % rows), b = (int)(rest / rows);
+  const int p = n >> 3, co = n & 7;
+  const int Y = row - 1;
+  f32x4 out = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (Y >= 0 && Y < H) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int X = 8 * gx - 2 + 2 * r + p;
+      if (X < 0 || X >= W) continue;
+      float acc = 0.f;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = Y + ky - 1;
+        if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = X + kx - 1;
+          if (xx < 0 || xx >= W) continue;
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((size_t)(b * H + yy) * W + xx) * 4);
+          const float *wt = wpA + (size_t)((ky * 3 + kx) * 4) * CoutAP + co;
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci)
+            if (ci != plane_chan) acc = fmaf(v[ci], wt[ci * CoutAP], acc);
+        }
+      }
+      out[r] = acc;
+    }
+  }
+  *reinterpret_cast<f32x4 *>(cache + idx * 4) = out;
+}
+
+inline void cache_dims(int H, int W, int &rows, int &ngx) {
+  rows = ceil_div(H, NGeo<4>::TH) * NGeo<4>::TH + 4;
+  ngx = ceil_div(W, NGeo<4>::TW) * (NGeo<4>::TW / 8) + 1;
 }
 
 template <int CINA, int CMID, int NCB, int GX, int GYB>
@@ -647,6 +746,8 @@ extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws
   const size_t bytes0 = (size_t)B * Hs * Ws * Cin * 4;
   a.bytes0 = (int)bytes0;
   a.bytes_p = (int)((size_t)B * Hs * Ws * 4);
+  a.cache = nullptr;
+  a.cache_rows = a.cache_gx = a.bytes_c = 0;
   static int no8 = -1;  // RA_PAIR_NO8=1: tuning aid, disables the N-packed kernel
   if (no8 < 0) no8 = getenv("RA_PAIR_NO8") ? 1 : 0;
   if (!no8 && CoutA == 8 && CoutB <= 8 && poolB == 2 && !a.ups && bytes0 < (1u << 31) && a.W > 16) {
@@ -659,4 +760,73 @@ extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws
     case 16: return cpair::dispatch_mid<16>(a, CoutA, B, st);
     default: return cpair::dispatch_mid<32>(a, CoutA, B, st);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CACHED form of the N-packed first pair (controller CNN L0 + L1 on the 4-channel packed image):
+// ra_conv_first_cache_f32 once per forward, ra_conv_pair_cached_f32 per timestep.
+extern "C" int ra_conv_first_cache_supported(int Cin, int CoutA, int CoutB, int poolB, int H, int W) {
+  return Cin == 4 && CoutA == 8 && CoutB >= 1 && CoutB <= 8 && poolB == 2 && W > 16 && !((H | W) & 1);
+}
+
+extern "C" size_t ra_conv_first_cache_floats(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  int rows, ngx;
+  cpair::cache_dims(H, W, rows, ngx);
+  return (size_t)B * rows * ngx * 64;
+}
+
+extern "C" int ra_conv_first_cache_f32(const float *src, int B, int H, int W, const float *wpA, int CoutA,
+                                       int plane_chan, float *cache, void *stream) {
+  if (!src || !wpA || !cache || B <= 0 || H <= 0 || W <= 0 || plane_chan < 0 || plane_chan > 3)
+    return fail(RA_E_INVALID, "ra_conv_first_cache_f32: bad argument");
+  if (CoutA != 8) return fail(RA_E_SHAPE, "ra_conv_first_cache_f32: CoutA %d", CoutA);
+  int rows, ngx;
+  cpair::cache_dims(H, W, rows, ngx);
+  const size_t total = (size_t)B * rows * ngx * 16;
+  if (total * 16 >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_first_cache_f32: cache exceeds 2 GiB");
+  hipLaunchKernelGGL(cpair::first_cache_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     src, wpA, ra_conv_cout_padded(CoutA), plane_chan, B, H, W, rows, ngx, cache);
+  return launch_status("ra_conv_first_cache_f32");
+}
+
+extern "C" int ra_conv_pair_cached_f32(const float *cache, const float *plane, int plane_chan, int B, int H, int W,
+                                       const float *wpA, const float *scaleA, const float *shiftA, int reluA,
+                                       const float *wpB, const float *scaleB, const float *shiftB, int CoutB,
+                                       int reluB, float *y, void *stream) {
+  if (!cache || !plane || !wpA || !scaleA || !shiftA || !wpB || !scaleB || !shiftB || !y || B <= 0)
+    return fail(RA_E_INVALID, "ra_conv_pair_cached_f32: bad argument");
+  if (!ra_conv_first_cache_supported(4, 8, CoutB, 2, H, W) || plane_chan < 0 || plane_chan > 3)
+    return fail(RA_E_SHAPE, "ra_conv_pair_cached_f32: unsupported shape");
+  cpair::PArgs a;
+  a.src = plane;  // unused by the cached form (only the canvas plane is staged)
+  a.y = y;
+  a.wpA = wpA;
+  a.scA = scaleA;
+  a.shA = shiftA;
+  a.wpB = wpB;
+  a.scB = scaleB;
+  a.shB = shiftB;
+  a.C0 = 4;
+  a.Hs = a.H = H;
+  a.Ws = a.W = W;
+  a.ups = 0;
+  a.CoutAP = ra_conv_cout_padded(8);
+  a.CoutB = CoutB;
+  a.CoutBP = ra_conv_cout_padded(CoutB);
+  a.poolB = 2;
+  a.Ho = H / 2;
+  a.Wo = W / 2;
+  a.reluA = reluA;
+  a.reluB = reluB;
+  a.plane = plane;
+  a.plane_chan = plane_chan;
+  a.bytes0 = 0;
+  a.bytes_p = (int)((size_t)B * H * W * 4);
+  a.cache = cache;
+  cpair::cache_dims(H, W, a.cache_rows, a.cache_gx);
+  const size_t cb = (size_t)B * a.cache_rows * a.cache_gx * 64 * sizeof(float);
+  if (cb >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_pair_cached_f32: cache exceeds 2 GiB");
+  a.bytes_c = (int)cb;
+  return cpair::launch8<4, true>(a, B, as_stream(stream));
 }

@@ -76,7 +76,7 @@ __device__ inline __amdgpu_buffer_rsrc_t rsrc(const void *p, int bytes) {
 // zero outside the image and, for a stride-2 transposed conv, on the stuffed positions
 // U[2i+1, 2j+1] = x[i, j].  LDS record of a pixel: [ksub 0..3][cg] (channel = 4*cg + ksub), so one
 // wide ds_read fetches a lane's A operands of all k-steps of a tap.
-template <int NCG>
+template <int NCG, bool SC1>
 __device__ inline void stage(const Phase &P, int ups, int RH, int RW, int b, int ry0, int rx0, int rh, int rw,
                              float *lds) {
   const __amdgpu_buffer_rsrc_t rs = rsrc(P.src, P.src_bytes);
@@ -96,7 +96,7 @@ __device__ inline void stage(const Phase &P, int ups, int RH, int RW, int b, int
     f32x4 v[NCG];
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg)
-      v[cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16 * cg, kSC1));
+      v[cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16 * cg, SC1 ? kSC1 : 0));
     if (e < npix) {
       float *rec = lds + e * (4 * NCG);
 #pragma unroll
@@ -119,11 +119,36 @@ struct vec_of {
 //   dst != nullptr: result -> LDS records of the next layer (CnN channels), zero outside the image
 //   else          : result -> global L.out (max-pooled if L.pool == 2), write-through stores
 template <int NCG>
+struct BOp {  // a wave's B operand (9 taps x NCG k-steps of one 16-cout tile) + its epilogue constants
+  float w[9 * NCG];
+  float sc, sh;
+  int ng;
+};
+
+// Issued BEFORE the wait for the previous phase: the weights do not depend on it, so their L2 / HBM
+// round trip hides behind the inter-workgroup hand-off instead of following it.
+template <int NCG>
+__device__ inline void load_b(const Layer &L, int ng, BOp<NCG> &B) {
+  constexpr int CK = NCG >= 4 ? 16 : 4 * NCG, NCGc = CK / 4;
+  const int lane = threadIdx.x & 63;
+  const int ksub = lane >> 4, n = lane & 15;
+  const float *wrow = L.wp + (size_t)ksub * L.CoutP + 16 * ng + n;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg)
+      B.w[tap * NCG + cg] = wrow[(size_t)((((cg / NCGc) * 9 + tap) * NCGc + (cg % NCGc)) * 4) * L.CoutP];
+  B.sc = L.scale[16 * ng + n];
+  B.sh = L.shift[16 * ng + n];
+  B.ng = ng;
+}
+
+template <int NCG, bool SC1>
 __device__ inline void conv_layer(const Layer &L, const float *src, int y0, int x0, int h, int w, float *dst,
-                                  int CnN, int b, int gw, int gstride) {
+                                  int CnN, int b, int gw, int gstride, BOp<NCG> &B) {
   typedef typename vec_of<NCG>::type avec;
   constexpr int Cin = 4 * NCG;
-  constexpr int CK = NCG >= 4 ? 16 : 4 * NCG, NCGc = CK / 4;
+  constexpr int AUX = SC1 ? kSC1 : 0;
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, ksub = lane >> 4, n = lane & 15, qo = lane >> 4;
   const int sw = w + 2;
@@ -135,22 +160,10 @@ __device__ inline void conv_layer(const Layer &L, const float *src, int y0, int 
   const int ntasks = ((nunits + upt - 1) / upt) * NNT;
   const float lo = L.relu ? 0.f : -__builtin_inff();
   const __amdgpu_buffer_rsrc_t ry = rsrc(L.out, L.out ? L.out_bytes : 0);
-  int cur_ng = -1;
-  float breg[9 * NCG];
-  float sc = 1.f, sh = 0.f;
   for (int t = gw; t < ntasks; t += gstride) {
     const int ng = t % NNT, mt = t / NNT;
-    if (ng != cur_ng) {
-      cur_ng = ng;
-      const float *wrow = L.wp + (size_t)ksub * L.CoutP + 16 * ng + n;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int cg = 0; cg < NCG; ++cg)
-          breg[tap * NCG + cg] = wrow[(size_t)((((cg / NCGc) * 9 + tap) * NCGc + (cg % NCGc)) * 4) * L.CoutP];
-      sc = L.scale[16 * ng + n];
-      sh = L.shift[16 * ng + n];
-    }
+    if (ng != B.ng) load_b<NCG>(L, ng, B);
+    const float sc = B.sc, sh = B.sh;
     int u = pl ? mt * 4 + (m >> 2) : mt * 16 + m;
     u = u < nunits ? u : nunits - 1;
     const int uy = u / wq, ux = u - uy * wq;
@@ -162,7 +175,7 @@ __device__ inline void conv_layer(const Layer &L, const float *src, int y0, int 
       const avec av = *reinterpret_cast<const avec *>(ap + ((tap / 3) * sw + (tap % 3)) * Cin);
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cg], breg[tap * NCG + cg], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cg], B.w[tap * NCG + cg], acc, 0, 0, 0);
     }
     const int co = 16 * ng + n;
     if (pl) {
@@ -173,7 +186,7 @@ __device__ inline void conv_layer(const Layer &L, const float *src, int y0, int 
         const int oy = uo / wq, ox = uo - oy * wq;
         const int gy = (y0 >> 1) + oy, gx = (x0 >> 1) + ox;
         const int off = (((b * (L.H >> 1) + gy) * (L.W >> 1) + gx) * L.Cout + co) * 4;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, kSC1);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, AUX);
       }
     } else {
 #pragma unroll
@@ -189,7 +202,7 @@ __device__ inline void conv_layer(const Layer &L, const float *src, int y0, int 
             if (co < CnN) dst[(oy * w + ox) * CnN + (co & 3) * (CnN >> 2) + (co >> 2)] = v;
           } else if (inside & (co < L.Cout)) {
             const int off = (((b * L.H + gy) * L.W + gx) * L.Cout + co) * 4;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, kSC1);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off, 0, AUX);
           }
         }
       }
@@ -197,68 +210,108 @@ __device__ inline void conv_layer(const Layer &L, const float *src, int y0, int 
   }
 }
 
-__device__ inline void stage_any(int ncg, const Phase &P, int ups, int RH, int RW, int b, int ry0, int rx0, int rh,
-                                 int rw, float *lds) {
-  switch (ncg) {
-    case 1: stage<1>(P, ups, RH, RW, b, ry0, rx0, rh, rw, lds); break;
-    case 2: stage<2>(P, ups, RH, RW, b, ry0, rx0, rh, rw, lds); break;
-    case 4: stage<4>(P, ups, RH, RW, b, ry0, rx0, rh, rw, lds); break;
-    default: stage<8>(P, ups, RH, RW, b, ry0, rx0, rh, rw, lds); break;
+template <int NCG, bool SC1>
+__device__ inline void chain_rest(const Args &a, const Phase &P, int k, int b, int ty0, int tx0, int gw, int gstride,
+                                  float *lds);
+
+// One phase for a workgroup whose first layer has 4*NCG input channels: prefetch that layer's B
+// operand, wait for the producers (fused launch only), stage, then run the chained layers.
+template <int NCG, bool SC1>
+__device__ inline void run_phase(const Args &a, int p, int p_begin, int b, int wg, int wave, int *cnt, float *lds) {
+  const Phase &P = a.P[p];
+  const Layer &L0 = a.L[P.first];
+  const int gw = P.share == 1 ? wave : wg * 4 + wave, gstride = 4 * P.share;
+  BOp<NCG> B0;
+  load_b<NCG>(L0, gw % (L0.CoutP >> 4), B0);
+  if (p > p_begin) {  // every workgroup of this image has published phase p - 1
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kNW * (p - p_begin)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) {
+          if (a.status) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int tile = P.share == 1 ? wg : 0;
+  const int ty0 = (tile / P.tiles_x) * P.TH, tx0 = (tile % P.tiles_x) * P.TW;
+  const int n = P.n;
+  // staged input: the tile grown by one pixel per chained layer
+  stage<NCG, SC1>(P, L0.ups, L0.H, L0.W, b, ty0 - n, tx0 - n, P.TH + 2 * n, P.TW + 2 * n, lds);
+  __syncthreads();
+  {
+    const int g = n - 1;
+    float *dst = n > 1 ? lds + a.lds_half : nullptr;
+    const int CnN = n > 1 ? 4 * a.L[P.first + 1].NCG : 0;
+    conv_layer<NCG, SC1>(L0, lds, ty0 - g, tx0 - g, P.TH + 2 * g, P.TW + 2 * g, dst, CnN, b, gw, gstride, B0);
+  }
+  if (n > 1) {
+    __syncthreads();
+    switch (a.L[P.first + 1].NCG) {
+      case 1: chain_rest<1, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
+      case 2: chain_rest<2, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
+      case 4: chain_rest<4, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
+      default: chain_rest<8, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
+    }
   }
 }
 
-__device__ inline void conv_any(const Layer &L, const float *src, int y0, int x0, int h, int w, float *dst, int CnN,
-                                int b, int gw, int gstride) {
-  switch (L.NCG) {
-    case 1: conv_layer<1>(L, src, y0, x0, h, w, dst, CnN, b, gw, gstride); break;
-    case 2: conv_layer<2>(L, src, y0, x0, h, w, dst, CnN, b, gw, gstride); break;
-    case 4: conv_layer<4>(L, src, y0, x0, h, w, dst, CnN, b, gw, gstride); break;
-    default: conv_layer<8>(L, src, y0, x0, h, w, dst, CnN, b, gw, gstride); break;
+// Layers 1.. of a chain (LDS -> LDS -> ... -> global).  A third layer re-dispatches on its own
+// channel count; chains are at most kMaxChain long.
+template <int NCG, bool SC1>
+__device__ inline void chain_rest(const Args &a, const Phase &P, int k, int b, int ty0, int tx0, int gw, int gstride,
+                                  float *lds) {
+  const Layer &L = a.L[P.first + k];
+  const int n = P.n, g = n - 1 - k;
+  const float *src = lds + (k & 1) * a.lds_half;
+  float *dst = (k + 1 < n) ? lds + ((k + 1) & 1) * a.lds_half : nullptr;
+  const int CnN = (k + 1 < n) ? 4 * a.L[P.first + k + 1].NCG : 0;
+  BOp<NCG> B;
+  B.ng = -1;
+  conv_layer<NCG, SC1>(L, src, ty0 - g, tx0 - g, P.TH + 2 * g, P.TW + 2 * g, dst, CnN, b, gw, gstride, B);
+  if (k + 1 < n) {
+    __syncthreads();
+    if (k + 1 < kMaxChain) {
+      const Layer &Ln = a.L[P.first + k + 1];
+      const int g2 = n - 2 - k;
+      BOp<2> B2;  // the last layer of a 3-chain: 8 or 4 input channels on every supported net
+      BOp<1> B1;
+      B2.ng = B1.ng = -1;
+      const float *src2 = lds + ((k + 1) & 1) * a.lds_half;
+      if (Ln.NCG == 2)
+        conv_layer<2, SC1>(Ln, src2, ty0 - g2, tx0 - g2, P.TH + 2 * g2, P.TW + 2 * g2, nullptr, 0, b, gw, gstride, B2);
+      else
+        conv_layer<1, SC1>(Ln, src2, ty0 - g2, tx0 - g2, P.TH + 2 * g2, P.TW + 2 * g2, nullptr, 0, b, gw, gstride, B1);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void patchnet_kernel(const Args a) {
+// FUSED = true : phases [p_begin, p_end) in ONE launch, exchanged through L2 (sc1 + counters)
+// FUSED = false: the launch runs exactly one phase; the stream boundary is the synchronisation
+template <bool FUSED>
+__global__ __launch_bounds__(256) void patchnet_kernel(const Args a, int p_begin, int p_end) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x / kNW, wg = blockIdx.x - b * kNW;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int *cnt = a.cnt + b;
-  for (int p = 0; p < a.nphases; ++p) {
-    const Phase &P = a.P[p];
-    const Layer &L0 = a.L[P.first];
-    if (p > 0) {  // every workgroup of this image has published phase p - 1
-      if (threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kNW * p) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > kSpinLimit) {
-            if (a.status) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
+  for (int p = p_begin; p < p_end; ++p) {
+    switch (a.L[a.P[p].first].NCG) {
+      case 1: run_phase<1, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
+      case 2: run_phase<2, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
+      case 4: run_phase<4, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
+      default: run_phase<8, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
+    }
+    if (FUSED && p + 1 < p_end) {
+      // publish: every storing wave drains its write-through stores, then ONE arrival per workgroup
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int tile = P.share == 1 ? wg : 0;
-    const int ty0 = (tile / P.tiles_x) * P.TH, tx0 = (tile % P.tiles_x) * P.TW;
-    const int n = P.n;
-    // staged input: the tile grown by one pixel per chained layer
-    stage_any(L0.NCG, P, L0.ups, L0.H, L0.W, b, ty0 - n, tx0 - n, P.TH + 2 * n, P.TW + 2 * n, lds);
-    __syncthreads();
-    const int gw = P.share == 1 ? wave : wg * 4 + wave, gstride = 4 * P.share;
-    for (int k = 0; k < n; ++k) {
-      const Layer &L = a.L[P.first + k];
-      const int g = n - 1 - k;  // growth of this layer's output region
-      const float *src = lds + (k & 1) * a.lds_half;
-      float *dst = (k + 1 < n) ? lds + ((k + 1) & 1) * a.lds_half : nullptr;
-      const int CnN = (k + 1 < n) ? 4 * a.L[P.first + k + 1].NCG : 0;
-      conv_any(L, src, ty0 - g, tx0 - g, P.TH + 2 * g, P.TW + 2 * g, dst, CnN, b, gw, gstride);
-      if (k + 1 < n) __syncthreads();
-    }
-    // publish: every storing wave drains its write-through stores, then ONE arrival per workgroup
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (p_end != a.nphases) return;
   // score rider: one workgroup per image, after the core layer's phase (which it has waited for)
   if (a.s_out && wg == kNW - 1) {
     __shared__ float red[4];
@@ -266,7 +319,8 @@ __global__ __launch_bounds__(256) void patchnet_kernel(const Args a) {
     float s = 0.f;
     for (int k = threadIdx.x; k < a.K0; k += 256) s += a.h[(size_t)b * a.K0 + k] * a.sw[k];
     for (int k = threadIdx.x; k < a.K1; k += 256) {
-      const float cv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (b * a.K1 + k) * 4, 0, kSC1));
+      const float cv = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rc, (b * a.K1 + k) * 4, 0, FUSED ? kSC1 : 0));
       s += cv * a.sw[a.K0 + k];
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -277,8 +331,8 @@ __global__ __launch_bounds__(256) void patchnet_kernel(const Args a) {
       a.s_out[(size_t)b * a.s_stride_b] = 1.f / (1.f + __expf(-z));
     }
   }
-  // the last workgroup of the image to finish re-arms the counters for the next launch / replay
-  if (threadIdx.x == 0) {
+  // the last workgroup of the image to finish re-arms the counter for the next launch / replay
+  if (FUSED && threadIdx.x == 0) {
     const int old = __hip_atomic_fetch_add(a.done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == kNW - 1) {
       __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -465,11 +519,26 @@ extern "C" int ra_patchnet_f32(const ra_pnet_layer *layers, int n_layers, int co
   }
   const size_t lds = (size_t)pl.lds_half * 2 * sizeof(float);
   static bool attr = false;
+  static int mode = -1;  // RA_PNET_MODE: 0 = one launch per phase (default), 1 = one launch, L2 hand-offs
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pnet::patchnet_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pnet::patchnet_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pnet::patchnet_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    const char *e = getenv("RA_PNET_MODE");
+    mode = e ? atoi(e) : 0;
     attr = true;
   }
-  hipLaunchKernelGGL(pnet::patchnet_kernel, dim3(B * pnet::kNW), dim3(256), lds, as_stream(stream), a);
-  return launch_status("ra_patchnet_f32");
+  if (mode == 1) {
+    hipLaunchKernelGGL(pnet::patchnet_kernel<true>, dim3(B * pnet::kNW), dim3(256), lds, as_stream(stream), a, 0,
+                       pl.nphases);
+    return launch_status("ra_patchnet_f32");
+  }
+  for (int p = 0; p < pl.nphases; ++p) {
+    hipLaunchKernelGGL(pnet::patchnet_kernel<false>, dim3(B * pnet::kNW), dim3(256), lds, as_stream(stream), a, p,
+                       p + 1);
+    const int rc2 = launch_status("ra_patchnet_f32");
+    if (rc2) return rc2;
+  }
+  return 0;
 }

@@ -46,6 +46,7 @@ class DecodeEngine(object):
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
     self.fuse_score = True  # score MLP as an extra workgroup of the paste launch
     self.fuse_patchnet = True  # attention CNN + DCNN + score as ONE launch (K4) where supported
+    self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -261,6 +262,10 @@ class DecodeEngine(object):
       b['fx'] = f(Bs, W, Fw)
       b['band'] = torch.zeros((Bs, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32,
                               device=device)
+      st0 = self.plan['ccnn'][0]
+      if self.cache_first and self.direct_attn and st0[0] == 'pair' and d['C0p'] == 4 and \
+          ops.first_cache_supported(4, d['ccnn_channels'][1], d['ccnn_channels'][2], d['ccnn_pool'][1], H, W):
+        b['l0cache'] = ops.first_cache_alloc(Bs, H, W, device)
       if self.split_ok and Bs <= 14:
         b['ctrl_ws'], b['ctrl_status'] = ops.ctrl_split_workspace(self.desc, Bs, device)
       if self.box:
@@ -347,7 +352,7 @@ class DecodeEngine(object):
 
   def _launch_encoder(self, b, tt):
     return self._run_cnn(self.plan['ccnn'], self.W['ccnn'], b['img'], b['ccnn'], tt, 'ctrl_cnn',
-                         plane=b.get('canvas'))
+                         plane=b.get('canvas'), cache=b.get('l0cache'))
 
   def _launch_pack(self, b):
     ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), self.d['C0p'], b['img'])
@@ -357,6 +362,8 @@ class DecodeEngine(object):
         # every pixel outside an attention window is sigmoid(0 - 5) (full_model.py:813-818): fill
         # once per forward at memset speed, the per-timestep paste then writes windows only
         ops.fill(b['y_out'], 1.0 / (1.0 + math.exp(5.0)))
+    if 'l0cache' in b:  # the image channels' share of ctrl-CNN layer 0: the same for every timestep
+      ops.first_cache(b['img'], self.W['ccnn'][0][0], self.d['ccnn_channels'][1], self.d['D'], b['l0cache'])
     self._mark('pack')
 
   def _launch_tail(self, b, tt, want_box, src):
@@ -449,15 +456,19 @@ class DecodeEngine(object):
                        b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
     self._mark('paste')
 
-  def _run_cnn(self, steps, layers, src, bufs, tt, name, plane=None):
-    """plane: the canvas plane standing in for channel D of the FIRST layer's packed input."""
+  def _run_cnn(self, steps, layers, src, bufs, tt, name, plane=None, cache=None):
+    """plane: the canvas plane standing in for channel D of the FIRST layer's packed input;
+    cache: the first layer's timestep-invariant image part (ops.first_cache)."""
     pc = self.d['D'] if plane is not None else -1
     for step in steps:
       pl = plane if step[1] == 0 else None
       if step[0] == 'pair':
         (wpa, sca, sha, ca, _), (wpb, scb, shb, cb, poolb) = layers[step[1]], layers[step[2]]
-        ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=poolb,
-                      out=bufs[step[2]], plane=pl, plane_chan=pc if pl is not None else -1)
+        if cache is not None and pl is not None:
+          ops.conv_pair_cached(cache, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, bufs[step[2]])
+        else:
+          ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=poolb,
+                        out=bufs[step[2]], plane=pl, plane_chan=pc if pl is not None else -1)
         src = bufs[step[2]]
         self._mark('%s_L%d+%d' % (name, step[1], step[2]))
       else:

@@ -91,6 +91,10 @@ SIGNATURES = {
     'ra_random_transform_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ra_fill_f32': (_I, [_P, _Z, _F, _P]),
+    'ra_conv_first_cache_supported': (_I, [_I, _I, _I, _I, _I, _I]),
+    'ra_conv_first_cache_floats': (_Z, [_I, _I, _I]),
+    'ra_conv_first_cache_f32': (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),
+    'ra_conv_pair_cached_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'ra_patchnet_supported': (_I, [_P, _I, _I, _I, _I]),
     'ra_patchnet_workspace_bytes': (_Z, [_P, _I, _I, _I, _I]),
     'ra_patchnet_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _Z, _P, _Z, _P, _P]),

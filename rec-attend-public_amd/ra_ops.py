@@ -185,6 +185,33 @@ def conv_pair(src, wpA, scA, shA, coutA, wpB, scB, shB, coutB, poolB=1, upsample
   return out
 
 
+def first_cache_supported(cin, cout_a, cout_b, pool_b, H, W):
+  return bool(rn.lib().ra_conv_first_cache_supported(int(cin), int(cout_a), int(cout_b), int(pool_b), int(H), int(W)))
+
+
+def first_cache_alloc(B, H, W, device):
+  return torch.zeros((rn.lib().ra_conv_first_cache_floats(B, H, W),), dtype=torch.float32, device=device)
+
+
+def first_cache(img, wpA, cout_a, plane_chan, cache):
+  """Once per forward: the image channels' share of the first conv layer (ra_conv_first_cache_f32)."""
+  _need_cuda(img, wpA, cache)
+  B, H, W, C = img.shape
+  assert C == 4
+  check(rn.lib().ra_conv_first_cache_f32(ptr(img), B, H, W, ptr(wpA), int(cout_a), int(plane_chan), ptr(cache),
+                                         rn.stream_ptr()), 'ra_conv_first_cache_f32')
+
+
+def conv_pair_cached(cache, plane, plane_chan, wpA, scA, shA, wpB, scB, shB, coutB, out, reluA=True, reluB=True):
+  """Per timestep: the first controller-CNN pair from the cached image part + the canvas plane."""
+  _need_cuda(cache, plane, wpA, scA, shA, wpB, scB, shB, out)
+  B, H, W = plane.shape
+  check(rn.lib().ra_conv_pair_cached_f32(ptr(cache), ptr(plane), int(plane_chan), B, H, W, ptr(wpA), ptr(scA),
+                                         ptr(shA), int(reluA), ptr(wpB), ptr(scB), ptr(shB), int(coutB),
+                                         int(reluB), ptr(out), rn.stream_ptr()), 'ra_conv_pair_cached_f32')
+  return out
+
+
 class PatchNet(object):
   """K4: the attention CNN + DCNN (+ score) of a timestep as ONE launch (ra_patchnet_f32).
   layers: [(wpacked, scale [T,CoutP], shift [T,CoutP], Cin, Cout, upsample, pool)] device tensors."""

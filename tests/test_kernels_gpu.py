@@ -464,11 +464,41 @@ def test_patchnet_fused_vs_per_layer(cuda, case):
     m.engine.fuse_patchnet = fused
     for rep in range(3):  # replays: the in-kernel counter re-arm
       res[fused] = m.run(names, {'x': x, 'phase_train': False}, as_numpy=True)
-    assert ('pnet_ws' in m.engine.subs[0]) == fused
-    if fused:
+    if fused and 'filter_height' not in case:  # the 32x32 patch exceeds the LDS budget: per-layer fallback
+      assert 'pnet_ws' in m.engine.subs[0]
       assert int(m.engine.subs[0]['pnet_status'].item()) == 0
+    if not fused:
+      assert 'pnet_ws' not in m.engine.subs[0]
   for a, b in zip(res[True], res[False]):
-    assert np.abs(a - b).max() < 1e-5
+    assert np.abs(a - b).max() < 1e-4
   ref = ora.full_model_forward(opt, P, x[:2])
   assert np.abs(res[True][0][:2] - ref['y_out_patch']).max() < 1e-3
   assert np.abs(res[True][1][:2] - ref['s_out']).max() < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 128, 160), (3, 48, 80)])
+def test_first_layer_cache_vs_plain_pair(cuda, shape):
+  """The cached form of the first controller-CNN pair (image part of layer 0 computed once,
+  canvas part per timestep) against the plain N-packed pair and the oracle."""
+  B, H, W = shape
+  rng = np.random.RandomState(11)
+  img = rng.rand(B, H, W, 4).astype(np.float32)
+  canvas = rng.rand(B, H, W).astype(np.float32)
+  wA, wB = (rng.randn(3, 3, 4, 8) * 0.3).astype(np.float32), (rng.randn(3, 3, 8, 8) * 0.2).astype(np.float32)
+  scA, shA = rng.uniform(0.5, 1.5, 16).astype(np.float32), rng.randn(16).astype(np.float32) * 0.1
+  scB, shB = rng.uniform(0.5, 1.5, 16).astype(np.float32), rng.randn(16).astype(np.float32) * 0.1
+  wpA, wpB = dev(ops.pack_conv_weights(wA), cuda), dev(ops.pack_conv_weights(wB), cuda)
+  d = lambda a: dev(a, cuda)
+  plain = ops.conv_pair(d(img), wpA, d(scA), d(shA), 8, wpB, d(scB), d(shB), 8, poolB=2, plane=d(canvas), plane_chan=3)
+  assert ops.first_cache_supported(4, 8, 8, 2, H, W)
+  cache = ops.first_cache_alloc(B, H, W, cuda)
+  ops.first_cache(d(img), wpA, 8, 3, cache)
+  out = torch.empty_like(plain)
+  ops.conv_pair_cached(cache, d(canvas), 3, wpA, d(scA), d(shA), wpB, d(scB), d(shB), 8, out)
+  x = img.copy()
+  x[..., 3] = canvas
+  ref = ora.conv2d(x.astype(np.float64), wA.astype(np.float64)) * scA[:8] + shA[:8]
+  ref = ora.conv2d(np.maximum(ref, 0), wB.astype(np.float64)) * scB[:8] + shB[:8]
+  ref = ora.max_pool(np.maximum(ref, 0), 2)
+  assert np.abs(plain.cpu().numpy() - ref).max() < 1e-4
+  assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
