@@ -432,6 +432,19 @@ int ra_patchnet_f32(const ra_pnet_layer *layers, int n_layers, int core_layer, c
                     const float *w, const float *bias, float *s_out, size_t s_stride_b, void *ws,
                     size_t ws_bytes, int *status_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Training step (full_model.py:1039-1057).
+ * ra_adam_step_f32 — gradient clip + Adam on one flat float32 bucket of n parameters:
+ *   g = clip(grads * grad_scale + wd_coef * params, -clip, clip)   (wd_coef nullable; the
+ *       wd * l2_loss(w) terms of nnlib.py:59-61 belong to total_loss; grad_scale = 1 / world
+ *       after the data-parallel RCCL sum),
+ *   m, v, params updated as tf.train.AdamOptimizer does (epsilon outside the bias correction);
+ *   lr_t = learn_rate * sqrt(1 - beta2^t) / (1 - beta1^t) is computed by the caller.
+ * ---------------------------------------------------------------------------------- */
+int ra_adam_step_f32(float *params, const float *grads, float *m, float *v, const float *wd_coef,
+                     size_t n, float lr_t, float beta1, float beta2, float eps, float clip,
+                     float grad_scale, void *stream);
+
 /* p[0..n) = value (p 16-byte aligned): the canvas reset `canvas = zeros` (full_model.py:239) and
  * the sigmoid(beta) prefill of y_out behind RA_PASTE_Y_PREFILLED, as a library launch so that the
  * captured forward holds no framework kernel. */

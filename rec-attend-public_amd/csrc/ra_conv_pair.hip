@@ -596,43 +596,39 @@ int launch8(const PArgs &a, int B, hipStream_t st) {
 // Timestep-invariant partial sums of the N-packed pair's layer A (see conv_pair8_mfma, CACHED):
 //   S[b][Y+1][gx][n = p*8 + co][r] = sum_{ky,kx} sum_{ci != plane_chan} x[b][Y+ky-1][X+kx-1][ci] * W[ky][kx][ci][co]
 // with X = 8*gx - 2 + 2*r + p (SAME zero padding; 0 for pixels outside the image), i.e. exactly
-// the float4 a lane of phase A initialises its accumulator with.  One thread per (b, row, gx, n).
+// the float4 a lane of phase A initialises its accumulator with.  The cache must be zero-filled when
+// allocated: entries outside the image are never written.
 __global__ __launch_bounds__(256) void first_cache_kernel(const float *x, const float *wpA, int CoutAP, int plane_chan,
                                                           int B, int H, int W, int rows, int ngx, float *cache) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)B * rows * ngx * 16;
-  if (idx >= total) return;
-  const int n = (int)(idx & 15);
-  long rest = idx >> 4;
-  const int gx = (int)(rest % ngx);
-  rest /= ngx;
-  const int row = (int)(rest % rows), b = (int)(rest / rows);
-  const int p = n >> 3, co = n & 7;
-  const int Y = row - 1;
-  f32x4 out = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (Y >= 0 && Y < H) {
+  // one thread per image pixel, all 8 output channels: 9 float4 loads, 27 x 8 FMAs whose weights
+  // are wave-uniform (scalar loads); entries of the cache no pixel maps to stay at their zero fill
+  const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+  if (X >= W || Y >= H) return;
+  float acc[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int X = 8 * gx - 2 + 2 * r + p;
-      if (X < 0 || X >= W) continue;
-      float acc = 0.f;
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = Y + ky - 1;
-        if (yy < 0 || yy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-          const int xx = X + kx - 1;
-          if (xx < 0 || xx >= W) continue;
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((size_t)(b * H + yy) * W + xx) * 4);
-          const float *wt = wpA + (size_t)((ky * 3 + kx) * 4) * CoutAP + co;
+  for (int co = 0; co < 8; ++co) acc[co] = 0.f;
 #pragma unroll
-          for (int ci = 0; ci < 4; ++ci)
-            if (ci != plane_chan) acc = fmaf(v[ci], wt[ci * CoutAP], acc);
-        }
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = Y + ky - 1;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = X + kx - 1;
+      const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4 *>(x + ((size_t)(b * H + yy) * W + xx) * 4);
+      const float *wt = wpA + (size_t)((ky * 3 + kx) * 4) * CoutAP;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const float xv = ci == plane_chan ? 0.f : v[ci];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[co] = fmaf(xv, wt[ci * CoutAP + co], acc[co]);
       }
-      out[r] = acc;
     }
   }
-  *reinterpret_cast<f32x4 *>(cache + idx * 4) = out;
+  const int gx = (X + 2) >> 3, rem = (X + 2) & 7, r = rem >> 1, p = rem & 1;
+  float *dst = cache + ((((size_t)b * rows + (Y + 1)) * ngx + gx) * 16 + p * 8) * 4 + r;
+#pragma unroll
+  for (int co = 0; co < 8; ++co) dst[co * 4] = acc[co];
 }
 
 inline void cache_dims(int H, int W, int &rows, int &ngx) {
@@ -785,8 +781,8 @@ extern "C" int ra_conv_first_cache_f32(const float *src, int B, int H, int W, co
   cpair::cache_dims(H, W, rows, ngx);
   const size_t total = (size_t)B * rows * ngx * 16;
   if (total * 16 >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_first_cache_f32: cache exceeds 2 GiB");
-  hipLaunchKernelGGL(cpair::first_cache_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                     src, wpA, ra_conv_cout_padded(CoutA), plane_chan, B, H, W, rows, ngx, cache);
+  hipLaunchKernelGGL(cpair::first_cache_kernel, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0,
+                     as_stream(stream), src, wpA, ra_conv_cout_padded(CoutA), plane_chan, B, H, W, rows, ngx, cache);
   return launch_status("ra_conv_first_cache_f32");
 }
 

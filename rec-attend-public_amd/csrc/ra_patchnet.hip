@@ -68,7 +68,7 @@ struct Args {
   long s_stride_b;
 };
 
-__device__ inline __amdgpu_buffer_rsrc_t rsrc(const void *p, int bytes) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void *p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 
@@ -77,7 +77,7 @@ __device__ inline __amdgpu_buffer_rsrc_t rsrc(const void *p, int bytes) {
 // U[2i+1, 2j+1] = x[i, j].  LDS record of a pixel: [ksub 0..3][cg] (channel = 4*cg + ksub), so one
 // wide ds_read fetches a lane's A operands of all k-steps of a tap.
 template <int NCG, bool SC1>
-__device__ inline void stage(const Phase &P, int ups, int RH, int RW, int b, int ry0, int rx0, int rh, int rw,
+__device__ __forceinline__ void stage(const Phase &P, int ups, int RH, int RW, int b, int ry0, int rx0, int rh, int rw,
                              float *lds) {
   const __amdgpu_buffer_rsrc_t rs = rsrc(P.src, P.src_bytes);
   const int npix = rh * rw;
@@ -128,7 +128,7 @@ struct BOp {  // a wave's B operand (9 taps x NCG k-steps of one 16-cout tile) +
 // Issued BEFORE the wait for the previous phase: the weights do not depend on it, so their L2 / HBM
 // round trip hides behind the inter-workgroup hand-off instead of following it.
 template <int NCG>
-__device__ inline void load_b(const Layer &L, int ng, BOp<NCG> &B) {
+__device__ __forceinline__ void load_b(const Layer &L, int ng, BOp<NCG> &B) {
   constexpr int CK = NCG >= 4 ? 16 : 4 * NCG, NCGc = CK / 4;
   const int lane = threadIdx.x & 63;
   const int ksub = lane >> 4, n = lane & 15;
@@ -144,7 +144,7 @@ __device__ inline void load_b(const Layer &L, int ng, BOp<NCG> &B) {
 }
 
 template <int NCG, bool SC1>
-__device__ inline void conv_layer(const Layer &L, const float *src, int y0, int x0, int h, int w, float *dst,
+__device__ __forceinline__ void conv_layer(const Layer &L, const float *src, int y0, int x0, int h, int w, float *dst,
                                   int CnN, int b, int gw, int gstride, BOp<NCG> &B) {
   typedef typename vec_of<NCG>::type avec;
   constexpr int Cin = 4 * NCG;
@@ -210,26 +210,24 @@ __device__ inline void conv_layer(const Layer &L, const float *src, int y0, int 
   }
 }
 
-template <int NCG, bool SC1>
-__device__ inline void chain_rest(const Args &a, const Phase &P, int k, int b, int ty0, int tx0, int gw, int gstride,
-                                  float *lds);
-
 // One phase for a workgroup whose first layer has 4*NCG input channels: prefetch that layer's B
 // operand, wait for the producers (fused launch only), stage, then run the chained layers.
+// The phase / layer records are passed BY VALUE (scalar registers): taking the address of the
+// kernel-argument struct would make the compiler copy all of it to scratch memory.
 template <int NCG, bool SC1>
-__device__ inline void run_phase(const Args &a, int p, int p_begin, int b, int wg, int wave, int *cnt, float *lds) {
-  const Phase &P = a.P[p];
-  const Layer &L0 = a.L[P.first];
+__device__ __forceinline__ void run_phase(const Phase P, const Layer L0, const Layer L1, const Layer L2, int lds_half,
+                                          int *status, int wait_for, int b, int wg, int wave, int *cnt,
+                                          float *lds) {
   const int gw = P.share == 1 ? wave : wg * 4 + wave, gstride = 4 * P.share;
   BOp<NCG> B0;
   load_b<NCG>(L0, gw % (L0.CoutP >> 4), B0);
-  if (p > p_begin) {  // every workgroup of this image has published phase p - 1
+  if (wait_for > 0) {  // every workgroup of this image has published the previous phase
     if (threadIdx.x == 0) {
       int spins = 0;
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kNW * (p - p_begin)) {
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_for) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kSpinLimit) {
-          if (a.status) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (status) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
@@ -244,48 +242,35 @@ __device__ inline void run_phase(const Args &a, int p, int p_begin, int b, int w
   __syncthreads();
   {
     const int g = n - 1;
-    float *dst = n > 1 ? lds + a.lds_half : nullptr;
-    const int CnN = n > 1 ? 4 * a.L[P.first + 1].NCG : 0;
-    conv_layer<NCG, SC1>(L0, lds, ty0 - g, tx0 - g, P.TH + 2 * g, P.TW + 2 * g, dst, CnN, b, gw, gstride, B0);
+    conv_layer<NCG, SC1>(L0, lds, ty0 - g, tx0 - g, P.TH + 2 * g, P.TW + 2 * g, n > 1 ? lds + lds_half : nullptr,
+                         n > 1 ? 4 * L1.NCG : 0, b, gw, gstride, B0);
   }
-  if (n > 1) {
+  if (n > 1) {  // second layer: LDS -> LDS (-> third) or -> global
     __syncthreads();
-    switch (a.L[P.first + 1].NCG) {
-      case 1: chain_rest<1, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
-      case 2: chain_rest<2, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
-      case 4: chain_rest<4, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
-      default: chain_rest<8, SC1>(a, P, 1, b, ty0, tx0, gw, gstride, lds); break;
+    const int g = n - 2;
+    float *dst = n > 2 ? lds : nullptr;
+    const int CnN = n > 2 ? 4 * L2.NCG : 0;
+    const float *src = lds + lds_half;
+    const int y0 = ty0 - g, x0 = tx0 - g, h = P.TH + 2 * g, w = P.TW + 2 * g;
+    if (L1.NCG == 2) {
+      BOp<2> B;
+      B.ng = -1;
+      conv_layer<2, SC1>(L1, src, y0, x0, h, w, dst, CnN, b, gw, gstride, B);
+    } else if (L1.NCG == 4) {
+      BOp<4> B;
+      B.ng = -1;
+      conv_layer<4, SC1>(L1, src, y0, x0, h, w, dst, CnN, b, gw, gstride, B);
+    } else {
+      BOp<8> B;
+      B.ng = -1;
+      conv_layer<8, SC1>(L1, src, y0, x0, h, w, dst, CnN, b, gw, gstride, B);
     }
   }
-}
-
-// Layers 1.. of a chain (LDS -> LDS -> ... -> global).  A third layer re-dispatches on its own
-// channel count; chains are at most kMaxChain long.
-template <int NCG, bool SC1>
-__device__ inline void chain_rest(const Args &a, const Phase &P, int k, int b, int ty0, int tx0, int gw, int gstride,
-                                  float *lds) {
-  const Layer &L = a.L[P.first + k];
-  const int n = P.n, g = n - 1 - k;
-  const float *src = lds + (k & 1) * a.lds_half;
-  float *dst = (k + 1 < n) ? lds + ((k + 1) & 1) * a.lds_half : nullptr;
-  const int CnN = (k + 1 < n) ? 4 * a.L[P.first + k + 1].NCG : 0;
-  BOp<NCG> B;
-  B.ng = -1;
-  conv_layer<NCG, SC1>(L, src, ty0 - g, tx0 - g, P.TH + 2 * g, P.TW + 2 * g, dst, CnN, b, gw, gstride, B);
-  if (k + 1 < n) {
+  if (n > 2) {  // third layer -> global; its input has 8 channels on every supported net (checked on the host)
     __syncthreads();
-    if (k + 1 < kMaxChain) {
-      const Layer &Ln = a.L[P.first + k + 1];
-      const int g2 = n - 2 - k;
-      BOp<2> B2;  // the last layer of a 3-chain: 8 or 4 input channels on every supported net
-      BOp<1> B1;
-      B2.ng = B1.ng = -1;
-      const float *src2 = lds + ((k + 1) & 1) * a.lds_half;
-      if (Ln.NCG == 2)
-        conv_layer<2, SC1>(Ln, src2, ty0 - g2, tx0 - g2, P.TH + 2 * g2, P.TW + 2 * g2, nullptr, 0, b, gw, gstride, B2);
-      else
-        conv_layer<1, SC1>(Ln, src2, ty0 - g2, tx0 - g2, P.TH + 2 * g2, P.TW + 2 * g2, nullptr, 0, b, gw, gstride, B1);
-    }
+    BOp<2> B;
+    B.ng = -1;
+    conv_layer<2, SC1>(L2, lds, ty0, tx0, P.TH, P.TW, nullptr, 0, b, gw, gstride, B);
   }
 }
 
@@ -298,11 +283,15 @@ __global__ __launch_bounds__(256) void patchnet_kernel(const Args a, int p_begin
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int *cnt = a.cnt + b;
   for (int p = p_begin; p < p_end; ++p) {
-    switch (a.L[a.P[p].first].NCG) {
-      case 1: run_phase<1, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
-      case 2: run_phase<2, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
-      case 4: run_phase<4, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
-      default: run_phase<8, FUSED>(a, p, p_begin, b, wg, wave, cnt, lds); break;
+    const Phase P = a.P[p];
+    const int l1 = P.n > 1 ? P.first + 1 : P.first, l2 = P.n > 2 ? P.first + 2 : P.first;
+    const Layer L0 = a.L[P.first], L1 = a.L[l1], L2 = a.L[l2];
+    const int wait_for = (FUSED && p > p_begin) ? kNW * (p - p_begin) : 0;
+    switch (L0.NCG) {
+      case 1: run_phase<1, FUSED>(P, L0, L1, L2, a.lds_half, a.status, wait_for, b, wg, wave, cnt, lds); break;
+      case 2: run_phase<2, FUSED>(P, L0, L1, L2, a.lds_half, a.status, wait_for, b, wg, wave, cnt, lds); break;
+      case 4: run_phase<4, FUSED>(P, L0, L1, L2, a.lds_half, a.status, wait_for, b, wg, wave, cnt, lds); break;
+      default: run_phase<8, FUSED>(P, L0, L1, L2, a.lds_half, a.status, wait_for, b, wg, wave, cnt, lds); break;
     }
     if (FUSED && p + 1 < p_end) {
       // publish: every storing wave drains its write-through stores, then ONE arrival per workgroup
@@ -390,6 +379,9 @@ int make_plan(const ra_pnet_layer *ls, int nl, int Hp, int Wp, int C0, int B, Pl
     pl.TH[p] = tiled ? ch / 4 : ch;
     pl.TW[p] = tiled ? cw / 4 : cw;
     pl.tiles_x[p] = tiled ? 4 : 1;
+    if (n > 2 && ls[i + 2].Cin != 8) n = 2;   // the kernel's third chained layer is the 8-channel form
+    if (n > 1 && ls[i + 1].Cin == 4) n = 1;   // and its second one takes 8 / 16 / 32 channels
+    pl.n[p] = n;
     for (int k = 0; k < n; ++k) {  // LDS regions: staged input, then every chained intermediate
       const int g = n - k;         // growth of layer k's INPUT region
       const int fl = (pl.TH[p] + 2 * g) * (pl.TW[p] + 2 * g) * ls[i + k].Cin;

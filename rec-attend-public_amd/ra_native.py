@@ -91,6 +91,7 @@ SIGNATURES = {
     'ra_random_transform_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ra_fill_f32': (_I, [_P, _Z, _F, _P]),
+    'ra_adam_step_f32': (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P]),
     'ra_conv_first_cache_supported': (_I, [_I, _I, _I, _I, _I, _I]),
     'ra_conv_first_cache_floats': (_Z, [_I, _I, _I]),
     'ra_conv_first_cache_f32': (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),

@@ -52,3 +52,99 @@ def test_two_rank_gloo():
   assert all(abs(r[3] - 0.75) < 1e-12 for r in res)           # max over ranks
   full = np.stack([np.arange(8), 2 * np.arange(8)], 1).astype(np.float32)
   assert all((r[4] == full).all() for r in res)               # every image decoded exactly once
+
+
+# ---------------------------------------------------------------------------------------------
+# Data-parallel training step: ONE flat bucket, ONE all-reduce, then
+# scale -> weight decay -> clip -> Adam.  The collective and the bucket bookkeeping are the
+# product code (ra_train.GradBucket, gloo here, RCCL on the GPUs); the optimizer arithmetic the
+# HIP kernel performs is restated in NumPy below (its own parity test runs on the GPU).
+class _FakeModel(dict):
+  def __init__(self, tensors, opt):
+    dict.__init__(self, tensors)
+    self.opt = opt
+
+  def weight_keys(self):
+    return sorted(k for k, v in self.items() if isinstance(v, torch.Tensor))
+
+
+def _toy_model():
+  g = torch.Generator().manual_seed(7)
+  shapes = {'ctrl_cnn_w_0': (3, 3, 4, 8), 'ctrl_cnn_b_0': (8,), 'ctrl_cnn_0_0_beta': (8,), 'ctrl_cnn_0_0_gamma': (8,),
+            'ctrl_cnn_0_0_ema_mean': (8,), 'ctrl_lstm_w_xi': (5, 7), 'score_mlp_w_0': (9, 1)}
+  opt = dict(weight_decay=5e-5, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000)
+  return _FakeModel({k: torch.randn(s, generator=g) for k, s in shapes.items()}, opt)
+
+
+def _per_example_grads(n_total):
+  """Deterministic per-example gradients (the same on every rank), several beyond the +-1 clip."""
+  import ra_train
+  m = _toy_model()
+  b = ra_train.GradBucket(m)
+  g = torch.Generator().manual_seed(11)
+  return 4.0 * torch.randn((n_total, b.n), generator=g)
+
+
+def _reference_update(param, grad_mean, wd, lr_t):
+  gg = np.clip(grad_mean + wd * param, -1.0, 1.0)
+  m = 0.1 * gg
+  v = 0.001 * gg * gg
+  return param - lr_t * m / (np.sqrt(v) + 1e-7)
+
+
+def _train_worker(rank, world, port, q):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  sys.path.insert(0, os.path.dirname(ra_dist.__file__))
+  import ra_train
+  r, w, _ = ra_dist.init('gloo')
+  model = _toy_model()
+  bucket = ra_train.GradBucket(model)
+  per_ex = _per_example_grads(8)
+  lo, hi = ra_dist.shard_range(r, w, 8)
+  # the rank's backward: its loss divides by ITS example count (full_model.py:916 on the shard)
+  bucket.grad.copy_(per_ex[lo:hi].mean(dim=0))
+  n = bucket.allreduce()
+  q.put((r, n, bucket.grad.numpy().copy(), bucket.param.numpy().copy(), bucket.wd.numpy().copy(),
+         {k: bucket.offsets[k] for k in bucket.names}))
+  ra_dist.barrier()
+  torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_bucket_equals_single_process():
+  import ra_train
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29950 + (os.getpid() % 40)
+  procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  single = _per_example_grads(8).mean(dim=0).numpy()       # one process, the whole batch
+  lr_t = ra_train.learn_rate(_toy_model().opt, 0) * np.sqrt(1 - 0.999) / (1 - 0.9)
+  for r, world, gsum, param, wd, offsets in res:
+    assert world == 2
+    assert (gsum == res[0][2]).all()                        # every rank holds the same sum
+    assert np.abs(gsum / world - single).max() < 1e-6       # sum-then-scale == single-process mean
+    upd_dp = _reference_update(param, gsum / world, wd, lr_t)
+    upd_single = _reference_update(param, single, wd, lr_t)
+    assert np.abs(upd_dp - upd_single).max() < 1e-7         # ... and so is the clipped Adam update
+    # clipping BEFORE the mean would differ: the order matters and is the documented one
+    assert np.abs(np.clip(gsum, -1, 1) / world - np.clip(single, -1, 1)).max() > 1e-3
+    # bucket layout: EMA shadows are not trainable, weight decay only on `w` tensors
+    assert 'ctrl_cnn_0_0_ema_mean' not in offsets
+    o, n, _ = offsets['ctrl_cnn_w_0']
+    assert (wd[o:o + n] == np.float32(5e-5)).all()
+    o, n, _ = offsets['ctrl_cnn_b_0']
+    assert (wd[o:o + n] == 0).all()
+
+
+def test_learn_rate_and_knob_schedules():
+  import ra_train
+  opt = dict(base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000, knob_base=1.0,
+             knob_decay=0.9, steps_per_knob_decay=300)
+  assert ra_train.learn_rate(opt, 4999) == 1e-3 and abs(ra_train.learn_rate(opt, 5000) - 0.96e-3) < 1e-12
+  assert ra_train.knob_prob(opt, 100, 200) == 1.0 and abs(ra_train.knob_prob(opt, 500, 200) - 0.9) < 1e-12

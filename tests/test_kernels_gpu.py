@@ -502,3 +502,26 @@ def test_first_layer_cache_vs_plain_pair(cuda, shape):
   ref = ora.max_pool(np.maximum(ref, 0), 2)
   assert np.abs(plain.cpu().numpy() - ref).max() < 1e-4
   assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+
+
+def test_adam_step_matches_tf_adam(cuda):
+  """ra_adam_step_f32: clip(g / world + wd * w, +-1) then tf.train.AdamOptimizer's update
+  (full_model.py:1046-1056), three steps against a float64 restatement."""
+  import ctypes as C
+  rng = np.random.RandomState(0)
+  n = 1003
+  p0, wd = rng.randn(n).astype(np.float32), (rng.rand(n) < 0.5).astype(np.float32) * 5e-5
+  p, m, v = dev(p0, cuda), dev(np.zeros(n), cuda), dev(np.zeros(n), cuda)
+  pr, mr, vr = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+  b1, b2, eps, lr, world = 0.9, 0.999, 1e-7, 1e-3, 2
+  for t in range(1, 4):
+    g = (rng.randn(n) * 3).astype(np.float32)  # many elements beyond the clip
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    rn.check(rn.lib().ra_adam_step_f32(rn.ptr(p), rn.ptr(dev(g, cuda)), rn.ptr(m), rn.ptr(v), rn.ptr(dev(wd, cuda)),
+                                       n, C.c_float(lr_t), C.c_float(b1), C.c_float(b2), C.c_float(eps),
+                                       C.c_float(1.0), C.c_float(1.0 / world), rn.stream_ptr()), 'adam')
+    gg = np.clip(g.astype(np.float64) / world + wd * pr, -1, 1)
+    mr = b1 * mr + (1 - b1) * gg
+    vr = b2 * vr + (1 - b2) * gg * gg
+    pr = pr - lr_t * mr / (np.sqrt(vr) + eps)
+    assert np.abs(p.cpu().numpy() - pr).max() < 1e-5
