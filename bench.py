@@ -186,7 +186,8 @@ def main():
   ap.add_argument('--pmc-which', default='enc', choices=['enc', 'attn', 'tail'],
                   help='which launch group --pmc-group repeats: the encoder, extract+paste, or the whole tail')
   ap.add_argument('--attn-b32', action='store_true', help='also time extract+paste at B=32 (roofline_attn.at_B32)')
-  ap.add_argument('--no-fuse-patchnet', action='store_true', help='tuning aid: per-layer patch-net launches')
+  ap.add_argument('--fuse-patchnet', action='store_true',
+                  help='tuning aid: the patch net through the phase kernel K4 (RA_PNET_MODE=1: one launch)')
   ap.add_argument('--no-cache-first', action='store_true', help='tuning aid: recompute the whole first layer per timestep')
   args = ap.parse_args()
 
@@ -205,7 +206,7 @@ def main():
   eng.use_graph = not args.no_graph
   eng.nsub = args.nsub
   eng.fuse_score = not args.no_fuse_score
-  eng.fuse_patchnet = not args.no_fuse_patchnet
+  eng.fuse_patchnet = args.fuse_patchnet
   eng.cache_first = not args.no_cache_first
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()

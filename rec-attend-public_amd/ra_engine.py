@@ -45,7 +45,9 @@ class DecodeEngine(object):
     self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
     self.fuse_score = True  # score MLP as an extra workgroup of the paste launch
-    self.fuse_patchnet = True  # attention CNN + DCNN + score as ONE launch (K4) where supported
+    # attention CNN + DCNN + score through the phase kernel K4 (ra_patchnet_f32).  Measured on MI355X at
+    # cfg2 it is 11-15 us per timestep SLOWER than the 13 per-layer launches, so off.
+    self.fuse_patchnet = False
     self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True

@@ -517,7 +517,8 @@ def test_adam_step_matches_tf_adam(cuda):
   for t in range(1, 4):
     g = (rng.randn(n) * 3).astype(np.float32)  # many elements beyond the clip
     lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-    rn.check(rn.lib().ra_adam_step_f32(rn.ptr(p), rn.ptr(dev(g, cuda)), rn.ptr(m), rn.ptr(v), rn.ptr(dev(wd, cuda)),
+    gd, wdd = dev(g, cuda), dev(wd, cuda)  # keep the device copies alive across the launch
+    rn.check(rn.lib().ra_adam_step_f32(rn.ptr(p), rn.ptr(gd), rn.ptr(m), rn.ptr(v), rn.ptr(wdd),
                                        n, C.c_float(lr_t), C.c_float(b1), C.c_float(b2), C.c_float(eps),
                                        C.c_float(1.0), C.c_float(1.0 / world), rn.stream_ptr()), 'adam')
     gg = np.clip(g.astype(np.float64) / world + wd * pr, -1, 1)
@@ -525,3 +526,4 @@ def test_adam_step_matches_tf_adam(cuda):
     vr = b2 * vr + (1 - b2) * gg * gg
     pr = pr - lr_t * mr / (np.sqrt(vr) + eps)
     assert np.abs(p.cpu().numpy() - pr).max() < 1e-5
+    del gd, wdd
