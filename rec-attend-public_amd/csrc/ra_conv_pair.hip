@@ -271,6 +271,231 @@ __global__ __launch_bounds__(256) void conv_pair_mfma(const PArgs a, int tiles_x
   }
 }
 
+template <int CINA, int CMID, int NCB, int GX, int GYB>
+__global__ __launch_bounds__(256) void conv_pair_persist_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
+  using G = PGeo<CINA, CMID, NCB, GX, GYB>;
+  constexpr int NCA = G::NCA;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tin = lds;                  // [LHA][LWA][CINA]  records [ksub][cg]
+  float *tmid = lds + G::IN_FLOATS;  // [AH][AW][CMID]    records [ksub][cg]
+  typedef typename vec_of<G::NCGAC>::type avecA;
+  typedef typename vec_of<G::NCGBC>::type avecB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: group bookkeeping on the SALU
+  const int m = lane & 15, ksub = lane >> 4;
+  const int q = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
+  const int co_lane = lane & 15, qo = lane >> 4;
+  const int per = tiles_x * tiles_y;
+  static_assert(G::NCHA == 1 && G::NCHB == 1, "persistent pair: single-chunk layers");
+  // both layers' B operands and epilogue constants: once per workgroup
+  float scA[NCA], shA[NCA];
+#pragma unroll
+  for (int n = 0; n < NCA; ++n) {
+    scA[n] = a.scA[16 * n + co_lane];
+    shA[n] = a.shA[16 * n + co_lane];
+  }
+  float bregA[G::KSA][NCA], bregB[G::KSB][NCB];
+  {
+    const float *wrow = a.wpA + (size_t)ksub * a.CoutAP + co_lane;
+#pragma unroll
+    for (int s = 0; s < G::KSA; ++s)
+#pragma unroll
+      for (int n = 0; n < NCA; ++n) bregA[s][n] = wrow[(size_t)s * 4 * a.CoutAP + 16 * n];
+    const float *wrowb = a.wpB + (size_t)ksub * a.CoutBP + co_lane;
+#pragma unroll
+    for (int s = 0; s < G::KSB; ++s)
+#pragma unroll
+      for (int n = 0; n < NCB; ++n) bregB[s][n] = wrowb[(size_t)s * 4 * a.CoutBP + 16 * n];
+  }
+  // the input window (tile + 2-pixel halo) of a tile is fetched into registers one tile ahead
+  constexpr int NPIXA = G::LHA * G::LWA, NIT = (NPIXA + 255) / 256;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src), 0, a.bytes0, 0x00020000);
+  int e_r[NIT], e_c[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int e = tid + 256 * i;
+    e_r[i] = e / G::LWA - 2;
+    e_c[i] = e % G::LWA - 2;
+    if (e >= NPIXA) e_r[i] = -(1 << 20);
+  }
+  f32x4 pre[NIT][G::NCGA];
+  auto fetch = [&](int T) {
+    const int fb = T / per, fr = T - fb * per;
+    const int fy0 = (fr / tiles_x) * G::THB, fx0 = (fr % tiles_x) * G::TWB;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int Y = fy0 + e_r[i], X = fx0 + e_c[i];
+      const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+      const int off = ok ? (((fb * a.Hs + Y) * a.Ws + X) * a.C0) * 4 : 0x7fffffff;
+#pragma unroll
+      for (int cg = 0; cg < G::NCGA; ++cg)
+        pre[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16 * cg, 0));
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+  const int b = tile / per;
+  const int trem = tile - b * per;
+  const int ty0 = (trem / tiles_x) * G::THB, tx0 = (trem % tiles_x) * G::TWB;
+
+  // ---------------- phase 0: prefetched registers -> LDS (previous tile's phase B is complete
+  // for every wave once all have arrived at the barrier below) ----------------
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int e = tid + 256 * i;
+    if (e < NPIXA) {
+      float *rec = tin + e * CINA;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if constexpr (G::NCGA == 1) {
+          rec[ks] = pre[i][0][ks];
+        } else if constexpr (G::NCGA == 2) {
+          rec[ks * 2] = pre[i][0][ks];
+          rec[ks * 2 + 1] = pre[i][1][ks];
+        } else {
+#pragma unroll
+          for (int c4 = 0; c4 < G::NCGA / 4; ++c4)
+            *reinterpret_cast<f32x4 *>(rec + ks * G::NCGA + 4 * c4) =
+                f32x4{pre[i][4 * c4][ks], pre[i][4 * c4 + 1][ks], pre[i][4 * c4 + 2][ks], pre[i][4 * c4 + 3][ks]};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);  // in flight across both MFMA phases
+  }
+
+  // ---------------- phase A: conv A over the B tile + halo, result -> LDS ----------------
+  {
+    const int lane_in = (dy * G::LWA + 2 * q + dx) * CINA + ksub * G::NCGA;
+    for (int rd = 0; rd < G::ROUNDS; ++rd) {
+      f32x4 acc[G::RA][NCA];
+      int gbase[G::RA], gr[G::RA], gc[G::RA];
+#pragma unroll
+      for (int j = 0; j < G::RA; ++j) {
+        int gi = wave + 4 * (rd * G::RA + j);
+        if (gi >= G::NGA) gi = G::NGA - 1;  // duplicate work, masked at the store
+        gr[j] = gi / G::GXA;
+        gc[j] = gi % G::GXA;
+        gbase[j] = (2 * gr[j] * G::LWA + 8 * gc[j]) * CINA + lane_in;
+#pragma unroll
+        for (int n = 0; n < NCA; ++n) acc[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      for (int ch = 0; ch < G::NCHA; ++ch) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          avecA av[G::RA];
+#pragma unroll
+          for (int j = 0; j < G::RA; ++j)
+            av[j] = *reinterpret_cast<const avecA *>(
+                &tin[gbase[j] + (ky * G::LWA + kx) * CINA + ch * G::NCGAC]);
+#pragma unroll
+          for (int cg = 0; cg < G::NCGAC; ++cg)
+#pragma unroll
+            for (int j = 0; j < G::RA; ++j)
+#pragma unroll
+              for (int n = 0; n < NCA; ++n)
+                acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][cg], bregA[tap * G::NCGAC + cg][n],
+                                                                 acc[j][n], 0, 0, 0);
+        }
+      }
+      // A epilogue -> tmid (zero outside the image: it is B's SAME padding).  Tiles whose whole
+      // A region lies inside the image (uniform test) skip the per-value bounds arithmetic.
+      const bool interior = (ty0 >= 1) & (ty0 - 1 + G::AH <= a.H) & (tx0 >= 1) & (tx0 + G::TWB + 1 <= a.W);
+      const float loA = a.reluA ? 0.f : -__builtin_inff();
+#pragma unroll
+      for (int j = 0; j < G::RA; ++j) {
+        const bool live = (wave + 4 * (rd * G::RA + j)) < G::NGA;
+#pragma unroll
+        for (int n = 0; n < NCA; ++n) {
+          const int co = 16 * n + co_lane;
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[j][n][r] * scA[n] + shA[n], loA);
+          if (!interior) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int Y = ty0 - 1 + 2 * gr[j] + (r >> 1), X = tx0 - 1 + 8 * gc[j] + 2 * qo + (r & 1);
+              o[r] = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o[r] : 0.f;
+            }
+          }
+          if (live && co < CMID) {
+            float *dst = tmid + ((2 * gr[j]) * G::AW + 8 * gc[j] + 2 * qo) * CMID + (co & 3) * G::NCGB + (co >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((r >> 1) * G::AW + (r & 1)) * CMID] = o[r];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase B: conv B out of tmid, epilogue -> global ----------------
+  {
+    f32x4 acc[G::PMB][NCB];
+#pragma unroll
+    for (int g = 0; g < G::PMB; ++g)
+#pragma unroll
+      for (int n = 0; n < NCB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_base = ((wave * 2 * GYB + dy) * G::AW + 2 * q + dx) * CMID + ksub * G::NCGB;
+    for (int ch = 0; ch < G::NCHB; ++ch) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        avecB av[G::PMB];
+#pragma unroll
+        for (int g = 0; g < G::PMB; ++g) {
+          const int gx = g % GX, gy = g / GX;
+          av[g] = *reinterpret_cast<const avecB *>(
+              &tmid[a_base + ((2 * gy + ky) * G::AW + 8 * gx + kx) * CMID + ch * G::NCGBC]);
+        }
+#pragma unroll
+        for (int cg = 0; cg < G::NCGBC; ++cg)
+#pragma unroll
+          for (int g = 0; g < G::PMB; ++g)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n)
+              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][cg], bregB[tap * G::NCGBC + cg][n],
+                                                               acc[g][n], 0, 0, 0);
+      }
+    }
+    const int opool = a.poolB;
+    const float loB = a.reluB ? 0.f : -__builtin_inff();
+    const int wrow0 = ty0 + wave * 2 * GYB, lcol0 = tx0 + 2 * qo;
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) {
+      const int co = 16 * n + co_lane;
+      const float sc = a.scB[co], sh = a.shB[co];
+      const bool co_ok = co < a.CoutB;
+      const int obase = ((b * a.Ho + wrow0 / opool) * a.Wo + lcol0 / opool) * a.CoutB + co;
+#pragma unroll
+      for (int g = 0; g < G::PMB; ++g) {
+        const int gx = g % GX, gy = g / GX;
+        const int row0 = wrow0 + 2 * gy, col0 = lcol0 + 8 * gx;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[g][n][r] * sc + sh, loB);
+        if (opool == 2) {
+          const float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+          if (co_ok && (row0 >> 1) < a.Ho && (col0 >> 1) < a.Wo)
+            a.y[obase + (gy * a.Wo + 4 * gx) * a.CoutB] = o;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co_ok && row0 + (r >> 1) < a.Ho && col0 + (r & 1) < a.Wo)
+              a.y[obase + ((2 * gy + (r >> 1)) * a.Wo + 8 * gx + (r & 1)) * a.CoutB] = v[r];
+        }
+      }
+    }
+  }
+  }  // persistent tile loop
+}
+
 // ---------------------------------------------------------------------------------------------
 // N-packed form for the full-resolution 8-channel pairs (controller CNN L0+L1: Cin -> 8 -> <=8,
 // pool 2).  A 16x16x4 MFMA has 16 output columns; with 8 output channels half of them would
@@ -587,7 +812,7 @@ int launch8(const PArgs &a, int B, hipStream_t st) {
   static int wgs = -1;  // RA_PAIR8_WGS: tuning aid, persistent workgroups (default 3 per CU)
   if (wgs < 0) {
     const char *e = getenv("RA_PAIR8_WGS");
-    wgs = e ? atoi(e) : 768;
+    wgs = e ? atoi(e) : (CACHED ? 1024 : 768);  // the cached form needs 122 VGPRs: 4 workgroups per CU
   }
   hipLaunchKernelGGL(kern, dim3(ntiles < wgs ? ntiles : wgs), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_f32");
@@ -600,35 +825,50 @@ int launch8(const PArgs &a, int B, hipStream_t st) {
 // allocated: entries outside the image are never written.
 __global__ __launch_bounds__(256) void first_cache_kernel(const float *x, const float *wpA, int CoutAP, int plane_chan,
                                                           int B, int H, int W, int rows, int ngx, float *cache) {
-  // one thread per image pixel, all 8 output channels: 9 float4 loads, 27 x 8 FMAs whose weights
-  // are wave-uniform (scalar loads); entries of the cache no pixel maps to stay at their zero fill
-  const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
-  if (X >= W || Y >= H) return;
+  // a workgroup = 4 image rows x 64 columns starting at X = 64*bx - 2, i.e. 8 complete column
+  // groups of the cache.  One thread per pixel computes all 8 output channels (9 float4 loads,
+  // 27 x 8 FMAs with wave-uniform weights), the block is transposed through LDS and written as
+  // coalesced float4 [n][r] records.
+  __shared__ float sm[4][64][9];  // +1: conflict-free transposed reads
+  const int xl = threadIdx.x & 63, yl = threadIdx.x >> 6;
+  const int X = blockIdx.x * 64 - 2 + xl, Y = blockIdx.y * 4 + yl, b = blockIdx.z;
   float acc[8];
 #pragma unroll
   for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+  if (X >= 0 && X < W && Y < H) {
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int yy = Y + ky - 1;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = Y + ky - 1;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int xx = X + kx - 1;
-      const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4 *>(x + ((size_t)(b * H + yy) * W + xx) * 4);
-      const float *wt = wpA + (size_t)((ky * 3 + kx) * 4) * CoutAP;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = X + kx - 1;
+        const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4 *>(x + ((size_t)(b * H + yy) * W + xx) * 4);
+        const float *wt = wpA + (size_t)((ky * 3 + kx) * 4) * CoutAP;
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci) {
-        const float xv = ci == plane_chan ? 0.f : v[ci];
+        for (int ci = 0; ci < 4; ++ci) {
+          const float xv = ci == plane_chan ? 0.f : v[ci];
 #pragma unroll
-        for (int co = 0; co < 8; ++co) acc[co] = fmaf(xv, wt[ci * CoutAP + co], acc[co]);
+          for (int co = 0; co < 8; ++co) acc[co] = fmaf(xv, wt[ci * CoutAP + co], acc[co]);
+        }
       }
     }
   }
-  const int gx = (X + 2) >> 3, rem = (X + 2) & 7, r = rem >> 1, p = rem & 1;
-  float *dst = cache + ((((size_t)b * rows + (Y + 1)) * ngx + gx) * 16 + p * 8) * 4 + r;
 #pragma unroll
-  for (int co = 0; co < 8; ++co) dst[co * 4] = acc[co];
+  for (int co = 0; co < 8; ++co) sm[yl][xl][co] = acc[co];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 4 * 8 * 16; e += 256) {
+    const int n = e & 15, g = (e >> 4) & 7, row = e >> 7;
+    const int p = n >> 3, co = n & 7;
+    const int Yo = blockIdx.y * 4 + row, gx = blockIdx.x * 8 + g;
+    if (Yo < H && gx < ngx) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = sm[row][8 * g + 2 * r + p][co];
+      *reinterpret_cast<f32x4 *>(cache + ((((size_t)b * rows + (Yo + 1)) * ngx + gx) * 16 + n) * 4) = o;
+    }
+  }
 }
 
 inline void cache_dims(int H, int W, int &rows, int &ngx) {
@@ -649,7 +889,30 @@ int launch(const PArgs &a, int B, hipStream_t st) {
     attr = true;
   }
   const int tiles_x = ceil_div(a.W, G::TWB), tiles_y = ceil_div(a.H, G::THB);
-  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * B), dim3(256), lds, st, a, tiles_x, tiles_y);
+  const int ntiles = tiles_x * tiles_y * B;
+  if constexpr (G::NCHA == 1 && G::NCHB == 1) {
+    // plain single-chunk pairs (controller CNN L2+L3 at full size): persistent workgroups, weights
+    // loaded once, the next tile's input prefetched into registers behind the MFMA phases
+    static int pers = -1, cap = 0;
+    if (pers < 0) {
+      const char *e = getenv("RA_PAIR_PERSIST");
+      pers = e ? atoi(e) : 1;
+      auto kp = conv_pair_persist_mfma<CINA, CMID, NCB, GX, GYB>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp, 256, lds) != hipSuccess || nb < 1) nb = 1;
+      hipDeviceProp_t prop;
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      cap = nb * cus;
+    }
+    if (pers && !a.ups && !a.plane && ntiles > cap && a.bytes0 > 0) {
+      hipLaunchKernelGGL((conv_pair_persist_mfma<CINA, CMID, NCB, GX, GYB>), dim3(cap), dim3(256), lds, st, a, tiles_x,
+                         tiles_y, ntiles);
+      return launch_status("ra_conv_pair_f32");
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, a, tiles_x, tiles_y);
   return launch_status("ra_conv_pair_f32");
 }
 
@@ -781,7 +1044,7 @@ extern "C" int ra_conv_first_cache_f32(const float *src, int B, int H, int W, co
   cpair::cache_dims(H, W, rows, ngx);
   const size_t total = (size_t)B * rows * ngx * 16;
   if (total * 16 >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_first_cache_f32: cache exceeds 2 GiB");
-  hipLaunchKernelGGL(cpair::first_cache_kernel, dim3(ceil_div(W, 64), ceil_div(H, 4), B), dim3(256), 0,
+  hipLaunchKernelGGL(cpair::first_cache_kernel, dim3(ceil_div(W + 2, 64), ceil_div(H, 4), B), dim3(256), 0,
                      as_stream(stream), src, wpA, ra_conv_cout_padded(CoutA), plane_chan, B, H, W, rows, ngx, cache);
   return launch_status("ra_conv_first_cache_f32");
 }
