@@ -45,3 +45,499 @@ extern "C" int ra_adam_step_f32(float *params, const float *grads, float *m, flo
                      wd_coef, n, lr_t, beta1, beta2, eps, clip, grad_scale);
   return launch_status("ra_adam_step_f32");
 }
+
+// =================================================================================================
+// Train-mode layer pieces.  A layer of nnlib.cnn / nnlib.dcnn in training is
+//   u = conv(x, w) + b                       ra_conv3x3_f32 (scale 1, shift b, no ReLU, no pool)
+//   mean, var = moments(u over B,H,W)        ra_bn_moments_f32            nnlib.py:98 (biased variance)
+//   y = pool(relu(gamma (u - mean) rsqrt(var + 1e-3) + beta))   ra_bn_act_pool_f32   nnlib.py:111-119,250-253
+// and backward (batch statistics are part of the graph, nnlib.py:98-112):
+//   dbeta, dgamma, du                        ra_bn_act_pool_bwd_f32
+//   dx = conv(du, w^T flipped)               ra_conv3x3_f32 on ra_conv_pack_weights_dev(.., TRANSPOSED)
+//   dw, db                                   ra_conv3x3_wgrad_f32
+// All reductions are two-stage with a fixed summation order (no atomics): bit-reproducible.
+namespace ra {
+namespace train {
+
+constexpr int kRedBlocks = 512;
+
+// ---- per-channel moments: pass 1 sum, pass 2 sum of squared deviations (tf.nn.moments) ----
+__global__ __launch_bounds__(256) void chan_sum_kernel(const float *u, size_t npix, int C, const float *mean,
+                                                       float *part) {
+  // thread = (pixel lane, channel): channel = tid % C when C divides 256; generic otherwise
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int lanes = 256 / C;  // pixel lanes per block (C <= 256, power-of-two-friendly but generic)
+  const int c = tid % C, pl = tid / C;
+  float s = 0.f;
+  if (pl < lanes) {
+    const float mu = mean ? mean[c] : 0.f;
+    for (size_t p = (size_t)blockIdx.x * lanes + pl; p < npix; p += (size_t)gridDim.x * lanes) {
+      const float v = u[p * C + c] - mu;
+      s += mean ? v * v : v;
+    }
+  }
+  red[tid] = pl < lanes ? s : 0.f;
+  __syncthreads();
+  if (tid < C) {
+    float t = 0.f;
+    for (int k = 0; k < lanes; ++k) t += red[k * C + tid];
+    part[(size_t)blockIdx.x * C + tid] = t;
+  }
+}
+__global__ void chan_final_kernel(const float *part, int nblocks, int C, float inv_n, float *out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int k = 0; k < nblocks; ++k) t += part[(size_t)k * C + c];
+  out[c] = t * inv_n;
+}
+
+// ---- y = pool(relu(gamma * (u - mean) * rstd + beta)) ----
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *u, const float *mean, const float *var,
+                                                          const float *gamma, const float *beta, float eps, int relu,
+                                                          int pool, int B, int H, int W, int C, float *y) {
+  const int Ho = H / pool, Wo = W / pool;
+  const size_t total = (size_t)B * Ho * Wo * C;
+  const float lo = relu ? 0.f : -__builtin_inff();
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    size_t r = e / C;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    const float g = (gamma ? gamma[c] : 1.f) * (var ? rsqrtf(var[c] + eps) : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - (mean ? mean[c] : 0.f) * g;
+    float best = -__builtin_inff();
+    for (int dy = 0; dy < pool; ++dy)
+      for (int dx = 0; dx < pool; ++dx) {
+        const float v = u[(((size_t)b * H + yo * pool + dy) * W + xo * pool + dx) * C + c] * g + sh;
+        best = fmaxf(best, fmaxf(v, lo));
+      }
+    y[e] = best;
+  }
+}
+
+// ---- backward, stage 1: per-channel sums of dv and dv * xhat (dv = dy routed through pool + ReLU) ----
+__device__ inline void bwd_point(const float *u, const float *dy, float g, float sh, float mu, float rstd, float lo,
+                                 int relu, int pool, int b, int yy, int xx, int H, int W, int C, int c, float &dv,
+                                 float &xhat) {
+  // gradient reaching pre-activation v at conv pixel (yy, xx): the pooled window's FIRST maximum gets dy
+  const float uv = u[(((size_t)b * H + yy) * W + xx) * C + c];
+  xhat = (uv - mu) * rstd;
+  const float v = uv * g + sh;
+  if (pool == 1) {
+    dv = (relu && v <= 0.f) ? 0.f : dy[(((size_t)b * H + yy) * W + xx) * C + c];
+    return;
+  }
+  const int yo = yy >> 1, xo = xx >> 1, Ho = H >> 1, Wo = W >> 1;
+  float best = -__builtin_inff();
+  int arg = 0;
+  for (int k = 0; k < 4; ++k) {
+    const float w = u[(((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * C + c] * g + sh;
+    const float a = fmaxf(w, lo);
+    if (a > best) {
+      best = a;
+      arg = k;
+    }
+  }
+  const bool mine = arg == (((yy & 1) << 1) | (xx & 1));
+  dv = (mine && !(relu && v <= 0.f)) ? dy[(((size_t)b * Ho + yo) * Wo + xo) * C + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *u, const float *dy, const float *mean,
+                                                            const float *var, const float *gamma, const float *beta,
+                                                            float eps, int relu, int pool, int B, int H, int W, int C,
+                                                            float *part) {
+  __shared__ float r0[256], r1[256];
+  const int tid = threadIdx.x, lanes = 256 / C, c = tid % C, pl = tid / C;
+  float s0 = 0.f, s1 = 0.f;
+  if (pl < lanes) {
+    const float rstd = var ? rsqrtf(var[c] + eps) : 1.f, mu = mean ? mean[c] : 0.f;
+    const float g = (gamma ? gamma[c] : 1.f) * rstd, sh = (beta ? beta[c] : 0.f) - mu * g;
+    const float lo = relu ? 0.f : -__builtin_inff();
+    const size_t npix = (size_t)B * H * W;
+    for (size_t p = (size_t)blockIdx.x * lanes + pl; p < npix; p += (size_t)gridDim.x * lanes) {
+      const int xx = (int)(p % W);
+      const size_t r = p / W;
+      const int yy = (int)(r % H), b = (int)(r / H);
+      float dv, xhat;
+      bwd_point(u, dy, g, sh, mu, rstd, lo, relu, pool, b, yy, xx, H, W, C, c, dv, xhat);
+      s0 += dv;
+      s1 += dv * xhat;
+    }
+  }
+  r0[tid] = pl < lanes ? s0 : 0.f;
+  r1[tid] = pl < lanes ? s1 : 0.f;
+  __syncthreads();
+  if (tid < C) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < lanes; ++k) {
+      t0 += r0[k * C + tid];
+      t1 += r1[k * C + tid];
+    }
+    part[((size_t)blockIdx.x * 2) * C + tid] = t0;
+    part[((size_t)blockIdx.x * 2 + 1) * C + tid] = t1;
+  }
+}
+__global__ void bn_bwd_final_kernel(const float *part, int nblocks, int C, float *dbeta, float *dgamma) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t0 = 0.f, t1 = 0.f;
+  for (int k = 0; k < nblocks; ++k) {
+    t0 += part[((size_t)k * 2) * C + c];
+    t1 += part[((size_t)k * 2 + 1) * C + c];
+  }
+  dbeta[c] = t0;
+  dgamma[c] = t1;
+}
+// ---- stage 2: du = gamma * rstd * (dv - dbeta / n - xhat * dgamma / n)   (batch-norm: var given)
+//               du = dv                                                    (no BN)
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float *u, const float *dy, const float *mean,
+                                                        const float *var, const float *gamma, const float *beta,
+                                                        const float *dbeta, const float *dgamma, float eps, int relu,
+                                                        int pool, int B, int H, int W, int C, float *du) {
+  const size_t total = (size_t)B * H * W * C;
+  const float inv_n = 1.f / (float)((size_t)B * H * W);
+  const float lo = relu ? 0.f : -__builtin_inff();
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    size_t r = e / C;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H), b = (int)(r / H);
+    const float rstd = var ? rsqrtf(var[c] + eps) : 1.f, mu = mean ? mean[c] : 0.f;
+    const float g = (gamma ? gamma[c] : 1.f) * rstd, sh = (beta ? beta[c] : 0.f) - mu * g;
+    float dv, xhat;
+    bwd_point(u, dy, g, sh, mu, rstd, lo, relu, pool, b, yy, xx, H, W, C, c, dv, xhat);
+    du[e] = var ? g * (dv - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n) : dv;
+  }
+}
+
+// ---- device-side weight repack (the host form is ra_conv_pack_weights) ----
+__global__ void pack_weights_kernel(const float *w, int Cin_w, int Cout, int Cin, const int *chan_map, int tr, int CK,
+                                    int cp, float *out) {
+  const int total = 9 * Cin * cp;
+  const int NCG = CK / 4;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int co = e % cp;
+    int r = e / cp;
+    const int ksub = r % 4;
+    r /= 4;
+    const int cg = r % NCG;
+    r /= NCG;
+    const int tap = r % 9, chunk = r / 9;
+    const int c = chunk * CK + cg * 4 + ksub;
+    const int src_c = chan_map ? chan_map[c] : c;
+    const int ky = tap / 3, kx = tap % 3;
+    float v = 0.f;
+    if (co < Cout && src_c >= 0) {
+      if (!tr)
+        v = w[(((size_t)ky * 3 + kx) * Cin_w + src_c) * Cout + co];
+      else
+        v = w[(((size_t)(2 - ky) * 3 + (2 - kx)) * Cout + co) * Cin_w + src_c];
+    }
+    out[e] = v;
+  }
+}
+
+// ---- y[b,i,j,:] = x[b,2i+1,2j+1,:]: the adjoint of the zero-stuffing of a stride-2 transposed conv ----
+__global__ __launch_bounds__(256) void subsample_odd_kernel(const float *x, int B, int H, int W, int C, float *y) {
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    size_t r = e / C;
+    const int j = (int)(r % W);
+    r /= W;
+    const int i = (int)(r % H), b = (int)(r / H);
+    y[e] = x[(((size_t)b * 2 * H + 2 * i + 1) * 2 * W + 2 * j + 1) * C + c];
+  }
+}
+
+// ---- out[b,n,p] = sum_t w[b,n,t] * y[b,t,p] + bias[b,n]: the adjoint of the pairwise soft IoU ----
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void weighted_sum_multi_kernel(const float *w, const float *bias, const float *y, int N,
+                                                                 int T, int HW, float *out) {
+  const int b = blockIdx.z, n = blockIdx.y;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= HW) return;
+  const float *yb = y + (size_t)b * T * HW + e;
+  const float b0 = bias ? bias[(size_t)b * N + n] : 0.f;
+  f32x4 acc = f32x4{b0, b0, b0, b0};
+  for (int t = 0; t < T; ++t) {
+    const float wt = w[((size_t)b * N + n) * T + t];
+    if (wt != 0.f) acc += wt * *reinterpret_cast<const f32x4 *>(yb + (size_t)t * HW);  // uniform per (b, n)
+  }
+  *reinterpret_cast<f32x4 *>(out + ((size_t)b * N + n) * HW + e) = acc;
+}
+
+}  // namespace train
+}  // namespace ra
+
+extern "C" size_t ra_bn_workspace_floats(int C) { return (size_t)ra::train::kRedBlocks * 2 * (C > 0 ? C : 1); }
+
+extern "C" int ra_bn_moments_f32(const float *u, size_t npix, int C, float *ws, size_t ws_floats, float *mean,
+                                 float *var, void *stream) {
+  if (!u || !ws || !mean || !var || npix == 0 || C <= 0) return fail(RA_E_INVALID, "ra_bn_moments_f32: bad argument");
+  if (C > 256) return fail(RA_E_SHAPE, "ra_bn_moments_f32: C %d > 256", C);
+  if (ws_floats < ra_bn_workspace_floats(C)) return fail(RA_E_WORKSPACE, "ra_bn_moments_f32: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int lanes = 256 / C;
+  int nb = (int)((npix + lanes - 1) / lanes);
+  if (nb > train::kRedBlocks) nb = train::kRedBlocks;
+  const float inv_n = 1.f / (float)npix;
+  hipLaunchKernelGGL(train::chan_sum_kernel, dim3(nb), dim3(256), 0, st, u, npix, C, static_cast<const float *>(nullptr), ws);
+  hipLaunchKernelGGL(train::chan_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, inv_n, mean);
+  hipLaunchKernelGGL(train::chan_sum_kernel, dim3(nb), dim3(256), 0, st, u, npix, C, mean, ws);
+  hipLaunchKernelGGL(train::chan_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, inv_n, var);
+  return launch_status("ra_bn_moments_f32");
+}
+
+extern "C" int ra_bn_act_pool_f32(const float *u, const float *mean, const float *var, const float *gamma,
+                                  const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *y,
+                                  void *stream) {
+  if (!u || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(RA_E_INVALID, "ra_bn_act_pool_f32: bad argument");
+  if ((pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1))) return fail(RA_E_SHAPE, "ra_bn_act_pool_f32: pool");
+  const size_t total = (size_t)B * (H / pool) * (W / pool) * C;
+  size_t grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(train::bn_act_pool_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), u, mean, var, gamma,
+                     beta, eps, relu, pool, B, H, W, C, y);
+  return launch_status("ra_bn_act_pool_f32");
+}
+
+extern "C" int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const float *mean, const float *var,
+                                      const float *gamma, const float *beta, float eps, int relu, int pool, int B,
+                                      int H, int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta,
+                                      float *du, void *stream) {
+  if (!u || !dy || !ws || !dgamma || !dbeta || !du || B <= 0 || H <= 0 || W <= 0 || C <= 0)
+    return fail(RA_E_INVALID, "ra_bn_act_pool_bwd_f32: bad argument");
+  if (C > 256) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_f32: C %d > 256", C);
+  if ((pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1))) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_f32: pool");
+  if (ws_floats < ra_bn_workspace_floats(C)) return fail(RA_E_WORKSPACE, "ra_bn_act_pool_bwd_f32: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const size_t npix = (size_t)B * H * W;
+  const int lanes = 256 / C;
+  int nb = (int)((npix + lanes - 1) / lanes);
+  if (nb > train::kRedBlocks) nb = train::kRedBlocks;
+  hipLaunchKernelGGL(train::bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, u, dy, mean, var, gamma, beta, eps, relu, pool,
+                     B, H, W, C, ws);
+  hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, dbeta, dgamma);
+  size_t grid = (npix * C + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(train::bn_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, st, u, dy, mean, var, gamma, beta, dbeta,
+                     dgamma, eps, relu, pool, B, H, W, C, du);
+  return launch_status("ra_bn_act_pool_bwd_f32");
+}
+
+extern "C" int ra_conv_pack_weights_dev(const float *w, int Cin_w, int Cout, int Cin, const int *chan_map, int flags,
+                                        float *out, void *stream) {
+  const int cp = ra_conv_cout_padded(Cout);
+  if (!w || !out || Cin_w <= 0 || Cin <= 0) return fail(RA_E_INVALID, "ra_conv_pack_weights_dev: bad argument");
+  if (Cin % 4 || !cp) return fail(RA_E_SHAPE, "ra_conv_pack_weights_dev: Cin %d %% 4 or Cout %d", Cin, Cout);
+  if (!chan_map && Cin_w != Cin) return fail(RA_E_SHAPE, "ra_conv_pack_weights_dev: Cin_w != Cin without map");
+  const int CK = (Cin % 16 == 0) ? 16 : (Cin % 8 == 0) ? 8 : 4;
+  const int total = 9 * Cin * cp;
+  hipLaunchKernelGGL(train::pack_weights_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, Cin_w, Cout,
+                     Cin, chan_map, (flags & RA_CONV_TRANSPOSED) ? 1 : 0, CK, cp, out);
+  return launch_status("ra_conv_pack_weights_dev");
+}
+
+extern "C" int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(RA_E_INVALID, "ra_subsample_odd_f32: bad argument");
+  size_t grid = ((size_t)B * H * W * C + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(train::subsample_odd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, B, H, W, C, y);
+  return launch_status("ra_subsample_odd_f32");
+}
+
+extern "C" int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T, int HW,
+                                         float *out, void *stream) {
+  if (!w || !y || !out || B <= 0 || N <= 0 || T <= 0 || HW <= 0)
+    return fail(RA_E_INVALID, "ra_weighted_sum_multi_f32: bad argument");
+  if (HW % 4 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return fail(RA_E_SHAPE, "ra_weighted_sum_multi_f32: H*W %% 4 and 16-byte aligned tensors required");
+  hipLaunchKernelGGL(train::weighted_sum_multi_kernel, dim3(ceil_div(HW, 1024), N, B), dim3(256), 0, as_stream(stream), w,
+                     bias, y, N, T, HW, out);
+  return launch_status("ra_weighted_sum_multi_f32");
+}
+
+// =================================================================================================
+// conv3x3 backward-weight on f32 MFMA.  For the SAME conv u = conv(X, Wf) the kernel returns
+//   dWf[ky][kx][ci][co] = sum_{b,y,x} X[b, y+ky-1, x+kx-1, ci] * dU[b, y, x, co]      (X zero-padded;
+//   with `upsample` X is the zero-stuffed image of a stride-2 transposed conv) and  db[co] = sum dU.
+// GEMM view per tap: D[ci, co] = sum_pixels A[ci, pixel] * B[pixel, co]  — pixels are the K
+// dimension of v_mfma_f32_16x16x4_f32 (A = 16 input channels x 4 pixels, B = 4 pixels x 16 couts).
+// A workgroup owns a 16-channel slice of Cin (blockIdx.y) and walks 8 x 32 pixel tiles
+// persistently; its 4 waves split the tile's rows (K split), every wave keeps all
+// 10 (9 taps + bias) x CoutP/16 accumulator tiles for its rows in registers across tiles; at the
+// end the waves are summed through LDS and the workgroup writes ONE partial; a second kernel adds
+// the partials in a fixed order (deterministic, no atomics).
+namespace ra {
+namespace train {
+
+constexpr int WTH = 8, WTW = 32, WLW = WTW + 2, WLH = WTH + 2;
+
+template <int NT>  // CoutP / 16
+__global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
+                                                    int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
+                                                    int ntiles, float *part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tx = lds;                      // [WLH][WLW][16]   input slice + halo, channel-contiguous
+  float *tu = lds + WLH * WLW * 16;     // [WTH][WTW][16*NT] output gradient tile
+  constexpr int CP = 16 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, ksub = lane >> 4;
+  const int c0 = blockIdx.y * 16;             // first input channel of this workgroup's slice
+  const int cn = Cin - c0 < 16 ? Cin - c0 : 16;  // real channels in the slice
+  f32x4 acc[10][NT];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int per = tiles_x * tiles_y;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / per, tr = tile - b * per;
+    const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
+    __syncthreads();  // the previous tile's MFMA reads are complete
+    for (int e = tid; e < WLH * WLW * 4; e += 256) {  // input slice: one float4 (4 channels) per item
+      const int c4 = e & 3, pix = e >> 2;
+      const int r = pix / WLW, c = pix - r * WLW;
+      const int Y = ty0 + r - 1, X = tx0 + c - 1;
+      bool ok = (Y >= 0) & (Y < H) & (X >= 0) & (X < W) & (4 * c4 < cn);
+      int ys = Y, xs = X;
+      if (ups) {
+        ok = ok & (Y & 1) & (X & 1);
+        ys = (Y - 1) >> 1;
+        xs = (X - 1) >> 1;
+      }
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4 *>(x + (((size_t)b * Hs + ys) * Ws + xs) * Cin + c0 + 4 * c4);
+      *reinterpret_cast<f32x4 *>(tx + pix * 16 + 4 * c4) = v;
+    }
+    for (int e = tid; e < WTH * WTW * CP; e += 256) {  // output-gradient tile, zero beyond Cout / the image
+      const int co = e % CP, pix = e / CP;
+      const int r = pix / WTW, c = pix - r * WTW;
+      const int Y = ty0 + r, X = tx0 + c;
+      float v = 0.f;
+      if (Y < H && X < W && co < Cout) v = du[(((size_t)b * H + Y) * W + X) * Cout + co];
+      tu[e] = v;
+    }
+    __syncthreads();
+    // this wave's rows: 2 of the 8; K steps of 4 consecutive pixels of a row
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = wave * 2 + rr;
+#pragma unroll 2
+      for (int s = 0; s < WTW / 4; ++s) {
+        const int col = 4 * s + ksub;  // this lane's pixel within the K step
+        float bv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[n] = tu[(row * WTW + col) * CP + 16 * n + m];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float av = tx[((row + tap / 3) * WLW + col + tap % 3) * 16 + m];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[tap][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[tap][n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[9][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bv[n], acc[9][n], 0, 0, 0);
+      }
+    }
+  }
+  // sum the 4 waves (K split) through LDS in wave order, then one partial per workgroup:
+  // part[(blockIdx.y * gridDim.x + blockIdx.x)][10][16][CP]; D layout: rows 4*(lane>>4)+r, column lane&15
+  __syncthreads();
+  float *red = lds;  // 10 * 16 * CP floats <= the staging area
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float *d = red + (t * 16 + 4 * ksub + r) * CP + 16 * n + m;
+            *d = (w == 0 ? 0.f : *d) + acc[t][n][r];
+          }
+    }
+    __syncthreads();
+  }
+  float *dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (10 * 16 * CP);
+  for (int e = tid; e < 10 * 16 * CP; e += 256) dst[e] = red[e];
+}
+
+// dW[tap][ci][co] (= TF [3,3,Cin,Cout]) and db[co] from the partials, fixed order.
+__global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
+                                                          float *dw, float *db) {
+  const int total = 9 * Cin * Cout + Cout;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  int tap, ci, co;
+  if (e < 9 * Cin * Cout) {
+    co = e % Cout;
+    ci = (e / Cout) % Cin;
+    tap = e / (Cout * Cin);
+  } else {
+    tap = 9;
+    ci = 0;
+    co = e - 9 * Cin * Cout;
+  }
+  const int chunk = ci / 16, cl = ci % 16;
+  float s = 0.f;
+  for (int k = 0; k < nwg; ++k) s += part[(((size_t)chunk * nwg + k) * 10 + tap) * 16 * CP + cl * CP + co];
+  if (tap < 9) dw[e] = s;
+  else if (db) db[co] = s;
+}
+
+}  // namespace train
+}  // namespace ra
+
+namespace {
+inline int wgrad_grid_x(int ntiles) { return ntiles < 256 ? ntiles : 256; }
+}  // namespace
+
+extern "C" size_t ra_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int B, int H, int W) {
+  const int cp = ra_conv_cout_padded(Cout);
+  if (!cp || Cin <= 0 || B <= 0) return 0;
+  const int ntiles = ceil_div(W, ra::train::WTW) * ceil_div(H, ra::train::WTH) * B;
+  return (size_t)ceil_div(Cin, 16) * wgrad_grid_x(ntiles) * 10 * 16 * cp;
+}
+
+extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
+                                    int Cout, float *ws, size_t ws_floats, float *dw, float *db, void *stream) {
+  if (!x || !du || !ws || !dw || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
+    return fail(RA_E_INVALID, "ra_conv3x3_wgrad_f32: bad argument");
+  const int cp = ra_conv_cout_padded(Cout);
+  if (Cin % 4 || !cp || cp > 64) return fail(RA_E_SHAPE, "ra_conv3x3_wgrad_f32: Cin %d %% 4 or Cout %d > 64", Cin, Cout);
+  const int ups = upsample ? 1 : 0, H = Hs * (1 + ups), W = Ws * (1 + ups);
+  if (ws_floats < ra_conv3x3_wgrad_workspace_floats(Cin, Cout, B, H, W))
+    return fail(RA_E_WORKSPACE, "ra_conv3x3_wgrad_f32: workspace too small");
+  using namespace ra::train;
+  const int tiles_x = ceil_div(W, WTW), tiles_y = ceil_div(H, WTH), ntiles = tiles_x * tiles_y * B;
+  const int gx = wgrad_grid_x(ntiles), chunks = ceil_div(Cin, 16);
+  const size_t lds_stage = (size_t)(WLH * WLW * 16 + WTH * WTW * cp) * sizeof(float);
+  const size_t lds_red = (size_t)10 * 16 * cp * sizeof(float);
+  const size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
+  hipStream_t st = as_stream(stream);
+#define RA_WGRAD(NT)                                                                                              \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    if (!attr) {                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<NT>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);                         \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(wgrad_kernel<NT>, dim3(gx, chunks), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, H, W, \
+                       Cout, tiles_x, tiles_y, ntiles, ws);                                                      \
+  }
+  switch (cp / 16) {
+    case 1: RA_WGRAD(1) break;
+    case 2: RA_WGRAD(2) break;
+    default: RA_WGRAD(4) break;
+  }
+#undef RA_WGRAD
+  const int total = 9 * Cin * Cout + Cout;
+  hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, ws, gx, chunks, cp, Cin, Cout, dw, db);
+  return launch_status("ra_conv3x3_wgrad_f32");
+}
