@@ -445,6 +445,50 @@ int ra_adam_step_f32(float *params, const float *grads, float *m, float *v, cons
                      size_t n, float lr_t, float beta1, float beta2, float eps, float clip,
                      float grad_scale, void *stream);
 
+/* Train-mode layer pieces of nnlib.cnn / nnlib.dcnn (nnlib.py:229-253,362-400 with
+ * phase_train = True).  The convolution itself is ra_conv3x3_f32 with scale = 1, shift = bias,
+ * no ReLU, no pool (u = conv(x, w) + b); then
+ *   ra_bn_moments_f32       mean[c], var[c] = tf.nn.moments(u, [0,1,2]) (nnlib.py:98; biased,
+ *                           two passes, fixed summation order); u [npix, C], C <= 256.
+ *   ra_bn_act_pool_f32      y = max_pool(relu?(gamma (u - mean) rsqrt(var + eps) + beta))
+ *                           (nnlib.py:111-119,250-253); mean/var/gamma/beta nullable together
+ *                           (use_bn False: y = pool(relu(u))).
+ *   ra_bn_act_pool_bwd_f32  given dy [B,H/pool,W/pool,C]: dbeta, dgamma [C] and
+ *                           du = gamma rstd (dv - mean(dv) - xhat mean(dv xhat)), dv = dy routed to
+ *                           the first maximum of each pool window and masked by the ReLU — the
+ *                           batch statistics are differentiated through, as tf.gradients does.
+ *   ws: ra_bn_workspace_floats(C) device floats.
+ * ra_conv_pack_weights_dev  ra_conv_pack_weights on device pointers (weights change every step).
+ * ra_conv3x3_wgrad_f32      dWf[ky][kx][ci][co] = sum X[b,y+ky-1,x+kx-1,ci] dU[b,y,x,co] for the
+ *                           SAME conv that ran (X zero-stuffed when upsample = 1), db[co] = sum dU
+ *                           (db nullable); f32 MFMA with pixels as the K dimension; Cout <= 64;
+ *                           ws: ra_conv3x3_wgrad_workspace_floats() floats.
+ *   Backward-data is ra_conv3x3_f32 itself on the flipped / in-out-swapped packing
+ *   (RA_CONV_TRANSPOSED for a cnn layer, plain packing of the [3,3,out,in] filter for a dcnn
+ *   layer), followed for stride-2 layers by
+ * ra_subsample_odd_f32      y[b,i,j,:] = x[b,2i+1,2j+1,:], x [B,2H,2W,C] (adjoint of zero-stuffing).
+ * ra_weighted_sum_multi_f32 out[b,n,:] = sum_t w[b,n,t] y[b,t,:] + bias[b,n]: with the coefficients
+ *                           of modellib.f_iou's quotient rule this is d loss / d y_out. */
+size_t ra_bn_workspace_floats(int C);
+int ra_bn_moments_f32(const float *u, size_t npix, int C, float *ws, size_t ws_floats, float *mean,
+                      float *var, void *stream);
+int ra_bn_act_pool_f32(const float *u, const float *mean, const float *var, const float *gamma,
+                       const float *beta, float eps, int relu, int pool, int B, int H, int W, int C,
+                       float *y, void *stream);
+int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const float *mean, const float *var,
+                           const float *gamma, const float *beta, float eps, int relu, int pool,
+                           int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
+                           float *dbeta, float *du, void *stream);
+int ra_conv_pack_weights_dev(const float *w, int Cin_w, int Cout, int Cin, const int *chan_map,
+                             int flags, float *out, void *stream);
+size_t ra_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int B, int H, int W);
+int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
+                         const float *du, int Cout, float *ws, size_t ws_floats, float *dw,
+                         float *db, void *stream);
+int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
+int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
+                              int HW, float *out, void *stream);
+
 /* p[0..n) = value (p 16-byte aligned): the canvas reset `canvas = zeros` (full_model.py:239) and
  * the sigmoid(beta) prefill of y_out behind RA_PASTE_Y_PREFILLED, as a library launch so that the
  * captured forward holds no framework kernel. */

@@ -927,6 +927,11 @@ int dispatch_geo(const PArgs &a, int B, hipStream_t st) {
     const char *e = getenv("RA_PAIR_GEO");
     force = e ? atoi(e) : 0;
   }
+  // single-chunk plain pairs run the persistent kernel, which measures fastest with the 8-row tile
+  // (cfg2 L2+L3: 41.8 us at 32x8 against 47.4 at 32x16 and 45.3 one-shot; profiles/r02)
+  constexpr bool single_chunk = Big::NCHA == 1 && Big::NCHB == 1;
+  if (!force && single_chunk && !a.ups && !a.plane && !narrow && wgs(4, 1) >= 2048)
+    return launch<CINA, CMID, NCB, 4, 1>(a, B, st);
   if constexpr (big_fits) {
     if (force == 42 || (!force && !narrow && wgs(4, 2) >= 512)) return launch<CINA, CMID, NCB, 4, 2>(a, B, st);
   }

@@ -92,6 +92,15 @@ SIGNATURES = {
     'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ra_fill_f32': (_I, [_P, _Z, _F, _P]),
     'ra_adam_step_f32': (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P]),
+    'ra_bn_workspace_floats': (_Z, [_I]),
+    'ra_bn_moments_f32': (_I, [_P, _Z, _I, _P, _Z, _P, _P, _P]),
+    'ra_bn_act_pool_f32': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_bn_act_pool_bwd_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
+    'ra_conv_pack_weights_dev': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    'ra_conv3x3_wgrad_workspace_floats': (_Z, [_I, _I, _I, _I, _I]),
+    'ra_conv3x3_wgrad_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _P, _P]),
+    'ra_subsample_odd_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    'ra_weighted_sum_multi_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'ra_conv_first_cache_supported': (_I, [_I, _I, _I, _I, _I, _I]),
     'ra_conv_first_cache_floats': (_Z, [_I, _I, _I]),
     'ra_conv_first_cache_f32': (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),
