@@ -72,13 +72,31 @@ def bn_eval(x, P, key):
   return x * inv + (P[key + '_beta'] - P[key + '_ema_mean'] * inv)
 
 
+def bn_train(x, P, key, stats):
+  """nnlib.batch_norm, training branch (nnlib.py:98-112): moments over (B, H, W) with the biased
+  variance, differentiated through; the (mean, var) pair is recorded for the EMA update
+  shadow = 0.9 shadow + 0.1 value (nnlib.py:103-110)."""
+  mean = x.mean(dim=(0, 1, 2))
+  var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+  if stats is not None:
+    stats[key] = (mean.detach(), var.detach())
+  return (x - mean) * torch.rsqrt(var + 1e-3) * P[key + '_gamma'] + P[key + '_beta']
+
+
+_BN = {'train': False, 'stats': None}
+
+
+def bn(x, P, key):
+  return bn_train(x, P, key, _BN['stats']) if _BN['train'] else bn_eval(x, P, key)
+
+
 def cnn(x, P, scope, n, pools, tt, use_bn):
   """nnlib.cnn / run_cnn (nnlib.py:214-255): conv + b -> BN -> ReLU -> pool, all layers returned."""
   hs = []
   for i in range(n):
     h = conv_same(x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)])
     if use_bn:
-      h = bn_eval(h, P, '%s_%d_%d' % (scope, i, tt))
+      h = bn(h, P, '%s_%d_%d' % (scope, i, tt))
     x = pool(torch.relu(h), pools[i])
     hs.append(x)
   return hs
@@ -92,7 +110,7 @@ def dcnn(x, P, scope, n, unpool, tt, skip, use_bn):
       x = torch.cat([x, skip[i]], dim=3)
     h = deconv_same(x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)], unpool[i])
     if use_bn:
-      h = bn_eval(h, P, '%s_%d_%d' % (scope, i, tt))
+      h = bn(h, P, '%s_%d_%d' % (scope, i, tt))
     x = torch.relu(h)
     hs.append(x)
   return hs
@@ -135,9 +153,18 @@ def extract(x, fy, fx):
   return torch.einsum('bjwc,bwi->bjic', t, fx)
 
 
-def forward(opt, Pnp, x, d_in=None, y_in=None, requires_grad=()):
-  """Eval-mode forward of full_model.py:638-907.  Returns (outputs dict of torch tensors, P dict);
-  parameters named in `requires_grad` are leaves with gradients enabled."""
+def forward(opt, Pnp, x, d_in=None, y_in=None, requires_grad=(), phase_train=False, bn_stats=None):
+  """Forward of full_model.py:638-907 with use_knob False.  Returns (outputs dict of torch tensors,
+  P dict); parameters named in `requires_grad` are leaves with gradients enabled.  phase_train:
+  BatchNorm on batch statistics (recorded into `bn_stats` when a dict is passed)."""
+  _BN['train'], _BN['stats'] = bool(phase_train), bn_stats
+  try:
+    return _forward(opt, Pnp, x, d_in, y_in, requires_grad)
+  finally:
+    _BN['train'], _BN['stats'] = False, None
+
+
+def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
   d = ora.derive(opt)
   P = {k: t64(v).requires_grad_(k in requires_grad) for k, v in Pnp.items()}
   x = t64(x)
@@ -210,6 +237,18 @@ def iou_pairwise(a, b):
   inter = torch.einsum('bnhw,bmhw->bnm', a, b)
   sa, sb = a.sum(dim=(2, 3))[:, :, None], b.sum(dim=(2, 3))[:, None, :]
   return inter / (sa + sb - inter + 1e-5 * a.shape[2] * a.shape[3])
+
+
+def weight_decay_term(opt, P):
+  """The wd * l2_loss(w) terms nnlib.weight_variable adds to the 'losses' collection
+  (nnlib.py:59-61): l2_loss = sum(w^2) / 2, filters and matrices only."""
+  wd = ora._opt(opt, 'weight_decay', 0.0) or 0.0
+  tot = 0.0
+  for k, v in P.items():
+    tail = k.split('_')
+    if 'w' in tail or (len(tail[-1]) == 3 and tail[-1][0] == 'w' and tail[-1][1] in 'xh'):
+      tot = tot + wd * 0.5 * (v ** 2).sum()
+  return tot
 
 
 def loss_head(opt, fwd, y_gt, s_gt):

@@ -179,13 +179,12 @@ class Model(dict):
     single = isinstance(outputs, str)
     names = [outputs] if single else list(outputs)
     for n in names:
-      if n in self.TRAIN_ONLY:
-        raise NotImplementedError(
-            'output %r needs the training step (SURVEY.md §8f rank 2), not built yet' % n)
-      if n not in self.OUTPUTS and n not in self.LOSS_OUTPUTS:
+      if n not in self.OUTPUTS and n not in self.LOSS_OUTPUTS and n not in self.TRAIN_ONLY:
         raise KeyError(n)
-    if nn._is_train(feed.get('phase_train', False)):
-      raise NotImplementedError('phase_train=True is the training step (not built yet)')
+    if 'train_step' in names or nn._is_train(feed.get('phase_train', False)):
+      return self._run_train(names, feed, single, as_numpy)
+    if any(n in self.TRAIN_ONLY for n in names):
+      raise RecAttendError('outputs %r need phase_train = True' % [n for n in names if n in self.TRAIN_ONLY])
     d = self.dims
     want_loss = any(n in self.LOSS_OUTPUTS for n in names)
     if want_loss and self.box_model:
@@ -199,6 +198,40 @@ class Model(dict):
     if as_numpy:
       torch.cuda.synchronize()
       res = [r.detach().cpu().numpy() for r in res]
+    return res[0] if single else res
+
+  def _run_train(self, names, feed, single, as_numpy):
+    """sess.run([loss, train_step], feed{x, y_gt, s_gt, phase_train=True}) (full_model_train.py:107):
+    the training graph on BatchNorm batch statistics; fetching `train_step` applies one optimizer
+    step (ra_train.TrainStep: backward, gradient all-reduce over the ranks, clip + Adam, EMA)."""
+    import ra_train
+    if self.box_model:
+      raise NotImplementedError('box_model training (box_model.py:520-652) is not built')
+    if 'y_gt' not in feed or 's_gt' not in feed:
+      raise RecAttendError('the training graph needs y_gt and s_gt in the feed')
+    if getattr(self, 'trainer', None) is None:
+      self.trainer = ra_train.TrainStep(self)
+    tr = self.trainer
+    if 'train_step' in names:
+      out = tr.run(feed['x'], feed['y_gt'], feed['s_gt'])
+    else:
+      with torch.no_grad():
+        _, out, _ = tr.forward_loss(feed['x'], feed['y_gt'], feed['s_gt'])
+      out = dict(out)
+      out['learn_rate'] = ra_train.learn_rate(self.opt, tr.bucket.global_step)
+    res = []
+    for n in names:
+      if n == 'train_step':
+        res.append(None)
+      elif n == 'learn_rate':
+        res.append(out['learn_rate'])
+      elif n in out:
+        res.append(out[n])
+      else:
+        raise NotImplementedError('output %r is not available from the training graph' % n)
+    if as_numpy:
+      torch.cuda.synchronize()
+      res = [r.detach().cpu().numpy() if isinstance(r, torch.Tensor) else r for r in res]
     return res[0] if single else res
 
   def _loss_head(self, eng, feed):

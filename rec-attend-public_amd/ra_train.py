@@ -106,6 +106,9 @@ class GradBucket(object):
                                     rn.stream_ptr()), 'ra_adam_step_f32')
     self.global_step = t
     self.model['global_step'] = float(t)
+    eng = getattr(self.model, 'engine', None)
+    if eng is not None:  # the kernel wrote the weights behind torch's version counters: repack on next decode
+      eng._stamp = None
     return lr
 
 
@@ -116,3 +119,381 @@ def allreduce_moments(sums):
   if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
   return sums
+
+
+# =====================================================================================================
+# The training graph (full_model.py:638-1057, phase_train = True) as a torch.autograd tape over
+# HIP kernels.  torch is the tape and the memory; what runs on the GPU:
+#   * every conv layer of the three CNNs — forward (MFMA conv, BN batch moments, normalise + ReLU +
+#     pool) and backward (BN / pool / ReLU adjoint, backward-data on the MFMA conv kernel with the
+#     flipped packing, backward-weight on MFMA) — ConvBNActPool, csrc/ra_train.hip + ra_conv.hip;
+#   * the pairwise soft IoU of the two losses and its adjoint — PairIoU, csrc/ra_loss.hip;
+#   * the ground-truth boxes and both Hungarian matchings (device solver), clip + Adam;
+#   * the small dense algebra (LSTM / MLP GEMMs, the [L,F] Gaussian filter banks and the
+#     F_y^T X F_x contractions of extract / paste) as library GEMMs + elementwise ops under autograd.
+# =====================================================================================================
+import ctypes as _C
+
+import ra_ops as ops
+
+BN_EPS = ops.BN_EPS
+EMA_DECAY = 0.9  # 1 - 0.1 * phase_train (nnlib.py:103-104)
+
+
+def _f(*shape, device):
+  return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _pack_dev(w, cin_w, cout, cin, cmap_t, transposed):
+  n = rn.lib().ra_conv_packed_floats(cin, cout)
+  if n == 0:
+    raise rn.RecAttendError('unsupported conv shape Cin=%d Cout=%d' % (cin, cout))
+  out = _f(n, device=w.device)
+  check(rn.lib().ra_conv_pack_weights_dev(ptr(w), int(cin_w), int(cout), int(cin), ptr(cmap_t),
+                                          rn.RA_CONV_TRANSPOSED if transposed else 0, ptr(out), rn.stream_ptr()),
+        'ra_conv_pack_weights_dev')
+  return out
+
+
+def _pad_map(n_real, n_kernel, device):
+  """chan_map for a kernel input of n_kernel channels whose first n_real are real."""
+  if n_real == n_kernel:
+    return None
+  return torch.tensor(list(range(n_real)) + [-1] * (n_kernel - n_real), dtype=torch.int32, device=device)
+
+
+def _pad_channels(t, mult=4):
+  c = t.shape[-1]
+  cp = -(-c // mult) * mult
+  if cp == c:
+    return t.contiguous()
+  out = torch.zeros(t.shape[:-1] + (cp,), dtype=t.dtype, device=t.device)
+  out[..., :c] = t
+  return out
+
+
+class ConvBNActPool(torch.autograd.Function):
+  """One layer of nnlib.cnn (nnlib.py:229-253) or nnlib.dcnn (nnlib.py:362-400) in training mode.
+
+  x [B,Hs,Ws,Cx] (Cx % 4 == 0), w in the reference layout ([3,3,Cin,Cout]; transposed:
+  [3,3,Cout,Cin]), b [Cout], gamma / beta [Cout] or None.  Returns (y, batch mean, batch var)."""
+
+  @staticmethod
+  def forward(ctx, x, w, b, gamma, beta, meta):
+    dev = x.device
+    x = x.contiguous()
+    B, Hs, Ws, Cx = x.shape
+    tr, stride, pool, relu = meta['transposed'], meta['stride'], meta['pool'], meta['relu']
+    cout, cin_w = (w.shape[2], w.shape[3]) if tr else (w.shape[3], w.shape[2])
+    cmap = meta.get('chan_map')
+    cmap_t = torch.tensor(cmap, dtype=torch.int32, device=dev) if cmap is not None else _pad_map(cin_w, Cx, dev)
+    cp = ops.cout_padded(cout)
+    wp = _pack_dev(w.contiguous(), cin_w, cout, Cx, cmap_t, tr)
+    scale = torch.ones(cp, dtype=torch.float32, device=dev)
+    shift = torch.zeros(cp, dtype=torch.float32, device=dev)
+    shift[:cout] = b
+    u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2))
+    H, W = u.shape[1], u.shape[2]
+    use_bn = gamma is not None
+    mean = var = None
+    if use_bn:
+      mean, var, ws = _f(cout, device=dev), _f(cout, device=dev), _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
+      check(rn.lib().ra_bn_moments_f32(ptr(u), B * H * W, cout, ptr(ws), ws.numel(), ptr(mean), ptr(var),
+                                       rn.stream_ptr()), 'ra_bn_moments_f32')
+    y = _f(B, H // pool, W // pool, cout, device=dev)
+    check(rn.lib().ra_bn_act_pool_f32(ptr(u), ptr(mean), ptr(var), ptr(gamma), ptr(beta), _C.c_float(BN_EPS), int(relu),
+                                      int(pool), B, H, W, cout, ptr(y), rn.stream_ptr()), 'ra_bn_act_pool_f32')
+    ctx.meta, ctx.cmap = meta, cmap
+    ctx.save_for_backward(x, w, u, mean, var, gamma, beta)
+    if use_bn:
+      ctx.mark_non_differentiable(mean, var)
+      return y, mean, var
+    z = torch.zeros(0, device=dev)
+    ctx.mark_non_differentiable(z)
+    return y, z, z
+
+  @staticmethod
+  def backward(ctx, dy, _dm, _dv):
+    x, w, u, mean, var, gamma, beta = ctx.saved_tensors
+    meta, cmap = ctx.meta, ctx.cmap
+    dev = x.device
+    tr, stride, pool, relu = meta['transposed'], meta['stride'], meta['pool'], meta['relu']
+    B, Hs, Ws, Cx = x.shape
+    _, H, W, cout = u.shape
+    cin_w = w.shape[3] if tr else w.shape[2]
+    dy = dy.contiguous()
+    ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
+    dgamma, dbeta, du = _f(cout, device=dev), _f(cout, device=dev), torch.empty_like(u)
+    check(rn.lib().ra_bn_act_pool_bwd_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                          _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
+                                          ptr(dgamma), ptr(dbeta), ptr(du), rn.stream_ptr()), 'ra_bn_act_pool_bwd_f32')
+    # ---- backward-weight (of the SAME conv that ran) + bias
+    nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, B, H, W)
+    wws = _f(nws, device=dev)
+    dWf, db = _f(3, 3, Cx, cout, device=dev), _f(cout, device=dev)
+    check(rn.lib().ra_conv3x3_wgrad_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
+                                        ptr(dWf), ptr(db), rn.stream_ptr()), 'ra_conv3x3_wgrad_f32')
+    if cmap is not None:  # packed kernel channels -> the filter's own input channels
+      real = torch.zeros((3, 3, cin_w, cout), dtype=torch.float32, device=dev)
+      for c, j in enumerate(cmap):
+        if j >= 0:
+          real[:, :, j, :] += dWf[:, :, c, :]
+      dWf = real
+    elif Cx != cin_w:
+      dWf = dWf[:, :, :cin_w, :]
+    dw = dWf.flip(0, 1).permute(0, 1, 3, 2).contiguous() if tr else dWf.contiguous()
+    # ---- backward-data: the same MFMA conv kernel on the flipped / in-out-swapped packing
+    dx = None
+    if ctx.needs_input_grad[0]:
+      duc = _pad_channels(du)
+      cd = duc.shape[3]
+      ones = torch.ones(ops.cout_padded(cin_w), dtype=torch.float32, device=dev)
+      zeros = torch.zeros_like(ones)
+      wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr)
+      dxr = ops.conv3x3(duc, wpb, ones, zeros, cin_w, relu=False, pool=1)
+      if stride == 2:
+        sub = _f(B, Hs, Ws, cin_w, device=dev)
+        check(rn.lib().ra_subsample_odd_f32(ptr(dxr), B, Hs, Ws, cin_w, ptr(sub), rn.stream_ptr()),
+              'ra_subsample_odd_f32')
+        dxr = sub
+      if cmap is not None:
+        dx = torch.zeros_like(x)
+        for c, j in enumerate(cmap):
+          if j >= 0:
+            dx[..., c] = dxr[..., j]
+      elif Cx != cin_w:
+        dx = torch.zeros_like(x)
+        dx[..., :cin_w] = dxr
+      else:
+        dx = dxr
+    use_bn = gamma is not None
+    return dx, dw, db, (dgamma if use_bn else None), (dbeta if use_bn else None), None
+
+
+class PairIoU(torch.autograd.Function):
+  """modellib.f_iou(a, b, pairwise=True) (modellib.py:124-155) with its gradient in a: one
+  streaming MFMA pass forward (K8), one weighted-sum pass backward."""
+
+  @staticmethod
+  def forward(ctx, a, b):
+    a, b = a.contiguous(), b.contiguous()
+    st = ops.pair_stats(a, b, want=('iou_soft', 'inter', 'sum_a', 'sum_b'))
+    ctx.save_for_backward(b, st['inter'], st['sum_a'], st['sum_b'])
+    ctx.hw = a.shape[2] * a.shape[3]
+    ctx.shape = a.shape
+    return st['iou_soft']
+
+  @staticmethod
+  def backward(ctx, g):
+    b, I, sa, sb = ctx.saved_tensors
+    U = sa[:, :, None] + sb[:, None, :] - I + 1e-5 * ctx.hw
+    c1 = (g * (U + I) / (U * U)).contiguous()     # d iou / d a_p = b_p (U + I) / U^2 - I / U^2
+    c0 = (-(g * I / (U * U)).sum(dim=2)).contiguous()
+    B, N, H, W = ctx.shape
+    out = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
+    check(rn.lib().ra_weighted_sum_multi_f32(ptr(c1), ptr(c0), ptr(b), B, N, b.shape[1], H * W, ptr(out),
+                                             rn.stream_ptr()), 'ra_weighted_sum_multi_f32')
+    return out, None
+
+
+def gaussian_filter(ctr, size, lg_var, L, F):
+  """modellib.get_gaussian_filter (modellib.py:581-612), differentiable: ctr, size, lg_var [B]."""
+  dev = ctr.device
+  j = torch.arange(F, dtype=torch.float32, device=dev)
+  mu = ctr[:, None] + ((size[:, None] + 1.0) / F) * (j[None, :] - (F - 1) / 2.0)
+  l = torch.arange(L, dtype=torch.float32, device=dev)
+  var = torch.exp(lg_var)[:, None, None]
+  dd = l[None, :, None] - mu[:, None, :]
+  return torch.exp(-0.5 * dd * dd / var) / (torch.sqrt(var) * math.sqrt(2 * math.pi))
+
+
+def extract(x, fy, fx):
+  """modellib.extract_patch (modellib.py:615-641): F_y^T X_c F_x per channel; x [B,H,W,C]."""
+  B, H, W, C = x.shape
+  t = torch.bmm(fy.transpose(1, 2), x.reshape(B, H, W * C)).reshape(B, -1, W, C)     # [B,Fh,W,C]
+  t = torch.matmul(t.permute(0, 1, 3, 2), fx[:, None])                                # [B,Fh,C,Fw]
+  return t.permute(0, 1, 3, 2)
+
+
+def paste(p, fy, fx):
+  """extract_patch(p, F_y^T, F_x^T) of a one-channel patch (full_model.py:810-811): F_y P F_x^T."""
+  return torch.bmm(torch.bmm(fy, p), fx.transpose(1, 2))
+
+
+class TrainStep(object):
+  """model.run(['loss', 'train_step'], feed) of the reference's trainer (full_model_train.py:107)."""
+
+  def __init__(self, model, world=1):
+    import full_model  # noqa: F401  (the Model class)
+    self.model, self.opt, self.d = model, model.opt, model.dims
+    d = self.d
+    if not torch.cuda.is_available():
+      raise rn.RecAttendError('the training step needs an MI355X (HIP device); there is no CPU fallback')
+    if d['add_d_out'] or d['skip_ch'] is not None and any(d['skip_ch']):
+      raise NotImplementedError('training is built for the CVPPP architecture (no d_in / y_in, no skip connections)')
+    if not self.opt.get('stop_canvas_grad', True):
+      raise NotImplementedError('stop_canvas_grad = False (gradient through the canvas) is not built')
+    if self.opt.get('box_loss_fn', 'iou') != 'iou' or self.opt.get('segm_loss_fn', 'iou') != 'iou':
+      raise NotImplementedError('training is built for box_loss_fn = segm_loss_fn = "iou" (the run scripts)')
+    self.bucket = GradBucket(model)
+    self.world = world
+    self.leaves = {}
+    for k in self.bucket.names:
+      leaf = model[k].detach().requires_grad_(True)  # shares the bucket's storage
+      leaf.grad = self.bucket.grad_of[k]            # autograd accumulates straight into the bucket
+      self.leaves[k] = leaf
+    cmap_c, _ = model.engine._chan_map(d['ctrl_in'])
+    cmap_a, _ = model.engine._chan_map(d['attn_in'])
+    self.cmap_c = None if cmap_c == list(range(len(cmap_c))) else cmap_c
+    self.cmap_a = None if cmap_a == list(range(len(cmap_a))) else cmap_a
+
+  # ------------------------------------------------------------------ pieces
+  def _cnn(self, x, scope, n, pools, tt, cmap0, stats):
+    P, hs = self.leaves, []
+    for i in range(n):
+      bn = self.d['use_bn']
+      key = '%s_%d_%d' % (scope, i, tt)
+      meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None)
+      x, mean, var = ConvBNActPool.apply(_pad_channels(x) if i else x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
+                                         P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
+      if bn:
+        stats[key] = (mean, var)
+      hs.append(x)
+    return hs
+
+  def _dcnn(self, x, scope, n, unpool, tt, stats):
+    P = self.leaves
+    for i in range(n):
+      bn = self.d['use_bn']
+      key = '%s_%d_%d' % (scope, i, tt)
+      meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=None)
+      x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
+                                         P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
+      if bn:
+        stats[key] = (mean, var)
+    return x
+
+  def _controller(self, feat):
+    """full_model.py:668-689 on [B,G,Cf] features: glimpse read-out, LSTM (state = [c|h], zeroed per
+    timestep), glimpse MLP (softmax over G), controller MLP."""
+    P, d = self.leaves, self.d
+    B, G, hid = feat.shape[0], d['G'], d['hid']
+    c = torch.zeros((B, hid), device=feat.device)
+    h = torch.zeros((B, hid), device=feat.device)
+    gmap = torch.full((B, G, 1), 1.0 / G, device=feat.device)
+    gate = lambda g, xin, hh: xin @ P['ctrl_lstm_w_x' + g] + hh @ P['ctrl_lstm_w_h' + g] + P['ctrl_lstm_b_' + g]
+    for it in range(d['iters']):
+      glimpse = (feat * gmap).sum(dim=1)
+      gi, gf, go = torch.sigmoid(gate('i', glimpse, h)), torch.sigmoid(gate('f', glimpse, h)), torch.sigmoid(gate('o', glimpse, h))
+      u = torch.tanh(gate('u', glimpse, h))
+      c = gf * c + gi * u
+      h = go * torch.tanh(c)
+      if it < d['iters'] - 1:
+        z = h
+        for l in range(d['n_gmlp']):
+          z = z @ P['glimpse_mlp_w_%d' % l] + P['glimpse_mlp_b_%d' % l]
+          z = torch.relu(z) if l < d['n_gmlp'] - 1 else torch.softmax(z, dim=1)
+        gmap = z[:, :, None]
+    z = h
+    for l in range(d['n_cmlp']):
+      z = z @ P['ctrl_mlp_w_%d' % l] + P['ctrl_mlp_b_%d' % l]
+      if l < d['n_cmlp'] - 1:
+        z = torch.relu(z)
+    return h, z
+
+  # ------------------------------------------------------------------ forward + loss
+  def forward_loss(self, x, y_gt, s_gt):
+    """The training graph with use_knob False: returns (total loss, dict of pieces, BN batch stats)."""
+    P, d, opt = self.leaves, self.d, self.opt
+    dev = self.bucket.param.device
+    as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
+        device=dev, dtype=torch.float32).contiguous()
+    x, y_gt, s_gt = as_t(x), as_t(y_gt), as_t(s_gt)
+    B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
+    if opt.get('use_knob', False):
+      raise NotImplementedError('use_knob = True (ground-truth mixing, full_model.py:744-773,826-841)')
+    canvas = torch.zeros((B, H, W, 1), device=dev)
+    stats, y_list, s_list, box_list = {}, [], [], []
+    dims_hw = torch.tensor([H, W], dtype=torch.float32, device=dev)
+    dims_f = torch.tensor([Fh, Fw], dtype=torch.float32, device=dev)
+    for tt in range(T):
+      inp = torch.cat([x, canvas], dim=3)   # packed [x | canvas]; C0p = 4 on this architecture
+      if inp.shape[3] != d['C0p']:
+        inp = _pad_channels(inp)
+      feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
+      h, co = self._controller(feat.reshape(B, d['G'], -1))
+      cn, ls = co[:, 0:2], co[:, 2:4]
+      if d['squash']:
+        cn, ls = torch.tanh(cn), -torch.nn.functional.softplus(ls)
+      ctr = (cn + 1.0) * dims_hw / 2.0                          # modellib.py:752-764
+      size = torch.exp(ls) * dims_hw                            # :812-825
+      lg_var = torch.zeros_like(ctr) if d['fixed_var'] else torch.log(size) - torch.log(dims_f)
+      if d['dynamic_var']:
+        lg_var = co[:, 4:6]
+      if d['fixed_gamma']:
+        attn_gamma, y_lg_gamma = torch.ones((B, 1, 1, 1), device=dev), torch.full((B, 1, 1), 2.0, device=dev)
+      else:
+        attn_gamma, y_lg_gamma = torch.exp(co[:, 6]).reshape(B, 1, 1, 1), co[:, 8].reshape(B, 1, 1)
+      box_gamma = torch.exp(co[:, 7]).reshape(B, 1, 1)
+      fy = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh)
+      fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+      # attention box: extract_patch(ones * gamma, F_y^T, F_x^T) = gamma * rowsum(F_y) (x) rowsum(F_x)
+      box = torch.sigmoid(box_gamma * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
+      x_patch = attn_gamma * extract(inp.detach(), fy, fx)
+      core = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)[-1]
+      y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats)
+      y = torch.sigmoid(torch.exp(y_lg_gamma) * paste(y_patch[..., 0], fy, fx) - 5.0)        # [B,H,W]
+      if d['disable_overwrite']:
+        y = (1.0 - canvas[..., 0]) * y
+      s = torch.sigmoid(torch.cat([h, core.reshape(B, -1)], dim=1) @ P['score_mlp_w_0'] + P['score_mlp_b_0'])
+      canvas = torch.maximum(y.detach()[..., None], canvas)      # stop_canvas_grad (full_model.py:843-848)
+      y_list.append(y)
+      s_list.append(s)
+      box_list.append(box)
+    y_out, s_out = torch.stack(y_list, dim=1), torch.cat(s_list, dim=1)
+    attn_box = torch.stack(box_list, dim=1)
+    # ---- losses (full_model.py:913-1035), box_loss_fn = segm_loss_fn = 'iou'
+    _, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0)
+    fixed = bool(opt.get('fixed_order', False))
+    ident = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
+
+    def matched_iou(a, b):
+      iou = PairIoU.apply(a, b)
+      if fixed:
+        m = ident
+      else:
+        m, st = ops.segm_match(iou.detach(), s_gt)
+        ops.check_match_status(st, 'f_segm_match')
+      cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
+      return ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B, m
+
+    iou_box, m_box = matched_iou(attn_box, box_gt)
+    iou_soft, m = matched_iou(y_out, y_gt)
+    s_min = torch.cummin(s_out, dim=1)[0]
+    s_max = torch.flip(torch.cummax(torch.flip(s_out, [1]), dim=1)[0], [1])
+    ms = m.sum(dim=2)
+    conf = (-ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)).sum() / B / T
+    loss = -iou_box - iou_soft + float(opt.get('loss_mix_ratio', 1.0)) * conf
+    pieces = {'loss': loss, 'box_loss': -iou_box, 'segm_loss': -iou_soft, 'conf_loss': conf, 'iou_soft': iou_soft,
+              'iou_soft_box': iou_box, 'match': m, 'match_box': m_box, 'y_out': y_out, 's_out': s_out}
+    return loss, pieces, stats
+
+  # ------------------------------------------------------------------ one optimisation step
+  def run(self, x, y_gt, s_gt):
+    """loss + train_step: backward into the flat bucket, one all-reduce, clip + Adam, BN EMA update.
+    The reported `loss` excludes nothing the reference includes except the weight-decay terms, which
+    enter through their gradient (wd * w) inside the optimizer kernel."""
+    self.bucket.zero_grad()
+    loss, pieces, stats = self.forward_loss(x, y_gt, s_gt)
+    loss.backward()
+    world = self.bucket.allreduce()
+    lr = self.bucket.step(world=world)
+    with torch.no_grad():  # shadow = 0.9 shadow + 0.1 batch statistic (nnlib.py:103-110)
+      for key, (mean, var) in stats.items():
+        self.model[key + '_ema_mean'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * mean)
+        self.model[key + '_ema_var'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * var)
+    wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
+    out = {k: v.detach() for k, v in pieces.items()}
+    out['learn_rate'] = lr
+    out['weight_decay_loss'] = 0.5 * (self.bucket.wd * self.bucket.param * self.bucket.param).sum().detach() if wd else 0.0
+    return out

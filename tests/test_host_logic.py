@@ -105,10 +105,17 @@ def test_bn_fold_and_controller_packing():
 def test_unbuilt_parts_fail_loudly():
   opt = ora.make_opt('cvppp', 64, 64, 2)
   m = full_model.get_model(opt)
-  with pytest.raises(NotImplementedError):
+  with pytest.raises(rn.RecAttendError):  # the training graph needs the ground truth in the feed
     m.run(['loss', 'train_step'], {'x': np.zeros((1, 64, 64, 3), np.float32), 'phase_train': True})
-  with pytest.raises(NotImplementedError):
-    m.run('y_out', {'x': np.zeros((1, 64, 64, 3), np.float32), 'phase_train': True})
+  if not torch.cuda.is_available():
+    zeros = lambda *s: np.zeros(s, np.float32)
+    with pytest.raises(rn.RecAttendError):  # and an MI355X: the optimizer / conv kernels have no CPU form
+      m.run(['loss', 'train_step'], {'x': zeros(1, 64, 64, 3), 'y_gt': zeros(1, 2, 64, 64), 's_gt': zeros(1, 2),
+                                     'phase_train': True})
+  if torch.cuda.is_available():
+    with pytest.raises(NotImplementedError):  # the KITTI / Cityscapes training graphs (skips, d_in / y_in)
+      import ra_train
+      ra_train.TrainStep(full_model.get_model(ora.make_opt('kitti', 64, 96, 2)))
   with pytest.raises(KeyError):
     m.run('nonsense', {'x': None})
   with pytest.raises(NotImplementedError):
