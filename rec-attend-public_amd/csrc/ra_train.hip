@@ -106,12 +106,14 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *u, const 
     const int xo = (int)(r % Wo);
     r /= Wo;
     const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    // (u - mean) first: the folded form u * g + (beta - mean * g) cancels badly in channels whose
+    // mean is large against their spread, and rstd amplifies that error layer after layer
     const float g = (gamma ? gamma[c] : 1.f) * (var ? rsqrtf(var[c] + eps) : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - (mean ? mean[c] : 0.f) * g;
+    const float mu = mean ? mean[c] : 0.f, be = beta ? beta[c] : 0.f;
     float best = -__builtin_inff();
     for (int dy = 0; dy < pool; ++dy)
       for (int dx = 0; dx < pool; ++dx) {
-        const float v = u[(((size_t)b * H + yo * pool + dy) * W + xo * pool + dx) * C + c] * g + sh;
+        const float v = (u[(((size_t)b * H + yo * pool + dy) * W + xo * pool + dx) * C + c] - mu) * g + be;
         best = fmaxf(best, fmaxf(v, lo));
       }
     y[e] = best;
@@ -119,13 +121,13 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *u, const 
 }
 
 // ---- backward, stage 1: per-channel sums of dv and dv * xhat (dv = dy routed through pool + ReLU) ----
-__device__ inline void bwd_point(const float *u, const float *dy, float g, float sh, float mu, float rstd, float lo,
+__device__ inline void bwd_point(const float *u, const float *dy, float g, float be, float mu, float rstd, float lo,
                                  int relu, int pool, int b, int yy, int xx, int H, int W, int C, int c, float &dv,
                                  float &xhat) {
   // gradient reaching pre-activation v at conv pixel (yy, xx): the pooled window's FIRST maximum gets dy
   const float uv = u[(((size_t)b * H + yy) * W + xx) * C + c];
   xhat = (uv - mu) * rstd;
-  const float v = uv * g + sh;
+  const float v = (uv - mu) * g + be;
   if (pool == 1) {
     dv = (relu && v <= 0.f) ? 0.f : dy[(((size_t)b * H + yy) * W + xx) * C + c];
     return;
@@ -134,7 +136,7 @@ __device__ inline void bwd_point(const float *u, const float *dy, float g, float
   float best = -__builtin_inff();
   int arg = 0;
   for (int k = 0; k < 4; ++k) {
-    const float w = u[(((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * C + c] * g + sh;
+    const float w = (u[(((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * C + c] - mu) * g + be;
     const float a = fmaxf(w, lo);
     if (a > best) {
       best = a;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *u, cons
   float s0 = 0.f, s1 = 0.f;
   if (pl < lanes) {
     const float rstd = var ? rsqrtf(var[c] + eps) : 1.f, mu = mean ? mean[c] : 0.f;
-    const float g = (gamma ? gamma[c] : 1.f) * rstd, sh = (beta ? beta[c] : 0.f) - mu * g;
+    const float g = (gamma ? gamma[c] : 1.f) * rstd, sh = beta ? beta[c] : 0.f;
     const float lo = relu ? 0.f : -__builtin_inff();
     const size_t npix = (size_t)B * H * W;
     for (size_t p = (size_t)blockIdx.x * lanes + pl; p < npix; p += (size_t)gridDim.x * lanes) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float *u, const fl
     r /= W;
     const int yy = (int)(r % H), b = (int)(r / H);
     const float rstd = var ? rsqrtf(var[c] + eps) : 1.f, mu = mean ? mean[c] : 0.f;
-    const float g = (gamma ? gamma[c] : 1.f) * rstd, sh = (beta ? beta[c] : 0.f) - mu * g;
+    const float g = (gamma ? gamma[c] : 1.f) * rstd, sh = beta ? beta[c] : 0.f;
     float dv, xhat;
     bwd_point(u, dy, g, sh, mu, rstd, lo, relu, pool, b, yy, xx, H, W, C, c, dv, xhat);
     du[e] = var ? g * (dv - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n) : dv;
