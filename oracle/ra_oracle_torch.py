@@ -153,15 +153,40 @@ def extract(x, fy, fx):
   return torch.einsum('bjwc,bwi->bjic', t, fx)
 
 
-def forward(opt, Pnp, x, d_in=None, y_in=None, requires_grad=(), phase_train=False, bn_stats=None):
+def knob_setup(opt, y_gt, knobs, global_step):
+  """full_model.py:559-625: the noisy ground-truth attention (get_gt_attn with the drawn padding /
+  centre shift), the plain GT boxes for the greedy match, and the two knob masks."""
+  T = y_gt.shape[1]
+  mp = opt['padding'] + 4.0
+  _, _, box_gt = ora.get_gt_box(y_gt, padding_ratio=opt['attn_box_padding_ratio'], center_shift_ratio=0.0, min_padding=mp)
+  tl, br, _ = ora.get_gt_box(y_gt, padding_ratio=knobs['pad'], center_shift_ratio=knobs['shift'], min_padding=mp)
+  scale = 1.0 + np.log(1.0 + np.arange(T) * 3.0) if ora._opt(opt, 'knob_use_timescale', False) else np.ones(T)
+  prob = lambda off: np.minimum(1.0, opt['knob_base'] * opt['knob_decay'] ** (
+      max(0.0, global_step - off) / opt['steps_per_knob_decay']) * scale)[None, :, None]
+  return {'ctr': t64((tl + br) / 2.0), 'size': t64(br - tl), 'box_gt': box_gt,
+          'kb': t64((knobs['u_box'] <= prob(opt['knob_box_offset'])).astype(np.float64)),
+          'ks': t64((knobs['u_segm'] <= prob(opt['knob_segm_offset'])).astype(np.float64)),
+          'noise': t64(knobs['segm_noise']), 'y_gt': t64(y_gt)}
+
+
+_KNOB = {'k': None}
+
+
+def forward(opt, Pnp, x, d_in=None, y_in=None, requires_grad=(), phase_train=False, bn_stats=None, knobs=None,
+            y_gt=None, global_step=0):
   """Forward of full_model.py:638-907 with use_knob False.  Returns (outputs dict of torch tensors,
   P dict); parameters named in `requires_grad` are leaves with gradients enabled.  phase_train:
   BatchNorm on batch statistics (recorded into `bn_stats` when a dict is passed)."""
   _BN['train'], _BN['stats'] = bool(phase_train), bn_stats
+  _KNOB['k'] = None
+  if knobs is not None and ora._opt(opt, 'use_knob', False):  # ground-truth mixing, training only
+    kn = {k: np.asarray(v, dtype=np.float64) for k, v in knobs.items()}
+    _KNOB['k'] = knob_setup(opt, np.asarray(y_gt, dtype=np.float64), kn, global_step)
   try:
     return _forward(opt, Pnp, x, d_in, y_in, requires_grad)
   finally:
     _BN['train'], _BN['stats'] = False, None
+    _KNOB['k'] = None
 
 
 def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
@@ -209,6 +234,21 @@ def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
     fyi, fxi = fy.transpose(1, 2), fx.transpose(1, 2)
     ones = torch.ones((B, Fh, Fw, 1), dtype=DT)
     attn_box = torch.sigmoid(extract(ones * box_gamma, fyi, fxi) - 5.0).reshape(B, 1, H, W)  # :738-741
+    K = _KNOB['k']
+    if K is not None:  # full_model.py:744-785: GT box kicked in, filters recomputed (lg_var unchanged)
+      if ora._opt(opt, 'fixed_order', False):
+        ctr_m, size_m, gm = K['ctr'][:, tt], K['size'][:, tt], None
+      else:
+        a = attn_box.detach().numpy()
+        iou_t = ora.f_inter(a, K['box_gt']) / ora.f_union(a, K['box_gt'], eps=1e-5)
+        gm = t64(ora.f_greedy_match(iou_t, np.zeros_like(iou_t)))
+        ctr_m, size_m = (gm[:, :, None] * K['ctr']).sum(dim=1), (gm[:, :, None] * K['size']).sum(dim=1)
+      kb = K['kb'][:, tt]
+      ctr = kb * ctr_m + (1 - kb) * ctr
+      size = kb * size_m + (1 - kb) * size
+      fy, fx = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh), \
+          gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+      fyi, fxi = fy.transpose(1, 2), fx.transpose(1, 2)
     x_patch = attn_gamma * extract(cat(d['attn_in']), fy, fx)                              # :788-789
     h_acnn = cnn(x_patch, P, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, d['use_bn'])
     h_core = h_acnn[-1].reshape(B, -1)                                                        # :794
@@ -221,7 +261,13 @@ def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
     if d['disable_overwrite']:
       y = (1 - canvas).reshape(B, 1, H, W) * y
     s = torch.sigmoid(torch.cat([h, h_core], dim=1) @ P['score_mlp_w_0'] + P['score_mlp_b_0'])  # :821-822
-    canvas = torch.maximum(y.reshape(B, H, W, 1), canvas)                                      # :843-848
+    y_c = y.reshape(B, H, W, 1)
+    if K is not None:  # :826-841: GT segmentation (with noise) kicked in for the canvas
+      gsel = K['y_gt'][:, tt] if gm is None else (gm[:, :, None, None] * K['y_gt']).sum(dim=1)
+      gsel = gsel - gsel * K['noise'][tt]
+      ks = K['ks'][:, tt].reshape(B, 1, 1, 1)
+      y_c = ks * gsel[..., None] + (1 - ks) * y_c
+    canvas = torch.maximum(y_c, canvas)                                                        # :843-848
     if ora._opt(opt, 'stop_canvas_grad', True):
       canvas = canvas.detach()
     for k, v in (('y_out', y), ('s_out', s), ('attn_box', attn_box), ('attn_ctr', ctr[:, None]),

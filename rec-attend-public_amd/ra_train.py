@@ -402,16 +402,62 @@ class TrainStep(object):
     return h, z
 
   # ------------------------------------------------------------------ forward + loss
-  def forward_loss(self, x, y_gt, s_gt):
-    """The training graph with use_knob False: returns (total loss, dict of pieces, BN batch stats)."""
+  def draw_knobs(self, B, generator=None):
+    """The random draws of one training step (full_model.py:567-577,612-625,829-831): GT-box padding
+    and centre noise, the two Bernoulli knobs, the per-timestep segmentation noise.  One generator
+    per rank (seeded rank-offset by the caller) keeps data-parallel ranks decorrelated."""
+    d, opt = self.d, self.opt
+    dev = self.bucket.param.device
+    T, H, W = d['T'], d['H'], d['W']
+    u = lambda *s: torch.rand(s, generator=generator, device=dev)
+    pr, pn, cn = float(opt['attn_box_padding_ratio']), float(opt['gt_box_pad_noise']), float(opt['gt_box_ctr_noise'])
+    return {'pad': pr - pn + 2 * pn * u(B, T, 1), 'shift': -cn + 2 * cn * u(B, T, 2), 'u_box': u(B, T, 1),
+            'u_segm': u(B, T, 1), 'segm_noise': float(opt['gt_segm_noise']) * u(T, B, H, W)}
+
+  def _knob_setup(self, y_gt, knobs):
+    """Noisy GT attention (modellib.get_gt_attn with tensor padding / centre shift,
+    full_model.py:567-577) and the knob masks (:596-625) at the current global step."""
+    d, opt = self.d, self.opt
+    T = d['T']
+    dev = y_gt.device
+    mp = float(opt['padding']) + 4.0
+    raw, _ = ops.gt_box(y_gt, 0.0, 0.0, want_box=False)          # raw min / max indices (0 for empty instances)
+    tl, br = raw[:, :, 0:2], raw[:, :, 2:4]
+    nz = (ops.pair_stats(y_gt, y_gt, want=('sum_b',))['sum_b'] > 0).to(torch.float32)[:, :, None]
+    size = br - tl
+    padv = torch.clamp(knobs['pad'] * size, min=mp)              # modellib.py:688-691
+    tl_n = (tl + knobs['shift'] * size - padv) * nz
+    br_n = nz * (br + knobs['shift'] * size + padv) + (1 - nz) * (2 * mp)
+    ctr_n, size_n = (tl_n + br_n) / 2.0, br_n - tl_n
+    if opt.get('knob_use_timescale', False):
+      scale = 1.0 + torch.log(1.0 + torch.arange(T, dtype=torch.float32, device=dev) * 3.0)
+    else:
+      scale = torch.ones(T, device=dev)
+    step = self.bucket.global_step
+    pb = torch.clamp(knob_prob(opt, step, opt['knob_box_offset']) * scale, max=1.0)[None, :, None]
+    ps = torch.clamp(knob_prob(opt, step, opt['knob_segm_offset']) * scale, max=1.0)[None, :, None]
+    return ctr_n, size_n, (knobs['u_box'] <= pb).to(torch.float32), (knobs['u_segm'] <= ps).to(torch.float32)
+
+  def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
+    """The training graph (phase_train = True): returns (total loss, dict of pieces, BN batch stats).
+    With model_opt use_knob the ground truth is mixed in (full_model.py:744-773,826-841) using the
+    draws in `knobs` (draw_knobs() when None)."""
     P, d, opt = self.leaves, self.d, self.opt
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
     x, y_gt, s_gt = as_t(x), as_t(y_gt), as_t(s_gt)
     B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
-    if opt.get('use_knob', False):
-      raise NotImplementedError('use_knob = True (ground-truth mixing, full_model.py:744-773,826-841)')
+    use_knob = bool(opt.get('use_knob', False))
+    fixed = bool(opt.get('fixed_order', False))
+    _, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0)
+    if use_knob:
+      if opt.get('use_iou_box', False):
+        raise NotImplementedError('use_iou_box (modellib.f_iou_box) in the knob is not built')
+      if knobs is None:
+        knobs = self.draw_knobs(B, generator)
+      ctr_gtn, size_gtn, knob_box, knob_segm = self._knob_setup(y_gt, knobs)
+      ysel = torch.empty((B, H, W), device=dev)
     canvas = torch.zeros((B, H, W, 1), device=dev)
     stats, y_list, s_list, box_list = {}, [], [], []
     dims_hw = torch.tensor([H, W], dtype=torch.float32, device=dev)
@@ -439,6 +485,20 @@ class TrainStep(object):
       fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
       # attention box: extract_patch(ones * gamma, F_y^T, F_x^T) = gamma * rowsum(F_y) (x) rowsum(F_x)
       box = torch.sigmoid(box_gamma * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
+      if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
+        if fixed:
+          ctr_m, size_m = ctr_gtn[:, tt], size_gtn[:, tt]
+          gmatch = None
+        else:
+          iou_t = ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
+          gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
+          ctr_m = (gmatch[:, :, None] * ctr_gtn).sum(dim=1)
+          size_m = (gmatch[:, :, None] * size_gtn).sum(dim=1)
+        kb = knob_box[:, tt]
+        ctr = kb * ctr_m + (1 - kb) * ctr
+        size = kb * size_m + (1 - kb) * size
+        fy = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh)
+        fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
       x_patch = attn_gamma * extract(inp.detach(), fy, fx)
       core = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)[-1]
       y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats)
@@ -446,15 +506,24 @@ class TrainStep(object):
       if d['disable_overwrite']:
         y = (1.0 - canvas[..., 0]) * y
       s = torch.sigmoid(torch.cat([h, core.reshape(B, -1)], dim=1) @ P['score_mlp_w_0'] + P['score_mlp_b_0'])
-      canvas = torch.maximum(y.detach()[..., None], canvas)      # stop_canvas_grad (full_model.py:843-848)
+      y_c = y.detach()
+      if use_knob:  # kick in the (noisy) ground-truth segmentation for the canvas (:826-841)
+        if fixed:
+          gsel = y_gt[:, tt]
+        else:
+          ops.weighted_sum(gmatch, y_gt, ysel)
+          gsel = ysel
+        gsel = gsel - gsel * knobs['segm_noise'][tt]
+        ks = knob_segm[:, tt, :, None]
+        y_c = ks * gsel + (1 - ks) * y_c
+      canvas = torch.maximum(y_c[..., None], canvas)             # stop_canvas_grad (full_model.py:843-848)
       y_list.append(y)
       s_list.append(s)
       box_list.append(box)
     y_out, s_out = torch.stack(y_list, dim=1), torch.cat(s_list, dim=1)
     attn_box = torch.stack(box_list, dim=1)
-    # ---- losses (full_model.py:913-1035), box_loss_fn = segm_loss_fn = 'iou'
-    _, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0)
-    fixed = bool(opt.get('fixed_order', False))
+    # ---- losses (full_model.py:913-1035), box_loss_fn = segm_loss_fn = 'iou'.  With the knob the
+    # reference stacks the per-timestep box IoUs (:931-934): the same numbers as the pairwise f_iou.
     ident = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
 
     def matched_iou(a, b):
@@ -479,12 +548,12 @@ class TrainStep(object):
     return loss, pieces, stats
 
   # ------------------------------------------------------------------ one optimisation step
-  def run(self, x, y_gt, s_gt):
+  def run(self, x, y_gt, s_gt, knobs=None, generator=None):
     """loss + train_step: backward into the flat bucket, one all-reduce, clip + Adam, BN EMA update.
     The reported `loss` excludes nothing the reference includes except the weight-decay terms, which
     enter through their gradient (wd * w) inside the optimizer kernel."""
     self.bucket.zero_grad()
-    loss, pieces, stats = self.forward_loss(x, y_gt, s_gt)
+    loss, pieces, stats = self.forward_loss(x, y_gt, s_gt, knobs=knobs, generator=generator)
     loss.backward()
     world = self.bucket.allreduce()
     lr = self.bucket.step(world=world)

@@ -192,3 +192,43 @@ def test_train_step_update_and_three_steps(cuda):
   # the decode path sees the trained weights (the optimizer kernel invalidates the packed copies)
   y = m.run('y_out', {'x': x, 'phase_train': False}, as_numpy=True)
   assert np.isfinite(y).all() and y.shape == (x.shape[0], 2, 64, 64)
+
+
+KNOB_OPT = dict(use_knob=True, knob_base=1.0, knob_decay=0.9, steps_per_knob_decay=300, knob_box_offset=300,
+                knob_segm_offset=500, knob_use_timescale=True, gt_box_ctr_noise=0.05, gt_box_pad_noise=0.1,
+                gt_segm_noise=0.3)
+
+
+@pytest.mark.parametrize('step,fixed', [(0, False), (700, False), (0, True)], ids=['knobs_on', 'knobs_decayed', 'fixed_order'])
+def test_knob_mixing_vs_oracle(cuda, step, fixed):
+  """use_knob = True (run_cvppp.sh; full_model.py:559-625,744-773,826-841): noisy GT boxes, greedy
+  per-timestep match, box / segmentation knobs — same draws into product and oracle: loss pieces
+  and the whole gradient.  Step 700: both knob probabilities have decayed below 1, so some draws
+  keep the prediction."""
+  import full_model
+  import ra_train
+  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, fixed_order=fixed, **KNOB_OPT)
+  B, T, H, W = 2, 3, 64, 64
+  rng = np.random.RandomState(5)
+  knobs = {'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)),
+           'u_box': rng.rand(B, T, 1), 'u_segm': rng.rand(B, T, 1), 'segm_noise': 0.3 * rng.rand(T, B, H, W)}
+  keys = [k for k in P if not (k.endswith('_ema_mean') or k.endswith('_ema_var'))]
+  fwd, Pt = ort.forward(opt, P, x, requires_grad=keys, phase_train=True, knobs=knobs, y_gt=y_gt, global_step=step)
+  head = ort.loss_head(opt, fwd, y_gt, s_gt)
+  (head['loss'] + ort.weight_decay_term(opt, {k: Pt[k] for k in keys})).backward()
+  gref = {k: Pt[k].grad.numpy() if Pt[k].grad is not None else np.zeros(P[k].shape) for k in keys}
+  m = full_model.get_model(opt).load_weights(P)
+  ts = ra_train.TrainStep(m)
+  ts.bucket.global_step = step
+  kd = {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in knobs.items()}
+  ts.bucket.zero_grad()
+  loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd)
+  loss.backward()
+  for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
+    assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
+  assert (pieces['match'].cpu().numpy() == head['match'].numpy()).all()
+  _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
+  # the knob changes the graph: without it the loss is a different number
+  loss0, _, _ = ts.forward_loss(x, y_gt, s_gt, knobs={k: (torch.ones_like(v) * 2 if k.startswith('u_') else v) for k, v in kd.items()})
+  if step == 0:
+    assert abs(float(loss0) - float(loss)) > 1e-3
