@@ -166,6 +166,47 @@ def cpu_baseline(opt, seed, budget_s=12.0, batch=2, steps=4):
                        ', '.join('%d threads %.2f s' % kv for kv in sorted(probe.items())))}
 
 
+def bench_train(args, rank, world, B, T, S):
+  """One step = forward (BN batch statistics, GT knobs) + both matchings + backward + gradient
+  all-reduce + clip/Adam on B synthetic CVPPP-shaped images per GPU.  float32 throughout: the
+  bf16 variant BASELINE.json's configs[3] names is not built."""
+  import full_model
+  import full_model_train as fmt
+  import ra_dist
+  opt = make_opt('cvppp', S, S, T)
+  opt.update(use_knob=True, knob_base=1.0, knob_decay=0.9, steps_per_knob_decay=300, knob_box_offset=300,
+             knob_segm_offset=500, knob_use_timescale=True, gt_box_ctr_noise=0.05, gt_box_pad_noise=0.1,
+             gt_segm_noise=0.3, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000)
+  model = full_model.get_model(opt, is_training=True)
+  rng = np.random.RandomState(1234 + rank)
+  x, y_gt, s_gt = fmt.synthetic_batch(rng, B, S, S, T)
+  gen = torch.Generator(device='cuda').manual_seed(1234 + rank)
+  feed = {'x': torch.as_tensor(x).cuda(), 'y_gt': torch.as_tensor(y_gt).cuda(), 's_gt': torch.as_tensor(s_gt).cuda(),
+          'phase_train': True, 'generator': gen}
+  for _ in range(max(args.warmup, 1)):
+    loss, _ = model.run(['loss', 'train_step'], feed)
+  ra_dist.barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    loss, _ = model.run(['loss', 'train_step'], feed)
+  ra_dist.barrier()
+  elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'training instance-timesteps/sec (forward + backward + all-reduce + Adam), whole job',
+        'value': world * B * T * args.steps / elapsed, 'unit': 'instance-timesteps/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'cfg4 shapes: CVPPP-arch full_model TRAINING step, %dx%d, T=%d, B=%d per GPU '
+                               '(global %d), use_knob, data-parallel with one flat-bucket all-reduce' % (S, S, T, B, B * world),
+                   'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                   'grad_bucket_floats': int(model.trainer.bucket.n), 'bn_moments': 'per-rank shard'},
+        'final_loss': float(loss)}))
+  if world > 1:
+    ra_dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -189,6 +230,9 @@ def main():
   ap.add_argument('--fuse-patchnet', action='store_true',
                   help='tuning aid: the patch net through the phase kernel K4 (RA_PNET_MODE=1: one launch)')
   ap.add_argument('--no-cache-first', action='store_true', help='tuning aid: recompute the whole first layer per timestep')
+  ap.add_argument('--train', action='store_true',
+                  help='time the TRAINING step instead (BASELINE.json configs[3] shapes: B images per GPU, '
+                       'data-parallel, one RCCL all-reduce of the gradient bucket per step); prints its own JSON line')
   args = ap.parse_args()
 
   import ra_dist
@@ -215,6 +259,9 @@ def main():
   feed = {'x': x, 'phase_train': False}
 
   barrier = ra_dist.barrier
+
+  if args.train:
+    return bench_train(args, rank, world, B, T, S)
 
   if args.pmc_group:
     eng.forward(feed['x'])

@@ -213,10 +213,11 @@ class Model(dict):
       self.trainer = ra_train.TrainStep(self)
     tr = self.trainer
     if 'train_step' in names:
-      out = tr.run(feed['x'], feed['y_gt'], feed['s_gt'])
+      out = tr.run(feed['x'], feed['y_gt'], feed['s_gt'], knobs=feed.get('knobs'), generator=feed.get('generator'))
     else:
       with torch.no_grad():
-        _, out, _ = tr.forward_loss(feed['x'], feed['y_gt'], feed['s_gt'])
+        _, out, _ = tr.forward_loss(feed['x'], feed['y_gt'], feed['s_gt'], knobs=feed.get('knobs'),
+                                    generator=feed.get('generator'))
       out = dict(out)
       out['learn_rate'] = ra_train.learn_rate(self.opt, tr.bucket.global_step)
     res = []

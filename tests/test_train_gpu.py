@@ -24,7 +24,7 @@ def _case(H=64, W=64, T=3, B=2, seed=3, wmul=1.0, **over):
   y_gt, s_gt = np.zeros((B, T, H, W), np.float32), np.zeros((B, T), np.float32)
   for b in range(B):
     y_gt[b, 0, H // 10:H // 2 - 2, W // 8:W // 2 + 2] = 1
-    y_gt[b, 1, H // 2 + 2:H - 6, W // 2 - 2 + 2 * b:W - 4] = 1
+    y_gt[b, 1, H // 2 + 4:H - 10, W // 2 - 2 + 2 * b:W - 4] = 1  # a different area: no tie in the greedy match
     s_gt[b, :2] = 1
   return opt, P, x, y_gt, s_gt
 
@@ -232,3 +232,31 @@ def test_knob_mixing_vs_oracle(cuda, step, fixed):
   loss0, _, _ = ts.forward_loss(x, y_gt, s_gt, knobs={k: (torch.ones_like(v) * 2 if k.startswith('u_') else v) for k, v in kd.items()})
   if step == 0:
     assert abs(float(loss0) - float(loss)) > 1e-3
+
+
+CVPPP_FLAGS = ['--ctrl_add_inp', '--ctrl_add_canvas', '--attn_add_inp', '--attn_add_canvas', '--fixed_gamma',
+               '--stop_canvas_grad', '--use_knob', '--knob_use_timescale',                       # run_cvppp.sh:44-72
+               '--ctrl_cnn_filter_size', '3,3,3,3,3,3,3,3', '--ctrl_cnn_depth', '8,8,16,16,32,32,64,64',
+               '--ctrl_cnn_pool', '1,2,1,2,1,2,2,2', '--attn_cnn_filter_size', '3,3,3,3,3,3',
+               '--attn_cnn_depth', '8,8,16,16,32,32', '--attn_cnn_pool', '1,2,1,2,1,2',
+               '--attn_dcnn_filter_size', '3,3,3,3,3,3,3', '--attn_dcnn_depth', '32,32,16,16,8,8,1',
+               '--attn_dcnn_pool', '2,1,2,1,2,1,1']
+
+
+def test_train_cli_then_eval_cli(cuda, tmp_path, capsys):
+  """full_model_train.py WITHOUT --init_only: a few optimizer steps on synthetic CVPPP-shaped batches
+  with the run script's flags, then full_model_eval.py restores what the trainer wrote."""
+  import full_model_eval
+  import full_model_train
+  res = str(tmp_path / 'results')
+  full_model_train.main(['--results', res, '--model_id', 't0', '--inp_height', '64', '--inp_width', '64',
+                         '--timespan', '4', '--batch_size', '2', '--num_steps', '4', '--steps_per_log', '1'] + CVPPP_FLAGS)
+  out = capsys.readouterr().out
+  losses = [float(l.split('loss')[1].split()[0]) for l in out.splitlines() if l.startswith('step ')]
+  assert len(losses) == 4 and all(np.isfinite(losses))
+  w0 = dict(np.load(str(tmp_path / 'results' / 't0' / 'weights.npz')))
+  assert all(np.isfinite(v).all() for v in w0.values())
+  assert float(np.abs(w0['ctrl_cnn_0_0_ema_var']).sum()) > 0   # the EMA shadows moved off their zero init
+  full_model_eval.main(['--model_id', 't0', '--results', res, '--num_synthetic', '2', '--batch_size', '2'])
+  pred = np.load(str(tmp_path / 'results' / 't0' / 'output_valid' / 'pred_rank0.npz'))
+  assert pred['y_out'].shape == (2, 4, 64, 64) and np.isfinite(pred['y_out']).all()
