@@ -197,7 +197,8 @@ def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
   y_in = None if y_in is None else t64(y_in)
   B, T, H, W, Fh, Fw, hid, G = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw'], d['hid'], d['G']
   canvas = torch.zeros((B, H, W, 1), dtype=DT)
-  outs = {k: [] for k in ('y_out', 's_out', 'attn_box', 'attn_ctr', 'attn_size', 'x_patch')}
+  outs = {k: [] for k in ('y_out', 's_out', 'attn_box', 'attn_ctr', 'attn_size', 'x_patch', 'attn_ctr_norm',
+                          'attn_lg_size')}
 
   def cat(flags):  # full_model.py:640-661: x, canvas, d_in, y_in in that order
     parts = [p for f, p in zip(flags, (x, canvas, d_in, y_in)) if f]
@@ -271,7 +272,8 @@ def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
     if ora._opt(opt, 'stop_canvas_grad', True):
       canvas = canvas.detach()
     for k, v in (('y_out', y), ('s_out', s), ('attn_box', attn_box), ('attn_ctr', ctr[:, None]),
-                 ('attn_size', size[:, None]), ('x_patch', x_patch[:, None])):
+                 ('attn_size', size[:, None]), ('x_patch', x_patch[:, None]), ('attn_ctr_norm', cn[:, None]),
+                 ('attn_lg_size', ls[:, None])):
       outs[k].append(v)
   res = {k: torch.cat(v, dim=1) for k, v in outs.items()}
   res['canvas'] = canvas
@@ -327,6 +329,26 @@ def loss_head(opt, fwd, y_gt, s_gt):
   ms = m.sum(dim=2)
   bce = -ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)  # :430-437
   out['conf_loss'] = bce.sum() / B / T
-  out['loss'] = -out['iou_soft_box'] - out['iou_soft'] + ora._opt(opt, 'loss_mix_ratio', 1.0) * out['conf_loss']
+  box_loss, segm_loss = -out['iou_soft_box'], -out['iou_soft']
+  blf = ora._opt(opt, 'box_loss_fn', 'iou')
+  if blf in ('mse', 'huber'):  # f_match_loss on (ctr_norm, lg_size) (full_model.py:891-892,952-964; modellib.py:440-478)
+    tl, br, _ = ora.get_gt_box(y_gt.numpy(), padding_ratio=opt['attn_box_padding_ratio'], center_shift_ratio=0.0,
+                               min_padding=opt['padding'] + 4.0)
+    hw = np.array([opt['inp_height'], opt['inp_width']], dtype=np.float64)
+    pgt = t64(np.concatenate([((tl + br) / 2.0) / (hw / 2.0) - 1.0, np.log((br - tl) / hw)], axis=2))
+    p = torch.cat([fwd['attn_ctr_norm'], fwd['attn_lg_size']], dim=2)
+    err = p[:, :, None, :] - pgt[:, None, :, :]
+    if blf == 'mse':
+      pair = 0.5 * err * err
+    else:  # modellib.py:514-522: indicator err <= 1
+      ind = (err <= 1).to(err.dtype)
+      pair = 0.5 * err * err * ind + (err.abs() - 0.5) * (1 - ind)
+    box_loss = ((pair.sum(dim=3) * m_box).sum(dim=(1, 2)) / cnt_box).sum() / B / 4.0
+  if ora._opt(opt, 'segm_loss_fn', 'iou') == 'wt_cov':  # modellib.py:277-302
+    sg = y_gt.sum(dim=(2, 3))
+    wts = sg / (sg.sum(dim=1, keepdim=True) + (sg == 0).to(sg.dtype))
+    segm_loss = -(iou.max(dim=1)[0] * wts).sum() / B
+  out['box_loss'], out['segm_loss'] = box_loss, segm_loss
+  out['loss'] = box_loss + segm_loss + ora._opt(opt, 'loss_mix_ratio', 1.0) * out['conf_loss']
   out['match'], out['match_box'] = m, m_box
   return out

@@ -260,6 +260,45 @@ def get_gt_attn(y_gt, filter_height, filter_width, padding_ratio=0.0, center_shi
   return ctr, size, lg_var, lg_gamma, box, top_left, bot_right
 
 
+def f_iou_box(top_left_a, bot_right_a, top_left_b, bot_right_b):
+  """modellib.py:206-238: IoU of axis-aligned boxes from their corners, [B,T,2] each (broadcast over
+  T) -> [B,T].  [B,T]-sized bookkeeping; differentiable."""
+  y1a, x1a, y2a, x2a = top_left_a[..., 0], top_left_a[..., 1], bot_right_a[..., 0], bot_right_a[..., 1]
+  y1b, x1b, y2b, x2b = top_left_b[..., 0], top_left_b[..., 1], bot_right_b[..., 0], bot_right_b[..., 1]
+  x1, y1 = torch.maximum(x1a, x1b), torch.maximum(y1a, y1b)
+  x2, y2 = torch.minimum(x2a, x2b), torch.minimum(y2a, y2b)
+  flag = (x1 < x2).to(x1.dtype) * (y1 < y2).to(x1.dtype)
+  inter = flag * (x2 - x1) * (y2 - y1)
+  return inter / ((x2a - x1a) * (y2a - y1a) + (x2b - x1b) * (y2b - y1b) - inter)
+
+
+def f_squared_err(y_out, y_gt):
+  """modellib.py:525-530."""
+  err = y_out - y_gt
+  return 0.5 * err * err
+
+
+def f_huber(y_out, y_gt, threshold=1.0):
+  """modellib.py:514-522 (note the reference's indicator is `err <= 1`, not |err| <= threshold)."""
+  err = y_out - y_gt
+  ind = (err <= 1).to(err.dtype)
+  return 0.5 * err * err * ind + (err.abs() - (threshold - 0.5 * threshold ** 2)) * (1 - ind)
+
+
+def f_match_loss(y_out, y_gt, match, timespan, loss_fn, model=None):
+  """modellib.py:440-478: sum_ij match[b,i,j] * sum_d loss_fn(y_out[b,i,:], y_gt[b,j,:]), divided by
+  the match count, the batch size and the feature size.  [B,N,D] inputs (the attention parameters,
+  full_model.py:891-892,952-964); the [B,N,H,W] use never executes in the reference (its only call
+  sites are `box_loss_fn = ...f_bce` — an assignment to the wrong name, :971 — and the undefined
+  f_match_bce, :1016)."""
+  if y_out.dim() != 3:
+    raise NotImplementedError('f_match_loss on [B,N,H,W] inputs is dead code in the reference (full_model.py:971,1016)')
+  B, N, D = y_out.shape
+  pair = loss_fn(y_out[:, :, None, :], y_gt[:, None, :, :]).sum(dim=3)      # [B,N,N]
+  count = torch.clamp(match.sum(dim=(1, 2)), min=1.0)
+  return ((pair * match).sum(dim=(1, 2)) / count).sum() / float(B) / float(D)
+
+
 def _not_built(name):
   def fn(*a, **k):
     raise NotImplementedError('modellib.%s belongs to the training step (SURVEY.md §8f rank 2) '
@@ -268,5 +307,5 @@ def _not_built(name):
   return fn
 
 
-for _n in ('f_iou_box', 'f_match_loss', 'f_huber', 'f_squared_err', 'f_sem_loss'):
+for _n in ('f_sem_loss',):
   globals()[_n] = _not_built(_n)

@@ -333,8 +333,12 @@ class TrainStep(object):
       raise NotImplementedError('training is built for the CVPPP architecture (no d_in / y_in, no skip connections)')
     if not self.opt.get('stop_canvas_grad', True):
       raise NotImplementedError('stop_canvas_grad = False (gradient through the canvas) is not built')
-    if self.opt.get('box_loss_fn', 'iou') != 'iou' or self.opt.get('segm_loss_fn', 'iou') != 'iou':
-      raise NotImplementedError('training is built for box_loss_fn = segm_loss_fn = "iou" (the run scripts)')
+    if self.opt.get('box_loss_fn', 'iou') not in ('iou', 'mse', 'huber') or \
+        self.opt.get('segm_loss_fn', 'iou') not in ('iou', 'wt_cov'):
+      # the reference's other branches cannot run: box 'wt_cov' feeds a scalar to f_weighted_coverage
+      # (full_model.py:949,968), box 'bce' assigns to box_loss_fn (:971), segm 'bce' calls an undefined name (:1016)
+      raise NotImplementedError('box_loss_fn in (iou, mse, huber) and segm_loss_fn in (iou, wt_cov) are the '
+                                'branches that execute in the reference')
     self.bucket = GradBucket(model)
     self.world = world
     self.leaves = {}
@@ -459,7 +463,7 @@ class TrainStep(object):
       ctr_gtn, size_gtn, knob_box, knob_segm = self._knob_setup(y_gt, knobs)
       ysel = torch.empty((B, H, W), device=dev)
     canvas = torch.zeros((B, H, W, 1), device=dev)
-    stats, y_list, s_list, box_list = {}, [], [], []
+    stats, y_list, s_list, box_list, cn_list, ls_list = {}, [], [], [], [], []
     dims_hw = torch.tensor([H, W], dtype=torch.float32, device=dev)
     dims_f = torch.tensor([Fh, Fw], dtype=torch.float32, device=dev)
     for tt in range(T):
@@ -520,6 +524,8 @@ class TrainStep(object):
       y_list.append(y)
       s_list.append(s)
       box_list.append(box)
+      cn_list.append(cn)
+      ls_list.append(ls)
     y_out, s_out = torch.stack(y_list, dim=1), torch.cat(s_list, dim=1)
     attn_box = torch.stack(box_list, dim=1)
     # ---- losses (full_model.py:913-1035), box_loss_fn = segm_loss_fn = 'iou'.  With the knob the
@@ -538,12 +544,26 @@ class TrainStep(object):
 
     iou_box, m_box = matched_iou(attn_box, box_gt)
     iou_soft, m = matched_iou(y_out, y_gt)
+    box_loss, segm_loss = -iou_box, -iou_soft
+    blf = opt.get('box_loss_fn', 'iou')
+    if blf in ('mse', 'huber'):  # matched regression of (centre, log size) (full_model.py:891-892,952-964)
+      import modellib
+      gp, _ = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0, want_box=False)
+      ctr_gt, size_gt = (gp[:, :, 0:2] + gp[:, :, 2:4]) / 2.0, gp[:, :, 2:4] - gp[:, :, 0:2]
+      params_gt = torch.cat([ctr_gt / (dims_hw / 2.0) - 1.0, torch.log(size_gt / dims_hw)], dim=2)
+      params = torch.cat([torch.stack(cn_list, dim=1), torch.stack(ls_list, dim=1)], dim=2)
+      box_loss = modellib.f_match_loss(params, params_gt, m_box, T, modellib.f_squared_err if blf == 'mse' else modellib.f_huber)
+    if opt.get('segm_loss_fn', 'iou') == 'wt_cov':  # modellib.f_weighted_coverage (modellib.py:292-302)
+      iou_p = PairIoU.apply(y_out, y_gt)
+      sg = ops.pair_stats(y_gt, y_gt, want=('sum_b',))['sum_b']
+      wts = sg / (sg.sum(dim=1, keepdim=True) + (sg == 0).to(sg.dtype))
+      segm_loss = -(iou_p.max(dim=1)[0] * wts).sum() / B
     s_min = torch.cummin(s_out, dim=1)[0]
     s_max = torch.flip(torch.cummax(torch.flip(s_out, [1]), dim=1)[0], [1])
     ms = m.sum(dim=2)
     conf = (-ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)).sum() / B / T
-    loss = -iou_box - iou_soft + float(opt.get('loss_mix_ratio', 1.0)) * conf
-    pieces = {'loss': loss, 'box_loss': -iou_box, 'segm_loss': -iou_soft, 'conf_loss': conf, 'iou_soft': iou_soft,
+    loss = box_loss + segm_loss + float(opt.get('loss_mix_ratio', 1.0)) * conf
+    pieces = {'loss': loss, 'box_loss': box_loss, 'segm_loss': segm_loss, 'conf_loss': conf, 'iou_soft': iou_soft,
               'iou_soft_box': iou_box, 'match': m, 'match_box': m_box, 'y_out': y_out, 's_out': s_out}
     return loss, pieces, stats
 

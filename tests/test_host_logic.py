@@ -119,7 +119,9 @@ def test_unbuilt_parts_fail_loudly():
   with pytest.raises(KeyError):
     m.run('nonsense', {'x': None})
   with pytest.raises(NotImplementedError):
-    modellib.f_match_loss(None, None, None, 2, None)  # the loss variants that only matter with a backward pass
+    modellib.f_sem_loss(None, None)  # fg_model's semantic loss: out of scope
+  with pytest.raises(NotImplementedError):  # dead code in the reference (full_model.py:971,1016)
+    modellib.f_match_loss(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 2), 2, modellib.f_bce)
   if not torch.cuda.is_available():
     with pytest.raises(rn.RecAttendError):   # no silent CPU fallback
       m.run('y_out', {'x': np.zeros((1, 64, 64, 3), np.float32), 'phase_train': False})
@@ -159,3 +161,26 @@ def test_eval_and_loss_modules_have_no_cpu_fallback():
 def ops_segm(y, s):
   import ra_ops
   return ra_ops.segm_match(torch.rand(1, 3, 3), s)
+
+
+def test_small_loss_functions_match_numpy():
+  """f_iou_box / f_match_loss / f_huber / f_squared_err (modellib.py:206-238,440-530): [B,T,...]-sized
+  bookkeeping, checked against a NumPy restatement."""
+  rng = np.random.RandomState(2)
+  tl_a, tl_b = rng.rand(2, 3, 2) * 10, rng.rand(2, 3, 2) * 10
+  br_a, br_b = tl_a + 1 + rng.rand(2, 3, 2) * 8, tl_b + 1 + rng.rand(2, 3, 2) * 8
+  t = lambda a: torch.tensor(a, dtype=torch.float64)
+  got = modellib.f_iou_box(t(tl_a), t(br_a), t(tl_b), t(br_b)).numpy()
+  iy = np.maximum(0, np.minimum(br_a[..., 0], br_b[..., 0]) - np.maximum(tl_a[..., 0], tl_b[..., 0]))
+  ix = np.maximum(0, np.minimum(br_a[..., 1], br_b[..., 1]) - np.maximum(tl_a[..., 1], tl_b[..., 1]))
+  area = lambda tl, br: (br[..., 0] - tl[..., 0]) * (br[..., 1] - tl[..., 1])
+  assert np.abs(got - iy * ix / (area(tl_a, br_a) + area(tl_b, br_b) - iy * ix)).max() < 1e-12
+  p, g = rng.randn(2, 3, 4) * 2, rng.randn(2, 3, 4)
+  match = np.zeros((2, 3, 3))
+  match[0, 0, 1] = match[0, 1, 0] = match[1, 2, 2] = 1
+  for fn, ref in ((modellib.f_squared_err, lambda e: 0.5 * e * e),
+                  (modellib.f_huber, lambda e: np.where(e <= 1, 0.5 * e * e, np.abs(e) - 0.5))):
+    got = float(modellib.f_match_loss(t(p), t(g), t(match), 3, fn))
+    exp = sum(sum(ref(p[b, i] - g[b, j]).sum() for i in range(3) for j in range(3) if match[b, i, j]) /
+              max(match[b].sum(), 1) for b in range(2)) / 2 / 4
+    assert abs(got - exp) < 1e-12

@@ -260,3 +260,22 @@ def test_train_cli_then_eval_cli(cuda, tmp_path, capsys):
   full_model_eval.main(['--model_id', 't0', '--results', res, '--num_synthetic', '2', '--batch_size', '2'])
   pred = np.load(str(tmp_path / 'results' / 't0' / 'output_valid' / 'pred_rank0.npz'))
   assert pred['y_out'].shape == (2, 4, 64, 64) and np.isfinite(pred['y_out']).all()
+
+
+@pytest.mark.parametrize('over', [dict(box_loss_fn='mse'), dict(box_loss_fn='huber', segm_loss_fn='wt_cov')],
+                         ids=['box_mse', 'box_huber_segm_wt_cov'])
+def test_loss_variants_vs_oracle(cuda, over):
+  """The other loss branches that execute in the reference: matched regression of the attention
+  parameters (f_match_loss with f_squared_err / f_huber) and weighted coverage for the masks."""
+  import full_model
+  import ra_train
+  opt, P, x, y_gt, s_gt = _case(wmul=0.6, **over)
+  head, gref, _ = _oracle_grads(opt, P, x, y_gt, s_gt)
+  m = full_model.get_model(opt).load_weights(P)
+  ts = ra_train.TrainStep(m)
+  ts.bucket.zero_grad()
+  loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt)
+  loss.backward()
+  for k in ('loss', 'box_loss', 'segm_loss', 'conf_loss'):
+    assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
+  _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
