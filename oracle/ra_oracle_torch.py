@@ -352,3 +352,87 @@ def loss_head(opt, fwd, y_gt, s_gt):
   out['loss'] = box_loss + segm_loss + ora._opt(opt, 'loss_mix_ratio', 1.0) * out['conf_loss']
   out['match'], out['match_box'] = m, m_box
   return out
+
+
+def box_forward_loss(opt, Pnp, x, y_gt, s_gt, noise, requires_grad=(), phase_train=True, bn_stats=None):
+  """box_model.py:403-652 restated differentiably: the controller-only model, its canvas always
+  teacher-forced from the greedily matched ground truth times (1 - noise[tt]) (noise [T,B,H,W], the
+  draws of :500-502), box loss (matched soft IoU; 'mse' / 'huber' on (centre, log size)) + conf loss
+  (+ the caller adds weight decay).  CVPPP-style inputs (no d_in / y_in)."""
+  _BN['train'], _BN['stats'] = bool(phase_train), bn_stats
+  try:
+    d = ora.derive(opt, box_model=True)
+    P = {k: t64(v).requires_grad_(k in requires_grad) for k, v in Pnp.items()}
+    x, y_gt_t, s_gt_t, noise = t64(x), t64(y_gt), t64(s_gt), t64(noise)
+    B, T, H, W, Fh, Fw, hid, G = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw'], d['hid'], d['G']
+    tl, br, box_gt_np = ora.get_gt_box(np.asarray(y_gt, dtype=np.float64), padding_ratio=opt['attn_box_padding_ratio'],
+                                       center_shift_ratio=0.0)
+    box_gt = t64(box_gt_np)
+    canvas = torch.zeros((B, H, W, 1), dtype=DT)
+    boxes, ss, cns, lss = [], [], [], []
+    dims = torch.tensor([H, W], dtype=DT)
+    for tt in range(T):
+      feat = cnn(torch.cat([x, canvas], dim=3), P, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, d['use_bn'])[-1]
+      feat = feat.reshape(B, G, -1)
+      state = torch.zeros((B, 2 * hid), dtype=DT)
+      gmap = torch.full((B, G, 1), 1.0 / G, dtype=DT)
+      for it in range(d['iters']):
+        state = lstm((feat * gmap).sum(dim=1), state, P, hid)
+        h = state[:, hid:]
+        if it < d['iters'] - 1:
+          acts = [torch.relu] * (d['n_gmlp'] - 1) + [lambda z: torch.softmax(z, dim=1)]
+          gmap = mlp(h, P, 'glimpse_mlp', acts)[-1][:, :, None]
+      co = mlp(h, P, 'ctrl_mlp', [torch.relu] * (d['n_cmlp'] - 1) + [None])[-1]
+      cn, ls = co[:, 0:2], co[:, 2:4]
+      if d['squash']:
+        cn, ls = torch.tanh(cn), -F.softplus(ls)
+      ctr, size = (cn + 1.0) * dims / 2.0, torch.exp(ls) * dims
+      lg_var = torch.zeros_like(ctr) if d['fixed_var'] else torch.log(size) - torch.log(torch.tensor([Fh, Fw], dtype=DT))
+      if d['dynamic_var']:
+        lg_var = co[:, 4:6]
+      fy, fx = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh), \
+          gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+      box = torch.sigmoid(torch.exp(co[:, 7]).reshape(B, 1, 1) * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
+      if ora._opt(opt, 'fixed_order', False):
+        ysel = y_gt_t[:, tt]
+      else:
+        a = box.detach().numpy()[:, None]
+        gm = t64(ora.f_greedy_match(ora.f_inter(a, box_gt_np) / ora.f_union(a, box_gt_np, eps=1e-5), np.zeros((B, T))))
+        ysel = (gm[:, :, None, None] * y_gt_t).sum(dim=1)
+      ysel = ysel - ysel * noise[tt]
+      canvas = torch.maximum(ysel[..., None], canvas).detach()
+      s = h @ P['score_mlp_w_0'] + P['score_mlp_b_0']
+      s = torch.sigmoid(s) if d['nsc'] == 1 else torch.softmax(s, dim=1)
+      boxes.append(box)
+      ss.append(s[:, None])
+      cns.append(cn[:, None])
+      lss.append(ls[:, None])
+    attn_box, s_out = torch.stack(boxes, dim=1), torch.cat(ss, dim=1)
+    iou = iou_pairwise(attn_box, box_gt)
+    if ora._opt(opt, 'fixed_order', False):
+      m = t64(ora.get_identity_match(np.asarray(s_gt, np.float64)))
+    else:
+      m = t64(ora.f_segm_match(iou.detach().numpy(), np.asarray(s_gt, np.float64)))
+    cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
+    iou_soft_box = ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B
+    box_loss = -iou_soft_box
+    blf = ora._opt(opt, 'box_loss_fn', 'iou')
+    if blf in ('mse', 'huber'):
+      hw = np.array([H, W], dtype=np.float64)
+      pgt = t64(np.concatenate([((tl + br) / 2.0) / (hw / 2.0) - 1.0, np.log((br - tl) / hw)], axis=2))
+      err = torch.cat([torch.cat(cns, dim=1), torch.cat(lss, dim=1)], dim=2)[:, :, None, :] - pgt[:, None, :, :]
+      if blf == 'mse':
+        pair = 0.5 * err * err
+      else:
+        ind = (err <= 1).to(err.dtype)
+        pair = 0.5 * err * err * ind + (err.abs() - 0.5) * (1 - ind)
+      box_loss = ((pair.sum(dim=3) * m).sum(dim=(1, 2)) / cnt).sum() / B / 4.0
+    sc = s_out[:, :, 0] if d['nsc'] == 1 else 1 - s_out[:, :, 0]                         # box_model.py:620-625
+    s_min = torch.cummin(sc, dim=1)[0]
+    s_max = torch.flip(torch.cummax(torch.flip(sc, [1]), dim=1)[0], [1])
+    ms = m.sum(dim=2)
+    conf = (-ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)).sum() / B / T
+    return {'loss': box_loss + conf, 'box_loss': box_loss, 'conf_loss': conf, 'iou_soft_box': iou_soft_box,
+            'match_box': m, 's_out': s_out, 'attn_box': attn_box}, P
+  finally:
+    _BN['train'], _BN['stats'] = False, None

@@ -6,7 +6,9 @@ box; the canvas is ALWAYS teacher-forced from the greedily matched ground truth 
 (1 - U[0, 0.3]) noise (box_model.py:484-504), so `run` needs `y_gt` and draws (or is fed,
 key `noise` [T,B,H,W]) that noise.  Outputs: `s_out` [B,T] (sigmoid) or [B,T,nc] (softmax,
 box_model.py:508-519), `attn_box` [B,T,H,W], `attn_ctr`, `attn_size`, `attn_top_left`,
-`attn_bot_right`, `attn_ctr_norm`, `attn_lg_size`.  Losses / train_step: not built yet.
+`attn_bot_right`, `attn_ctr_norm`, `attn_lg_size`.  With `phase_train` True / `train_step` in the
+fetch list (feed `y_gt`, `s_gt`) `run` executes the training graph (box_model.py:520-652:
+matched box loss + conf loss, clip + Adam; ra_train.BoxTrainStep).
 """
 import full_model as fm
 import nnlib as nn

@@ -127,7 +127,8 @@ class Model(dict):
   # needs y_gt and s_gt in the feed
   LOSS_OUTPUTS = ops.STAT_NAMES + ('match', 'match_box', 'attn_box_gt', 'attn_top_left_gt',
                                    'attn_bot_right_gt')
-  TRAIN_ONLY = ('train_step', 'learn_rate', 'gt_knob_prob_box', 'gt_knob_prob_segm')
+  TRAIN_ONLY = ('train_step', 'learn_rate', 'gt_knob_prob_box', 'gt_knob_prob_segm', 'box_loss', 'conf_loss',
+                'iou_soft_box', 'match_box')
 
   def __init__(self, opt, dims, box_model=False):
     dict.__init__(self)
@@ -205,13 +206,13 @@ class Model(dict):
     the training graph on BatchNorm batch statistics; fetching `train_step` applies one optimizer
     step (ra_train.TrainStep: backward, gradient all-reduce over the ranks, clip + Adam, EMA)."""
     import ra_train
-    if self.box_model:
-      raise NotImplementedError('box_model training (box_model.py:520-652) is not built')
     if 'y_gt' not in feed or 's_gt' not in feed:
       raise RecAttendError('the training graph needs y_gt and s_gt in the feed')
     if getattr(self, 'trainer', None) is None:
-      self.trainer = ra_train.TrainStep(self)
+      self.trainer = (ra_train.BoxTrainStep if self.box_model else ra_train.TrainStep)(self)
     tr = self.trainer
+    if 'noise' in feed and 'knobs' not in feed:  # box_model's canvas noise (box_model.py:500-502), as at eval
+      feed = dict(feed, knobs={'noise': feed['noise']})
     if 'train_step' in names:
       out = tr.run(feed['x'], feed['y_gt'], feed['s_gt'], knobs=feed.get('knobs'), generator=feed.get('generator'))
     else:

@@ -586,3 +586,98 @@ class TrainStep(object):
     out['learn_rate'] = lr
     out['weight_decay_loss'] = 0.5 * (self.bucket.wd * self.bucket.param * self.bucket.param).sum().detach() if wd else 0.0
     return out
+
+
+class BoxTrainStep(TrainStep):
+  """box_model's training graph (box_model.py:403-652): the controller-only model whose canvas is
+  always teacher-forced from the greedily matched ground truth times (1 - U[0, 0.3)) noise; loss =
+  matched box loss ('iou' | 'mse' | 'huber') + conf loss (sigmoid score, or 1 - softmax[:, :, 0] with
+  several semantic classes).  Pre-trains the controller weights full_model picks up
+  (run_cvppp.sh:16-28).  Same kernels and bucket as TrainStep."""
+
+  def __init__(self, model, world=1):
+    self.model, self.opt, self.d = model, model.opt, model.dims
+    if not torch.cuda.is_available():
+      raise rn.RecAttendError('the training step needs an MI355X (HIP device); there is no CPU fallback')
+    if self.d['add_d_out']:
+      raise NotImplementedError('box_model training is built for image + canvas inputs (no d_in / y_in)')
+    if self.opt.get('box_loss_fn', 'iou') not in ('iou', 'mse', 'huber'):
+      raise NotImplementedError("box_loss_fn in ('iou', 'mse', 'huber')")
+    self.bucket = GradBucket(model)
+    self.world = world
+    self.leaves = {}
+    for k in self.bucket.names:
+      leaf = model[k].detach().requires_grad_(True)
+      leaf.grad = self.bucket.grad_of[k]
+      self.leaves[k] = leaf
+    self.cmap_c = self.cmap_a = None
+
+  def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
+    P, d, opt = self.leaves, self.d, self.opt
+    dev = self.bucket.param.device
+    as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
+        device=dev, dtype=torch.float32).contiguous()
+    x, y_gt, s_gt = as_t(x), as_t(y_gt), as_t(s_gt)
+    B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
+    noise = as_t(knobs['noise']) if knobs is not None and 'noise' in knobs else \
+        0.3 * torch.rand((T, B, H, W), generator=generator, device=dev)        # box_model.py:500-502
+    fixed = bool(opt.get('fixed_order', False))
+    gp, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), 10.0)   # get_gt_attn's default min_padding
+    canvas = torch.zeros((B, H, W, 1), device=dev)
+    ysel = torch.empty((B, H, W), device=dev)
+    stats, box_list, s_list, cn_list, ls_list = {}, [], [], [], []
+    dims_hw = torch.tensor([H, W], dtype=torch.float32, device=dev)
+    dims_f = torch.tensor([Fh, Fw], dtype=torch.float32, device=dev)
+    for tt in range(T):
+      inp = torch.cat([x, canvas], dim=3)
+      feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, None, stats)[-1]
+      h, co = self._controller(feat.reshape(B, d['G'], -1))
+      cn, ls = co[:, 0:2], co[:, 2:4]
+      if d['squash']:
+        cn, ls = torch.tanh(cn), -torch.nn.functional.softplus(ls)
+      ctr, size = (cn + 1.0) * dims_hw / 2.0, torch.exp(ls) * dims_hw
+      lg_var = torch.zeros_like(ctr) if d['fixed_var'] else torch.log(size) - torch.log(dims_f)
+      if d['dynamic_var']:
+        lg_var = co[:, 4:6]
+      fy = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh)
+      fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+      box = torch.sigmoid(torch.exp(co[:, 7]).reshape(B, 1, 1) * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
+      if fixed:
+        gsel = y_gt[:, tt]
+      else:
+        iou_t = ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
+        ops.weighted_sum(ops.greedy_match(iou_t.view(B, T)), y_gt, ysel)
+        gsel = ysel
+      gsel = gsel - gsel * noise[tt]
+      canvas = torch.maximum(gsel[..., None], canvas)                            # stop_gradient (:504)
+      s = h @ P['score_mlp_w_0'] + P['score_mlp_b_0']
+      s_list.append((torch.sigmoid(s) if d['nsc'] == 1 else torch.softmax(s, dim=1))[:, None])
+      box_list.append(box)
+      cn_list.append(cn)
+      ls_list.append(ls)
+    attn_box, s_out = torch.stack(box_list, dim=1), torch.cat(s_list, dim=1)
+    iou = PairIoU.apply(attn_box, box_gt)
+    if fixed:
+      m = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
+    else:
+      m, st = ops.segm_match(iou.detach(), s_gt)
+      ops.check_match_status(st, 'f_segm_match')
+    cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
+    iou_box = ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B
+    box_loss = -iou_box
+    blf = opt.get('box_loss_fn', 'iou')
+    if blf in ('mse', 'huber'):
+      import modellib
+      ctr_gt, size_gt = (gp[:, :, 0:2] + gp[:, :, 2:4]) / 2.0, gp[:, :, 2:4] - gp[:, :, 0:2]
+      params_gt = torch.cat([ctr_gt / (dims_hw / 2.0) - 1.0, torch.log(size_gt / dims_hw)], dim=2)
+      params = torch.cat([torch.stack(cn_list, dim=1), torch.stack(ls_list, dim=1)], dim=2)
+      box_loss = modellib.f_match_loss(params, params_gt, m, T, modellib.f_squared_err if blf == 'mse' else modellib.f_huber)
+    sc = s_out[:, :, 0] if d['nsc'] == 1 else 1.0 - s_out[:, :, 0]               # box_model.py:620-625
+    s_min = torch.cummin(sc, dim=1)[0]
+    s_max = torch.flip(torch.cummax(torch.flip(sc, [1]), dim=1)[0], [1])
+    ms = m.sum(dim=2)
+    conf = (-ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)).sum() / B / T
+    loss = box_loss + conf
+    pieces = {'loss': loss, 'box_loss': box_loss, 'conf_loss': conf, 'iou_soft_box': iou_box, 'match_box': m,
+              's_out': s_out[:, :, 0] if d['nsc'] == 1 else s_out, 'attn_box': attn_box}
+    return loss, pieces, stats

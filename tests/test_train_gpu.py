@@ -279,3 +279,34 @@ def test_loss_variants_vs_oracle(cuda, over):
   for k in ('loss', 'box_loss', 'segm_loss', 'conf_loss'):
     assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
   _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
+
+
+@pytest.mark.parametrize('over', [dict(), dict(box_loss_fn='mse', fixed_order=True)], ids=['iou_matched', 'mse_fixed_order'])
+def test_box_model_training_vs_oracle(cuda, over):
+  """box_model's training graph (box_model.py:403-652): loss pieces and every gradient against the
+  differentiable oracle with the same canvas-noise draws, then train_step through model.run."""
+  import box_model
+  import ra_train
+  opt, _, x, y_gt, s_gt = _case(wmul=1.0, **over)
+  P = ora.random_params(opt, 7, box_model=True)
+  for k in P:
+    if ra_is_w(k):
+      P[k] = (P[k] * 0.6).astype(np.float32)
+  noise = np.random.RandomState(9).uniform(0, 0.3, (3, 2, 64, 64)).astype(np.float32)
+  keys = [k for k in P if not (k.endswith('_ema_mean') or k.endswith('_ema_var'))]
+  head, Pt = ort.box_forward_loss(opt, P, x, y_gt, s_gt, noise, requires_grad=keys)
+  (head['loss'] + ort.weight_decay_term(opt, {k: Pt[k] for k in keys})).backward()
+  gref = {k: Pt[k].grad.numpy() if Pt[k].grad is not None else np.zeros(P[k].shape) for k in keys}
+  m = box_model.get_model(opt).load_weights(P)
+  ts = ra_train.BoxTrainStep(m)
+  ts.bucket.zero_grad()
+  loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs={'noise': noise})
+  loss.backward()
+  for k in ('loss', 'box_loss', 'conf_loss', 'iou_soft_box'):
+    assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
+  assert (pieces['match_box'].cpu().numpy() == head['match_box'].numpy()).all()
+  _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
+  m2 = box_model.get_model(opt).load_weights(P)
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'noise': noise, 'phase_train': True}
+  l = [float(m2.run(['loss', 'train_step'], feed)[0]) for _ in range(3)]
+  assert abs(l[0] - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss']))) and l[2] < l[0] and float(m2['global_step']) == 3.0
