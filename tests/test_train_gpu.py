@@ -310,3 +310,28 @@ def test_box_model_training_vs_oracle(cuda, over):
   feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'noise': noise, 'phase_train': True}
   l = [float(m2.run(['loss', 'train_step'], feed)[0]) for _ in range(3)]
   assert abs(l[0] - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss']))) and l[2] < l[0] and float(m2['global_step']) == 3.0
+
+
+def test_two_stage_cli_box_then_full(cuda, tmp_path, capsys):
+  """The reference's two-stage recipe (run_cvppp.sh:16-72): box_model_train.py pre-trains the
+  controller, full_model_train.py --pretrain_ctrl_net starts from its weights."""
+  import box_model_train
+  import full_model_train
+  res = str(tmp_path / 'results')
+  size = ['--inp_height', '64', '--inp_width', '64', '--timespan', '3', '--batch_size', '2', '--steps_per_log', '1']
+  ctrl = [f for f in CVPPP_FLAGS if 'attn' not in f]
+  ctrl = [a for i, a in enumerate(CVPPP_FLAGS) if not (a.startswith('--attn') or (i and CVPPP_FLAGS[i - 1].startswith('--attn_')))]
+  ctrl = [a for a in ctrl if a not in ('--use_knob', '--knob_use_timescale', '--stop_canvas_grad', '--fixed_gamma',
+                                       '--ctrl_add_inp', '--ctrl_add_canvas')]
+  box_model_train.main(['--results', res, '--model_id', 'b0', '--num_steps', '3'] + size + ctrl)
+  out = capsys.readouterr().out
+  assert out.count('step ') == 3 and 'weights ->' in out
+  wb = dict(np.load(str(tmp_path / 'results' / 'b0' / 'weights.npz')))
+  full_model_train.main(['--results', res, '--model_id', 'f0', '--num_steps', '2', '--pretrain_ctrl_net',
+                         str(tmp_path / 'results' / 'b0' / 'weights.npz')] + size + CVPPP_FLAGS)
+  out = capsys.readouterr().out
+  assert out.count('step ') == 2
+  wf = dict(np.load(str(tmp_path / 'results' / 'f0' / 'weights.npz')))
+  # the LSTM came from the box model: two Adam steps move a weight by at most 2e-3
+  assert np.abs(wf['ctrl_lstm_w_hi'] - wb['ctrl_lstm_w_hi']).max() < 2.5e-3
+  assert np.abs(wb['ctrl_lstm_w_hi']).max() > 0.01
