@@ -52,7 +52,15 @@ def make_opt(arch, H, W, T):
       attn_cnn_depth=[8, 8, 16, 16, 32, 32], attn_cnn_pool=[1, 2, 1, 2, 1, 2],
       attn_dcnn_filter_size=[3] * 7, attn_dcnn_depth=[32, 32, 16, 16, 8, 8, 1],
       attn_dcnn_pool=[2, 1, 2, 1, 2, 1, 1], attn_cnn_skip='1,1,1')
-  if arch != 'cvppp':
+  if arch in ('kitti', 'cityscapes'):  # run_kitti.sh:68-111, run_cityscapes.sh:62-110
+    opt.update(ctrl_cnn_depth=[16, 16, 32, 32, 64, 64, 64, 64], ctrl_cnn_pool=[2, 2, 1, 2, 1, 2, 1, 2],
+               attn_cnn_depth=[16, 32, 32, 64, 64, 96], attn_dcnn_depth=[64, 64, 32, 32, 16, 16, 1],
+               dynamic_var=True, fixed_gamma=False, add_skip_conn=True, add_d_out=True, add_y_out=True,
+               attn_add_d_out=True, attn_add_y_out=True, ctrl_add_d_out=True, ctrl_add_y_out=True,
+               attn_cnn_skip='1,0,1,0,1,0,1,0')
+    if arch == 'cityscapes':
+      opt.update(num_semantic_classes=9, fixed_gamma=True, use_iou_box=True)
+  elif arch != 'cvppp':
     raise ValueError(arch)
   return opt
 
@@ -166,6 +174,68 @@ def cpu_baseline(opt, seed, budget_s=12.0, batch=2, steps=4):
                        ', '.join('%d threads %.2f s' % kv for kv in sorted(probe.items())))}
 
 
+OTHER_CONFIGS = {  # BASELINE.json configs[2] / configs[4] at the sizes the reference feeds the model
+    'cfg3': dict(arch='kitti', H=128, W=448, T=20, B=16, stages=('box_model', 'full_model'),
+                 what='KITTI arch 128x448 (1242x375 crops resized as the reference does), box_model + full_model two-stage, T=20, B=16'),
+    'cfg5': dict(arch='cityscapes', H=256, W=512, T=20, B=4, stages=('full_model',),
+                 what='Cityscapes arch 256x512 (2048x1024 tiles resized), full_model, T=20, 4 images per GPU of a batch of 32 over 8 GPUs'),
+}
+
+
+def bench_other(args, rank, world, name):
+  """The other single-GPU-sized BASELINE.json configurations as driver-reproducible lines
+  (`--config cfg3|cfg5`): eval forward of every stage on synthetic inputs, same protocol as cfg2."""
+  import box_model
+  import full_model
+  import ra_dist
+  c = OTHER_CONFIGS[name]
+  B, T, H, W = c['B'], c['T'], c['H'], c['W']
+  opt = make_opt(c['arch'], H, W, T)
+  g = torch.Generator().manual_seed(1234 + rank)
+  feed = {'x': torch.rand((B, H, W, 3), generator=g).cuda(), 'phase_train': False}
+  nc = opt['num_semantic_classes']
+  feed['d_in'] = torch.nn.functional.one_hot(torch.randint(0, 8, (B, H, W), generator=g), 8).float().cuda()
+  feed['y_in'] = torch.softmax(torch.randn((B, H, W, nc), generator=g), dim=-1).cuda()
+  yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+  y_gt = torch.zeros((B, T, H, W))
+  for t in range(min(T, 6)):
+    y_gt[:, t] = (((yy - (20 + 15 * t) % H) ** 2 / 400.0 + (xx - (30 + 60 * t) % W) ** 2 / 900.0) <= 1).float()
+  models = []
+  for st in c['stages']:
+    m = (box_model.get_model(opt) if st == 'box_model' else full_model.get_model(opt, is_training=False))
+    seed_weights(m, 1234 + rank)
+    models.append((st, m))
+
+  def step():
+    for st, m in models:
+      if st == 'box_model':
+        m.engine.forward(feed['x'], d_in=feed['d_in'], y_in=feed['y_in'], y_gt=y_gt, noise=None)
+      else:
+        m.engine.forward(feed['x'], d_in=feed['d_in'], y_in=feed['y_in'])
+
+  for _ in range(max(args.warmup, 1)):
+    step()
+  ra_dist.barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  ra_dist.barrier()
+  elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'instance-timesteps/sec, %s (whole job)' % name, 'value': world * B * T * args.steps / elapsed,
+        'unit': 'instance-timesteps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: %s' % (name, c['what']), 'arch': c['arch'], 'H': H, 'W': W, 'T': T,
+                   'batch_per_gpu': B, 'stages': list(c['stages']),
+                   'controller': 'split (16 workgroups per image)' if 'ctrl_ws' in models[-1][1].engine.subs[0]
+                   else 'single workgroup per image (B > 14 exceeds the split form\'s co-residency)'}}))
+  if world > 1:
+    ra_dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def bench_train(args, rank, world, B, T, S):
   """One step = forward (BN batch statistics, GT knobs) + both matchings + backward + gradient
   all-reduce + clip/Adam on B synthetic CVPPP-shaped images per GPU.  float32 throughout: the
@@ -230,6 +300,9 @@ def main():
   ap.add_argument('--fuse-patchnet', action='store_true',
                   help='tuning aid: the patch net through the phase kernel K4 (RA_PNET_MODE=1: one launch)')
   ap.add_argument('--no-cache-first', action='store_true', help='tuning aid: recompute the whole first layer per timestep')
+  ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+                  help='cfg2 (default) = the headline workload; cfg3 / cfg5 = the KITTI two-stage and Cityscapes '
+                       'configurations of BASELINE.json as their own JSON lines')
   ap.add_argument('--train', action='store_true',
                   help='time the TRAINING step instead (BASELINE.json configs[3] shapes: B images per GPU, '
                        'data-parallel, one RCCL all-reduce of the gradient bucket per step); prints its own JSON line')
@@ -241,6 +314,8 @@ def main():
   torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
   rank, world, local_rank = ra_dist.init('nccl')  # 'nccl' is RCCL on ROCm
 
+  if args.config != 'cfg2':
+    return bench_other(args, rank, world, args.config)
   import full_model
   B, T, S = args.batch, args.timespan, args.size
   opt = make_opt('cvppp', S, S, T)
