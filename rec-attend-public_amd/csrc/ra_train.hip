@@ -85,12 +85,27 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const float *u, size_t np
     part[(size_t)blockIdx.x * C + tid] = t;
   }
 }
-__global__ void chan_final_kernel(const float *part, int nblocks, int C, float inv_n, float *out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// One workgroup per channel: 256 threads stride over the partial blocks, then a fixed-shape tree
+// (deterministic); a single thread per channel walking 512 strided partials took ~60 us.
+__device__ inline float block_sum256(float v, float *red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void chan_final_kernel(const float *part, int nblocks, int C, float inv_n, float *out) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
   float t = 0.f;
-  for (int k = 0; k < nblocks; ++k) t += part[(size_t)k * C + c];
-  out[c] = t * inv_n;
+  for (int k = threadIdx.x; k < nblocks; k += 256) t += part[(size_t)k * C + c];
+  t = block_sum256(t, red);
+  if (threadIdx.x == 0) out[c] = t * inv_n;
 }
 
 // ---- y = pool(relu(gamma * (u - mean) * rstd + beta)) ----
@@ -182,16 +197,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *u, cons
     part[((size_t)blockIdx.x * 2 + 1) * C + tid] = t1;
   }
 }
-__global__ void bn_bwd_final_kernel(const float *part, int nblocks, int C, float *dbeta, float *dgamma) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *part, int nblocks, int C, float *dbeta, float *dgamma) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
   float t0 = 0.f, t1 = 0.f;
-  for (int k = 0; k < nblocks; ++k) {
+  for (int k = threadIdx.x; k < nblocks; k += 256) {
     t0 += part[((size_t)k * 2) * C + c];
     t1 += part[((size_t)k * 2 + 1) * C + c];
   }
-  dbeta[c] = t0;
-  dgamma[c] = t1;
+  t0 = block_sum256(t0, red);
+  t1 = block_sum256(t1, red);
+  if (threadIdx.x == 0) {
+    dbeta[c] = t0;
+    dgamma[c] = t1;
+  }
 }
 // ---- stage 2: du = gamma * rstd * (dv - dbeta / n - xhat * dgamma / n)   (batch-norm: var given)
 //               du = dv                                                    (no BN)
@@ -289,9 +308,9 @@ extern "C" int ra_bn_moments_f32(const float *u, size_t npix, int C, float *ws, 
   if (nb > train::kRedBlocks) nb = train::kRedBlocks;
   const float inv_n = 1.f / (float)npix;
   hipLaunchKernelGGL(train::chan_sum_kernel, dim3(nb), dim3(256), 0, st, u, npix, C, static_cast<const float *>(nullptr), ws);
-  hipLaunchKernelGGL(train::chan_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, inv_n, mean);
+  hipLaunchKernelGGL(train::chan_final_kernel, dim3(C), dim3(256), 0, st, ws, nb, C, inv_n, mean);
   hipLaunchKernelGGL(train::chan_sum_kernel, dim3(nb), dim3(256), 0, st, u, npix, C, mean, ws);
-  hipLaunchKernelGGL(train::chan_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, inv_n, var);
+  hipLaunchKernelGGL(train::chan_final_kernel, dim3(C), dim3(256), 0, st, ws, nb, C, inv_n, var);
   return launch_status("ra_bn_moments_f32");
 }
 
@@ -324,7 +343,7 @@ extern "C" int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const flo
   if (nb > train::kRedBlocks) nb = train::kRedBlocks;
   hipLaunchKernelGGL(train::bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, u, dy, mean, var, gamma, beta, eps, relu, pool,
                      B, H, W, C, ws);
-  hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, dbeta, dgamma);
+  hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, nb, C, dbeta, dgamma);
   size_t grid = (npix * C + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(train::bn_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, st, u, dy, mean, var, gamma, beta, dbeta,
@@ -472,8 +491,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
 // dW[tap][ci][co] (= TF [3,3,Cin,Cout]) and db[co] from the partials, fixed order.
 __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
                                                           float *dw, float *db) {
+  // 4 output elements per workgroup, one wave each: the 64 lanes stride over the partials, then a
+  // fixed butterfly (deterministic)
   const int total = 9 * Cin * Cout + Cout;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (e >= total) return;
   int tap, ci, co;
   if (e < 9 * Cin * Cout) {
@@ -487,9 +508,12 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int
   }
   const int chunk = ci / 16, cl = ci % 16;
   float s = 0.f;
-  for (int k = 0; k < nwg; ++k) s += part[(((size_t)chunk * nwg + k) * 10 + tap) * 16 * CP + cl * CP + co];
-  if (tap < 9) dw[e] = s;
-  else if (db) db[co] = s;
+  for (int k = lane; k < nwg; k += 64) s += part[(((size_t)chunk * nwg + k) * 10 + tap) * 16 * CP + cl * CP + co];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    if (tap < 9) dw[e] = s;
+    else if (db) db[co] = s;
+  }
 }
 
 }  // namespace train
@@ -540,6 +564,6 @@ extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int 
   }
 #undef RA_WGRAD
   const int total = 9 * Cin * Cout + Cout;
-  hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, ws, gx, chunks, cp, Cin, Cout, dw, db);
+  hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, cp, Cin, Cout, dw, db);
   return launch_status("ra_conv3x3_wgrad_f32");
 }

@@ -127,8 +127,7 @@ class Model(dict):
   # needs y_gt and s_gt in the feed
   LOSS_OUTPUTS = ops.STAT_NAMES + ('match', 'match_box', 'attn_box_gt', 'attn_top_left_gt',
                                    'attn_bot_right_gt')
-  TRAIN_ONLY = ('train_step', 'learn_rate', 'gt_knob_prob_box', 'gt_knob_prob_segm', 'box_loss', 'conf_loss',
-                'iou_soft_box', 'match_box')
+  TRAIN_ONLY = ('train_step', 'learn_rate', 'gt_knob_prob_box', 'gt_knob_prob_segm')
 
   def __init__(self, opt, dims, box_model=False):
     dict.__init__(self)
