@@ -26,8 +26,9 @@ BETA1, BETA2, ADAM_EPS, CLIP = 0.9, 0.999, 1e-7, 1.0  # tf.train.AdamOptimizer d
 def learn_rate(opt, global_step):
   """tf.train.exponential_decay(base, step, steps_per_decay, decay, staircase=True)
   (full_model.py:1039-1045)."""
-  k = int(global_step) // int(opt['steps_per_learn_rate_decay'])
-  return float(opt['base_learn_rate']) * float(opt['learn_rate_decay']) ** k
+  # the reference CLI's defaults where a hand-built model_opt omits them (full_model_train.py:481-484)
+  k = int(global_step) // int(opt.get('steps_per_learn_rate_decay', 5000))
+  return float(opt.get('base_learn_rate', 0.001)) * float(opt.get('learn_rate_decay', 0.96)) ** k
 
 
 def knob_prob(opt, global_step, offset):
