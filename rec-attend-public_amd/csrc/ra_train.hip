@@ -399,7 +399,7 @@ namespace train {
 
 constexpr int WTH = 8, WTW = 32, WLW = WTW + 2, WLH = WTH + 2;
 
-template <int NT>  // CoutP / 16
+template <int NT>  // output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
                                                     int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
                                                     int ntiles, float *part) {
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
   constexpr int CP = 16 * NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, ksub = lane >> 4;
+  const int co0 = blockIdx.z * 16 * NT;       // first output channel of this workgroup's slice
   const int c0 = blockIdx.y * 16;             // first input channel of this workgroup's slice
   const int cn = Cin - c0 < 16 ? Cin - c0 : 16;  // real channels in the slice
   f32x4 acc[10][NT];
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
       const int r = pix / WTW, c = pix - r * WTW;
       const int Y = ty0 + r, X = tx0 + c;
       float v = 0.f;
-      if (Y < H && X < W && co < Cout) v = du[(((size_t)b * H + Y) * W + X) * Cout + co];
+      if (Y < H && X < W && co0 + co < Cout) v = du[(((size_t)b * H + Y) * W + X) * Cout + co0 + co];
       tu[e] = v;
     }
     __syncthreads();
@@ -484,13 +485,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
     }
     __syncthreads();
   }
-  float *dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (10 * 16 * CP);
+  float *dst = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (10 * 16 * CP);
   for (int e = tid; e < 10 * 16 * CP; e += 256) dst[e] = red[e];
 }
 
 // dW[tap][ci][co] (= TF [3,3,Cin,Cout]) and db[co] from the partials, fixed order.
 __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
-                                                          float *dw, float *db) {
+                                                          float *dw, float *db) {  // CP = couts per slice
   // 4 output elements per workgroup, one wave each: the 64 lanes stride over the partials, then a
   // fixed butterfly (deterministic)
   const int total = 9 * Cin * Cout + Cout;
@@ -506,9 +507,10 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int
     ci = 0;
     co = e - 9 * Cin * Cout;
   }
-  const int chunk = ci / 16, cl = ci % 16;
+  const int chunk = ci / 16, cl = ci % 16, slice = co / CP, cs = co % CP;
   float s = 0.f;
-  for (int k = lane; k < nwg; k += 64) s += part[(((size_t)chunk * nwg + k) * 10 + tap) * 16 * CP + cl * CP + co];
+  for (int k = lane; k < nwg; k += 64)
+    s += part[((((size_t)slice * nchunks + chunk) * nwg + k) * 10 + tap) * 16 * CP + cl * CP + cs];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) {
     if (tap < 9) dw[e] = s;
@@ -527,7 +529,8 @@ extern "C" size_t ra_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int B, in
   const int cp = ra_conv_cout_padded(Cout);
   if (!cp || Cin <= 0 || B <= 0) return 0;
   const int ntiles = ceil_div(W, ra::train::WTW) * ceil_div(H, ra::train::WTH) * B;
-  return (size_t)ceil_div(Cin, 16) * wgrad_grid_x(ntiles) * 10 * 16 * cp;
+  const int per = cp < 64 ? cp : 64;
+  return (size_t)(cp / per) * ceil_div(Cin, 16) * wgrad_grid_x(ntiles) * 10 * 16 * per;
 }
 
 extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
@@ -535,15 +538,16 @@ extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int 
   if (!x || !du || !ws || !dw || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
     return fail(RA_E_INVALID, "ra_conv3x3_wgrad_f32: bad argument");
   const int cp = ra_conv_cout_padded(Cout);
-  if (Cin % 4 || !cp || cp > 64) return fail(RA_E_SHAPE, "ra_conv3x3_wgrad_f32: Cin %d %% 4 or Cout %d > 64", Cin, Cout);
+  if (Cin % 4 || !cp) return fail(RA_E_SHAPE, "ra_conv3x3_wgrad_f32: Cin %d %% 4 or Cout %d", Cin, Cout);
+  const int per = cp < 64 ? cp : 64, slices = cp / per;  // output channels per workgroup
   const int ups = upsample ? 1 : 0, H = Hs * (1 + ups), W = Ws * (1 + ups);
   if (ws_floats < ra_conv3x3_wgrad_workspace_floats(Cin, Cout, B, H, W))
     return fail(RA_E_WORKSPACE, "ra_conv3x3_wgrad_f32: workspace too small");
   using namespace ra::train;
   const int tiles_x = ceil_div(W, WTW), tiles_y = ceil_div(H, WTH), ntiles = tiles_x * tiles_y * B;
   const int gx = wgrad_grid_x(ntiles), chunks = ceil_div(Cin, 16);
-  const size_t lds_stage = (size_t)(WLH * WLW * 16 + WTH * WTW * cp) * sizeof(float);
-  const size_t lds_red = (size_t)10 * 16 * cp * sizeof(float);
+  const size_t lds_stage = (size_t)(WLH * WLW * 16 + WTH * WTW * per) * sizeof(float);
+  const size_t lds_red = (size_t)10 * 16 * per * sizeof(float);
   const size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
   hipStream_t st = as_stream(stream);
 #define RA_WGRAD(NT)                                                                                              \
@@ -554,16 +558,16 @@ extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);                         \
       attr = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL(wgrad_kernel<NT>, dim3(gx, chunks), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, H, W, \
+    hipLaunchKernelGGL(wgrad_kernel<NT>, dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, H, W, \
                        Cout, tiles_x, tiles_y, ntiles, ws);                                                      \
   }
-  switch (cp / 16) {
+  switch (per / 16) {
     case 1: RA_WGRAD(1) break;
     case 2: RA_WGRAD(2) break;
     default: RA_WGRAD(4) break;
   }
 #undef RA_WGRAD
   const int total = 9 * Cin * Cout + Cout;
-  hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, cp, Cin, Cout, dw, db);
+  hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout, dw, db);
   return launch_status("ra_conv3x3_wgrad_f32");
 }

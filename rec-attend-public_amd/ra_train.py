@@ -330,8 +330,6 @@ class TrainStep(object):
     d = self.d
     if not torch.cuda.is_available():
       raise rn.RecAttendError('the training step needs an MI355X (HIP device); there is no CPU fallback')
-    if d['add_d_out'] or d['skip_ch'] is not None and any(d['skip_ch']):
-      raise NotImplementedError('training is built for the CVPPP architecture (no d_in / y_in, no skip connections)')
     if not self.opt.get('stop_canvas_grad', True):
       raise NotImplementedError('stop_canvas_grad = False (gradient through the canvas) is not built')
     if self.opt.get('box_loss_fn', 'iou') not in ('iou', 'mse', 'huber') or \
@@ -366,12 +364,24 @@ class TrainStep(object):
       hs.append(x)
     return hs
 
-  def _dcnn(self, x, scope, n, unpool, tt, stats):
+  def _dcnn(self, x, scope, n, unpool, tt, stats, skips=None):
+    """nnlib.dcnn (nnlib.py:362-400).  skips[i] = (tensor, real channel map or None) is concatenated
+    behind the previous layer's output (concat(prev, skip), :365): one packed kernel input whose
+    chan_map sends every packed channel to its row of the [3,3,out,in] filter."""
     P = self.leaves
     for i in range(n):
       bn = self.d['use_bn']
       key = '%s_%d_%d' % (scope, i, tt)
-      meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=None)
+      cmap = None
+      if skips is not None and skips[i] is not None:
+        sk, smap = skips[i]
+        prev_c = x.shape[3]
+        xp, skp = _pad_channels(x), _pad_channels(sk)
+        smap = list(range(sk.shape[3])) if smap is None else smap
+        cmap = list(range(prev_c)) + [-1] * (xp.shape[3] - prev_c) + [prev_c + m if m >= 0 else -1 for m in smap] + \
+            [-1] * (skp.shape[3] - len(smap))
+        x = torch.cat([xp, skp], dim=3)
+      meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap)
       x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -443,15 +453,21 @@ class TrainStep(object):
     ps = torch.clamp(knob_prob(opt, step, opt['knob_segm_offset']) * scale, max=1.0)[None, :, None]
     return ctr_n, size_n, (knobs['u_box'] <= pb).to(torch.float32), (knobs['u_segm'] <= ps).to(torch.float32)
 
-  def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
+  def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None, d_in=None, y_in=None):
     """The training graph (phase_train = True): returns (total loss, dict of pieces, BN batch stats).
     With model_opt use_knob the ground truth is mixed in (full_model.py:744-773,826-841) using the
-    draws in `knobs` (draw_knobs() when None)."""
+    draws in `knobs` (draw_knobs() when None).  d_in / y_in: the extra input channels of the KITTI /
+    Cityscapes architectures (full_model.py:165-194)."""
     P, d, opt = self.leaves, self.d, self.opt
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
     x, y_gt, s_gt = as_t(x), as_t(y_gt), as_t(s_gt)
+    extra = []
+    if d['add_d_out']:
+      if d_in is None or y_in is None:
+        raise rn.RecAttendError('this architecture feeds d_in and y_in (full_model.py:165-194)')
+      extra = [as_t(d_in), as_t(y_in)]
     B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
     use_knob = bool(opt.get('use_knob', False))
     fixed = bool(opt.get('fixed_order', False))
@@ -468,7 +484,7 @@ class TrainStep(object):
     dims_hw = torch.tensor([H, W], dtype=torch.float32, device=dev)
     dims_f = torch.tensor([Fh, Fw], dtype=torch.float32, device=dev)
     for tt in range(T):
-      inp = torch.cat([x, canvas], dim=3)   # packed [x | canvas]; C0p = 4 on this architecture
+      inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
       if inp.shape[3] != d['C0p']:
         inp = _pad_channels(inp)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
@@ -505,8 +521,15 @@ class TrainStep(object):
         fy = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh)
         fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
       x_patch = attn_gamma * extract(inp.detach(), fy, fx)
-      core = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)[-1]
-      y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats)
+      h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
+      core = h_acnn[-1]
+      skips = None
+      if d['skip_ch'] is not None and any(d['skip_ch']):   # full_model.py:798-805: reversed CNN outputs, then x_patch
+        full_a, _ = self.model.engine._chan_map(d['attn_in'])
+        rev = [(hh, None) for hh in h_acnn[::-1][1:]] + [(x_patch, full_a)]
+        skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None
+                          for i in range(1, d['adcnn_nlayers'])]
+      y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
       y = torch.sigmoid(torch.exp(y_lg_gamma) * paste(y_patch[..., 0], fy, fx) - 5.0)        # [B,H,W]
       if d['disable_overwrite']:
         y = (1.0 - canvas[..., 0]) * y
@@ -569,12 +592,12 @@ class TrainStep(object):
     return loss, pieces, stats
 
   # ------------------------------------------------------------------ one optimisation step
-  def run(self, x, y_gt, s_gt, knobs=None, generator=None):
+  def run(self, x, y_gt, s_gt, knobs=None, generator=None, **extra):
     """loss + train_step: backward into the flat bucket, one all-reduce, clip + Adam, BN EMA update.
     The reported `loss` excludes nothing the reference includes except the weight-decay terms, which
     enter through their gradient (wd * w) inside the optimizer kernel."""
     self.bucket.zero_grad()
-    loss, pieces, stats = self.forward_loss(x, y_gt, s_gt, knobs=knobs, generator=generator)
+    loss, pieces, stats = self.forward_loss(x, y_gt, s_gt, knobs=knobs, generator=generator, **extra)
     loss.backward()
     world = self.bucket.allreduce()
     lr = self.bucket.step(world=world)

@@ -112,10 +112,6 @@ def test_unbuilt_parts_fail_loudly():
     with pytest.raises(rn.RecAttendError):  # and an MI355X: the optimizer / conv kernels have no CPU form
       m.run(['loss', 'train_step'], {'x': zeros(1, 64, 64, 3), 'y_gt': zeros(1, 2, 64, 64), 's_gt': zeros(1, 2),
                                      'phase_train': True})
-  if torch.cuda.is_available():
-    with pytest.raises(NotImplementedError):  # the KITTI / Cityscapes training graphs (skips, d_in / y_in)
-      import ra_train
-      ra_train.TrainStep(full_model.get_model(ora.make_opt('kitti', 64, 96, 2)))
   with pytest.raises(KeyError):
     m.run('nonsense', {'x': None})
   with pytest.raises(NotImplementedError):

@@ -335,3 +335,47 @@ def test_two_stage_cli_box_then_full(cuda, tmp_path, capsys):
   # the LSTM came from the box model: two Adam steps move a weight by at most 2e-3
   assert np.abs(wf['ctrl_lstm_w_hi'] - wb['ctrl_lstm_w_hi']).max() < 2.5e-3
   assert np.abs(wb['ctrl_lstm_w_hi']).max() > 0.01
+
+
+@pytest.mark.parametrize('knob', [False, True], ids=['plain', 'knob'])
+def test_kitti_arch_training_vs_oracle(cuda, knob):
+  """The KITTI-style training graph: 13 packed input channels (x, canvas, d_in, y_in) through channel
+  maps, skip connections into the transposed-conv decoder (concat(prev, skip), nnlib.py:365),
+  dynamic_var, free gammas, a 96-channel layer (backward-weight in two cout slices)."""
+  import full_model
+  import ra_train
+  H, W, T, B = 64, 96, 2, 2
+  over = dict(KNOB_OPT) if knob else {}
+  opt = ora.make_opt('kitti', H, W, T, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000, **over)
+  P = ora.random_params(opt, 13)
+  for k in P:
+    if ra_is_w(k):
+      P[k] = (P[k] * 0.6).astype(np.float32)
+  rng = np.random.RandomState(14)
+  x = rng.rand(B, H, W, 3).astype(np.float32)
+  d_in = np.eye(8, dtype=np.float32)[rng.randint(0, 8, (B, H, W))]
+  y_in = ora.softmax(rng.randn(B, H, W, 1)).astype(np.float32)
+  y_gt, s_gt = np.zeros((B, T, H, W), np.float32), np.ones((B, T), np.float32)
+  y_gt[:, 0, 6:30, 8:40] = 1
+  y_gt[:, 1, 36:56, 50:90] = 1
+  knobs = None
+  if knob:
+    knobs = {'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)),
+             'u_box': rng.rand(B, T, 1), 'u_segm': rng.rand(B, T, 1), 'segm_noise': 0.3 * rng.rand(T, B, H, W)}
+  keys = [k for k in P if not (k.endswith('_ema_mean') or k.endswith('_ema_var'))]
+  fwd, Pt = ort.forward(opt, P, x, d_in=d_in, y_in=y_in, requires_grad=keys, phase_train=True, knobs=knobs, y_gt=y_gt)
+  head = ort.loss_head(opt, fwd, y_gt, s_gt)
+  (head['loss'] + ort.weight_decay_term(opt, {k: Pt[k] for k in keys})).backward()
+  gref = {k: Pt[k].grad.numpy() if Pt[k].grad is not None else np.zeros(P[k].shape) for k in keys}
+  m = full_model.get_model(opt).load_weights(P)
+  ts = ra_train.TrainStep(m)
+  ts.bucket.zero_grad()
+  kd = None if knobs is None else {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in knobs.items()}
+  loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd, d_in=d_in, y_in=y_in)
+  loss.backward()
+  for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
+    assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
+  _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
+  loss2, _ = m.run(['loss', 'train_step'], {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'd_in': d_in, 'y_in': y_in,
+                                            'phase_train': True, 'knobs': kd})
+  assert abs(float(loss2) - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss'])))
