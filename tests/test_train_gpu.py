@@ -349,8 +349,8 @@ def test_kitti_arch_training_vs_oracle(cuda, knob):
   opt = ora.make_opt('kitti', H, W, T, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000, **over)
   P = ora.random_params(opt, 13)
   for k in P:
-    if ra_is_w(k):
-      P[k] = (P[k] * 0.6).astype(np.float32)
+    if ra_is_w(k):  # the deeper / wider KITTI stacks amplify float32 round-off more: tamer gains
+      P[k] = (P[k] * 0.5).astype(np.float32)
   rng = np.random.RandomState(14)
   x = rng.rand(B, H, W, 3).astype(np.float32)
   d_in = np.eye(8, dtype=np.float32)[rng.randint(0, 8, (B, H, W))]
