@@ -156,11 +156,25 @@ def _pack_dev(w, cin_w, cout, cin, cmap_t, transposed):
   return out
 
 
+_CONST = {}
+
+
+def _const(kind, key, device, make):
+  """Small constant device tensors (unit scales, zero shifts, channel maps) are built once: a training
+  step runs ~1300 layer calls and each host->device upload costs more than the kernel it feeds."""
+  k = (kind, key, str(device))
+  t = _CONST.get(k)
+  if t is None:
+    t = _CONST[k] = make()
+  return t
+
+
 def _pad_map(n_real, n_kernel, device):
   """chan_map for a kernel input of n_kernel channels whose first n_real are real."""
   if n_real == n_kernel:
     return None
-  return torch.tensor(list(range(n_real)) + [-1] * (n_kernel - n_real), dtype=torch.int32, device=device)
+  return _const('padmap', (n_real, n_kernel), device, lambda: torch.tensor(
+      list(range(n_real)) + [-1] * (n_kernel - n_real), dtype=torch.int32, device=device))
 
 
 def _pad_channels(t, mult=4):
@@ -187,12 +201,12 @@ class ConvBNActPool(torch.autograd.Function):
     tr, stride, pool, relu = meta['transposed'], meta['stride'], meta['pool'], meta['relu']
     cout, cin_w = (w.shape[2], w.shape[3]) if tr else (w.shape[3], w.shape[2])
     cmap = meta.get('chan_map')
-    cmap_t = torch.tensor(cmap, dtype=torch.int32, device=dev) if cmap is not None else _pad_map(cin_w, Cx, dev)
+    cmap_t = _const('cmap', tuple(cmap), dev, lambda: torch.tensor(cmap, dtype=torch.int32, device=dev)) \
+        if cmap is not None else _pad_map(cin_w, Cx, dev)
     cp = ops.cout_padded(cout)
     wp = _pack_dev(w.contiguous(), cin_w, cout, Cx, cmap_t, tr)
-    scale = torch.ones(cp, dtype=torch.float32, device=dev)
-    shift = torch.zeros(cp, dtype=torch.float32, device=dev)
-    shift[:cout] = b
+    scale = _const('ones', cp, dev, lambda: torch.ones(cp, dtype=torch.float32, device=dev))
+    shift = torch.nn.functional.pad(b.detach(), (0, cp - cout)) if cp != cout else b.detach()
     u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2))
     H, W = u.shape[1], u.shape[2]
     use_bn = gamma is not None
@@ -248,8 +262,9 @@ class ConvBNActPool(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       duc = _pad_channels(du)
       cd = duc.shape[3]
-      ones = torch.ones(ops.cout_padded(cin_w), dtype=torch.float32, device=dev)
-      zeros = torch.zeros_like(ones)
+      cpb = ops.cout_padded(cin_w)
+      ones = _const('ones', cpb, dev, lambda: torch.ones(cpb, dtype=torch.float32, device=dev))
+      zeros = _const('zeros', cpb, dev, lambda: torch.zeros(cpb, dtype=torch.float32, device=dev))
       wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr)
       dxr = ops.conv3x3(duc, wpb, ones, zeros, cin_w, relu=False, pool=1)
       if stride == 2:
