@@ -830,14 +830,8 @@ __global__ __launch_bounds__(256) void first_cache_kernel(const float *x, const 
   // 27 x 8 FMAs with wave-uniform weights), the block is transposed through LDS and written as
   // coalesced float4 [n][r] records.
   __shared__ float sm[4][64][9];  // +1: conflict-free transposed reads
-  __shared__ __attribute__((aligned(16))) float wsm[9][4][8];  // the filter: LDS broadcast reads, not 216 scalar loads
   const int xl = threadIdx.x & 63, yl = threadIdx.x >> 6;
   const int X = blockIdx.x * 64 - 2 + xl, Y = blockIdx.y * 4 + yl, b = blockIdx.z;
-  for (int e = threadIdx.x; e < 9 * 4 * 8; e += 256) {
-    const int co = e & 7, ci = (e >> 3) & 3, tap = e >> 5;
-    wsm[tap][ci][co] = ci == plane_chan ? 0.f : wpA[(size_t)(tap * 4 + ci) * CoutAP + co];
-  }
-  __syncthreads();
   float acc[8];
 #pragma unroll
   for (int co = 0; co < 8; ++co) acc[co] = 0.f;
@@ -851,15 +845,12 @@ __global__ __launch_bounds__(256) void first_cache_kernel(const float *x, const 
         const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok) v = *reinterpret_cast<const f32x4 *>(x + ((size_t)(b * H + yy) * W + xx) * 4);
+        const float *wt = wpA + (size_t)((ky * 3 + kx) * 4) * CoutAP;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
-          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(&wsm[ky * 3 + kx][ci][0]);
-          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(&wsm[ky * 3 + kx][ci][4]);
+          const float xv = ci == plane_chan ? 0.f : v[ci];
 #pragma unroll
-          for (int co = 0; co < 4; ++co) {
-            acc[co] = fmaf(v[ci], w0[co], acc[co]);
-            acc[4 + co] = fmaf(v[ci], w1[co], acc[4 + co]);
-          }
+          for (int co = 0; co < 8; ++co) acc[co] = fmaf(xv, wt[ci * CoutAP + co], acc[co]);
         }
       }
     }
