@@ -131,6 +131,15 @@ int ra_conv_first_cache_supported(int Cin, int CoutA, int CoutB, int poolB, int 
 size_t ra_conv_first_cache_floats(int B, int H, int W);
 int ra_conv_first_cache_f32(const float *src, int B, int H, int W, const float *wpA, int CoutA,
                             int plane_chan, float *cache, void *stream);
+/* The first timestep of a forward, where the canvas is all zero (full_model.py:239): the plain pair
+ * (layer A over all 4 channels) that also WRITES the cache — with a zero canvas layer A's raw sums are
+ * exactly the image part — so that no separate cache launch is needed.  The caller must only use it
+ * while `plane` is zero. */
+int ra_conv_pair_fill_cache_f32(const float *src, const float *plane, int plane_chan, int B, int H,
+                                int W, const float *wpA, const float *scaleA, const float *shiftA,
+                                int reluA, const float *wpB, const float *scaleB,
+                                const float *shiftB, int CoutB, int reluB, float *cache, float *y,
+                                void *stream);
 int ra_conv_pair_cached_f32(const float *cache, const float *plane, int plane_chan, int B, int H,
                             int W, const float *wpA, const float *scaleA, const float *shiftA,
                             int reluA, const float *wpB, const float *scaleB, const float *shiftB,

@@ -562,6 +562,10 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
   const float loA = a.reluA ? 0.f : -__builtin_inff(), loB = a.reluB ? 0.f : -__builtin_inff();
   // W' of both layers, once per workgroup: one dword per (tap', cg) per lane, zero where the
   // tap misses pixel p
+  // FILL (un-cached kernel with a cache pointer): the first timestep of a forward.  Its canvas is all
+  // zero, so layer A's raw sums ARE the image part: they are written to the cache on the way
+  // (weights left unscaled, scale / shift applied afterwards) and no separate cache kernel runs.
+  const bool fill = !CACHED && a.cache != nullptr;
   float bA[CACHED ? 1 : 12][NCGA], bB[12][2];
   float bAc[3];  // CACHED: k = the 4 window columns of row ky of the canvas channel alone
 #pragma unroll
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
 #pragma unroll
         for (int cg = 0; cg < NCGA; ++cg) {
           const float w = a.wpA[((tap * NCGA + cg) * 4 + ksub) * a.CoutAP + co];
-          bA[ky * 4 + kxp][cg] = ok ? w * scA : 0.f;
+          bA[ky * 4 + kxp][cg] = ok ? w * (fill ? 1.f : scA) : 0.f;
         }
       }
 #pragma unroll
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
   const int lane_in = CACHED ? (m >> 2) * G::LW + 2 * (m & 3) + ksub
                              : ((m >> 2) * G::LW + 2 * (m & 3)) * CINA + ksub * NCGA;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(CACHED ? a.cache : a.src), 0, CACHED ? a.bytes_c : 0, 0x00020000);
+      const_cast<float *>(a.cache ? a.cache : a.src), 0, a.cache ? a.bytes_c : 0, 0x00020000);
   const int chpos = (co & 3) * 2 + (co >> 2);
   const int lane_mid = (qo * G::AW + p) * 8 + chpos;
   const int lane_b = ((m & 1) * G::AW + 2 * (m >> 1) + 1) * 8 + ksub * 2;
@@ -700,7 +704,8 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
           const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0));
           acc[s] = c * scA + shA;
         } else {
-          acc[s] = f32x4{shA, shA, shA, shA};
+          const float i0 = fill ? 0.f : shA;
+          acc[s] = f32x4{i0, i0, i0, i0};
         }
       }
       if constexpr (CACHED) {
@@ -727,6 +732,18 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
 #pragma unroll
             for (int s = 0; s < G::GPW; ++s)
               acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[ky * 4 + kxp][cg], acc[s], 0, 0, 0);
+        }
+      }
+      if (fill) {  // uniform: raw sums -> cache, then the folded scale / shift
+#pragma unroll
+        for (int s = 0; s < G::GPW; ++s) {
+          int gi = wave + 4 * s;
+          if (gi >= G::NGA) gi = G::NGA - 1;
+          const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
+          const int crow = ty0 + 4 * gr + qo, cgx = (tx0 >> 3) + gc;
+          const int off = (((b * a.cache_rows + crow) * a.cache_gx + cgx) * 16 + n) * 16;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[s]), rc, off, 0, 0);
+          acc[s] = acc[s] * scA + shA;
         }
       }
 #pragma unroll
@@ -1052,6 +1069,49 @@ extern "C" int ra_conv_first_cache_f32(const float *src, int B, int H, int W, co
   hipLaunchKernelGGL(cpair::first_cache_kernel, dim3(ceil_div(W + 2, 64), ceil_div(H, 4), B), dim3(256), 0,
                      as_stream(stream), src, wpA, ra_conv_cout_padded(CoutA), plane_chan, B, H, W, rows, ngx, cache);
   return launch_status("ra_conv_first_cache_f32");
+}
+
+extern "C" int ra_conv_pair_fill_cache_f32(const float *src, const float *plane, int plane_chan, int B, int H, int W,
+                                           const float *wpA, const float *scaleA, const float *shiftA, int reluA,
+                                           const float *wpB, const float *scaleB, const float *shiftB, int CoutB,
+                                           int reluB, float *cache, float *y, void *stream) {
+  if (!src || !plane || !cache || !wpA || !scaleA || !shiftA || !wpB || !scaleB || !shiftB || !y || B <= 0)
+    return fail(RA_E_INVALID, "ra_conv_pair_fill_cache_f32: bad argument");
+  if (!ra_conv_first_cache_supported(4, 8, CoutB, 2, H, W) || plane_chan < 0 || plane_chan > 3)
+    return fail(RA_E_SHAPE, "ra_conv_pair_fill_cache_f32: unsupported shape");
+  cpair::PArgs a;
+  a.src = src;
+  a.y = y;
+  a.wpA = wpA;
+  a.scA = scaleA;
+  a.shA = shiftA;
+  a.wpB = wpB;
+  a.scB = scaleB;
+  a.shB = shiftB;
+  a.C0 = 4;
+  a.Hs = a.H = H;
+  a.Ws = a.W = W;
+  a.ups = 0;
+  a.CoutAP = ra_conv_cout_padded(8);
+  a.CoutB = CoutB;
+  a.CoutBP = ra_conv_cout_padded(CoutB);
+  a.poolB = 2;
+  a.Ho = H / 2;
+  a.Wo = W / 2;
+  a.reluA = reluA;
+  a.reluB = reluB;
+  a.plane = plane;
+  a.plane_chan = plane_chan;
+  const size_t b0 = (size_t)B * H * W * 4 * sizeof(float);
+  if (b0 >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_pair_fill_cache_f32: input exceeds 2 GiB");
+  a.bytes0 = (int)b0;
+  a.bytes_p = (int)((size_t)B * H * W * 4);
+  a.cache = cache;
+  cpair::cache_dims(H, W, a.cache_rows, a.cache_gx);
+  const size_t cb = (size_t)B * a.cache_rows * a.cache_gx * 64 * sizeof(float);
+  if (cb >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_pair_fill_cache_f32: cache exceeds 2 GiB");
+  a.bytes_c = (int)cb;
+  return cpair::launch8<4, false>(a, B, as_stream(stream));
 }
 
 extern "C" int ra_conv_pair_cached_f32(const float *cache, const float *plane, int plane_chan, int B, int H, int W,

@@ -49,6 +49,7 @@ class DecodeEngine(object):
     # cfg2 it is 11-15 us per timestep SLOWER than the 13 per-layer launches, so off.
     self.fuse_patchnet = False
     self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
+    self.fill_cache_inline = True  # ... by the first timestep's own launch (else: a separate kernel)
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -364,7 +365,9 @@ class DecodeEngine(object):
         # every pixel outside an attention window is sigmoid(0 - 5) (full_model.py:813-818): fill
         # once per forward at memset speed, the per-timestep paste then writes windows only
         ops.fill(b['y_out'], 1.0 / (1.0 + math.exp(5.0)))
-    if 'l0cache' in b:  # the image channels' share of ctrl-CNN layer 0: the same for every timestep
+    # the image channels' share of ctrl-CNN layer 0, b['l0cache'], is written by the first timestep's
+    # own launch (its canvas is all zero, so the layer's raw sums ARE that share — _run_cnn, tt == 0)
+    if 'l0cache' in b and not self.fill_cache_inline:
       ops.first_cache(b['img'], self.W['ccnn'][0][0], self.d['ccnn_channels'][1], self.d['D'], b['l0cache'])
     self._mark('pack')
 
@@ -466,7 +469,9 @@ class DecodeEngine(object):
       pl = plane if step[1] == 0 else None
       if step[0] == 'pair':
         (wpa, sca, sha, ca, _), (wpb, scb, shb, cb, poolb) = layers[step[1]], layers[step[2]]
-        if cache is not None and pl is not None:
+        if cache is not None and pl is not None and tt == 0 and self.fill_cache_inline:
+          ops.conv_pair_fill_cache(src, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, cache, bufs[step[2]])
+        elif cache is not None and pl is not None:
           ops.conv_pair_cached(cache, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, bufs[step[2]])
         else:
           ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=poolb,

@@ -104,6 +104,7 @@ SIGNATURES = {
     'ra_conv_first_cache_supported': (_I, [_I, _I, _I, _I, _I, _I]),
     'ra_conv_first_cache_floats': (_Z, [_I, _I, _I]),
     'ra_conv_first_cache_f32': (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),
+    'ra_conv_pair_fill_cache_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'ra_conv_pair_cached_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'ra_patchnet_supported': (_I, [_P, _I, _I, _I, _I]),
     'ra_patchnet_workspace_bytes': (_Z, [_P, _I, _I, _I, _I]),

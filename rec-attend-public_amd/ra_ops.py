@@ -202,6 +202,17 @@ def first_cache(img, wpA, cout_a, plane_chan, cache):
                                          rn.stream_ptr()), 'ra_conv_first_cache_f32')
 
 
+def conv_pair_fill_cache(img, plane, plane_chan, wpA, scA, shA, wpB, scB, shB, coutB, cache, out, reluA=True, reluB=True):
+  """First timestep (canvas plane all zero): the plain first pair, writing the cache on the way."""
+  _need_cuda(img, plane, wpA, scA, shA, wpB, scB, shB, cache, out)
+  B, H, W = plane.shape
+  check(rn.lib().ra_conv_pair_fill_cache_f32(ptr(img), ptr(plane), int(plane_chan), B, H, W, ptr(wpA), ptr(scA),
+                                             ptr(shA), int(reluA), ptr(wpB), ptr(scB), ptr(shB), int(coutB),
+                                             int(reluB), ptr(cache), ptr(out), rn.stream_ptr()),
+        'ra_conv_pair_fill_cache_f32')
+  return out
+
+
 def conv_pair_cached(cache, plane, plane_chan, wpA, scA, shA, wpB, scB, shB, coutB, out, reluA=True, reluB=True):
   """Per timestep: the first controller-CNN pair from the cached image part + the canvas plane."""
   _need_cuda(cache, plane, wpA, scA, shA, wpB, scB, shB, out)

@@ -502,6 +502,16 @@ def test_first_layer_cache_vs_plain_pair(cuda, shape):
   ref = ora.max_pool(np.maximum(ref, 0), 2)
   assert np.abs(plain.cpu().numpy() - ref).max() < 1e-4
   assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+  # the first timestep's form: zero canvas, the plain kernel writes the cache as a by-product
+  zero = torch.zeros_like(d(canvas))
+  cache2 = ops.first_cache_alloc(B, H, W, cuda)
+  out0 = torch.empty_like(plain)
+  ops.conv_pair_fill_cache(d(img), zero, 3, wpA, d(scA), d(shA), wpB, d(scB), d(shB), 8, cache2, out0)
+  plain0 = ops.conv_pair(d(img), wpA, d(scA), d(shA), 8, wpB, d(scB), d(shB), 8, poolB=2, plane=zero, plane_chan=3)
+  assert np.abs(out0.cpu().numpy() - plain0.cpu().numpy()).max() < 1e-4
+  out1 = torch.empty_like(plain)
+  ops.conv_pair_cached(cache2, d(canvas), 3, wpA, d(scA), d(shA), wpB, d(scB), d(shB), 8, out1)
+  assert np.abs(out1.cpu().numpy() - ref).max() < 1e-4   # the by-product cache serves the later timesteps
 
 
 def test_adam_step_matches_tf_adam(cuda):
