@@ -741,7 +741,12 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
           if (gi >= G::NGA) gi = G::NGA - 1;
           const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
           const int crow = ty0 + 4 * gr + qo, cgx = (tx0 >> 3) + gc;
-          const int off = (((b * a.cache_rows + crow) * a.cache_gx + cgx) * 16 + n) * 16;
+          // a tile stores only cells whose four pixel pairs it computed from a complete window: its
+          // rows 0..17 (16 / 17 are computed identically by the tile below) and column groups 0..3;
+          // group 4 (pairs 2, 3 reach past the staged window) belongs to the tile on the right, except
+          // in the last tile column, where those pairs lie outside the image
+          const bool mine = (4 * gr + qo < G::AHS) & ((gc < 4) | (tx0 + G::TW >= a.W));
+          const int off = mine ? (((b * a.cache_rows + crow) * a.cache_gx + cgx) * 16 + n) * 16 : 0x7fffffff;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[s]), rc, off, 0, 0);
           acc[s] = acc[s] * scA + shA;
         }
