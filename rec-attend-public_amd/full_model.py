@@ -200,6 +200,10 @@ class Model(dict):
       res = [r.detach().cpu().numpy() for r in res]
     return res[0] if single else res
 
+  def pipeline(self, depth=4):
+    """`depth` batches of this model in flight (DecodePipeline below)."""
+    return DecodePipeline(self, depth)
+
   def _run_train(self, names, feed, single, as_numpy):
     """sess.run([loss, train_step], feed{x, y_gt, s_gt, phase_train=True}) (full_model_train.py:107):
     the training graph on BatchNorm batch statistics; fetching `train_step` applies one optimizer
@@ -293,7 +297,7 @@ class Model(dict):
     a = b['attn']  # [T,B,16]
     if name == 'x_patch':
       xp = tb(b['x_patch'])
-      sel = self.engine.attn_sel
+      sel = eng.attn_sel
       if sel != list(range(xp.shape[-1])):
         xp = xp[..., sel].contiguous()
       return xp
@@ -321,6 +325,110 @@ class Model(dict):
     if name == 'canvas':
       return b['img'][..., d['D']:d['D'] + 1].contiguous()
     raise KeyError(name)
+
+
+class DecodePipeline(object):
+  """Several eval batches of one model in flight on one GPU.
+
+  The reference's evaluator decodes its batches one `sess.run` after the other
+  (full_model_eval.py:286-344).  Within one batch the timestep loop is strictly serial and half of
+  each timestep is latency-bound (16-workgroup controller, patch-sized convs), so one batch alone
+  leaves the chip idle between the controller-CNN launches.  Batches are independent, so slot k
+  of the pipeline owns a DecodeEngine — its own activation buffers and its own linear HIP graph —
+  and replays it on its own HIP stream: the streams land on different hardware queues and the
+  latency-bound tail of one batch runs under the MFMA-bound controller CNN of the others.
+  Measured at cfg2 on MI355X: 5.3 ms per batch alone, 3.9 / 3.3 / 3.05 ms per batch with 2 / 3 / 4
+  in flight (41k instance-timesteps/s); 5-8 in flight lose again.  The HIP runtime multiplexes its
+  streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the null stream and the
+  graph-capture stream): two slots on one queue serialise (3.9 ms), so ra_native raises the default
+  to 8 before the runtime starts.
+  Every batch's results are bit-identical to a lone `model.run` (tests/test_full_model_gpu.py).
+
+    pipe = model.pipeline(4)
+    for feed in batches:
+      if pipe.full():
+        consume(pipe.collect())
+      pipe.submit(['y_out', 's_out'], feed)
+    while len(pipe):
+      consume(pipe.collect())
+  """
+
+  def __init__(self, model, depth=4):
+    if depth < 1:
+      raise ValueError('depth must be >= 1')
+    self.model, self.depth = model, int(depth)
+    self.slots = None
+    self.pending = []  # (slot, names, single, event) in submission order
+    self.next_slot = 0
+
+  def _make_slots(self):
+    proto = self.model.engine
+    self.slots = []
+    for k in range(self.depth):
+      eng = ra_engine.DecodeEngine(proto.d, self.model, box_model=proto.box)
+      for flag in ('direct_attn', 'fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score', 'fuse_patchnet',
+                   'cache_first', 'fill_cache_inline', 'nsub', 'use_graph'):
+        setattr(eng, flag, getattr(proto, flag))
+      self.slots.append((eng, torch.cuda.Stream()))
+
+  def __len__(self):
+    return len(self.pending)
+
+  def full(self):
+    return len(self.pending) >= self.depth
+
+  def submit(self, outputs, feed):
+    """Start decoding one batch (eval outputs only); returns immediately."""
+    if not torch.cuda.is_available():
+      raise RecAttendError('the decode loop needs an MI355X (HIP device); no CPU fallback')
+    single = isinstance(outputs, str)
+    names = [outputs] if single else list(outputs)
+    for n in names:
+      if n not in self.model.OUTPUTS:
+        raise KeyError(n)
+    if nn._is_train(feed.get('phase_train', False)):
+      raise RecAttendError('DecodePipeline decodes eval batches; training steps go through model.run')
+    if self.full():
+      raise RecAttendError('%d batches in flight: collect() one before the next submit()' % self.depth)
+    if self.slots is None:
+      self._make_slots()
+    k = self.next_slot
+    self.next_slot = (k + 1) % self.depth
+    eng, stream = self.slots[k]
+    stream.wait_stream(torch.cuda.current_stream())  # the feed tensors were produced there
+    with torch.cuda.stream(stream):
+      eng.forward(feed['x'], d_in=feed.get('d_in'), y_in=feed.get('y_in'),
+                  y_gt=feed.get('y_gt') if self.model.box_model else None, noise=feed.get('noise'),
+                  want_box='attn_box' in names)
+      ev = torch.cuda.Event()
+      ev.record(stream)
+    self.pending.append((k, names, single, ev))
+
+  def collect(self, as_numpy=False):
+    """Results of the OLDEST batch in flight (blocks until it has finished), as model.run returns them."""
+    if not self.pending:
+      raise RecAttendError('collect() with no batch in flight')
+    k, names, single, ev = self.pending.pop(0)
+    eng, stream = self.slots[k]
+    ev.synchronize()
+    with torch.cuda.stream(stream):
+      res = [self.model._fetch(n, eng) for n in names]
+      if as_numpy:
+        res = [r.detach().cpu().numpy() for r in res]
+    stream.synchronize()
+    return res[0] if single else res
+
+  def retire(self):
+    """Wait for the OLDEST batch in flight and drop it without fetching (throughput measurement)."""
+    if not self.pending:
+      raise RecAttendError('retire() with no batch in flight')
+    self.pending.pop(0)[3].synchronize()
+
+  def drain(self):
+    """Wait for every batch in flight without fetching anything (throughput measurement)."""
+    for _, stream in (self.slots or []):
+      stream.synchronize()
+    self.pending = []
 
 
 def _register_controller(model, opt, d, pt_ctrl=None):

@@ -31,6 +31,7 @@ def build_parser():
     cap.add_flags(p, table)
   p.add_argument('--input', default=None, help='.npz with x [N,H,W,3] (+ d_in, y_in)')
   p.add_argument('--num_synthetic', type=int, default=8)
+  p.add_argument('--in_flight', type=int, default=4, help='batches decoded concurrently on one GPU')
   return p
 
 
@@ -78,11 +79,7 @@ def main(argv=None):
 
 def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, analyze, acc, ys, ss, t0):
   import torch
-  for b0 in range(lo, hi, args.batch_size):
-    b1 = min(hi, b0 + args.batch_size)
-    feed = {k: v[b0:b1] for k, v in data.items() if k in ('x', 'd_in', 'y_in')}
-    feed['phase_train'] = False
-    y_dev, s_dev = model.run(['y_out', 's_out'], feed)
+  def consume(b0, b1, y_dev, s_dev):
     if analyze:
       import analysis
       from utils import postprocess as pp
@@ -97,6 +94,20 @@ def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, anal
           acc[th][n].append(analysis.create_analyzer(n)(results).cpu().numpy())
     ys.append(y_dev.cpu().numpy())
     ss.append(s_dev.cpu().numpy())
+
+  # batches are independent: keep several in flight, each on its own HIP stream, so that the
+  # latency-bound tail of one decodes under the controller CNN of the others (DecodePipeline)
+  pipe, spans = model.pipeline(max(1, args.in_flight)), []
+  for b0 in range(lo, hi, args.batch_size):
+    b1 = min(hi, b0 + args.batch_size)
+    feed = {k: v[b0:b1] for k, v in data.items() if k in ('x', 'd_in', 'y_in')}
+    feed['phase_train'] = False
+    if pipe.full():
+      consume(*(spans.pop(0) + tuple(pipe.collect())))
+    pipe.submit(['y_out', 's_out'], feed)
+    spans.append((b0, b1))
+  while len(pipe):
+    consume(*(spans.pop(0) + tuple(pipe.collect())))
   out_dir = os.path.join(args.output or restore, 'output_' + args.split.split(',')[0])
   os.makedirs(out_dir, exist_ok=True)
   path = os.path.join(out_dir, 'pred_rank%d.npz' % rank)

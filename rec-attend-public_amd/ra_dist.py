@@ -7,6 +7,8 @@ import os
 
 import torch
 
+import ra_native  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the first HIP call)
+
 
 def init(backend=None):
   """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).  Returns

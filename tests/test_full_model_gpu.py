@@ -317,3 +317,45 @@ def test_box_model_softmax_score(cuda):
   """num_semantic_classes > 1: the score is a softmax over classes (box_model.py:508-513)."""
   out, ref = _box_case('cityscapes', 64, 128, 3, 2, 131)
   assert out['s_out'].shape == (2, 3, 9) and abs(float(out['s_out'][0, 0].sum()) - 1.0) < 1e-5
+
+
+def test_decode_pipeline_matches_lone_run(cuda):
+  """Batches in flight on their own HIP streams (full_model.DecodePipeline, the evaluator's loop)
+  return, batch for batch, exactly what a lone model.run returns — including a ragged last
+  batch and two laps over the slots — and the oracle's masks."""
+  import full_model
+  from ra_native import RecAttendError
+  opt = ora.make_opt('cvppp', 128, 160, 6)
+  P = ora.random_params(opt, 41)
+  m = full_model.get_model(opt).load_weights(P)
+  rng = np.random.RandomState(5)
+  sizes = [3, 3, 3, 3, 3, 3, 3, 2]
+  feeds = [{'x': rng.rand(b, 128, 160, 3).astype(np.float32), 'phase_train': False} for b in sizes]
+  names = ['y_out', 's_out', 'attn_box', 'x_patch']
+  lone = [m.run(names, f, as_numpy=True) for f in feeds]
+  pipe = m.pipeline(3)
+  got = []
+  for f in feeds:
+    if pipe.full():
+      got.append(pipe.collect(as_numpy=True))
+    pipe.submit(names, f)
+  with pytest.raises(KeyError):
+    pipe.submit(['loss'], feeds[0])
+  while len(pipe):
+    got.append(pipe.collect(as_numpy=True))
+  with pytest.raises(RecAttendError):
+    pipe.collect()
+  assert len(got) == len(lone)
+  for a, b in zip(got, lone):
+    for u, v in zip(a, b):
+      assert u.shape == v.shape and np.array_equal(u, v)
+  ref = ora.full_model_forward(opt, P, feeds[-1]['x'], None, None)
+  assert np.abs(got[-1][0] - ref['y_out']).max() < MASK_TOL
+  # full pipeline refuses a further submit instead of overwriting a batch not yet collected
+  for f in feeds[:3]:
+    pipe.submit('y_out', f)
+  with pytest.raises(RecAttendError):
+    pipe.submit('y_out', feeds[0])
+  assert np.array_equal(pipe.collect(as_numpy=True), lone[0][0])
+  pipe.drain()
+  assert len(pipe) == 0

@@ -180,3 +180,20 @@ def test_small_loss_functions_match_numpy():
     exp = sum(sum(ref(p[b, i] - g[b, j]).sum() for i in range(3) for j in range(3) if match[b, i, j]) /
               max(match[b].sum(), 1) for b in range(2)) / 2 / 4
     assert abs(got - exp) < 1e-12
+
+
+def test_decode_pipeline_host_contract():
+  """DecodePipeline without a GPU: argument checks come first, then the loud no-CPU-fallback error."""
+  import full_model
+  from ra_native import RecAttendError
+  import ra_oracle as ora
+  m = full_model.get_model(ora.make_opt('cvppp', 32, 32, 2))
+  with pytest.raises(ValueError):
+    m.pipeline(0)
+  pipe = m.pipeline(2)
+  assert len(pipe) == 0 and not pipe.full()
+  with pytest.raises(RecAttendError):
+    pipe.collect()
+  if not torch.cuda.is_available():
+    with pytest.raises(RecAttendError):
+      pipe.submit(['y_out'], {'x': np.zeros((1, 32, 32, 3), np.float32)})
