@@ -9,7 +9,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
 R="rocprofv3 --output-format csv"
-$R --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.log
+# kernel durations that can be compared with the bench line's roofline: one batch in flight (with 4 in
+# flight the kernels of different batches share the chip and every duration is inflated by the overlap);
+# the second trace is the default run, for the record
+$R --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --in-flight 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.log
+$R --kernel-trace --stats -d $OUT/trace4 -o t -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline > $OUT/trace4_bench.json 2> $OUT/trace4.log
 for which in enc attn; do
   $R --pmc FETCH_SIZE -d $OUT/pmc_${which}_f -o f -- python bench.py --pmc-group 10 --pmc-which $which > $OUT/pmc_${which}_f.json 2> $OUT/pmc_${which}_f.log
   $R --pmc WRITE_SIZE -d $OUT/pmc_${which}_w -o w -- python bench.py --pmc-group 10 --pmc-which $which > $OUT/pmc_${which}_w.json 2> $OUT/pmc_${which}_w.log
@@ -22,8 +26,9 @@ python tools/pmc_traffic.py $F $W 10 8 512 $OUT/r02_pmc_attn_traffic.json "ra::a
 S=$(find $OUT/pmc_sq -name '*counter_collection.csv' | head -1)
 python tools/pmc_summary.py $S > $OUT/r02_pmc_sq_mfma_per_kernel.csv 2> $OUT/sq.txt
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/r02_bench_kernel_stats.csv
+cp $(find $OUT/trace4 -name '*kernel_stats.csv' | head -1) $OUT/r02_bench_kernel_stats_inflight4.csv
 # keep the merge small: the raw traces are not needed
-rm -rf $OUT/trace/*kernel_trace.csv $OUT/pmc_*_f $OUT/pmc_*_w $OUT/pmc_sq
+rm -rf $OUT/trace $OUT/trace4 $OUT/pmc_*_f $OUT/pmc_*_w $OUT/pmc_sq
 python bench.py --attn-b32 > $OUT/r02_bench_n1.json 2> $OUT/bench.err
 python bench.py --train --steps 3 --warmup 1 > $OUT/r02_train_n1.json 2>> $OUT/bench.err
 ls -la $OUT
