@@ -207,19 +207,32 @@ def bench_other(args, rank, world, name):
     seed_weights(m, 1234 + rank)
     models.append((st, m))
 
-  def step():
-    for st, m in models:
-      if st == 'box_model':
-        m.engine.forward(feed['x'], d_in=feed['d_in'], y_in=feed['y_in'], y_gt=y_gt, noise=None)
-      else:
-        m.engine.forward(feed['x'], d_in=feed['d_in'], y_in=feed['y_in'])
+  # every stage decodes through its own DecodePipeline (full_model.py): `--in-flight` batches (or parts
+  # of --part-images images) decode concurrently over all stages, each on its own HIP graph + stream
+  feed['y_gt'] = y_gt.cuda()
+  per = args.part_images or B
+  parts = -(-B // per)
+  depth = max(parts, max(1, args.in_flight) // len(models))
+  pipes = [(st, m.pipeline(depth, max_images=per, co_resident=depth * len(models))) for st, m in models]
 
-  for _ in range(max(args.warmup, 1)):
+  def step():
+    for st, pipe in pipes:
+      while pipe.full(B):
+        pipe.retire()
+      pipe.submit(['attn_box', 's_out'] if st == 'box_model' else ['y_out', 's_out'], feed)
+
+  def drain():
+    for _, pipe in pipes:
+      pipe.drain()
+
+  for _ in range(max(args.warmup, 2 * depth)):
     step()
+  drain()
   ra_dist.barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     step()
+  drain()
   ra_dist.barrier()
   elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
   if rank == 0:
@@ -229,9 +242,10 @@ def bench_other(args, rank, world, name):
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s' % (name, c['what']), 'arch': c['arch'], 'H': H, 'W': W, 'T': T,
-                   'batch_per_gpu': B, 'stages': list(c['stages']),
-                   'controller': 'split (16 workgroups per image)' if 'ctrl_ws' in models[-1][1].engine.subs[0]
-                   else 'single workgroup per image (B > 14 exceeds the split form\'s co-residency)'}}))
+                   'batch_per_gpu': B, 'stages': list(c['stages']), 'parts_per_batch': parts,
+                   'parts_in_flight': depth * len(pipes),
+                   'controller': 'split (16 workgroups per image)' if 'ctrl_ws' in pipes[-1][1].slots[0][0].subs[0]
+                   else 'single workgroup per image'}}))
   if world > 1:
     ra_dist.barrier()
     torch.distributed.destroy_process_group()
@@ -288,8 +302,11 @@ def main():
   ap.add_argument('--timespan', type=int, default=16)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-graph', action='store_true')
-  ap.add_argument('--in-flight', type=int, default=4,
-                  help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other)')
+  ap.add_argument('--part-images', type=int, default=0, help='--config cfg3|cfg5: cut each batch into parts of this many images')
+  ap.add_argument('--no-ctrl-split', action='store_true', help='tuning aid: one-workgroup-per-image controller')
+  ap.add_argument('--in-flight', type=int, default=0,
+                  help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other; '
+                       'default: 4 at cfg2, 8 at cfg3 over its two stages, 2 at cfg5)')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
   ap.add_argument('--no-fuse-score', action='store_true', help='tuning aid: score MLP as its own launch')
   ap.add_argument('--host-input', action='store_true',
@@ -310,6 +327,8 @@ def main():
                   help='time the TRAINING step instead (BASELINE.json configs[3] shapes: B images per GPU, '
                        'data-parallel, one RCCL all-reduce of the gradient bucket per step); prints its own JSON line')
   args = ap.parse_args()
+  if args.in_flight <= 0:
+    args.in_flight = {'cfg2': 4, 'cfg3': 8, 'cfg5': 2}[args.config]
 
   import ra_dist
   if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus > 1:
@@ -328,6 +347,7 @@ def main():
   eng.use_graph = not args.no_graph
   eng.nsub = args.nsub
   eng.fuse_score = not args.no_fuse_score
+  eng.ctrl_split = not args.no_ctrl_split
   eng.fuse_patchnet = args.fuse_patchnet
   eng.cache_first = not args.no_cache_first
   g = torch.Generator().manual_seed(1234 + rank)

@@ -27,6 +27,7 @@ struct PArgs {
   int bytes0, bytes_p;  // tensor sizes for the buffer descriptors (each < 2 GiB)
   const float *cache;   // conv_pair8 CACHED form: layer A's timestep-invariant partial sums
   int cache_rows, cache_gx, bytes_c;
+  int bytes_y;  // conv_pair8: size of y for its buffer descriptor (< 2 GiB whenever the input is)
 };
 
 template <int CINA, int CMID, int NCB, int GX, int GYB>
@@ -536,7 +537,7 @@ struct NGeo {
 //   acc = S * scale(tt) + shift(tt)  (+)  3 MFMAs over the 3 x 4 canvas window
 // instead of 12 MFMAs over the 4-channel window, and only the 4-byte canvas plane is staged.
 template <int CINA, bool CACHED>
-__global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = NGeo<CINA>;
   constexpr int NCGA = G::NCGA;
   static_assert(!CACHED || CINA == 4, "cached form: 4 input channels");
@@ -610,12 +611,65 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
     e_cc[i] = e - e_rr[i] * G::LWL;
     if (e >= NE) e_rr[i] = -(1 << 20);  // never inside the image
   }
+  // byte offset of those pixels inside the window, (rr * W + cc) * 4 (x CINA for the packed input):
+  // tile-invariant, so an interior window costs ONE add per load; elements past the window carry 2^31,
+  // which keeps any sum with a tile base outside the buffer (reads as 0)
+  unsigned e_offp[NIT], e_offs[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const bool in = tid + 256 * i < NE;
+    const unsigned o = (unsigned)(e_rr[i] * a.W + e_cc[i]) * 4u;
+    e_offp[i] = in ? o : 0x80000000u;
+    e_offs[i] = in ? o * CINA : 0x80000000u;
+  }
+  // tile index -> (image, tile row, tile column) without divisions in the loop: the stride gridDim.x
+  // is decomposed once and added with carries (all scalar)
+  struct TC {
+    int b, ty, tx;
+  };
+  auto split = [&](int t) {
+    TC c;
+    c.b = t / per;
+    const int r = t - c.b * per;
+    c.ty = r / tiles_x;
+    c.tx = r - c.ty * tiles_x;
+    return c;
+  };
+  const TC stride = split(gridDim.x);
+  auto advance = [&](TC c) {
+    c.tx += stride.tx;
+    if (c.tx >= tiles_x) {
+      c.tx -= tiles_x;
+      ++c.ty;
+    }
+    c.ty += stride.ty;
+    if (c.ty >= tiles_y) {
+      c.ty -= tiles_y;
+      ++c.b;
+    }
+    c.b += stride.b;
+    return c;
+  };
   f32x4 v[NIT][NCGA];
   float pv[NIT];
   // global loads of one tile's input window (tile + halo) into registers; zeros outside the image
-  auto fetch = [&](int tile) {
-    const int fb = tile / per, frem = tile - fb * per;
-    const int fy0 = (frem / tiles_x) * G::TH - 2, fx0 = (frem % tiles_x) * G::TW - 3;
+  auto fetch = [&](const TC &c) {
+    const int fb = c.b, fy0 = c.ty * G::TH - 2, fx0 = c.tx * G::TW - 3;
+    const bool inside = (fy0 >= 0) & (fy0 + G::LHL <= a.H) & (fx0 >= 0) & (fx0 + G::LWL <= a.W);
+    if (inside) {  // uniform
+      const unsigned base = (unsigned)((fb * a.H + fy0) * a.W + fx0) * 4u;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        if constexpr (!CACHED) {
+#pragma unroll
+          for (int cg = 0; cg < NCGA; ++cg)
+            v[i][cg] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(base * CINA + e_offs[i] + 16u * cg), 0, 0));
+        }
+        pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)(base + e_offp[i]), 0, 0));
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int Y = fy0 + e_rr[i], X = fx0 + e_cc[i];
@@ -640,16 +694,32 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
   const int lane_b = ((m & 1) * G::AW + 2 * (m >> 1) + 1) * 8 + ksub * 2;
   const int pg = a.plane_chan >> 2, slot = a.plane_chan & 3;
 
+  // tile-invariant pieces of the cache / output addresses: per group slot (scalar) and per lane
+  int slot_c[G::GPW];
+#pragma unroll
+  for (int s = 0; s < G::GPW; ++s) {
+    int gi = wave + 4 * s;
+    if (gi >= G::NGA) gi = G::NGA - 1;
+    const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
+    slot_c[s] = (4 * gr * a.cache_gx + gc) * 256;
+  }
+  const int lane_c = (qo * a.cache_gx * 16 + n) * 16;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes_y, 0x00020000);
+  const unsigned lane_y = co < a.CoutB ? (unsigned)(((2 * qo + p) * a.CoutB + co) * 4) : 0x80000000u;
+  int g_y[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) g_y[g] = ((g >> 1) * a.Wo + 8 * (g & 1)) * a.CoutB * 4;
+
   int tile = blockIdx.x;
-  if (tile < ntiles) fetch(tile);
+  TC cur = split(tile), nxt = cur;
+  if (tile < ntiles) fetch(cur);
   // the padded groups read LDS this kernel never writes; whatever an earlier kernel left there
   // must not be NaN/Inf (their results are discarded, but keep the arithmetic clean)
   for (int e = tid; e < (IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
     reinterpret_cast<f32x4 *>(lds)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int b = tile / per, trem = tile - b * per;
-    const int ty0 = (trem / tiles_x) * G::TH, tx0 = (trem % tiles_x) * G::TW;
+  for (; tile < ntiles; tile += gridDim.x, cur = nxt) {
+    const int b = cur.b, ty0 = cur.ty * G::TH, tx0 = cur.tx * G::TW;
 
     // ---------------- stage layer A's input window (prefetched registers -> LDS) ----------------
 #pragma unroll
@@ -680,14 +750,13 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
       }
     }
     __syncthreads();
-    {  // the next tile's loads fly while this one is computed
-      const int next = tile + gridDim.x;
-      if (next < ntiles) fetch(next);
-    }
+    nxt = advance(cur);
+    if (tile + (int)gridDim.x < ntiles) fetch(nxt);  // the next tile's loads fly while this one is computed
 
     // ---------------- phase A: layer A on the 18 x 36 region -> tmid ----------------
     {
       const bool interior = (ty0 >= 1) & (ty0 + G::TH + 1 <= a.H) & (tx0 >= 2) & (tx0 + G::TW + 1 <= a.W);
+      const int tile_c = ((b * a.cache_rows + ty0) * a.cache_gx + (tx0 >> 3)) * 256;
       f32x4 acc[G::GPW];
       int gin[G::GPW];
 #pragma unroll
@@ -699,8 +768,8 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
         if constexpr (CACHED) {
           // this lane's 4 partial sums (rows 4*qo + r of the group) are one float4 of the cache:
           // [image][row ty0-1+4gr+qo (+1)][column group tx0/8+gc][n][r]
-          const int crow = ty0 + 4 * gr + qo, cgx = (tx0 >> 3) + gc;
-          const int off = (((b * a.cache_rows + crow) * a.cache_gx + cgx) * 16 + n) * 16;
+          // (byte offset = tile part + slot part + lane part; only the first changes per tile)
+          const int off = tile_c + slot_c[s] + lane_c;
           const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0));
           acc[s] = c * scA + shA;
         } else {
@@ -740,13 +809,12 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
           int gi = wave + 4 * s;
           if (gi >= G::NGA) gi = G::NGA - 1;
           const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
-          const int crow = ty0 + 4 * gr + qo, cgx = (tx0 >> 3) + gc;
           // a tile stores only cells whose four pixel pairs it computed from a complete window: its
           // rows 0..17 (16 / 17 are computed identically by the tile below) and column groups 0..3;
           // group 4 (pairs 2, 3 reach past the staged window) belongs to the tile on the right, except
           // in the last tile column, where those pairs lie outside the image
           const bool mine = (4 * gr + qo < G::AHS) & ((gc < 4) | (tx0 + G::TW >= a.W));
-          const int off = mine ? (((b * a.cache_rows + crow) * a.cache_gx + cgx) * 16 + n) * 16 : 0x7fffffff;
+          const int off = mine ? tile_c + slot_c[s] + lane_c : 0x7fffffff;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[s]), rc, off, 0, 0);
           acc[s] = acc[s] * scA + shA;
         }
@@ -802,6 +870,8 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
               acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][cg], bB[ky * 4 + kxp][cg], acc[g], 0, 0, 0);
         }
       const int prow0 = (ty0 >> 1) + wave * 2, pcol0 = (tx0 >> 1) + 2 * qo + p;
+      const bool whole = ((ty0 >> 1) + G::TH / 2 <= a.Ho) & ((tx0 >> 1) + G::TW / 2 <= a.Wo);  // uniform
+      const unsigned tile_y = (unsigned)(((b * a.Ho + prow0) * a.Wo + (tx0 >> 1)) * a.CoutB * 4) + lane_y;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // ReLU commutes with max: pool first.  registers (2j, 2j+1) = rows (0, 1) of pair
@@ -811,16 +881,19 @@ __global__ __launch_bounds__(256, RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs
         const float u1 = fmaxf(t1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x128, 0xf, 0xf, true)));
         const float ov = p ? u1 : u0;  // lane (p, co) stores pooled pixel 2*qo + p
         const int prow = prow0 + (g >> 1), pcol = pcol0 + 8 * (g & 1);
-        if ((co < a.CoutB) & (prow < a.Ho) & (pcol < a.Wo))
-          a.y[((size_t)(b * a.Ho + prow) * a.Wo + pcol) * a.CoutB + co] = ov;
+        unsigned off = tile_y + (unsigned)g_y[g];
+        if (!whole) off = ((prow < a.Ho) & (pcol < a.Wo)) ? off : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), ry, (int)off, 0, 0);
       }
     }
   }
 }
 
 template <int CINA, bool CACHED = false>
-int launch8(const PArgs &a, int B, hipStream_t st) {
+int launch8(const PArgs &a_in, int B, hipStream_t st) {
   using G = NGeo<CINA>;
+  PArgs a = a_in;
+  a.bytes_y = (int)((size_t)B * a.Ho * a.Wo * a.CoutB * sizeof(float));
   auto kern = conv_pair8_mfma<CINA, CACHED>;
   constexpr size_t lds = (size_t)(((G::LH * G::LW * (CACHED ? 1 : CINA) + 3) & ~3) + G::MID_FLOATS) * sizeof(float);
   static bool attr = false;

@@ -193,6 +193,7 @@ class Model(dict):
                             y_gt=feed.get('y_gt') if self.box_model else None,
                             noise=feed.get('noise'),
                             want_box=want_loss or 'attn_box' in names)
+    b.check_status()
     head = self._loss_head(b, feed) if want_loss else {}
     res = [head[n] if n in head else self._fetch(n, b) for n in names]
     if as_numpy:
@@ -200,9 +201,9 @@ class Model(dict):
       res = [r.detach().cpu().numpy() for r in res]
     return res[0] if single else res
 
-  def pipeline(self, depth=4):
+  def pipeline(self, depth=4, max_images=None, co_resident=None):
     """`depth` batches of this model in flight (DecodePipeline below)."""
-    return DecodePipeline(self, depth)
+    return DecodePipeline(self, depth, max_images, co_resident)
 
   def _run_train(self, names, feed, single, as_numpy):
     """sess.run([loss, train_step], feed{x, y_gt, s_gt, phase_train=True}) (full_model_train.py:107):
@@ -337,8 +338,11 @@ class DecodePipeline(object):
   of the pipeline owns a DecodeEngine — its own activation buffers and its own linear HIP graph —
   and replays it on its own HIP stream: the streams land on different hardware queues and the
   latency-bound tail of one batch runs under the MFMA-bound controller CNN of the others.
-  Measured at cfg2 on MI355X: 5.3 ms per batch alone, 3.9 / 3.3 / 3.05 ms per batch with 2 / 3 / 4
-  in flight (41k instance-timesteps/s); 5-8 in flight lose again.  The HIP runtime multiplexes its
+  Measured at cfg2 on MI355X: 5.3 ms per batch alone, 3.3 ms per batch (39k instance-timesteps/s)
+  with 4 in flight; 5-8 in flight lose again.  The slots decode with the one-workgroup-per-image
+  controller unless depth x images x 16 workgroups fit the chip: the 16-workgroup controller spin-waits
+  on its peers, and several such launches from different queues can each end up partially resident
+  and starve one another (seen at cfg3 with 8-12 parts in flight: 0.1-3.7 s per step).  The HIP runtime multiplexes its
   streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the null stream and the
   graph-capture stream): two slots on one queue serialise (3.9 ms), so ra_native raises the default
   to 8 before the runtime starts.
@@ -353,13 +357,20 @@ class DecodePipeline(object):
       consume(pipe.collect())
   """
 
-  def __init__(self, model, depth=4):
+  def __init__(self, model, depth=4, max_images=None, co_resident=None):
+    """co_resident: engines decoding at the same time on this GPU if other pipelines run beside this one
+    (default: depth); max_images: a batch with more images is decoded as ceil(B / max_images) near-equal parts,
+    each on its own slot, and collect() returns them concatenated (KITTI's batch of 16 as 2 x 8: the
+    16-workgroup controller needs all of a launch's workgroups co-resident, <= 14 images)."""
     if depth < 1:
       raise ValueError('depth must be >= 1')
-    self.model, self.depth = model, int(depth)
+    if max_images is not None and max_images < 1:
+      raise ValueError('max_images must be >= 1')
+    self.model, self.depth, self.max_images = model, int(depth), max_images
+    self.co_resident = int(co_resident or depth)
     self.slots = None
-    self.pending = []  # (slot, names, single, event) in submission order
-    self.next_slot = 0
+    self.free = list(range(self.depth))
+    self.pending = []  # tickets in submission order: (slot indices, names, single, events)
 
   def _make_slots(self):
     proto = self.model.engine
@@ -369,13 +380,19 @@ class DecodePipeline(object):
       for flag in ('direct_attn', 'fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score', 'fuse_patchnet',
                    'cache_first', 'fill_cache_inline', 'nsub', 'use_graph'):
         setattr(eng, flag, getattr(proto, flag))
+      eng.co_resident = self.co_resident
       self.slots.append((eng, torch.cuda.Stream()))
 
   def __len__(self):
     return len(self.pending)
 
-  def full(self):
-    return len(self.pending) >= self.depth
+  def parts(self, B):
+    """How many slots a batch of B images takes."""
+    return 1 if not self.max_images else max(1, -(-int(B) // int(self.max_images)))
+
+  def full(self, B=None):
+    """No room for another batch (of B images; default: a batch that takes one slot)."""
+    return len(self.free) < (1 if B is None else self.parts(B))
 
   def submit(self, outputs, feed):
     """Start decoding one batch (eval outputs only); returns immediately."""
@@ -388,47 +405,74 @@ class DecodePipeline(object):
         raise KeyError(n)
     if nn._is_train(feed.get('phase_train', False)):
       raise RecAttendError('DecodePipeline decodes eval batches; training steps go through model.run')
-    if self.full():
-      raise RecAttendError('%d batches in flight: collect() one before the next submit()' % self.depth)
+    B = int(feed['x'].shape[0])
+    nparts = self.parts(B)
+    if nparts > self.depth:
+      raise RecAttendError('a batch of %d images needs %d slots of <= %d images; the pipeline has %d' %
+                           (B, nparts, self.max_images, self.depth))
+    if nparts > len(self.free):
+      raise RecAttendError('%d of %d slots busy: collect() a batch before the next submit()' %
+                           (self.depth - len(self.free), self.depth))
     if self.slots is None:
       self._make_slots()
-    k = self.next_slot
-    self.next_slot = (k + 1) % self.depth
-    eng, stream = self.slots[k]
-    stream.wait_stream(torch.cuda.current_stream())  # the feed tensors were produced there
-    with torch.cuda.stream(stream):
-      eng.forward(feed['x'], d_in=feed.get('d_in'), y_in=feed.get('y_in'),
-                  y_gt=feed.get('y_gt') if self.model.box_model else None, noise=feed.get('noise'),
-                  want_box='attn_box' in names)
-      ev = torch.cuda.Event()
-      ev.record(stream)
-    self.pending.append((k, names, single, ev))
+    bounds = [(B * i) // nparts for i in range(nparts + 1)]
+    cut = lambda v, lo, hi: None if v is None else v[lo:hi]
+    used, events = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+      k = self.free.pop(0)
+      eng, stream = self.slots[k]
+      stream.wait_stream(torch.cuda.current_stream())  # the feed tensors were produced there
+      noise = feed.get('noise')  # box_model: [T, B, H, W]
+      with torch.cuda.stream(stream):
+        eng.forward(cut(feed['x'], lo, hi), d_in=cut(feed.get('d_in'), lo, hi), y_in=cut(feed.get('y_in'), lo, hi),
+                    y_gt=cut(feed.get('y_gt'), lo, hi) if self.model.box_model else None,
+                    noise=None if noise is None else noise[:, lo:hi], want_box='attn_box' in names)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+      used.append(k)
+      events.append(ev)
+    self.pending.append((used, names, single, events))
 
   def collect(self, as_numpy=False):
     """Results of the OLDEST batch in flight (blocks until it has finished), as model.run returns them."""
     if not self.pending:
       raise RecAttendError('collect() with no batch in flight')
-    k, names, single, ev = self.pending.pop(0)
-    eng, stream = self.slots[k]
-    ev.synchronize()
-    with torch.cuda.stream(stream):
-      res = [self.model._fetch(n, eng) for n in names]
-      if as_numpy:
-        res = [r.detach().cpu().numpy() for r in res]
-    stream.synchronize()
+    used, names, single, events = self.pending.pop(0)
+    parts = []
+    for k, ev in zip(used, events):
+      eng, stream = self.slots[k]
+      ev.synchronize()
+      eng.check_status()
+      with torch.cuda.stream(stream):
+        res = [self.model._fetch(n, eng) for n in names]
+        if as_numpy:
+          res = [r.detach().cpu().numpy() for r in res]
+      stream.synchronize()
+      parts.append(res)
+      self.free.append(k)
+    if len(parts) == 1:
+      res = parts[0]
+    elif as_numpy:
+      res = [np.concatenate(col, axis=0) for col in zip(*parts)]
+    else:
+      res = [torch.cat(col, dim=0) for col in zip(*parts)]
     return res[0] if single else res
 
   def retire(self):
     """Wait for the OLDEST batch in flight and drop it without fetching (throughput measurement)."""
     if not self.pending:
       raise RecAttendError('retire() with no batch in flight')
-    self.pending.pop(0)[3].synchronize()
+    used, _, _, events = self.pending.pop(0)
+    for ev in events:
+      ev.synchronize()
+    self.free.extend(used)
 
   def drain(self):
     """Wait for every batch in flight without fetching anything (throughput measurement)."""
     for _, stream in (self.slots or []):
       stream.synchronize()
     self.pending = []
+    self.free = list(range(self.depth))
 
 
 def _register_controller(model, opt, d, pt_ctrl=None):

@@ -50,6 +50,7 @@ class DecodeEngine(object):
     self.fuse_patchnet = False
     self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
     self.fill_cache_inline = True  # ... by the first timestep's own launch (else: a separate kernel)
+    self.co_resident = 1  # engines decoding concurrently on this GPU (set by full_model.DecodePipeline)
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
@@ -269,7 +270,10 @@ class DecodeEngine(object):
       if self.cache_first and self.direct_attn and st0[0] == 'pair' and d['C0p'] == 4 and \
           ops.first_cache_supported(4, d['ccnn_channels'][1], d['ccnn_channels'][2], d['ccnn_pool'][1], H, W):
         b['l0cache'] = ops.first_cache_alloc(Bs, H, W, device)
-      if self.split_ok and Bs <= 14:
+      # the 16 workgroups of an image exchange through spin-waits, so ALL workgroups of every launch that
+      # can be running at the same time must be resident at once (112 KB of LDS each: one per CU).
+      # `co_resident` = how many such launches may overlap (DecodePipeline: its depth)
+      if self.split_ok and Bs * 16 * max(1, self.co_resident) <= ops.cu_count() - 32:  # the C side's margin: 224 of 256
         b['ctrl_ws'], b['ctrl_status'] = ops.ctrl_split_workspace(self.desc, Bs, device)
       if self.box:
         b['noise'] = f(T, Bs, H, W)
@@ -312,6 +316,17 @@ class DecodeEngine(object):
       return parts[0]
     dim = 0 if name in ('img', 'fy', 'fx', 'canvas') else 1
     return torch.cat(parts, dim=dim)
+
+  def check_status(self):
+    """After the forward has finished: the 16-workgroup controller's status words.  Non-zero means a
+    workgroup waited for a peer that never became resident (ra_ctrl_split.hip, kSpinLimit): the
+    outputs of that forward are garbage, so raise instead of returning them."""
+    for sb in self.subs:
+      st = sb.get('ctrl_status')
+      if st is not None and int(st.item()) != 0:
+        st.zero_()
+        raise rn.RecAttendError('controller_split: a workgroup timed out waiting for its peers (the launch was '
+                                'not fully resident); decode with engine.ctrl_split = False')
 
   # ------------------------------------------------------------------ launch sequence
   def _mark(self, name):

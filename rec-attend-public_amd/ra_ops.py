@@ -124,6 +124,16 @@ def pack_ctrl_split_weights(desc, lstm, gmlp, cmlp):
   return out
 
 
+_CUS = []
+
+
+def cu_count():
+  """Compute units of the current device (256 on MI355X)."""
+  if not _CUS:
+    _CUS.append(int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count))
+  return _CUS[0]
+
+
 def ctrl_split_workspace(desc, B, device):
   """Zero-filled exchange workspace (+ status word) for ONE stream of launches."""
   nb = rn.lib().ra_ctrl_split_workspace_bytes(C.byref(desc), B)

@@ -359,3 +359,37 @@ def test_decode_pipeline_matches_lone_run(cuda):
   assert np.array_equal(pipe.collect(as_numpy=True), lone[0][0])
   pipe.drain()
   assert len(pipe) == 0
+  # a batch cut into parts of <= 2 images (3 slots for 5 images) comes back whole and in order
+  x5 = rng.rand(5, 128, 160, 3).astype(np.float32)
+  whole = m.run(names, {'x': x5, 'phase_train': False}, as_numpy=True)
+  cut = m.pipeline(3, max_images=2)
+  assert cut.parts(5) == 3 and not cut.full(5)
+  cut.submit(names, {'x': x5, 'phase_train': False})
+  assert cut.full() and cut.full(5)
+  with pytest.raises(RecAttendError):
+    cut.submit(names, {'x': x5, 'phase_train': False})
+  for u, v in zip(cut.collect(as_numpy=True), whole):
+    assert u.shape == v.shape and np.array_equal(u, v)
+  with pytest.raises(RecAttendError):
+    m.pipeline(2, max_images=2).submit(names, {'x': x5, 'phase_train': False})
+
+
+def test_decode_pipeline_box_model(cuda):
+  """box_model through the pipeline (y_gt and the canvas noise are cut with the batch)."""
+  import box_model
+  opt = ora.make_opt('kitti', 64, 96, 4)
+  m = box_model.get_model(opt).load_weights(ora.random_params(opt, 3, box_model=True))
+  rng = np.random.RandomState(2)
+  B, T, H, W = 4, 4, 64, 96
+  x, d_in, y_in = _inputs(opt, B, 7)
+  y_gt = np.zeros((B, T, H, W), np.float32)
+  y_gt[:, 0, 10:30, 20:50] = 1.0
+  y_gt[:, 1, 35:60, 40:90] = 1.0
+  noise = rng.uniform(0, 0.3, (T, B, H, W)).astype(np.float32)
+  feed = {'x': x, 'd_in': d_in, 'y_in': y_in, 'y_gt': y_gt, 'noise': noise, 'phase_train': False}
+  names = ['attn_box', 's_out']
+  whole = m.run(names, feed, as_numpy=True)
+  pipe = m.pipeline(2, max_images=2)
+  pipe.submit(names, feed)
+  for u, v in zip(pipe.collect(as_numpy=True), whole):
+    assert u.shape == v.shape and np.array_equal(u, v)
