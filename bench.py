@@ -541,6 +541,41 @@ def main():
                 'read+write the canvas = H*W*(C0+3)*4 B per image-timestep) / time.  The kernels are '
                 'window-only: `traffic` (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_attn_traffic.json) '
                 'is what they really move; each is bounded by a dependent-load latency chain, not by bytes'}
+    # the product's operating point: the decode pipeline keeps `depth` batches in flight, so `depth`
+    # of these launch groups (one per slot, each on its slot's buffers and stream) share the chip
+    if pipe.depth > 1 and pipe.slots:
+      graphs, inner, reps = [], 16, 10
+      for e_k, st_k in pipe.slots:
+        sbk = e_k.subs[0]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st_k):
+          attn_group(sbk)
+          st_k.synchronize()
+          gk = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(gk, stream=st_k):
+            for _ in range(inner):
+              attn_group(sbk)
+        graphs.append(gk)
+
+      def replay_all():
+        for gk, (_, st_k) in zip(graphs, pipe.slots):
+          with torch.cuda.stream(st_k):
+            gk.replay()
+      replay_all()
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(reps):
+        replay_all()
+      torch.cuda.synchronize()
+      us_all = 1e6 * (time.perf_counter() - t1) / (reps * inner)  # `depth` groups complete per us_all
+      us_all += fill_us / T  # each slot's prefill share, charged as if it did not overlap at all
+      out['roofline_attn']['in_flight'] = {
+          'groups': pipe.depth, 'us_per_%d_groups' % pipe.depth: us_all,
+          'achieved': pipe.depth * attn_bytes / (us_all * 1e-6) / 1e9,
+          'frac': pipe.depth * attn_bytes / (us_all * 1e-6) / 1e9 / PEAK_HBM_GBS,
+          'note': 'the same launch group issued from every pipeline slot at once (wall time of %d graph replays '
+                  'per slot, %d groups per graph)' % (reps, inner)}
+      del graphs
     if args.attn_b32:  # the same group at a large batch, where latency amortises
       import full_model as fm2
       m32 = fm2.get_model(opt, is_training=False)
