@@ -145,7 +145,29 @@ def _f(*shape, device):
   return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+  k = str(device)
+  if k not in _SIDE:
+    _SIDE[k] = torch.cuda.Stream(device=device)
+  return _SIDE[k]
+
+
+_PACK = {}  # per step: (weight storage, geometry) -> packed filter; the filters are shared by the T timesteps
+
+
 def _pack_dev(w, cin_w, cout, cin, cmap_t, transposed):
+  key = (w.data_ptr(), int(cin_w), int(cout), int(cin), 0 if cmap_t is None else cmap_t.data_ptr(), bool(transposed))
+  hit = _PACK.get(key)
+  if hit is not None:
+    return hit
+  out = _PACK[key] = _pack_dev_now(w, cin_w, cout, cin, cmap_t, transposed)
+  return out
+
+
+def _pack_dev_now(w, cin_w, cout, cin, cmap_t, transposed):
   n = rn.lib().ra_conv_packed_floats(cin, cout)
   if n == 0:
     raise rn.RecAttendError('unsupported conv shape Cin=%d Cout=%d' % (cin, cout))
@@ -212,7 +234,8 @@ class ConvBNActPool(torch.autograd.Function):
     use_bn = gamma is not None
     mean = var = None
     if use_bn:
-      mean, var, ws = _f(cout, device=dev), _f(cout, device=dev), _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
+      mean, var = meta['stat_out'] if meta.get('stat_out') is not None else (_f(cout, device=dev), _f(cout, device=dev))
+      ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
       check(rn.lib().ra_bn_moments_f32(ptr(u), B * H * W, cout, ptr(ws), ws.numel(), ptr(mean), ptr(var),
                                        rn.stream_ptr()), 'ra_bn_moments_f32')
     y = _f(B, H // pool, W // pool, cout, device=dev)
@@ -336,6 +359,31 @@ def paste(p, fy, fx):
   return torch.bmm(torch.bmm(fy, p), fx.transpose(1, 2))
 
 
+def _flat_bn_statistics(trainer):
+  """One flat buffer for every BatchNorm shadow (ema_mean | ema_var, per layer and timestep copy) and a
+  buffer of the same layout that the moment kernels write the batch statistics into: the EMA update
+  of a step (nnlib.py:103-110, 2 x 640 small tensors at the CVPPP arch) becomes two launches."""
+  model, dev = trainer.model, trainer.bucket.param.device
+  keys = sorted(k[:-len('_ema_mean')] for k in model.weight_keys() if k.endswith('_ema_mean'))
+  offs, off = {}, 0
+  for k in keys:
+    n = model[k + '_ema_mean'].numel()
+    offs[k] = (off, n)
+    off += n
+  trainer.ema = torch.zeros(2 * off, dtype=torch.float32, device=dev)
+  trainer.stat = torch.zeros(2 * off, dtype=torch.float32, device=dev)
+  trainer._stat_views = {}
+  for k, (o, n) in offs.items():
+    for half, name in ((0, '_ema_mean'), (off, '_ema_var')):
+      view = trainer.ema[half + o:half + o + n]
+      view.copy_(model[k + name].reshape(-1).to(dev))
+      model[k + name] = view.view(model[k + name].shape)  # the model (and the decode engine) read the flat buffer
+    trainer._stat_views[k] = (trainer.stat[o:o + n], trainer.stat[off + o:off + o + n])
+  eng = getattr(model, 'engine', None)
+  if eng is not None:
+    eng._stamp = None
+
+
 class TrainStep(object):
   """model.run(['loss', 'train_step'], feed) of the reference's trainer (full_model_train.py:107)."""
 
@@ -364,6 +412,7 @@ class TrainStep(object):
     cmap_a, _ = model.engine._chan_map(d['attn_in'])
     self.cmap_c = None if cmap_c == list(range(len(cmap_c))) else cmap_c
     self.cmap_a = None if cmap_a == list(range(len(cmap_a))) else cmap_a
+    _flat_bn_statistics(self)
 
   # ------------------------------------------------------------------ pieces
   def _cnn(self, x, scope, n, pools, tt, cmap0, stats):
@@ -371,7 +420,8 @@ class TrainStep(object):
     for i in range(n):
       bn = self.d['use_bn']
       key = '%s_%d_%d' % (scope, i, tt)
-      meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None)
+      meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None,
+                  stat_out=self._stat_views.get(key))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x) if i else x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -396,7 +446,7 @@ class TrainStep(object):
         cmap = list(range(prev_c)) + [-1] * (xp.shape[3] - prev_c) + [prev_c + m if m >= 0 else -1 for m in smap] + \
             [-1] * (skp.shape[3] - len(smap))
         x = torch.cat([xp, skp], dim=3)
-      meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap)
+      meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -464,8 +514,11 @@ class TrainStep(object):
     else:
       scale = torch.ones(T, device=dev)
     step = self.bucket.global_step
-    pb = torch.clamp(knob_prob(opt, step, opt['knob_box_offset']) * scale, max=1.0)[None, :, None]
-    ps = torch.clamp(knob_prob(opt, step, opt['knob_segm_offset']) * scale, max=1.0)[None, :, None]
+    sched = getattr(self, '_sched', None)  # graph replay: the two probabilities live in a device tensor
+    kb0 = sched[0] if sched is not None else knob_prob(opt, step, opt['knob_box_offset'])
+    ks0 = sched[1] if sched is not None else knob_prob(opt, step, opt['knob_segm_offset'])
+    pb = torch.clamp(kb0 * scale, max=1.0)[None, :, None]
+    ps = torch.clamp(ks0 * scale, max=1.0)[None, :, None]
     return ctr_n, size_n, (knobs['u_box'] <= pb).to(torch.float32), (knobs['u_segm'] <= ps).to(torch.float32)
 
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None, d_in=None, y_in=None):
@@ -474,6 +527,7 @@ class TrainStep(object):
     draws in `knobs` (draw_knobs() when None).  d_in / y_in: the extra input channels of the KITTI /
     Cityscapes architectures (full_model.py:165-194)."""
     P, d, opt = self.leaves, self.d, self.opt
+    _PACK.clear()  # the optimizer wrote new weights since the last step
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
@@ -496,8 +550,8 @@ class TrainStep(object):
       ysel = torch.empty((B, H, W), device=dev)
     canvas = torch.zeros((B, H, W, 1), device=dev)
     stats, y_list, s_list, box_list, cn_list, ls_list = {}, [], [], [], [], []
-    dims_hw = torch.tensor([H, W], dtype=torch.float32, device=dev)
-    dims_f = torch.tensor([Fh, Fw], dtype=torch.float32, device=dev)
+    dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
+    dims_f = _const('dims', (Fh, Fw), dev, lambda: torch.tensor([Fh, Fw], dtype=torch.float32, device=dev))
     for tt in range(T):
       inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
       if inp.shape[3] != d['C0p']:
@@ -577,12 +631,20 @@ class TrainStep(object):
         m = ident
       else:
         m, st = ops.segm_match(iou.detach(), s_gt)
-        ops.check_match_status(st, 'f_segm_match')
+        statuses.append(st)  # checked by the caller once the step has run (no host sync in here)
       cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
       return ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B, m
 
-    iou_box, m_box = matched_iou(attn_box, box_gt)
+    statuses = []
+    # the two matchings are independent and each is one wave per image for milliseconds (dense soft-IoU
+    # matrices early in training): the box matching runs on a side stream under the mask matching
+    cur = torch.cuda.current_stream()
+    side = _side_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+      iou_box, m_box = matched_iou(attn_box, box_gt)
     iou_soft, m = matched_iou(y_out, y_gt)
+    cur.wait_stream(side)
     box_loss, segm_loss = -iou_box, -iou_soft
     blf = opt.get('box_loss_fn', 'iou')
     if blf in ('mse', 'huber'):  # matched regression of (centre, log size) (full_model.py:891-892,952-964)
@@ -603,25 +665,94 @@ class TrainStep(object):
     conf = (-ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)).sum() / B / T
     loss = box_loss + segm_loss + float(opt.get('loss_mix_ratio', 1.0)) * conf
     pieces = {'loss': loss, 'box_loss': box_loss, 'segm_loss': segm_loss, 'conf_loss': conf, 'iou_soft': iou_soft,
-              'iou_soft_box': iou_box, 'match': m, 'match_box': m_box, 'y_out': y_out, 's_out': s_out}
+              'iou_soft_box': iou_box, 'match': m, 'match_box': m_box, 'y_out': y_out, 's_out': s_out,
+              '_match_status': statuses}
     return loss, pieces, stats
 
   # ------------------------------------------------------------------ one optimisation step
+  use_graph = True  # capture forward + backward + EMA of a repeated step shape in one HIP graph
+
+  def _grads_and_stats(self, x, y_gt, s_gt, knobs, generator, extra):
+    """zero_grad + forward + backward + BN EMA update: everything of a step that is pure device work."""
+    self.bucket.zero_grad()
+    loss, pieces, stats = self.forward_loss(x, y_gt, s_gt, knobs=knobs, generator=generator, **extra)
+    loss.backward()
+    with torch.no_grad():  # shadow = 0.9 shadow + 0.1 batch statistic (nnlib.py:103-110)
+      if set(stats.keys()) == set(self._stat_views.keys()):  # every BN copy ran: one update of the flat buffers
+        self.ema.mul_(EMA_DECAY).add_(self.stat, alpha=1 - EMA_DECAY)
+      else:
+        for key, (mean, var) in stats.items():
+          self.model[key + '_ema_mean'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * mean)
+          self.model[key + '_ema_var'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * var)
+    return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in pieces.items()}
+
+  def _graphed(self, x, y_gt, s_gt, knobs, generator, extra):
+    """The same work as _grads_and_stats, replayed from a HIP graph.  A training step issues ~24 000
+    kernels (16 timesteps x 40 layers x forward / backward pieces plus the dense glue under autograd);
+    eagerly the host needs ~10 us for each, more than most of them run.  Inputs, the step's random
+    draws and the two knob probabilities live in static device buffers that are refreshed before
+    every replay; the first step of a shape runs eagerly (it also warms every cache), the second one
+    is captured."""
+    dev = self.bucket.param.device
+    as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
+        device=dev, dtype=torch.float32)
+    ins = {'x': as_t(x), 'y_gt': as_t(y_gt), 's_gt': as_t(s_gt)}
+    ins.update({k: as_t(v) for k, v in extra.items() if v is not None})
+    use_knob = bool(self.opt.get('use_knob', False)) or isinstance(self, BoxTrainStep)
+    if knobs is None and use_knob:
+      knobs = self.draw_knobs(ins['x'].shape[0], generator)
+    knobs = {k: as_t(v) for k, v in (knobs or {}).items()}
+    key = tuple((k, tuple(v.shape)) for k, v in sorted(ins.items())) + tuple((k, tuple(v.shape)) for k, v in sorted(knobs.items()))
+    st = self._graphs.get(key)
+    if st is None:  # first step of this shape: eager
+      self._graphs[key] = {'warm': True}
+      self._sched = None
+      return self._grads_and_stats(ins['x'], ins['y_gt'], ins['s_gt'], knobs or None, None,
+                                   {k: ins[k] for k in ('d_in', 'y_in') if k in ins})
+    step = self.bucket.global_step
+    sched = [knob_prob(self.opt, step, self.opt['knob_box_offset']), knob_prob(self.opt, step, self.opt['knob_segm_offset'])] \
+        if bool(self.opt.get('use_knob', False)) else [0.0, 0.0]
+    if 'graph' not in st:
+      st['ins'] = {k: v.clone() for k, v in ins.items()}
+      st['knobs'] = {k: v.clone() for k, v in knobs.items()}
+      st['sched'] = torch.tensor(sched, dtype=torch.float32, device=dev)
+      self._sched = st['sched']
+      torch.cuda.synchronize()
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        st['out'] = self._grads_and_stats(st['ins']['x'], st['ins']['y_gt'], st['ins']['s_gt'], st['knobs'] or None, None,
+                                          {k: st['ins'][k] for k in ('d_in', 'y_in') if k in st['ins']})
+      self._sched = None
+      st['graph'] = g
+    else:
+      for k, v in ins.items():
+        st['ins'][k].copy_(v)
+      for k, v in knobs.items():
+        st['knobs'][k].copy_(v)
+      st['sched'].copy_(torch.tensor(sched, dtype=torch.float32), non_blocking=False)
+    st['graph'].replay()
+    return dict(st['out'])
+
   def run(self, x, y_gt, s_gt, knobs=None, generator=None, **extra):
     """loss + train_step: backward into the flat bucket, one all-reduce, clip + Adam, BN EMA update.
     The reported `loss` excludes nothing the reference includes except the weight-decay terms, which
     enter through their gradient (wd * w) inside the optimizer kernel."""
-    self.bucket.zero_grad()
-    loss, pieces, stats = self.forward_loss(x, y_gt, s_gt, knobs=knobs, generator=generator, **extra)
-    loss.backward()
+    if not hasattr(self, '_graphs'):
+      self._graphs = {}
+    if knobs is not None:
+      dev = self.bucket.param.device
+      knobs = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32))).to(
+          device=dev, dtype=torch.float32) for k, v in knobs.items()}
+    if self.use_graph:
+      out = self._graphed(x, y_gt, s_gt, knobs, generator, extra)
+    else:
+      self._sched = None
+      out = self._grads_and_stats(x, y_gt, s_gt, knobs, generator, extra)
     world = self.bucket.allreduce()
     lr = self.bucket.step(world=world)
-    with torch.no_grad():  # shadow = 0.9 shadow + 0.1 batch statistic (nnlib.py:103-110)
-      for key, (mean, var) in stats.items():
-        self.model[key + '_ema_mean'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * mean)
-        self.model[key + '_ema_var'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * var)
+    for st in out.pop('_match_status', []):  # one host sync per step, after everything has been queued
+      ops.check_match_status(st, 'f_segm_match')
     wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
-    out = {k: v.detach() for k, v in pieces.items()}
     out['learn_rate'] = lr
     out['weight_decay_loss'] = 0.5 * (self.bucket.wd * self.bucket.param * self.bucket.param).sum().detach() if wd else 0.0
     return out
@@ -650,23 +781,29 @@ class BoxTrainStep(TrainStep):
       leaf.grad = self.bucket.grad_of[k]
       self.leaves[k] = leaf
     self.cmap_c = self.cmap_a = None
+    _flat_bn_statistics(self)
+
+  def draw_knobs(self, B, generator=None):
+    """The step's one random draw: the canvas noise U[0, 0.3) (box_model.py:500-502)."""
+    d = self.d
+    return {'noise': 0.3 * torch.rand((d['T'], B, d['H'], d['W']), generator=generator, device=self.bucket.param.device)}
 
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
     P, d, opt = self.leaves, self.d, self.opt
+    _PACK.clear()  # the optimizer wrote new weights since the last step
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
     x, y_gt, s_gt = as_t(x), as_t(y_gt), as_t(s_gt)
     B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
-    noise = as_t(knobs['noise']) if knobs is not None and 'noise' in knobs else \
-        0.3 * torch.rand((T, B, H, W), generator=generator, device=dev)        # box_model.py:500-502
+    noise = as_t(knobs['noise']) if knobs is not None and 'noise' in knobs else self.draw_knobs(B, generator)['noise']
     fixed = bool(opt.get('fixed_order', False))
     gp, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), 10.0)   # get_gt_attn's default min_padding
     canvas = torch.zeros((B, H, W, 1), device=dev)
     ysel = torch.empty((B, H, W), device=dev)
     stats, box_list, s_list, cn_list, ls_list = {}, [], [], [], []
-    dims_hw = torch.tensor([H, W], dtype=torch.float32, device=dev)
-    dims_f = torch.tensor([Fh, Fw], dtype=torch.float32, device=dev)
+    dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
+    dims_f = _const('dims', (Fh, Fw), dev, lambda: torch.tensor([Fh, Fw], dtype=torch.float32, device=dev))
     for tt in range(T):
       inp = torch.cat([x, canvas], dim=3)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, None, stats)[-1]
@@ -696,11 +833,12 @@ class BoxTrainStep(TrainStep):
       ls_list.append(ls)
     attn_box, s_out = torch.stack(box_list, dim=1), torch.cat(s_list, dim=1)
     iou = PairIoU.apply(attn_box, box_gt)
+    statuses = []
     if fixed:
       m = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
     else:
       m, st = ops.segm_match(iou.detach(), s_gt)
-      ops.check_match_status(st, 'f_segm_match')
+      statuses.append(st)
     cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
     iou_box = ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B
     box_loss = -iou_box
@@ -718,5 +856,5 @@ class BoxTrainStep(TrainStep):
     conf = (-ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)).sum() / B / T
     loss = box_loss + conf
     pieces = {'loss': loss, 'box_loss': box_loss, 'conf_loss': conf, 'iou_soft_box': iou_box, 'match_box': m,
-              's_out': s_out[:, :, 0] if d['nsc'] == 1 else s_out, 'attn_box': attn_box}
+              's_out': s_out[:, :, 0] if d['nsc'] == 1 else s_out, 'attn_box': attn_box, '_match_status': statuses}
     return loss, pieces, stats

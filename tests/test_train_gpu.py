@@ -379,3 +379,36 @@ def test_kitti_arch_training_vs_oracle(cuda, knob):
   loss2, _ = m.run(['loss', 'train_step'], {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'd_in': d_in, 'y_in': y_in,
                                             'phase_train': True, 'knobs': kd})
   assert abs(float(loss2) - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss'])))
+
+
+def test_graphed_step_equals_eager_step(cuda):
+  """TrainStep.use_graph: from the second step of a shape on, zero_grad + forward + backward + EMA are
+  replayed from one HIP graph (inputs, random draws and the knob probabilities in static buffers).
+  Five steps with knobs on a decaying schedule: losses, weights and BN shadows equal the eager run's."""
+  import full_model
+  import ra_train
+  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, **dict(KNOB_OPT, steps_per_knob_decay=2, knob_box_offset=1, knob_segm_offset=1))
+  rng = np.random.RandomState(11)
+  B, T, H, W = x.shape[0], 3, 64, 64
+  draws = [{'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)),
+            'u_box': rng.rand(B, T, 1), 'u_segm': rng.rand(B, T, 1), 'segm_noise': 0.3 * rng.rand(T, B, H, W)}
+           for _ in range(5)]
+  xs = [x, x[::-1].copy(), x, x * 0.5, x]
+  res = {}
+  for graphed in (False, True):
+    m = full_model.get_model(opt).load_weights(P)
+    losses = []
+    for k, xk in zip(draws, xs):
+      if getattr(m, 'trainer', None) is not None:
+        m.trainer.use_graph = graphed
+      else:
+        ra_train.TrainStep.use_graph = graphed
+      loss, _ = m.run(['loss', 'train_step'], {'x': xk, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'knobs': k})
+      losses.append(float(loss))
+    res[graphed] = (losses, m.state_dict_numpy())
+    assert (graphed and any('graph' in v for v in m.trainer._graphs.values())) or \
+        (not graphed and not any('graph' in v for v in m.trainer._graphs.values()))
+  ra_train.TrainStep.use_graph = True
+  assert np.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6), (res[True][0], res[False][0])
+  for k, v in res[False][1].items():
+    assert np.allclose(res[True][1][k], v, rtol=1e-4, atol=1e-6), k
