@@ -494,6 +494,20 @@ size_t ra_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int B, int H, int W)
 int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
                          const float *du, int Cout, float *ws, size_t ws_floats, float *dw,
                          float *db, void *stream);
+/* The accumulating forms add the layer's parameter gradients straight into the trainer's flat
+ * gradient bucket (one writer per element), replacing ~2 500 small `grad += g` launches of a step:
+ *   ra_conv3x3_wgrad_acc_f32    gw += dW in the REFERENCE layout of the filter that ran — [3,3,cin_w,Cout],
+ *                               or [3,3,Cout,cin_w] with flipped taps when transposed (nnlib.dcnn's
+ *                               filters, nnlib.py:362-400) — chan_map (device, nullable) sends packed kernel
+ *                               channel c to filter row chan_map[c] (-1: padding); gb += db (nullable).
+ *   ra_bn_act_pool_bwd_acc_f32  ra_bn_act_pool_bwd_f32 + acc_gamma += dgamma, acc_beta += dbeta (nullable). */
+int ra_conv3x3_wgrad_acc_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
+                             const float *du, int Cout, float *ws, size_t ws_floats, const int *chan_map,
+                             int cin_w, int transposed, float *gw, float *gb, void *stream);
+int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mean, const float *var,
+                               const float *gamma, const float *beta, float eps, int relu, int pool,
+                               int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
+                               float *dbeta, float *du, float *acc_gamma, float *acc_beta, void *stream);
 int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
 int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
                               int HW, float *out, void *stream);

@@ -158,12 +158,12 @@ def knob_setup(opt, y_gt, knobs, global_step):
   centre shift), the plain GT boxes for the greedy match, and the two knob masks."""
   T = y_gt.shape[1]
   mp = opt['padding'] + 4.0
-  _, _, box_gt = ora.get_gt_box(y_gt, padding_ratio=opt['attn_box_padding_ratio'], center_shift_ratio=0.0, min_padding=mp)
+  tl0, br0, box_gt = ora.get_gt_box(y_gt, padding_ratio=opt['attn_box_padding_ratio'], center_shift_ratio=0.0, min_padding=mp)
   tl, br, _ = ora.get_gt_box(y_gt, padding_ratio=knobs['pad'], center_shift_ratio=knobs['shift'], min_padding=mp)
   scale = 1.0 + np.log(1.0 + np.arange(T) * 3.0) if ora._opt(opt, 'knob_use_timescale', False) else np.ones(T)
   prob = lambda off: np.minimum(1.0, opt['knob_base'] * opt['knob_decay'] ** (
       max(0.0, global_step - off) / opt['steps_per_knob_decay']) * scale)[None, :, None]
-  return {'ctr': t64((tl + br) / 2.0), 'size': t64(br - tl), 'box_gt': box_gt,
+  return {'ctr': t64((tl + br) / 2.0), 'size': t64(br - tl), 'box_gt': box_gt, 'tl_gt': tl0, 'br_gt': br0,
           'kb': t64((knobs['u_box'] <= prob(opt['knob_box_offset'])).astype(np.float64)),
           'ks': t64((knobs['u_segm'] <= prob(opt['knob_segm_offset'])).astype(np.float64)),
           'noise': t64(knobs['segm_noise']), 'y_gt': t64(y_gt)}
@@ -240,8 +240,18 @@ def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
       if ora._opt(opt, 'fixed_order', False):
         ctr_m, size_m, gm = K['ctr'][:, tt], K['size'][:, tt], None
       else:
-        a = attn_box.detach().numpy()
-        iou_t = ora.f_inter(a, K['box_gt']) / ora.f_union(a, K['box_gt'], eps=1e-5)
+        if ora._opt(opt, 'use_iou_box', False):  # modellib.f_iou_box on the corners (full_model.py:750-754)
+          c_, s_ = ctr.detach().numpy(), size.detach().numpy()
+          ta, ba = (c_ - s_ / 2.0)[:, None, :], (c_ + s_ / 2.0)[:, None, :]
+          tb, bb = K['tl_gt'], K['br_gt']
+          y1, x1 = np.maximum(ta[..., 0], tb[..., 0]), np.maximum(ta[..., 1], tb[..., 1])
+          y2, x2 = np.minimum(ba[..., 0], bb[..., 0]), np.minimum(ba[..., 1], bb[..., 1])
+          inter = (x1 < x2) * (y1 < y2) * (x2 - x1) * (y2 - y1)
+          iou_t = (inter / ((ba[..., 1] - ta[..., 1]) * (ba[..., 0] - ta[..., 0]) +
+                            (bb[..., 1] - tb[..., 1]) * (bb[..., 0] - tb[..., 0]) - inter))
+        else:
+          a = attn_box.detach().numpy()
+          iou_t = ora.f_inter(a, K['box_gt']) / ora.f_union(a, K['box_gt'], eps=1e-5)
         gm = t64(ora.f_greedy_match(iou_t, np.zeros_like(iou_t)))
         ctr_m, size_m = (gm[:, :, None] * K['ctr']).sum(dim=1), (gm[:, :, None] * K['size']).sum(dim=1)
       kb = K['kb'][:, tt]

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *u, cons
     part[((size_t)blockIdx.x * 2 + 1) * C + tid] = t1;
   }
 }
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *part, int nblocks, int C, float *dbeta, float *dgamma) {
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *part, int nblocks, int C, float *dbeta, float *dgamma,
+                                                           float *acc_beta = nullptr, float *acc_gamma = nullptr) {
   __shared__ float red[256];
   const int c = blockIdx.x;
   float t0 = 0.f, t1 = 0.f;
@@ -210,6 +211,8 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *part, in
   if (threadIdx.x == 0) {
     dbeta[c] = t0;
     dgamma[c] = t1;
+    if (acc_beta) acc_beta[c] += t0;    // straight into the gradient bucket (one writer per element)
+    if (acc_gamma) acc_gamma[c] += t1;
   }
 }
 // ---- stage 2: du = gamma * rstd * (dv - dbeta / n - xhat * dgamma / n)   (batch-norm: var given)
@@ -327,10 +330,11 @@ extern "C" int ra_bn_act_pool_f32(const float *u, const float *mean, const float
   return launch_status("ra_bn_act_pool_f32");
 }
 
-extern "C" int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const float *mean, const float *var,
-                                      const float *gamma, const float *beta, float eps, int relu, int pool, int B,
-                                      int H, int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta,
-                                      float *du, void *stream) {
+namespace {
+int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float *var, const float *gamma,
+                const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *ws,
+                size_t ws_floats, float *dgamma, float *dbeta, float *du, float *acc_gamma, float *acc_beta,
+                void *stream) {
   if (!u || !dy || !ws || !dgamma || !dbeta || !du || B <= 0 || H <= 0 || W <= 0 || C <= 0)
     return fail(RA_E_INVALID, "ra_bn_act_pool_bwd_f32: bad argument");
   if (C > 256) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_f32: C %d > 256", C);
@@ -343,12 +347,29 @@ extern "C" int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const flo
   if (nb > train::kRedBlocks) nb = train::kRedBlocks;
   hipLaunchKernelGGL(train::bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, u, dy, mean, var, gamma, beta, eps, relu, pool,
                      B, H, W, C, ws);
-  hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, nb, C, dbeta, dgamma);
+  hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, nb, C, dbeta, dgamma, acc_beta, acc_gamma);
   size_t grid = (npix * C + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(train::bn_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, st, u, dy, mean, var, gamma, beta, dbeta,
                      dgamma, eps, relu, pool, B, H, W, C, du);
   return launch_status("ra_bn_act_pool_bwd_f32");
+}
+}  // namespace
+
+extern "C" int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const float *mean, const float *var,
+                                      const float *gamma, const float *beta, float eps, int relu, int pool, int B,
+                                      int H, int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta,
+                                      float *du, void *stream) {
+  return bn_bwd_impl(u, dy, mean, var, gamma, beta, eps, relu, pool, B, H, W, C, ws, ws_floats, dgamma, dbeta, du, nullptr,
+                     nullptr, stream);
+}
+
+extern "C" int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mean, const float *var,
+                                          const float *gamma, const float *beta, float eps, int relu, int pool, int B,
+                                          int H, int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta,
+                                          float *du, float *acc_gamma, float *acc_beta, void *stream) {
+  return bn_bwd_impl(u, dy, mean, var, gamma, beta, eps, relu, pool, B, H, W, C, ws, ws_floats, dgamma, dbeta, du, acc_gamma,
+                     acc_beta, stream);
 }
 
 extern "C" int ra_conv_pack_weights_dev(const float *w, int Cin_w, int Cout, int Cin, const int *chan_map, int flags,
@@ -518,6 +539,44 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int
   }
 }
 
+// The same reduction, ADDED to the filter's gradient in the reference's own layout (the gradient
+// bucket): [3,3,cin_w,Cout], or [3,3,Cout,cin_w] with the taps flipped for a transposed (dcnn) layer;
+// chan_map sends a packed kernel channel to its filter row (-1: padding).  One writer per element.
+__global__ __launch_bounds__(256) void wgrad_final_acc_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
+                                                              const int *chan_map, int cin_w, int transposed, float *gw,
+                                                              float *gb) {
+  const int total = 9 * Cin * Cout + Cout;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= total) return;
+  int tap, ci, co;
+  if (e < 9 * Cin * Cout) {
+    co = e % Cout;
+    ci = (e / Cout) % Cin;
+    tap = e / (Cout * Cin);
+  } else {
+    tap = 9;
+    ci = 0;
+    co = e - 9 * Cin * Cout;
+  }
+  const int j = tap == 9 ? 0 : (chan_map ? chan_map[ci] : (ci < cin_w ? ci : -1));
+  if (j < 0) return;  // wave-uniform
+  const int chunk = ci / 16, cl = ci % 16, slice = co / CP, cs = co % CP;
+  float s = 0.f;
+  for (int k = lane; k < nwg; k += 64)
+    s += part[((((size_t)slice * nchunks + chunk) * nwg + k) * 10 + tap) * 16 * CP + cl * CP + cs];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    if (tap == 9) {
+      if (gb) gb[co] += s;
+    } else {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const size_t idx = transposed ? ((size_t)((2 - ky) * 3 + (2 - kx)) * Cout + co) * cin_w + j
+                                    : ((size_t)(ky * 3 + kx) * cin_w + j) * Cout + co;
+      gw[idx] += s;
+    }
+  }
+}
+
 }  // namespace train
 }  // namespace ra
 
@@ -533,8 +592,12 @@ extern "C" size_t ra_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int B, in
   return (size_t)(cp / per) * ceil_div(Cin, 16) * wgrad_grid_x(ntiles) * 10 * 16 * per;
 }
 
-extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
-                                    int Cout, float *ws, size_t ws_floats, float *dw, float *db, void *stream) {
+namespace {
+// acc == false: dw / db are written in the kernel's own [3,3,Cin,Cout] / [Cout] layout; acc == true: the
+// sums are added to gw / gb in the reference layout (chan_map, cin_w, transposed as in wgrad_final_acc_kernel)
+int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du, int Cout, float *ws,
+               size_t ws_floats, float *dw, float *db, bool acc, const int *chan_map, int cin_w, int transposed,
+               void *stream) {
   if (!x || !du || !ws || !dw || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
     return fail(RA_E_INVALID, "ra_conv3x3_wgrad_f32: bad argument");
   const int cp = ra_conv_cout_padded(Cout);
@@ -568,6 +631,24 @@ extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int 
   }
 #undef RA_WGRAD
   const int total = 9 * Cin * Cout + Cout;
-  hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout, dw, db);
+  if (acc)
+    hipLaunchKernelGGL(wgrad_final_acc_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout,
+                       chan_map, cin_w, transposed, dw, db);
+  else
+    hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout, dw, db);
   return launch_status("ra_conv3x3_wgrad_f32");
+}
+}  // namespace
+
+extern "C" int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
+                                    int Cout, float *ws, size_t ws_floats, float *dw, float *db, void *stream) {
+  return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, dw, db, false, nullptr, Cin, 0, stream);
+}
+
+extern "C" int ra_conv3x3_wgrad_acc_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
+                                        int Cout, float *ws, size_t ws_floats, const int *chan_map, int cin_w,
+                                        int transposed, float *gw, float *gb, void *stream) {
+  if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_acc_f32: cin_w %d", cin_w);
+  return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w, transposed ? 1 : 0,
+                    stream);
 }

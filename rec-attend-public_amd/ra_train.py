@@ -262,24 +262,42 @@ class ConvBNActPool(torch.autograd.Function):
     dy = dy.contiguous()
     ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
     dgamma, dbeta, du = _f(cout, device=dev), _f(cout, device=dev), torch.empty_like(u)
-    check(rn.lib().ra_bn_act_pool_bwd_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
-                                          _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
-                                          ptr(dgamma), ptr(dbeta), ptr(du), rn.stream_ptr()), 'ra_bn_act_pool_bwd_f32')
-    # ---- backward-weight (of the SAME conv that ran) + bias
+    grads = meta.get('grads')  # (gw, gb, ggamma, gbeta): views of the flat gradient bucket -> accumulate in-kernel
     nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, B, H, W)
     wws = _f(nws, device=dev)
-    dWf, db = _f(3, 3, Cx, cout, device=dev), _f(cout, device=dev)
-    check(rn.lib().ra_conv3x3_wgrad_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
-                                        ptr(dWf), ptr(db), rn.stream_ptr()), 'ra_conv3x3_wgrad_f32')
-    if cmap is not None:  # packed kernel channels -> the filter's own input channels
-      real = torch.zeros((3, 3, cin_w, cout), dtype=torch.float32, device=dev)
-      for c, j in enumerate(cmap):
-        if j >= 0:
-          real[:, :, j, :] += dWf[:, :, c, :]
-      dWf = real
-    elif Cx != cin_w:
-      dWf = dWf[:, :, :cin_w, :]
-    dw = dWf.flip(0, 1).permute(0, 1, 3, 2).contiguous() if tr else dWf.contiguous()
+    if grads is not None:
+      gw, gb, gg, gbt = grads
+      check(rn.lib().ra_bn_act_pool_bwd_acc_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                                _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
+                                                ptr(dgamma), ptr(dbeta), ptr(du), ptr(gg), ptr(gbt), rn.stream_ptr()),
+            'ra_bn_act_pool_bwd_acc_f32')
+      cmap_t = _const('cmap', tuple(cmap), dev, lambda: torch.tensor(cmap, dtype=torch.int32, device=dev)) \
+          if cmap is not None else None
+      if cmap is not None:
+        real = [j for j in cmap if j >= 0]
+        assert len(set(real)) == len(real), 'chan_map must be injective (one writer per gradient element)'
+      check(rn.lib().ra_conv3x3_wgrad_acc_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
+                                              ptr(cmap_t), int(cin_w), int(tr), ptr(gw), ptr(gb), rn.stream_ptr()),
+            'ra_conv3x3_wgrad_acc_f32')
+      dw = db = None
+      dgamma = dbeta = None
+    else:
+      check(rn.lib().ra_bn_act_pool_bwd_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                            _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
+                                            ptr(dgamma), ptr(dbeta), ptr(du), rn.stream_ptr()), 'ra_bn_act_pool_bwd_f32')
+      # ---- backward-weight (of the SAME conv that ran) + bias
+      dWf, db = _f(3, 3, Cx, cout, device=dev), _f(cout, device=dev)
+      check(rn.lib().ra_conv3x3_wgrad_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
+                                          ptr(dWf), ptr(db), rn.stream_ptr()), 'ra_conv3x3_wgrad_f32')
+      if cmap is not None:  # packed kernel channels -> the filter's own input channels
+        real = torch.zeros((3, 3, cin_w, cout), dtype=torch.float32, device=dev)
+        for c, j in enumerate(cmap):
+          if j >= 0:
+            real[:, :, j, :] += dWf[:, :, c, :]
+        dWf = real
+      elif Cx != cin_w:
+        dWf = dWf[:, :, :cin_w, :]
+      dw = dWf.flip(0, 1).permute(0, 1, 3, 2).contiguous() if tr else dWf.contiguous()
     # ---- backward-data: the same MFMA conv kernel on the flipped / in-out-swapped packing
     dx = None
     if ctx.needs_input_grad[0]:
@@ -415,13 +433,25 @@ class TrainStep(object):
     _flat_bn_statistics(self)
 
   # ------------------------------------------------------------------ pieces
+  def _grad_views(self, scope, i, key, bn):
+    """The layer's parameter gradients go straight into the bucket (ConvBNActPool.backward, in-kernel)."""
+    if not (self.fuse_param_grads and bn and torch.is_grad_enabled()):
+      return None
+    g = self.bucket.grad_of
+    names = ('%s_w_%d' % (scope, i), '%s_b_%d' % (scope, i), key + '_gamma', key + '_beta')
+    if not all(n in g for n in names):
+      return None
+    return tuple(g[n] for n in names)
+
+  fuse_param_grads = True
+
   def _cnn(self, x, scope, n, pools, tt, cmap0, stats):
     P, hs = self.leaves, []
     for i in range(n):
       bn = self.d['use_bn']
       key = '%s_%d_%d' % (scope, i, tt)
       meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None,
-                  stat_out=self._stat_views.get(key))
+                  stat_out=self._stat_views.get(key), grads=self._grad_views(scope, i, key, bn))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x) if i else x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -446,7 +476,8 @@ class TrainStep(object):
         cmap = list(range(prev_c)) + [-1] * (xp.shape[3] - prev_c) + [prev_c + m if m >= 0 else -1 for m in smap] + \
             [-1] * (skp.shape[3] - len(smap))
         x = torch.cat([xp, skp], dim=3)
-      meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key))
+      meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key),
+                  grads=self._grad_views(scope, i, key, bn))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -540,10 +571,8 @@ class TrainStep(object):
     B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
     use_knob = bool(opt.get('use_knob', False))
     fixed = bool(opt.get('fixed_order', False))
-    _, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0)
+    gt_corners, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0)
     if use_knob:
-      if opt.get('use_iou_box', False):
-        raise NotImplementedError('use_iou_box (modellib.f_iou_box) in the knob is not built')
       if knobs is None:
         knobs = self.draw_knobs(B, generator)
       ctr_gtn, size_gtn, knob_box, knob_segm = self._knob_setup(y_gt, knobs)
@@ -580,7 +609,13 @@ class TrainStep(object):
           ctr_m, size_m = ctr_gtn[:, tt], size_gtn[:, tt]
           gmatch = None
         else:
-          iou_t = ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
+          if opt.get('use_iou_box', False):  # IoU of the box corners (modellib.f_iou_box, full_model.py:750-754)
+            import modellib
+            cd, sd = ctr.detach(), size.detach()
+            iou_t = modellib.f_iou_box((cd - sd / 2.0)[:, None], (cd + sd / 2.0)[:, None], gt_corners[:, :, 0:2],
+                                       gt_corners[:, :, 2:4]).contiguous()
+          else:
+            iou_t = ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
           gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
           ctr_m = (gmatch[:, :, None] * ctr_gtn).sum(dim=1)
           size_m = (gmatch[:, :, None] * size_gtn).sum(dim=1)

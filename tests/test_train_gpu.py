@@ -199,15 +199,16 @@ KNOB_OPT = dict(use_knob=True, knob_base=1.0, knob_decay=0.9, steps_per_knob_dec
                 gt_segm_noise=0.3)
 
 
-@pytest.mark.parametrize('step,fixed', [(0, False), (700, False), (0, True)], ids=['knobs_on', 'knobs_decayed', 'fixed_order'])
-def test_knob_mixing_vs_oracle(cuda, step, fixed):
+@pytest.mark.parametrize('step,fixed,ioub', [(0, False, False), (700, False, False), (0, True, False), (0, False, True)],
+                         ids=['knobs_on', 'knobs_decayed', 'fixed_order', 'use_iou_box'])
+def test_knob_mixing_vs_oracle(cuda, step, fixed, ioub):
   """use_knob = True (run_cvppp.sh; full_model.py:559-625,744-773,826-841): noisy GT boxes, greedy
   per-timestep match, box / segmentation knobs — same draws into product and oracle: loss pieces
   and the whole gradient.  Step 700: both knob probabilities have decayed below 1, so some draws
   keep the prediction."""
   import full_model
   import ra_train
-  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, fixed_order=fixed, **KNOB_OPT)
+  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, fixed_order=fixed, use_iou_box=ioub, **KNOB_OPT)  # use_iou_box: Cityscapes' knob
   B, T, H, W = 2, 3, 64, 64
   rng = np.random.RandomState(5)
   knobs = {'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)),
