@@ -508,6 +508,14 @@ int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mea
                                const float *gamma, const float *beta, float eps, int relu, int pool,
                                int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
                                float *dbeta, float *du, float *acc_gamma, float *acc_beta, void *stream);
+/* The pointwise half of the controller's LSTM cell (nnlib.py:641-646; the GEMM half is a library call):
+ * pre [B][4*hid] = gate pre-activations in the order (i, f, o, u), c_prev [B][hid]:
+ *   c = sigm(f) c_prev + sigm(i) tanh(u),  h = sigm(o) tanh(c);  act [B][4*hid] keeps the gate values.
+ * Backward: dh / dc nullable (a gradient that does not exist is zero) -> dpre [B][4*hid], dc_prev. */
+int ra_lstm_cell_f32(const float *pre, const float *c_prev, int B, int hid, float *h, float *c,
+                     float *act, void *stream);
+int ra_lstm_cell_bwd_f32(const float *act, const float *c_prev, const float *c, const float *dh,
+                         const float *dc, int B, int hid, float *dpre, float *dc_prev, void *stream);
 int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
 int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
                               int HW, float *out, void *stream);

@@ -539,6 +539,45 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int
   }
 }
 
+// ---- LSTM cell pointwise part (nnlib.py:641-646): pre [B][4*hid] = the four gate pre-activations
+// (i, f, o, u), c_prev [B][hid]  ->  c = f c_prev + i u,  h = o tanh(c).  act keeps the gate values
+// for the backward; one thread per (image, unit).
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float *pre, const float *c_prev, int n, int hid, float *h,
+                                                        float *c, float *act) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int b = idx / hid, j = idx - b * hid;
+  const float *p = pre + (size_t)b * 4 * hid + j;
+  const float gi = 1.f / (1.f + expf(-p[0])), gf = 1.f / (1.f + expf(-p[hid])), go = 1.f / (1.f + expf(-p[2 * hid])),
+              gu = tanhf(p[3 * hid]);
+  const float cn = gf * c_prev[idx] + gi * gu;
+  float *a = act + (size_t)b * 4 * hid + j;
+  a[0] = gi;
+  a[hid] = gf;
+  a[2 * hid] = go;
+  a[3 * hid] = gu;
+  c[idx] = cn;
+  h[idx] = go * tanhf(cn);
+}
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float *act, const float *c_prev, const float *c,
+                                                            const float *dh, const float *dc, int n, int hid, float *dpre,
+                                                            float *dc_prev) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int b = idx / hid, j = idx - b * hid;
+  const float *a = act + (size_t)b * 4 * hid + j;
+  const float gi = a[0], gf = a[hid], go = a[2 * hid], gu = a[3 * hid];
+  const float tc = tanhf(c[idx]);
+  const float gh = dh ? dh[idx] : 0.f;
+  const float dcn = (dc ? dc[idx] : 0.f) + gh * go * (1.f - tc * tc);
+  float *d = dpre + (size_t)b * 4 * hid + j;
+  d[0] = dcn * gu * gi * (1.f - gi);
+  d[hid] = dcn * c_prev[idx] * gf * (1.f - gf);
+  d[2 * hid] = gh * tc * go * (1.f - go);
+  d[3 * hid] = dcn * gi * (1.f - gu * gu);
+  dc_prev[idx] = dcn * gf;
+}
+
 // The same reduction, ADDED to the filter's gradient in the reference's own layout (the gradient
 // bucket): [3,3,cin_w,Cout], or [3,3,Cout,cin_w] with the taps flipped for a transposed (dcnn) layer;
 // chan_map sends a packed kernel channel to its filter row (-1: padding).  One writer per element.
@@ -651,4 +690,23 @@ extern "C" int ra_conv3x3_wgrad_acc_f32(const float *x, int Cin, int B, int Hs, 
   if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_acc_f32: cin_w %d", cin_w);
   return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w, transposed ? 1 : 0,
                     stream);
+}
+
+extern "C" int ra_lstm_cell_f32(const float *pre, const float *c_prev, int B, int hid, float *h, float *c, float *act,
+                                void *stream) {
+  if (!pre || !c_prev || !h || !c || !act || B <= 0 || hid <= 0) return fail(RA_E_INVALID, "ra_lstm_cell_f32: bad argument");
+  const int n = B * hid;
+  hipLaunchKernelGGL(train::lstm_cell_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), pre, c_prev, n, hid, h, c,
+                     act);
+  return launch_status("ra_lstm_cell_f32");
+}
+
+extern "C" int ra_lstm_cell_bwd_f32(const float *act, const float *c_prev, const float *c, const float *dh, const float *dc,
+                                    int B, int hid, float *dpre, float *dc_prev, void *stream) {
+  if (!act || !c_prev || !c || !dpre || !dc_prev || B <= 0 || hid <= 0)
+    return fail(RA_E_INVALID, "ra_lstm_cell_bwd_f32: bad argument");
+  const int n = B * hid;
+  hipLaunchKernelGGL(train::lstm_cell_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), act, c_prev, c, dh,
+                     dc, n, hid, dpre, dc_prev);
+  return launch_status("ra_lstm_cell_bwd_f32");
 }

@@ -353,6 +353,30 @@ class PairIoU(torch.autograd.Function):
     return out, None
 
 
+class LSTMCell(torch.autograd.Function):
+  """Pointwise half of nnlib.lstm's cell (nnlib.py:641-646): pre [B,4*hid] in gate order (i, f, o, u)."""
+
+  @staticmethod
+  def forward(ctx, pre, c_prev):
+    pre, c_prev = pre.contiguous(), c_prev.contiguous()
+    B, hid = c_prev.shape
+    h, c, act = torch.empty_like(c_prev), torch.empty_like(c_prev), torch.empty_like(pre)
+    check(rn.lib().ra_lstm_cell_f32(ptr(pre), ptr(c_prev), B, hid, ptr(h), ptr(c), ptr(act), rn.stream_ptr()), 'ra_lstm_cell_f32')
+    ctx.save_for_backward(act, c_prev, c)
+    return h, c
+
+  @staticmethod
+  def backward(ctx, dh, dc):
+    act, c_prev, c = ctx.saved_tensors
+    B, hid = c_prev.shape
+    dpre, dcp = torch.empty_like(act), torch.empty_like(c_prev)
+    dh = None if dh is None else dh.contiguous()
+    dc = None if dc is None else dc.contiguous()
+    check(rn.lib().ra_lstm_cell_bwd_f32(ptr(act), ptr(c_prev), ptr(c), ptr(dh), ptr(dc), B, hid, ptr(dpre), ptr(dcp),
+                                        rn.stream_ptr()), 'ra_lstm_cell_bwd_f32')
+    return dpre, dcp
+
+
 def gaussian_filter(ctr, size, lg_var, L, F):
   """modellib.get_gaussian_filter (modellib.py:581-612), differentiable: ctr, size, lg_var [B]."""
   dev = ctr.device
@@ -491,26 +515,35 @@ class TrainStep(object):
     B, G, hid = feat.shape[0], d['G'], d['hid']
     c = torch.zeros((B, hid), device=feat.device)
     h = torch.zeros((B, hid), device=feat.device)
-    gmap = torch.full((B, G, 1), 1.0 / G, device=feat.device)
-    gate = lambda g, xin, hh: xin @ P['ctrl_lstm_w_x' + g] + hh @ P['ctrl_lstm_w_h' + g] + P['ctrl_lstm_b_' + g]
+    gmap = torch.full((B, 1, G), 1.0 / G, device=feat.device)
+    Wg, bg = self._lstm_weights()
     for it in range(d['iters']):
-      glimpse = (feat * gmap).sum(dim=1)
-      gi, gf, go = torch.sigmoid(gate('i', glimpse, h)), torch.sigmoid(gate('f', glimpse, h)), torch.sigmoid(gate('o', glimpse, h))
-      u = torch.tanh(gate('u', glimpse, h))
-      c = gf * c + gi * u
-      h = go * torch.tanh(c)
+      glimpse = torch.bmm(gmap, feat)[:, 0]                       # sum_g map[g] feat[g, :]
+      pre = torch.addmm(bg, torch.cat([glimpse, h], dim=1), Wg)   # all four gates: one GEMM
+      h, c = LSTMCell.apply(pre, c)
       if it < d['iters'] - 1:
         z = h
         for l in range(d['n_gmlp']):
-          z = z @ P['glimpse_mlp_w_%d' % l] + P['glimpse_mlp_b_%d' % l]
+          z = torch.addmm(P['glimpse_mlp_b_%d' % l], z, P['glimpse_mlp_w_%d' % l])
           z = torch.relu(z) if l < d['n_gmlp'] - 1 else torch.softmax(z, dim=1)
-        gmap = z[:, :, None]
+        gmap = z[:, None, :]
     z = h
     for l in range(d['n_cmlp']):
-      z = z @ P['ctrl_mlp_w_%d' % l] + P['ctrl_mlp_b_%d' % l]
+      z = torch.addmm(P['ctrl_mlp_b_%d' % l], z, P['ctrl_mlp_w_%d' % l])
       if l < d['n_cmlp'] - 1:
         z = torch.relu(z)
     return h, z
+
+  def _lstm_weights(self):
+    """[w_x ; w_h] of the four gates side by side (i, f, o, u) and their biases: built once per step (the
+    weights are shared by all timesteps and glimpses), so a cell is one GEMM + one pointwise kernel."""
+    hit = _PACK.get('lstm')
+    if hit is None:
+      P = self.leaves
+      Wg = torch.cat([torch.cat([P['ctrl_lstm_w_x' + g], P['ctrl_lstm_w_h' + g]], dim=0) for g in 'ifou'], dim=1)
+      bg = torch.cat([P['ctrl_lstm_b_' + g] for g in 'ifou'], dim=0)
+      hit = _PACK['lstm'] = (Wg, bg)
+    return hit
 
   # ------------------------------------------------------------------ forward + loss
   def draw_knobs(self, B, generator=None):
