@@ -516,6 +516,14 @@ int ra_lstm_cell_f32(const float *pre, const float *c_prev, int B, int hid, floa
                      float *act, void *stream);
 int ra_lstm_cell_bwd_f32(const float *act, const float *c_prev, const float *c, const float *dh,
                          const float *dc, int B, int hid, float *dpre, float *dc_prev, void *stream);
+/* modellib.get_gaussian_filter (modellib.py:581-612) and its adjoint for the training graph:
+ *   out[b][l][j] = N(l; mu_j, exp(lg_var[b])),  mu_j = ctr[b] + (size[b] + 1) / NF * (j - (NF - 1) / 2);
+ *   backward: g [B][L][NF] -> dctr, dsize, dlg_var [B] (the bank is recomputed, not stored). */
+int ra_gauss_filter_f32(const float *ctr, const float *size, const float *lg_var, int B, int L, int NF,
+                        float *out, void *stream);
+int ra_gauss_filter_bwd_f32(const float *ctr, const float *size, const float *lg_var, const float *g,
+                            int B, int L, int NF, float *dctr, float *dsize, float *dlg_var,
+                            void *stream);
 int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
 int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
                               int HW, float *out, void *stream);

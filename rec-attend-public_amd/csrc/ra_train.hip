@@ -578,6 +578,47 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float *act, co
   dc_prev[idx] = dcn * gf;
 }
 
+// ---- Gaussian filter bank (modellib.py:581-612): F[b][l][j] = N(l; mu_j, var), mu_j = ctr + (size + 1) / NF * (j - (NF - 1) / 2),
+// var = exp(lg_var); its adjoint reduces over the whole [L, NF] bank of an image: one workgroup per image.
+__global__ __launch_bounds__(256) void gauss_filter_kernel(const float *ctr, const float *size, const float *lg_var, int L,
+                                                           int NF, float *out) {
+  const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= L * NF) return;
+  const int l = e / NF, j = e - l * NF;
+  const float var = expf(lg_var[b]);
+  const float mu = ctr[b] + (size[b] + 1.0f) / (float)NF * ((float)j - 0.5f * (float)(NF - 1));
+  const float dd = (float)l - mu;
+  out[(size_t)b * L * NF + e] = expf(-0.5f * dd * dd / var) / (sqrtf(var) * 2.5066282746310002f);
+}
+__global__ __launch_bounds__(256) void gauss_filter_bwd_kernel(const float *ctr, const float *size, const float *lg_var,
+                                                               const float *g, int L, int NF, float *dctr, float *dsize,
+                                                               float *dlgv) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  const float var = expf(lg_var[b]), c0 = ctr[b], step = (size[b] + 1.0f) / (float)NF;
+  const float norm = 1.0f / (sqrtf(var) * 2.5066282746310002f);
+  float a_ctr = 0.f, a_size = 0.f, a_var = 0.f;
+  for (int e = threadIdx.x; e < L * NF; e += 256) {
+    const int l = e / NF, j = e - l * NF;
+    const float off = (float)j - 0.5f * (float)(NF - 1);
+    const float dd = (float)l - (c0 + step * off);
+    const float f = expf(-0.5f * dd * dd / var) * norm;
+    const float gf = g[(size_t)b * L * NF + e] * f;
+    const float dmu = gf * dd / var;
+    a_ctr += dmu;
+    a_size += dmu * off / (float)NF;
+    a_var += gf * (0.5f * dd * dd / (var * var) - 0.5f / var);
+  }
+  a_ctr = block_sum256(a_ctr, red);
+  a_size = block_sum256(a_size, red);
+  a_var = block_sum256(a_var, red);
+  if (threadIdx.x == 0) {
+    dctr[b] = a_ctr;
+    dsize[b] = a_size;
+    dlgv[b] = a_var * var;
+  }
+}
+
 // The same reduction, ADDED to the filter's gradient in the reference's own layout (the gradient
 // bucket): [3,3,cin_w,Cout], or [3,3,Cout,cin_w] with the taps flipped for a transposed (dcnn) layer;
 // chan_map sends a packed kernel channel to its filter row (-1: padding).  One writer per element.
@@ -709,4 +750,21 @@ extern "C" int ra_lstm_cell_bwd_f32(const float *act, const float *c_prev, const
   hipLaunchKernelGGL(train::lstm_cell_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), act, c_prev, c, dh,
                      dc, n, hid, dpre, dc_prev);
   return launch_status("ra_lstm_cell_bwd_f32");
+}
+
+extern "C" int ra_gauss_filter_f32(const float *ctr, const float *size, const float *lg_var, int B, int L, int NF, float *out,
+                                   void *stream) {
+  if (!ctr || !size || !lg_var || !out || B <= 0 || L <= 0 || NF <= 0) return fail(RA_E_INVALID, "ra_gauss_filter_f32: bad argument");
+  hipLaunchKernelGGL(train::gauss_filter_kernel, dim3(ceil_div(L * NF, 256), B), dim3(256), 0, as_stream(stream), ctr, size,
+                     lg_var, L, NF, out);
+  return launch_status("ra_gauss_filter_f32");
+}
+
+extern "C" int ra_gauss_filter_bwd_f32(const float *ctr, const float *size, const float *lg_var, const float *g, int B, int L,
+                                       int NF, float *dctr, float *dsize, float *dlg_var, void *stream) {
+  if (!ctr || !size || !lg_var || !g || !dctr || !dsize || !dlg_var || B <= 0 || L <= 0 || NF <= 0)
+    return fail(RA_E_INVALID, "ra_gauss_filter_bwd_f32: bad argument");
+  hipLaunchKernelGGL(train::gauss_filter_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), ctr, size, lg_var, g, L, NF, dctr,
+                     dsize, dlg_var);
+  return launch_status("ra_gauss_filter_bwd_f32");
 }

@@ -377,15 +377,34 @@ class LSTMCell(torch.autograd.Function):
     return dpre, dcp
 
 
+class GaussFilter(torch.autograd.Function):
+  """modellib.get_gaussian_filter (modellib.py:581-612) with its adjoint: ctr, size, lg_var [B] -> [B,L,F]."""
+
+  @staticmethod
+  def forward(ctx, ctr, size, lg_var, L, F):
+    ctr, size, lg_var = ctr.contiguous(), size.contiguous(), lg_var.contiguous()
+    B = ctr.shape[0]
+    out = torch.empty((B, L, F), dtype=torch.float32, device=ctr.device)
+    check(rn.lib().ra_gauss_filter_f32(ptr(ctr), ptr(size), ptr(lg_var), B, int(L), int(F), ptr(out), rn.stream_ptr()),
+          'ra_gauss_filter_f32')
+    ctx.save_for_backward(ctr, size, lg_var)
+    ctx.dims = (int(L), int(F))
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    ctr, size, lg_var = ctx.saved_tensors
+    L, F = ctx.dims
+    B = ctr.shape[0]
+    dc, ds, dv = torch.empty_like(ctr), torch.empty_like(ctr), torch.empty_like(ctr)
+    check(rn.lib().ra_gauss_filter_bwd_f32(ptr(ctr), ptr(size), ptr(lg_var), ptr(g.contiguous()), B, L, F, ptr(dc), ptr(ds),
+                                           ptr(dv), rn.stream_ptr()), 'ra_gauss_filter_bwd_f32')
+    return dc, ds, dv, None, None
+
+
 def gaussian_filter(ctr, size, lg_var, L, F):
   """modellib.get_gaussian_filter (modellib.py:581-612), differentiable: ctr, size, lg_var [B]."""
-  dev = ctr.device
-  j = torch.arange(F, dtype=torch.float32, device=dev)
-  mu = ctr[:, None] + ((size[:, None] + 1.0) / F) * (j[None, :] - (F - 1) / 2.0)
-  l = torch.arange(L, dtype=torch.float32, device=dev)
-  var = torch.exp(lg_var)[:, None, None]
-  dd = l[None, :, None] - mu[:, None, :]
-  return torch.exp(-0.5 * dd * dd / var) / (torch.sqrt(var) * math.sqrt(2 * math.pi))
+  return GaussFilter.apply(ctr, size, lg_var, L, F)
 
 
 def extract(x, fy, fx):

@@ -413,3 +413,46 @@ def test_graphed_step_equals_eager_step(cuda):
   assert np.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6), (res[True][0], res[False][0])
   for k, v in res[False][1].items():
     assert np.allclose(res[True][1][k], v, rtol=1e-4, atol=1e-6), k
+
+
+def test_fused_pointwise_kernels_vs_torch_autograd(cuda):
+  """GaussFilter and LSTMCell (one kernel forward, one backward) against the same formulas under
+  torch autograd in float64."""
+  import math
+  import ra_train
+  g = torch.Generator().manual_seed(4)
+  B, L, F = 3, 96, 16
+  ctr = (torch.rand(B, generator=g) * L).double().requires_grad_(True)
+  size = (10 + 40 * torch.rand(B, generator=g)).double().requires_grad_(True)
+  lgv = (torch.randn(B, generator=g) * 0.5).double().requires_grad_(True)
+  j = torch.arange(F, dtype=torch.float64)
+  mu = ctr[:, None] + ((size[:, None] + 1.0) / F) * (j[None, :] - (F - 1) / 2.0)
+  dd = torch.arange(L, dtype=torch.float64)[None, :, None] - mu[:, None, :]
+  var = torch.exp(lgv)[:, None, None]
+  ref = torch.exp(-0.5 * dd * dd / var) / (torch.sqrt(var) * math.sqrt(2 * math.pi))
+  wgt = torch.randn(B, L, F, generator=g).double()
+  (ref * wgt).sum().backward()
+  c32, s32, v32 = [t.detach().float().to(cuda).requires_grad_(True) for t in (ctr, size, lgv)]
+  out = ra_train.gaussian_filter(c32, s32, v32, L, F)
+  (out * wgt.float().to(cuda)).sum().backward()
+  assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 1e-6
+  for a, b in ((c32, ctr), (s32, size), (v32, lgv)):
+    assert np.abs(a.grad.cpu().numpy() - b.grad.numpy()).max() < 2e-4 * max(1.0, np.abs(b.grad.numpy()).max())
+  hid = 32
+  pre = torch.randn(B, 4 * hid, generator=g).double().requires_grad_(True)
+  c0 = torch.randn(B, hid, generator=g).double().requires_grad_(True)
+  gi, gf, go, gu = [pre[:, k * hid:(k + 1) * hid] for k in range(4)]
+  c1 = torch.sigmoid(gf) * c0 + torch.sigmoid(gi) * torch.tanh(gu)
+  h1 = torch.sigmoid(go) * torch.tanh(c1)
+  wh, wc = torch.randn(B, hid, generator=g).double(), torch.randn(B, hid, generator=g).double()
+  ((h1 * wh).sum() + (c1 * wc).sum()).backward()
+  p32, c32 = [t.detach().float().to(cuda).requires_grad_(True) for t in (pre, c0)]
+  h, c = ra_train.LSTMCell.apply(p32, c32)
+  ((h * wh.float().to(cuda)).sum() + (c * wc.float().to(cuda)).sum()).backward()
+  assert np.abs(h.detach().cpu().numpy() - h1.detach().numpy()).max() < 1e-6
+  assert np.abs(p32.grad.cpu().numpy() - pre.grad.numpy()).max() < 1e-5
+  assert np.abs(c32.grad.cpu().numpy() - c0.grad.numpy()).max() < 1e-5
+  p32.grad = None
+  h, c = ra_train.LSTMCell.apply(p32, c32)  # c's gradient absent (the last glimpse of a timestep)
+  (h * wh.float().to(cuda)).sum().backward()
+  assert np.isfinite(p32.grad.cpu().numpy()).all()
