@@ -896,7 +896,16 @@ __global__ __launch_bounds__(256) void wgrad_final_acc_kernel(const float *part,
 }  // namespace ra
 
 namespace {
-inline int wgrad_grid_x(int ntiles) { return ntiles < 256 ? ntiles : 256; }
+inline int wgrad_grid_x(int ntiles) {
+  // persistent workgroups: 4 per CU (38 KB of LDS each) hide the un-prefetched tile staging; 256 left 4 waves per CU
+  static int cap = 0;
+  if (!cap) {
+    const char *e = getenv("RA_WGRAD_WGS");
+    cap = e ? atoi(e) : 1024;
+    if (cap < 1) cap = 1;
+  }
+  return ntiles < cap ? ntiles : cap;
+}
 }  // namespace
 
 extern "C" size_t ra_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int B, int H, int W) {
