@@ -217,6 +217,7 @@ class ConvBNActPool(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, b, gamma, beta, meta):
+    ctx.set_materialize_grads(False)  # nothing differentiates mean / var: no zero tensors for their gradients
     dev = x.device
     x = x.contiguous()
     B, Hs, Ws, Cx = x.shape
@@ -252,6 +253,8 @@ class ConvBNActPool(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, dy, _dm, _dv):
+    if dy is None:
+      return None, None, None, None, None, None
     x, w, u, mean, var, gamma, beta = ctx.saved_tensors
     meta, cmap = ctx.meta, ctx.cmap
     dev = x.device
@@ -358,6 +361,7 @@ class LSTMCell(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, pre, c_prev):
+    ctx.set_materialize_grads(False)  # the last cell of a timestep has no gradient in c: a null pointer, not zeros
     pre, c_prev = pre.contiguous(), c_prev.contiguous()
     B, hid = c_prev.shape
     h, c, act = torch.empty_like(c_prev), torch.empty_like(c_prev), torch.empty_like(pre)
@@ -367,6 +371,8 @@ class LSTMCell(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, dh, dc):
+    if dh is None and dc is None:
+      return None, None
     act, c_prev, c = ctx.saved_tensors
     B, hid = c_prev.shape
     dpre, dcp = torch.empty_like(act), torch.empty_like(c_prev)
