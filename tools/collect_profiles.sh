@@ -30,5 +30,11 @@ cp $(find $OUT/trace4 -name '*kernel_stats.csv' | head -1) $OUT/r02_bench_kernel
 # keep the merge small: the raw traces are not needed
 rm -rf $OUT/trace $OUT/trace4 $OUT/pmc_*_f $OUT/pmc_*_w $OUT/pmc_sq
 python bench.py --attn-b32 > $OUT/r02_bench_n1.json 2> $OUT/bench.err
-python bench.py --train --steps 3 --warmup 1 > $OUT/r02_train_n1.json 2>> $OUT/bench.err
+python bench.py --train --steps 4 --warmup 3 > $OUT/r02_train_n1.json 2>> $OUT/bench.err
+$R --kernel-trace --stats -d $OUT/trace_train -o t -- python bench.py --train --steps 4 --warmup 2 > $OUT/trace_train.json 2> $OUT/trace_train.log
+cp $(find $OUT/trace_train -name '*kernel_stats.csv' | head -1) $OUT/r02_train_kernel_stats.csv
+python tools/kernel_families.py $OUT/r02_train_kernel_stats.csv 6 > $OUT/r02_train_kernel_families.txt
+rm -rf $OUT/trace_train
+python bench.py --config cfg3 > $OUT/r02_bench_cfg3.json 2>> $OUT/bench.err
+python bench.py --config cfg5 > $OUT/r02_bench_cfg5.json 2>> $OUT/bench.err
 ls -la $OUT
