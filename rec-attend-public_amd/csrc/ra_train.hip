@@ -655,7 +655,11 @@ namespace train {
 
 constexpr int WTH = 8, WTW = 32, WLW = WTW + 2, WLH = WTH + 2;
 
-template <int NT>  // output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
+// PACK = 0: the M rows of an MFMA are the 16 input channels of the slice, one accumulator tile per tap
+// (9 + bias).  PACK = Cin (4 or 8): the M rows are (tap, channel) pairs, 9 * Cin of them in
+// ceil(9 * Cin / 16) tiles — 3 instead of 9 k-step MFMAs per pixel quad for Cin = 4 (where 12 of the 16
+// channel rows were zero), 5 for Cin = 8; a lane reads its row's pixel through a per-tile LDS offset.
+template <int NT, int PACK = 0>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
                                                     int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
                                                     int ntiles, float *part) {
@@ -668,11 +672,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
   const int co0 = blockIdx.z * 16 * NT;       // first output channel of this workgroup's slice
   const int c0 = blockIdx.y * 16;             // first input channel of this workgroup's slice
   const int cn = Cin - c0 < 16 ? Cin - c0 : 16;  // real channels in the slice
-  f32x4 acc[10][NT];
+  constexpr int MT = PACK ? (9 * PACK + 15) / 16 : 9;  // accumulator tiles of the filter taps; tile MT = the bias
+  f32x4 acc[MT + 1][NT];
 #pragma unroll
-  for (int t = 0; t < 10; ++t)
+  for (int t = 0; t <= MT; ++t)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // PACK: LDS offset (floats, relative to the lane's pixel) of row m of tile t: its tap's pixel shift + its
+  // channel; padding rows read channel 15 of the pixel, which is staged as zero (cn <= 8)
+  int aoff[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    if constexpr (PACK != 0) {
+      const int R = 16 * t + m, tap = R / PACK, ci = R - tap * PACK;
+      aoff[t] = tap < 9 ? ((tap / 3) * WLW + tap % 3) * 16 + ci : 15;
+    } else {
+      aoff[t] = ((t / 3) * WLW + t % 3) * 16 + m;
+    }
+  }
   const int per = tiles_x * tiles_y;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / per, tr = tile - b * per;
@@ -713,30 +730,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
 #pragma unroll
         for (int n = 0; n < NT; ++n) bv[n] = tu[(row * WTW + col) * CP + 16 * n + m];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const float av = tx[((row + tap / 3) * WLW + col + tap % 3) * 16 + m];
+        for (int t = 0; t < MT; ++t) {
+          const float av = tx[(row * WLW + col) * 16 + aoff[t]];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[tap][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[tap][n], 0, 0, 0);
+          for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[t][n], 0, 0, 0);
         }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[9][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bv[n], acc[9][n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) acc[MT][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bv[n], acc[MT][n], 0, 0, 0);
       }
     }
   }
   // sum the 4 waves (K split) through LDS in wave order, then one partial per workgroup:
   // part[(blockIdx.y * gridDim.x + blockIdx.x)][10][16][CP]; D layout: rows 4*(lane>>4)+r, column lane&15
   __syncthreads();
-  float *red = lds;  // 10 * 16 * CP floats <= the staging area
+  float *red = lds;  // 10 * 16 * CP floats <= the staging area: [tap (9 = bias)][channel of the slice][cout]
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int t = 0; t < 10; ++t)
+      for (int t = 0; t <= MT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float *d = red + (t * 16 + 4 * ksub + r) * CP + 16 * n + m;
-            *d = (w == 0 ? 0.f : *d) + acc[t][n][r];
+            int slot = t * 16 + 4 * ksub + r;  // D row 4 * ksub + r of tile t
+            if constexpr (PACK != 0) {
+              if (t < MT) {
+                const int R = 16 * t + 4 * ksub + r, tap = R / PACK;
+                slot = tap < 9 ? tap * 16 + (R - tap * PACK) : -1;
+              } else {
+                slot = 9 * 16 + 4 * ksub + r;
+              }
+            }
+            if (slot >= 0) {
+              float *d = red + slot * CP + 16 * n + m;
+              *d = (w == 0 ? 0.f : *d) + acc[t][n][r];
+            }
           }
     }
     __syncthreads();
@@ -937,21 +965,31 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
   const size_t lds_red = (size_t)10 * 16 * per * sizeof(float);
   const size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
   hipStream_t st = as_stream(stream);
-#define RA_WGRAD(NT)                                                                                              \
+#define RA_WGRAD(NT, PACK)                                                                                        \
   {                                                                                                               \
     static bool attr = false;                                                                                     \
     if (!attr) {                                                                                                  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<NT>),                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<NT, PACK>),                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);                         \
       attr = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL(wgrad_kernel<NT>, dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, H, W, \
-                       Cout, tiles_x, tiles_y, ntiles, ws);                                                      \
+    hipLaunchKernelGGL((wgrad_kernel<NT, PACK>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, H, \
+                       W, Cout, tiles_x, tiles_y, ntiles, ws);                                                   \
   }
+  static int pack_ok = -1;  // RA_WGRAD_PACK=0: tuning aid, channel rows for every Cin
+  if (pack_ok < 0) {
+    const char *e = getenv("RA_WGRAD_PACK");
+    pack_ok = e ? atoi(e) : 1;
+  }
+  const int pack = (pack_ok && (Cin == 4 || Cin == 8)) ? Cin : 0;
   switch (per / 16) {
-    case 1: RA_WGRAD(1) break;
-    case 2: RA_WGRAD(2) break;
-    default: RA_WGRAD(4) break;
+    case 1:
+      if (pack == 4) RA_WGRAD(1, 4) else if (pack == 8) RA_WGRAD(1, 8) else RA_WGRAD(1, 0)
+      break;
+    case 2:
+      if (pack == 4) RA_WGRAD(2, 4) else if (pack == 8) RA_WGRAD(2, 8) else RA_WGRAD(2, 0)
+      break;
+    default: RA_WGRAD(4, 0) break;
   }
 #undef RA_WGRAD
   const int total = 9 * Cin * Cout + Cout;
