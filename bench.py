@@ -309,6 +309,8 @@ def main():
                        'default: 4 at cfg2, 8 at cfg3 over its two stages, 2 at cfg5)')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
   ap.add_argument('--no-fuse-score', action='store_true', help='tuning aid: score MLP as its own launch')
+  ap.add_argument('--host-output', action='store_true',
+                  help='also copy y_out + s_out of every batch to pinned host memory (PCIe inclusive; not the headline value)')
   ap.add_argument('--host-input', action='store_true',
                   help='hand x over as a pinned HOST buffer each step (PCIe-inclusive rate; never the headline value)')
   ap.add_argument('--pmc-group', type=int, default=0, metavar='REPS',
@@ -400,7 +402,7 @@ def main():
   def step():
     if pipe.full():
       pipe.retire()
-    pipe.submit(['y_out', 's_out'], feed)
+    pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output)
 
   for _ in range(max(args.warmup, pipe.depth)):  # every slot allocates + captures its graph
     step()
@@ -425,7 +427,8 @@ def main():
                  'arch': 'cvppp', 'H': S, 'W': S, 'T': T, 'batch_per_gpu': B,
                  'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no collective' % world,
                  'hip_graph': bool(eng.use_graph), 'batches_in_flight': pipe.depth,
-                 'lone_batch_ms': lone_ms, 'lone_batch_value': B * T / (lone_ms * 1e-3), 'input': 'host (PCIe inclusive)' if args.host_input else 'resident in HBM'},
+                 'lone_batch_ms': lone_ms, 'lone_batch_value': B * T / (lone_ms * 1e-3), 'input': 'host (PCIe inclusive)' if args.host_input else 'resident in HBM',
+                 'output': 'y_out + s_out copied to pinned host memory (PCIe inclusive)' if args.host_output else 'left in HBM'},
   }
 
   if rank == 0:

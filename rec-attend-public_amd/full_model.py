@@ -394,8 +394,11 @@ class DecodePipeline(object):
     """No room for another batch (of B images; default: a batch that takes one slot)."""
     return len(self.free) < (1 if B is None else self.parts(B))
 
-  def submit(self, outputs, feed):
-    """Start decoding one batch (eval outputs only); returns immediately."""
+  def submit(self, outputs, feed, to_host=False):
+    """Start decoding one batch (eval outputs only); returns immediately.  to_host: the outputs are also
+    copied to pinned host memory on the slot's stream (asynchronously, under the other batches' compute —
+    y_out of a cfg2 batch is 134 MB, 2.7 ms of PCIe); collect() then returns NumPy arrays without a
+    further copy."""
     if not torch.cuda.is_available():
       raise RecAttendError('the decode loop needs an MI355X (HIP device); no CPU fallback')
     single = isinstance(outputs, str)
@@ -427,10 +430,16 @@ class DecodePipeline(object):
         eng.forward(cut(feed['x'], lo, hi), d_in=cut(feed.get('d_in'), lo, hi), y_in=cut(feed.get('y_in'), lo, hi),
                     y_gt=cut(feed.get('y_gt'), lo, hi) if self.model.box_model else None,
                     noise=None if noise is None else noise[:, lo:hi], want_box='attn_box' in names)
+        host = None
+        if to_host:
+          host = []
+          for n in names:
+            r = self.model._fetch(n, eng)
+            host.append(torch.empty(r.shape, dtype=r.dtype, pin_memory=True).copy_(r, non_blocking=True))
         ev = torch.cuda.Event()
         ev.record(stream)
       used.append(k)
-      events.append(ev)
+      events.append((ev, host))
     self.pending.append((used, names, single, events))
 
   def collect(self, as_numpy=False):
@@ -439,15 +448,19 @@ class DecodePipeline(object):
       raise RecAttendError('collect() with no batch in flight')
     used, names, single, events = self.pending.pop(0)
     parts = []
-    for k, ev in zip(used, events):
+    for k, (ev, host) in zip(used, events):
       eng, stream = self.slots[k]
       ev.synchronize()
       eng.check_status()
-      with torch.cuda.stream(stream):
-        res = [self.model._fetch(n, eng) for n in names]
-        if as_numpy:
-          res = [r.detach().cpu().numpy() for r in res]
-      stream.synchronize()
+      if host is not None:  # submit(to_host=True): already in pinned host memory
+        res = [h.numpy() for h in host]
+        as_numpy = True
+      else:
+        with torch.cuda.stream(stream):
+          res = [self.model._fetch(n, eng) for n in names]
+          if as_numpy:
+            res = [r.detach().cpu().numpy() for r in res]
+        stream.synchronize()
       parts.append(res)
       self.free.append(k)
     if len(parts) == 1:
@@ -463,7 +476,7 @@ class DecodePipeline(object):
     if not self.pending:
       raise RecAttendError('retire() with no batch in flight')
     used, _, _, events = self.pending.pop(0)
-    for ev in events:
+    for ev, _ in events:
       ev.synchronize()
     self.free.extend(used)
 

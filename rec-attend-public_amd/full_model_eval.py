@@ -92,8 +92,8 @@ def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, anal
         results = {'y_out': y_bin, 'y_gt': gt, 's_out': s_hard, 's_gt': sg}
         for n in names:
           acc[th][n].append(analysis.create_analyzer(n)(results).cpu().numpy())
-    ys.append(y_dev.cpu().numpy())
-    ss.append(s_dev.cpu().numpy())
+    ys.append(y_dev if isinstance(y_dev, np.ndarray) else y_dev.cpu().numpy())  # to_host: already host arrays
+    ss.append(s_dev if isinstance(s_dev, np.ndarray) else s_dev.cpu().numpy())
 
   # batches are independent: keep several in flight, each on its own HIP stream, so that the
   # latency-bound tail of one decodes under the controller CNN of the others (DecodePipeline)
@@ -104,7 +104,7 @@ def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, anal
     feed['phase_train'] = False
     if pipe.full():
       consume(*(spans.pop(0) + tuple(pipe.collect())))
-    pipe.submit(['y_out', 's_out'], feed)
+    pipe.submit(['y_out', 's_out'], feed, to_host=not analyze)
     spans.append((b0, b1))
   while len(pipe):
     consume(*(spans.pop(0) + tuple(pipe.collect())))

@@ -421,3 +421,24 @@ def test_decode_pipeline_controller_policy(cuda):
   small.submit('y_out', feed)
   assert np.array_equal(small.collect(as_numpy=True), split[0])
   assert 'ctrl_ws' in small.slots[0][0].subs[0]
+
+
+def test_decode_pipeline_to_host(cuda):
+  """submit(to_host=True): outputs arrive as NumPy arrays in pinned host memory, equal to model.run's."""
+  import full_model
+  opt = ora.make_opt('cvppp', 64, 64, 3)
+  m = full_model.get_model(opt).load_weights(ora.random_params(opt, 2))
+  rng = np.random.RandomState(8)
+  feeds = [{'x': rng.rand(2, 64, 64, 3).astype(np.float32), 'phase_train': False} for _ in range(3)]
+  lone = [m.run(['y_out', 's_out'], f, as_numpy=True) for f in feeds]
+  pipe = m.pipeline(2)
+  got = []
+  for f in feeds:
+    if pipe.full():
+      got.append(pipe.collect())
+    pipe.submit(['y_out', 's_out'], f, to_host=True)
+  while len(pipe):
+    got.append(pipe.collect())
+  for a, b in zip(got, lone):
+    for u, v in zip(a, b):
+      assert isinstance(u, np.ndarray) and np.array_equal(u, v)

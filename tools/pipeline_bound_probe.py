@@ -36,7 +36,35 @@ def both(e):
   for tt in range(T):
     e._launch_tail(sb, tt, False, e._launch_encoder(sb, max(tt, 1)))
 
-for name, fn in (('controller CNN only', enc_only), ('tail only', tail_only), ('both', both)):
+import ra_ops as ops
+def both_minus(skip):
+  """the whole timestep with one kind of tail launch made a no-op (results are garbage; timing only)"""
+  def run(e):
+    saved = {}
+    names = {'controller': ['controller', 'controller_split'], 'attn': ['extract_direct', 'paste_direct', 'paste_score_direct'],
+             'patch': ['conv3x3', 'conv_pair']}[skip]
+    if skip == 'patch':  # only the patch-sized convs: wrap and filter on the input size
+      o3, op = ops.conv3x3, ops.conv_pair
+      ops.conv3x3 = lambda x, *a, **k: (k.get('out') if x.shape[1] <= 48 and k.get('out') is not None else o3(x, *a, **k))
+      ops.conv_pair = lambda x, *a, **k: (k.get('out') if x.shape[1] <= 48 and k.get('out') is not None else op(x, *a, **k))
+      try:
+        both(e)
+      finally:
+        ops.conv3x3, ops.conv_pair = o3, op
+      return
+    for n in names:
+      saved[n] = getattr(ops, n)
+      setattr(ops, n, lambda *a, **k: None)
+    try:
+      both(e)
+    finally:
+      for n, f in saved.items():
+        setattr(ops, n, f)
+  return run
+
+for name, fn in (('controller CNN only', enc_only), ('tail only', tail_only), ('both', both),
+                 ('both - controller', both_minus('controller')), ('both - extract/paste', both_minus('attn')),
+                 ('both - patch convs', both_minus('patch'))):
   graphs = [capture(lambda e=e: fn(e)) for e in engs]
   for n in (1, 2, 4):
     streams = [torch.cuda.Stream() for _ in range(n)]
