@@ -1,0 +1,244 @@
+// K1w — 3x3 convolution as Winograd F(2x2, 3x3) on the f32 MFMA, for the mid-resolution layers of the
+// controller CNN (nnlib.cnn: conv3x3 SAME + BN + ReLU + max-pool, nnlib.py:229-253).
+//
+// Why: the decode pipeline is bound by the controller CNN, the CNN by the f32 matrix core (157 TF/s;
+// FP32 VALU time adds to it).  F(2x2, 3x3) does 16 multiplies per 2x2 outputs and channel pair where the
+// direct form does 36: 2.25x fewer MFMAs, paid with adds on the VALU (input transform 8 per MFMA
+// group, output transform spread over all lanes).  Exact-arithmetic identity; in float32 the result
+// differs from the direct kernel by summation order and the 0.5 factors of G (~1e-6 relative).
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        per 2x2 output tile and output channel
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// Work split (the round-1 cut kept all 16 transformed filters per wave and ran one wave per SIMD with
+// 140 KB of LDS): a workgroup owns a 16x16 output tile = 64 Winograd tiles = 4 MFMA row blocks, and
+// 32 output channels; WAVE p owns ROW p of the 4x4 transform domain:
+//   * its B operands U[p][q][ci][co] (q = 0..3) stay in registers for the whole launch (64 VGPRs at Cin = 32);
+//   * per row block and k-step it reads 2 of the 4 patch rows from LDS (8 ds_read_b32), forms the 4
+//     transformed values V[p][q] (8 adds) and issues 8 MFMAs (4 q x 2 cout blocks);
+//   * it applies the q half of A^T in registers (T[p][j], 2 values from 4) and hands T to LDS;
+//   * after a barrier all 256 threads finish the p half of A^T for (tile, cout) pairs, apply the folded
+//     BatchNorm scale / shift, ReLU and the 2x2 max-pool (one Winograd tile IS one pooling window)
+//     and store channel-contiguous.
+// LDS: 18x18 staged pixels x (Cin + 2) floats (the +2 makes the 16 tiles of a row block hit 16
+// different banks) + 18 KB exchange = 62 KB at Cin = 32: two workgroups per CU.
+#include "ra_common.h"
+
+namespace ra {
+namespace wino {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TS = 16;       // output tile side
+constexpr int WS = TS + 2;   // staged window side
+constexpr int TEX = 36;      // exchange stride per tile (floats): 16 * ksub banks apart
+
+struct WArgs {
+  const float *x, *wp, *scale, *shift;
+  float *y;
+  int B, H, W, Cout, relu;
+  int bytes_x;
+};
+
+template <int CIN, int POOL>
+__global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int KK = CIN / 4, S = CIN + 2, C4 = CIN / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tin = lds;                  // [WS][WS][S]
+  float *tex = lds + WS * WS * S;    // [4 p][2 j][16 tiles][TEX]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, ksub = lane >> 4;
+  const int slice = blockIdx.y, NBT = a.Cout / 16;
+
+  // this wave's transformed filters, q = 0..3, all k-steps, 2 blocks of 16 output channels
+  float bw[4][KK][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        bw[q][kk][nb] = a.wp[((size_t)((p * 4 + q) * KK + kk) * NBT + 2 * slice + nb) * 64 + lane];
+
+  // rows of the 4x4 patch that row p of B^T combines: r_j = d[ra][j] + sg * d[rb][j]
+  const int ra = (p == 0) ? 0 : (p == 2) ? 2 : 1;
+  const int rb = (p == 0) ? 2 : (p == 1) ? 2 : (p == 2) ? 1 : 3;
+  const float sg = (p == 1) ? 1.f : -1.f;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
+  const int per = tiles_x * tiles_y;
+  // epilogue constants of this thread's two (tile, cout) pairs per row block: cout = tid % 32
+  const int eco = tid & 31;
+  const float sc = a.scale[32 * slice + eco], sh = a.shift[32 * slice + eco];
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  const int Ho = a.H / POOL, Wo = a.W / POOL;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / per, trem = tile - b * per;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int oy = ty * TS - 1, ox = tx * TS - 1;
+    __syncthreads();  // the previous tile's reads of tin / tex are complete
+    for (int e = tid; e < WS * WS * C4; e += 256) {
+      const int c4 = e % C4, pix = e / C4;
+      const int r = pix / WS, c = pix - r * WS;
+      const int Y = oy + r, X = ox + c;
+      const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+      const int off = ok ? (((b * a.H + Y) * a.W + X) * CIN + 4 * c4) * 4 : 0x7fffffff;
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      float *d = tin + pix * S + 4 * c4;
+      *reinterpret_cast<f32x2 *>(d) = f32x2{v.x, v.y};
+      *reinterpret_cast<f32x2 *>(d + 2) = f32x2{v.z, v.w};
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int mblk = 0; mblk < 4; ++mblk) {
+      // lane m's Winograd tile of this row block and its patch origin in the staged window
+      const int tyi = 2 * mblk + (m >> 3), txi = m & 7;
+      const float *pa = tin + ((2 * tyi + ra) * WS + 2 * txi) * S + ksub;
+      const float *pb = tin + ((2 * tyi + rb) * WS + 2 * txi) * S + ksub;
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[q][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = pa[j * S + 4 * kk] + sg * pb[j * S + 4 * kk];
+        const float v[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[q][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[q][kk][nb], acc[q][nb], 0, 0, 0);
+      }
+      // q half of A^T: T[p][0] = M0 + M1 + M2, T[p][1] = M1 - M2 - M3; D rows = tiles 4 * ksub + r, col = cout
+      if (mblk) __syncthreads();  // the previous row block's exchange has been consumed
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const f32x4 t0 = acc[0][nb] + acc[1][nb] + acc[2][nb];
+        const f32x4 t1 = acc[1][nb] - acc[2][nb] - acc[3][nb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          tex[((p * 2 + 0) * 16 + 4 * ksub + r) * TEX + 16 * nb + m] = t0[r];
+          tex[((p * 2 + 1) * 16 + 4 * ksub + r) * TEX + 16 * nb + m] = t1[r];
+        }
+      }
+      __syncthreads();
+      // p half of A^T + BN + ReLU + pool for (tile, cout) pairs: 512 per row block, 2 per thread
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int tl = (tid >> 5) + 8 * k;  // tile 0..15 of the row block
+        float T[4][2];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) T[pp][j] = tex[((pp * 2 + j) * 16 + tl) * TEX + eco];
+        float yv[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          yv[0][j] = fmaxf((T[0][j] + T[1][j] + T[2][j]) * sc + sh, lo);
+          yv[1][j] = fmaxf((T[1][j] - T[2][j] - T[3][j]) * sc + sh, lo);
+        }
+        const int oty = ty * 8 + 2 * mblk + (tl >> 3), otx = tx * 8 + (tl & 7);  // Winograd tile coordinates in the image
+        if constexpr (POOL == 2) {
+          const float best = fmaxf(fmaxf(yv[0][0], yv[0][1]), fmaxf(yv[1][0], yv[1][1]));
+          a.y[((size_t)(b * Ho + oty) * Wo + otx) * a.Cout + 32 * slice + eco] = best;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              a.y[((size_t)(b * Ho + 2 * oty + i) * Wo + 2 * otx + j) * a.Cout + 32 * slice + eco] = yv[i][j];
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, int POOL>
+int launch(const WArgs &a, hipStream_t st) {
+  auto kern = conv_wino_mfma<CIN, POOL>;
+  constexpr size_t lds = (size_t)(WS * WS * (CIN + 2) + 8 * 16 * TEX) * sizeof(float);
+  static bool attr = false;
+  static int cap = 0;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    hipDeviceProp_t prop;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    cap = nb * cus;
+    attr = true;
+  }
+  const int tiles_x = a.W / TS, tiles_y = a.H / TS, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / 32;
+  int gx = cap / slices;
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  return launch_status("ra_conv_wino_f32");
+}
+
+}  // namespace wino
+}  // namespace ra
+
+using namespace ra;
+
+extern "C" int ra_conv_wino_supported(int Cin, int Cout, int pool, int H, int W) {
+  return (Cin == 16 || Cin == 32) && Cout > 0 && Cout % 32 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
+         H % wino::TS == 0 && W % wino::TS == 0;
+}
+
+extern "C" size_t ra_conv_wino_packed_floats(int Cin, int Cout) {
+  if (!(Cin == 16 || Cin == 32) || Cout <= 0 || Cout % 32) return 0;
+  return (size_t)16 * Cin * Cout;
+}
+
+// w: the reference's [3,3,Cin,Cout] filter (host).  out[(((p*4+q)*KK + kk)*NBT + nb)*64 + lane] =
+// (G g G^T)[p][q] of input channel 4*kk + lane/16 and output channel 16*nb + lane%16: the B operand of
+// one MFMA, one coalesced 256-byte load per wave.
+extern "C" int ra_conv_wino_pack_weights(const float *w, int Cin, int Cout, float *out) {
+  if (!w || !out || !ra_conv_wino_packed_floats(Cin, Cout)) return fail(RA_E_SHAPE, "ra_conv_wino_pack_weights: Cin %d Cout %d", Cin, Cout);
+  static const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  const int KK = Cin / 4, NBT = Cout / 16;
+  for (int p = 0; p < 4; ++p)
+    for (int q = 0; q < 4; ++q)
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int co = 0; co < Cout; ++co) {
+          double u = 0.0;
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) u += (double)G[p][ky] * (double)G[q][kx] * (double)w[((size_t)(ky * 3 + kx) * Cin + ci) * Cout + co];
+          const int kk = ci / 4, ks = ci % 4, nb = co / 16, n = co % 16;
+          out[((size_t)((p * 4 + q) * KK + kk) * NBT + nb) * 64 + ks * 16 + n] = (float)u;
+        }
+  return 0;
+}
+
+extern "C" int ra_conv_wino_f32(const float *x, int B, int H, int W, int Cin, const float *wpacked, const float *scale,
+                                const float *shift, int Cout, int relu, int pool, float *y, void *stream) {
+  if (!x || !wpacked || !scale || !shift || !y || B <= 0) return fail(RA_E_INVALID, "ra_conv_wino_f32: bad argument");
+  if (!ra_conv_wino_supported(Cin, Cout, pool, H, W))
+    return fail(RA_E_SHAPE, "ra_conv_wino_f32: Cin=%d Cout=%d pool=%d %dx%d", Cin, Cout, pool, H, W);
+  const size_t bytes = (size_t)B * H * W * Cin * sizeof(float);
+  if (bytes >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_wino_f32: input exceeds 2 GiB");
+  wino::WArgs a;
+  a.x = x;
+  a.wp = wpacked;
+  a.scale = scale;
+  a.shift = shift;
+  a.y = y;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.Cout = Cout;
+  a.relu = relu;
+  a.bytes_x = (int)bytes;
+  hipStream_t st = as_stream(stream);
+  if (Cin == 16) return pool == 2 ? wino::launch<16, 2>(a, st) : wino::launch<16, 1>(a, st);
+  return pool == 2 ? wino::launch<32, 2>(a, st) : wino::launch<32, 1>(a, st);
+}

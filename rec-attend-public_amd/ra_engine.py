@@ -48,6 +48,7 @@ class DecodeEngine(object):
     # attention CNN + DCNN + score through the phase kernel K4 (ra_patchnet_f32).  Measured on MI355X at
     # cfg2 it is 11-15 us per timestep SLOWER than the 13 per-layer launches, so off.
     self.fuse_patchnet = False
+    self.use_wino = True  # controller-CNN layers with Cin 16 | 32, Cout % 32 == 0 as Winograd F(2x2,3x3) (K1w)
     self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
     self.fill_cache_inline = True  # ... by the first timestep's own launch (else: a separate kernel)
     self.co_resident = 1  # engines decoding concurrently on this GPU (set by full_model.DecodePipeline)
@@ -99,7 +100,8 @@ class DecodeEngine(object):
     W = {}
     cmap_c, n_c = self._chan_map(d['ctrl_in'])
     assert n_c == d['ccnn_channels'][0]
-    W['ccnn'] = []
+    W['ccnn'], W['ccnn_wino'] = [], []
+    hh, ww = d['H'], d['W']
     for i in range(d['ccnn_nlayers']):
       cin, cout = d['ccnn_channels'][i], d['ccnn_channels'][i + 1]
       if i == 0:
@@ -108,6 +110,10 @@ class DecodeEngine(object):
         wp = ops.pack_conv_weights(M['ctrl_cnn_w_%d' % i], cin_kernel=_r4(cin))
       sc, sh = fold_all('ctrl_cnn', i, cout)
       W['ccnn'].append((_dev(wp, device), sc, sh, cout, d['ccnn_pool'][i]))
+      # mid-resolution layers also as Winograd F(2x2,3x3) filters (K1w: 2.25x fewer MFMAs), where the shape allows
+      wino = i > 0 and self.use_wino and ops.conv_wino_supported(cin, cout, d['ccnn_pool'][i], hh, ww)
+      W['ccnn_wino'].append(_dev(ops.pack_wino_weights(M['ctrl_cnn_w_%d' % i]), device) if wino else None)
+      hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
     Cf = d['ccnn_channels'][-1]
     self.desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
                                    d['mlp_dim'], d['H'], d['W'], d['Fh'], d['Fw'], d['squash'],
@@ -496,8 +502,12 @@ class DecodeEngine(object):
       else:
         i = step[1]
         wp, sc, sh, cout, pool = layers[i]
-        ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i], plane=pl,
-                    plane_chan=pc if pl is not None else -1)
+        wino = self.W['ccnn_wino'][i] if (layers is self.W.get('ccnn') and pl is None and self.use_wino) else None
+        if wino is not None:
+          ops.conv_wino(src, wino, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i])
+        else:
+          ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i], plane=pl,
+                      plane_chan=pc if pl is not None else -1)
         src = bufs[i]
         self._mark('%s_L%d' % (name, i))
     return src
@@ -565,7 +575,7 @@ class DecodeEngine(object):
       self._launch_all(want_box)  # warm-up (also sets kernel attributes)
       torch.cuda.synchronize()
       g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g):
+      with rn.quiet_capture(), torch.cuda.graph(g):
         self._launch_all(want_box)
       self._graphs[key] = g
     g.replay()

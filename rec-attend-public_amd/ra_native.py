@@ -105,6 +105,10 @@ SIGNATURES = {
     'ra_conv_pack_weights_dev': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_conv3x3_wgrad_workspace_floats': (_Z, [_I, _I, _I, _I, _I]),
     'ra_conv3x3_wgrad_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _P, _P]),
+    'ra_conv_wino_supported': (_I, [_I, _I, _I, _I, _I]),
+    'ra_conv_wino_packed_floats': (_Z, [_I, _I]),
+    'ra_conv_wino_pack_weights': (_I, [_P, _I, _I, _P]),
+    'ra_conv_wino_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_gauss_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_gauss_filter_bwd_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'ra_lstm_cell_f32': (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
@@ -169,3 +173,23 @@ def ptr(t):
 def stream_ptr():
   import torch
   return torch.cuda.current_stream().cuda_stream
+
+
+class quiet_capture(object):
+  """Context for a HIP-graph capture: Python's cyclic garbage collector is parked for its duration.  A
+  collection that happens to run inside the capture can destroy an old graph, event or pinned buffer,
+  and the runtime aborts the process on such a call while a stream is capturing (seen once the test
+  suite ran decode pipelines before a training-step capture)."""
+
+  def __enter__(self):
+    import gc
+    gc.collect()
+    self._was = gc.isenabled()
+    gc.disable()
+    return self
+
+  def __exit__(self, *exc):
+    import gc
+    if self._was:
+      gc.enable()
+    return False

@@ -169,6 +169,33 @@ def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample
   return out
 
 
+def conv_wino_supported(cin, cout, pool, H, W):
+  return bool(rn.lib().ra_conv_wino_supported(int(cin), int(cout), int(pool), int(H), int(W)))
+
+
+def pack_wino_weights(w):
+  """TF-layout [3,3,Cin,Cout] filter -> transformed filters G g G^T in MFMA B-operand order (numpy, host)."""
+  w = _np32(w)
+  cin, cout = w.shape[2], w.shape[3]
+  n = rn.lib().ra_conv_wino_packed_floats(cin, cout)
+  if w.shape[0] != 3 or w.shape[1] != 3 or n == 0:
+    raise rn.RecAttendError('unsupported Winograd conv shape %r' % (w.shape,))
+  out = np.empty(n, dtype=np.float32)
+  check(rn.lib().ra_conv_wino_pack_weights(ptr(w), cin, cout, ptr(out)), 'ra_conv_wino_pack_weights')
+  return out
+
+
+def conv_wino(x, wp, scale, shift, cout, relu=True, pool=1, out=None):
+  """conv3x3 SAME + folded BN + ReLU + pool as Winograd F(2x2,3x3) (ra_conv_wino_f32).  x [B,H,W,Cin]."""
+  _need_cuda(x, wp, scale, shift, out)
+  B, H, W, cin = x.shape
+  if out is None:
+    out = torch.empty((B, H // pool, W // pool, cout), dtype=torch.float32, device=x.device)
+  check(rn.lib().ra_conv_wino_f32(ptr(x), B, H, W, cin, ptr(wp), ptr(scale), ptr(shift), int(cout), int(relu), int(pool),
+                                  ptr(out), rn.stream_ptr()), 'ra_conv_wino_f32')
+  return out
+
+
 def poison_lds():
   """Test aid: leave NaN in every CU's LDS (see ra_debug_poison_lds)."""
   check(rn.lib().ra_debug_poison_lds(rn.stream_ptr()), 'ra_debug_poison_lds')

@@ -812,7 +812,7 @@ class TrainStep(object):
       self._sched = st['sched']
       torch.cuda.synchronize()
       g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g):
+      with rn.quiet_capture(), torch.cuda.graph(g):
         st['out'] = self._grads_and_stats(st['ins']['x'], st['ins']['y_gt'], st['ins']['s_gt'], st['knobs'] or None, None,
                                           {k: st['ins'][k] for k in ('d_in', 'y_in') if k in st['ins']})
       self._sched = None

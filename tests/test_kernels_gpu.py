@@ -537,3 +537,37 @@ def test_adam_step_matches_tf_adam(cuda):
     pr = pr - lr_t * mr / (np.sqrt(vr) + eps)
     assert np.abs(p.cpu().numpy() - pr).max() < 1e-5
     del gd, wdd
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,pool,relu', [
+    (2, 32, 48, 32, 32, 2, True),    # controller CNN L5 shape class
+    (3, 16, 16, 32, 64, 2, True),    # L6: two cout slices
+    (2, 48, 32, 16, 32, 1, True),    # L4: no pool, Cin 16
+    (1, 32, 32, 16, 32, 2, False),
+    (8, 128, 128, 32, 32, 2, True),  # cfg2's L5 itself: persistent workgroups, several tiles each
+])
+def test_conv_winograd(cuda, B, H, W, Ci, Co, pool, relu):
+  """ra_conv_wino_f32 (Winograd F(2x2,3x3) on the MFMA) against the float64 direct convolution and
+  against ra_conv3x3_f32 on the same inputs."""
+  rng = np.random.RandomState(B * 100 + H + Ci + Co + pool)
+  x = rng.randn(B, H, W, Ci).astype(np.float32)
+  w = (rng.randn(3, 3, Ci, Co) / np.sqrt(9 * Ci)).astype(np.float32)
+  b = rng.randn(Co).astype(np.float32) * 0.1
+  bn = tuple(a.astype(np.float32) for a in (rng.randn(Co) * 0.2, rng.uniform(0.5, 1.5, Co) * rng.choice([-1, 1], Co),
+                                            rng.randn(Co) * 0.2, rng.uniform(0.5, 1.5, Co)))
+  assert ops.conv_wino_supported(Ci, Co, pool, H, W)
+  assert not ops.conv_wino_supported(Ci, Co, pool, H + 8, W) and not ops.conv_wino_supported(8, Co, pool, H, W)
+  sc, sh = ops.fold_bn(b, Co, bn)
+  xd, scd, shd = dev(x, cuda), dev(sc, cuda), dev(sh, cuda)
+  ops.poison_lds()
+  y = ops.conv_wino(xd, dev(ops.pack_wino_weights(w), cuda), scd, shd, Co, relu=relu, pool=pool)
+  direct = ops.conv3x3(xd, dev(ops.pack_conv_weights(w), cuda), scd, shd, Co, relu=relu, pool=pool)
+  torch.cuda.synchronize()
+  y, direct = y.cpu().numpy(), direct.cpu().numpy()
+  assert y.shape == direct.shape
+  assert relerr(y, direct) < 2e-5
+  if B * H * W <= 8192:
+    ref = ora.batch_norm_eval(ora.conv2d(x.astype(np.float64), w.astype(np.float64)) + b, *[a.astype(np.float64) for a in bn])
+    ref = ora.relu(ref) if relu else ref
+    ref = ora.max_pool(ref, pool) if pool > 1 else ref
+    assert relerr(y, ref) < 2e-5
