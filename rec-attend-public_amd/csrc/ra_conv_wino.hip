@@ -20,8 +20,12 @@
 //   * after a barrier all 256 threads finish the p half of A^T for (tile, cout) pairs, apply the folded
 //     BatchNorm scale / shift, ReLU and the 2x2 max-pool (one Winograd tile IS one pooling window)
 //     and store channel-contiguous.
-// LDS: 18x18 staged pixels x (Cin + 2) floats (the +2 makes the 16 tiles of a row block hit 16
-// different banks) + 18 KB exchange = 62 KB at Cin = 32: two workgroups per CU.
+// LDS: (TSY + 2) x 18 staged pixels x (Cin + 2) floats (the +2 makes the 16 tiles of a row block hit 16
+// different banks) + 18 KB exchange = 62 KB (TSY = 16) / 42 KB (TSY = 8) at Cin = 32.
+// Where the time goes at cfg2's L5 (8 x 128 x 128, 32 -> 32, 16.6 us against 23.4 direct): the MFMA floor
+// of this form is 6.8 us per CU (2048 MFMAs over 4 SIMDs), the k-loop measures 11 us (tools/wino_variants.py:
+// ablation builds), the rest is per-workgroup fixed cost — filter load 1.5, first rows, exchange,
+// stores — that the two workgroups of a CU pay in lockstep because every tile starts at once.
 #include "ra_common.h"
 
 namespace ra {
@@ -30,8 +34,8 @@ namespace wino {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TS = 16;       // output tile side
-constexpr int WS = TS + 2;   // staged window side
+constexpr int TS = 16;       // output tile width (and height of the tall form)
+constexpr int WS = TS + 2;   // staged window width
 constexpr int TEX = 36;      // exchange stride per tile (floats): 16 * ksub banks apart
 
 struct WArgs {
@@ -41,12 +45,14 @@ struct WArgs {
   int bytes_x;
 };
 
-template <int CIN, int POOL>
+// TSY: output tile height, 16 (4 row blocks) or 8 (2 row blocks: more, smaller workgroups for the layers whose
+// 16x16 tiles would not give every CU two workgroups)
+template <int CIN, int POOL, int TSY>
 __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tiles_x, int tiles_y, int ntiles) {
-  constexpr int KK = CIN / 4, S = CIN + 2, C4 = CIN / 4;
+  constexpr int KK = CIN / 4, S = CIN + 2, C4 = CIN / 4, NMB = TSY / 4, WSY = TSY + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *tin = lds;                  // [WS][WS][S]
-  float *tex = lds + WS * WS * S;    // [4 p][2 j][16 tiles][TEX]
+  float *tin = lds;                  // [WSY][WS][S]
+  float *tex = lds + WSY * WS * S;   // [4 p][2 j][16 tiles][TEX]
   const int tid = threadIdx.x, lane = tid & 63;
   const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, ksub = lane >> 4;
@@ -75,26 +81,51 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
   const float lo = a.relu ? 0.f : -__builtin_inff();
   const int Ho = a.H / POOL, Wo = a.W / POOL;
 
+  // Staging is cut by row blocks: block k needs window rows 4k .. 4k + 5.  Rows 0..5 are staged up front,
+  // the 4 new rows of block k + 1 are loaded into registers before block k's MFMAs and written to LDS after
+  // them (nobody reads those rows yet; the exchange barrier publishes them), so only the first 6 rows of a
+  // tile are exposed.
+  constexpr int N0 = (6 * WS * C4 + 255) / 256, N1 = (4 * WS * C4 + 255) / 256;
+  auto load_rows = [&](int b, int oy, int ox, int row0, int nrows, int i) -> f32x4 {  // item i of this thread
+    const int e = tid + 256 * i;
+    const int c4 = e % C4, pix = e / C4;
+    const int r = row0 + pix / WS, c = pix % WS;
+    const int Y = oy + r, X = ox + c;
+    const bool ok = (e < nrows * WS * C4) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+    const int off = ok ? (((b * a.H + Y) * a.W + X) * CIN + 4 * c4) * 4 : 0x7fffffff;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+  };
+  auto store_rows = [&](int row0, int nrows, int i, f32x4 v) {
+    const int e = tid + 256 * i;
+    if (e < nrows * WS * C4) {
+      const int c4 = e % C4, pix = e / C4;
+      float *d = tin + (row0 * WS + pix) * S + 4 * c4;
+      *reinterpret_cast<f32x2 *>(d) = f32x2{v.x, v.y};
+      *reinterpret_cast<f32x2 *>(d + 2) = f32x2{v.z, v.w};
+    }
+  };
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    const int oy = ty * TS - 1, ox = tx * TS - 1;
+    const int oy = ty * TSY - 1, ox = tx * TS - 1;
     __syncthreads();  // the previous tile's reads of tin / tex are complete
-    for (int e = tid; e < WS * WS * C4; e += 256) {
-      const int c4 = e % C4, pix = e / C4;
-      const int r = pix / WS, c = pix - r * WS;
-      const int Y = oy + r, X = ox + c;
-      const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-      const int off = ok ? (((b * a.H + Y) * a.W + X) * CIN + 4 * c4) * 4 : 0x7fffffff;
-      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-      float *d = tin + pix * S + 4 * c4;
-      *reinterpret_cast<f32x2 *>(d) = f32x2{v.x, v.y};
-      *reinterpret_cast<f32x2 *>(d + 2) = f32x2{v.z, v.w};
+    {
+      f32x4 v0[N0];
+#pragma unroll
+      for (int i = 0; i < N0; ++i) v0[i] = load_rows(b, oy, ox, 0, 6, i);
+#pragma unroll
+      for (int i = 0; i < N0; ++i) store_rows(0, 6, i, v0[i]);
     }
     __syncthreads();
 
 #pragma unroll 1
-    for (int mblk = 0; mblk < 4; ++mblk) {
+    for (int mblk = 0; mblk < NMB; ++mblk) {
+      f32x4 vn[N1];
+      if (mblk + 1 < NMB) {
+#pragma unroll
+        for (int i = 0; i < N1; ++i) vn[i] = load_rows(b, oy, ox, 4 * mblk + 6, 4, i);
+      }
       // lane m's Winograd tile of this row block and its patch origin in the staged window
       const int tyi = 2 * mblk + (m >> 3), txi = m & 7;
       const float *pa = tin + ((2 * tyi + ra) * WS + 2 * txi) * S + ksub;
@@ -104,17 +135,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[q][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the patch values of k-step kk + 1 are read while the MFMAs of k-step kk issue
+      float da[2][4], db[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        da[0][j] = pa[j * S];
+        db[0][j] = pb[j * S];
+      }
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
+        if (kk + 1 < KK) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            da[(kk + 1) & 1][j] = pa[j * S + 4 * (kk + 1)];
+            db[(kk + 1) & 1][j] = pb[j * S + 4 * (kk + 1)];
+          }
+        }
         float r[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = pa[j * S + 4 * kk] + sg * pb[j * S + 4 * kk];
+        for (int j = 0; j < 4; ++j) r[j] = da[kk & 1][j] + sg * db[kk & 1][j];
         const float v[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
             acc[q][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[q][kk][nb], acc[q][nb], 0, 0, 0);
+      }
+      if (mblk + 1 < NMB) {
+#pragma unroll
+        for (int i = 0; i < N1; ++i) store_rows(4 * mblk + 6, 4, i, vn[i]);
       }
       // q half of A^T: T[p][0] = M0 + M1 + M2, T[p][1] = M1 - M2 - M3; D rows = tiles 4 * ksub + r, col = cout
       if (mblk) __syncthreads();  // the previous row block's exchange has been consumed
@@ -144,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
           yv[0][j] = fmaxf((T[0][j] + T[1][j] + T[2][j]) * sc + sh, lo);
           yv[1][j] = fmaxf((T[1][j] - T[2][j] - T[3][j]) * sc + sh, lo);
         }
-        const int oty = ty * 8 + 2 * mblk + (tl >> 3), otx = tx * 8 + (tl & 7);  // Winograd tile coordinates in the image
+        const int oty = ty * (TSY / 2) + 2 * mblk + (tl >> 3), otx = tx * 8 + (tl & 7);  // Winograd tile coordinates in the image
         if constexpr (POOL == 2) {
           const float best = fmaxf(fmaxf(yv[0][0], yv[0][1]), fmaxf(yv[1][0], yv[1][1]));
           a.y[((size_t)(b * Ho + oty) * Wo + otx) * a.Cout + 32 * slice + eco] = best;
@@ -160,28 +209,52 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
   }
 }
 
-template <int CIN, int POOL>
+inline int cu_count();
+
+template <int CIN, int POOL, int TSY>
 int launch(const WArgs &a, hipStream_t st) {
-  auto kern = conv_wino_mfma<CIN, POOL>;
-  constexpr size_t lds = (size_t)(WS * WS * (CIN + 2) + 8 * 16 * TEX) * sizeof(float);
+  auto kern = conv_wino_mfma<CIN, POOL, TSY>;
+  constexpr size_t lds = (size_t)((TSY + 2) * WS * (CIN + 2) + 8 * 16 * TEX) * sizeof(float);
   static bool attr = false;
   static int cap = 0;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
-    hipDeviceProp_t prop;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    cap = nb * cus;
+    cap = nb * cu_count();
     attr = true;
   }
-  const int tiles_x = a.W / TS, tiles_y = a.H / TS, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / 32;
+  const int tiles_x = a.W / TS, tiles_y = a.H / TSY, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / 32;
   int gx = cap / slices;
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_wino_f32");
+}
+
+inline int cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+// 16-row tiles only when they give every CU more than two workgroups (RA_WINO_TSY=8|16 forces one form):
+// measured at cfg2, 8-row tiles 9.8 vs 11.5 us (L6), 12.7 vs 13.3 (L4), 16.5 vs 16.6 (L5)
+template <int CIN, int POOL>
+int launch_any(const WArgs &a, hipStream_t st) {
+  static int force = -1;
+  if (force < 0) {
+    const char *e = getenv("RA_WINO_TSY");
+    force = e ? atoi(e) : 0;
+  }
+  const int tall = (a.W / TS) * (a.H / 16) * a.B * (a.Cout / 32);
+  const bool small = force ? force == 8 : tall <= 2 * cu_count();
+  return small ? launch<CIN, POOL, 8>(a, st) : launch<CIN, POOL, 16>(a, st);
 }
 
 }  // namespace wino
@@ -239,6 +312,6 @@ extern "C" int ra_conv_wino_f32(const float *x, int B, int H, int W, int Cin, co
   a.relu = relu;
   a.bytes_x = (int)bytes;
   hipStream_t st = as_stream(stream);
-  if (Cin == 16) return pool == 2 ? wino::launch<16, 2>(a, st) : wino::launch<16, 1>(a, st);
-  return pool == 2 ? wino::launch<32, 2>(a, st) : wino::launch<32, 1>(a, st);
+  if (Cin == 16) return pool == 2 ? wino::launch_any<16, 2>(a, st) : wino::launch_any<16, 1>(a, st);
+  return pool == 2 ? wino::launch_any<32, 2>(a, st) : wino::launch_any<32, 1>(a, st);
 }
