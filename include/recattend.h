@@ -120,7 +120,7 @@ int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsam
 /* K1w: conv3x3 SAME + folded BN + ReLU + optional 2x2 max-pool (nnlib.py:229-253) as Winograd F(2x2, 3x3)
  * on the f32 MFMA: 2.25x fewer matrix multiplies than ra_conv3x3_f32 for the same layer, results equal
  * to ~1e-6 relative (summation order and the 0.5 factors of the filter transform).  Cin 16 | 32,
- * Cout % 32 == 0, H and W multiples of 16 (ra_conv_wino_supported).  wpacked: the transformed filters
+ * Cout % 16 == 0, H and W multiples of 16 (ra_conv_wino_supported).  wpacked: the transformed filters
  * G g G^T in MFMA B-operand order, ra_conv_wino_packed_floats() floats, from the reference's
  * [3,3,Cin,Cout] filter by ra_conv_wino_pack_weights (host).  scale / shift: the folded BatchNorm of
  * this timestep, as for ra_conv3x3_f32.  x [B,H,W,Cin] -> y [B,H/pool,W/pool,Cout]. */

@@ -47,9 +47,10 @@ struct WArgs {
 
 // TSY: output tile height, 16 (4 row blocks) or 8 (2 row blocks: more, smaller workgroups for the layers whose
 // 16x16 tiles would not give every CU two workgroups)
-template <int CIN, int POOL, int TSY>
+// NB: blocks of 16 output channels per workgroup (2, or 1 for layers with 16 output channels)
+template <int CIN, int POOL, int TSY, int NB>
 __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tiles_x, int tiles_y, int ntiles) {
-  constexpr int KK = CIN / 4, S = CIN + 2, C4 = CIN / 4, NMB = TSY / 4, WSY = TSY + 2;
+  constexpr int KK = CIN / 4, S = CIN + 2, C4 = CIN / 4, NMB = TSY / 4, WSY = TSY + 2, CO = 16 * NB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tin = lds;                  // [WSY][WS][S]
   float *tex = lds + WSY * WS * S;   // [4 p][2 j][16 tiles][TEX]
@@ -59,14 +60,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
   const int slice = blockIdx.y, NBT = a.Cout / 16;
 
   // this wave's transformed filters, q = 0..3, all k-steps, 2 blocks of 16 output channels
-  float bw[4][KK][2];
+  float bw[4][KK][NB];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-        bw[q][kk][nb] = a.wp[((size_t)((p * 4 + q) * KK + kk) * NBT + 2 * slice + nb) * 64 + lane];
+      for (int nb = 0; nb < NB; ++nb)
+        bw[q][kk][nb] = a.wp[((size_t)((p * 4 + q) * KK + kk) * NBT + NB * slice + nb) * 64 + lane];
 
   // rows of the 4x4 patch that row p of B^T combines: r_j = d[ra][j] + sg * d[rb][j]
   const int ra = (p == 0) ? 0 : (p == 2) ? 2 : 1;
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
   const int per = tiles_x * tiles_y;
-  // epilogue constants of this thread's two (tile, cout) pairs per row block: cout = tid % 32
-  const int eco = tid & 31;
-  const float sc = a.scale[32 * slice + eco], sh = a.shift[32 * slice + eco];
+  // epilogue constants of this thread's (tile, cout) pairs of a row block: cout = tid % CO
+  const int eco = tid % CO;
+  const float sc = a.scale[CO * slice + eco], sh = a.shift[CO * slice + eco];
   const float lo = a.relu ? 0.f : -__builtin_inff();
   const int Ho = a.H / POOL, Wo = a.W / POOL;
 
@@ -130,11 +131,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
       const int tyi = 2 * mblk + (m >> 3), txi = m & 7;
       const float *pa = tin + ((2 * tyi + ra) * WS + 2 * txi) * S + ksub;
       const float *pb = tin + ((2 * tyi + rb) * WS + 2 * txi) * S + ksub;
-      f32x4 acc[4][2];
+      f32x4 acc[4][NB];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[q][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NB; ++nb) acc[q][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       // the patch values of k-step kk + 1 are read while the MFMAs of k-step kk issue
       float da[2][4], db[2][4];
 #pragma unroll
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < NB; ++nb)
             acc[q][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[q][kk][nb], acc[q][nb], 0, 0, 0);
       }
       if (mblk + 1 < NMB) {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
       // q half of A^T: T[p][0] = M0 + M1 + M2, T[p][1] = M1 - M2 - M3; D rows = tiles 4 * ksub + r, col = cout
       if (mblk) __syncthreads();  // the previous row block's exchange has been consumed
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
+      for (int nb = 0; nb < NB; ++nb) {
         const f32x4 t0 = acc[0][nb] + acc[1][nb] + acc[2][nb];
         const f32x4 t1 = acc[1][nb] - acc[2][nb] - acc[3][nb];
 #pragma unroll
@@ -178,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
         }
       }
       __syncthreads();
-      // p half of A^T + BN + ReLU + pool for (tile, cout) pairs: 512 per row block, 2 per thread
+      // p half of A^T + BN + ReLU + pool for the 16 x CO (tile, cout) pairs of the row block, NB per thread
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int tl = (tid >> 5) + 8 * k;  // tile 0..15 of the row block
+      for (int k = 0; k < NB; ++k) {
+        const int tl = tid / CO + (256 / CO) * k;  // tile 0..15 of the row block
         float T[4][2];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
@@ -196,13 +197,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
         const int oty = ty * (TSY / 2) + 2 * mblk + (tl >> 3), otx = tx * 8 + (tl & 7);  // Winograd tile coordinates in the image
         if constexpr (POOL == 2) {
           const float best = fmaxf(fmaxf(yv[0][0], yv[0][1]), fmaxf(yv[1][0], yv[1][1]));
-          a.y[((size_t)(b * Ho + oty) * Wo + otx) * a.Cout + 32 * slice + eco] = best;
+          a.y[((size_t)(b * Ho + oty) * Wo + otx) * a.Cout + CO * slice + eco] = best;
         } else {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              a.y[((size_t)(b * Ho + 2 * oty + i) * Wo + 2 * otx + j) * a.Cout + 32 * slice + eco] = yv[i][j];
+              a.y[((size_t)(b * Ho + 2 * oty + i) * Wo + 2 * otx + j) * a.Cout + CO * slice + eco] = yv[i][j];
         }
       }
     }
@@ -211,9 +212,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
 
 inline int cu_count();
 
-template <int CIN, int POOL, int TSY>
+template <int CIN, int POOL, int TSY, int NB>
 int launch(const WArgs &a, hipStream_t st) {
-  auto kern = conv_wino_mfma<CIN, POOL, TSY>;
+  auto kern = conv_wino_mfma<CIN, POOL, TSY, NB>;
   constexpr size_t lds = (size_t)((TSY + 2) * WS * (CIN + 2) + 8 * 16 * TEX) * sizeof(float);
   static bool attr = false;
   static int cap = 0;
@@ -224,7 +225,7 @@ int launch(const WArgs &a, hipStream_t st) {
     cap = nb * cu_count();
     attr = true;
   }
-  const int tiles_x = a.W / TS, tiles_y = a.H / TSY, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / 32;
+  const int tiles_x = a.W / TS, tiles_y = a.H / TSY, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / (16 * NB);
   int gx = cap / slices;
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
@@ -245,16 +246,16 @@ inline int cu_count() {
 
 // 16-row tiles only when they give every CU more than two workgroups (RA_WINO_TSY=8|16 forces one form):
 // measured at cfg2, 8-row tiles 9.8 vs 11.5 us (L6), 12.7 vs 13.3 (L4), 16.5 vs 16.6 (L5)
-template <int CIN, int POOL>
+template <int CIN, int POOL, int NB>
 int launch_any(const WArgs &a, hipStream_t st) {
   static int force = -1;
   if (force < 0) {
     const char *e = getenv("RA_WINO_TSY");
     force = e ? atoi(e) : 0;
   }
-  const int tall = (a.W / TS) * (a.H / 16) * a.B * (a.Cout / 32);
+  const int tall = (a.W / TS) * (a.H / 16) * a.B * (a.Cout / (16 * NB));
   const bool small = force ? force == 8 : tall <= 2 * cu_count();
-  return small ? launch<CIN, POOL, 8>(a, st) : launch<CIN, POOL, 16>(a, st);
+  return small ? launch<CIN, POOL, 8, NB>(a, st) : launch<CIN, POOL, 16, NB>(a, st);
 }
 
 }  // namespace wino
@@ -263,12 +264,12 @@ int launch_any(const WArgs &a, hipStream_t st) {
 using namespace ra;
 
 extern "C" int ra_conv_wino_supported(int Cin, int Cout, int pool, int H, int W) {
-  return (Cin == 16 || Cin == 32) && Cout > 0 && Cout % 32 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
+  return (Cin == 16 || Cin == 32) && Cout > 0 && Cout % 16 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
          H % wino::TS == 0 && W % wino::TS == 0;
 }
 
 extern "C" size_t ra_conv_wino_packed_floats(int Cin, int Cout) {
-  if (!(Cin == 16 || Cin == 32) || Cout <= 0 || Cout % 32) return 0;
+  if (!(Cin == 16 || Cin == 32) || Cout <= 0 || Cout % 16) return 0;
   return (size_t)16 * Cin * Cout;
 }
 
@@ -312,6 +313,10 @@ extern "C" int ra_conv_wino_f32(const float *x, int B, int H, int W, int Cin, co
   a.relu = relu;
   a.bytes_x = (int)bytes;
   hipStream_t st = as_stream(stream);
-  if (Cin == 16) return pool == 2 ? wino::launch_any<16, 2>(a, st) : wino::launch_any<16, 1>(a, st);
-  return pool == 2 ? wino::launch_any<32, 2>(a, st) : wino::launch_any<32, 1>(a, st);
+  if (Cout % 32) {  // 16 output channels per workgroup
+    if (Cin == 16) return pool == 2 ? wino::launch_any<16, 2, 1>(a, st) : wino::launch_any<16, 1, 1>(a, st);
+    return pool == 2 ? wino::launch_any<32, 2, 1>(a, st) : wino::launch_any<32, 1, 1>(a, st);
+  }
+  if (Cin == 16) return pool == 2 ? wino::launch_any<16, 2, 2>(a, st) : wino::launch_any<16, 1, 2>(a, st);
+  return pool == 2 ? wino::launch_any<32, 2, 2>(a, st) : wino::launch_any<32, 1, 2>(a, st);
 }

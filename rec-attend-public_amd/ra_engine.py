@@ -48,6 +48,9 @@ class DecodeEngine(object):
     # attention CNN + DCNN + score through the phase kernel K4 (ra_patchnet_f32).  Measured on MI355X at
     # cfg2 it is 11-15 us per timestep SLOWER than the 13 per-layer launches, so off.
     self.fuse_patchnet = False
+    # ... also where that splits a fused pair (the 16 -> 16 layer of L2+L3)?  Measured at cfg2: L2 direct 20.6 +
+    # L3 Winograd 22.2 us against 41.8 us fused: no gain, one more launch -> off
+    self.wino_unfuse = False
     self.use_wino = True  # controller-CNN layers with Cin 16 | 32, Cout % 32 == 0 as Winograd F(2x2,3x3) (K1w)
     self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
     self.fill_cache_inline = True  # ... by the first timestep's own launch (else: a separate kernel)
@@ -192,13 +195,13 @@ class DecodeEngine(object):
     d = self.d
     plan = {}
 
-    def pair_up(n, cin, cout, a_ok, b_ok):
+    def pair_up(n, cin, cout, a_ok, b_ok, unfuse=lambda i: False):
       steps, i = [], 0
       while i < n:
         # measured on MI355X: fusion pays while the intermediate has <= 16 channels (LDS tile
         # small enough for a 16x32 tile); wider pairs recompute too much halo
         if (self.fuse_pairs and i + 1 < n and a_ok(i) and b_ok(i + 1) and cout(i) <= 16 and
-            ops.conv_pair_supported(cin(i), cout(i), cout(i + 1))):
+            ops.conv_pair_supported(cin(i), cout(i), cout(i + 1)) and not unfuse(i + 1)):
           steps.append(('pair', i, i + 1))
           i += 2
         else:
@@ -207,8 +210,10 @@ class DecodeEngine(object):
       return steps
 
     cc = d['ccnn_channels']
+    # a layer that can run as Winograd (K1w) is worth more alone than as the second half of a fused pair
+    wino_alone = lambda i: self.use_wino and self.wino_unfuse and W['ccnn_wino'][i] is not None
     plan['ccnn'] = pair_up(d['ccnn_nlayers'], lambda i: d['C0p'] if i == 0 else _r4(cc[i]),
-                           lambda i: cc[i + 1], lambda i: d['ccnn_pool'][i] == 1, lambda i: True)
+                           lambda i: cc[i + 1], lambda i: d['ccnn_pool'][i] == 1, lambda i: True, wino_alone)
     if not self.box:
       ac = d['acnn_channels']
       L = d['acnn_nlayers']

@@ -544,6 +544,8 @@ def test_adam_step_matches_tf_adam(cuda):
     (3, 16, 16, 32, 64, 2, True),    # L6: two cout slices
     (2, 48, 32, 16, 32, 1, True),    # L4: no pool, Cin 16
     (1, 32, 32, 16, 32, 2, False),
+    (2, 64, 32, 16, 16, 2, True),    # L3 shape class: one block of 16 output channels per workgroup
+    (1, 16, 48, 32, 16, 1, True),
     (8, 128, 128, 32, 32, 2, True),  # cfg2's L5 itself: persistent workgroups, several tiles each
 ])
 def test_conv_winograd(cuda, B, H, W, Ci, Co, pool, relu):
