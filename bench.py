@@ -495,7 +495,7 @@ def main():
       enc_bytes += 4.0 * (src_.numel() + sb['ccnn'][st_[-1]].numel())
     achieved = tot_f * Bs / (enc_us * 1e-6) / 1e12
     out['roofline'] = {
-        'kernel': 'ra::cpair::conv_pair_mfma + ra::conv::conv3x3_mfma (controller CNN: %d layers in %d '
+        'kernel': 'ra::cpair::conv_pair8_mfma / conv_pair_persist_mfma + ra::wino::conv_wino_mfma + ra::conv::conv3x3_mfma (controller CNN: %d layers in %d '
                   'launches per timestep per sub-batch of %d images)' % (d['ccnn_nlayers'],
                                                                        len(eng.plan['ccnn']), Bs),
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -504,7 +504,7 @@ def main():
                         '(profiles/r0x_pmc_encoder_traffic.json; FETCH_SIZE x2 gfx950 correction + '
                         'WRITE_SIZE); null if no pass matches this shape',
         'algorithmic_bytes_per_launch_group': enc_bytes,
-        'peak_note': 'dense f32-input MFMA (v_mfma_f32_16x16x4_f32); the kernel computes in exact f32',
+        'peak_note': 'dense f32-input MFMA (v_mfma_f32_16x16x4_f32); float32 arithmetic throughout.  achieved = ALGORITHMIC FLOPs (2*9*Cin*Cout per output pixel, SURVEY 8d) / time: the Winograd layers (L4-L6, K1w) execute 2.25x fewer multiplies than that count',
         'flop_per_launch_group': tot_f * Bs, 'avg_us_per_launch_group': enc_us,
         'first_layer_cache': None if 'l0cache' not in sb else {
             'us_per_forward': cache_us,
