@@ -304,6 +304,7 @@ def main():
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--part-images', type=int, default=0, help='--config cfg3|cfg5: cut each batch into parts of this many images')
   ap.add_argument('--wino-unfuse', action='store_true', help='tuning aid: L2 direct + L3 Winograd instead of the fused L2+L3 pair')
+  ap.add_argument('--no-pair-wino', action='store_true', help='tuning aid: direct second layer in the fused L2+L3 pair')
   ap.add_argument('--no-wino', action='store_true', help='tuning aid: direct conv for every controller-CNN layer')
   ap.add_argument('--no-ctrl-split', action='store_true', help='tuning aid: one-workgroup-per-image controller')
   ap.add_argument('--in-flight', type=int, default=0,
@@ -354,6 +355,7 @@ def main():
   eng.ctrl_split = not args.no_ctrl_split
   eng.use_wino = not args.no_wino
   eng.wino_unfuse = args.wino_unfuse
+  eng.pair_wino = not args.no_pair_wino
   eng.fuse_patchnet = args.fuse_patchnet
   eng.cache_first = not args.no_cache_first
   g = torch.Generator().manual_seed(1234 + rank)

@@ -131,6 +131,15 @@ int ra_conv_wino_f32(const float *x, int B, int H, int W, int Cin, const float *
                      const float *scale, const float *shift, int Cout, int relu, int pool, float *y,
                      void *stream);
 
+/* K1pw: ra_conv_pair_f32 for the pair 8 -> 16 -> 16 with poolB = 2 (the controller CNN's L2+L3 at the CVPPP
+ * arch, full_model.py:640-661 / nnlib.py:229-253) with layer B computed as Winograd F(2x2,3x3) straight
+ * from the LDS tile layer A was written to.  wpA: ra_conv_pack_weights (Cin = 8); wpB_wino:
+ * ra_conv_wino_pack_weights of layer B's [3,3,16,16] filter.  H, W multiples of 16. */
+int ra_conv_pair_wino_supported(int Cin, int CoutA, int CoutB, int poolB, int H, int W);
+int ra_conv_pair_wino_f32(const float *x, int B, int H, int W, const float *wpA, const float *scaleA,
+                          const float *shiftA, int reluA, const float *wpB_wino, const float *scaleB,
+                          const float *shiftB, int reluB, float *y, void *stream);
+
 /* The first controller-CNN pair with the image part of layer A cached.  Of layer A's input
  * concat(x, canvas) (full_model.py:640-661) only the canvas changes between timesteps
  * (:843-848), and a convolution is linear in its input channels, so

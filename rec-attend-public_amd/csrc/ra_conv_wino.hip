@@ -258,6 +258,215 @@ int launch_any(const WArgs &a, hipStream_t st) {
   return small ? launch<CIN, POOL, 8, NB>(a, st) : launch<CIN, POOL, 16, NB>(a, st);
 }
 
+// -------------------------------------------------------------------------------------------------
+// K1pw — a fused layer pair whose second layer is Winograd: the controller CNN's L2+L3 (8 -> 16 -> 16, pool 2).
+// Layer A (direct 3x3 on the MFMA, as in conv_pair_persist_mfma) is computed on the output tile + 1-pixel
+// halo straight into the LDS window layer B's Winograd reads — [window pixel][16 + 2 floats], zero outside
+// the image (layer B's SAME padding) — so the intermediate never leaves the CU and layer B (2/3 of the
+// pair's FLOPs) costs 2.25x fewer MFMAs.  The A region is walked as a LINEAR list of its 18 x (TSY + 2)
+// pixels in groups of 16 (1.31x / 1.41x the tile's pixels at TSY = 16 / 8; the 8-pixel-group walk of the
+// direct pair kernel pads 32 x 8 tiles to 1.56x).  Persistent; the next tile's input window is fetched
+// into registers behind both phases; the Winograd exchange buffer aliases the input tile, which is dead
+// by then.
+struct PWArgs {
+  const float *x, *wpA, *scA, *shA, *wpB, *scB, *shB;
+  float *y;
+  int B, H, W, CoutAP, reluA, reluB;
+  int bytes_x;
+};
+
+template <int TSY>
+__global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int CINA = 8, CMID = 16, KK = CMID / 4, S = CMID + 2, NMB = TSY / 4;
+  constexpr int AWY = TSY + 2, IWY = TSY + 4, IWX = TS + 4;   // layer-A output window / input window (rows; 18 / 20 wide)
+  constexpr int NPA = AWY * WS, NGA = (NPA + 15) / 16, GPW = (NGA + 3) / 4;
+  constexpr int NPI = IWY * IWX, NIT = (NPI * 2 + 255) / 256;  // input items: (pixel, half of its 8 channels)
+  constexpr int TEXP = 20;                   // exchange stride per tile for 16 output channels: 16 * ksub banks apart
+  constexpr int R0 = NPI * CINA > 8 * 16 * TEXP ? NPI * CINA : 8 * 16 * TEXP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tinp = lds;                         // [IWY][IWX][8]   records [ksub][cg]  (channel = 4 * cg + ksub)
+  float *tex = lds;                          // [4 p][2 j][16 tiles][TEXP]: phase B only, when tinp is dead
+  float *tin = lds + R0;                     // [AWY * 18][S]   layer-A output window (+ one group of slack:
+                                             // the padding rows of the last group land there)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, ksub = lane >> 4;
+  const int per = tiles_x * tiles_y;
+
+  // layer A: direct-form B operands (9 taps x 2 channel groups) and epilogue constants of column m
+  float bA[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) bA[tap][cg] = a.wpA[(size_t)((tap * 2 + cg) * 4 + ksub) * a.CoutAP + m];
+  const float scA = a.scA[m], shA = a.shA[m];
+  const float loA = a.reluA ? 0.f : -__builtin_inff();
+  // layer B: this wave's row p of the transformed filters (one block of 16 output channels)
+  float bw[4][KK];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) bw[q][kk] = a.wpB[((size_t)((p * 4 + q) * KK + kk)) * 64 + lane];
+  const int ra = (p == 0) ? 0 : (p == 2) ? 2 : 1;
+  const int rb = (p == 0) ? 2 : (p == 1) ? 2 : (p == 2) ? 1 : 3;
+  const float sg = (p == 1) ? 1.f : -1.f;
+  const int eco = tid & 15;
+  const float scB = a.scB[eco], shB = a.shB[eco];
+  const float loB = a.reluB ? 0.f : -__builtin_inff();
+  const int Ho = a.H / 2, Wo = a.W / 2;
+
+  // phase A bookkeeping: LDS offset of this lane's pixel of each of the wave's groups (tile-invariant)
+  int ain[GPW];
+#pragma unroll
+  for (int s = 0; s < GPW; ++s) {
+    int li = 16 * (p + 4 * s) + m;
+    if (li >= NPA) li = NPA - 1;  // padding rows of the last group repeat a real pixel; their results go to the slack
+    const int r = li / WS, c = li - r * WS;
+    ain[s] = (r * IWX + c) * CINA + 2 * ksub;
+  }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
+  f32x4 pre[NIT];
+  auto fetch = [&](int T) {
+    const int fb = T / per, fr = T - fb * per;
+    const int fy0 = (fr / tiles_x) * TSY - 2, fx0 = (fr % tiles_x) * TS - 2;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tid + 256 * i, cg = e & 1, pix = e >> 1;
+      const int r = pix / IWX, c = pix - r * IWX;
+      const int Y = fy0 + r, X = fx0 + c;
+      const bool ok = (e < NPI * 2) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+      const int off = ok ? (((fb * a.H + Y) * a.W + X) * CINA + 4 * cg) * 4 : 0x7fffffff;
+      pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / per, trem = tile - b * per;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    __syncthreads();  // the previous tile's phase B (exchange reads) is complete
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tid + 256 * i, cg = e & 1, pix = e >> 1;
+      if (e < NPI * 2) {
+        float *rec = tinp + pix * CINA + cg;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) rec[2 * ks] = pre[i][ks];
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+
+    // ---------------- phase A: layer A on the window, BN + ReLU, -> tin ----------------
+    {
+      const int oyA = ty * TSY - 1, oxA = tx * TS - 1;  // image coordinates of window pixel (0, 0)
+      const bool interior = (oyA >= 0) & (oyA + AWY <= a.H) & (oxA >= 0) & (oxA + WS <= a.W);
+      f32x4 acc[GPW];
+#pragma unroll
+      for (int s = 0; s < GPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        f32x2 av[GPW];
+#pragma unroll
+        for (int s = 0; s < GPW; ++s)
+          av[s] = *reinterpret_cast<const f32x2 *>(&tinp[ain[s] + ((tap / 3) * IWX + tap % 3) * CINA]);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+          for (int s = 0; s < GPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[tap][cg], acc[s], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < GPW; ++s) {
+        const int g = p + 4 * s;
+        if (g < NGA) {  // wave-uniform
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int li = 16 * g + 4 * ksub + r;  // D row 4 * ksub + r of the group = window pixel li
+            float o = fmaxf(acc[s][r] * scA + shA, loA);
+            if (!interior) {
+              const int wr = li / WS, wc = li - wr * WS;
+              const int Y = oyA + wr, X = oxA + wc;
+              o = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o : 0.f;
+            }
+            tin[li * S + m] = o;  // li >= NPA: the slack behind the window
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---------------- phase B: Winograd F(2x2, 3x3) out of tin (see conv_wino_mfma) ----------------
+#pragma unroll 1
+    for (int mblk = 0; mblk < NMB; ++mblk) {
+      const int tyi = 2 * mblk + (m >> 3), txi = m & 7;
+      const float *pa = tin + ((2 * tyi + ra) * WS + 2 * txi) * S + ksub;
+      const float *pb = tin + ((2 * tyi + rb) * WS + 2 * txi) * S + ksub;
+      f32x4 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = pa[j * S + 4 * kk] + sg * pb[j * S + 4 * kk];
+        const float v[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[q][kk], acc[q], 0, 0, 0);
+      }
+      if (mblk) __syncthreads();  // the previous row block's exchange has been consumed
+      {
+        const f32x4 t0 = acc[0] + acc[1] + acc[2];
+        const f32x4 t1 = acc[1] - acc[2] - acc[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          tex[((p * 2 + 0) * 16 + 4 * ksub + r) * TEXP + m] = t0[r];
+          tex[((p * 2 + 1) * 16 + 4 * ksub + r) * TEXP + m] = t1[r];
+        }
+      }
+      __syncthreads();
+      {
+        const int tl = tid >> 4;  // tile 0..15 of the row block, cout = tid % 16
+        float T[4][2];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) T[pp][j] = tex[((pp * 2 + j) * 16 + tl) * TEXP + eco];
+        float best = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          best = fmaxf(best, fmaxf((T[0][j] + T[1][j] + T[2][j]) * scB + shB, loB));
+          best = fmaxf(best, fmaxf((T[1][j] - T[2][j] - T[3][j]) * scB + shB, loB));
+        }
+        const int oty = ty * (TSY / 2) + 2 * mblk + (tl >> 3), otx = tx * 8 + (tl & 7);
+        a.y[((size_t)(b * Ho + oty) * Wo + otx) * 16 + eco] = best;
+      }
+    }
+  }
+}
+
+template <int TSY>
+int launch_pair(const PWArgs &a, hipStream_t st) {
+  auto kern = conv_pair_wino_mfma<TSY>;
+  constexpr int r0 = (TSY + 4) * (TS + 4) * 8 > 8 * 16 * 20 ? (TSY + 4) * (TS + 4) * 8 : 8 * 16 * 20;
+  constexpr size_t lds = (size_t)(r0 + ((TSY + 2) * WS + 16) * 18) * sizeof(float);
+  static bool attr = false;
+  static int cap = 0;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    cap = nb * cu_count();
+    const char *e = getenv("RA_PAIRW_WGS");
+    if (e && atoi(e) > 0) cap = atoi(e);
+    attr = true;
+  }
+  const int tiles_x = a.W / TS, tiles_y = a.H / TSY, ntiles = tiles_x * tiles_y * a.B;
+  hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  return launch_status("ra_conv_pair_wino_f32");
+}
+
 }  // namespace wino
 }  // namespace ra
 
@@ -319,4 +528,40 @@ extern "C" int ra_conv_wino_f32(const float *x, int B, int H, int W, int Cin, co
   }
   if (Cin == 16) return pool == 2 ? wino::launch_any<16, 2, 2>(a, st) : wino::launch_any<16, 1, 2>(a, st);
   return pool == 2 ? wino::launch_any<32, 2, 2>(a, st) : wino::launch_any<32, 1, 2>(a, st);
+}
+
+extern "C" int ra_conv_pair_wino_supported(int Cin, int CoutA, int CoutB, int poolB, int H, int W) {
+  return Cin == 8 && CoutA == 16 && CoutB == 16 && poolB == 2 && H > 0 && W > 0 && H % wino::TS == 0 && W % wino::TS == 0;
+}
+
+extern "C" int ra_conv_pair_wino_f32(const float *x, int B, int H, int W, const float *wpA, const float *scaleA,
+                                     const float *shiftA, int reluA, const float *wpB_wino, const float *scaleB,
+                                     const float *shiftB, int reluB, float *y, void *stream) {
+  if (!x || !wpA || !scaleA || !shiftA || !wpB_wino || !scaleB || !shiftB || !y || B <= 0)
+    return fail(RA_E_INVALID, "ra_conv_pair_wino_f32: bad argument");
+  if (!ra_conv_pair_wino_supported(8, 16, 16, 2, H, W)) return fail(RA_E_SHAPE, "ra_conv_pair_wino_f32: %dx%d", H, W);
+  const size_t bytes = (size_t)B * H * W * 8 * sizeof(float);
+  if (bytes >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_pair_wino_f32: input exceeds 2 GiB");
+  wino::PWArgs a;
+  a.x = x;
+  a.wpA = wpA;
+  a.scA = scaleA;
+  a.shA = shiftA;
+  a.wpB = wpB_wino;
+  a.scB = scaleB;
+  a.shB = shiftB;
+  a.y = y;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.CoutAP = ra_conv_cout_padded(16);
+  a.reluA = reluA;
+  a.reluB = reluB;
+  a.bytes_x = (int)bytes;
+  static int tsy = 0;  // RA_PAIRW_TSY=16: tuning aid
+  if (!tsy) {
+    const char *e = getenv("RA_PAIRW_TSY");
+    tsy = (e && atoi(e) == 16) ? 16 : 8;  // 8-row tiles: 128 VGPRs and 24 KB of LDS, 4 workgroups per CU (39.1 vs 42.5 us)
+  }
+  return tsy == 8 ? wino::launch_pair<8>(a, as_stream(stream)) : wino::launch_pair<16>(a, as_stream(stream));
 }

@@ -51,6 +51,7 @@ class DecodeEngine(object):
     # ... also where that splits a fused pair (the 16 -> 16 layer of L2+L3)?  Measured at cfg2: L2 direct 20.6 +
     # L3 Winograd 22.2 us against 41.8 us fused: no gain, one more launch -> off
     self.wino_unfuse = False
+    self.pair_wino = True  # the fused L2+L3 pair with its second layer as Winograd (K1pw)
     self.use_wino = True  # controller-CNN layers with Cin 16 | 32, Cout % 32 == 0 as Winograd F(2x2,3x3) (K1w)
     self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
     self.fill_cache_inline = True  # ... by the first timestep's own launch (else: a separate kernel)
@@ -499,6 +500,11 @@ class DecodeEngine(object):
           ops.conv_pair_fill_cache(src, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, cache, bufs[step[2]])
         elif cache is not None and pl is not None:
           ops.conv_pair_cached(cache, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, bufs[step[2]])
+        elif (self.use_wino and self.pair_wino and layers is self.W.get('ccnn') and pl is None and
+              self.W['ccnn_wino'][step[2]] is not None and
+              ops.conv_pair_wino_supported(src.shape[3], ca, cb, poolb, src.shape[1], src.shape[2])):
+          # K1pw: layer B as Winograd straight from the LDS tile layer A was written to
+          ops.conv_pair_wino(src, wpa, sca[tt], sha[tt], self.W['ccnn_wino'][step[2]], scb[tt], shb[tt], out=bufs[step[2]])
         else:
           ops.conv_pair(src, wpa, sca[tt], sha[tt], ca, wpb, scb[tt], shb[tt], cb, poolB=poolb,
                         out=bufs[step[2]], plane=pl, plane_chan=pc if pl is not None else -1)

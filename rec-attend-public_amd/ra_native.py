@@ -109,6 +109,8 @@ SIGNATURES = {
     'ra_conv_wino_packed_floats': (_Z, [_I, _I]),
     'ra_conv_wino_pack_weights': (_I, [_P, _I, _I, _P]),
     'ra_conv_wino_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'ra_conv_pair_wino_supported': (_I, [_I, _I, _I, _I, _I, _I]),
+    'ra_conv_pair_wino_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     'ra_gauss_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_gauss_filter_bwd_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'ra_lstm_cell_f32': (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),

@@ -196,6 +196,21 @@ def conv_wino(x, wp, scale, shift, cout, relu=True, pool=1, out=None):
   return out
 
 
+def conv_pair_wino_supported(cin, cout_a, cout_b, pool_b, H, W):
+  return bool(rn.lib().ra_conv_pair_wino_supported(int(cin), int(cout_a), int(cout_b), int(pool_b), int(H), int(W)))
+
+
+def conv_pair_wino(x, wpA, scA, shA, wpB_wino, scB, shB, reluA=True, reluB=True, out=None):
+  """The fused pair 8 -> 16 -> 16, pool 2, with layer B as Winograd (ra_conv_pair_wino_f32).  x [B,H,W,8]."""
+  _need_cuda(x, wpA, scA, shA, wpB_wino, scB, shB, out)
+  B, H, W, _ = x.shape
+  if out is None:
+    out = torch.empty((B, H // 2, W // 2, 16), dtype=torch.float32, device=x.device)
+  check(rn.lib().ra_conv_pair_wino_f32(ptr(x), B, H, W, ptr(wpA), ptr(scA), ptr(shA), int(reluA), ptr(wpB_wino), ptr(scB),
+                                       ptr(shB), int(reluB), ptr(out), rn.stream_ptr()), 'ra_conv_pair_wino_f32')
+  return out
+
+
 def poison_lds():
   """Test aid: leave NaN in every CU's LDS (see ra_debug_poison_lds)."""
   check(rn.lib().ra_debug_poison_lds(rn.stream_ptr()), 'ra_debug_poison_lds')

@@ -573,3 +573,32 @@ def test_conv_winograd(cuda, B, H, W, Ci, Co, pool, relu):
     ref = ora.relu(ref) if relu else ref
     ref = ora.max_pool(ref, pool) if pool > 1 else ref
     assert relerr(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 32, 48), (1, 16, 16), (8, 256, 256)])
+def test_conv_pair_winograd(cuda, B, H, W):
+  """ra_conv_pair_wino_f32 (8 -> 16 -> 16, pool 2; layer B as Winograd from the LDS tile) against the
+  direct fused pair on the same inputs and, at the small sizes, the float64 oracle."""
+  rng = np.random.RandomState(B + H + W)
+  x = rng.randn(B, H, W, 8).astype(np.float32)
+  wA = (rng.randn(3, 3, 8, 16) / np.sqrt(72)).astype(np.float32)
+  wB = (rng.randn(3, 3, 16, 16) / np.sqrt(144)).astype(np.float32)
+  bA, bB = rng.randn(16).astype(np.float32) * 0.1, rng.randn(16).astype(np.float32) * 0.1
+  mk = lambda: tuple(a.astype(np.float32) for a in (rng.randn(16) * 0.2, rng.uniform(0.5, 1.5, 16) * rng.choice([-1, 1], 16),
+                                                     rng.randn(16) * 0.2, rng.uniform(0.5, 1.5, 16)))
+  bnA, bnB = mk(), mk()
+  scA, shA = [dev(a, cuda) for a in ops.fold_bn(bA, 16, bnA)]
+  scB, shB = [dev(a, cuda) for a in ops.fold_bn(bB, 16, bnB)]
+  assert ops.conv_pair_wino_supported(8, 16, 16, 2, H, W) and not ops.conv_pair_wino_supported(8, 16, 16, 1, H, W)
+  xd, wpa = dev(x, cuda), dev(ops.pack_conv_weights(wA), cuda)
+  ops.poison_lds()
+  y = ops.conv_pair_wino(xd, wpa, scA, shA, dev(ops.pack_wino_weights(wB), cuda), scB, shB)
+  direct = ops.conv_pair(xd, wpa, scA, shA, 16, dev(ops.pack_conv_weights(wB), cuda), scB, shB, 16, poolB=2)
+  torch.cuda.synchronize()
+  y, direct = y.cpu().numpy(), direct.cpu().numpy()
+  assert y.shape == direct.shape == (B, H // 2, W // 2, 16)
+  assert relerr(y, direct) < 2e-5
+  if B * H * W <= 8192:
+    h = ora.relu(ora.batch_norm_eval(ora.conv2d(x.astype(np.float64), wA.astype(np.float64)) + bA, *[a.astype(np.float64) for a in bnA]))
+    ref = ora.relu(ora.batch_norm_eval(ora.conv2d(h, wB.astype(np.float64)) + bB, *[a.astype(np.float64) for a in bnB]))
+    assert relerr(y, ora.max_pool(ref, 2)) < 2e-5
