@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
 // output transform finishes in registers: no LDS exchange, no barrier inside phase B, the 16 patch values
 // of a (tile, channel) are read once instead of twice, and the pooled result is stored straight from the
 // accumulator layout (lane = output channel, 4 tiles per lane).  Tile 16 x 16 (4 row blocks = 4 waves).
-__global__ __launch_bounds__(256, 3) void conv_pair_wino2_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, 2) void conv_pair_wino2_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
   constexpr int TSY = 16, CINA = 8, CMID = 16, KK = CMID / 4, S = CMID + 2;
   constexpr int AWY = TSY + 2, IWY = TSY + 4, IWX = TS + 4;
   constexpr int NPA = AWY * WS, NGA = (NPA + 15) / 16, GPW = (NGA + 3) / 4;
@@ -471,6 +471,8 @@ __global__ __launch_bounds__(256, 3) void conv_pair_wino2_mfma(const PWArgs a, i
     for (int cg = 0; cg < 2; ++cg) bA[tap][cg] = a.wpA[(size_t)((tap * 2 + cg) * 4 + ksub) * a.CoutAP + m];
   const float scA = a.scA[m], shA = a.shA[m];
   const float loA = a.reluA ? 0.f : -__builtin_inff();
+  // layer B's whole transformed filter: 64 VGPRs, live across phase A (244 VGPRs in all, two workgroups per CU).
+  // From LDS instead (16 KB, one ds_read per MFMA) the kernel fits 168 VGPRs but spills and loses: 41.0 vs 37.8 us.
   float bw[4][4][KK];  // [p][q][kk]
 #pragma unroll
   for (int pp = 0; pp < 4; ++pp)
@@ -567,34 +569,24 @@ __global__ __launch_bounds__(256, 3) void conv_pair_wino2_mfma(const PWArgs a, i
 
     {  // ---------------- phase B: this wave's row block, all four transform rows, in registers ----------------
       f32x4 y00 = f32x4{0.f, 0.f, 0.f, 0.f}, y01 = y00, y10 = y00, y11 = y00;
-      f32x4 acc[4][4];  // [p][q]
 #pragma unroll
-      for (int pp = 0; pp < 4; ++pp)
+      for (int pp = 0; pp < 4; ++pp) {  // transform row p: patch rows (ra, rb), r_j = d[ra][j] + sg * d[rb][j]
+        constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
+        const float sg = pp == 1 ? 1.f : -1.f;
+        f32x4 acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[pp][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        float d[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[i][j] = pd[(i * WS + j) * S + 4 * kk];
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
+        for (int kk = 0; kk < KK; ++kk) {
           float r[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            r[j] = pp == 0 ? d[0][j] - d[2][j] : pp == 1 ? d[1][j] + d[2][j] : pp == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
+          for (int j = 0; j < 4; ++j) r[j] = pd[(RA[pp] * WS + j) * S + 4 * kk] + sg * pd[(RB[pp] * WS + j) * S + 4 * kk];
           const float v[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[pp][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[pp][q][kk], acc[pp][q], 0, 0, 0);
+          for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[pp][q][kk], acc[q], 0, 0, 0);
         }
-      }
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        const f32x4 t0 = acc[pp][0] + acc[pp][1] + acc[pp][2];
-        const f32x4 t1 = acc[pp][1] - acc[pp][2] - acc[pp][3];
+        const f32x4 t0 = acc[0] + acc[1] + acc[2];
+        const f32x4 t1 = acc[1] - acc[2] - acc[3];
         if (pp < 3) {
           y00 += t0;
           y01 += t1;
