@@ -5,7 +5,7 @@ profiles/r01_pmc_encoder_traffic.json.
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <REPS>
        <images> <size> <out.json> [kernel-substring,kernel-substring,...]
 The optional last argument selects the kernels of the group (default: the controller-CNN kernels
-ra::conv:: / ra::cpair::; e.g. "ra::attnd::" for the extract + paste pair).
+ra::conv:: / ra::cpair:: / ra::wino::; e.g. "ra::attnd::" for the extract + paste pair).
 
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  Per MI355X_MICROARCH.md (HBM section) gfx950's
 FETCH_SIZE tallies 128-B requests as 64 B, so it is doubled; WRITE_SIZE is taken as is.  Only the
@@ -16,7 +16,7 @@ last REPS x launches_per_group dispatches of the run.
 import csv, json, sys
 
 
-KEYS = ['ra::conv::', 'ra::cpair::']
+KEYS = ['ra::conv::', 'ra::cpair::', 'ra::wino::']
 
 
 def tail_sum(path, counter, reps):
