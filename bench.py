@@ -244,8 +244,9 @@ def bench_other(args, rank, world, name):
         'config': {'workload': '%s: %s' % (name, c['what']), 'arch': c['arch'], 'H': H, 'W': W, 'T': T,
                    'batch_per_gpu': B, 'stages': list(c['stages']), 'parts_per_batch': parts,
                    'parts_in_flight': depth * len(pipes),
-                   'controller': 'split (16 workgroups per image)' if 'ctrl_ws' in pipes[-1][1].slots[0][0].subs[0]
-                   else 'single workgroup per image'}}))
+                   'controller': ('group-shared (16 workgroups per 8 images)' if pipes[-1][1].slots[0][0].subs[0].get('ctrl_batch')
+                                  else 'split (16 workgroups per image)' if 'ctrl_ws' in pipes[-1][1].slots[0][0].subs[0]
+                                  else 'single workgroup per image')}}))
   if world > 1:
     ra_dist.barrier()
     torch.distributed.destroy_process_group()
@@ -309,7 +310,7 @@ def main():
   ap.add_argument('--no-ctrl-split', action='store_true', help='tuning aid: one-workgroup-per-image controller')
   ap.add_argument('--in-flight', type=int, default=0,
                   help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other; '
-                       'default: 4 at cfg2, 8 at cfg3 over its two stages, 2 at cfg5)')
+                       'default: 4 at cfg2, 6 at cfg3 over its two stages, 2 at cfg5)')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
   ap.add_argument('--no-fuse-score', action='store_true', help='tuning aid: score MLP as its own launch')
   ap.add_argument('--host-output', action='store_true',
@@ -333,7 +334,7 @@ def main():
                        'data-parallel, one RCCL all-reduce of the gradient bucket per step); prints its own JSON line')
   args = ap.parse_args()
   if args.in_flight <= 0:
-    args.in_flight = {'cfg2': 4, 'cfg3': 8, 'cfg5': 2}[args.config]
+    args.in_flight = {'cfg2': 4, 'cfg3': 6, 'cfg5': 2}[args.config]
 
   import ra_dist
   if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus > 1:
@@ -607,6 +608,12 @@ def main():
           eng.desc, sb['ccnn'][-1], Wt['ctrl_split'], sb['h_last'][0], sb['ctrl_out'][0],
           sb['gmaps'][0], sb['attn'][0], sb['ctrl_ws'], sb['ctrl_status']))
       out['controller_status'] = int(sb['ctrl_status'].item())
+      if pipe.slots and pipe.slots[0][0].subs[0].get('ctrl_batch'):  # the form the pipeline's slots run
+        ps = pipe.slots[0][0].subs[0]
+        out['controller_us_in_slots'] = graph_time_us(lambda: ops.controller_batch(
+            eng.desc, ps['ccnn'][-1], pipe.slots[0][0].W['ctrl_split'], ps['h_last'][0], ps['ctrl_out'][0], ps['gmaps'][0],
+            ps['attn'][0], ps['ctrl_ws'], ps['ctrl_status']))
+        out['controller_in_slots'] = 'group-shared (K2b: 16 workgroups per 8 images)'
     else:
       out['controller_us'] = graph_time_us(lambda: ops.controller(
           eng.desc, sb['ccnn'][-1], Wt['ctrl'], sb['h_last'][0], sb['ctrl_out'][0], sb['gmaps'][0],

@@ -227,6 +227,17 @@ int ra_ctrl_split_pack_weights(const ra_ctrl_desc *d, const float *const *lstm_w
 int ra_controller_split_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
                             float *h_last, float *ctrl_out, float *glimpse_maps, float *attn,
                             void *ws, size_t ws_bytes, int *status_dev, void *stream);
+/* K2b: the split controller with its 16 weight slices shared by groups of 8 images (16 workgroups per
+ * GROUP instead of per image; weights packed exactly as for ra_controller_split_f32).  Results equal
+ * ra_controller_split_f32's to float32 round-off; a launch is ceil(B / 8) * 16 workgroups, so several
+ * launches from different streams are resident together (ra_controller_split_f32 beside its own kind
+ * can starve: its spinning workgroups hold the CUs their peers wait for).  ws: zero-filled,
+ * ra_ctrl_batch_workspace_bytes(), owned by one stream of launches; status_dev as above. */
+int ra_ctrl_batch_supported(const ra_ctrl_desc *d);
+size_t ra_ctrl_batch_workspace_bytes(const ra_ctrl_desc *d, int B);
+int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
+                            float *h_last, float *ctrl_out, float *glimpse_maps, float *attn, void *ws,
+                            size_t ws_bytes, int *status_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * K3/K5  Gaussian attention.  Replaces modellib.get_gaussian_filter (modellib.py:581-612),

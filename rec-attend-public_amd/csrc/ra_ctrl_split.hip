@@ -382,6 +382,325 @@ int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, flo
   return launch_status("ra_controller_split_f32");
 }
 
+// -------------------------------------------------------------------------------------------------
+// K2b — the same recurrence with the 16 weight slices shared by a GROUP of up to kNI images: 16 workgroups
+// per group instead of 16 per image.  A launch of 8 images is 16 workgroups, so four decode pipelines'
+// controllers (or cfg3's 16-image batches: two groups) are resident together many times over — the
+// co-residency that the per-image form cannot guarantee beside its own kind — and every
+// weight is read from LDS once for all images of the group.  Per glimpse iteration the workgroups
+// exchange the glimpses (each image's soft-attention read-out is computed by ONE workgroup, from the
+// feature map it keeps in registers), h, the MLP hidden vector and the logits: 4 all-gathers of
+// {tag, value} granules instead of 3.
+constexpr int kNI = 8;
+
+__host__ __device__ inline size_t granules_per_group(const ra_ctrl_desc &d) {
+  const Layout L = layout(d);
+  return (size_t)d.iters * kNI * (d.Cf + d.hid + (size_t)L.n_hidden * d.hid + (size_t)kP * L.gs);
+}
+__host__ __device__ inline size_t ws_words_per_group(const ra_ctrl_desc &d) { return 2 + 2 * granules_per_group(d); }
+
+__host__ inline size_t batch_lds_bytes(const ra_ctrl_desc &d) {
+  const Layout L = layout(d);
+  return (L.slice + (size_t)kThreads * kNI + (size_t)kNI * round_up(L.K, 4) + (size_t)kNI * d.hid +
+          (size_t)kNI * round_up(kP * L.gs, 4) + 64) * sizeof(float);
+}
+
+__host__ inline int batch_supported(const ra_ctrl_desc &d) {
+  if (!supported(d)) return 0;
+  const Layout L = layout(d);
+  int gsp = 1;
+  while (gsp < L.gs) gsp <<= 1;
+  if (gsp > 64 || L.us * kNI > kThreads || d.Cf > kThreads) return 0;
+  return batch_lds_bytes(d) <= 160 * 1024;
+}
+
+// n values per image, images i < nimg: granule (i * n + j) -> dst[i * stride + j].  A thread owns up to 8
+// granules per pass and polls them TOGETHER (all loads in flight, then the tag checks): polled one after
+// the other, eight L2 round trips per gather made the kernel slower than the one-workgroup form.
+__device__ inline void gather_multi(const u64 *g, int n, int nimg, unsigned tag, float *dst, int stride, int *err) {
+  const int total = n * nimg;
+  for (int base = 0; base < total; base += kThreads * 8) {
+    unsigned pending = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (base + threadIdx.x + kThreads * j < total) pending |= 1u << j;
+    unsigned spins = 0;
+    while (pending) {
+      u64 x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (pending & (1u << j))
+          x[j] = __hip_atomic_load(g + base + threadIdx.x + kThreads * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((pending & (1u << j)) && (unsigned)(x[j] >> 32) == tag) {
+          const int e = base + threadIdx.x + kThreads * j;
+          const int i = e / n, c = e - i * n;
+          dst[i * stride + c] = __uint_as_float((unsigned)x[j]);
+          pending &= ~(1u << j);
+        }
+      if (pending) {
+        if (++spins > kSpinLimit) {
+          *err = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// out[i][col] = sum_k x[i][k] * W[k][col] for the images of the group; ncol a power of two <= 64, n real columns;
+// threads = (col, k-part), a part walks quads of consecutive k (one 16-byte LDS read of x per image and quad);
+// xs and K multiples of 4 (K: the tail is zero-padded by the caller's layout or handled below);
+// result in red[(part * kNI + i) * ncol + col], returns parts.
+__device__ inline int gemv_multi(const float *W, int n, int ncol, const float *x, int xs, int K, float *red) {
+  const int t = threadIdx.x, parts = kThreads / ncol;
+  const int col = t % ncol, part = t / ncol;
+  float acc[kNI];
+#pragma unroll
+  for (int i = 0; i < kNI; ++i) acc[i] = 0.0f;
+  if (col < n) {
+    const int K4 = K & ~3;
+    for (int k = 4 * part; k < K4; k += 4 * parts) {
+      const float w0 = W[(size_t)k * n + col], w1 = W[(size_t)(k + 1) * n + col], w2 = W[(size_t)(k + 2) * n + col],
+                  w3 = W[(size_t)(k + 3) * n + col];
+#pragma unroll
+      for (int i = 0; i < kNI; ++i) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + i * xs + k);
+        acc[i] += xv.x * w0 + xv.y * w1 + xv.z * w2 + xv.w * w3;
+      }
+    }
+    if (part == 0)
+      for (int k = K4; k < K; ++k) {
+        const float w = W[(size_t)k * n + col];
+#pragma unroll
+        for (int i = 0; i < kNI; ++i) acc[i] += x[i * xs + k] * w;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < kNI; ++i) red[(part * kNI + i) * ncol + col] = acc[i];
+  __syncthreads();
+  return parts;
+}
+
+template <int FR>
+__global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctrl_desc d, const float *feat,
+                                                                    const float *__restrict__ wp, int B, float *h_last,
+                                                                    float *ctrl_out, float *gmaps, float *attn,
+                                                                    unsigned *ws, int *status) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Layout L = layout(d);
+  const int t = threadIdx.x, p = blockIdx.x, grp = blockIdx.y;
+  const int G = d.G, Cf = d.Cf, hid = d.hid, us = L.us, gs = L.gs, K = L.K;
+  const int Gx = kP * gs, Kp = round_up(K, 4), Gxp = round_up(Gx, 4);
+  const int b0 = grp * kNI, nimg = (B - b0 < kNI) ? B - b0 : kNI;
+  float *W = smem;                          // the slice
+  float *red = W + L.slice;                 // [256 * kNI]
+  float *xh = red + kThreads * kNI;         // [kNI][Kp]  = [glimpse ; h] per image
+  float *va = xh + kNI * Kp;                // [kNI][hid] hidden MLP vector
+  float *gm = va + kNI * hid;               // [kNI][Gxp] logits -> glimpse map
+  unsigned *wsg = ws + (size_t)grp * ws_words_per_group(d);
+  const unsigned tag = wsg[0] + 1u;
+  u64 *gran = reinterpret_cast<u64 *>(wsg + 2);
+  int err = 0;
+
+  {  // weight slice -> LDS (stays for the whole launch)
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(wp + (size_t)p * L.slice);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(W);
+    const int n4 = (int)(L.slice / 4);
+    constexpr int U = 16;
+    for (int e0 = t; e0 < n4; e0 += kThreads * U) {
+      f32x4 tmp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * kThreads;
+        tmp[u] = src[e < n4 ? e : n4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < n4) dst[e] = tmp[u];
+      }
+    }
+  }
+  // this workgroup reads out the glimpse of image `mine` (the first nimg workgroups publish theirs)
+  const int mine = p % nimg;
+  float fr[FR];
+  const float *fsrc = feat + (size_t)(b0 + mine) * G * Cf;
+#pragma unroll
+  for (int i = 0; i < FR; ++i) {
+    const int e = t + kThreads * i;
+    fr[i] = (e < G * Cf) ? fsrc[e] : 0.0f;
+  }
+  for (int e = t; e < kNI * Kp; e += kThreads) xh[e] = 0.0f;  // h = 0 (and defined glimpse slots)
+  for (int e = t; e < kNI * Gxp; e += kThreads) gm[e] = ((e % Gxp) < G) ? 1.0f / (float)G : 0.0f;
+  float cst = 0.0f;  // cell state of (image t / us, unit p * us + t % us), threads t < us * kNI
+  const int ci = t / us, cu = t % us;
+  __syncthreads();
+
+  size_t goff = 0;
+  for (int it = 0; it < d.iters; ++it) {
+    if (gmaps && p == 0)
+      for (int e = t; e < nimg * G; e += kThreads) {
+        const int i = e / G, g = e - i * G;
+        gmaps[((size_t)(b0 + i) * d.iters + it) * G + g] = gm[i * Gxp + g];
+      }
+    {  // ---- glimpse of image `mine` from registers ----
+      const int g0 = t / Cf, gstep = kThreads / Cf;
+      const float *gmm = gm + mine * Gxp;
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < FR; ++i) {
+        const int g = g0 + gstep * i;
+        s += fr[i] * ((g < G) ? gmm[g] : 0.0f);
+      }
+      red[t] = s;
+      __syncthreads();
+      if (t < Cf && p < nimg) {
+        float a = 0.0f;
+        for (int q = 0; q < gstep; ++q) a += red[q * Cf + t];
+        publish(gran + goff + (size_t)mine * Cf + t, tag, a);
+      }
+      __syncthreads();
+    }
+    gather_multi(gran + goff, Cf, nimg, tag, xh, Kp, &err);
+    goff += (size_t)kNI * Cf;
+    // ---- LSTM slice, all images ----
+    {
+      const int parts = gemv_multi(W + L.lstm_w, L.NL, L.NL, xh, Kp, (it == 0) ? Cf : K, red);
+      if (t < us * kNI && ci < nimg) {
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float a = W[L.lstm_b + g * us + cu];
+          for (int q = 0; q < parts; ++q) a += red[(q * kNI + ci) * L.NL + g * us + cu];
+          pre[g] = a;
+        }
+        const float gi = sigm(pre[0]), gf = sigm(pre[1]), go = sigm(pre[2]), u = tanhf(pre[3]);
+        cst = gf * cst + gi * u;
+        publish(gran + goff + (size_t)ci * hid + p * us + cu, tag, go * tanhf(cst));
+      }
+    }
+    gather_multi(gran + goff, hid, nimg, tag, xh + Cf, Kp, &err);
+    goff += (size_t)kNI * hid;
+    if (it == d.iters - 1) break;
+    // ---- glimpse MLP hidden layers (relu) ----
+    const float *in = xh + Cf;
+    int ins = Kp;
+    for (int l = 0; l < L.n_hidden; ++l) {
+      const int parts = gemv_multi(W + L.gh_w[l], us, us, in, ins, hid, red);
+      if (t < us * kNI && ci < nimg) {
+        float a = W[L.gh_b[l] + cu];
+        for (int q = 0; q < parts; ++q) a += red[(q * kNI + ci) * us + cu];
+        publish(gran + goff + (size_t)ci * hid + p * us + cu, tag, fmaxf(a, 0.0f));
+      }
+      gather_multi(gran + goff, hid, nimg, tag, va, hid, &err);
+      goff += (size_t)kNI * hid;
+      in = va;
+      ins = hid;
+    }
+    {  // ---- logits slice, gathered; softmax over G per image, two images per wave ----
+      int ncol = 1;
+      while (ncol < gs) ncol <<= 1;
+      const int parts = gemv_multi(W + L.gl_w, gs, ncol, in, ins, hid, red);
+      const int li = t / ncol, lu = t % ncol;  // (image, logit) for the first ncol * kNI threads
+      if (t < ncol * kNI && li < nimg && lu < gs) {
+        float a = W[L.gl_b + lu];
+        for (int q = 0; q < parts; ++q) a += red[(q * kNI + li) * ncol + lu];
+        publish(gran + goff + (size_t)li * Gx + p * gs + lu, tag, a);
+      }
+      gather_multi(gran + goff, Gx, nimg, tag, gm, Gxp, &err);
+      goff += (size_t)kNI * Gx;
+      const int wave = t >> 6, lane = t & 63;
+      for (int i = wave; i < nimg; i += kThreads / 64) {
+        float *gi = gm + i * Gxp;
+        float mx = -3.0e38f;
+        for (int g = lane; g < G; g += 64) mx = fmaxf(mx, gi[g]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.0f;
+        for (int g = lane; g < G; g += 64) sum += expf(gi[g] - mx);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int g = lane; g < Gx; g += 64) gi[g] = (g < G) ? expf(gi[g] - mx) / sum : 0.0f;
+      }
+      __syncthreads();
+    }
+  }
+
+  if (p < nimg) {
+    // ---- controller MLP + attention decode of image p (weights from L2) ----
+    const int b = b0 + p;
+    const float *in = xh + p * Kp + Cf;
+    float *o1 = va + p * hid, *o2 = red;  // va row p is this workgroup's own; red is free now
+    for (int l = 0; l < d.n_cmlp; ++l) {
+      const int N = L.cm_out[l], Kin = L.cm_in[l];
+      const float *Wc = wp + L.cm_w[l], *bc = wp + L.cm_b[l];
+      const bool last = (l == d.n_cmlp - 1);
+      int ncol;
+      float *scratch = gm;  // [4 * 256] <= kNI * Gxp floats: the maps are no longer needed
+      const int parts = any_gemv(Wc, N, in, Kin, scratch, &ncol);
+      if (t < N) {
+        float a = bc[t];
+        for (int q = 0; q < parts; ++q) a += scratch[q * ncol + t];
+        o1[t] = last ? a : fmaxf(a, 0.0f);
+      }
+      __syncthreads();
+      in = o1;
+      float *tmp = o1;
+      o1 = o2;
+      o2 = tmp;
+    }
+    const float *co = in;
+    if (t < hid && h_last) h_last[(size_t)b * hid + t] = xh[p * Kp + Cf + t];
+    if (t < 9 && ctrl_out) ctrl_out[(size_t)b * 9 + t] = co[t];
+    if (t == 0 && attn) {
+      float *r = attn + (size_t)b * RA_ATTN_STRIDE;
+      float cn[2] = {co[0], co[1]}, ls[2] = {co[2], co[3]};
+      if (d.squash) {
+        cn[0] = tanhf(cn[0]);
+        cn[1] = tanhf(cn[1]);
+        ls[0] = -log1pf(expf(ls[0]));
+        ls[1] = -log1pf(expf(ls[1]));
+      }
+      const float dim[2] = {(float)d.H, (float)d.W}, fs[2] = {(float)d.Fh, (float)d.Fw};
+      for (int k = 0; k < 2; ++k) {
+        const float ctr = (cn[k] + 1.0f) * (dim[k] / 2.0f);
+        const float size = expf(ls[k]) * dim[k];
+        float lv = d.fixed_var ? 0.0f : logf(size) - logf(fs[k]);
+        if (d.dynamic_var) lv = co[4 + k];
+        r[0 + k] = ctr;
+        r[2 + k] = size;
+        r[4 + k] = lv;
+        r[9 + k] = cn[k];
+        r[11 + k] = ls[k];
+      }
+      r[6] = d.fixed_gamma ? 1.0f : expf(co[6]);
+      r[7] = expf(co[7]);
+      r[8] = d.fixed_gamma ? 2.0f : co[8];
+      r[13] = r[14] = r[15] = 0.0f;
+    }
+  }
+  // new generation for the next launch: workgroup 0 could not have finished its last gather unless every peer
+  // had published with this tag, i.e. had read wsg[0]
+  if (p == 0 && t == 0) __hip_atomic_store(wsg, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (err && status) atomicMax(status, 1);
+}
+
+template <int FR>
+int launch_batch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, float *h_last, float *ctrl_out,
+                 float *gmaps, float *attn, unsigned *ws, int *status, size_t lds, hipStream_t st) {
+  auto kern = controller_batch_kernel<FR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(kP, ceil_div(B, kNI)), dim3(kThreads), lds, st, d, feat, wp, B, h_last, ctrl_out, gmaps,
+                     attn, ws, status);
+  return launch_status("ra_controller_batch_f32");
+}
+
 }  // namespace ctrl2
 }  // namespace ra
 
@@ -464,4 +783,33 @@ extern "C" int ra_controller_split_f32(const ra_ctrl_desc *d, const float *feat,
   if (fr <= 64) RA_C2(64);
   RA_C2(96);
 #undef RA_C2
+}
+
+// ---- K2b: one group of 16 workgroups per 8 images (weights packed as for ra_controller_split_f32) ----
+extern "C" int ra_ctrl_batch_supported(const ra_ctrl_desc *d) { return d ? ctrl2::batch_supported(*d) : 0; }
+
+extern "C" size_t ra_ctrl_batch_workspace_bytes(const ra_ctrl_desc *d, int B) {
+  if (!d || B <= 0 || !ctrl2::batch_supported(*d)) return 0;
+  return (size_t)ceil_div(B, ctrl2::kNI) * ctrl2::ws_words_per_group(*d) * 4;
+}
+
+extern "C" int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
+                                       float *h_last, float *ctrl_out, float *glimpse_maps, float *attn, void *ws,
+                                       size_t ws_bytes, int *status_dev, void *stream) {
+  if (!d || !feat || !wpacked || !ws || B <= 0) return fail(RA_E_INVALID, "ra_controller_batch_f32: bad argument");
+  if (!ctrl2::batch_supported(*d)) return fail(RA_E_SHAPE, "ra_controller_batch_f32: unsupported descriptor");
+  if (ceil_div(B, ctrl2::kNI) * ctrl2::kP > 224)
+    return fail(RA_E_SHAPE, "ra_controller_batch_f32: B=%d exceeds co-residency (%d)", B, 14 * ctrl2::kNI);
+  if (ws_bytes < ra_ctrl_batch_workspace_bytes(d, B)) return fail(RA_E_WORKSPACE, "ra_controller_batch_f32: workspace");
+  const size_t lds = ctrl2::batch_lds_bytes(*d);
+  const int fr = ceil_div(d->G * d->Cf, ctrl2::kThreads);
+  hipStream_t st = as_stream(stream);
+  unsigned *w = reinterpret_cast<unsigned *>(ws);
+#define RA_C3(FR) return ctrl2::launch_batch<FR>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, status_dev, lds, st)
+  if (fr <= 4) RA_C3(4);
+  if (fr <= 16) RA_C3(16);
+  if (fr <= 32) RA_C3(32);
+  if (fr <= 64) RA_C3(64);
+  RA_C3(96);
+#undef RA_C3
 }

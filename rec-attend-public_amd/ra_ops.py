@@ -149,6 +149,25 @@ def controller_split(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
         'ra_controller_split_f32')
 
 
+def ctrl_batch_supported(desc):
+  return bool(rn.lib().ra_ctrl_batch_supported(C.byref(desc)))
+
+
+def ctrl_batch_workspace(desc, B, device):
+  """Zero-filled exchange workspace (+ status word) of the group-shared controller, for ONE stream of launches."""
+  nb = rn.lib().ra_ctrl_batch_workspace_bytes(C.byref(desc), B)
+  return (torch.zeros((nb + 7) // 8, dtype=torch.int64, device=device),
+          torch.zeros(1, dtype=torch.int32, device=device))
+
+
+def controller_batch(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
+  """K2b: ra_controller_split_f32's recurrence with the weight slices shared by groups of 8 images."""
+  _need_cuda(feat, wp, h_last, ctrl_out, gmaps, attn)
+  check(rn.lib().ra_controller_batch_f32(C.byref(desc), ptr(feat), ptr(wp), feat.shape[0], ptr(h_last), ptr(ctrl_out),
+                                         ptr(gmaps), ptr(attn), ptr(ws), ws.numel() * 8, ptr(status), rn.stream_ptr()),
+        'ra_controller_batch_f32')
+
+
 # ---------------------------------------------------------------------------- device ops
 
 

@@ -396,9 +396,10 @@ def test_decode_pipeline_box_model(cuda):
 
 
 def test_decode_pipeline_controller_policy(cuda):
-  """Slots decode with the 16-workgroup controller only if every launch that can run at the same
-  time fits the chip (depth x images x 16 <= 224); otherwise with the one-workgroup form, whose results
-  equal a lone run with engine.ctrl_split = False bit for bit and the split form's to round-off."""
+  """Slots decode with the per-image 16-workgroup controller only if every launch that can run at the same
+  time fits the chip (depth x images x 16 <= 224); otherwise with the group-shared form (K2b: 16 workgroups
+  per 8 images, resident many times over), whose results equal the per-image form's to round-off; and with
+  the one-workgroup form where neither fits."""
   import full_model
   opt = ora.make_opt('cvppp', 64, 64, 3)
   P = ora.random_params(opt, 9)
@@ -406,21 +407,27 @@ def test_decode_pipeline_controller_policy(cuda):
   feed = {'x': x, 'phase_train': False}
   m = full_model.get_model(opt).load_weights(P)
   split = m.run(['y_out', 's_out'], feed, as_numpy=True)
-  assert 'ctrl_ws' in m.engine.subs[0]
-  pipe = m.pipeline(4)  # 4 x 8 x 16 = 512 workgroups > 224
+  assert 'ctrl_ws' in m.engine.subs[0] and not m.engine.subs[0].get('ctrl_batch')
+  pipe = m.pipeline(4)  # 4 x 8 x 16 = 512 workgroups > 224; 4 x 16 = 64 in the group-shared form
   pipe.submit(['y_out', 's_out'], feed)
   got = pipe.collect(as_numpy=True)
-  assert 'ctrl_ws' not in pipe.slots[0][0].subs[0]
+  assert pipe.slots[0][0].subs[0].get('ctrl_batch')
+  for u, w in zip(got, split):
+    assert np.abs(u - w).max() < 1e-4
+  wide = m.pipeline(16)  # 16 x 16 = 256 > 224: the one-workgroup form
+  wide.submit(['y_out', 's_out'], feed)
+  got1 = wide.collect(as_numpy=True)
+  assert 'ctrl_ws' not in wide.slots[0][0].subs[0]
   m2 = full_model.get_model(opt).load_weights(P)
   m2.engine.ctrl_split = False
   single = m2.run(['y_out', 's_out'], feed, as_numpy=True)
-  for u, v, w in zip(got, single, split):
+  for u, v, w in zip(got1, single, split):
     assert np.array_equal(u, v)
     assert np.abs(u - w).max() < 1e-4
   small = m.pipeline(1)  # 1 x 8 x 16 = 128
   small.submit('y_out', feed)
   assert np.array_equal(small.collect(as_numpy=True), split[0])
-  assert 'ctrl_ws' in small.slots[0][0].subs[0]
+  assert 'ctrl_ws' in small.slots[0][0].subs[0] and not small.slots[0][0].subs[0].get('ctrl_batch')
 
 
 def test_decode_pipeline_to_host(cuda):

@@ -242,6 +242,59 @@ def test_controller_split(cuda, arch, H, W, flags):
     assert relerr(a[:, 2:4], size) < 1e-4 and np.abs(a[:, 4:6] - lv).max() < 1e-4
 
 
+@pytest.mark.parametrize('arch,H,W,flags,B', [
+    ('cvppp', 128, 128, {}, 5),
+    ('cvppp', 224, 224, {'squash_ctrl_params': True}, 8),   # G = 49 -> gs = 4, padded logits
+    ('kitti', 128, 448, {}, 16),                             # two groups of 8
+    ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2}, 11),  # groups of 8 + 3
+    ('cvppp', 512, 512, {'num_glimpse_mlp_layers': 1}, 1),
+])
+def test_controller_batch(cuda, arch, H, W, flags, B):
+  """K2b, the split controller with its weight slices shared by groups of 8 images: the oracle's recurrence,
+  three launches on one workspace (generation tags), full and ragged groups, and agreement with the
+  per-image split form."""
+  opt = ora.make_opt(arch, H, W, 2, **flags)
+  d, P = _ctrl_setup(opt, 4)
+  Cf = d['ccnn_channels'][-1]
+  desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
+                            opt['ctrl_mlp_dim'], H, W, 48, 48, d['squash'], d['fixed_var'],
+                            d['dynamic_var'], d['fixed_gamma'])
+  assert ops.ctrl_batch_supported(desc)
+  # a third glimpse-MLP layer makes the slice + the group's vectors exceed 160 KB of LDS: reported, not attempted
+  big = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], 3, d['n_cmlp'], opt['ctrl_mlp_dim'], H, W, 48, 48,
+                           d['squash'], d['fixed_var'], d['dynamic_var'], d['fixed_gamma'])
+  if d['G'] * 4 >= 1024:  # (with few logits per slice the larger form still fits)
+    assert ops.ctrl_split_supported(big) and not ops.ctrl_batch_supported(big)
+  lstm = {k[len('ctrl_lstm_'):]: v for k, v in P.items() if k.startswith('ctrl_lstm_')}
+  gmw = [(P['glimpse_mlp_w_%d' % i], P['glimpse_mlp_b_%d' % i]) for i in range(d['n_gmlp'])]
+  cmw = [(P['ctrl_mlp_w_%d' % i], P['ctrl_mlp_b_%d' % i]) for i in range(d['n_cmlp'])]
+  wp = dev(ops.pack_ctrl_split_weights(desc, lstm, gmw, cmw), cuda)
+  ws, status = ops.ctrl_batch_workspace(desc, B, cuda)
+  P64 = {k: v.astype(np.float64) for k, v in P.items()}
+  z = lambda *s: torch.full(s, 7.0, dtype=torch.float32, device=cuda)
+  for rep in range(3):
+    rng = np.random.RandomState(70 + rep)
+    feat = np.maximum(rng.randn(B, d['G'], Cf), 0).astype(np.float32)
+    h, co, gm = ora._controller(d, P64, feat.astype(np.float64), np.dtype(np.float64))
+    cn, ls, ctr, size, lv = ora._decode_ctrl(d, co, np.dtype(np.float64))
+    h_last, ctrl_out, gmaps, attn = z(B, d['hid']), z(B, 9), z(B, d['iters'], d['G']), z(B, 16)
+    ops.controller_batch(desc, dev(feat, cuda), wp, h_last, ctrl_out, gmaps, attn, ws, status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    assert relerr(h_last.cpu().numpy(), h) < 5e-5
+    assert np.abs(ctrl_out.cpu().numpy() - co).max() < 5e-5
+    assert np.abs(gmaps.cpu().numpy() - gm).max() < 1e-5
+    a = attn.cpu().numpy()
+    assert np.abs(a[:, 0:2] - ctr).max() < 1e-3 * max(H, W) / 100
+    assert relerr(a[:, 2:4], size) < 1e-4 and np.abs(a[:, 4:6] - lv).max() < 1e-4
+  if B <= 14:
+    ws2, st2 = ops.ctrl_split_workspace(desc, B, cuda)
+    h2, c2, g2, a2 = z(B, d['hid']), z(B, 9), z(B, d['iters'], d['G']), z(B, 16)
+    ops.controller_split(desc, dev(feat, cuda), wp, h2, c2, g2, a2, ws2, st2)
+    torch.cuda.synchronize()
+    assert np.abs(c2.cpu().numpy() - ctrl_out.cpu().numpy()).max() < 2e-5
+
+
 def _attn_rec(B, H, W, rng, big_var=False):
   rec = np.zeros((B, 16), np.float32)
   rec[:, 0] = rng.uniform(0.1, 0.9, B) * H
