@@ -391,7 +391,11 @@ int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, flo
 // exchange the glimpses (each image's soft-attention read-out is computed by ONE workgroup, from the
 // feature map it keeps in registers), h, the MLP hidden vector and the logits: 4 all-gathers of
 // {tag, value} granules instead of 3.
-constexpr int kNI = 8;
+#ifndef RA_CTRL_NI
+#define RA_CTRL_NI 8
+#endif
+constexpr int kNI = RA_CTRL_NI;  // images per group.  4 (-DRA_CTRL_NI=4): 88.9 instead of 112.6 us per launch at cfg2, the same
+                                 // pipelined rate, and twice the workgroups to keep resident -> 8
 
 __host__ __device__ inline size_t granules_per_group(const ra_ctrl_desc &d) {
   const Layout L = layout(d);
