@@ -307,6 +307,7 @@ def main():
   ap.add_argument('--wino-unfuse', action='store_true', help='tuning aid: L2 direct + L3 Winograd instead of the fused L2+L3 pair')
   ap.add_argument('--no-pair-wino', action='store_true', help='tuning aid: direct second layer in the fused L2+L3 pair')
   ap.add_argument('--no-wino', action='store_true', help='tuning aid: direct conv for every controller-CNN layer')
+  ap.add_argument('--fuse-patch-pairs', action='store_true', help='tuning aid: fused two-layer launches in the patch-sized nets too')
   ap.add_argument('--no-ctrl-split', action='store_true', help='tuning aid: one-workgroup-per-image controller')
   ap.add_argument('--in-flight', type=int, default=0,
                   help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other; '
@@ -355,6 +356,7 @@ def main():
   eng.fuse_score = not args.no_fuse_score
   eng.ctrl_split = not args.no_ctrl_split
   eng.use_wino = not args.no_wino
+  eng.fuse_patch_pairs = args.fuse_patch_pairs
   eng.wino_unfuse = args.wino_unfuse
   eng.pair_wino = not args.no_pair_wino
   eng.fuse_patchnet = args.fuse_patchnet
