@@ -13,6 +13,7 @@ TrainStep scales it.  BatchNorm batch moments (nnlib.py:98) are all-reduced sepa
 (allreduce_moments) so that the normalisation equals the single-process one too.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -530,6 +531,7 @@ class TrainStep(object):
     return tuple(g[n] for n in names)
 
   fuse_param_grads = True
+  match_side_stream = os.environ.get('RA_MATCH_SIDE', '1') != '0'  # the box matching under the mask matching (one fork / join)
 
   def _cnn(self, x, scope, n, pools, tt, cmap0, stats):
     P, hs = self.leaves, []
@@ -768,13 +770,17 @@ class TrainStep(object):
     statuses = []
     # the two matchings are independent and each is one wave per image for milliseconds (dense soft-IoU
     # matrices early in training): the box matching runs on a side stream under the mask matching
-    cur = torch.cuda.current_stream()
-    side = _side_stream(dev)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
+    if self.match_side_stream:
+      cur = torch.cuda.current_stream()
+      side = _side_stream(dev)
+      side.wait_stream(cur)
+      with torch.cuda.stream(side):
+        iou_box, m_box = matched_iou(attn_box, box_gt)
+      iou_soft, m = matched_iou(y_out, y_gt)
+      cur.wait_stream(side)
+    else:
       iou_box, m_box = matched_iou(attn_box, box_gt)
-    iou_soft, m = matched_iou(y_out, y_gt)
-    cur.wait_stream(side)
+      iou_soft, m = matched_iou(y_out, y_gt)
     box_loss, segm_loss = -iou_box, -iou_soft
     blf = opt.get('box_loss_fn', 'iou')
     if blf in ('mse', 'huber'):  # matched regression of (centre, log size) (full_model.py:891-892,952-964)
