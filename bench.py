@@ -424,6 +424,8 @@ def main():
   barrier()
   elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
   value = world * B * T * args.steps / elapsed
+  for eng_k, _ in pipe.slots:  # a controller workgroup that timed out on its peers would have produced garbage: fail loudly
+    eng_k.check_status()
 
   out = {
       'metric': 'instance-timesteps/sec, full_model forward 512x512 T=16 (whole job)',
