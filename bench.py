@@ -235,6 +235,9 @@ def bench_other(args, rank, world, name):
   drain()
   ra_dist.barrier()
   elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
+  for _, pipe in pipes:
+    for eng_k, _ in pipe.slots:
+      eng_k.check_status()
   if rank == 0:
     print(json.dumps({
         'metric': 'instance-timesteps/sec, %s (whole job)' % name, 'value': world * B * T * args.steps / elapsed,
