@@ -640,7 +640,7 @@ int launch_pair2(const PWArgs &a, hipStream_t st) {
 // register file holds max(A, B) instead of A + B, a SIMD carries four waves of a workgroup pair, and the two
 // phases of consecutive tiles overlap.  Two barriers per tile, executed by both roles (the B role runs one
 // tile behind and one iteration longer; the A role pads with an empty iteration).
-__global__ __launch_bounds__(512, 2) void conv_pair_wino3_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(512, 4) void conv_pair_wino3_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
   constexpr int TSY = 16, CINA = 8, CMID = 16, KK = CMID / 4, S = CMID + 2;
   constexpr int AWY = TSY + 2, IWY = TSY + 4, IWX = TS + 4;
   constexpr int NPA = AWY * WS, NGA = (NPA + 15) / 16, GPW = (NGA + 3) / 4;
@@ -675,16 +675,21 @@ __global__ __launch_bounds__(512, 2) void conv_pair_wino3_mfma(const PWArgs a, i
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
     f32x4 pre[NIT];
+    int e_r[NIT], e_c[NIT];  // this thread's staged items: window row / column (tile-invariant)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tr + 256 * i, pix = e >> 1;
+      e_r[i] = (e < NPI * 2) ? pix / IWX : -(1 << 20);  // never inside the image
+      e_c[i] = pix % IWX;
+    }
     auto fetch = [&](int T) {
       const int fb = T / per, fr = T - fb * per;
       const int fy0 = (fr / tiles_x) * TSY - 2, fx0 = (fr % tiles_x) * TS - 2;
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
-        const int e = tr + 256 * i, cg = e & 1, pix = e >> 1;
-        const int r = pix / IWX, c = pix - r * IWX;
-        const int Y = fy0 + r, X = fx0 + c;
-        const bool ok = (e < NPI * 2) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-        const int off = ok ? (((fb * a.H + Y) * a.W + X) * CINA + 4 * cg) * 4 : 0x7fffffff;
+        const int Y = fy0 + e_r[i], X = fx0 + e_c[i];
+        const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+        const int off = ok ? (((fb * a.H + Y) * a.W + X) * CINA + 4 * (tr & 1)) * 4 : 0x7fffffff;
         pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
       }
     };
@@ -709,34 +714,42 @@ __global__ __launch_bounds__(512, 2) void conv_pair_wino3_mfma(const PWArgs a, i
         const int oyA = ty * TSY - 1, oxA = tx * TS - 1;
         const bool interior = (oyA >= 0) & (oyA + AWY <= a.H) & (oxA >= 0) & (oxA + WS <= a.W);
         float *tin = tin0 + (it & 1) * TINF;
-        f32x4 acc[GPW];
+        constexpr int HG = (GPW + 1) / 2;  // two passes over the wave's groups: half the accumulators and operands live
+#pragma unroll 1
+        for (int s0 = 0; s0 < GPW; s0 += HG) {
+          f32x4 acc[HG];
+          int ai[HG];
 #pragma unroll
-        for (int s = 0; s < GPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int s = 0; s < HG; ++s) {
+            acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ai[s] = ain[s0 + s < GPW ? s0 + s : GPW - 1];
+          }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          f32x2 av[GPW];
+          for (int tap = 0; tap < 9; ++tap) {
+            f32x2 av[HG];
 #pragma unroll
-          for (int s = 0; s < GPW; ++s)
-            av[s] = *reinterpret_cast<const f32x2 *>(&tinp[ain[s] + ((tap / 3) * IWX + tap % 3) * CINA]);
+            for (int s = 0; s < HG; ++s)
+              av[s] = *reinterpret_cast<const f32x2 *>(&tinp[ai[s] + ((tap / 3) * IWX + tap % 3) * CINA]);
 #pragma unroll
-          for (int cg = 0; cg < 2; ++cg)
+            for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
-            for (int s = 0; s < GPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[tap][cg], acc[s], 0, 0, 0);
-        }
+              for (int s = 0; s < HG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[tap][cg], acc[s], 0, 0, 0);
+          }
 #pragma unroll
-        for (int s = 0; s < GPW; ++s) {
-          const int g = wv + 4 * s;
-          if (g < NGA) {
+          for (int s = 0; s < HG; ++s) {
+            const int g = wv + 4 * (s0 + s);
+            if (s0 + s < GPW && g < NGA) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int li = 16 * g + 4 * ksub + r;
-              float o = fmaxf(acc[s][r] * scA + shA, loA);
-              if (!interior) {
-                const int wr = li / WS, wc = li - wr * WS;
-                const int Y = oyA + wr, X = oxA + wc;
-                o = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o : 0.f;
+              for (int r = 0; r < 4; ++r) {
+                const int li = 16 * g + 4 * ksub + r;
+                float o = fmaxf(acc[s][r] * scA + shA, loA);
+                if (!interior) {
+                  const int wr = li / WS, wc = li - wr * WS;
+                  const int Y = oyA + wr, X = oxA + wc;
+                  o = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o : 0.f;
+                }
+                tin[li * S + m] = o;
               }
-              tin[li * S + m] = o;
             }
           }
         }
@@ -745,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_wino3_mfma(const PWArgs a, i
     }
   } else {
     // =============================== role B: Winograd layer B, one tile behind ===============================
-    float bw[4][4][KK];
+    float bw[4][4][KK];  // the whole transformed filter of layer B: 64 VGPRs, only this role carries them
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
@@ -794,6 +807,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_wino3_mfma(const PWArgs a, i
             y10 -= t0;
             y11 -= t1;
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -630,6 +630,22 @@ def test_conv_winograd(cuda, B, H, W, Ci, Co, pool, relu):
 
 @pytest.mark.parametrize('B,H,W', [(2, 32, 48), (1, 16, 16), (8, 256, 256)])
 def test_conv_pair_winograd(cuda, B, H, W):
+  _pair_winograd_case(cuda, B, H, W)
+
+
+def test_conv_pair_winograd_other_forms(cuda):
+  """The exchange-through-LDS form (1) and the role-split form (3) of the same kernel, in fresh processes
+  (the form is read from RA_PAIRW_FORM once per process)."""
+  import os, subprocess, sys
+  for form in ('1', '3'):
+    env = dict(os.environ, RA_PAIRW_FORM=form)
+    code = ('import sys; sys.path[:0] = %r; import torch, test_kernels_gpu as t; '
+            '[t._pair_winograd_case(torch.device("cuda"), *c) for c in ((2, 32, 48), (3, 64, 64))]; print("ok")' % (sys.path[:6],))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+def _pair_winograd_case(cuda, B, H, W):
   """ra_conv_pair_wino_f32 (8 -> 16 -> 16, pool 2; layer B as Winograd from the LDS tile) against the
   direct fused pair on the same inputs and, at the small sizes, the float64 oracle."""
   rng = np.random.RandomState(B + H + W)
