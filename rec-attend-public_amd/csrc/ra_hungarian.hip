@@ -21,12 +21,22 @@ namespace hung {
 constexpr int kMaxIter = 1000;  // MAX_NUM_ITERATION, hungarian.cc:20
 #define RA_HUNG_EPS 1e-6        // EPSILON (a double), hungarian.cc:18
 
+// The device keeps a window of the BFS queue in LDS; typing it as an LDS pointer keeps the compiler
+// from folding "ring or global queue" into one generic (flat) access.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) int ring_int;
+#else
+typedef int ring_int;
+#endif
+
 // Flow network + scratch for one [nx, ny] problem, carved out of a caller buffer.
 struct Scratch {
   int n;  // nx + ny + 2 nodes: s = 0, X = 1..nx, Y = nx+1..nx+ny, t = n-1 (hungarian.cc:197-202)
   float *cap, *flow, *res, *eq;
   int *queue, *parent;
   unsigned char *mark, *inS, *inT, *inN;
+  ring_int *ring;  // device: LDS window over the tail of the BFS queue (ring_n entries, a power of two)
+  int ring_n;  // 0 = none, every queue access goes to `queue`
 };
 
 // The scratch has a HOT part (flow network, equality graph, marks: a few n^2 floats, touched by
@@ -62,6 +72,8 @@ __host__ __device__ inline Scratch carve(void *hot, void *queue, int nx, int ny)
   s.inT = s.inS + nx;
   s.inN = s.inT + ny;
   s.queue = reinterpret_cast<int *>(queue);
+  s.ring = nullptr;
+  s.ring_n = 0;
   return s;
 }
 
@@ -264,15 +276,15 @@ __host__ __device__ inline int solve(const float *w, int nx, int ny, float *M, f
 // serial solver's, bit for bit (tests/test_hungarian.py checks it on the reference's vectors and
 // hundreds of random problems).  All lanes hold identical copies of the scalar state.
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ inline void wsync() { __syncthreads(); }  // one wave per workgroup: orders LDS/global traffic
-__device__ inline float wave_min(float v) {
+__device__ __forceinline__ void wsync() { __syncthreads(); }  // one wave per workgroup: orders LDS/global traffic
+__device__ __forceinline__ float wave_min(float v) {
   for (int o = 32; o > 0; o >>= 1) {
     const float t = __shfl_xor(v, o);
     v = (t < v) ? t : v;
   }
   return v;
 }
-__device__ inline float wave_max(float v) {
+__device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) {
     const float t = __shfl_xor(v, o);
     v = (t > v) ? t : v;
@@ -280,20 +292,38 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
-__device__ inline int augment_wave(Scratch &g, float cap_max, int lane) {
+// The BFS queue can grow to (kMaxIter + 2) * n entries (nodes are re-pushed until popped), which
+// only global memory holds — but a pop that waits on a global load, behind a fence on the pushes
+// before it, is most of a microsecond, and a solve makes tens of thousands of them.  So the queue
+// lives in an LDS ring while its LIVE window [qh, qt) fits (it always does at the path's sizes);
+// the first push that would overrun the ring moves the window to the global queue and the search
+// continues there.  Same pops in the same order either way.
+__device__ __forceinline__ int augment_wave(Scratch &g, float cap_max, int lane) {
   const int n = g.n, src = 0, dst = n - 1;
+  const int R = g.ring_n;
+  bool spilled = (R == 0);
   for (int v = lane; v < n; v += 64) {
     g.mark[v] = 0;
     g.parent[v] = -1;
   }
-  if (lane == 0) g.queue[0] = src;
-  __threadfence_block();
+  if (lane == 0) {
+    if (spilled)
+      g.queue[0] = src;
+    else
+      g.ring[0] = src;
+  }
+  if (spilled) __threadfence_block();
   wsync();
   int qh = 0, qt = 1;
   bool reached = false;
   for (int it = 0; qt > qh && it <= kMaxIter; ++it) {
     if (it == kMaxIter) return RA_E_HUNG_BFS;
-    const int v = g.queue[qh++];
+    int v;
+    if (spilled)
+      v = g.queue[qh];
+    else
+      v = g.ring[qh & (R - 1)];
+    ++qh;
     if (lane == 0) g.mark[v] = 1;  // marked on pop, not on push
     wsync();
     if (v == dst) {
@@ -305,13 +335,22 @@ __device__ inline int augment_wave(Scratch &g, float cap_max, int lane) {
       const int u = base + lane;
       const bool push = u < n && !g.mark[u] && row[u] > 0;
       const unsigned long long m = __ballot(push);
-      if (push) {
-        g.queue[qt + __popcll(m & ((1ull << lane) - 1ull))] = u;  // ascending u, like the serial scan
-        g.parent[u] = v;                                            // later pushers overwrite
+      const int cnt = __popcll(m);
+      if (!spilled && qt + cnt - qh > R) {
+        for (int i = qh + lane; i < qt; i += 64) g.queue[i] = g.ring[i & (R - 1)];
+        spilled = true;
       }
-      qt += __popcll(m);
+      if (push) {
+        const int at = qt + __popcll(m & ((1ull << lane) - 1ull));  // ascending u, like the serial scan
+        if (spilled)
+          g.queue[at] = u;
+        else
+          g.ring[at & (R - 1)] = u;
+        g.parent[u] = v;  // later pushers overwrite
+      }
+      qt += cnt;
     }
-    __threadfence_block();
+    if (spilled) __threadfence_block();
     wsync();
   }
   if (!reached) return 0;
@@ -349,7 +388,7 @@ __device__ inline int augment_wave(Scratch &g, float cap_max, int lane) {
   return rc;
 }
 
-__device__ inline int rematch_wave(Scratch &g, int nx, int ny, float *M, int lane) {
+__device__ __forceinline__ int rematch_wave(Scratch &g, int nx, int ny, float *M, int lane) {
   const int n = g.n, dst = n - 1, nn = n * n;
   for (int k = lane; k < nn; k += 64) g.cap[k] = 0.0f;
   wsync();
@@ -383,9 +422,151 @@ __device__ inline int rematch_wave(Scratch &g, int nx, int ny, float *M, int lan
   return 0;
 }
 
-__device__ inline int solve_wave(const float *w, int nx, int ny, float *M, float *cx, float *cy,
-                                 void *hot_buf, void *queue_buf, int lane) {
+// ---- n <= 64: the search state lives in registers ----
+// With at most 64 nodes the BFS needs no memory round trip per pop: lane v keeps row v of the
+// residual graph as a 64-bit adjacency mask (bit u = res[v][u] > 0) and parent[v]; the marks are
+// one uniform 64-bit mask; the queue is read 64 entries at a time into a register window and
+// popped with v_readlane.  A pop is then a handful of scalar instructions plus one LDS store per
+// pushed node, instead of two LDS round trips and two barriers.  The float network (cap / flow /
+// res) stays in LDS and is updated along the path exactly as before; the masks are derived from it.
+// One wave's LDS operations execute in issue order, so only the compiler needs a fence.
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long x, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int augment_wave64(Scratch &g, float cap_max, int lane, unsigned long long &adj) {
+  const int n = g.n, src = 0, dst = n - 1;
+  const int R = g.ring_n;  // >= 64 on this path
+  bool spilled = false;
+  unsigned long long marks = 0;
+  int parent = -1;
+  if (lane == 0) g.ring[0] = src;
+  int win = src, wbase = 0, wvalid = 1;  // queue[wbase + lane] for wbase + lane < wvalid
+  int qh = 0, qt = 1;
+  bool reached = false;
+  for (int it = 0; qt > qh && it <= kMaxIter; ++it) {
+    if (it == kMaxIter) return RA_E_HUNG_BFS;
+    if (qh >= wvalid) {  // refill the window from the queue
+      if (spilled) __threadfence_block();
+      lds_order();
+      wbase = qh;
+      wvalid = (qt < qh + 64) ? qt : qh + 64;
+      const int at = qh + lane;
+      win = 0;
+      if (at < wvalid) {
+        if (spilled)
+          win = g.queue[at];
+        else
+          win = g.ring[at & (R - 1)];
+      }
+    }
+    const int v = __builtin_amdgcn_readlane(win, qh - wbase);
+    ++qh;
+    marks |= 1ull << v;  // marked on pop, not on push
+    if (v == dst) {
+      reached = true;
+      break;
+    }
+    const unsigned long long m = readlane64(adj, v) & ~marks;
+    if (m == 0ull) continue;
+    const int cnt = __popcll(m);
+    if (!spilled && qt + cnt - qh > R) {  // the live window would overrun the ring: go global
+      lds_order();
+      for (int i = qh + lane; i < qt; i += 64) g.queue[i] = g.ring[i & (R - 1)];
+      spilled = true;
+    }
+    if ((m >> lane) & 1ull) {
+      const int at = qt + __popcll(m & ((1ull << lane) - 1ull));  // ascending u, like the serial scan
+      if (spilled)
+        g.queue[at] = lane;
+      else
+        g.ring[at & (R - 1)] = lane;
+      parent = v;  // later pushers overwrite
+    }
+    qt += cnt;
+  }
+  if (!reached) return 0;
+  // the path walk, on uniform scalars: every lane reads the same LDS words, lane 0 writes
+  float bottleneck = cap_max;  // capacity.maxCoeff(), hungarian.cc:144
+  int v = dst;
+  for (int it = 0;; ++it) {
+    const int p = __builtin_amdgcn_readlane(parent, v);
+    if (p == -1) break;
+    if (it == kMaxIter) return RA_E_HUNG_PATH;
+    const float r = g.res[(size_t)p * n + v];
+    bottleneck = (bottleneck < r) ? bottleneck : r;
+    v = p;
+  }
+  v = dst;
+  for (int it = 0;; ++it) {
+    const int p = __builtin_amdgcn_readlane(parent, v);
+    if (p == -1) break;
+    if (it == kMaxIter) return RA_E_HUNG_PATH;
+    const size_t pv = (size_t)p * n + v, vp = (size_t)v * n + p;
+    const bool fwd = g.cap[pv] > 0;
+    const float f = fwd ? g.flow[pv] + bottleneck : g.flow[vp] - bottleneck;
+    const float rpv = g.res[pv] - bottleneck, rvp = g.res[vp] + bottleneck;
+    lds_order();
+    if (lane == 0) {
+      g.flow[fwd ? pv : vp] = f;
+      g.res[pv] = rpv;
+      g.res[vp] = rvp;
+    }
+    lds_order();
+    if (lane == p) adj = (adj & ~(1ull << v)) | ((rpv > 0) ? (1ull << v) : 0ull);
+    if (lane == v) adj = (adj & ~(1ull << p)) | ((rvp > 0) ? (1ull << p) : 0ull);
+    v = p;
+  }
+  return 1;
+}
+
+__device__ __forceinline__ int rematch_wave64(Scratch &g, int nx, int ny, float *M, int lane) {
+  const int n = g.n, dst = n - 1, nn = n * n;
+  for (int k = lane; k < nn; k += 64) {
+    g.cap[k] = 0.0f;
+    g.flow[k] = 0.0f;
+  }
+  lds_order();
+  for (int k = lane; k < nx * ny; k += 64) {
+    const int x = k / ny, y = k - x * ny;
+    g.cap[(size_t)(1 + x) * n + (1 + nx + y)] = g.eq[k];
+  }
+  for (int x = lane; x < nx; x += 64) g.cap[1 + x] = 1.0f;                                // s -> x
+  for (int y = lane; y < ny; y += 64) g.cap[(size_t)(1 + nx + y) * n + dst] = 1.0f;      // y -> t
+  lds_order();
+  float cap_max = -FLT_MAX;
+  for (int k = lane; k < nn; k += 64) {
+    const float c = g.cap[k];
+    g.res[k] = c;
+    cap_max = (c > cap_max) ? c : cap_max;
+  }
+  cap_max = wave_max(cap_max);
+  unsigned long long adj = 0;  // row `lane` of the residual graph
+  if (lane < n)
+    for (int u = 0; u < n; ++u) adj |= (g.cap[(size_t)lane * n + u] > 0) ? (1ull << u) : 0ull;
+  for (int it = 0;; ++it) {
+    const int r = augment_wave64(g, cap_max, lane, adj);
+    if (r < 0) return r;
+    if (r == 0 || it > kMaxIter) break;
+    if (it == kMaxIter) return RA_E_HUNG_FLOW;
+  }
+  lds_order();
+  for (int k = lane; k < nx * ny; k += 64) {
+    const int x = k / ny, y = k - x * ny;
+    M[k] = g.flow[(size_t)(1 + x) * n + (1 + nx + y)];
+  }
+  wsync();
+  return 0;
+}
+
+__device__ __forceinline__ int solve_wave(const float *w, int nx, int ny, float *M, float *cx, float *cy,
+                                 void *hot_buf, void *queue_buf, ring_int *ring, int ring_n, int lane) {
   Scratch g = carve(hot_buf, queue_buf, nx, ny);
+  g.ring = ring;
+  g.ring_n = ring_n;
   for (int x = lane; x < nx; x += 64) {
     float top = w[x * ny];
     for (int y = 1; y < ny; ++y) top = (w[x * ny + y] > top) ? w[x * ny + y] : top;
@@ -411,7 +592,8 @@ __device__ inline int solve_wave(const float *w, int nx, int ny, float *M, float
     }
     wsync();
     if (need_match) {
-      const int r = rematch_wave(g, nx, ny, M, lane);
+      const int r = (g.n <= 64 && g.ring_n >= 64) ? rematch_wave64(g, nx, ny, M, lane)
+                                                  : rematch_wave(g, nx, ny, M, lane);
       if (r < 0) return r;
       {  // saturating(): every vertex of the smaller side is matched (hungarian.cc:219-248)
         const bool by_col = nx >= ny;
@@ -513,10 +695,12 @@ __device__ inline int solve_wave(const float *w, int nx, int ny, float *M, float
 #endif  // __HIP_DEVICE_COMPILE__
 
 // One workgroup (one wave) per example running solve_wave().  use_lds: the hot scratch and private
-// copies of w / M / cx / cy live in LDS (all 64 lanes stage them in and out).
+// copies of w / M / cx / cy live in LDS (all 64 lanes stage them in and out).  ring_n: entries of
+// the BFS-queue ring that follows them in LDS (a power of two, or 0).
 __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, int ny, float *M,
                                                         float *cx, float *cy, int *status,
-                                                        char *ws, size_t ws_per_ex, int use_lds) {
+                                                        char *ws, size_t ws_per_ex, int use_lds,
+                                                        int ring_n, int ring_off) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int b = blockIdx.x, t = threadIdx.x;
   const float *wb = w + (size_t)b * nx * ny;
@@ -524,7 +708,8 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, i
   [[maybe_unused]] char *wsb = ws + (size_t)b * ws_per_ex;  // device pass only
   if (!use_lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int rc = solve_wave(wb, nx, ny, Mb, cxb, cyb, wsb, wsb + hot_bytes(nx, ny), t);
+    const int rc = solve_wave(wb, nx, ny, Mb, cxb, cyb, wsb, wsb + hot_bytes(nx, ny),
+                              (ring_int *)(lds + ring_off), ring_n, t);
     if (t == 0 && status) status[b] = rc;
 #endif
     return;
@@ -535,7 +720,8 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, i
   __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
   {
-    const int rc = solve_wave(lw, nx, ny, lM, lcx, lcy, lds, wsb + hot_bytes(nx, ny), t);
+    const int rc = solve_wave(lw, nx, ny, lM, lcx, lcy, lds, wsb + hot_bytes(nx, ny),
+                              (ring_int *)(lds + ring_off), ring_n, t);
     if (t == 0 && status) status[b] = rc;
   }
 #endif
@@ -586,14 +772,21 @@ extern "C" int ra_hungarian_f32_dev(const float *weights, int B, int N, int M, f
                     per * (size_t)B);
   const size_t lds = ra::hung::hot_bytes(N, M) + ((size_t)2 * N * M + N + M) * sizeof(float);
   const int use_lds = lds <= 150 * 1024;
+  // BFS-queue ring after the staged data: the largest power of two that fits, at most 8192 entries
+  // (RA_HUNG_RING=0 keeps the queue in global memory)
+  const size_t ring_off = use_lds ? (lds + 15) / 16 * 16 : 0;
+  const char *ring_env = getenv("RA_HUNG_RING");  // read per call: the tests force the spill path
+  const int ring_cap = ring_env ? atoi(ring_env) : 8192;
+  int ring_n = 0;
+  for (int r = 64; r <= ring_cap && ring_off + (size_t)r * 4 <= 150 * 1024; r *= 2) ring_n = r;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra::hung::hungarian_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(ra::hung::hungarian_kernel, dim3(B), dim3(64), use_lds ? lds : 0, ra::as_stream(stream),
-                     weights, N, M, matching, cover_x, cover_y, status_dev,
-                     reinterpret_cast<char *>(ws), per, use_lds);
+  hipLaunchKernelGGL(ra::hung::hungarian_kernel, dim3(B), dim3(64), ring_off + (size_t)ring_n * 4,
+                     ra::as_stream(stream), weights, N, M, matching, cover_x, cover_y, status_dev,
+                     reinterpret_cast<char *>(ws), per, use_lds, ring_n, (int)ring_off);
   return ra::launch_status("ra_hungarian_f32_dev");
 }

@@ -133,6 +133,23 @@ def test_device_equals_host(cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('ring', ['0', '64'])
+def test_device_queue_ring_spill(cuda, monkeypatch, ring):
+  """The BFS queue's LDS ring is only a cache of the global queue: with no ring, and with one so
+  small that the live window overruns it mid-search, the device result is still the host's."""
+  import torch
+  monkeypatch.setenv('RA_HUNG_RING', ring)
+  rng = np.random.RandomState(21)
+  iou = rng.rand(8, 21, 21).astype(np.float32)
+  iou[:, :, 13:] = 0  # f_segm_match's shape: dead ground-truth columns all at the eps fill
+  for W in (iou + 1e-5, rng.rand(4, 32, 32).astype(np.float32)):
+    Mh, cxh, cyh = ops.hungarian(W)
+    Md, cxd, cyd = ops.hungarian(torch.from_numpy(W).to(cuda))
+    assert (Md.cpu().numpy() == Mh).all()
+    assert (cxd.cpu().numpy() == cxh).all() and (cyd.cpu().numpy() == cyh).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', KATS, ids=[c['name'] for c in KATS])
 def test_reference_vectors_device(cuda, case):
   """The DEVICE solver against the reference's own asserted answers (hungarian_tf_tests.py:9-90)
