@@ -907,7 +907,9 @@ int launch8(const PArgs &a_in, int B, hipStream_t st) {
   static int wgs = -1;  // RA_PAIR8_WGS: tuning aid, persistent workgroups (default 3 per CU)
   if (wgs < 0) {
     const char *e = getenv("RA_PAIR8_WGS");
-    wgs = e ? atoi(e) : (CACHED ? 1024 : 768);  // the cached form needs 122 VGPRs: 4 workgroups per CU
+    // the cached form (122 VGPRs) could run 4 workgroups per CU and is 0.3 us faster alone that way, but 3 leave
+    // room for the kernels of the other decode graphs: 50.4k vs 49.7k instance-timesteps/s with four batches in flight
+    wgs = e ? atoi(e) : 768;
   }
   hipLaunchKernelGGL(kern, dim3(ntiles < wgs ? ntiles : wgs), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_f32");

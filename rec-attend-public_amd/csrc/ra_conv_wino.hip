@@ -956,10 +956,13 @@ extern "C" int ra_conv_pair_wino_f32(const float *x, int B, int H, int W, const 
   a.reluA = reluA;
   a.reluB = reluB;
   a.bytes_x = (int)bytes;
-  static int form = -1;  // RA_PAIRW_FORM=1: tuning aid, the exchange-through-LDS form of phase B
+  static int form = -1;  // RA_PAIRW_FORM=2|3: tuning aid, the other forms of phase B
   if (form < 0) {
+    // form 2 (row-block waves, in-register output transform, 244 VGPRs) is the fastest alone (37.6 vs 39.0 us), but form 1
+    // (LDS exchange, 128 VGPRs, 4 workgroups per CU) shares the CUs better with the other decode graphs' kernels:
+    // 49.8k vs 48.9k instance-timesteps/s with four batches in flight — the evaluator's loop decides
     const char *e = getenv("RA_PAIRW_FORM");
-    form = e ? atoi(e) : 2;
+    form = e ? atoi(e) : 1;
   }
   if (form == 3) return wino::launch_pair3(a, as_stream(stream));
   if (form == 2) return wino::launch_pair2(a, as_stream(stream));

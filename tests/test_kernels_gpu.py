@@ -634,10 +634,10 @@ def test_conv_pair_winograd(cuda, B, H, W):
 
 
 def test_conv_pair_winograd_other_forms(cuda):
-  """The exchange-through-LDS form (1) and the role-split form (3) of the same kernel, in fresh processes
-  (the form is read from RA_PAIRW_FORM once per process)."""
+  """The row-block form (2) and the role-split form (3) of the same kernel (the default is the
+  exchange-through-LDS form 1), in fresh processes (the form is read from RA_PAIRW_FORM once per process)."""
   import os, subprocess, sys
-  for form in ('1', '3'):
+  for form in ('2', '3'):
     env = dict(os.environ, RA_PAIRW_FORM=form)
     code = ('import sys; sys.path[:0] = %r; import torch, test_kernels_gpu as t; '
             '[t._pair_winograd_case(torch.device("cuda"), *c) for c in ((2, 32, 48), (3, 64, 64))]; print("ok")' % (sys.path[:6],))
