@@ -213,7 +213,9 @@ def bench_other(args, rank, world, name):
   per = args.part_images or B
   parts = -(-B // per)
   depth = max(parts, max(1, args.in_flight) // len(models))
-  pipes = [(st, m.pipeline(depth, max_images=per, co_resident=depth * len(models))) for st, m in models]
+  per_stage = max(1, args.streams // len(models)) if args.streams else None  # HIP streams per stage (default min(depth, 4))
+  pipes = [(st, m.pipeline(depth, max_images=per, co_resident=min(depth, per_stage or 4) * len(models), streams=per_stage))
+           for st, m in models]
 
   def step():
     for st, pipe in pipes:
@@ -247,12 +249,17 @@ def bench_other(args, rank, world, name):
         'config': {'workload': '%s: %s' % (name, c['what']), 'arch': c['arch'], 'H': H, 'W': W, 'T': T,
                    'batch_per_gpu': B, 'stages': list(c['stages']), 'parts_per_batch': parts,
                    'parts_in_flight': depth * len(pipes),
-                   'controller': ('group-shared (16 workgroups per 8 images)' if pipes[-1][1].slots[0][0].subs[0].get('ctrl_batch')
+                   'controller': ('group-shared (16 workgroups per %d images)' % ops_group(pipes[-1][1].slots[0][0]) if pipes[-1][1].slots[0][0].subs[0].get('ctrl_batch')
                                   else 'split (16 workgroups per image)' if 'ctrl_ws' in pipes[-1][1].slots[0][0].subs[0]
                                   else 'single workgroup per image')}}))
   if world > 1:
     ra_dist.barrier()
     torch.distributed.destroy_process_group()
+
+
+def ops_group(eng):
+  import ra_ops
+  return ra_ops.ctrl_batch_group(eng.desc, eng.subs[0]['img'].shape[0])
 
 
 def bench_train(args, rank, world, B, T, S):
@@ -312,6 +319,7 @@ def main():
   ap.add_argument('--no-wino', action='store_true', help='tuning aid: direct conv for every controller-CNN layer')
   ap.add_argument('--fuse-patch-pairs', action='store_true', help='tuning aid: fused two-layer launches in the patch-sized nets too')
   ap.add_argument('--no-ctrl-split', action='store_true', help='tuning aid: one-workgroup-per-image controller')
+  ap.add_argument('--streams', type=int, default=0, help='HIP streams the in-flight batches share (default: min(in-flight, 4))')
   ap.add_argument('--in-flight', type=int, default=0,
                   help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other; '
                        'default: 4 at cfg2, 6 at cfg3 over its two stages, 2 at cfg5)')
@@ -338,7 +346,7 @@ def main():
                        'data-parallel, one RCCL all-reduce of the gradient bucket per step); prints its own JSON line')
   args = ap.parse_args()
   if args.in_flight <= 0:
-    args.in_flight = {'cfg2': 4, 'cfg3': 6, 'cfg5': 2}[args.config]
+    args.in_flight = {'cfg2': 8, 'cfg3': 6, 'cfg5': 2}[args.config]
 
   import ra_dist
   if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus > 1:
@@ -409,7 +417,7 @@ def main():
   # the timed region: K steps = K batches through the evaluator's decode pipeline
   # (full_model.DecodePipeline: up to --in-flight batches decode concurrently, each a whole
   # forward of B images on its own HIP graph + stream; every step is a complete forward)
-  pipe = model.pipeline(max(1, args.in_flight))
+  pipe = model.pipeline(max(1, args.in_flight), streams=args.streams or None)
 
   def step():
     if pipe.full():
@@ -620,7 +628,7 @@ def main():
         out['controller_us_in_slots'] = graph_time_us(lambda: ops.controller_batch(
             eng.desc, ps['ccnn'][-1], pipe.slots[0][0].W['ctrl_split'], ps['h_last'][0], ps['ctrl_out'][0], ps['gmaps'][0],
             ps['attn'][0], ps['ctrl_ws'], ps['ctrl_status']))
-        out['controller_in_slots'] = 'group-shared (K2b: 16 workgroups per 8 images)'
+        out['controller_in_slots'] = 'group-shared (K2b: 16 workgroups per %d images)' % ops_group(pipe.slots[0][0])
     else:
       out['controller_us'] = graph_time_us(lambda: ops.controller(
           eng.desc, sb['ccnn'][-1], Wt['ctrl'], sb['h_last'][0], sb['ctrl_out'][0], sb['gmaps'][0],

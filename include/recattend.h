@@ -227,12 +227,14 @@ int ra_ctrl_split_pack_weights(const ra_ctrl_desc *d, const float *const *lstm_w
 int ra_controller_split_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
                             float *h_last, float *ctrl_out, float *glimpse_maps, float *attn,
                             void *ws, size_t ws_bytes, int *status_dev, void *stream);
-/* K2b: the split controller with its 16 weight slices shared by groups of 8 images (16 workgroups per
- * GROUP instead of per image; weights packed exactly as for ra_controller_split_f32).  Results equal
- * ra_controller_split_f32's to float32 round-off; a launch is ceil(B / 8) * 16 workgroups, so several
+/* K2b: the split controller with its 16 weight slices shared by groups of g = ra_ctrl_batch_group_images(d, B)
+ * images — 4 for launches of up to 8 images, 8 above where that fits the LDS — (16 workgroups per GROUP
+ * instead of per image; weights packed exactly as for ra_controller_split_f32).  Results equal ra_controller_split_f32's to float32 round-off; a launch is
+ * ceil(B / g) * 16 workgroups (at most 224: RA_E_SHAPE beyond), so several
  * launches from different streams are resident together (ra_controller_split_f32 beside its own kind
  * can starve: its spinning workgroups hold the CUs their peers wait for).  ws: zero-filled,
  * ra_ctrl_batch_workspace_bytes(), owned by one stream of launches; status_dev as above. */
+int ra_ctrl_batch_group_images(const ra_ctrl_desc *d, int B);
 int ra_ctrl_batch_supported(const ra_ctrl_desc *d);
 size_t ra_ctrl_batch_workspace_bytes(const ra_ctrl_desc *d, int B);
 int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,

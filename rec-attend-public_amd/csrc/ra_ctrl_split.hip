@@ -383,39 +383,42 @@ int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, flo
 }
 
 // -------------------------------------------------------------------------------------------------
-// K2b — the same recurrence with the 16 weight slices shared by a GROUP of up to kNI images: 16 workgroups
-// per group instead of 16 per image.  A launch of 8 images is 16 workgroups, so four decode pipelines'
-// controllers (or cfg3's 16-image batches: two groups) are resident together many times over — the
+// K2b — the same recurrence with the 16 weight slices shared by a GROUP of up to NI images: 16 workgroups
+// per group instead of 16 per image.  A launch of 8 images is 32 workgroups, so four decode pipelines'
+// controllers (or cfg3's 16-image batches: two groups of 8) are resident together many times over — the
 // co-residency that the per-image form cannot guarantee beside its own kind — and every
 // weight is read from LDS once for all images of the group.  Per glimpse iteration the workgroups
 // exchange the glimpses (each image's soft-attention read-out is computed by ONE workgroup, from the
 // feature map it keeps in registers), h, the MLP hidden vector and the logits: 4 all-gathers of
 // {tag, value} granules instead of 3.
-#ifndef RA_CTRL_NI
-#define RA_CTRL_NI 8
-#endif
-constexpr int kNI = RA_CTRL_NI;  // images per group.  4 (-DRA_CTRL_NI=4): 88.9 instead of 112.6 us per launch at cfg2, the same
-                                 // pipelined rate, and twice the workgroups to keep resident -> 8
-
+// Images per group, NI: 4 for launches of up to 8 images, 8 above (ra_ctrl_batch_group_images()), so a launch is at
+// most 32 workgroups up to 16 images.  At cfg2 a launch takes 88.9 us with groups of 4 and 112.6 us with groups of 8;
+// once the encoder launches had been made to share the CUs, the shorter tail showed in the pipelined rate (51.8k vs
+// 51.2k instance-timesteps/s, 8 batches on 4 streams).  KITTI's 16-image batches keep groups of 8: with six parts in
+// flight, four groups each would not fit the co-residency margin.
+template <int NI>
 __host__ __device__ inline size_t granules_per_group(const ra_ctrl_desc &d) {
   const Layout L = layout(d);
-  return (size_t)d.iters * kNI * (d.Cf + d.hid + (size_t)L.n_hidden * d.hid + (size_t)kP * L.gs);
+  return (size_t)d.iters * NI * (d.Cf + d.hid + (size_t)L.n_hidden * d.hid + (size_t)kP * L.gs);
 }
-__host__ __device__ inline size_t ws_words_per_group(const ra_ctrl_desc &d) { return 2 + 2 * granules_per_group(d); }
+template <int NI>
+__host__ __device__ inline size_t ws_words_per_group(const ra_ctrl_desc &d) { return 2 + 2 * granules_per_group<NI>(d); }
 
+template <int NI>
 __host__ inline size_t batch_lds_bytes(const ra_ctrl_desc &d) {
   const Layout L = layout(d);
-  return (L.slice + (size_t)kThreads * kNI + (size_t)kNI * round_up(L.K, 4) + (size_t)kNI * d.hid +
-          (size_t)kNI * round_up(kP * L.gs, 4) + 64) * sizeof(float);
+  return (L.slice + (size_t)kThreads * NI + (size_t)NI * round_up(L.K, 4) + (size_t)NI * d.hid +
+          (size_t)NI * round_up(kP * L.gs, 4) + 64) * sizeof(float);
 }
 
+template <int NI>
 __host__ inline int batch_supported(const ra_ctrl_desc &d) {
   if (!supported(d)) return 0;
   const Layout L = layout(d);
   int gsp = 1;
   while (gsp < L.gs) gsp <<= 1;
-  if (gsp > 64 || L.us * kNI > kThreads || d.Cf > kThreads) return 0;
-  return batch_lds_bytes(d) <= 160 * 1024;
+  if (gsp > 64 || L.us * NI > kThreads || d.Cf > kThreads) return 0;
+  return batch_lds_bytes<NI>(d) <= 160 * 1024;
 }
 
 // n values per image, images i < nimg: granule (i * n + j) -> dst[i * stride + j].  A thread owns up to 8
@@ -458,20 +461,21 @@ __device__ inline void gather_multi(const u64 *g, int n, int nimg, unsigned tag,
 // out[i][col] = sum_k x[i][k] * W[k][col] for the images of the group; ncol a power of two <= 64, n real columns;
 // threads = (col, k-part), a part walks quads of consecutive k (one 16-byte LDS read of x per image and quad);
 // xs and K multiples of 4 (K: the tail is zero-padded by the caller's layout or handled below);
-// result in red[(part * kNI + i) * ncol + col], returns parts.
+// result in red[(part * NI + i) * ncol + col], returns parts.
+template <int NI>
 __device__ inline int gemv_multi(const float *W, int n, int ncol, const float *x, int xs, int K, float *red) {
   const int t = threadIdx.x, parts = kThreads / ncol;
   const int col = t % ncol, part = t / ncol;
-  float acc[kNI];
+  float acc[NI];
 #pragma unroll
-  for (int i = 0; i < kNI; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < NI; ++i) acc[i] = 0.0f;
   if (col < n) {
     const int K4 = K & ~3;
     for (int k = 4 * part; k < K4; k += 4 * parts) {
       const float w0 = W[(size_t)k * n + col], w1 = W[(size_t)(k + 1) * n + col], w2 = W[(size_t)(k + 2) * n + col],
                   w3 = W[(size_t)(k + 3) * n + col];
 #pragma unroll
-      for (int i = 0; i < kNI; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + i * xs + k);
         acc[i] += xv.x * w0 + xv.y * w1 + xv.z * w2 + xv.w * w3;
       }
@@ -480,16 +484,16 @@ __device__ inline int gemv_multi(const float *W, int n, int ncol, const float *x
       for (int k = K4; k < K; ++k) {
         const float w = W[(size_t)k * n + col];
 #pragma unroll
-        for (int i = 0; i < kNI; ++i) acc[i] += x[i * xs + k] * w;
+        for (int i = 0; i < NI; ++i) acc[i] += x[i * xs + k] * w;
       }
   }
 #pragma unroll
-  for (int i = 0; i < kNI; ++i) red[(part * kNI + i) * ncol + col] = acc[i];
+  for (int i = 0; i < NI; ++i) red[(part * NI + i) * ncol + col] = acc[i];
   __syncthreads();
   return parts;
 }
 
-template <int FR>
+template <int FR, int NI>
 __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctrl_desc d, const float *feat,
                                                                     const float *__restrict__ wp, int B, float *h_last,
                                                                     float *ctrl_out, float *gmaps, float *attn,
@@ -499,13 +503,13 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
   const int t = threadIdx.x, p = blockIdx.x, grp = blockIdx.y;
   const int G = d.G, Cf = d.Cf, hid = d.hid, us = L.us, gs = L.gs, K = L.K;
   const int Gx = kP * gs, Kp = round_up(K, 4), Gxp = round_up(Gx, 4);
-  const int b0 = grp * kNI, nimg = (B - b0 < kNI) ? B - b0 : kNI;
+  const int b0 = grp * NI, nimg = (B - b0 < NI) ? B - b0 : NI;
   float *W = smem;                          // the slice
-  float *red = W + L.slice;                 // [256 * kNI]
-  float *xh = red + kThreads * kNI;         // [kNI][Kp]  = [glimpse ; h] per image
-  float *va = xh + kNI * Kp;                // [kNI][hid] hidden MLP vector
-  float *gm = va + kNI * hid;               // [kNI][Gxp] logits -> glimpse map
-  unsigned *wsg = ws + (size_t)grp * ws_words_per_group(d);
+  float *red = W + L.slice;                 // [256 * NI]
+  float *xh = red + kThreads * NI;         // [NI][Kp]  = [glimpse ; h] per image
+  float *va = xh + NI * Kp;                // [NI][hid] hidden MLP vector
+  float *gm = va + NI * hid;               // [NI][Gxp] logits -> glimpse map
+  unsigned *wsg = ws + (size_t)grp * ws_words_per_group<NI>(d);
   const unsigned tag = wsg[0] + 1u;
   u64 *gran = reinterpret_cast<u64 *>(wsg + 2);
   int err = 0;
@@ -538,9 +542,9 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
     const int e = t + kThreads * i;
     fr[i] = (e < G * Cf) ? fsrc[e] : 0.0f;
   }
-  for (int e = t; e < kNI * Kp; e += kThreads) xh[e] = 0.0f;  // h = 0 (and defined glimpse slots)
-  for (int e = t; e < kNI * Gxp; e += kThreads) gm[e] = ((e % Gxp) < G) ? 1.0f / (float)G : 0.0f;
-  float cst = 0.0f;  // cell state of (image t / us, unit p * us + t % us), threads t < us * kNI
+  for (int e = t; e < NI * Kp; e += kThreads) xh[e] = 0.0f;  // h = 0 (and defined glimpse slots)
+  for (int e = t; e < NI * Gxp; e += kThreads) gm[e] = ((e % Gxp) < G) ? 1.0f / (float)G : 0.0f;
+  float cst = 0.0f;  // cell state of (image t / us, unit p * us + t % us), threads t < us * NI
   const int ci = t / us, cu = t % us;
   __syncthreads();
 
@@ -570,16 +574,16 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
       __syncthreads();
     }
     gather_multi(gran + goff, Cf, nimg, tag, xh, Kp, &err);
-    goff += (size_t)kNI * Cf;
+    goff += (size_t)NI * Cf;
     // ---- LSTM slice, all images ----
     {
-      const int parts = gemv_multi(W + L.lstm_w, L.NL, L.NL, xh, Kp, (it == 0) ? Cf : K, red);
-      if (t < us * kNI && ci < nimg) {
+      const int parts = gemv_multi<NI>(W + L.lstm_w, L.NL, L.NL, xh, Kp, (it == 0) ? Cf : K, red);
+      if (t < us * NI && ci < nimg) {
         float pre[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float a = W[L.lstm_b + g * us + cu];
-          for (int q = 0; q < parts; ++q) a += red[(q * kNI + ci) * L.NL + g * us + cu];
+          for (int q = 0; q < parts; ++q) a += red[(q * NI + ci) * L.NL + g * us + cu];
           pre[g] = a;
         }
         const float gi = sigm(pre[0]), gf = sigm(pre[1]), go = sigm(pre[2]), u = tanhf(pre[3]);
@@ -588,35 +592,35 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
       }
     }
     gather_multi(gran + goff, hid, nimg, tag, xh + Cf, Kp, &err);
-    goff += (size_t)kNI * hid;
+    goff += (size_t)NI * hid;
     if (it == d.iters - 1) break;
     // ---- glimpse MLP hidden layers (relu) ----
     const float *in = xh + Cf;
     int ins = Kp;
     for (int l = 0; l < L.n_hidden; ++l) {
-      const int parts = gemv_multi(W + L.gh_w[l], us, us, in, ins, hid, red);
-      if (t < us * kNI && ci < nimg) {
+      const int parts = gemv_multi<NI>(W + L.gh_w[l], us, us, in, ins, hid, red);
+      if (t < us * NI && ci < nimg) {
         float a = W[L.gh_b[l] + cu];
-        for (int q = 0; q < parts; ++q) a += red[(q * kNI + ci) * us + cu];
+        for (int q = 0; q < parts; ++q) a += red[(q * NI + ci) * us + cu];
         publish(gran + goff + (size_t)ci * hid + p * us + cu, tag, fmaxf(a, 0.0f));
       }
       gather_multi(gran + goff, hid, nimg, tag, va, hid, &err);
-      goff += (size_t)kNI * hid;
+      goff += (size_t)NI * hid;
       in = va;
       ins = hid;
     }
     {  // ---- logits slice, gathered; softmax over G per image, two images per wave ----
       int ncol = 1;
       while (ncol < gs) ncol <<= 1;
-      const int parts = gemv_multi(W + L.gl_w, gs, ncol, in, ins, hid, red);
-      const int li = t / ncol, lu = t % ncol;  // (image, logit) for the first ncol * kNI threads
-      if (t < ncol * kNI && li < nimg && lu < gs) {
+      const int parts = gemv_multi<NI>(W + L.gl_w, gs, ncol, in, ins, hid, red);
+      const int li = t / ncol, lu = t % ncol;  // (image, logit) for the first ncol * NI threads
+      if (t < ncol * NI && li < nimg && lu < gs) {
         float a = W[L.gl_b + lu];
-        for (int q = 0; q < parts; ++q) a += red[(q * kNI + li) * ncol + lu];
+        for (int q = 0; q < parts; ++q) a += red[(q * NI + li) * ncol + lu];
         publish(gran + goff + (size_t)li * Gx + p * gs + lu, tag, a);
       }
       gather_multi(gran + goff, Gx, nimg, tag, gm, Gxp, &err);
-      goff += (size_t)kNI * Gx;
+      goff += (size_t)NI * Gx;
       const int wave = t >> 6, lane = t & 63;
       for (int i = wave; i < nimg; i += kThreads / 64) {
         float *gi = gm + i * Gxp;
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
       const float *Wc = wp + L.cm_w[l], *bc = wp + L.cm_b[l];
       const bool last = (l == d.n_cmlp - 1);
       int ncol;
-      float *scratch = gm;  // [4 * 256] <= kNI * Gxp floats: the maps are no longer needed
+      float *scratch = red + 2 * kThreads;  // one partial per thread; red is [256 * NI], o2 uses its first hid <= 256 floats
       const int parts = any_gemv(Wc, N, in, Kin, scratch, &ncol);
       if (t < N) {
         float a = bc[t];
@@ -691,19 +695,22 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
   if (err && status) atomicMax(status, 1);
 }
 
-template <int FR>
+template <int FR, int NI>
 int launch_batch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, float *h_last, float *ctrl_out,
                  float *gmaps, float *attn, unsigned *ws, int *status, size_t lds, hipStream_t st) {
-  auto kern = controller_batch_kernel<FR>;
+  auto kern = controller_batch_kernel<FR, NI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(kP, ceil_div(B, kNI)), dim3(kThreads), lds, st, d, feat, wp, B, h_last, ctrl_out, gmaps,
+  hipLaunchKernelGGL(kern, dim3(kP, ceil_div(B, NI)), dim3(kThreads), lds, st, d, feat, wp, B, h_last, ctrl_out, gmaps,
                      attn, ws, status);
   return launch_status("ra_controller_batch_f32");
 }
+
+// the group size a launch of B images uses (groups of 8 only where their larger LDS footprint fits)
+inline int group_images(const ra_ctrl_desc &d, int B) { return (B > 8 && batch_supported<8>(d)) ? 8 : 4; }
 
 }  // namespace ctrl2
 }  // namespace ra
@@ -789,27 +796,36 @@ extern "C" int ra_controller_split_f32(const ra_ctrl_desc *d, const float *feat,
 #undef RA_C2
 }
 
-// ---- K2b: one group of 16 workgroups per 8 images (weights packed as for ra_controller_split_f32) ----
-extern "C" int ra_ctrl_batch_supported(const ra_ctrl_desc *d) { return d ? ctrl2::batch_supported(*d) : 0; }
+// ---- K2b: one group of 16 workgroups per 4 or 8 images (weights packed as for ra_controller_split_f32) ----
+extern "C" int ra_ctrl_batch_supported(const ra_ctrl_desc *d) { return d ? ctrl2::batch_supported<4>(*d) : 0; }
+
+extern "C" int ra_ctrl_batch_group_images(const ra_ctrl_desc *d, int B) {
+  if (!d || B <= 0 || !ctrl2::batch_supported<4>(*d)) return 0;
+  return ctrl2::group_images(*d, B);
+}
 
 extern "C" size_t ra_ctrl_batch_workspace_bytes(const ra_ctrl_desc *d, int B) {
-  if (!d || B <= 0 || !ctrl2::batch_supported(*d)) return 0;
-  return (size_t)ceil_div(B, ctrl2::kNI) * ctrl2::ws_words_per_group(*d) * 4;
+  if (!d || B <= 0 || !ctrl2::batch_supported<4>(*d)) return 0;
+  const int g = ctrl2::group_images(*d, B);
+  return (size_t)ceil_div(B, g) * (g == 8 ? ctrl2::ws_words_per_group<8>(*d) : ctrl2::ws_words_per_group<4>(*d)) * 4;
 }
 
 extern "C" int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
                                        float *h_last, float *ctrl_out, float *glimpse_maps, float *attn, void *ws,
                                        size_t ws_bytes, int *status_dev, void *stream) {
   if (!d || !feat || !wpacked || !ws || B <= 0) return fail(RA_E_INVALID, "ra_controller_batch_f32: bad argument");
-  if (!ctrl2::batch_supported(*d)) return fail(RA_E_SHAPE, "ra_controller_batch_f32: unsupported descriptor");
-  if (ceil_div(B, ctrl2::kNI) * ctrl2::kP > 224)
-    return fail(RA_E_SHAPE, "ra_controller_batch_f32: B=%d exceeds co-residency (%d)", B, 14 * ctrl2::kNI);
+  if (!ctrl2::batch_supported<4>(*d)) return fail(RA_E_SHAPE, "ra_controller_batch_f32: unsupported descriptor");
+  const int g = ctrl2::group_images(*d, B);
+  if (ceil_div(B, g) * ctrl2::kP > 224)
+    return fail(RA_E_SHAPE, "ra_controller_batch_f32: B=%d exceeds co-residency (%d)", B, 14 * g);
   if (ws_bytes < ra_ctrl_batch_workspace_bytes(d, B)) return fail(RA_E_WORKSPACE, "ra_controller_batch_f32: workspace");
-  const size_t lds = ctrl2::batch_lds_bytes(*d);
+  const size_t lds = g == 8 ? ctrl2::batch_lds_bytes<8>(*d) : ctrl2::batch_lds_bytes<4>(*d);
   const int fr = ceil_div(d->G * d->Cf, ctrl2::kThreads);
   hipStream_t st = as_stream(stream);
   unsigned *w = reinterpret_cast<unsigned *>(ws);
-#define RA_C3(FR) return ctrl2::launch_batch<FR>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, status_dev, lds, st)
+#define RA_C3(FR)                                                                                                        \
+  return g == 8 ? ctrl2::launch_batch<FR, 8>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, status_dev, lds, st) \
+                : ctrl2::launch_batch<FR, 4>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, status_dev, lds, st)
   if (fr <= 4) RA_C3(4);
   if (fr <= 16) RA_C3(16);
   if (fr <= 32) RA_C3(32);

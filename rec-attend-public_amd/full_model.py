@@ -201,9 +201,9 @@ class Model(dict):
       res = [r.detach().cpu().numpy() for r in res]
     return res[0] if single else res
 
-  def pipeline(self, depth=4, max_images=None, co_resident=None):
+  def pipeline(self, depth=4, max_images=None, co_resident=None, streams=None):
     """`depth` batches of this model in flight (DecodePipeline below)."""
-    return DecodePipeline(self, depth, max_images, co_resident)
+    return DecodePipeline(self, depth, max_images, co_resident, streams)
 
   def _run_train(self, names, feed, single, as_numpy):
     """sess.run([loss, train_step], feed{x, y_gt, s_gt, phase_train=True}) (full_model_train.py:107):
@@ -357,9 +357,12 @@ class DecodePipeline(object):
       consume(pipe.collect())
   """
 
-  def __init__(self, model, depth=4, max_images=None, co_resident=None):
-    """co_resident: engines decoding at the same time on this GPU if other pipelines run beside this one
-    (default: depth); max_images: a batch with more images is decoded as ceil(B / max_images) near-equal parts,
+  def __init__(self, model, depth=4, max_images=None, co_resident=None, streams=None):
+    """streams: HIP streams the slots are dealt onto, round robin (default min(depth, 4): the GPU runs four
+    queues at a time); with depth > streams a slot's batch is queued behind another slot's on the same stream,
+    so the stream never waits for the host to notice a finished batch and submit the next.
+    co_resident: engines decoding at the same time on this GPU if other pipelines run beside this one
+    (default: streams); max_images: a batch with more images is decoded as ceil(B / max_images) near-equal parts,
     each on its own slot, and collect() returns them concatenated (KITTI's batch of 16 as 2 x 8: the
     16-workgroup controller needs all of a launch's workgroups co-resident, <= 14 images)."""
     if depth < 1:
@@ -367,7 +370,8 @@ class DecodePipeline(object):
     if max_images is not None and max_images < 1:
       raise ValueError('max_images must be >= 1')
     self.model, self.depth, self.max_images = model, int(depth), max_images
-    self.co_resident = int(co_resident or depth)
+    self.streams = max(1, min(self.depth, int(streams or 4)))
+    self.co_resident = int(co_resident or self.streams)
     self.slots = None
     self.free = list(range(self.depth))
     self.pending = []  # tickets in submission order: (slot indices, names, single, events)
@@ -375,13 +379,14 @@ class DecodePipeline(object):
   def _make_slots(self):
     proto = self.model.engine
     self.slots = []
+    streams = [torch.cuda.Stream() for _ in range(self.streams)]
     for k in range(self.depth):
       eng = ra_engine.DecodeEngine(proto.d, self.model, box_model=proto.box)
       for flag in ('direct_attn', 'fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score', 'fuse_patchnet',
                    'cache_first', 'fill_cache_inline', 'nsub', 'use_graph', 'use_wino', 'wino_unfuse', 'pair_wino'):
         setattr(eng, flag, getattr(proto, flag))
       eng.co_resident = self.co_resident
-      self.slots.append((eng, torch.cuda.Stream()))
+      self.slots.append((eng, streams[k % self.streams]))
 
   def __len__(self):
     return len(self.pending)

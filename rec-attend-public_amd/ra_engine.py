@@ -288,8 +288,8 @@ class DecodeEngine(object):
       if self.split_ok and Bs * 16 * max(1, self.co_resident) <= ops.cu_count() - 32:  # the C side's margin: 224 of 256
         b['ctrl_ws'], b['ctrl_status'] = ops.ctrl_split_workspace(self.desc, Bs, device)
       elif (self.split_ok and ops.ctrl_batch_supported(self.desc) and
-            -(-Bs // 8) * 16 * max(1, self.co_resident) <= ops.cu_count() - 32):
-        # more than 14 images: the group-shared form (K2b, 16 workgroups per 8 images) — 89 vs 101 us at KITTI B = 16
+            -(-Bs // ops.ctrl_batch_group(self.desc, Bs)) * 16 * max(1, self.co_resident) <= ops.cu_count() - 32):
+        # more than 14 images, or launches that overlap: the group-shared form (K2b, 16 workgroups per group of images)
         b['ctrl_ws'], b['ctrl_status'] = ops.ctrl_batch_workspace(self.desc, Bs, device)
         b['ctrl_batch'] = True
       if self.box:

@@ -66,6 +66,7 @@ SIGNATURES = {
     'ra_ctrl_split_workspace_bytes': (_Z, [C.POINTER(CtrlDesc), _I]),
     'ra_ctrl_split_pack_weights': (_I, [C.POINTER(CtrlDesc), _P, _P, _P, _P]),
     'ra_controller_split_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    'ra_ctrl_batch_group_images': (_I, [C.POINTER(CtrlDesc), _I]),
     'ra_ctrl_batch_supported': (_I, [C.POINTER(CtrlDesc)]),
     'ra_ctrl_batch_workspace_bytes': (_Z, [C.POINTER(CtrlDesc), _I]),
     'ra_controller_batch_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P]),

@@ -149,6 +149,11 @@ def controller_split(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
         'ra_controller_split_f32')
 
 
+def ctrl_batch_group(desc, B):
+  """Images that share one set of 16 controller workgroups in a controller_batch (K2b) launch of B images."""
+  return int(rn.lib().ra_ctrl_batch_group_images(C.byref(desc), int(B)))
+
+
 def ctrl_batch_supported(desc):
   return bool(rn.lib().ra_ctrl_batch_supported(C.byref(desc)))
 
@@ -161,7 +166,7 @@ def ctrl_batch_workspace(desc, B, device):
 
 
 def controller_batch(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
-  """K2b: ra_controller_split_f32's recurrence with the weight slices shared by groups of 8 images."""
+  """K2b: ra_controller_split_f32's recurrence with the weight slices shared by groups of ctrl_batch_group(desc, B) images."""
   _need_cuda(feat, wp, h_last, ctrl_out, gmaps, attn)
   check(rn.lib().ra_controller_batch_f32(C.byref(desc), ptr(feat), ptr(wp), feat.shape[0], ptr(h_last), ptr(ctrl_out),
                                          ptr(gmaps), ptr(attn), ptr(ws), ws.numel() * 8, ptr(status), rn.stream_ptr()),

@@ -397,9 +397,9 @@ def test_decode_pipeline_box_model(cuda):
 
 def test_decode_pipeline_controller_policy(cuda):
   """Slots decode with the per-image 16-workgroup controller only if every launch that can run at the same
-  time fits the chip (depth x images x 16 <= 224); otherwise with the group-shared form (K2b: 16 workgroups
-  per 8 images, resident many times over), whose results equal the per-image form's to round-off; and with
-  the one-workgroup form where neither fits."""
+  time fits the chip (streams x images x 16 <= 224); otherwise with the group-shared form (K2b: 16 workgroups
+  per group of images, resident many times over), whose results equal the per-image form's to round-off; and
+  with the one-workgroup form where neither fits."""
   import full_model
   opt = ora.make_opt('cvppp', 64, 64, 3)
   P = ora.random_params(opt, 9)
@@ -408,13 +408,13 @@ def test_decode_pipeline_controller_policy(cuda):
   m = full_model.get_model(opt).load_weights(P)
   split = m.run(['y_out', 's_out'], feed, as_numpy=True)
   assert 'ctrl_ws' in m.engine.subs[0] and not m.engine.subs[0].get('ctrl_batch')
-  pipe = m.pipeline(4)  # 4 x 8 x 16 = 512 workgroups > 224; 4 x 16 = 64 in the group-shared form
+  pipe = m.pipeline(4)  # 4 x 8 x 16 = 512 workgroups > 224; 4 x ceil(8 / group) x 16 <= 128 in the group-shared form
   pipe.submit(['y_out', 's_out'], feed)
   got = pipe.collect(as_numpy=True)
   assert pipe.slots[0][0].subs[0].get('ctrl_batch')
   for u, w in zip(got, split):
     assert np.abs(u - w).max() < 1e-4
-  wide = m.pipeline(16)  # 16 x 16 = 256 > 224: the one-workgroup form
+  wide = m.pipeline(16, streams=16)  # 16 launches at a time x 16 workgroups or more > 224: the one-workgroup form
   wide.submit(['y_out', 's_out'], feed)
   got1 = wide.collect(as_numpy=True)
   assert 'ctrl_ws' not in wide.slots[0][0].subs[0]

@@ -245,12 +245,12 @@ def test_controller_split(cuda, arch, H, W, flags):
 @pytest.mark.parametrize('arch,H,W,flags,B', [
     ('cvppp', 128, 128, {}, 5),
     ('cvppp', 224, 224, {'squash_ctrl_params': True}, 8),   # G = 49 -> gs = 4, padded logits
-    ('kitti', 128, 448, {}, 16),                             # two groups of 8
-    ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2}, 11),  # groups of 8 + 3
+    ('kitti', 128, 448, {}, 16),                             # full groups only
+    ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2}, 11),  # full groups + a ragged one
     ('cvppp', 512, 512, {'num_glimpse_mlp_layers': 1}, 1),
 ])
 def test_controller_batch(cuda, arch, H, W, flags, B):
-  """K2b, the split controller with its weight slices shared by groups of 8 images: the oracle's recurrence,
+  """K2b, the split controller with its weight slices shared by groups of 4 images (8 for launches of more than 8): the oracle's recurrence,
   three launches on one workspace (generation tags), full and ragged groups, and agreement with the
   per-image split form."""
   opt = ora.make_opt(arch, H, W, 2, **flags)
@@ -260,11 +260,12 @@ def test_controller_batch(cuda, arch, H, W, flags, B):
                             opt['ctrl_mlp_dim'], H, W, 48, 48, d['squash'], d['fixed_var'],
                             d['dynamic_var'], d['fixed_gamma'])
   assert ops.ctrl_batch_supported(desc)
-  # a third glimpse-MLP layer makes the slice + the group's vectors exceed 160 KB of LDS: reported, not attempted
+  assert ops.ctrl_batch_group(desc, B) == (8 if B > 8 else 4)
+  # a third glimpse-MLP layer makes the slice + a group of 8's vectors exceed 160 KB of LDS: such launches keep groups of 4
   big = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], 3, d['n_cmlp'], opt['ctrl_mlp_dim'], H, W, 48, 48,
                            d['squash'], d['fixed_var'], d['dynamic_var'], d['fixed_gamma'])
   if d['G'] * 4 >= 1024:  # (with few logits per slice the larger form still fits)
-    assert ops.ctrl_split_supported(big) and not ops.ctrl_batch_supported(big)
+    assert ops.ctrl_split_supported(big) and ops.ctrl_batch_supported(big) and ops.ctrl_batch_group(big, 16) == 4
   lstm = {k[len('ctrl_lstm_'):]: v for k, v in P.items() if k.startswith('ctrl_lstm_')}
   gmw = [(P['glimpse_mlp_w_%d' % i], P['glimpse_mlp_b_%d' % i]) for i in range(d['n_gmlp'])]
   cmw = [(P['ctrl_mlp_w_%d' % i], P['ctrl_mlp_b_%d' % i]) for i in range(d['n_cmlp'])]

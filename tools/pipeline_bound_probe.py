@@ -12,6 +12,7 @@ engs = []
 for k in range(K):
   m = full_model.get_model(opt, is_training=False)
   bench.seed_weights(m, 1234 + k)
+  m.engine.co_resident = K  # as a DecodePipeline slot: the group-shared controller
   m.engine.forward(torch.rand((B, S, S, 3)).cuda())
   engs.append(m.engine)
 torch.cuda.synchronize()
@@ -41,7 +42,7 @@ def both_minus(skip):
   """the whole timestep with one kind of tail launch made a no-op (results are garbage; timing only)"""
   def run(e):
     saved = {}
-    names = {'controller': ['controller', 'controller_split'], 'attn': ['extract_direct', 'paste_direct', 'paste_score_direct'],
+    names = {'controller': ['controller', 'controller_split', 'controller_batch'], 'attn': ['extract_direct', 'paste_direct', 'paste_score_direct'],
              'patch': ['conv3x3', 'conv_pair']}[skip]
     if skip == 'patch':  # only the patch-sized convs: wrap and filter on the input size
       o3, op = ops.conv3x3, ops.conv_pair
