@@ -338,8 +338,8 @@ class DecodePipeline(object):
   of the pipeline owns a DecodeEngine — its own activation buffers and its own linear HIP graph —
   and replays it on its own HIP stream: the streams land on different hardware queues and the
   latency-bound tail of one batch runs under the MFMA-bound controller CNN of the others.
-  Measured at cfg2 on MI355X: 5.3 ms per batch alone, 3.3 ms per batch (39k instance-timesteps/s)
-  with 4 in flight; 5-8 in flight lose again.  The slots decode with the one-workgroup-per-image
+  Measured at cfg2 on MI355X: 4.85 ms per batch alone, 2.50 ms per batch with 4 in flight, 2.48 ms
+  (51.7k instance-timesteps/s) with 8 in flight on 4 streams; more than 4 streams lose again.  The slots decode with the one-workgroup-per-image
   controller unless depth x images x 16 workgroups fit the chip: the 16-workgroup controller spin-waits
   on its peers, and several such launches from different queues can each end up partially resident
   and starve one another (seen at cfg3 with 8-12 parts in flight: 0.1-3.7 s per step).  The HIP runtime multiplexes its
@@ -348,7 +348,7 @@ class DecodePipeline(object):
   to 8 before the runtime starts.
   Every batch's results are bit-identical to a lone `model.run` (tests/test_full_model_gpu.py).
 
-    pipe = model.pipeline(4)
+    pipe = model.pipeline(8)
     for feed in batches:
       if pipe.full():
         consume(pipe.collect())

@@ -31,7 +31,7 @@ def build_parser():
     cap.add_flags(p, table)
   p.add_argument('--input', default=None, help='.npz with x [N,H,W,3] (+ d_in, y_in)')
   p.add_argument('--num_synthetic', type=int, default=8)
-  p.add_argument('--in_flight', type=int, default=4, help='batches decoded concurrently on one GPU')
+  p.add_argument('--in_flight', type=int, default=8, help='batches submitted to one GPU at a time (four decode concurrently, the rest queue behind them)')
   return p
 
 

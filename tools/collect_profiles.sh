@@ -26,7 +26,7 @@ python tools/pmc_traffic.py $F $W 10 8 512 $OUT/r02_pmc_attn_traffic.json "ra::a
 S=$(find $OUT/pmc_sq -name '*counter_collection.csv' | head -1)
 python tools/pmc_summary.py $S > $OUT/r02_pmc_sq_mfma_per_kernel.csv 2> $OUT/sq.txt
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/r02_bench_kernel_stats.csv
-cp $(find $OUT/trace4 -name '*kernel_stats.csv' | head -1) $OUT/r02_bench_kernel_stats_inflight4.csv
+cp $(find $OUT/trace4 -name '*kernel_stats.csv' | head -1) $OUT/r02_bench_kernel_stats_pipeline.csv
 # keep the merge small: the raw traces are not needed
 rm -rf $OUT/trace $OUT/trace4 $OUT/pmc_*_f $OUT/pmc_*_w $OUT/pmc_sq
 python bench.py --attn-b32 > $OUT/r02_bench_n1.json 2> $OUT/bench.err
