@@ -322,7 +322,7 @@ def main():
   ap.add_argument('--streams', type=int, default=0, help='HIP streams the in-flight batches share (default: min(in-flight, 4))')
   ap.add_argument('--in-flight', type=int, default=0,
                   help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other; '
-                       'default: 4 at cfg2, 6 at cfg3 over its two stages, 2 at cfg5)')
+                       'default: 8 at cfg2 (on 4 streams), 6 at cfg3 over its two stages, 2 at cfg5)')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
   ap.add_argument('--no-fuse-score', action='store_true', help='tuning aid: score MLP as its own launch')
   ap.add_argument('--host-output', action='store_true',

@@ -560,6 +560,15 @@ int ra_gauss_filter_f32(const float *ctr, const float *size, const float *lg_var
 int ra_gauss_filter_bwd_f32(const float *ctr, const float *size, const float *lg_var, const float *g,
                             int B, int L, int NF, float *dctr, float *dsize, float *dlg_var,
                             void *stream);
+/* The same two with element strides between consecutive images (one column of a [B,2] tensor is handed in
+ * as it lies; stride_lg_var may be 0: one variance for all images); stride_grad: of dctr / dsize / dlg_var. */
+int ra_gauss_filter_strided_f32(const float *ctr, const float *size, const float *lg_var, int stride_ctr,
+                                int stride_size, int stride_lg_var, int B, int L, int NF, float *out,
+                                void *stream);
+int ra_gauss_filter_strided_bwd_f32(const float *ctr, const float *size, const float *lg_var,
+                                    int stride_ctr, int stride_size, int stride_lg_var, const float *g,
+                                    int B, int L, int NF, float *dctr, float *dsize, float *dlg_var,
+                                    int stride_grad, void *stream);
 int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
 int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
                               int HW, float *out, void *stream);

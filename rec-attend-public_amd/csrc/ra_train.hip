@@ -843,22 +843,24 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float *act, co
 
 // ---- Gaussian filter bank (modellib.py:581-612): F[b][l][j] = N(l; mu_j, var), mu_j = ctr + (size + 1) / NF * (j - (NF - 1) / 2),
 // var = exp(lg_var); its adjoint reduces over the whole [L, NF] bank of an image: one workgroup per image.
-__global__ __launch_bounds__(256) void gauss_filter_kernel(const float *ctr, const float *size, const float *lg_var, int L,
-                                                           int NF, float *out) {
+// sc / ss / sv: elements between consecutive images in ctr / size / lg_var (1: a dense [B] vector; the training graph
+// hands in one column of a [B,2] tensor without copying it out)
+__global__ __launch_bounds__(256) void gauss_filter_kernel(const float *ctr, const float *size, const float *lg_var, int sc,
+                                                           int ss, int sv, int L, int NF, float *out) {
   const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
   if (e >= L * NF) return;
   const int l = e / NF, j = e - l * NF;
-  const float var = expf(lg_var[b]);
-  const float mu = ctr[b] + (size[b] + 1.0f) / (float)NF * ((float)j - 0.5f * (float)(NF - 1));
+  const float var = expf(lg_var[(size_t)b * sv]);
+  const float mu = ctr[(size_t)b * sc] + (size[(size_t)b * ss] + 1.0f) / (float)NF * ((float)j - 0.5f * (float)(NF - 1));
   const float dd = (float)l - mu;
   out[(size_t)b * L * NF + e] = expf(-0.5f * dd * dd / var) / (sqrtf(var) * 2.5066282746310002f);
 }
 __global__ __launch_bounds__(256) void gauss_filter_bwd_kernel(const float *ctr, const float *size, const float *lg_var,
-                                                               const float *g, int L, int NF, float *dctr, float *dsize,
-                                                               float *dlgv) {
+                                                               int sc, int ss, int sv, const float *g, int L, int NF,
+                                                               float *dctr, float *dsize, float *dlgv, int sd) {
   __shared__ float red[256];
   const int b = blockIdx.x;
-  const float var = expf(lg_var[b]), c0 = ctr[b], step = (size[b] + 1.0f) / (float)NF;
+  const float var = expf(lg_var[(size_t)b * sv]), c0 = ctr[(size_t)b * sc], step = (size[(size_t)b * ss] + 1.0f) / (float)NF;
   const float norm = 1.0f / (sqrtf(var) * 2.5066282746310002f);
   float a_ctr = 0.f, a_size = 0.f, a_var = 0.f;
   for (int e = threadIdx.x; e < L * NF; e += 256) {
@@ -876,9 +878,9 @@ __global__ __launch_bounds__(256) void gauss_filter_bwd_kernel(const float *ctr,
   a_size = block_sum256(a_size, red);
   a_var = block_sum256(a_var, red);
   if (threadIdx.x == 0) {
-    dctr[b] = a_ctr;
-    dsize[b] = a_size;
-    dlgv[b] = a_var * var;
+    dctr[(size_t)b * sd] = a_ctr;
+    dsize[(size_t)b * sd] = a_size;
+    dlgv[(size_t)b * sd] = a_var * var;
   }
 }
 
@@ -1034,19 +1036,30 @@ extern "C" int ra_lstm_cell_bwd_f32(const float *act, const float *c_prev, const
   return launch_status("ra_lstm_cell_bwd_f32");
 }
 
-extern "C" int ra_gauss_filter_f32(const float *ctr, const float *size, const float *lg_var, int B, int L, int NF, float *out,
-                                   void *stream) {
-  if (!ctr || !size || !lg_var || !out || B <= 0 || L <= 0 || NF <= 0) return fail(RA_E_INVALID, "ra_gauss_filter_f32: bad argument");
+extern "C" int ra_gauss_filter_strided_f32(const float *ctr, const float *size, const float *lg_var, int stride_ctr,
+                                           int stride_size, int stride_lg_var, int B, int L, int NF, float *out, void *stream) {
+  if (!ctr || !size || !lg_var || !out || B <= 0 || L <= 0 || NF <= 0 || stride_ctr < 1 || stride_size < 1 || stride_lg_var < 0)
+    return fail(RA_E_INVALID, "ra_gauss_filter_f32: bad argument");
   hipLaunchKernelGGL(train::gauss_filter_kernel, dim3(ceil_div(L * NF, 256), B), dim3(256), 0, as_stream(stream), ctr, size,
-                     lg_var, L, NF, out);
+                     lg_var, stride_ctr, stride_size, stride_lg_var, L, NF, out);
   return launch_status("ra_gauss_filter_f32");
 }
+extern "C" int ra_gauss_filter_f32(const float *ctr, const float *size, const float *lg_var, int B, int L, int NF, float *out,
+                                   void *stream) {
+  return ra_gauss_filter_strided_f32(ctr, size, lg_var, 1, 1, 1, B, L, NF, out, stream);
+}
 
+extern "C" int ra_gauss_filter_strided_bwd_f32(const float *ctr, const float *size, const float *lg_var, int stride_ctr,
+                                               int stride_size, int stride_lg_var, const float *g, int B, int L, int NF,
+                                               float *dctr, float *dsize, float *dlg_var, int stride_grad, void *stream) {
+  if (!ctr || !size || !lg_var || !g || !dctr || !dsize || !dlg_var || B <= 0 || L <= 0 || NF <= 0 || stride_ctr < 1 ||
+      stride_size < 1 || stride_lg_var < 0 || stride_grad < 1)
+    return fail(RA_E_INVALID, "ra_gauss_filter_bwd_f32: bad argument");
+  hipLaunchKernelGGL(train::gauss_filter_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), ctr, size, lg_var, stride_ctr,
+                     stride_size, stride_lg_var, g, L, NF, dctr, dsize, dlg_var, stride_grad);
+  return launch_status("ra_gauss_filter_bwd_f32");
+}
 extern "C" int ra_gauss_filter_bwd_f32(const float *ctr, const float *size, const float *lg_var, const float *g, int B, int L,
                                        int NF, float *dctr, float *dsize, float *dlg_var, void *stream) {
-  if (!ctr || !size || !lg_var || !g || !dctr || !dsize || !dlg_var || B <= 0 || L <= 0 || NF <= 0)
-    return fail(RA_E_INVALID, "ra_gauss_filter_bwd_f32: bad argument");
-  hipLaunchKernelGGL(train::gauss_filter_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), ctr, size, lg_var, g, L, NF, dctr,
-                     dsize, dlg_var);
-  return launch_status("ra_gauss_filter_bwd_f32");
+  return ra_gauss_filter_strided_bwd_f32(ctr, size, lg_var, 1, 1, 1, g, B, L, NF, dctr, dsize, dlg_var, 1, stream);
 }

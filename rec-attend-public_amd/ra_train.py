@@ -258,7 +258,12 @@ class ConvBNActPool(torch.autograd.Function):
     cp = ops.cout_padded(cout)
     wp = _pack_dev(w.contiguous(), cin_w, cout, Cx, cmap_t, tr)
     scale = _const('ones', cp, dev, lambda: torch.ones(cp, dtype=torch.float32, device=dev))
-    shift = torch.nn.functional.pad(b.detach(), (0, cp - cout)) if cp != cout else b.detach()
+    shift = b.detach()
+    if cp != cout:  # padded once per step (the layer's bias is shared by all timesteps), not once per use
+      key = ('shift', b.data_ptr(), cp)
+      shift = _PACK.get(key)
+      if shift is None:
+        shift = _PACK[key] = torch.nn.functional.pad(b.detach(), (0, cp - cout))
     u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2))
     H, W = u.shape[1], u.shape[2]
     use_bn = gamma is not None
@@ -451,6 +456,92 @@ def gaussian_filter(ctr, size, lg_var, L, F):
   return GaussFilter.apply(ctr, size, lg_var, L, F)
 
 
+class LinearAcc(torch.autograd.Function):
+  """y = x W + b whose parameter gradients are ADDED in place to gw / gb (views of the trainer's flat gradient bucket,
+  or a step-local buffer): one GEMM (beta = 1) and one GEMV per use, where autograd's mm + sum + the `grad += g`
+  that merges the uses of a shared weight (80 uses of the LSTM's, 64 of each glimpse-MLP layer's) are four launches."""
+
+  @staticmethod
+  def forward(ctx, x, W, b, gw, gb, after=None):
+    """after: a callable run ONCE at the end of the backward pass this use takes part in (the packed LSTM weights'
+    buffers are scattered to the eight parameters' gradients there)."""
+    ctx.save_for_backward(x, W)
+    ctx.acc = (gw, gb, after)
+    return torch.addmm(b, x, W)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, W = ctx.saved_tensors
+    gw, gb, after = ctx.acc
+    if after is not None and not after.armed:
+      after.armed = True
+      torch.autograd.Variable._execution_engine.queue_callback(after)
+    gw.addmm_(x.t(), dy)
+    ones = _const('ones', dy.shape[0], dy.device, lambda: torch.ones(dy.shape[0], dtype=torch.float32, device=dy.device))
+    gb.addmv_(dy.t(), ones)
+    return (dy @ W.t() if ctx.needs_input_grad[0] else None), None, None, None, None, None
+
+
+class _LstmGradScatter(object):
+  """End-of-backward callback: the step-local gradient of the packed gate weights goes to the eight parameters."""
+
+  def __init__(self, trainer, gW, gb):
+    self.trainer, self.gW, self.gb, self.armed = trainer, gW, gb, False
+
+  def __call__(self):
+    self.armed = False
+    g, hid = self.trainer.bucket.grad_of, self.trainer.d['hid']
+    nx = g['ctrl_lstm_w_xi'].shape[0]
+    for j, k in enumerate('ifou'):
+      cols = slice(j * hid, (j + 1) * hid)
+      g['ctrl_lstm_w_x' + k].add_(self.gW[:nx, cols])
+      g['ctrl_lstm_w_h' + k].add_(self.gW[nx:, cols])
+      g['ctrl_lstm_b_' + k].add_(self.gb[cols])
+    self.gW.zero_()  # a second backward through the same forward must not count this one again
+    self.gb.zero_()
+
+
+class GaussFilterPair(torch.autograd.Function):
+  """Both banks of an attention window from the [B,2] tensors (y, x) the controller head produces: two kernel
+  launches forward and two backward, reading the columns where they lie and writing the [B,2] gradients in place
+  — per timestep this replaced 12 column copies, 6 zero-fills + 6 scatters of select_backward and the adds that
+  merged them."""
+
+  @staticmethod
+  def forward(ctx, ctr, size, lg_var, H, W, Fh, Fw):
+    ts = [t if (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= 1) else t.contiguous() for t in (ctr, size, lg_var)]
+    B, dev = ctr.shape[0], ctr.device
+    outs = []
+    for k, (L, F) in enumerate(((H, Fh), (W, Fw))):
+      out = torch.empty((B, int(L), int(F)), dtype=torch.float32, device=dev)
+      check(rn.lib().ra_gauss_filter_strided_f32(*[_C.c_void_p(t.data_ptr() + 4 * k) for t in ts], *[int(t.stride(0)) for t in ts],
+                                                 B, int(L), int(F), ptr(out), rn.stream_ptr()), 'ra_gauss_filter_strided_f32')
+      outs.append(out)
+    ctx.save_for_backward(*ts)
+    ctx.dims = ((int(H), int(Fh)), (int(W), int(Fw)))
+    return outs[0], outs[1]
+
+  @staticmethod
+  def backward(ctx, gy, gx):
+    ts = ctx.saved_tensors
+    B, dev = ts[0].shape[0], ts[0].device
+    make = torch.zeros if (gy is None or gx is None) else torch.empty
+    grads = [make((B, 2), dtype=torch.float32, device=dev) for _ in range(3)]
+    for k, (g, (L, F)) in enumerate(zip((gy, gx), ctx.dims)):
+      if g is None:
+        continue
+      check(rn.lib().ra_gauss_filter_strided_bwd_f32(*[_C.c_void_p(t.data_ptr() + 4 * k) for t in ts],
+                                                     *[int(t.stride(0)) for t in ts], ptr(g.contiguous()), B, L, F,
+                                                     *[_C.c_void_p(t.data_ptr() + 4 * k) for t in grads], 2, rn.stream_ptr()),
+            'ra_gauss_filter_strided_bwd_f32')
+    return grads[0], grads[1], grads[2], None, None, None, None
+
+
+def gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw):
+  """(F_y [B,H,Fh], F_x [B,W,Fw]) of modellib.get_gaussian_filter for ctr, size, lg_var [B,2] = (y, x)."""
+  return GaussFilterPair.apply(ctr, size, lg_var, H, W, Fh, Fw)
+
+
 def extract(x, fy, fx):
   """modellib.extract_patch (modellib.py:615-641): F_y^T X_c F_x per channel; x [B,H,W,C]."""
   B, H, W, C = x.shape
@@ -572,31 +663,57 @@ class TrainStep(object):
         stats[key] = (mean, var)
     return x
 
+  def _linear(self, x, wname, bname):
+    """x W + b for two parameters of the bucket; their gradients accumulate in place when the step fuses them."""
+    P, g = self.leaves, self.bucket.grad_of
+    if self.fuse_param_grads and torch.is_grad_enabled() and wname in g and bname in g:
+      return LinearAcc.apply(x, P[wname], P[bname], g[wname], g[bname])
+    return torch.addmm(P[bname], x, P[wname])
+
   def _controller(self, feat):
     """full_model.py:668-689 on [B,G,Cf] features: glimpse read-out, LSTM (state = [c|h], zeroed per
     timestep), glimpse MLP (softmax over G), controller MLP."""
     P, d = self.leaves, self.d
     B, G, hid = feat.shape[0], d['G'], d['hid']
-    c = torch.zeros((B, hid), device=feat.device)
-    h = torch.zeros((B, hid), device=feat.device)
-    gmap = torch.full((B, 1, G), 1.0 / G, device=feat.device)
+    dev = feat.device  # constants of the recurrence's start: built once, never written
+    c = h = _const('zeros', (B, hid), dev, lambda: torch.zeros((B, hid), device=dev))
+    gmap = _const('gmap0', (B, G), dev, lambda: torch.full((B, 1, G), 1.0 / G, device=dev))
     Wg, bg = self._lstm_weights()
+    acc = self._lstm_grad_acc(Wg, bg)
     for it in range(d['iters']):
       glimpse = torch.bmm(gmap, feat)[:, 0]                       # sum_g map[g] feat[g, :]
-      pre = torch.addmm(bg, torch.cat([glimpse, h], dim=1), Wg)   # all four gates: one GEMM
+      xh = torch.cat([glimpse, h], dim=1)
+      pre = LinearAcc.apply(xh, Wg, bg, *acc) if acc is not None else torch.addmm(bg, xh, Wg)   # all four gates: one GEMM
       h, c = LSTMCell.apply(pre, c)
       if it < d['iters'] - 1:
         z = h
         for l in range(d['n_gmlp']):
-          z = torch.addmm(P['glimpse_mlp_b_%d' % l], z, P['glimpse_mlp_w_%d' % l])
+          z = self._linear(z, 'glimpse_mlp_w_%d' % l, 'glimpse_mlp_b_%d' % l)
           z = torch.relu(z) if l < d['n_gmlp'] - 1 else torch.softmax(z, dim=1)
         gmap = z[:, None, :]
     z = h
     for l in range(d['n_cmlp']):
-      z = torch.addmm(P['ctrl_mlp_b_%d' % l], z, P['ctrl_mlp_w_%d' % l])
+      z = self._linear(z, 'ctrl_mlp_w_%d' % l, 'ctrl_mlp_b_%d' % l)
       if l < d['n_cmlp'] - 1:
         z = torch.relu(z)
     return h, z
+
+  def _lstm_grad_acc(self, Wg, bg):
+    """(gW, gb, end-of-backward scatter) for the packed gate weights: step-local gradient buffers, zeroed once per
+    step, whose blocks are added to the eight parameter gradients when the backward pass ends.  None: plain autograd."""
+    g = self.bucket.grad_of
+    names = ['ctrl_lstm_w_x' + k for k in 'ifou'] + ['ctrl_lstm_w_h' + k for k in 'ifou'] + ['ctrl_lstm_b_' + k for k in 'ifou']
+    if not (self.fuse_param_grads and torch.is_grad_enabled() and all(n in g for n in names)):
+      return None
+    hit = _PACK.get('lstm_acc')
+    if hit is None:
+      buf = getattr(self, '_lstm_gbuf', None)
+      if buf is None or buf[0].shape != Wg.shape:
+        buf = self._lstm_gbuf = (torch.empty_like(Wg), torch.empty_like(bg))
+      buf[0].zero_()
+      buf[1].zero_()
+      hit = _PACK['lstm_acc'] = (buf[0], buf[1], _LstmGradScatter(self, buf[0], buf[1]))
+    return hit
 
   def _lstm_weights(self):
     """[w_x ; w_h] of the four gates side by side (i, f, o, u) and their biases: built once per step (the
@@ -693,12 +810,12 @@ class TrainStep(object):
       if d['dynamic_var']:
         lg_var = co[:, 4:6]
       if d['fixed_gamma']:
-        attn_gamma, y_lg_gamma = torch.ones((B, 1, 1, 1), device=dev), torch.full((B, 1, 1), 2.0, device=dev)
+        attn_gamma = _const('ones', (B, 1, 1, 1), dev, lambda: torch.ones((B, 1, 1, 1), device=dev))
+        y_lg_gamma = _const('twos', (B, 1, 1), dev, lambda: torch.full((B, 1, 1), 2.0, device=dev))
       else:
         attn_gamma, y_lg_gamma = torch.exp(co[:, 6]).reshape(B, 1, 1, 1), co[:, 8].reshape(B, 1, 1)
       box_gamma = torch.exp(co[:, 7]).reshape(B, 1, 1)
-      fy = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh)
-      fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+      fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
       # attention box: extract_patch(ones * gamma, F_y^T, F_x^T) = gamma * rowsum(F_y) (x) rowsum(F_x)
       box = torch.sigmoid(box_gamma * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
       if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
@@ -719,8 +836,7 @@ class TrainStep(object):
         kb = knob_box[:, tt]
         ctr = kb * ctr_m + (1 - kb) * ctr
         size = kb * size_m + (1 - kb) * size
-        fy = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh)
-        fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+        fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
       x_patch = attn_gamma * extract(inp.detach(), fy, fx)
       h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
       core = h_acnn[-1]
@@ -734,7 +850,7 @@ class TrainStep(object):
       y = torch.sigmoid(torch.exp(y_lg_gamma) * paste(y_patch[..., 0], fy, fx) - 5.0)        # [B,H,W]
       if d['disable_overwrite']:
         y = (1.0 - canvas[..., 0]) * y
-      s = torch.sigmoid(torch.cat([h, core.reshape(B, -1)], dim=1) @ P['score_mlp_w_0'] + P['score_mlp_b_0'])
+      s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
       y_c = y.detach()
       if use_knob:  # kick in the (noisy) ground-truth segmentation for the canvas (:826-841)
         if fixed:
@@ -952,8 +1068,7 @@ class BoxTrainStep(TrainStep):
       lg_var = torch.zeros_like(ctr) if d['fixed_var'] else torch.log(size) - torch.log(dims_f)
       if d['dynamic_var']:
         lg_var = co[:, 4:6]
-      fy = gaussian_filter(ctr[:, 0], size[:, 0], lg_var[:, 0], H, Fh)
-      fx = gaussian_filter(ctr[:, 1], size[:, 1], lg_var[:, 1], W, Fw)
+      fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
       box = torch.sigmoid(torch.exp(co[:, 7]).reshape(B, 1, 1) * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
       if fixed:
         gsel = y_gt[:, tt]
@@ -963,7 +1078,7 @@ class BoxTrainStep(TrainStep):
         gsel = ysel
       gsel = gsel - gsel * noise[tt]
       canvas = torch.maximum(gsel[..., None], canvas)                            # stop_gradient (:504)
-      s = h @ P['score_mlp_w_0'] + P['score_mlp_b_0']
+      s = self._linear(h, 'score_mlp_w_0', 'score_mlp_b_0')
       s_list.append((torch.sigmoid(s) if d['nsc'] == 1 else torch.softmax(s, dim=1))[:, None])
       box_list.append(box)
       cn_list.append(cn)
