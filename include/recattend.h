@@ -569,6 +569,26 @@ int ra_gauss_filter_strided_bwd_f32(const float *ctr, const float *size, const f
                                     int stride_ctr, int stride_size, int stride_lg_var, const float *g,
                                     int B, int L, int NF, float *dctr, float *dsize, float *dlg_var,
                                     int stride_grad, void *stream);
+/* The attention head of the training graph in one launch each way (it is scalar math on nine numbers per image):
+ *   ra_attn_head_f32   ctrl_out [B][stride >= 9] -> out [B][16] = cn[2] ls[2] ctr[2] size[2] lg_var[2] attn_gamma
+ *                      box_gamma y_lg_gamma (full_model.py:702-722, modellib.py:752-764,812-825); flags: 1 squash
+ *                      (tanh / -softplus), 2 fixed_var, 4 dynamic_var, 8 fixed_gamma.
+ *   ra_attn_head_bwd_f32  gradients of those fields (dense [B,2] / [B], each nullable = zero) -> d ctrl_out [B][9].
+ *   ra_knob_mix_f32    the ground-truth knob on the window (full_model.py:744-773): p2 = knob m + (1 - knob) p for
+ *                      centre and size, m = sum_t match[b][t] gt[b][t][:]; knob [B] with element stride knob_stride,
+ *                      ctr / size rows row_stride floats apart (fields of the head's record); outputs dense [B,2].
+ *   ra_knob_mix_bwd_f32   d p = (1 - knob) g (g nullable). */
+int ra_attn_head_f32(const float *ctrl_out, int stride, int B, int H, int W, int Fh, int Fw, int flags,
+                     float *out, void *stream);
+int ra_attn_head_bwd_f32(const float *ctrl_out, int stride, const float *out, const float *g_cn,
+                         const float *g_ls, const float *g_ctr, const float *g_size, const float *g_lg_var,
+                         const float *g_attn_gamma, const float *g_box_gamma, const float *g_y_lg_gamma, int B,
+                         int H, int W, int flags, float *d_ctrl_out, void *stream);
+int ra_knob_mix_f32(const float *ctr, const float *size, const float *match, const float *ctr_gt,
+                    const float *size_gt, const float *knob, int knob_stride, int row_stride, int B, int T,
+                    float *ctr2, float *size2, void *stream);
+int ra_knob_mix_bwd_f32(const float *g_ctr2, const float *g_size2, const float *knob, int knob_stride, int B,
+                        float *d_ctr, float *d_size, void *stream);
 int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
 int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
                               int HW, float *out, void *stream);

@@ -1063,3 +1063,133 @@ extern "C" int ra_gauss_filter_bwd_f32(const float *ctr, const float *size, cons
                                        int NF, float *dctr, float *dsize, float *dlg_var, void *stream) {
   return ra_gauss_filter_strided_bwd_f32(ctr, size, lg_var, 1, 1, 1, g, B, L, NF, dctr, dsize, dlg_var, 1, stream);
 }
+
+// ---- the attention head of the training graph: controller output -> attention parameters (full_model.py:702-722,
+// modellib.py:752-764,812-825), and the ground-truth knob on them (full_model.py:744-773).  Scalar math on nine numbers
+// per image; as separate torch ops it was ~45 launches per timestep forward + backward. ----
+namespace ra {
+namespace train {
+constexpr int kHeadStride = 16;  // floats per image in the head's output record
+// record: [0,1] cn  [2,3] ls  [4,5] ctr  [6,7] size  [8,9] lg_var  [10] attn_gamma  [11] box_gamma  [12] y_lg_gamma
+__device__ inline float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch.nn.functional.softplus
+__global__ __launch_bounds__(64) void attn_head_kernel(const float *co, int sco, int B, float H, float W, float Fh, float Fw,
+                                                       int flags, float *out) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float *c = co + (size_t)b * sco;
+  float *o = out + (size_t)b * kHeadStride;
+  const bool squash = flags & 1, fixed_var = flags & 2, dynamic_var = flags & 4, fixed_gamma = flags & 8;
+  const float dim[2] = {H, W}, fs[2] = {Fh, Fw};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float cn = squash ? tanhf(c[k]) : c[k];
+    const float ls = squash ? -softplus_t(c[2 + k]) : c[2 + k];
+    const float ctr = (cn + 1.0f) * dim[k] / 2.0f, size = expf(ls) * dim[k];
+    float lv = fixed_var ? 0.f : logf(size) - logf(fs[k]);
+    if (dynamic_var) lv = c[4 + k];
+    o[k] = cn;
+    o[2 + k] = ls;
+    o[4 + k] = ctr;
+    o[6 + k] = size;
+    o[8 + k] = lv;
+  }
+  o[10] = fixed_gamma ? 1.f : expf(c[6]);
+  o[11] = expf(c[7]);
+  o[12] = fixed_gamma ? 2.f : c[8];
+}
+// g_*: gradients of the record's fields, each nullable (no gradient = zero), dense [B,2] / [B]
+__global__ __launch_bounds__(64) void attn_head_bwd_kernel(const float *co, int sco, const float *out, const float *g_cn,
+                                                           const float *g_ls, const float *g_ctr, const float *g_size,
+                                                           const float *g_lv, const float *g_ag, const float *g_bg,
+                                                           const float *g_ylg, int B, float H, float W, int flags, float *dco) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float *c = co + (size_t)b * sco, *o = out + (size_t)b * kHeadStride;
+  float *d = dco + (size_t)b * 9;
+  const bool squash = flags & 1, fixed_var = flags & 2, dynamic_var = flags & 4, fixed_gamma = flags & 8;
+  const float dim[2] = {H, W};
+  auto at2 = [&](const float *g, int k) { return g ? g[2 * b + k] : 0.f; };
+  auto at1 = [&](const float *g) { return g ? g[b] : 0.f; };
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float cn = o[k], size = o[6 + k];
+    const float d_cn = at2(g_cn, k) + at2(g_ctr, k) * dim[k] / 2.0f;
+    // size = exp(ls) dim, lg_var = ls + log(dim / F): both follow ls
+    const float d_ls = at2(g_ls, k) + at2(g_size, k) * size + ((fixed_var || dynamic_var) ? 0.f : at2(g_lv, k));
+    d[k] = squash ? d_cn * (1.0f - cn * cn) : d_cn;
+    const float x = c[2 + k];
+    d[2 + k] = squash ? d_ls * (x > 20.f ? -1.0f : -1.0f / (1.0f + expf(-x))) : d_ls;
+    d[4 + k] = dynamic_var ? at2(g_lv, k) : 0.f;
+  }
+  d[6] = fixed_gamma ? 0.f : at1(g_ag) * o[10];
+  d[7] = at1(g_bg) * o[11];
+  d[8] = fixed_gamma ? 0.f : at1(g_ylg);
+}
+// p2 = kb m + (1 - kb) p for the window centre and size, m = sum_t match[b][t] gt[b][t][:] (the matched noisy GT box)
+__global__ __launch_bounds__(64) void knob_mix_kernel(const float *ctr, const float *size, const float *match, const float *ctr_gt,
+                                                      const float *size_gt, const float *kb, int skb, int sp, int B, int T,
+                                                      float *ctr2, float *size2) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float mc[2] = {0.f, 0.f}, ms[2] = {0.f, 0.f};
+  for (int t = 0; t < T; ++t) {
+    const float w = match[(size_t)b * T + t];
+    mc[0] += w * ctr_gt[((size_t)b * T + t) * 2];
+    mc[1] += w * ctr_gt[((size_t)b * T + t) * 2 + 1];
+    ms[0] += w * size_gt[((size_t)b * T + t) * 2];
+    ms[1] += w * size_gt[((size_t)b * T + t) * 2 + 1];
+  }
+  const float k = kb[(size_t)b * skb];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ctr2[2 * b + i] = k * mc[i] + (1.0f - k) * ctr[(size_t)b * sp + i];
+    size2[2 * b + i] = k * ms[i] + (1.0f - k) * size[(size_t)b * sp + i];
+  }
+}
+__global__ __launch_bounds__(64) void knob_mix_bwd_kernel(const float *g_ctr2, const float *g_size2, const float *kb, int skb, int B,
+                                                          float *d_ctr, float *d_size) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float k = 1.0f - kb[(size_t)b * skb];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    d_ctr[2 * b + i] = g_ctr2 ? k * g_ctr2[2 * b + i] : 0.f;
+    d_size[2 * b + i] = g_size2 ? k * g_size2[2 * b + i] : 0.f;
+  }
+}
+}  // namespace train
+}  // namespace ra
+
+extern "C" int ra_attn_head_f32(const float *ctrl_out, int stride, int B, int H, int W, int Fh, int Fw, int flags, float *out,
+                                void *stream) {
+  if (!ctrl_out || !out || B <= 0 || stride < 9) return fail(RA_E_INVALID, "ra_attn_head_f32: bad argument");
+  hipLaunchKernelGGL(train::attn_head_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), ctrl_out, stride, B, (float)H,
+                     (float)W, (float)Fh, (float)Fw, flags, out);
+  return launch_status("ra_attn_head_f32");
+}
+extern "C" int ra_attn_head_bwd_f32(const float *ctrl_out, int stride, const float *out, const float *g_cn, const float *g_ls,
+                                    const float *g_ctr, const float *g_size, const float *g_lg_var, const float *g_attn_gamma,
+                                    const float *g_box_gamma, const float *g_y_lg_gamma, int B, int H, int W, int flags,
+                                    float *d_ctrl_out, void *stream) {
+  if (!ctrl_out || !out || !d_ctrl_out || B <= 0 || stride < 9) return fail(RA_E_INVALID, "ra_attn_head_bwd_f32: bad argument");
+  hipLaunchKernelGGL(train::attn_head_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), ctrl_out, stride, out, g_cn,
+                     g_ls, g_ctr, g_size, g_lg_var, g_attn_gamma, g_box_gamma, g_y_lg_gamma, B, (float)H, (float)W, flags,
+                     d_ctrl_out);
+  return launch_status("ra_attn_head_bwd_f32");
+}
+extern "C" int ra_knob_mix_f32(const float *ctr, const float *size, const float *match, const float *ctr_gt, const float *size_gt,
+                               const float *knob, int knob_stride, int row_stride, int B, int T, float *ctr2, float *size2,
+                               void *stream) {
+  if (!ctr || !size || !match || !ctr_gt || !size_gt || !knob || !ctr2 || !size2 || B <= 0 || T <= 0 || row_stride < 2)
+    return fail(RA_E_INVALID, "ra_knob_mix_f32: bad argument");
+  hipLaunchKernelGGL(train::knob_mix_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), ctr, size, match, ctr_gt, size_gt,
+                     knob, knob_stride, row_stride, B, T, ctr2, size2);
+  return launch_status("ra_knob_mix_f32");
+}
+extern "C" int ra_knob_mix_bwd_f32(const float *g_ctr2, const float *g_size2, const float *knob, int knob_stride, int B,
+                                   float *d_ctr, float *d_size, void *stream) {
+  if (!knob || !d_ctr || !d_size || B <= 0) return fail(RA_E_INVALID, "ra_knob_mix_bwd_f32: bad argument");
+  hipLaunchKernelGGL(train::knob_mix_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), g_ctr2, g_size2, knob,
+                     knob_stride, B, d_ctr, d_size);
+  return launch_status("ra_knob_mix_bwd_f32");
+}

@@ -117,6 +117,10 @@ SIGNATURES = {
     'ra_conv_pair_wino_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     'ra_gauss_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_gauss_filter_bwd_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'ra_attn_head_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_attn_head_bwd_f32': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    'ra_knob_mix_f32': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'ra_knob_mix_bwd_f32': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'ra_gauss_filter_strided_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_gauss_filter_strided_bwd_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     'ra_lstm_cell_f32': (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),

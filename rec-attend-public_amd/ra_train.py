@@ -501,6 +501,73 @@ class _LstmGradScatter(object):
     self.gb.zero_()
 
 
+def _dense(g):
+  return None if g is None else g.contiguous()
+
+
+class AttnHead(torch.autograd.Function):
+  """Controller output [B,>=9] -> (cn, ls, ctr, size, lg_var [B,2], attn_gamma, box_gamma, y_lg_gamma [B]) of
+  full_model.py:702-722 / modellib.py:752-764,812-825: one launch forward, one backward (ra_attn_head_f32)."""
+
+  @staticmethod
+  def forward(ctx, co, H, W, Fh, Fw, flags):
+    ctx.set_materialize_grads(False)
+    co = co if (co.dim() == 2 and co.stride(1) == 1) else co.contiguous()
+    B = co.shape[0]
+    rec = torch.empty((B, 16), dtype=torch.float32, device=co.device)
+    check(rn.lib().ra_attn_head_f32(ptr(co), int(co.stride(0)), B, int(H), int(W), int(Fh), int(Fw), int(flags), ptr(rec),
+                                    rn.stream_ptr()), 'ra_attn_head_f32')
+    ctx.save_for_backward(co, rec)
+    ctx.meta = (int(H), int(W), int(flags))
+    return rec[:, 0:2], rec[:, 2:4], rec[:, 4:6], rec[:, 6:8], rec[:, 8:10], rec[:, 10], rec[:, 11], rec[:, 12]
+
+  @staticmethod
+  def backward(ctx, *gs):
+    co, rec = ctx.saved_tensors
+    H, W, flags = ctx.meta
+    B = co.shape[0]
+    gs = [_dense(g) for g in gs]
+    dco = torch.empty((B, co.shape[1]), dtype=torch.float32, device=co.device)
+    if co.shape[1] != 9:
+      dco.zero_()
+    out9 = dco if co.shape[1] == 9 else torch.empty((B, 9), dtype=torch.float32, device=co.device)
+    check(rn.lib().ra_attn_head_bwd_f32(ptr(co), int(co.stride(0)), ptr(rec), *[ptr(g) for g in gs], B, H, W, flags, ptr(out9),
+                                        rn.stream_ptr()), 'ra_attn_head_bwd_f32')
+    if out9 is not dco:
+      dco[:, :9] = out9
+    return dco, None, None, None, None, None
+
+
+class KnobMix(torch.autograd.Function):
+  """The ground-truth knob on the attention window (full_model.py:744-773): (ctr, size) <- knob * matched noisy GT box
+  + (1 - knob) * prediction, the matched box being sum_t match[b][t] gt[b][t] — one launch each way."""
+
+  @staticmethod
+  def forward(ctx, ctr, size, match, ctr_gt, size_gt, knob):
+    ctx.set_materialize_grads(False)
+    B, T = match.shape
+    if not (ctr.stride(1) == 1 and size.stride(1) == 1 and ctr.stride(0) == size.stride(0)):
+      ctr, size = ctr.contiguous(), size.contiguous()
+    knob = knob.reshape(B, -1)[:, 0]
+    ctr2 = torch.empty((B, 2), dtype=torch.float32, device=ctr.device)
+    size2 = torch.empty_like(ctr2)
+    check(rn.lib().ra_knob_mix_f32(ptr(ctr), ptr(size), ptr(match.contiguous()), ptr(ctr_gt.contiguous()), ptr(size_gt.contiguous()),
+                                   ptr(knob), int(knob.stride(0)), int(ctr.stride(0)), B, T, ptr(ctr2), ptr(size2), rn.stream_ptr()),
+          'ra_knob_mix_f32')
+    ctx.save_for_backward(knob)
+    return ctr2, size2
+
+  @staticmethod
+  def backward(ctx, g_ctr, g_size):
+    knob, = ctx.saved_tensors
+    B = knob.shape[0]
+    d_ctr = torch.empty((B, 2), dtype=torch.float32, device=knob.device)
+    d_size = torch.empty_like(d_ctr)
+    check(rn.lib().ra_knob_mix_bwd_f32(ptr(_dense(g_ctr)), ptr(_dense(g_size)), ptr(knob), int(knob.stride(0)), B, ptr(d_ctr),
+                                       ptr(d_size), rn.stream_ptr()), 'ra_knob_mix_bwd_f32')
+    return d_ctr, d_size, None, None, None, None
+
+
 class GaussFilterPair(torch.autograd.Function):
   """Both banks of an attention window from the [B,2] tensors (y, x) the controller head produces: two kernel
   launches forward and two backward, reading the columns where they lie and writing the [B,2] gradients in place
@@ -794,34 +861,24 @@ class TrainStep(object):
     canvas = torch.zeros((B, H, W, 1), device=dev)
     stats, y_list, s_list, box_list, cn_list, ls_list = {}, [], [], [], [], []
     dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
-    dims_f = _const('dims', (Fh, Fw), dev, lambda: torch.tensor([Fh, Fw], dtype=torch.float32, device=dev))
+    head_flags = (1 if d['squash'] else 0) | (2 if d['fixed_var'] else 0) | (4 if d['dynamic_var'] else 0) | (8 if d['fixed_gamma'] else 0)
     for tt in range(T):
       inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
       if inp.shape[3] != d['C0p']:
         inp = _pad_channels(inp)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
       h, co = self._controller(feat.reshape(B, d['G'], -1))
-      cn, ls = co[:, 0:2], co[:, 2:4]
-      if d['squash']:
-        cn, ls = torch.tanh(cn), -torch.nn.functional.softplus(ls)
-      ctr = (cn + 1.0) * dims_hw / 2.0                          # modellib.py:752-764
-      size = torch.exp(ls) * dims_hw                            # :812-825
-      lg_var = torch.zeros_like(ctr) if d['fixed_var'] else torch.log(size) - torch.log(dims_f)
-      if d['dynamic_var']:
-        lg_var = co[:, 4:6]
-      if d['fixed_gamma']:
-        attn_gamma = _const('ones', (B, 1, 1, 1), dev, lambda: torch.ones((B, 1, 1, 1), device=dev))
-        y_lg_gamma = _const('twos', (B, 1, 1), dev, lambda: torch.full((B, 1, 1), 2.0, device=dev))
-      else:
-        attn_gamma, y_lg_gamma = torch.exp(co[:, 6]).reshape(B, 1, 1, 1), co[:, 8].reshape(B, 1, 1)
-      box_gamma = torch.exp(co[:, 7]).reshape(B, 1, 1)
+      # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
+      cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
+      attn_gamma, y_lg_gamma, box_gamma = ag.reshape(B, 1, 1, 1), ylg.reshape(B, 1, 1), bgm.reshape(B, 1, 1)
       fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
       # attention box: extract_patch(ones * gamma, F_y^T, F_x^T) = gamma * rowsum(F_y) (x) rowsum(F_x)
       box = torch.sigmoid(box_gamma * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
       if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
         if fixed:
-          ctr_m, size_m = ctr_gtn[:, tt], size_gtn[:, tt]
           gmatch = None
+          gsel_box = _const('onehot', (B, T, tt), dev, lambda: torch.nn.functional.one_hot(
+              torch.full((B,), tt, device=dev), T).to(torch.float32))
         else:
           if opt.get('use_iou_box', False):  # IoU of the box corners (modellib.f_iou_box, full_model.py:750-754)
             import modellib
@@ -831,11 +888,9 @@ class TrainStep(object):
           else:
             iou_t = ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
           gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
-          ctr_m = (gmatch[:, :, None] * ctr_gtn).sum(dim=1)
-          size_m = (gmatch[:, :, None] * size_gtn).sum(dim=1)
-        kb = knob_box[:, tt]
-        ctr = kb * ctr_m + (1 - kb) * ctr
-        size = kb * size_m + (1 - kb) * size
+          gsel_box = gmatch
+        # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)
+        ctr, size = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt])
         fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
       x_patch = attn_gamma * extract(inp.detach(), fy, fx)
       h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
@@ -1056,20 +1111,14 @@ class BoxTrainStep(TrainStep):
     ysel = torch.empty((B, H, W), device=dev)
     stats, box_list, s_list, cn_list, ls_list = {}, [], [], [], []
     dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
-    dims_f = _const('dims', (Fh, Fw), dev, lambda: torch.tensor([Fh, Fw], dtype=torch.float32, device=dev))
+    head_flags = (1 if d['squash'] else 0) | (2 if d['fixed_var'] else 0) | (4 if d['dynamic_var'] else 0) | 8
     for tt in range(T):
       inp = torch.cat([x, canvas], dim=3)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, None, stats)[-1]
       h, co = self._controller(feat.reshape(B, d['G'], -1))
-      cn, ls = co[:, 0:2], co[:, 2:4]
-      if d['squash']:
-        cn, ls = torch.tanh(cn), -torch.nn.functional.softplus(ls)
-      ctr, size = (cn + 1.0) * dims_hw / 2.0, torch.exp(ls) * dims_hw
-      lg_var = torch.zeros_like(ctr) if d['fixed_var'] else torch.log(size) - torch.log(dims_f)
-      if d['dynamic_var']:
-        lg_var = co[:, 4:6]
+      cn, ls, ctr, size, lg_var, _, bgm, _ = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
       fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
-      box = torch.sigmoid(torch.exp(co[:, 7]).reshape(B, 1, 1) * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
+      box = torch.sigmoid(bgm.reshape(B, 1, 1) * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
       if fixed:
         gsel = y_gt[:, tt]
       else:
