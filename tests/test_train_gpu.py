@@ -462,3 +462,77 @@ def test_fused_pointwise_kernels_vs_torch_autograd(cuda):
   h, c = ra_train.LSTMCell.apply(p32, c32)  # c's gradient absent (the last glimpse of a timestep)
   (h * wh.float().to(cuda)).sum().backward()
   assert np.isfinite(p32.grad.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize('flags', [0, 1, 2, 5, 8, 9, 15])
+def test_attention_head_and_knob_vs_torch_autograd(cuda, flags):
+  """AttnHead (controller output -> window parameters and gammas), GaussFilterPair (both banks from the [B,2]
+  tensors where they lie), KnobMix (the ground-truth knob) and LinearAcc (in-place parameter gradients): one launch
+  each way, against the reference formulas (full_model.py:702-722,744-773, modellib.py:752-764,812-825) under torch
+  autograd in float64.  flags: 1 squash, 2 fixed_var, 4 dynamic_var, 8 fixed_gamma."""
+  import math
+  import ra_train
+  g = torch.Generator().manual_seed(10 + flags)
+  B, T, H, W, Fh, Fw = 5, 4, 64, 96, 16, 16
+  squash, fixed_var, dynamic_var, fixed_gamma = bool(flags & 1), bool(flags & 2), bool(flags & 4), bool(flags & 8)
+  co = (torch.randn(B, 9, generator=g) * 0.7).double().requires_grad_(True)
+  ctr_gt, size_gt = torch.rand(B, T, 2, generator=g).double() * 60, 10 + torch.rand(B, T, 2, generator=g).double() * 30
+  match = torch.nn.functional.one_hot(torch.randint(0, T, (B,), generator=g), T).double()
+  knob = (torch.rand(B, 3, 1, generator=g) > 0.5).double()
+  dims, fdim = torch.tensor([H, W], dtype=torch.float64), torch.tensor([Fh, Fw], dtype=torch.float64)
+
+  def bank(c, s, lv, L, F):
+    j = torch.arange(F, dtype=torch.float64)
+    mu = c[:, None] + ((s[:, None] + 1.0) / F) * (j[None, :] - (F - 1) / 2.0)
+    dd = torch.arange(L, dtype=torch.float64)[None, :, None] - mu[:, None, :]
+    var = torch.exp(lv)[:, None, None]
+    return torch.exp(-0.5 * dd * dd / var) / (torch.sqrt(var) * math.sqrt(2 * math.pi))
+
+  cn, ls = co[:, 0:2], co[:, 2:4]
+  if squash:
+    cn, ls = torch.tanh(cn), -torch.nn.functional.softplus(ls)
+  ctr, size = (cn + 1.0) * dims / 2.0, torch.exp(ls) * dims
+  lv = torch.zeros_like(ctr) if fixed_var else torch.log(size) - torch.log(fdim)
+  if dynamic_var:
+    lv = co[:, 4:6]
+  ag = torch.ones(B, dtype=torch.float64) if fixed_gamma else torch.exp(co[:, 6])
+  ylg = torch.full((B,), 2.0, dtype=torch.float64) if fixed_gamma else co[:, 8]
+  bg = torch.exp(co[:, 7])
+  kb = knob[:, 1]
+  ctr2 = kb * (match[:, :, None] * ctr_gt).sum(dim=1) + (1 - kb) * ctr
+  size2 = kb * (match[:, :, None] * size_gt).sum(dim=1) + (1 - kb) * size
+  fy, fx = bank(ctr2[:, 0], size2[:, 0], lv[:, 0], H, Fh), bank(ctr2[:, 1], size2[:, 1], lv[:, 1], W, Fw)
+  fy0 = bank(ctr[:, 0], size[:, 0], lv[:, 0], H, Fh)
+  wy, wx, w0 = [torch.randn(*s, generator=g).double() for s in ((B, H, Fh), (B, W, Fw), (B, H, Fh))]
+  ws = torch.randn(B, 7, generator=g).double()
+  ref = (fy * wy).sum() + (fx * wx).sum() + (fy0 * w0).sum() + (ag * ws[:, 0]).sum() + (ylg * ws[:, 1]).sum() + \
+      (bg * ws[:, 2]).sum() + (cn * ws[:, 3:5]).sum() + (ls * ws[:, 5:7]).sum()
+  ref.backward()
+
+  f = lambda t: t.detach().float().to(cuda)
+  co32 = f(co).requires_grad_(True)
+  cn_, ls_, ctr_, size_, lv_, ag_, bg_, ylg_ = ra_train.AttnHead.apply(co32, H, W, Fh, Fw, flags)
+  c2, s2 = ra_train.KnobMix.apply(ctr_, size_, f(match), f(ctr_gt), f(size_gt), f(knob)[:, 1])
+  fy_, fx_ = ra_train.gaussian_filters(c2, s2, lv_, H, W, Fh, Fw)
+  fy0_, _ = ra_train.gaussian_filters(ctr_, size_, lv_, H, W, Fh, Fw)
+  wsd = f(ws)
+  out = (fy_ * f(wy)).sum() + (fx_ * f(wx)).sum() + (fy0_ * f(w0)).sum() + (ag_ * wsd[:, 0]).sum() + (ylg_ * wsd[:, 1]).sum() + \
+      (bg_ * wsd[:, 2]).sum() + (cn_ * wsd[:, 3:5]).sum() + (ls_ * wsd[:, 5:7]).sum()
+  out.backward()
+  for a, b in ((ctr_, ctr), (size_, size), (lv_, lv), (ag_, ag), (bg_, bg), (ylg_, ylg), (c2, ctr2), (s2, size2), (fy_, fy), (fx_, fx)):
+    assert np.abs(a.detach().cpu().numpy() - b.detach().numpy()).max() < 2e-5 * max(1.0, float(b.detach().abs().max()))
+  gr, gd = co.grad.numpy(), co32.grad.cpu().numpy()
+  assert np.abs(gd - gr).max() < 5e-4 * max(1.0, np.abs(gr).max()), np.abs(gd - gr).max()
+
+  # LinearAcc: y = x W + b with dW, db added in place to caller buffers, dx returned
+  x = torch.randn(B, 12, generator=g).double().requires_grad_(True)
+  Wl, bl = torch.randn(12, 7, generator=g).double().requires_grad_(True), torch.randn(7, generator=g).double().requires_grad_(True)
+  wo = torch.randn(B, 7, generator=g).double()
+  ((x @ Wl + bl) * wo).sum().backward()
+  x32 = f(x).requires_grad_(True)
+  gw, gb = torch.ones(12, 7, device=cuda), torch.ones(7, device=cuda)   # accumulate on top of what is there
+  y = ra_train.LinearAcc.apply(x32, f(Wl).requires_grad_(True), f(bl).requires_grad_(True), gw, gb)
+  (y * f(wo)).sum().backward()
+  assert np.abs(x32.grad.cpu().numpy() - x.grad.numpy()).max() < 1e-4
+  assert np.abs(gw.cpu().numpy() - 1.0 - Wl.grad.numpy()).max() < 1e-4
+  assert np.abs(gb.cpu().numpy() - 1.0 - bl.grad.numpy()).max() < 1e-4
