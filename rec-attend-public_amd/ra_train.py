@@ -184,15 +184,19 @@ def wgrad_join():
   _wgrad_join(torch.device('cuda', torch.cuda.current_device()))
 
 
-_PACK = {}  # per step: (weight storage, geometry) -> packed filter; the filters are shared by the T timesteps
+_PACK = {}  # per step: (weight storage, geometry) -> packed filter; the filters are shared by the T timesteps.
+# forward_loss() clears it (the optimizer writes the weights through raw pointers); an entry keeps its source tensor
+# alive and carries the tensor's version, so a caller outside forward_loss cannot be handed the pack of a freed
+# tensor whose address was reused, nor one that predates an in-place update.
 
 
 def _pack_dev(w, cin_w, cout, cin, cmap_t, transposed):
-  key = (w.data_ptr(), int(cin_w), int(cout), int(cin), 0 if cmap_t is None else cmap_t.data_ptr(), bool(transposed))
+  key = (w.data_ptr(), w._version, int(cin_w), int(cout), int(cin), 0 if cmap_t is None else cmap_t.data_ptr(), bool(transposed))
   hit = _PACK.get(key)
   if hit is not None:
-    return hit
-  out = _PACK[key] = _pack_dev_now(w, cin_w, cout, cin, cmap_t, transposed)
+    return hit[1]
+  out = _pack_dev_now(w, cin_w, cout, cin, cmap_t, transposed)
+  _PACK[key] = (w, out)
   return out
 
 
@@ -260,10 +264,11 @@ class ConvBNActPool(torch.autograd.Function):
     scale = _const('ones', cp, dev, lambda: torch.ones(cp, dtype=torch.float32, device=dev))
     shift = b.detach()
     if cp != cout:  # padded once per step (the layer's bias is shared by all timesteps), not once per use
-      key = ('shift', b.data_ptr(), cp)
-      shift = _PACK.get(key)
-      if shift is None:
-        shift = _PACK[key] = torch.nn.functional.pad(b.detach(), (0, cp - cout))
+      key = ('shift', b.data_ptr(), b._version, cp)
+      hit = _PACK.get(key)
+      if hit is None:
+        hit = _PACK[key] = (b, torch.nn.functional.pad(b.detach(), (0, cp - cout)))
+      shift = hit[1]
     u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2))
     H, W = u.shape[1], u.shape[2]
     use_bn = gamma is not None
@@ -748,7 +753,7 @@ class TrainStep(object):
     Wg, bg = self._lstm_weights()
     acc = self._lstm_grad_acc(Wg, bg)
     for it in range(d['iters']):
-      glimpse = torch.bmm(gmap, feat)[:, 0]                       # sum_g map[g] feat[g, :]
+      glimpse = torch.bmm(gmap, feat).reshape(B, -1)              # sum_g map[g] feat[g, :]  (a view: `[:, 0]` costs a zero-fill + copy backward)
       xh = torch.cat([glimpse, h], dim=1)
       pre = LinearAcc.apply(xh, Wg, bg, *acc) if acc is not None else torch.addmm(bg, xh, Wg)   # all four gates: one GEMM
       h, c = LSTMCell.apply(pre, c)
@@ -902,7 +907,7 @@ class TrainStep(object):
         skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None
                           for i in range(1, d['adcnn_nlayers'])]
       y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
-      y = torch.sigmoid(torch.exp(y_lg_gamma) * paste(y_patch[..., 0], fy, fx) - 5.0)        # [B,H,W]
+      y = torch.sigmoid(torch.exp(y_lg_gamma) * paste(y_patch.reshape(B, Fh, Fw) if y_patch.shape[-1] == 1 else y_patch[..., 0], fy, fx) - 5.0)  # [B,H,W]
       if d['disable_overwrite']:
         y = (1.0 - canvas[..., 0]) * y
       s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
