@@ -28,6 +28,7 @@ struct PArgs {
   const float *cache;   // conv_pair8 CACHED form: layer A's timestep-invariant partial sums
   int cache_rows, cache_gx, bytes_c;
   int bytes_y;  // conv_pair8: size of y for its buffer descriptor (< 2 GiB whenever the input is)
+  int xcd_map;  // conv_pair8: 1 = each XCD (workgroup id mod 8) walks its own contiguous eighth of the tiles
 };
 
 template <int CINA, int CMID, int NCB, int GX, int GYB>
@@ -635,7 +636,14 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
     c.tx = r - c.ty * tiles_x;
     return c;
   };
-  const TC stride = split(gridDim.x);
+  // tile walk: workgroup g takes tiles g, g + gridDim.x, ...; or, XCD-contiguous (a.xcd_map, gridDim.x % 8 == 0):
+  // workgroups are dealt to the 8 XCDs round robin, so XCD x = g % 8 walks the tiles [x * chunk, (x + 1) * chunk) with its
+  // gridDim.x / 8 workgroups — neighbouring tiles (shared halo rows, the cache's halo) then meet in ONE L2
+  const int nwx = a.xcd_map ? (int)gridDim.x >> 3 : (int)gridDim.x;
+  const int chunk = (ntiles + 7) >> 3;
+  const int t_first = a.xcd_map ? ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_end = a.xcd_map ? (((int)blockIdx.x & 7) * chunk + chunk < ntiles ? ((int)blockIdx.x & 7) * chunk + chunk : ntiles) : ntiles;
+  const TC stride = split(nwx);
   auto advance = [&](TC c) {
     c.tx += stride.tx;
     if (c.tx >= tiles_x) {
@@ -710,15 +718,15 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
 #pragma unroll
   for (int g = 0; g < 4; ++g) g_y[g] = ((g >> 1) * a.Wo + 8 * (g & 1)) * a.CoutB * 4;
 
-  int tile = blockIdx.x;
+  int tile = t_first;
   TC cur = split(tile), nxt = cur;
-  if (tile < ntiles) fetch(cur);
+  if (tile < t_end) fetch(cur);
   // the padded groups read LDS this kernel never writes; whatever an earlier kernel left there
   // must not be NaN/Inf (their results are discarded, but keep the arithmetic clean)
   for (int e = tid; e < (IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
     reinterpret_cast<f32x4 *>(lds)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x, cur = nxt) {
+  for (; tile < t_end; tile += nwx, cur = nxt) {
     const int b = cur.b, ty0 = cur.ty * G::TH, tx0 = cur.tx * G::TW;
 
     // ---------------- stage layer A's input window (prefetched registers -> LDS) ----------------
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
     }
     __syncthreads();
     nxt = advance(cur);
-    if (tile + (int)gridDim.x < ntiles) fetch(nxt);  // the next tile's loads fly while this one is computed
+    if (tile + nwx < t_end) fetch(nxt);  // the next tile's loads fly while this one is computed
 
     // ---------------- phase A: layer A on the 18 x 36 region -> tmid ----------------
     {
@@ -911,7 +919,15 @@ int launch8(const PArgs &a_in, int B, hipStream_t st) {
     // room for the kernels of the other decode graphs: 50.4k vs 49.7k instance-timesteps/s with four batches in flight
     wgs = e ? atoi(e) : 768;
   }
-  hipLaunchKernelGGL(kern, dim3(ntiles < wgs ? ntiles : wgs), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  static int xcd = -1;  // RA_PAIR8_XCD=0: tuning aid, the interleaved tile walk (51.7k vs 52.1k instance-timesteps/s pipelined)
+  if (xcd < 0) {
+    const char *e = getenv("RA_PAIR8_XCD");
+    xcd = e ? atoi(e) : 1;
+  }
+  PArgs a2 = a;
+  const int grid = ntiles < wgs ? ntiles : wgs;
+  a2.xcd_map = (xcd && grid % 8 == 0 && grid >= 8) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a2, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_f32");
 }
 

@@ -43,7 +43,29 @@ struct WArgs {
   float *y;
   int B, H, W, Cout, relu;
   int bytes_x;
+  int xcd_map;
 };
+
+// XCD-contiguous tile walk (see conv_pair8_mfma): workgroups are dealt to the 8 XCDs round robin, so with
+// gridDim.x % 8 == 0 XCD x = blockIdx.x % 8 walks the tiles [x * chunk, (x + 1) * chunk) with its gridDim.x / 8
+// workgroups and neighbouring tiles' halos meet in one L2.  first / end / step of this workgroup's walk.
+struct TileWalk {
+  int first, end, step;
+};
+__device__ inline TileWalk tile_walk(int ntiles, int xcd_map) {
+  TileWalk w;
+  if (!xcd_map) {
+    w.first = blockIdx.x;
+    w.end = ntiles;
+    w.step = gridDim.x;
+    return w;
+  }
+  const int chunk = (ntiles + 7) >> 3, x = blockIdx.x & 7;
+  w.first = x * chunk + ((int)blockIdx.x >> 3);
+  w.end = (x * chunk + chunk < ntiles) ? x * chunk + chunk : ntiles;
+  w.step = (int)gridDim.x >> 3;
+  return w;
+}
 
 // TSY: output tile height, 16 (4 row blocks) or 8 (2 row blocks: more, smaller workgroups for the layers whose
 // 16x16 tiles would not give every CU two workgroups)
@@ -106,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
     }
   };
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileWalk tw = tile_walk(ntiles, a.xcd_map);
+  for (int tile = tw.first; tile < tw.end; tile += tw.step) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy = ty * TSY - 1, ox = tx * TS - 1;
@@ -229,7 +252,9 @@ int launch(const WArgs &a, hipStream_t st) {
   int gx = cap / slices;
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  WArgs a2 = a;  // XCD-contiguous tile walk when the grid's rows are whole rounds of the 8 XCDs
+  a2.xcd_map = (gx % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a2, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_wino_f32");
 }
 
@@ -273,6 +298,7 @@ struct PWArgs {
   float *y;
   int B, H, W, CoutAP, reluA, reluB;
   int bytes_x;
+  int xcd_map;
 };
 
 template <int TSY>
@@ -341,9 +367,10 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile < ntiles) fetch(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
+  const TileWalk tw = tile_walk(ntiles, a.xcd_map);
+  int tile = tw.first;
+  if (tile < tw.end) fetch(tile);
+  for (; tile < tw.end; tile += tw.step) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     __syncthreads();  // the previous tile's phase B (exchange reads) is complete
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
       }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
     // ---------------- phase A: layer A on the window, BN + ReLU, -> tin ----------------
     {
@@ -861,7 +888,15 @@ int launch_pair(const PWArgs &a, hipStream_t st) {
     attr = true;
   }
   const int tiles_x = a.W / TS, tiles_y = a.H / TSY, ntiles = tiles_x * tiles_y * a.B;
-  hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  static int xcd = -1;  // RA_PAIRW_XCD=0: tuning aid, the interleaved tile walk
+  if (xcd < 0) {
+    const char *e = getenv("RA_PAIRW_XCD");
+    xcd = e ? atoi(e) : 1;
+  }
+  const int grid = ntiles < cap ? ntiles : cap;
+  PWArgs a2 = a;
+  a2.xcd_map = (xcd && grid % 8 == 0 && grid >= 8) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a2, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_wino_f32");
 }
 
@@ -919,6 +954,7 @@ extern "C" int ra_conv_wino_f32(const float *x, int B, int H, int W, int Cin, co
   a.Cout = Cout;
   a.relu = relu;
   a.bytes_x = (int)bytes;
+  a.xcd_map = 0;
   hipStream_t st = as_stream(stream);
   if (Cout % 32) {  // 16 output channels per workgroup
     if (Cin == 16) return pool == 2 ? wino::launch_any<16, 2, 1>(a, st) : wino::launch_any<16, 1, 1>(a, st);
@@ -956,6 +992,7 @@ extern "C" int ra_conv_pair_wino_f32(const float *x, int B, int H, int W, const 
   a.reluA = reluA;
   a.reluB = reluB;
   a.bytes_x = (int)bytes;
+  a.xcd_map = 0;
   static int form = -1;  // RA_PAIRW_FORM=2|3: tuning aid, the other forms of phase B
   if (form < 0) {
     // form 2 (row-block waves, in-register output transform, 244 VGPRs) is the fastest alone (37.6 vs 39.0 us), but form 1
