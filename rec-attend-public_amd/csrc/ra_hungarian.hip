@@ -37,6 +37,7 @@ struct Scratch {
   unsigned char *mark, *inS, *inT, *inN;
   ring_int *ring;  // device: LDS window over the tail of the BFS queue (ring_n entries, a power of two)
   int ring_n;  // 0 = none, every queue access goes to `queue`
+  int chunked;  // device, n <= 64: the chunk-parallel search (augment_wave64c); needs 64 more LDS entries behind the ring
 };
 
 // The scratch has a HOT part (flow network, equality graph, marks: a few n^2 floats, touched by
@@ -74,6 +75,7 @@ __host__ __device__ inline Scratch carve(void *hot, void *queue, int nx, int ny)
   s.queue = reinterpret_cast<int *>(queue);
   s.ring = nullptr;
   s.ring_n = 0;
+  s.chunked = 0;
   return s;
 }
 
@@ -437,6 +439,45 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long x, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The augmenting path's walk for the register-resident searches below, on uniform scalars: every lane reads the same
+// LDS words, lane 0 writes, lanes p and v update their adjacency masks.  parent: lane u holds parent[u].
+__device__ __forceinline__ int push_path64(Scratch &g, float cap_max, int lane, unsigned long long &adj, int parent) {
+  const int n = g.n, dst = n - 1;
+  // the path walk, on uniform scalars: every lane reads the same LDS words, lane 0 writes
+  float bottleneck = cap_max;  // capacity.maxCoeff(), hungarian.cc:144
+  int v = dst;
+  for (int it = 0;; ++it) {
+    const int p = __builtin_amdgcn_readlane(parent, v);
+    if (p == -1) break;
+    if (it == kMaxIter) return RA_E_HUNG_PATH;
+    const float r = g.res[(size_t)p * n + v];
+    bottleneck = (bottleneck < r) ? bottleneck : r;
+    v = p;
+  }
+  v = dst;
+  for (int it = 0;; ++it) {
+    const int p = __builtin_amdgcn_readlane(parent, v);
+    if (p == -1) break;
+    if (it == kMaxIter) return RA_E_HUNG_PATH;
+    const size_t pv = (size_t)p * n + v, vp = (size_t)v * n + p;
+    const bool fwd = g.cap[pv] > 0;
+    const float f = fwd ? g.flow[pv] + bottleneck : g.flow[vp] - bottleneck;
+    const float rpv = g.res[pv] - bottleneck, rvp = g.res[vp] + bottleneck;
+    lds_order();
+    if (lane == 0) {
+      g.flow[fwd ? pv : vp] = f;
+      g.res[pv] = rpv;
+      g.res[vp] = rvp;
+    }
+    lds_order();
+    if (lane == p) adj = (adj & ~(1ull << v)) | ((rpv > 0) ? (1ull << v) : 0ull);
+    if (lane == v) adj = (adj & ~(1ull << p)) | ((rvp > 0) ? (1ull << p) : 0ull);
+    v = p;
+  }
+  return 1;
+}
+
+
 __device__ __forceinline__ int augment_wave64(Scratch &g, float cap_max, int lane, unsigned long long &adj) {
   const int n = g.n, src = 0, dst = n - 1;
   const int R = g.ring_n;  // >= 64 on this path
@@ -489,38 +530,82 @@ __device__ __forceinline__ int augment_wave64(Scratch &g, float cap_max, int lan
     qt += cnt;
   }
   if (!reached) return 0;
-  // the path walk, on uniform scalars: every lane reads the same LDS words, lane 0 writes
-  float bottleneck = cap_max;  // capacity.maxCoeff(), hungarian.cc:144
-  int v = dst;
-  for (int it = 0;; ++it) {
-    const int p = __builtin_amdgcn_readlane(parent, v);
-    if (p == -1) break;
-    if (it == kMaxIter) return RA_E_HUNG_PATH;
-    const float r = g.res[(size_t)p * n + v];
-    bottleneck = (bottleneck < r) ? bottleneck : r;
-    v = p;
-  }
-  v = dst;
-  for (int it = 0;; ++it) {
-    const int p = __builtin_amdgcn_readlane(parent, v);
-    if (p == -1) break;
-    if (it == kMaxIter) return RA_E_HUNG_PATH;
-    const size_t pv = (size_t)p * n + v, vp = (size_t)v * n + p;
-    const bool fwd = g.cap[pv] > 0;
-    const float f = fwd ? g.flow[pv] + bottleneck : g.flow[vp] - bottleneck;
-    const float rpv = g.res[pv] - bottleneck, rvp = g.res[vp] + bottleneck;
+  return push_path64(g, cap_max, lane, adj, parent);
+}
+
+// Chunk-parallel form of the same search.  The queue entries [qh, qt) are known before any of them is popped, and
+// a pop only ever ADDS marks (pushes do not mark), so up to 64 pops are processed at once, lane k taking queue entry
+// qh + k: the marks pop k sees are the marks so far OR-ed with the bits of the nodes popped at lanes <= k (an inclusive
+// prefix-OR over the lanes), its pushes go to the queue behind the pushes of lanes < k (an exclusive prefix sum of the
+// push counts), parent[u] is the node popped at the LAST lane that pushed u (an LDS max), and everything from the
+// first pop of the sink onwards is discarded.  Same pops, same pushes in the same order, same parents as one pop
+// at a time — a search of ~100 pops becomes ~5 rounds.  A round whose pushes would overrun the LDS ring restarts
+// the search in augment_wave64 (which can move the queue to global memory); nothing but the search state was touched.
+__device__ __forceinline__ int augment_wave64c(Scratch &g, float cap_max, int lane, unsigned long long &adj) {
+  const int n = g.n, dst = n - 1;
+  const int R = g.ring_n;
+  ring_int *last = g.ring + R;  // [64]: lane of this round's last pusher of node u, -1 = none
+  unsigned long long marks = 0;
+  int parent = -1;
+  if (lane == 0) g.ring[0] = 0;  // the source
+  last[lane] = -1;
+  int qh = 0, qt = 1, it = 0;
+  bool reached = false;
+  while (qt > qh) {
+    if (it >= kMaxIter) return RA_E_HUNG_BFS;
+    int len = qt - qh;
+    len = len > 64 ? 64 : len;
+    len = len > kMaxIter - it ? kMaxIter - it : len;
     lds_order();
-    if (lane == 0) {
-      g.flow[fwd ? pv : vp] = f;
-      g.res[pv] = rpv;
-      g.res[vp] = rvp;
+    const bool valid = lane < len;
+    const int v = valid ? (int)g.ring[(qh + lane) & (R - 1)] : 0;
+    const unsigned long long sink = __ballot(valid && v == dst);
+    const int kstop = sink ? (int)__builtin_ctzll(sink) : 64;  // lane of the first pop of the sink
+    const int npop = kstop < len ? kstop + 1 : len;
+    unsigned long long pm = lane < npop ? 1ull << v : 0ull;  // -> marks added by the pops at lanes <= this one
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned lo = __shfl_up((unsigned)pm, d), hi = __shfl_up((unsigned)(pm >> 32), d);
+      if (lane >= d) pm |= ((unsigned long long)hi << 32) | lo;
+    }
+    const unsigned long long row = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(adj >> 32), v) << 32) |
+                                   (unsigned)__shfl((int)(unsigned)adj, v);
+    const unsigned long long m = (valid && lane < kstop) ? (row & ~(marks | pm)) : 0ull;
+    const int cnt = __popcll(m);
+    int off = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(off, d);
+      if (lane >= d) off += t;
+    }
+    const int total = __builtin_amdgcn_readlane(off, 63);
+    off -= cnt;
+    if (qt + total - (qh + npop) > R) return augment_wave64(g, cap_max, lane, adj);
+    unsigned long long mm = m;
+    for (int pos = qt + off; mm; ++pos) {  // ascending u, like the serial scan
+      const int u = (int)__builtin_ctzll(mm);
+      mm &= mm - 1;
+      g.ring[pos & (R - 1)] = u;
+      __hip_atomic_fetch_max(&last[u], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     lds_order();
-    if (lane == p) adj = (adj & ~(1ull << v)) | ((rpv > 0) ? (1ull << v) : 0ull);
-    if (lane == v) adj = (adj & ~(1ull << p)) | ((rvp > 0) ? (1ull << p) : 0ull);
-    v = p;
+    const int lk = last[lane];
+    const int pv = __shfl(v, lk < 0 ? 0 : lk);
+    if (lk >= 0) {
+      parent = pv;  // later pushers overwrite
+      last[lane] = -1;
+    }
+    marks |= readlane64(pm, npop - 1);
+    qh += npop;
+    it += npop;
+    qt += total;
+    if (kstop < len) {
+      reached = true;
+      break;
+    }
   }
-  return 1;
+  if (!reached) return 0;
+  return push_path64(g, cap_max, lane, adj, parent);
 }
 
 __device__ __forceinline__ int rematch_wave64(Scratch &g, int nx, int ny, float *M, int lane) {
@@ -548,7 +633,7 @@ __device__ __forceinline__ int rematch_wave64(Scratch &g, int nx, int ny, float 
   if (lane < n)
     for (int u = 0; u < n; ++u) adj |= (g.cap[(size_t)lane * n + u] > 0) ? (1ull << u) : 0ull;
   for (int it = 0;; ++it) {
-    const int r = augment_wave64(g, cap_max, lane, adj);
+    const int r = g.chunked ? augment_wave64c(g, cap_max, lane, adj) : augment_wave64(g, cap_max, lane, adj);
     if (r < 0) return r;
     if (r == 0 || it > kMaxIter) break;
     if (it == kMaxIter) return RA_E_HUNG_FLOW;
@@ -563,10 +648,11 @@ __device__ __forceinline__ int rematch_wave64(Scratch &g, int nx, int ny, float 
 }
 
 __device__ __forceinline__ int solve_wave(const float *w, int nx, int ny, float *M, float *cx, float *cy,
-                                 void *hot_buf, void *queue_buf, ring_int *ring, int ring_n, int lane) {
+                                 void *hot_buf, void *queue_buf, ring_int *ring, int ring_n, int chunked, int lane) {
   Scratch g = carve(hot_buf, queue_buf, nx, ny);
   g.ring = ring;
   g.ring_n = ring_n;
+  g.chunked = chunked;
   for (int x = lane; x < nx; x += 64) {
     float top = w[x * ny];
     for (int y = 1; y < ny; ++y) top = (w[x * ny + y] > top) ? w[x * ny + y] : top;
@@ -700,7 +786,7 @@ __device__ __forceinline__ int solve_wave(const float *w, int nx, int ny, float 
 __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, int ny, float *M,
                                                         float *cx, float *cy, int *status,
                                                         char *ws, size_t ws_per_ex, int use_lds,
-                                                        int ring_n, int ring_off) {
+                                                        int ring_n, int ring_off, int chunked) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int b = blockIdx.x, t = threadIdx.x;
   const float *wb = w + (size_t)b * nx * ny;
@@ -709,7 +795,7 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, i
   if (!use_lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int rc = solve_wave(wb, nx, ny, Mb, cxb, cyb, wsb, wsb + hot_bytes(nx, ny),
-                              (ring_int *)(lds + ring_off), ring_n, t);
+                              (ring_int *)(lds + ring_off), ring_n, chunked, t);
     if (t == 0 && status) status[b] = rc;
 #endif
     return;
@@ -721,7 +807,7 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *w, int nx, i
 #if defined(__HIP_DEVICE_COMPILE__)
   {
     const int rc = solve_wave(lw, nx, ny, lM, lcx, lcy, lds, wsb + hot_bytes(nx, ny),
-                              (ring_int *)(lds + ring_off), ring_n, t);
+                              (ring_int *)(lds + ring_off), ring_n, chunked, t);
     if (t == 0 && status) status[b] = rc;
   }
 #endif
@@ -778,15 +864,17 @@ extern "C" int ra_hungarian_f32_dev(const float *weights, int B, int N, int M, f
   const char *ring_env = getenv("RA_HUNG_RING");  // read per call: the tests force the spill path
   const int ring_cap = ring_env ? atoi(ring_env) : 8192;
   int ring_n = 0;
-  for (int r = 64; r <= ring_cap && ring_off + (size_t)r * 4 <= 150 * 1024; r *= 2) ring_n = r;
+  for (int r = 64; r <= ring_cap && ring_off + (size_t)(r + 64) * 4 <= 150 * 1024; r *= 2) ring_n = r;  // + 64: augment_wave64c's table
+  const char *bfs_env = getenv("RA_HUNG_BFS");  // 0: one pop at a time (tests run both forms)
+  const int chunked = (bfs_env ? atoi(bfs_env) : 1) && ring_n >= 64;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra::hung::hungarian_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(ra::hung::hungarian_kernel, dim3(B), dim3(64), ring_off + (size_t)ring_n * 4,
+  hipLaunchKernelGGL(ra::hung::hungarian_kernel, dim3(B), dim3(64), ring_off + (size_t)(ring_n + 64) * 4,
                      ra::as_stream(stream), weights, N, M, matching, cover_x, cover_y, status_dev,
-                     reinterpret_cast<char *>(ws), per, use_lds, ring_n, (int)ring_off);
+                     reinterpret_cast<char *>(ws), per, use_lds, ring_n, (int)ring_off, chunked);
   return ra::launch_status("ra_hungarian_f32_dev");
 }

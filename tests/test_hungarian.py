@@ -133,12 +133,15 @@ def test_device_equals_host(cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('ring', ['0', '64'])
-def test_device_queue_ring_spill(cuda, monkeypatch, ring):
+@pytest.mark.parametrize('ring,bfs', [('0', '1'), ('64', '1'), ('64', '0'), ('8192', '0')])
+def test_device_queue_ring_spill(cuda, monkeypatch, ring, bfs):
   """The BFS queue's LDS ring is only a cache of the global queue: with no ring, and with one so
-  small that the live window overruns it mid-search, the device result is still the host's."""
+  small that the live window overruns it mid-search, the device result is still the host's — for
+  the chunk-parallel search (bfs = 1: a round that would overrun the ring restarts one pop at a time)
+  and for the one-pop-at-a-time search (bfs = 0)."""
   import torch
   monkeypatch.setenv('RA_HUNG_RING', ring)
+  monkeypatch.setenv('RA_HUNG_BFS', bfs)
   rng = np.random.RandomState(21)
   iou = rng.rand(8, 21, 21).astype(np.float32)
   iou[:, :, 13:] = 0  # f_segm_match's shape: dead ground-truth columns all at the eps fill
