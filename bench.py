@@ -93,18 +93,18 @@ def seed_weights(model, seed):
   model['ctrl_mlp_b_0'].copy_(b)
 
 
-def pmc_traffic(images, size, name='r02_pmc_encoder_traffic.json'):
+def pmc_traffic(images, size, name='r03_pmc_encoder_traffic.json'):
   """HBM bytes per launch group measured with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE
-  passes over `bench.py --pmc-group REPS [--pmc-which attn]`, summarised by tools/pmc_traffic.py)."""
-  path = os.path.join(ROOT, 'profiles', name)
-  if not os.path.exists(path) and name.startswith('r02_pmc_encoder'):
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_encoder_traffic.json')
-  if not os.path.exists(path):
-    return None
-  rec = json.load(open(path))
-  if rec.get('images') != images or rec.get('size') != size:
-    return None
-  return rec['hbm_bytes_per_launch_group']
+  passes over `bench.py --pmc-group REPS [--pmc-which attn]`, summarised by tools/pmc_traffic.py);
+  the newest committed round's file that matches this shape."""
+  for rnd in ('r03', 'r02', 'r01'):
+    path = os.path.join(ROOT, 'profiles', rnd + name[3:])
+    if not os.path.exists(path):
+      continue
+    rec = json.load(open(path))
+    if rec.get('images') == images and rec.get('size') == size:
+      return rec['hbm_bytes_per_launch_group']
+  return None
 
 
 def _cgroup_cpus():
@@ -334,10 +334,10 @@ def main():
                        'eagerly and exit (run under rocprofv3 --pmc; see tools/pmc_traffic.py)')
   ap.add_argument('--pmc-which', default='enc', choices=['enc', 'attn', 'tail'],
                   help='which launch group --pmc-group repeats: the encoder, extract+paste, or the whole tail')
-  ap.add_argument('--attn-b32', action='store_true', help='also time extract+paste at B=32 (roofline_attn.at_B32)')
   ap.add_argument('--fuse-patchnet', action='store_true',
                   help='tuning aid: the patch net through the phase kernel K4 (RA_PNET_MODE=1: one launch)')
   ap.add_argument('--no-cache-first', action='store_true', help='tuning aid: recompute the whole first layer per timestep')
+  ap.add_argument('--no-prefill-ride', action='store_true', help='tuning aid: the per-forward y_out prefill as its own launch instead of riding on the first controller-CNN launch')
   ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
                   help='cfg2 (default) = the headline workload; cfg3 / cfg5 = the KITTI two-stage and Cityscapes '
                        'configurations of BASELINE.json as their own JSON lines')
@@ -372,6 +372,7 @@ def main():
   eng.pair_wino = not args.no_pair_wino
   eng.fuse_patchnet = args.fuse_patchnet
   eng.cache_first = not args.no_cache_first
+  eng.prefill_ride = not args.no_prefill_ride
   g = torch.Generator().manual_seed(1234 + rank)
   x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float32).cuda()
   if args.host_input:
@@ -483,11 +484,13 @@ def main():
       torch.cuda.synchronize()
       return 1e3 * e0.elapsed_time(e1) / (reps * inner)
 
+    rides = (not eng.box) and (not d['disable_overwrite']) and eng._prefill_rides(sb)
+
     def enc_step(step, tt_=1):  # tt_ = 1: the steady-state (cached) form; 0: the first timestep, which fills the cache
-      first = step[1]
+      first = step[1]           # ... and carries the once-per-forward prefill of y_out as a rider (ra_engine._launch_pack)
       src = sb['img'] if first == 0 else sb['ccnn'][first - 1]
       eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], tt_, 'ctrl_cnn', plane=sb.get('canvas'),
-                   cache=sb.get('l0cache'))
+                   cache=sb.get('l0cache'), fill=sb['y_out'] if (tt_ == 0 and first == 0 and rides) else None)
 
     tot_f, per_f = encoder_flops_per_image(d)
     layers = []
@@ -544,76 +547,48 @@ def main():
       ops.paste_direct(bb['y_out_patch'][0][:n], 0, bb['attn'][0][:n], -5.0, d['disable_overwrite'],
                        bb['y_out'].data_ptr(), T * S * S, S, S, canvas=bb['canvas'][:n], flags=pflags)
 
-    def prefill(bb=sb):  # once per forward: y_out = sigmoid(beta) everywhere, canvas = 0
-      ops.fill(bb['canvas'], 0.0)
-      ops.fill(bb['y_out'], 1.0 / (1.0 + np.exp(5.0)))
+    def prefill(bb=sb, ride=rides):  # once per forward: y_out = sigmoid(beta) everywhere, unless that rides on the first
+      if not ride:                   # controller-CNN launch (then it is inside roofline.first_layer_cache); the canvas is
+        ops.fill(bb['y_out'], 1.0 / (1.0 + np.exp(5.0)))  # zeroed by the input-packing launch
 
     attn_us = graph_time_us(attn_group)
-    # the window-only paste relies on a once-per-forward prefill of y_out [B,T,H,W] and canvas:
-    # its 1/T share belongs to every timestep's attention-resample time
-    fill_us = graph_time_us(prefill, reps=10, inner=2) if prefilled else 0.0
+    # the window-only paste relies on once-per-forward fills: their 1/T share belongs to every timestep's
+    # attention-resample time
+    fill_us = graph_time_us(prefill, reps=10, inner=2) if (prefilled and not rides) else 0.0
     group_us = attn_us + fill_us / T
     attn_bytes = float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs
-    attn_traffic = pmc_traffic(Bs, S, 'r02_pmc_attn_traffic.json')
+    attn_traffic = pmc_traffic(Bs, S, 'r03_pmc_attn_traffic.json')
     out['roofline_attn'] = {
-        'kernel': 'ra::attnd::extract_direct_kernel + paste_direct_kernel (+ 1/T of the per-forward '
-                  'prefill) — attention resample, one sub-batch of %d images' % Bs, 'bound': 'hbm',
+        'kernel': 'ra::attnd::extract_rows_kernel + paste_win_kernel (+ 1/T of the per-forward fills) — attention '
+                  'resample, one sub-batch of %d images' % Bs, 'bound': 'hbm',
         'achieved': attn_bytes / (group_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
         'frac': attn_bytes / (group_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': attn_traffic,
+        'achieved_traffic': None if attn_traffic is None else attn_traffic / (group_us * 1e-6) / 1e9,
         'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': group_us,
-        'extract_paste_us': attn_us, 'prefill_us_per_forward': fill_us,
+        'extract_paste_us': attn_us, 'fills_us_per_forward': fill_us,
+        'y_out_prefill': ('rides on the first timestep\'s first controller-CNN launch (MFMA-bound, HBM idle): its cost is '
+                          'inside roofline.first_layer_cache.us_per_forward') if rides else 'its own launch, inside fills_us_per_forward',
+        'launch_floor_us': graph_time_us(lambda: ops.fill(sb['attn'][0][:1, :4], 0.0)),
         'note': 'achieved = ALGORITHMIC bytes (SURVEY 8d: read the attention input once, write y_out, '
-                'read+write the canvas = H*W*(C0+3)*4 B per image-timestep) / time.  The kernels are '
-                'window-only: `traffic` (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_attn_traffic.json) '
-                'is what they really move; each is bounded by a dependent-load latency chain, not by bytes'}
-    # the product's operating point: the decode pipeline keeps `depth` batches in flight, so `depth`
-    # of these launch groups (one per slot, each on its slot's buffers and stream) share the chip
-    if pipe.depth > 1 and pipe.slots:
-      graphs, inner, reps = [], 16, 10
-      for e_k, st_k in pipe.slots:
-        sbk = e_k.subs[0]
-        torch.cuda.synchronize()
-        with torch.cuda.stream(st_k):
-          attn_group(sbk)
-          st_k.synchronize()
-          gk = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(gk, stream=st_k):
-            for _ in range(inner):
-              attn_group(sbk)
-        graphs.append(gk)
-
-      def replay_all():
-        for gk, (_, st_k) in zip(graphs, pipe.slots):
-          with torch.cuda.stream(st_k):
-            gk.replay()
-      replay_all()
-      torch.cuda.synchronize()
-      t1 = time.perf_counter()
-      for _ in range(reps):
-        replay_all()
-      torch.cuda.synchronize()
-      us_all = 1e6 * (time.perf_counter() - t1) / (reps * inner)  # `depth` groups complete per us_all
-      us_all += fill_us / T  # each slot's prefill share, charged as if it did not overlap at all
-      out['roofline_attn']['in_flight'] = {
-          'groups': pipe.depth, 'us_per_%d_groups' % pipe.depth: us_all,
-          'achieved': pipe.depth * attn_bytes / (us_all * 1e-6) / 1e9,
-          'frac': pipe.depth * attn_bytes / (us_all * 1e-6) / 1e9 / PEAK_HBM_GBS,
-          'note': 'the same launch group issued from every pipeline slot at once (wall time of %d graph replays '
-                  'per slot, %d groups per graph)' % (reps, inner)}
-      del graphs
-    if args.attn_b32:  # the same group at a large batch, where latency amortises
-      import full_model as fm2
-      m32 = fm2.get_model(opt, is_training=False)
-      seed_weights(m32, 99)
-      m32.engine.forward(torch.rand((32, S, S, 3), generator=g, dtype=torch.float32).cuda())
-      s32 = m32.engine.subs[0]
-      us32 = graph_time_us(lambda: attn_group(s32, 32))
-      f32us = graph_time_us(lambda: prefill(s32), reps=5, inner=1) if prefilled else 0.0
-      by32 = float(S * S * (d['acnn_channels'][0] + 3) * 4) * 32
-      out['roofline_attn']['at_B32'] = {'avg_us_per_launch_group': us32 + f32us / T, 'extract_paste_us': us32,
-                                        'achieved': by32 / ((us32 + f32us / T) * 1e-6) / 1e9,
-                                        'frac': by32 / ((us32 + f32us / T) * 1e-6) / 1e9 / PEAK_HBM_GBS}
-      del m32, s32
+                'read+write the canvas = H*W*(C0+3)*4 B per image-timestep) / time of the two dependent launches.  The '
+                'kernels are window-only: `traffic` (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_attn_traffic.json) is '
+                'what they really move and achieved_traffic = traffic / time.  launch_floor_us = one dependent launch of a '
+                '4-float fill in the same graph: two of them are the part of the group no kernel design can remove'}
+    # the same group at a large batch, where the fixed latencies amortise
+    import full_model as fm2
+    m32 = fm2.get_model(opt, is_training=False)
+    seed_weights(m32, 99)
+    m32.engine.forward(torch.rand((32, S, S, 3), generator=g, dtype=torch.float32).cuda())
+    s32 = m32.engine.subs[0]
+    r32 = m32.engine._prefill_rides(s32)
+    us32 = graph_time_us(lambda: attn_group(s32, 32))
+    f32us = graph_time_us(lambda: prefill(s32, r32), reps=5, inner=1) if (prefilled and not r32) else 0.0
+    by32 = float(S * S * (d['acnn_channels'][0] + 3) * 4) * 32
+    out['roofline_attn']['at_B32'] = {'avg_us_per_launch_group': us32 + f32us / T, 'extract_paste_us': us32,
+                                      'achieved': by32 / ((us32 + f32us / T) * 1e-6) / 1e9,
+                                      'frac': by32 / ((us32 + f32us / T) * 1e-6) / 1e9 / PEAK_HBM_GBS}
+    del m32, s32
+    torch.cuda.empty_cache()
     # the whole post-encoder tail of one timestep exactly as the forward issues it
     tail_us = graph_time_us(lambda: eng._launch_tail(sb, 1, False, sb['ccnn'][-1]))
     out['tail_us'] = tail_us

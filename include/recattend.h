@@ -163,6 +163,16 @@ int ra_conv_pair_fill_cache_f32(const float *src, const float *plane, int plane_
                                 int reluA, const float *wpB, const float *scaleB,
                                 const float *shiftB, int CoutB, int reluB, float *cache, float *y,
                                 void *stream);
+/* The same launch with a constant fill riding on it: fill_dst[0 .. fill_floats) = fill_value, written a few
+ * stores per thread and tile by the workgroups of this (MFMA-bound) kernel while HBM is otherwise idle.  The
+ * decode loop's once-per-forward prefill of y_out (sigmoid(beta) outside every attention window,
+ * full_model.py:813-818) travels this way instead of as a 28 us launch of its own.  fill_dst 16-byte
+ * aligned, fill_floats % 4 == 0, < 2 GiB; fill_dst == NULL: no fill. */
+int ra_conv_pair_fill_cache_rider_f32(const float *src, const float *plane, int plane_chan, int B, int H, int W,
+                                      const float *wpA, const float *scaleA, const float *shiftA, int reluA,
+                                      const float *wpB, const float *scaleB, const float *shiftB, int CoutB,
+                                      int reluB, float *cache, float *y, float *fill_dst, size_t fill_floats,
+                                      float fill_value, void *stream);
 int ra_conv_pair_cached_f32(const float *cache, const float *plane, int plane_chan, int B, int H,
                             int W, const float *wpA, const float *scaleA, const float *shiftA,
                             int reluA, const float *wpB, const float *scaleB, const float *shiftB,
@@ -333,6 +343,10 @@ int ra_dense_f32(const float *x0, int K0, const float *x1, int K1, const float *
  * (full_model.py:239,640-661; the canvas lives as channel D of the packed image). */
 int ra_pack_input_f32(const float *x, int D, const float *d_in, int Dd, const float *y_in, int Dy,
                       int B, int H, int W, int Cp, float *packed, void *stream);
+/* ... and, in the same pass, zeroes the decode loop's separate canvas plane [B,H,W] (canvas_plane may be
+ * NULL): one launch less per forward. */
+int ra_pack_input_plane_f32(const float *x, int D, const float *d_in, int Dd, const float *y_in, int Dy,
+                            int B, int H, int W, int Cp, float *packed, float *canvas_plane, void *stream);
 /* canvas channel update used by box_model (box_model.py:500-504):
  * canvas = max(canvas, ysel - ysel*noise). ysel,noise [B,H,W]. */
 int ra_canvas_max_f32(float *img, int Ci, int canvas_chan, const float *ysel, const float *noise,

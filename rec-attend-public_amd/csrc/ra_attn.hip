@@ -359,9 +359,10 @@ __global__ __launch_bounds__(256) void extract_dense_kernel(const float *x, cons
 
 // ---- elementwise helpers --------------------------------------------------------------------------
 __global__ void pack_input_kernel(const float *x, int D, const float *d_in, int Dd, const float *y_in,
-                                  int Dy, size_t npix, int Cp, float *packed) {
+                                  int Dy, size_t npix, int Cp, float *packed, float *plane) {
   for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix;
        p += (size_t)gridDim.x * blockDim.x) {
+    if (plane) plane[p] = 0.0f;  // the canvas plane of the decode loop starts at zero too (full_model.py:239)
     float *o = packed + p * Cp;
     int c = 0;
     for (int k = 0; k < D; ++k) o[c++] = x[p * D + k];
@@ -507,12 +508,18 @@ extern "C" int ra_extract_patch_dense_f32(const float *x, const float *f_y, cons
 
 extern "C" int ra_pack_input_f32(const float *x, int D, const float *d_in, int Dd, const float *y_in,
                                  int Dy, int B, int H, int W, int Cp, float *packed, void *stream) {
+  return ra_pack_input_plane_f32(x, D, d_in, Dd, y_in, Dy, B, H, W, Cp, packed, nullptr, stream);
+}
+
+extern "C" int ra_pack_input_plane_f32(const float *x, int D, const float *d_in, int Dd, const float *y_in,
+                                       int Dy, int B, int H, int W, int Cp, float *packed, float *canvas_plane,
+                                       void *stream) {
   if (!x || !packed || B <= 0 || H <= 0 || W <= 0 || D <= 0 || (Dd > 0 && !d_in) || (Dy > 0 && !y_in))
     return fail(RA_E_INVALID, "ra_pack_input_f32: bad argument");
   if (Cp % 4 || D + 1 + Dd + Dy > Cp) return fail(RA_E_SHAPE, "ra_pack_input_f32: Cp %d", Cp);
   const size_t npix = (size_t)B * H * W;
   hipLaunchKernelGGL(attn::pack_input_kernel, dim3(attn::grid_for(npix, 256)), dim3(256), 0,
-                     as_stream(stream), x, D, d_in, Dd, y_in, Dy, npix, Cp, packed);
+                     as_stream(stream), x, D, d_in, Dd, y_in, Dy, npix, Cp, packed, canvas_plane);
   return launch_status("ra_pack_input_f32");
 }
 

@@ -15,6 +15,7 @@ namespace ra {
 namespace cpair {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
 
 struct PArgs {
   const float *src;
@@ -29,6 +30,12 @@ struct PArgs {
   int cache_rows, cache_gx, bytes_c;
   int bytes_y;  // conv_pair8: size of y for its buffer descriptor (< 2 GiB whenever the input is)
   int xcd_map;  // conv_pair8: 1 = each XCD (workgroup id mod 8) walks its own contiguous eighth of the tiles
+  // conv_pair8, un-cached form only: a constant fill of another buffer rides on the launch (the decode loop's
+  // once-per-forward prefill of y_out, 134 MB at cfg2: this kernel is MFMA-bound and leaves HBM idle, so the
+  // stores, a few per thread and tile, cost nothing on the timeline — as a launch of its own they cost 28 us)
+  float *rider_dst;
+  int rider_quads;  // float4 groups to write (rider_dst 16-byte aligned, < 2 GiB)
+  float rider_val;
 };
 
 template <int CINA, int CMID, int NCB, int GX, int GYB>
@@ -726,6 +733,16 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
   for (int e = tid; e < (IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
     reinterpret_cast<f32x4 *>(lds)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
+  // the rider: this workgroup's share of the constant fill, dealt over its tiles
+  const bool rider = !CACHED && a.rider_dst != nullptr;
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rider ? a.rider_dst : a.y, 0,
+                                                                       rider ? a.rider_quads * 16 : 0, 0x00020000);
+  const int r_chunk = rider ? (a.rider_quads + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  int r_idx = (int)blockIdx.x * r_chunk + tid;
+  const int r_end = ((int)blockIdx.x + 1) * r_chunk < a.rider_quads ? ((int)blockIdx.x + 1) * r_chunk : a.rider_quads;
+  const int my_tiles = t_end > t_first ? (t_end - t_first + nwx - 1) / nwx : 1;
+  const int r_per_tile = (r_chunk + 256 * my_tiles - 1) / (256 * my_tiles);
+  const u32x4r r_bits = __builtin_bit_cast(u32x4r, f32x4{a.rider_val, a.rider_val, a.rider_val, a.rider_val});
   for (; tile < t_end; tile += nwx, cur = nxt) {
     const int b = cur.b, ty0 = cur.ty * G::TH, tx0 = cur.tx * G::TW;
 
@@ -760,6 +777,11 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
     __syncthreads();
     nxt = advance(cur);
     if (tile + nwx < t_end) fetch(nxt);  // the next tile's loads fly while this one is computed
+    if constexpr (!CACHED) {
+      if (rider)
+        for (int u = 0; u < r_per_tile; ++u, r_idx += 256)
+          __builtin_amdgcn_raw_buffer_store_b128(r_bits, rr, r_idx < r_end ? r_idx * 16 : 0x7fffffff, 0, 0);
+    }
 
     // ---------------- phase A: layer A on the 18 x 36 region -> tmid ----------------
     {
@@ -894,6 +916,10 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), ry, (int)off, 0, 0);
       }
     }
+  }
+  if constexpr (!CACHED) {
+    if (rider)  // what rounding left of this workgroup's share (and all of it for a workgroup without tiles)
+      for (; r_idx < r_end; r_idx += 256) __builtin_amdgcn_raw_buffer_store_b128(r_bits, rr, r_idx * 16, 0, 0);
   }
 }
 
@@ -1092,7 +1118,7 @@ extern "C" int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws
   if (!ra_conv_pair_supported(Cin, CoutA, CoutB))
     return fail(RA_E_SHAPE, "ra_conv_pair_f32: Cin=%d CoutA=%d CoutB=%d", Cin, CoutA, CoutB);
   if (poolB != 1 && poolB != 2) return fail(RA_E_SHAPE, "ra_conv_pair_f32: pool %d", poolB);
-  cpair::PArgs a;
+  cpair::PArgs a{};
   a.src = src;
   a.y = y;
   a.wpA = wpA;
@@ -1171,11 +1197,22 @@ extern "C" int ra_conv_pair_fill_cache_f32(const float *src, const float *plane,
                                            const float *wpA, const float *scaleA, const float *shiftA, int reluA,
                                            const float *wpB, const float *scaleB, const float *shiftB, int CoutB,
                                            int reluB, float *cache, float *y, void *stream) {
+  return ra_conv_pair_fill_cache_rider_f32(src, plane, plane_chan, B, H, W, wpA, scaleA, shiftA, reluA, wpB, scaleB, shiftB,
+                                           CoutB, reluB, cache, y, nullptr, 0, 0.0f, stream);
+}
+
+extern "C" int ra_conv_pair_fill_cache_rider_f32(const float *src, const float *plane, int plane_chan, int B, int H, int W,
+                                                 const float *wpA, const float *scaleA, const float *shiftA, int reluA,
+                                                 const float *wpB, const float *scaleB, const float *shiftB, int CoutB,
+                                                 int reluB, float *cache, float *y, float *fill_dst, size_t fill_floats,
+                                                 float fill_value, void *stream) {
   if (!src || !plane || !cache || !wpA || !scaleA || !shiftA || !wpB || !scaleB || !shiftB || !y || B <= 0)
     return fail(RA_E_INVALID, "ra_conv_pair_fill_cache_f32: bad argument");
+  if (fill_dst && ((reinterpret_cast<uintptr_t>(fill_dst) & 15) || (fill_floats & 3) || fill_floats * 4 >= (1ull << 31)))
+    return fail(RA_E_SHAPE, "ra_conv_pair_fill_cache_rider_f32: the fill must be 16-byte aligned, a multiple of 4 floats, < 2 GiB");
   if (!ra_conv_first_cache_supported(4, 8, CoutB, 2, H, W) || plane_chan < 0 || plane_chan > 3)
     return fail(RA_E_SHAPE, "ra_conv_pair_fill_cache_f32: unsupported shape");
-  cpair::PArgs a;
+  cpair::PArgs a{};
   a.src = src;
   a.y = y;
   a.wpA = wpA;
@@ -1207,6 +1244,9 @@ extern "C" int ra_conv_pair_fill_cache_f32(const float *src, const float *plane,
   const size_t cb = (size_t)B * a.cache_rows * a.cache_gx * 64 * sizeof(float);
   if (cb >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_pair_fill_cache_f32: cache exceeds 2 GiB");
   a.bytes_c = (int)cb;
+  a.rider_dst = fill_floats ? fill_dst : nullptr;
+  a.rider_quads = (int)(fill_floats / 4);
+  a.rider_val = fill_value;
   return cpair::launch8<4, false>(a, B, as_stream(stream));
 }
 
@@ -1218,7 +1258,7 @@ extern "C" int ra_conv_pair_cached_f32(const float *cache, const float *plane, i
     return fail(RA_E_INVALID, "ra_conv_pair_cached_f32: bad argument");
   if (!ra_conv_first_cache_supported(4, 8, CoutB, 2, H, W) || plane_chan < 0 || plane_chan > 3)
     return fail(RA_E_SHAPE, "ra_conv_pair_cached_f32: unsupported shape");
-  cpair::PArgs a;
+  cpair::PArgs a{};
   a.src = plane;  // unused by the cached form (only the canvas plane is staged)
   a.y = y;
   a.wpA = wpA;

@@ -383,7 +383,7 @@ class DecodePipeline(object):
     for k in range(self.depth):
       eng = ra_engine.DecodeEngine(proto.d, self.model, box_model=proto.box)
       for flag in ('direct_attn', 'fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score', 'fuse_patchnet',
-                   'cache_first', 'fill_cache_inline', 'nsub', 'use_graph', 'use_wino', 'wino_unfuse', 'pair_wino'):
+                   'cache_first', 'fill_cache_inline', 'nsub', 'use_graph', 'use_wino', 'wino_unfuse', 'pair_wino', 'prefill_ride'):
         setattr(eng, flag, getattr(proto, flag))
       eng.co_resident = self.co_resident
       self.slots.append((eng, streams[k % self.streams]))

@@ -58,6 +58,7 @@ class DecodeEngine(object):
     self.co_resident = 1  # engines decoding concurrently on this GPU (set by full_model.DecodePipeline)
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
+    self.prefill_ride = True  # the once-per-forward y_out prefill rides on the first controller-CNN launch
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
 
   # ------------------------------------------------------------------ weights
@@ -386,17 +387,30 @@ class DecodeEngine(object):
       self._launch_tail(b, tt, want_box, self._launch_encoder(b, tt))
 
   def _launch_encoder(self, b, tt):
+    fill = b['y_out'] if (tt == 0 and b.pop('_fill_rider', False)) else None
     return self._run_cnn(self.plan['ccnn'], self.W['ccnn'], b['img'], b['ccnn'], tt, 'ctrl_cnn',
-                         plane=b.get('canvas'), cache=b.get('l0cache'))
+                         plane=b.get('canvas'), cache=b.get('l0cache'), fill=fill)
+
+  def _prefill_rides(self, b):
+    """The y_out prefill can travel on the first timestep's cache-filling pair launch."""
+    st0 = self.plan['ccnn'][0]
+    return (self.prefill_ride and 'l0cache' in b and self.fill_cache_inline and st0[0] == 'pair' and
+            ops.fill_rider_ok(b['y_out']))
 
   def _launch_pack(self, b):
-    ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), self.d['C0p'], b['img'])
+    ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), self.d['C0p'], b['img'],
+                   canvas_plane=b.get('canvas'))  # canvas = 0 (full_model.py:239) in the same pass
     if 'canvas' in b:
-      ops.fill(b['canvas'], 0.0)  # full_model.py:239
       if not self.box and not self.d['disable_overwrite']:
         # every pixel outside an attention window is sigmoid(0 - 5) (full_model.py:813-818): fill
-        # once per forward at memset speed, the per-timestep paste then writes windows only
-        ops.fill(b['y_out'], 1.0 / (1.0 + math.exp(5.0)))
+        # once per forward, the per-timestep paste then writes windows only.  Nothing reads y_out before
+        # the first paste, so the fill (134 MB at cfg2, 28 us as a launch of its own) rides on the first
+        # timestep's first controller-CNN launch, which is MFMA-bound and leaves HBM idle (a side stream
+        # was tried: one forked node makes the captured graph 3x slower to replay, 7.6 vs 2.45 ms pipelined)
+        if self._prefill_rides(b):
+          b['_fill_rider'] = True  # _run_cnn, tt == 0: the fill travels on the first controller-CNN launch
+        else:
+          ops.fill(b['y_out'], 1.0 / (1.0 + math.exp(5.0)))
     # the image channels' share of ctrl-CNN layer 0, b['l0cache'], is written by the first timestep's
     # own launch (its canvas is all zero, so the layer's raw sums ARE that share — _run_cnn, tt == 0)
     if 'l0cache' in b and not self.fill_cache_inline:
@@ -494,7 +508,7 @@ class DecodeEngine(object):
                        b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
     self._mark('paste')
 
-  def _run_cnn(self, steps, layers, src, bufs, tt, name, plane=None, cache=None):
+  def _run_cnn(self, steps, layers, src, bufs, tt, name, plane=None, cache=None, fill=None):
     """plane: the canvas plane standing in for channel D of the FIRST layer's packed input;
     cache: the first layer's timestep-invariant image part (ops.first_cache)."""
     pc = self.d['D'] if plane is not None else -1
@@ -503,7 +517,8 @@ class DecodeEngine(object):
       if step[0] == 'pair':
         (wpa, sca, sha, ca, _), (wpb, scb, shb, cb, poolb) = layers[step[1]], layers[step[2]]
         if cache is not None and pl is not None and tt == 0 and self.fill_cache_inline:
-          ops.conv_pair_fill_cache(src, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, cache, bufs[step[2]])
+          ops.conv_pair_fill_cache(src, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, cache, bufs[step[2]],
+                                   fill=fill, fill_value=1.0 / (1.0 + math.exp(5.0)))
         elif cache is not None and pl is not None:
           ops.conv_pair_cached(cache, pl, pc, wpa, sca[tt], sha[tt], wpb, scb[tt], shb[tt], cb, bufs[step[2]])
         elif (self.use_wino and self.pair_wino and layers is self.W.get('ccnn') and pl is None and

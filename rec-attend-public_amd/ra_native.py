@@ -83,6 +83,7 @@ SIGNATURES = {
     'ra_extract_patch_dense_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_dense_f32': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _P]),
     'ra_pack_input_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_pack_input_plane_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'ra_canvas_max_f32': (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
     'ra_affine_act_f32': (_I, [_P, _P, _P, _Z, _I, _I, _P, _P]),
     'ra_max_pool_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     'ra_conv_first_cache_floats': (_Z, [_I, _I, _I]),
     'ra_conv_first_cache_f32': (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),
     'ra_conv_pair_fill_cache_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    'ra_conv_pair_fill_cache_rider_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _F, _P]),
     'ra_conv_pair_cached_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'ra_patchnet_supported': (_I, [_P, _I, _I, _I, _I]),
     'ra_patchnet_workspace_bytes': (_Z, [_P, _I, _I, _I, _I]),

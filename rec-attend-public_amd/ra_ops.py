@@ -278,14 +278,25 @@ def first_cache(img, wpA, cout_a, plane_chan, cache):
                                          rn.stream_ptr()), 'ra_conv_first_cache_f32')
 
 
-def conv_pair_fill_cache(img, plane, plane_chan, wpA, scA, shA, wpB, scB, shB, coutB, cache, out, reluA=True, reluB=True):
-  """First timestep (canvas plane all zero): the plain first pair, writing the cache on the way."""
-  _need_cuda(img, plane, wpA, scA, shA, wpB, scB, shB, cache, out)
+def fill_rider_ok(t):
+  """Can `t` be filled by the rider of conv_pair_fill_cache (contiguous, 16-byte aligned, % 4, < 2 GiB)?"""
+  return t.is_contiguous() and t.data_ptr() % 16 == 0 and t.numel() % 4 == 0 and t.numel() * 4 < (1 << 31)
+
+
+def conv_pair_fill_cache(img, plane, plane_chan, wpA, scA, shA, wpB, scB, shB, coutB, cache, out, reluA=True, reluB=True,
+                         fill=None, fill_value=0.0):
+  """First timestep (canvas plane all zero): the plain first pair, writing the cache on the way.
+  fill: a tensor set to fill_value by the same launch (the decode loop's y_out prefill)."""
+  _need_cuda(img, plane, wpA, scA, shA, wpB, scB, shB, cache, out, fill)
   B, H, W = plane.shape
-  check(rn.lib().ra_conv_pair_fill_cache_f32(ptr(img), ptr(plane), int(plane_chan), B, H, W, ptr(wpA), ptr(scA),
-                                             ptr(shA), int(reluA), ptr(wpB), ptr(scB), ptr(shB), int(coutB),
-                                             int(reluB), ptr(cache), ptr(out), rn.stream_ptr()),
-        'ra_conv_pair_fill_cache_f32')
+  if fill is not None and not fill_rider_ok(fill):
+    raise rn.RecAttendError('conv_pair_fill_cache: the rider fill needs a contiguous, 16-byte aligned tensor of 4k floats < 2 GiB')
+  check(rn.lib().ra_conv_pair_fill_cache_rider_f32(ptr(img), ptr(plane), int(plane_chan), B, H, W, ptr(wpA), ptr(scA),
+                                                   ptr(shA), int(reluA), ptr(wpB), ptr(scB), ptr(shB), int(coutB),
+                                                   int(reluB), ptr(cache), ptr(out), ptr(fill),
+                                                   0 if fill is None else fill.numel(), C.c_float(fill_value),
+                                                   rn.stream_ptr()),
+        'ra_conv_pair_fill_cache_rider_f32')
   return out
 
 
@@ -434,13 +445,14 @@ def dense(x0, W, b, act, out, out_stride_b, x1=None):
         'ra_dense_f32')
 
 
-def pack_input(x, d_in, y_in, Cp, packed):
-  _need_cuda(x, d_in, y_in, packed)
+def pack_input(x, d_in, y_in, Cp, packed, canvas_plane=None):
+  """canvas_plane: the decode loop's separate canvas [B,H,W], zeroed by the same launch."""
+  _need_cuda(x, d_in, y_in, packed, canvas_plane)
   B, H, W, D = x.shape
   Dd = 0 if d_in is None else d_in.shape[3]
   Dy = 0 if y_in is None else y_in.shape[3]
-  check(rn.lib().ra_pack_input_f32(ptr(x), D, ptr(d_in), Dd, ptr(y_in), Dy, B, H, W, Cp,
-                                   ptr(packed), rn.stream_ptr()), 'ra_pack_input_f32')
+  check(rn.lib().ra_pack_input_plane_f32(ptr(x), D, ptr(d_in), Dd, ptr(y_in), Dy, B, H, W, Cp,
+                                         ptr(packed), ptr(canvas_plane), rn.stream_ptr()), 'ra_pack_input_plane_f32')
 
 
 def canvas_max(img, canvas_chan, ysel, noise):

@@ -566,6 +566,29 @@ def test_first_layer_cache_vs_plain_pair(cuda, shape):
   out1 = torch.empty_like(plain)
   ops.conv_pair_cached(cache2, d(canvas), 3, wpA, d(scA), d(shA), wpB, d(scB), d(shB), 8, out1)
   assert np.abs(out1.cpu().numpy() - ref).max() < 1e-4   # the by-product cache serves the later timesteps
+  # the same launch with the decode loop's y_out prefill riding on it: a constant written by the conv kernel's
+  # workgroups (sizes that do not divide by the grid, guard words either side), results unchanged bit for bit
+  for nfill in (4, 1024 * 1024 + 12, 3 * 256 * 4 * 7):
+    buf = torch.full((nfill + 8,), 7.0, dtype=torch.float32, device=cuda)
+    cache3, out3 = ops.first_cache_alloc(B, H, W, cuda), torch.empty_like(plain)
+    ops.conv_pair_fill_cache(d(img), zero, 3, wpA, d(scA), d(shA), wpB, d(scB), d(shB), 8, cache3, out3,
+                             fill=buf[4:4 + nfill], fill_value=0.25)
+    got = buf.cpu().numpy()
+    assert (got[:4] == 7.0).all() and (got[4 + nfill:] == 7.0).all() and (got[4:4 + nfill] == 0.25).all()
+    assert (out3.cpu().numpy() == out0.cpu().numpy()).all() and (cache3.cpu().numpy() == cache2.cpu().numpy()).all()
+
+
+def test_pack_input_zeroes_canvas_plane(cuda):
+  """pack_input with the decode loop's separate canvas plane: packed record as before, plane = 0."""
+  rng = np.random.RandomState(5)
+  B, H, W = 2, 12, 20
+  x, d_in, y_in = rng.rand(B, H, W, 3), rng.rand(B, H, W, 8), rng.rand(B, H, W, 2)
+  packed = torch.full((B, H, W, 16), -1.0, dtype=torch.float32, device=cuda)
+  plane = torch.full((B, H, W), 3.0, dtype=torch.float32, device=cuda)
+  ops.pack_input(dev(x, cuda), dev(d_in, cuda), dev(y_in, cuda), 16, packed, canvas_plane=plane)
+  got = packed.cpu().numpy()
+  want = np.concatenate([x, np.zeros((B, H, W, 1)), d_in, y_in, np.zeros((B, H, W, 2))], axis=-1).astype(np.float32)
+  assert (got == want).all() and (plane.cpu().numpy() == 0).all()
 
 
 def test_adam_step_matches_tf_adam(cuda):
