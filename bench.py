@@ -296,7 +296,9 @@ def bench_train(args, rank, world, B, T, S):
         'config': {'workload': 'cfg4 shapes: CVPPP-arch full_model TRAINING step, %dx%d, T=%d, B=%d per GPU '
                                '(global %d), use_knob, data-parallel with one flat-bucket all-reduce' % (S, S, T, B, B * world),
                    'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                   'grad_bucket_floats': int(model.trainer.bucket.n), 'bn_moments': 'per-rank shard'},
+                   'grad_bucket_floats': int(model.trainer.bucket.n),
+                   'bn_moments': 'whole batch (sync_bn)' if model.trainer.sync_bn else 'per-rank shard',
+                   'ranks_in_communicator': ra_dist.comm_size()},
         'final_loss': float(loss)}))
   if world > 1:
     ra_dist.barrier()
@@ -449,6 +451,7 @@ def main():
                              'y_out+s_out' % (S, S, T, B),
                  'arch': 'cvppp', 'H': S, 'W': S, 'T': T, 'batch_per_gpu': B,
                  'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no collective' % world,
+                 'ranks_in_communicator': ra_dist.comm_size(),
                  'hip_graph': bool(eng.use_graph), 'batches_in_flight': pipe.depth,
                  'lone_batch_ms': lone_ms, 'lone_batch_value': B * T / (lone_ms * 1e-3), 'input': 'host (PCIe inclusive)' if args.host_input else 'resident in HBM',
                  'output': 'y_out + s_out copied to pinned host memory (PCIe inclusive)' if args.host_output else 'left in HBM'},

@@ -558,6 +558,18 @@ int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mea
                                const float *gamma, const float *beta, float eps, int relu, int pool,
                                int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
                                float *dbeta, float *du, float *acc_gamma, float *acc_beta, void *stream);
+/* The same backward in two launches groups, for data-parallel training on WHOLE-batch statistics (nnlib.py:98
+ * takes the moments over the whole batch): _reduce writes this rank's sums dbeta / dgamma (and adds them to
+ * acc_*, may be NULL); the caller all-reduces the 2C sums; _dx finishes with the summed vectors and the
+ * global pixel count n_total (mean / var are then the whole-batch moments too). */
+int ra_bn_act_pool_bwd_reduce_f32(const float *u, const float *dy, const float *mean, const float *var,
+                                  const float *gamma, const float *beta, float eps, int relu, int pool, int B, int H,
+                                  int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta,
+                                  float *acc_gamma, float *acc_beta, void *stream);
+int ra_bn_act_pool_bwd_dx_f32(const float *u, const float *dy, const float *mean, const float *var,
+                              const float *gamma, const float *beta, const float *dgamma_sum, const float *dbeta_sum,
+                              double n_total, float eps, int relu, int pool, int B, int H, int W, int C, float *du,
+                              void *stream);
 /* The pointwise half of the controller's LSTM cell (nnlib.py:641-646; the GEMM half is a library call):
  * pre [B][4*hid] = gate pre-activations in the order (i, f, o, u), c_prev [B][hid]:
  *   c = sigm(f) c_prev + sigm(i) tanh(u),  h = sigm(o) tanh(c);  act [B][4*hid] keeps the gate values.

@@ -39,6 +39,7 @@ def build_parser():
   cap.add_size_overrides(p)
   p.add_argument('--input', default=None, help='.npz with x, y_gt, s_gt (default: synthetic batches)')
   p.add_argument('--seed', type=int, default=1234)
+  p.add_argument('--sync_bn', action='store_true', help='BatchNorm batch moments over the whole data-parallel batch')
   return p
 
 
@@ -48,8 +49,9 @@ def main(argv=None):
   full = cap.make_model_opt(args, args.inp_height, args.inp_width, args.timespan)
   model_opt = {k: full[k] for k in BOX_KEYS if k in full}
   model_opt['attn_box_padding_ratio'], model_opt['weight_decay'], model_opt['use_bn'] = 0.2, 5e-5, True  # :421-423
-  if not any(a.startswith('--fixed_var') for a in (argv or [])):
-    model_opt['fixed_var'] = True  # box_model's own default (box_model.py:58-61)
+  # 'fixed_var' is args.fixed_var as the reference writes it (box_model_train.py:442; False unless the flag is given), so
+  # that the controller is pre-trained with the variance parameterisation full_model then continues with
+  model_opt['sync_bn'], model_opt['seed'] = bool(args.sync_bn), int(args.seed)
   rank, world, local_rank = ra_dist.init()
   if torch.cuda.is_available():
     torch.cuda.set_device(local_rank)
@@ -61,25 +63,14 @@ def main(argv=None):
     raise SystemExit('batch_size %d < world size %d' % (args.batch_size, world))
   data = dict(np.load(args.input)) if args.input else None
   rng = np.random.RandomState(args.seed + 7919 * rank)
-  gen = torch.Generator(device='cuda').manual_seed(args.seed + 7919 * rank)
-  t0 = time.time()
-  for step in range(args.num_steps):
+
+  def make_batch(step):
     if data is None:
-      x, y_gt, s_gt = fmt.synthetic_batch(rng, hi - lo, H, W, T)
-    else:
-      idx = (step * args.batch_size + np.arange(lo, hi)) % data['x'].shape[0]
-      x, y_gt, s_gt = data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
-    loss, _ = model.run(['loss', 'train_step'], {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'generator': gen})
-    if rank == 0 and (step % args.steps_per_log == 0 or step == args.num_steps - 1):
-      print('step %d  loss %.5f  learn_rate %.2e  %.2f s' % (step, float(loss), ra_train.learn_rate(model_opt, step),
-                                                             time.time() - t0))
-  ra_dist.barrier()
-  if rank == 0:
-    os.makedirs(folder, exist_ok=True)
-    with open(os.path.join(folder, 'model_opt.yaml'), 'w') as f:
-      yaml.safe_dump(model_opt, f)
-    np.savez(os.path.join(folder, 'weights.npz'), **model.state_dict_numpy())
-    print('trained %d steps, weights -> %s' % (args.num_steps, folder))
+      return fmt.synthetic_batch(rng, hi - lo, H, W, T)
+    idx = (step * args.batch_size + np.arange(lo, hi)) % data['x'].shape[0]
+    return data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
+
+  fmt.train_loop(args, model, model_opt, folder, rank, world, make_batch)
 
 
 if __name__ == '__main__':

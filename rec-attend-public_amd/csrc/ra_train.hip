@@ -182,14 +182,13 @@ template <int POOL>
 __global__ __launch_bounds__(256) void bn_bwd_dx_v4_kernel(const f32x4 *u, const f32x4 *dy, const float *mean,
                                                            const float *var, const float *gamma, const float *beta,
                                                            const float *dbeta, const float *dgamma, float eps, int relu,
-                                                           int B, int H, int W, int C4, int lg, f32x4 *du) {
+                                                           int B, int H, int W, int C4, int lg, f32x4 *du, float inv_n) {
   const int Ho = H / POOL, Wo = W / POOL;
   const int er = blockIdx.x * 256 + threadIdx.x;
   if (er >= Wo * C4) return;
   const int xo = er >> lg, cg = er & (C4 - 1);
   const BnConst k = bn_const(mean, var, gamma, beta, eps, 4 * cg);
   const float lo = relu ? 0.f : -__builtin_inff();
-  const float inv_n = 1.f / (float)((size_t)B * H * W);
   f32x4 db, dg;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -409,9 +408,8 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *part, in
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float *u, const float *dy, const float *mean,
                                                         const float *var, const float *gamma, const float *beta,
                                                         const float *dbeta, const float *dgamma, float eps, int relu,
-                                                        int pool, int B, int H, int W, int C, float *du) {
+                                                        int pool, int B, int H, int W, int C, float *du, float inv_n) {
   const size_t total = (size_t)B * H * W * C;
-  const float inv_n = 1.f / (float)((size_t)B * H * W);
   const float lo = relu ? 0.f : -__builtin_inff();
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int c = (int)(e % C);
@@ -544,17 +542,21 @@ extern "C" int ra_bn_act_pool_f32(const float *u, const float *mean, const float
 }
 
 namespace {
+// stages: 1 = the two reductions (dbeta, dgamma over THIS call's pixels), 2 = du from dbeta / dgamma and the count
+// they were summed over (n_total; 0 = this call's B*H*W).  Data-parallel training with whole-batch statistics
+// runs stage 1, all-reduces the 2C sums, then stage 2 with the global count (ra_train.ConvBNActPool).
 int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float *var, const float *gamma,
                 const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *ws,
                 size_t ws_floats, float *dgamma, float *dbeta, float *du, float *acc_gamma, float *acc_beta,
-                void *stream) {
-  if (!u || !dy || !ws || !dgamma || !dbeta || !du || B <= 0 || H <= 0 || W <= 0 || C <= 0)
+                void *stream, int stages = 3, double n_total = 0.0) {
+  if (!u || !dy || !dgamma || !dbeta || ((stages & 1) && !ws) || ((stages & 2) && !du) || B <= 0 || H <= 0 || W <= 0 || C <= 0)
     return fail(RA_E_INVALID, "ra_bn_act_pool_bwd_f32: bad argument");
   if (C > 256) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_f32: C %d > 256", C);
   if ((pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1))) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_f32: pool");
-  if (ws_floats < ra_bn_workspace_floats(C)) return fail(RA_E_WORKSPACE, "ra_bn_act_pool_bwd_f32: workspace too small");
+  if ((stages & 1) && ws_floats < ra_bn_workspace_floats(C)) return fail(RA_E_WORKSPACE, "ra_bn_act_pool_bwd_f32: workspace too small");
   hipStream_t st = as_stream(stream);
   const size_t npix = (size_t)B * H * W;
+  const float inv_n = (float)(1.0 / (n_total > 0.0 ? n_total : (double)npix));
   if (const int lg = train::v4_log2(C, npix * C); lg >= 0 && ceil_div((W / pool) * (C / 4), 256) <= train::kRedBlocks) {
     const int C4 = C / 4, rows = B * (H / pool), gx = ceil_div((W / pool) * C4, 256);
     int gy = train::kRedBlocks / gx;
@@ -562,31 +564,39 @@ int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float 
     const train::f32x4 *u4 = reinterpret_cast<const train::f32x4 *>(u), *dy4 = reinterpret_cast<const train::f32x4 *>(dy);
     train::f32x4 *du4 = reinterpret_cast<train::f32x4 *>(du);
     const dim3 gr(gx, gy), gd(gx, rows < 16384 ? rows : 16384);
-    if (pool == 2)
-      hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<2>, gr, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, eps, relu, B, H,
-                         W, C4, lg, ws);
-    else
-      hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<1>, gr, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, eps, relu, B, H,
-                         W, C4, lg, ws);
-    hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, gx * gy, C, dbeta, dgamma, acc_beta, acc_gamma);
-    if (pool == 2)
-      hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<2>, gd, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, dbeta, dgamma, eps,
-                         relu, B, H, W, C4, lg, du4);
-    else
-      hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<1>, gd, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, dbeta, dgamma, eps,
-                         relu, B, H, W, C4, lg, du4);
+    if (stages & 1) {
+      if (pool == 2)
+        hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<2>, gr, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, eps, relu, B, H,
+                           W, C4, lg, ws);
+      else
+        hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<1>, gr, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, eps, relu, B, H,
+                           W, C4, lg, ws);
+      hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, gx * gy, C, dbeta, dgamma, acc_beta, acc_gamma);
+    }
+    if (stages & 2) {
+      if (pool == 2)
+        hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<2>, gd, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, dbeta, dgamma, eps,
+                           relu, B, H, W, C4, lg, du4, inv_n);
+      else
+        hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<1>, gd, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, dbeta, dgamma, eps,
+                           relu, B, H, W, C4, lg, du4, inv_n);
+    }
     return launch_status("ra_bn_act_pool_bwd_f32");
   }
   const int lanes = 256 / C;
   int nb = (int)((npix + lanes - 1) / lanes);
   if (nb > train::kRedBlocks) nb = train::kRedBlocks;
-  hipLaunchKernelGGL(train::bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, u, dy, mean, var, gamma, beta, eps, relu, pool,
-                     B, H, W, C, ws);
-  hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, nb, C, dbeta, dgamma, acc_beta, acc_gamma);
-  size_t grid = (npix * C + 255) / 256;
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(train::bn_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, st, u, dy, mean, var, gamma, beta, dbeta,
-                     dgamma, eps, relu, pool, B, H, W, C, du);
+  if (stages & 1) {
+    hipLaunchKernelGGL(train::bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, u, dy, mean, var, gamma, beta, eps, relu, pool,
+                       B, H, W, C, ws);
+    hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, nb, C, dbeta, dgamma, acc_beta, acc_gamma);
+  }
+  if (stages & 2) {
+    size_t grid = (npix * C + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(train::bn_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, st, u, dy, mean, var, gamma, beta, dbeta,
+                       dgamma, eps, relu, pool, B, H, W, C, du, inv_n);
+  }
   return launch_status("ra_bn_act_pool_bwd_f32");
 }
 }  // namespace
@@ -605,6 +615,22 @@ extern "C" int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const
                                           float *du, float *acc_gamma, float *acc_beta, void *stream) {
   return bn_bwd_impl(u, dy, mean, var, gamma, beta, eps, relu, pool, B, H, W, C, ws, ws_floats, dgamma, dbeta, du, acc_gamma,
                      acc_beta, stream);
+}
+
+extern "C" int ra_bn_act_pool_bwd_reduce_f32(const float *u, const float *dy, const float *mean, const float *var,
+                                             const float *gamma, const float *beta, float eps, int relu, int pool, int B,
+                                             int H, int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta,
+                                             float *acc_gamma, float *acc_beta, void *stream) {
+  return bn_bwd_impl(u, dy, mean, var, gamma, beta, eps, relu, pool, B, H, W, C, ws, ws_floats, dgamma, dbeta, nullptr,
+                     acc_gamma, acc_beta, stream, 1);
+}
+
+extern "C" int ra_bn_act_pool_bwd_dx_f32(const float *u, const float *dy, const float *mean, const float *var,
+                                         const float *gamma, const float *beta, const float *dgamma_sum,
+                                         const float *dbeta_sum, double n_total, float eps, int relu, int pool, int B, int H,
+                                         int W, int C, float *du, void *stream) {
+  return bn_bwd_impl(u, dy, mean, var, gamma, beta, eps, relu, pool, B, H, W, C, nullptr, 0, const_cast<float *>(dgamma_sum),
+                     const_cast<float *>(dbeta_sum), du, nullptr, nullptr, stream, 2, n_total);
 }
 
 extern "C" int ra_conv_pack_weights_dev(const float *w, int Cin_w, int Cout, int Cin, const int *chan_map, int flags,

@@ -150,7 +150,7 @@ class Model(dict):
     register are reported with a warning.  strict=False loads what matches and returns quietly
     (the pre-training hand-off of a sub-network, full_model.py:271-284)."""
     known = set(self.weight_keys())
-    given = set(weights.keys())
+    given = set(k for k in weights.keys() if not k.startswith('optim/'))  # optimizer state of a training checkpoint: ra_train's
     if strict:
       missing = sorted(known - given)
       if missing:
@@ -219,7 +219,8 @@ class Model(dict):
       feed = dict(feed, knobs={'noise': feed['noise']})
     if 'train_step' in names:
       extra = {k: feed[k] for k in ('d_in', 'y_in') if feed.get(k) is not None and not self.box_model}
-      out = tr.run(feed['x'], feed['y_gt'], feed['s_gt'], knobs=feed.get('knobs'), generator=feed.get('generator'), **extra)
+      out = tr.run(feed['x'], feed['y_gt'], feed['s_gt'], knobs=feed.get('knobs'), generator=feed.get('generator'),
+                   aug=feed.get('aug'), **extra)
     else:
       with torch.no_grad():
         extra = {k: feed[k] for k in ('d_in', 'y_in') if feed.get(k) is not None and not self.box_model}

@@ -13,7 +13,9 @@ its own shard of the global --batch_size), clip + Adam, BN EMA (ra_train.TrainSt
 Data: --input (an .npz with x [N,H,W,3], y_gt [N,T,H,W], s_gt [N,T]) or synthetic CVPPP-shaped
 batches (8..T-1 ellipses per image, sorted by area); the reference's HDF5 datasets,
 plots and CSV loggers are out of scope.  BatchNorm moments are taken over the
-rank's shard."""
+rank's shard, or over the whole batch with --sync_bn.  Checkpoints (weights.npz +
+optim.npz: Adam slots and global_step, utils/saver.py:24-31) are written every --steps_per_ckpt steps and
+at the end; --restore <folder> continues from one (experiment.py:26-37)."""
 import argparse
 import os
 import time
@@ -36,6 +38,8 @@ def build_parser():
                  help='write model_opt.yaml + initial weights and stop')
   p.add_argument('--input', default=None, help='.npz with x, y_gt, s_gt (default: synthetic batches)')
   p.add_argument('--seed', type=int, default=1234)
+  p.add_argument('--sync_bn', action='store_true',
+                 help='data parallel: BatchNorm batch moments over the WHOLE batch (nnlib.py:98), one small collective per BN call')
   return p
 
 
@@ -62,50 +66,100 @@ def synthetic_batch(rng, B, H, W, T):
   return x, y, s
 
 
-def main(argv=None):
+def save_checkpoint(path, model):
+  """Everything utils/saver.py:24-31 saves (tf.all_variables()): the weights with their BN EMA shadows, and — once a
+  trainer exists — the Adam slots and global_step.  One .npz; `path` without the optimizer part stays loadable by
+  Model.load_weights (the keys are prefixed)."""
+  out = dict(model.state_dict_numpy())
+  tr = getattr(model, 'trainer', None)
+  if tr is not None:
+    out.update({'optim/' + k: v for k, v in tr.state_dict().items()})
+  else:
+    out['optim/global_step'] = np.asarray(int(model.get('global_step', 0) or 0), dtype=np.int64)
+  np.savez(path, **out)
+
+
+def load_checkpoint(path, model):
+  """Restore what save_checkpoint wrote into `model` (building its trainer): weights, EMA, Adam m / v, global_step."""
+  import ra_train
+  data = dict(np.load(path))
+  optim = {k[len('optim/'):]: v for k, v in data.items() if k.startswith('optim/')}
+  model.load_weights({k: v for k, v in data.items() if not k.startswith('optim/')})
+  if getattr(model, 'trainer', None) is None:
+    model.trainer = (ra_train.BoxTrainStep if model.box_model else ra_train.TrainStep)(model)
+  else:  # the bucket owns the weights' storage: load_weights above wrote through the views
+    model.trainer._graphs = {}
+  model.trainer.load_state_dict(optim, strict=len(optim) > 1)
+  model.trainer.broadcast_state()
+  return model
+
+
+def train_loop(args, model, model_opt, folder, rank, world, make_batch):
+  """experiment.py:220-274 -> Trainer.run_step (full_model_train.py:107), shared with box_model_train.py."""
   import torch
-  args = build_parser().parse_args(argv)
-  model_opt = cap.make_model_opt(args, args.inp_height, args.inp_width, args.timespan)
-  rank, world, local_rank = ra_dist.init()
-  if torch.cuda.is_available():
-    torch.cuda.set_device(local_rank)
-  model = full_model.get_model(model_opt, is_training=True)
-  model_id = args.model_id or 'full_model'
-  folder = os.path.join(args.results, model_id)
-  if rank == 0:
+  ckpt = os.path.join(folder, 'weights.npz')
+  if getattr(args, 'restore', None):
+    src = args.restore if args.restore.endswith('.npz') else os.path.join(args.restore, 'weights.npz')
+    load_checkpoint(src, model)
+    if rank == 0:
+      print('restored %s at global_step %d' % (src, model.trainer.bucket.global_step))
+  elif rank == 0:
     os.makedirs(folder, exist_ok=True)
     with open(os.path.join(folder, 'model_opt.yaml'), 'w') as f:
       yaml.safe_dump(model_opt, f)
-    np.savez(os.path.join(folder, 'weights.npz'), **model.state_dict_numpy())
+    save_checkpoint(ckpt, model)
     print('wrote %s (model_opt.yaml, weights.npz: %d tensors)' % (folder, len(model.weight_keys())))
-  if args.init_only:
+  if getattr(args, 'init_only', False):
     return
-  H, W, T = model_opt['inp_height'], model_opt['inp_width'], model_opt['timespan']
-  lo, hi = ra_dist.shard_range(rank, world, args.batch_size)
-  if hi <= lo:
-    raise SystemExit('batch_size %d < world size %d' % (args.batch_size, world))
-  data = dict(np.load(args.input)) if args.input else None
-  rng = np.random.RandomState(args.seed + 7919 * rank)       # rank-offset streams
-  gen = torch.Generator(device='cuda').manual_seed(args.seed + 7919 * rank)
+  if args.batch_size % world:
+    raise SystemExit('batch_size %d is not a multiple of the world size %d (equal shards: the gradient is averaged '
+                     'as sum / world)' % (args.batch_size, world))
+  gen = torch.Generator(device='cuda').manual_seed(args.seed + 7919 * rank)  # knob draws: rank-offset (SURVEY.md §8e)
+  start = int(model.get('global_step', 0) or 0)
   t0 = time.time()
-  for step in range(args.num_steps):
-    if data is None:
-      x, y_gt, s_gt = synthetic_batch(rng, hi - lo, H, W, T)
-    else:
-      n = data['x'].shape[0]
-      idx = (step * args.batch_size + np.arange(lo, hi)) % n
-      x, y_gt, s_gt = data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
+  for step in range(start, args.num_steps):
+    x, y_gt, s_gt = make_batch(step)
     feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'generator': gen}
     loss, _ = model.run(['loss', 'train_step'], feed)
     if rank == 0 and (step % args.steps_per_log == 0 or step == args.num_steps - 1):
       print('step %d  loss %.5f  learn_rate %.2e  %.2f s' % (step, float(loss), ra_train.learn_rate(model_opt, step),
                                                              time.time() - t0))
     if rank == 0 and args.save_ckpt and (step + 1) % args.steps_per_ckpt == 0:
-      np.savez(os.path.join(folder, 'weights.npz'), **model.state_dict_numpy())
+      save_checkpoint(ckpt, model)
   ra_dist.barrier()
   if rank == 0:
-    np.savez(os.path.join(folder, 'weights.npz'), **model.state_dict_numpy())
-    print('trained %d steps, weights -> %s' % (args.num_steps, folder))
+    os.makedirs(folder, exist_ok=True)
+    if not os.path.exists(os.path.join(folder, 'model_opt.yaml')):
+      with open(os.path.join(folder, 'model_opt.yaml'), 'w') as f:
+        yaml.safe_dump(model_opt, f)
+    save_checkpoint(ckpt, model)
+    print('trained %d steps, weights -> %s (weights.npz: weights, EMA shadows, optimizer state)' % (args.num_steps, folder))
+
+
+def main(argv=None):
+  import torch
+  args = build_parser().parse_args(argv)
+  model_opt = cap.make_model_opt(args, args.inp_height, args.inp_width, args.timespan)
+  model_opt['sync_bn'], model_opt['seed'] = bool(args.sync_bn), int(args.seed)
+  rank, world, local_rank = ra_dist.init()
+  if torch.cuda.is_available():
+    torch.cuda.set_device(local_rank)
+  model = full_model.get_model(model_opt, is_training=True)
+  folder = os.path.join(args.results, args.model_id or 'full_model')
+  H, W, T = model_opt['inp_height'], model_opt['inp_width'], model_opt['timespan']
+  lo, hi = ra_dist.shard_range(rank, world, args.batch_size)
+  if hi <= lo:
+    raise SystemExit('batch_size %d < world size %d' % (args.batch_size, world))
+  data = dict(np.load(args.input)) if args.input else None
+  rng = np.random.RandomState(args.seed + 7919 * rank)       # rank-offset streams (SURVEY.md §8e)
+
+  def make_batch(step):
+    if data is None:
+      return synthetic_batch(rng, hi - lo, H, W, T)
+    idx = (step * args.batch_size + np.arange(lo, hi)) % data['x'].shape[0]
+    return data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
+
+  train_loop(args, model, model_opt, folder, rank, world, make_batch)
 
 
 if __name__ == '__main__':

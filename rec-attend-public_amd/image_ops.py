@@ -13,8 +13,9 @@ import ra_ops as ops
 
 
 def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=True, rnd_transpose=True,
-                          rnd_colour=False, y=None, d=None, c=None, generator=None):
-  """x [B,H,W,3], y [B,T,H,W], d [B,H,W,8], c [B,H,W,1] -> dict with the same keys (x, y, d, c)."""
+                          rnd_colour=False, y=None, d=None, c=None, generator=None, draws=None):
+  """x [B,H,W,3], y [B,T,H,W], d [B,H,W,8], c [B,H,W,1] -> dict with the same keys (x, y, d, c).
+  draws: the step's decisions given instead of drawn ({off_y, off_x, flip_v, flip_h, transpose}; tests)."""
   results = {'x': x}
   for k, v in (('y', y), ('d', d), ('c', c)):
     if v is not None:
@@ -27,14 +28,19 @@ def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=Tru
     assert not rnd_vflip, 'Orientation mode is on, no random flips'
     assert not rnd_hflip, 'Orientation mode is on, no random flips'
     assert not rnd_transpose, 'Orientation mode is on, no random transpose'
-  g = generator
-  off = torch.randint(0, max(2 * padding, 1), (2,), generator=g) if padding > 0 else torch.zeros(2, dtype=torch.long)
-  u = torch.rand(3, generator=g)
-  # tf.random_uniform([1], 1.0 - float(flag), 1.0) < 0.5: never true when the flag is off (:85-94)
-  flip_h = bool(rnd_hflip) and float(u[0]) < 0.5 and d is None
-  flip_v = bool(rnd_vflip) and float(u[1]) < 0.5 and d is None
-  do_tr = bool(rnd_transpose) and float(u[2]) < 0.5 and d is None
-  kw = dict(padding=padding, off_y=int(off[0]), off_x=int(off[1]), flip_v=flip_v, flip_h=flip_h, transpose=do_tr)
+  if draws is not None:
+    kw = dict(padding=padding, off_y=int(draws.get('off_y', padding)), off_x=int(draws.get('off_x', padding)),
+              flip_v=bool(draws.get('flip_v', False)), flip_h=bool(draws.get('flip_h', False)),
+              transpose=bool(draws.get('transpose', False)))
+  else:
+    g = generator
+    off = torch.randint(0, max(2 * padding, 1), (2,), generator=g) if padding > 0 else torch.zeros(2, dtype=torch.long)
+    u = torch.rand(3, generator=g)
+    # tf.random_uniform([1], 1.0 - float(flag), 1.0) < 0.5: never true when the flag is off (:85-94)
+    flip_h = bool(rnd_hflip) and float(u[0]) < 0.5 and d is None
+    flip_v = bool(rnd_vflip) and float(u[1]) < 0.5 and d is None
+    do_tr = bool(rnd_transpose) and float(u[2]) < 0.5 and d is None
+    kw = dict(padding=padding, off_y=int(off[0]), off_x=int(off[1]), flip_v=flip_v, flip_h=flip_h, transpose=do_tr)
   results['x'] = ops.random_transform(x, **kw)
   if y is not None:
     B, T, H, W = y.shape

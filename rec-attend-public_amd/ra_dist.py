@@ -25,6 +25,13 @@ def init(backend=None):
   return rank, world, local_rank
 
 
+def comm_size():
+  """Ranks the initialised communicator (RCCL / gloo) actually holds; 1 without one."""
+  if torch.distributed.is_available() and torch.distributed.is_initialized():
+    return int(torch.distributed.get_world_size())
+  return 1
+
+
 def shard_range(rank, world, n):
   """Images [lo, hi) of a global batch of n that `rank` decodes: contiguous, sizes differ by
   at most one, every image owned exactly once."""

@@ -107,6 +107,8 @@ SIGNATURES = {
     'ra_bn_moments_f32': (_I, [_P, _Z, _I, _P, _Z, _P, _P, _P]),
     'ra_bn_act_pool_f32': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_bn_act_pool_bwd_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
+    'ra_bn_act_pool_bwd_reduce_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P]),
+    'ra_bn_act_pool_bwd_dx_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_double, _F, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_conv_pack_weights_dev': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_conv3x3_wgrad_workspace_floats': (_Z, [_I, _I, _I, _I, _I]),
     'ra_conv3x3_wgrad_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _P, _P]),

@@ -7,10 +7,15 @@ MI355X, gloo in the CPU tests) per step, then clip + Adam in one HIP pass.
   bucket.allreduce()                    # sum over ranks (no-op for world 1)
   bucket.step()                         # g/world -> +wd*w -> clip(+-1) -> Adam(eps 1e-7), global_step += 1
 
-Sum-then-scale-then-clip reproduces the single-process update on the concatenated batch when every
-rank's loss is divided by the GLOBAL example count (num_ex_f, full_model.py:916), which is how
-TrainStep scales it.  BatchNorm batch moments (nnlib.py:98) are all-reduced separately
-(allreduce_moments) so that the normalisation equals the single-process one too.
+Sum-then-scale-then-clip reproduces the single-process update on the concatenated batch: every rank's
+loss divides by ITS OWN example count (num_ex_f, full_model.py:916 on the shard), the bucket is summed
+over the ranks and the optimizer kernel scales it by 1 / world (equal shards: batch_size % world == 0 is
+required by the trainers).  BatchNorm batch moments (nnlib.py:98) are taken over the rank's shard by
+default; with model_opt['sync_bn'] every BN call gathers the ranks' (count, mean, M2) and its backward
+all-reduces the two per-channel sums, so that normalisation and gradient equal the single-process ones
+(sync_moments below).  Initial weights, Adam moments, EMA shadows and global_step are
+broadcast from rank 0 when a trainer is built (broadcast_state), so ranks start from ONE model whatever
+their random seeds were.
 """
 import math
 import os
@@ -94,6 +99,48 @@ class GradBucket(object):
     dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
     return dist.get_world_size()
 
+  def broadcast(self, src=0):
+    """Every rank takes rank `src`'s parameters, Adam moments and global_step: get_model() draws the initial
+    weights from each process's own generator, and a data-parallel step sums gradients — of ONE model only
+    if the ranks hold the same weights.  No-op for world 1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+      return 1
+    for t in (self.param, self.m, self.v):
+      dist.broadcast(t, src=src)
+    gs = torch.tensor([float(self.global_step)], dtype=torch.float64, device=self.param.device if dist.get_backend() == 'nccl' else 'cpu')
+    dist.broadcast(gs, src=src)
+    self.global_step = int(gs.item())
+    self.model['global_step'] = float(self.global_step)
+    return dist.get_world_size()
+
+  def state_dict(self):
+    """What utils/saver.py:24-31 saves beside the weights (tf.all_variables(): the Adam slots and global_step),
+    by parameter name, as NumPy arrays."""
+    out = {'global_step': np.asarray(self.global_step, dtype=np.int64)}
+    for k in self.names:
+      o, n, shp = self.offsets[k]
+      out['adam_m/' + k] = self.m[o:o + n].view(shp).detach().cpu().numpy()
+      out['adam_v/' + k] = self.v[o:o + n].view(shp).detach().cpu().numpy()
+    return out
+
+  def load_state_dict(self, state, strict=True):
+    for k in self.names:
+      o, n, shp = self.offsets[k]
+      for slot, buf in (('adam_m/', self.m), ('adam_v/', self.v)):
+        if slot + k in state:
+          v = torch.as_tensor(np.asarray(state[slot + k], dtype=np.float32))
+          if tuple(v.shape) != tuple(shp):
+            raise rn.RecAttendError('optimizer state %s%s: shape %r != %r' % (slot, k, tuple(v.shape), tuple(shp)))
+          buf[o:o + n].copy_(v.reshape(-1))
+        elif strict:
+          raise rn.RecAttendError('optimizer state lacks %s%s' % (slot, k))
+    if 'global_step' in state:
+      self.global_step = int(np.asarray(state['global_step']))
+      self.model['global_step'] = float(self.global_step)
+    elif strict:
+      raise rn.RecAttendError('optimizer state lacks global_step')
+
   def step(self, world=1, lr=None):
     """clip(grad / world + wd * w, +-1) -> Adam; increments global_step (full_model.py:1048-1056)."""
     t = self.global_step + 1
@@ -114,13 +161,42 @@ class GradBucket(object):
     return lr
 
 
-def allreduce_moments(sums):
-  """BatchNorm batch moments over the GLOBAL batch (nnlib.py:98 normalises over the whole batch):
-  `sums` [.., 2C+1] = per-channel (sum x, sum x^2) and the element count, summed over the ranks."""
+def combine_moments(count, mean, var):
+  """Whole-batch moments from per-shard ones: count [R], mean / var [R,C] (biased variance, as tf.nn.moments) ->
+  (total count, mean [C], var [C]) by Chan's pairwise update (no E[x^2] - E[x]^2 cancellation)."""
+  count = count.to(mean.dtype)
+  n = count.sum()
+  w = (count / n)[:, None]
+  m = (w * mean).sum(dim=0)
+  v = (w * (var + (mean - m[None, :]) ** 2)).sum(dim=0)
+  return n, m, v
+
+
+def sync_moments(mean, var, n_local):
+  """BatchNorm batch moments over the GLOBAL batch (nnlib.py:98 normalises over the whole batch): every rank
+  contributes (count, mean, var) of its shard in ONE all_gather of 2C+1 floats; mean / var are overwritten with
+  the whole-batch moments.  Returns the global element count (n_local for world 1)."""
+  import torch.distributed as dist
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    return float(n_local)
+  C = mean.numel()
+  mine = torch.empty(2 * C + 1, dtype=torch.float32, device=mean.device)
+  mine[:C], mine[C:2 * C], mine[2 * C] = mean, var, float(n_local)
+  parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+  dist.all_gather(parts, mine)
+  allp = torch.stack(parts)
+  n, m, v = combine_moments(allp[:, 2 * C], allp[:, :C], allp[:, C:2 * C])
+  mean.copy_(m)
+  var.copy_(v)
+  return float(n_local) * dist.get_world_size()  # equal shards (the trainers require batch_size % world == 0): no host sync
+
+
+def allreduce_sums(t):
+  """Sum of a small tensor over the ranks (the 2C per-channel sums of a synchronised BatchNorm backward)."""
   import torch.distributed as dist
   if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-  return sums
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  return t
 
 
 # =====================================================================================================
@@ -184,19 +260,21 @@ def wgrad_join():
   _wgrad_join(torch.device('cuda', torch.cuda.current_device()))
 
 
-_PACK = {}  # per step: (weight storage, geometry) -> packed filter; the filters are shared by the T timesteps.
-# forward_loss() clears it (the optimizer writes the weights through raw pointers); an entry keeps its source tensor
-# alive and carries the tensor's version, so a caller outside forward_loss cannot be handed the pack of a freed
-# tensor whose address was reused, nor one that predates an in-place update.
+_PACK = {}  # the pack cache of callers outside a TrainStep (tests, one-off layer calls); a TrainStep owns its own
+# (TrainStep._pack, handed to the layer functions through meta['cache']): per step, (weight storage, geometry) -> packed
+# filter — the filters are shared by the T timesteps.  forward_loss() clears the trainer's dict (the optimizer writes the
+# weights through raw pointers); an entry keeps its source tensor alive and carries the tensor's version, so a caller
+# cannot be handed the pack of a freed tensor whose address was reused, nor one that predates an in-place update.
 
 
-def _pack_dev(w, cin_w, cout, cin, cmap_t, transposed):
+def _pack_dev(w, cin_w, cout, cin, cmap_t, transposed, cache=None):
+  cache = _PACK if cache is None else cache
   key = (w.data_ptr(), w._version, int(cin_w), int(cout), int(cin), 0 if cmap_t is None else cmap_t.data_ptr(), bool(transposed))
-  hit = _PACK.get(key)
+  hit = cache.get(key)
   if hit is not None:
     return hit[1]
   out = _pack_dev_now(w, cin_w, cout, cin, cmap_t, transposed)
-  _PACK[key] = (w, out)
+  cache[key] = (w, out)
   return out
 
 
@@ -260,14 +338,16 @@ class ConvBNActPool(torch.autograd.Function):
     cmap_t = _const('cmap', tuple(cmap), dev, lambda: torch.tensor(cmap, dtype=torch.int32, device=dev)) \
         if cmap is not None else _pad_map(cin_w, Cx, dev)
     cp = ops.cout_padded(cout)
-    wp = _pack_dev(w.contiguous(), cin_w, cout, Cx, cmap_t, tr)
+    cache = meta.get('cache')
+    cache = _PACK if cache is None else cache
+    wp = _pack_dev(w.contiguous(), cin_w, cout, Cx, cmap_t, tr, cache)
     scale = _const('ones', cp, dev, lambda: torch.ones(cp, dtype=torch.float32, device=dev))
     shift = b.detach()
     if cp != cout:  # padded once per step (the layer's bias is shared by all timesteps), not once per use
       key = ('shift', b.data_ptr(), b._version, cp)
-      hit = _PACK.get(key)
+      hit = cache.get(key)
       if hit is None:
-        hit = _PACK[key] = (b, torch.nn.functional.pad(b.detach(), (0, cp - cout)))
+        hit = cache[key] = (b, torch.nn.functional.pad(b.detach(), (0, cp - cout)))
       shift = hit[1]
     u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2))
     H, W = u.shape[1], u.shape[2]
@@ -278,10 +358,14 @@ class ConvBNActPool(torch.autograd.Function):
       ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
       check(rn.lib().ra_bn_moments_f32(ptr(u), B * H * W, cout, ptr(ws), ws.numel(), ptr(mean), ptr(var),
                                        rn.stream_ptr()), 'ra_bn_moments_f32')
+      # whole-batch statistics under data parallelism (nnlib.py:98): one all_gather of (count, mean, var)
+      ctx.n_total = sync_moments(mean, var, B * H * W) if meta.get('sync_bn') else 0.0
     y = _f(B, H // pool, W // pool, cout, device=dev)
     check(rn.lib().ra_bn_act_pool_f32(ptr(u), ptr(mean), ptr(var), ptr(gamma), ptr(beta), _C.c_float(BN_EPS), int(relu),
                                       int(pool), B, H, W, cout, ptr(y), rn.stream_ptr()), 'ra_bn_act_pool_f32')
-    ctx.meta, ctx.cmap = meta, cmap
+    ctx.meta, ctx.cmap, ctx.cache = meta, cmap, cache
+    if not use_bn:
+      ctx.n_total = 0.0
     ctx.save_for_backward(x, w, u, mean, var, gamma, beta)
     if use_bn:
       ctx.mark_non_differentiable(mean, var)
@@ -307,12 +391,38 @@ class ConvBNActPool(torch.autograd.Function):
     grads = meta.get('grads')  # (gw, gb, ggamma, gbeta): views of the flat gradient bucket -> accumulate in-kernel
     nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, B, H, W)
     wws = _f(nws, device=dev)
+    synced = ctx.n_total > 0.0 and ctx.n_total != float(B * H * W)
+
+    def bn_backward(acc_g, acc_b):
+      """dgamma / dbeta / du; with whole-batch statistics the two per-channel sums are all-reduced between the
+      reduction and the du pass (the bucket still receives this rank's own sums: it is summed over the ranks later)."""
+      if not synced:
+        if acc_g is not None:
+          check(rn.lib().ra_bn_act_pool_bwd_acc_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                                    _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
+                                                    ptr(dgamma), ptr(dbeta), ptr(du), ptr(acc_g), ptr(acc_b), rn.stream_ptr()),
+                'ra_bn_act_pool_bwd_acc_f32')
+        else:
+          check(rn.lib().ra_bn_act_pool_bwd_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                                _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
+                                                ptr(dgamma), ptr(dbeta), ptr(du), rn.stream_ptr()), 'ra_bn_act_pool_bwd_f32')
+        return dgamma, dbeta
+      both = _f(2 * cout, device=dev)
+      dgl, dbl = both[:cout], both[cout:]
+      check(rn.lib().ra_bn_act_pool_bwd_reduce_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                                   _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
+                                                   ptr(dgl), ptr(dbl), ptr(acc_g), ptr(acc_b), rn.stream_ptr()),
+            'ra_bn_act_pool_bwd_reduce_f32')
+      mine = both.clone()
+      allreduce_sums(both)
+      check(rn.lib().ra_bn_act_pool_bwd_dx_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgl), ptr(dbl),
+                                               _C.c_double(ctx.n_total), _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout,
+                                               ptr(du), rn.stream_ptr()), 'ra_bn_act_pool_bwd_dx_f32')
+      return mine[:cout], mine[cout:]  # the parameter gradients of THIS rank's shard (the bucket all-reduce sums them)
+
     if grads is not None:
       gw, gb, gg, gbt = grads
-      check(rn.lib().ra_bn_act_pool_bwd_acc_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
-                                                _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
-                                                ptr(dgamma), ptr(dbeta), ptr(du), ptr(gg), ptr(gbt), rn.stream_ptr()),
-            'ra_bn_act_pool_bwd_acc_f32')
+      bn_backward(gg, gbt)
       cmap_t = _const('cmap', tuple(cmap), dev, lambda: torch.tensor(cmap, dtype=torch.int32, device=dev)) \
           if cmap is not None else None
       if cmap is not None:
@@ -333,9 +443,7 @@ class ConvBNActPool(torch.autograd.Function):
       dw = db = None
       dgamma = dbeta = None
     else:
-      check(rn.lib().ra_bn_act_pool_bwd_f32(ptr(u), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
-                                            _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
-                                            ptr(dgamma), ptr(dbeta), ptr(du), rn.stream_ptr()), 'ra_bn_act_pool_bwd_f32')
+      dgamma, dbeta = bn_backward(None, None)
       # ---- backward-weight (of the SAME conv that ran) + bias
       dWf, db = _f(3, 3, Cx, cout, device=dev), _f(cout, device=dev)
       check(rn.lib().ra_conv3x3_wgrad_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
@@ -357,7 +465,7 @@ class ConvBNActPool(torch.autograd.Function):
       cpb = ops.cout_padded(cin_w)
       ones = _const('ones', cpb, dev, lambda: torch.ones(cpb, dtype=torch.float32, device=dev))
       zeros = _const('zeros', cpb, dev, lambda: torch.zeros(cpb, dtype=torch.float32, device=dev))
-      wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr)
+      wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr, ctx.cache)
       dxr = ops.conv3x3(duc, wpb, ones, zeros, cin_w, relu=False, pool=1)
       if stride == 2:
         sub = _f(B, Hs, Ws, cin_w, device=dev)
@@ -669,18 +777,54 @@ class TrainStep(object):
       # (full_model.py:949,968), box 'bce' assigns to box_loss_fn (:971), segm 'bce' calls an undefined name (:1016)
       raise NotImplementedError('box_loss_fn in (iou, mse, huber) and segm_loss_fn in (iou, wt_cov) are the '
                                 'branches that execute in the reference')
+    self._setup(model, world)
+    cmap_c, _ = model.engine._chan_map(d['ctrl_in'])
+    cmap_a, _ = model.engine._chan_map(d['attn_in'])
+    self.cmap_c = None if cmap_c == list(range(len(cmap_c))) else cmap_c
+    self.cmap_a = None if cmap_a == list(range(len(cmap_a))) else cmap_a
+
+  def _setup(self, model, world):
+    """Bucket, autograd leaves, flat BN statistics, per-trainer caches; then every rank takes rank 0's state."""
+    import torch.distributed as dist
     self.bucket = GradBucket(model)
-    self.world = world
+    self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else int(world)
+    self._pack = {}  # this trainer's per-step cache of packed filters / padded biases / packed LSTM weights
+    self._graphs = {}
     self.leaves = {}
     for k in self.bucket.names:
       leaf = model[k].detach().requires_grad_(True)  # shares the bucket's storage
       leaf.grad = self.bucket.grad_of[k]            # autograd accumulates straight into the bucket
       self.leaves[k] = leaf
-    cmap_c, _ = model.engine._chan_map(d['ctrl_in'])
-    cmap_a, _ = model.engine._chan_map(d['attn_in'])
-    self.cmap_c = None if cmap_c == list(range(len(cmap_c))) else cmap_c
-    self.cmap_a = None if cmap_a == list(range(len(cmap_a))) else cmap_a
     _flat_bn_statistics(self)
+    # whole-batch BatchNorm statistics under data parallelism (nnlib.py:98): per BN call one all_gather forward and
+    # one all-reduce backward.  Collectives inside a captured HIP graph have not been exercised on this stack, so
+    # the synchronised step runs eagerly.
+    self.sync_bn = bool(self.opt.get('sync_bn', False)) and self.world > 1
+    if self.sync_bn:
+      self.use_graph = False
+    rank = dist.get_rank() if self.world > 1 else 0
+    self.aug_gen = torch.Generator().manual_seed(int(self.opt.get('seed', 1234)) + 7919 * rank)  # augmentation draws (CPU)
+    self.broadcast_state()
+
+  def broadcast_state(self, src=0):
+    """Rank `src`'s weights, Adam moments, global_step and BN EMA shadows to every rank (ADVICE r2: the ranks' own
+    initial draws differ)."""
+    import torch.distributed as dist
+    if self.bucket.broadcast(src) > 1:
+      dist.broadcast(self.ema, src=src)
+      eng = getattr(self.model, 'engine', None)
+      if eng is not None:
+        eng._stamp = None
+
+  # ------------------------------------------------------------------ checkpoint (utils/saver.py:24-31, experiment.py:26-37)
+  def state_dict(self):
+    """Everything a restart needs beyond Model.state_dict_numpy() (weights + EMA shadows): Adam m / v per parameter
+    and global_step (learn-rate staircase, knob schedules)."""
+    return self.bucket.state_dict()
+
+  def load_state_dict(self, state, strict=True):
+    self.bucket.load_state_dict(state, strict=strict)
+    self._graphs = {}  # a captured step froze nothing of this, but start clean
 
   # ------------------------------------------------------------------ pieces
   def _grad_views(self, scope, i, key, bn):
@@ -702,7 +846,8 @@ class TrainStep(object):
       bn = self.d['use_bn']
       key = '%s_%d_%d' % (scope, i, tt)
       meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None,
-                  stat_out=self._stat_views.get(key), grads=self._grad_views(scope, i, key, bn))
+                  stat_out=self._stat_views.get(key), grads=self._grad_views(scope, i, key, bn), cache=self._pack,
+                  sync_bn=self.sync_bn)
       x, mean, var = ConvBNActPool.apply(_pad_channels(x) if i else x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -728,7 +873,7 @@ class TrainStep(object):
             [-1] * (skp.shape[3] - len(smap))
         x = torch.cat([xp, skp], dim=3)
       meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key),
-                  grads=self._grad_views(scope, i, key, bn))
+                  grads=self._grad_views(scope, i, key, bn), cache=self._pack, sync_bn=self.sync_bn)
       x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -777,25 +922,25 @@ class TrainStep(object):
     names = ['ctrl_lstm_w_x' + k for k in 'ifou'] + ['ctrl_lstm_w_h' + k for k in 'ifou'] + ['ctrl_lstm_b_' + k for k in 'ifou']
     if not (self.fuse_param_grads and torch.is_grad_enabled() and all(n in g for n in names)):
       return None
-    hit = _PACK.get('lstm_acc')
+    hit = self._pack.get('lstm_acc')
     if hit is None:
       buf = getattr(self, '_lstm_gbuf', None)
       if buf is None or buf[0].shape != Wg.shape:
         buf = self._lstm_gbuf = (torch.empty_like(Wg), torch.empty_like(bg))
       buf[0].zero_()
       buf[1].zero_()
-      hit = _PACK['lstm_acc'] = (buf[0], buf[1], _LstmGradScatter(self, buf[0], buf[1]))
+      hit = self._pack['lstm_acc'] = (buf[0], buf[1], _LstmGradScatter(self, buf[0], buf[1]))
     return hit
 
   def _lstm_weights(self):
     """[w_x ; w_h] of the four gates side by side (i, f, o, u) and their biases: built once per step (the
     weights are shared by all timesteps and glimpses), so a cell is one GEMM + one pointwise kernel."""
-    hit = _PACK.get('lstm')
+    hit = self._pack.get('lstm')
     if hit is None:
       P = self.leaves
       Wg = torch.cat([torch.cat([P['ctrl_lstm_w_x' + g], P['ctrl_lstm_w_h' + g]], dim=0) for g in 'ifou'], dim=1)
       bg = torch.cat([P['ctrl_lstm_b_' + g] for g in 'ifou'], dim=0)
-      hit = _PACK['lstm'] = (Wg, bg)
+      hit = self._pack['lstm'] = (Wg, bg)
     return hit
 
   # ------------------------------------------------------------------ forward + loss
@@ -844,7 +989,7 @@ class TrainStep(object):
     draws in `knobs` (draw_knobs() when None).  d_in / y_in: the extra input channels of the KITTI /
     Cityscapes architectures (full_model.py:165-194)."""
     P, d, opt = self.leaves, self.d, self.opt
-    _PACK.clear()  # the optimizer wrote new weights since the last step
+    self._pack.clear()  # the optimizer wrote new weights since the last step
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
@@ -1046,12 +1191,39 @@ class TrainStep(object):
     st['graph'].replay()
     return dict(st['out'])
 
-  def run(self, x, y_gt, s_gt, knobs=None, generator=None, **extra):
-    """loss + train_step: backward into the flat bucket, one all-reduce, clip + Adam, BN EMA update.
+  def augment(self, x, y_gt, extra, aug=None):
+    """The in-graph augmentation in front of the training graph (full_model.py:203-232, box_model.py: the same
+    call): img.random_transformation on x, y_gt[, d_in, y_in] with phase_train true — ONE crop offset in
+    [0, 2 * padding) per batch after zero padding, and the flip / transpose decisions model_opt switches on
+    (rnd_hflip / rnd_vflip / rnd_transpose; the reference's trainers leave them off, full_model_train.py:653-656).
+    aug: None = draw from this trainer's (rank-offset) generator; a dict = given draws; False = none (the identity
+    crop, what evaluation does)."""
+    if aug is False:
+      return x, y_gt, extra
+    import image_ops
+    dev = self.bucket.param.device
+    as_t = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else torch.as_tensor(
+        np.asarray(a, dtype=np.float32))).to(device=dev, dtype=torch.float32).contiguous()
+    opt = self.opt
+    if opt.get('rnd_colour', False):
+      raise NotImplementedError('colour jitter (image_ops.py:99-103) is not built')
+    r = image_ops.random_transformation(
+        as_t(x), int(opt.get('padding', 0)), True, rnd_vflip=bool(opt.get('rnd_vflip', False)),
+        rnd_hflip=bool(opt.get('rnd_hflip', False)), rnd_transpose=bool(opt.get('rnd_transpose', False)), y=as_t(y_gt),
+        d=as_t(extra.get('d_in')), c=as_t(extra.get('y_in')), generator=self.aug_gen, draws=aug if isinstance(aug, dict) else None)
+    extra = dict(extra)
+    if 'd' in r:
+      extra['d_in'] = r['d']
+    if 'c' in r:
+      extra['y_in'] = r['c']
+    self.last_aug = r.get('_draws')
+    return r['x'], r['y'], extra
+
+  def run(self, x, y_gt, s_gt, knobs=None, generator=None, aug=None, **extra):
+    """loss + train_step: augmentation, backward into the flat bucket, one all-reduce, clip + Adam, BN EMA update.
     The reported `loss` excludes nothing the reference includes except the weight-decay terms, which
     enter through their gradient (wd * w) inside the optimizer kernel."""
-    if not hasattr(self, '_graphs'):
-      self._graphs = {}
+    x, y_gt, extra = self.augment(x, y_gt, extra, aug)
     if knobs is not None:
       dev = self.bucket.param.device
       knobs = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32))).to(
@@ -1066,6 +1238,8 @@ class TrainStep(object):
     for st in out.pop('_match_status', []):  # one host sync per step, after everything has been queued
       ops.check_match_status(st, 'f_segm_match')
     wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
+    if self.use_graph:  # the graph's output tensors are rewritten by the next replay: hand out copies of the small ones
+      out = {k: (v.clone() if isinstance(v, torch.Tensor) and v.numel() <= 4096 else v) for k, v in out.items()}
     out['learn_rate'] = lr
     out['weight_decay_loss'] = 0.5 * (self.bucket.wd * self.bucket.param * self.bucket.param).sum().detach() if wd else 0.0
     return out
@@ -1086,15 +1260,8 @@ class BoxTrainStep(TrainStep):
       raise NotImplementedError('box_model training is built for image + canvas inputs (no d_in / y_in)')
     if self.opt.get('box_loss_fn', 'iou') not in ('iou', 'mse', 'huber'):
       raise NotImplementedError("box_loss_fn in ('iou', 'mse', 'huber')")
-    self.bucket = GradBucket(model)
-    self.world = world
-    self.leaves = {}
-    for k in self.bucket.names:
-      leaf = model[k].detach().requires_grad_(True)
-      leaf.grad = self.bucket.grad_of[k]
-      self.leaves[k] = leaf
+    self._setup(model, world)
     self.cmap_c = self.cmap_a = None
-    _flat_bn_statistics(self)
 
   def draw_knobs(self, B, generator=None):
     """The step's one random draw: the canvas noise U[0, 0.3) (box_model.py:500-502)."""
@@ -1103,7 +1270,7 @@ class BoxTrainStep(TrainStep):
 
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
     P, d, opt = self.leaves, self.d, self.opt
-    _PACK.clear()  # the optimizer wrote new weights since the last step
+    self._pack.clear()  # the optimizer wrote new weights since the last step
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()

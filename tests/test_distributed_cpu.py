@@ -148,3 +148,92 @@ def test_learn_rate_and_knob_schedules():
              knob_decay=0.9, steps_per_knob_decay=300)
   assert ra_train.learn_rate(opt, 4999) == 1e-3 and abs(ra_train.learn_rate(opt, 5000) - 0.96e-3) < 1e-12
   assert ra_train.knob_prob(opt, 100, 200) == 1.0 and abs(ra_train.knob_prob(opt, 500, 200) - 0.9) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# every process draws its own initial weights; a data-parallel trainer must start
+# from ONE model.  Two gloo ranks build the model through get_model() with different torch seeds,
+# wrap it in the product's GradBucket, and take rank 0's state; also the whole-batch BatchNorm
+# moments (nnlib.py:98) from per-shard moments with the product's gather + Chan combination, and the
+# optimizer-state round trip of the checkpoint.
+def _state_worker(rank, world, port, q):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  here = os.path.dirname(ra_dist.__file__)
+  sys.path.insert(0, here)
+  sys.path.insert(0, os.path.join(os.path.dirname(here), 'oracle'))
+  import full_model
+  import ra_oracle as ora
+  import ra_train
+  r, w, _ = ra_dist.init('gloo')
+  torch.manual_seed(100 + 17 * r)  # what separate processes do anyway: different initial draws
+  opt = ora.make_opt('cvppp', 64, 64, 2)
+  model = full_model.get_model(opt)
+  bucket = ra_train.GradBucket(model)
+  before = bucket.param.clone()
+  bucket.m.fill_(float(r + 1))
+  bucket.global_step = 5 * r + 2
+  n = bucket.broadcast(0)
+  # whole-batch moments from the two shards' moments
+  g = torch.Generator().manual_seed(3)
+  xall = torch.randn((8, 6, 5, 4), generator=g) * 3 + 1.5
+  lo, hi = ra_dist.shard_range(r, w, 8)
+  xs = xall[lo:hi].reshape(-1, 4)
+  mean, var = xs.mean(dim=0), xs.var(dim=0, unbiased=False)
+  ntot = ra_train.sync_moments(mean, var, xs.shape[0])
+  q.put((r, n, before.numpy(), bucket.param.numpy().copy(), bucket.m.numpy().copy(), bucket.global_step,
+         float(model['global_step']), mean.numpy(), var.numpy(), ntot, model['ctrl_cnn_w_0'].numpy().copy()))
+  ra_dist.barrier()
+  torch.distributed.destroy_process_group()
+
+
+def test_two_rank_initial_state_is_rank0s_and_moments_are_whole_batch():
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29700 + (os.getpid() % 200)
+  procs = [ctx.Process(target=_state_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  (r0, n0, b0, p0, m0, gs0, mg0, mean0, var0, nt0, w0), (r1, n1, b1, p1, m1, gs1, mg1, mean1, var1, nt1, w1) = res
+  assert n0 == n1 == 2
+  assert np.abs(b0 - b1).max() > 1e-3                  # the ranks' own draws differed ...
+  assert (p0 == b0).all() and (p1 == b0).all()         # ... and both now hold rank 0's weights,
+  assert (w1 == w0).all()                              # through the model's views as well,
+  assert (m0 == 1.0).all() and (m1 == 1.0).all()       # its Adam moments
+  assert gs0 == gs1 == 2 and mg0 == mg1 == 2.0         # and its global_step (LR staircase, knob schedules)
+  g = torch.Generator().manual_seed(3)
+  xall = (torch.randn((8, 6, 5, 4), generator=g) * 3 + 1.5).reshape(-1, 4)
+  for mean, var, nt in ((mean0, var0, nt0), (mean1, var1, nt1)):
+    assert nt == xall.shape[0]
+    assert np.abs(mean - xall.mean(dim=0).numpy()).max() < 1e-6
+    assert np.abs(var - xall.var(dim=0, unbiased=False).numpy()).max() < 1e-5
+
+
+def test_optimizer_state_round_trip_and_combine_moments():
+  import ra_train
+  a, b = ra_train.GradBucket(_toy_model()), ra_train.GradBucket(_toy_model())
+  g = torch.Generator().manual_seed(5)
+  a.m.copy_(torch.randn(a.n, generator=g))
+  a.v.copy_(torch.rand(a.n, generator=g))
+  a.global_step = 7
+  st = a.state_dict()
+  assert set(k for k in st if k != 'global_step') == {s + k for s in ('adam_m/', 'adam_v/') for k in a.names}
+  b.load_state_dict(st)
+  for k in a.names:
+    o, n, _ = a.offsets[k]
+    assert (b.m[o:o + n] == a.m[o:o + n]).all() and (b.v[o:o + n] == a.v[o:o + n]).all()
+  assert b.global_step == 7 and b.model['global_step'] == 7.0
+  import pytest
+  with pytest.raises(Exception):
+    b.load_state_dict({'global_step': np.asarray(1)})    # strict: missing Adam slots
+  # unequal shard sizes: Chan's combination is exact for any split
+  x = torch.randn((37, 3), generator=g, dtype=torch.float64) * 2 + 5
+  parts = [x[:5], x[5:30], x[30:]]
+  n, m, v = ra_train.combine_moments(torch.tensor([float(p.shape[0]) for p in parts], dtype=torch.float64),
+                                     torch.stack([p.mean(dim=0) for p in parts]),
+                                     torch.stack([p.var(dim=0, unbiased=False) for p in parts]))
+  assert float(n) == 37 and (m - x.mean(dim=0)).abs().max() < 1e-12 and (v - x.var(dim=0, unbiased=False)).abs().max() < 1e-12

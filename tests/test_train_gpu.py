@@ -168,7 +168,7 @@ def test_train_step_update_and_three_steps(cuda):
   import full_model
   opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6)
   m = full_model.get_model(opt).load_weights(P)
-  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True}
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'aug': False}
   head, gref, stats = _oracle_grads(opt, P, x, y_gt, s_gt)
   loss1, _ = m.run(['loss', 'train_step'], feed)
   assert abs(float(loss1) - float(head['loss'])) < 2e-4 * max(1.0, abs(float(head['loss'])))
@@ -313,7 +313,7 @@ def test_box_model_training_vs_oracle(cuda, over):
   assert (pieces['match_box'].cpu().numpy() == head['match_box'].numpy()).all()
   _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
   m2 = box_model.get_model(opt).load_weights(P)
-  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'noise': noise, 'phase_train': True}
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'noise': noise, 'phase_train': True, 'aug': False}
   l = [float(m2.run(['loss', 'train_step'], feed)[0]) for _ in range(3)]
   assert abs(l[0] - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss']))) and l[2] < l[0] and float(m2['global_step']) == 3.0
 
@@ -384,7 +384,7 @@ def test_kitti_arch_training_vs_oracle(cuda, knob):
     assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
   _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
   loss2, _ = m.run(['loss', 'train_step'], {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'd_in': d_in, 'y_in': y_in,
-                                            'phase_train': True, 'knobs': kd})
+                                            'phase_train': True, 'knobs': kd, 'aug': False})
   assert abs(float(loss2) - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss'])))
 
 
@@ -410,7 +410,7 @@ def test_graphed_step_equals_eager_step(cuda):
         m.trainer.use_graph = graphed
       else:
         ra_train.TrainStep.use_graph = graphed
-      loss, _ = m.run(['loss', 'train_step'], {'x': xk, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'knobs': k})
+      loss, _ = m.run(['loss', 'train_step'], {'x': xk, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'knobs': k, 'aug': False})
       losses.append(float(loss))
     res[graphed] = (losses, m.state_dict_numpy())
     assert (graphed and any('graph' in v for v in m.trainer._graphs.values())) or \
@@ -536,3 +536,126 @@ def test_attention_head_and_knob_vs_torch_autograd(cuda, flags):
   assert np.abs(x32.grad.cpu().numpy() - x.grad.numpy()).max() < 1e-4
   assert np.abs(gw.cpu().numpy() - 1.0 - Wl.grad.numpy()).max() < 1e-4
   assert np.abs(gb.cpu().numpy() - 1.0 - bl.grad.numpy()).max() < 1e-4
+
+
+def test_training_graph_applies_the_augmentation(cuda):
+  """full_model.py:203-232: img.random_transformation(x, padding, phase_train, ..., y=y_gt) sits in front of the
+  training graph.  With the step's draws given (crop offset, flips, transpose), the product's loss equals the
+  oracle's loss on the oracle-transformed batch; without `aug` the trainer draws its own (rank-offset) offsets."""
+  import full_model
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6, rnd_hflip=True, rnd_vflip=True, rnd_transpose=True)
+  pad = int(opt['padding'])
+  for draws in (dict(off_y=3, off_x=2 * pad - 1, flip_v=True, flip_h=False, transpose=True),
+                dict(off_y=pad, off_x=pad, flip_v=False, flip_h=True, transpose=False)):
+    xt = ora.random_transformation(x, pad, **draws)
+    yt = np.stack([ora.random_transformation(y_gt[:, t][..., None], pad, **draws)[..., 0] for t in range(y_gt.shape[1])], axis=1)
+    fwd, _ = ort.forward(opt, P, xt, phase_train=True, bn_stats={})
+    head = ort.loss_head(opt, fwd, yt, s_gt)
+    m = full_model.get_model(opt).load_weights(P)
+    loss, _ = m.run(['loss', 'train_step'], {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'aug': draws})
+    assert abs(float(loss) - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss']))), draws
+    assert m.trainer.last_aug['off_y'] == draws['off_y'] and m.trainer.last_aug['transpose'] == draws['transpose']
+  m = full_model.get_model(opt).load_weights(P)
+  seen = set()
+  for _ in range(4):
+    loss, _ = m.run(['loss', 'train_step'], {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True})
+    a = m.trainer.last_aug
+    assert 0 <= a['off_y'] < 2 * pad and 0 <= a['off_x'] < 2 * pad and np.isfinite(float(loss))
+    seen.add((a['off_y'], a['off_x'], a['flip_v'], a['flip_h'], a['transpose']))
+  assert len(seen) > 1  # the draws change from step to step
+
+
+def test_resume_equals_uninterrupted(cuda, tmp_path):
+  """utils/saver.py:24-31 saves every variable (weights, Adam slots, global_step), experiment.py:26-37 restores
+  them: 2 steps + checkpoint + 2 steps in a fresh model equal 4 steps in one run, bit for bit (same inputs)."""
+  import full_model
+  import full_model_train
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6)
+  opt['steps_per_learn_rate_decay'] = 3  # the staircase moves inside the run: a restart from step 0 would show
+  feeds = [{'x': x * (1.0 - 0.1 * k), 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'aug': False} for k in range(4)]
+  a = full_model.get_model(opt).load_weights(P)
+  la = [float(a.run(['loss', 'train_step'], f)[0]) for f in feeds]
+  b = full_model.get_model(opt).load_weights(P)
+  lb = [float(b.run(['loss', 'train_step'], f)[0]) for f in feeds[:2]]
+  path = str(tmp_path / 'ckpt.npz')
+  full_model_train.save_checkpoint(path, b)
+  c = full_model.get_model(opt)           # fresh random weights, fresh optimizer
+  full_model_train.load_checkpoint(path, c)
+  assert c.trainer.bucket.global_step == 2 and float(c['global_step']) == 2.0
+  lc = [float(c.run(['loss', 'train_step'], f)[0]) for f in feeds[2:]]
+  assert lb == la[:2] and lc == la[2:], (la, lb, lc)
+  wa, wc = a.state_dict_numpy(), c.state_dict_numpy()
+  assert all((wa[k] == wc[k]).all() for k in wa)
+  sa, sc = a.trainer.state_dict(), c.trainer.state_dict()
+  assert all((sa[k] == sc[k]).all() for k in sa)
+
+
+def test_sync_bn_split_backward_equals_fused(cuda):
+  """The two-launch-group form of the BatchNorm backward (reduce | all-reduce | dx with the global count) that
+  data-parallel training on whole-batch statistics uses: for ONE rank holding the whole batch it must equal the
+  fused form; and two half-batches with whole-batch moments + summed per-channel sums reproduce the whole batch."""
+  import ctypes as C
+  import ra_native as rn
+  rng = np.random.RandomState(3)
+  B, H, W, Cc = 4, 8, 12, 8
+  u = torch.tensor(rng.randn(B, H, W, Cc).astype(np.float32), device=cuda)
+  dy = torch.tensor(rng.randn(B, H // 2, W // 2, Cc).astype(np.float32), device=cuda)
+  gamma = torch.tensor(rng.uniform(0.5, 1.5, Cc).astype(np.float32), device=cuda)
+  beta = torch.tensor(rng.randn(Cc).astype(np.float32) * 0.1, device=cuda)
+  lib, f = rn.lib(), lambda *s: torch.empty(s, dtype=torch.float32, device=cuda)
+  ws = f(lib.ra_bn_workspace_floats(Cc))
+
+  def moments(t):
+    mean, var = f(Cc), f(Cc)
+    rn.check(lib.ra_bn_moments_f32(rn.ptr(t), t.numel() // Cc, Cc, rn.ptr(ws), ws.numel(), rn.ptr(mean), rn.ptr(var), rn.stream_ptr()), 'm')
+    return mean, var
+  mean, var = moments(u)
+  dg, db, du = f(Cc), f(Cc), torch.empty_like(u)
+  rn.check(lib.ra_bn_act_pool_bwd_f32(rn.ptr(u), rn.ptr(dy), rn.ptr(mean), rn.ptr(var), rn.ptr(gamma), rn.ptr(beta), C.c_float(1e-3),
+                                      1, 2, B, H, W, Cc, rn.ptr(ws), ws.numel(), rn.ptr(dg), rn.ptr(db), rn.ptr(du), rn.stream_ptr()), 'bwd')
+  # the same through combine_moments + reduce / dx on two shards
+  halves = [(u[:2].contiguous(), dy[:2].contiguous()), (u[2:].contiguous(), dy[2:].contiguous())]
+  ms = [moments(h[0]) for h in halves]
+  n, gm, gv = ra_train.combine_moments(torch.tensor([2.0 * H * W, 2.0 * H * W], device=cuda), torch.stack([m[0] for m in ms]),
+                                       torch.stack([m[1] for m in ms]))
+  assert float(n) == B * H * W and np.abs(gm.cpu().numpy() - mean.cpu().numpy()).max() < 1e-6 and \
+      np.abs(gv.cpu().numpy() - var.cpu().numpy()).max() < 1e-6
+  sums = []
+  for uh, dyh in halves:
+    dgl, dbl = f(Cc), f(Cc)
+    rn.check(lib.ra_bn_act_pool_bwd_reduce_f32(rn.ptr(uh), rn.ptr(dyh), rn.ptr(gm), rn.ptr(gv), rn.ptr(gamma), rn.ptr(beta),
+                                               C.c_float(1e-3), 1, 2, 2, H, W, Cc, rn.ptr(ws), ws.numel(), rn.ptr(dgl), rn.ptr(dbl),
+                                               None, None, rn.stream_ptr()), 'reduce')
+    sums.append((dgl, dbl))
+  dgs, dbs = sums[0][0] + sums[1][0], sums[0][1] + sums[1][1]
+  assert np.abs(dgs.cpu().numpy() - dg.cpu().numpy()).max() < 1e-4 and np.abs(dbs.cpu().numpy() - db.cpu().numpy()).max() < 1e-4
+  outs = []
+  for uh, dyh in halves:
+    duh = torch.empty_like(uh)
+    rn.check(lib.ra_bn_act_pool_bwd_dx_f32(rn.ptr(uh), rn.ptr(dyh), rn.ptr(gm), rn.ptr(gv), rn.ptr(gamma), rn.ptr(beta), rn.ptr(dgs),
+                                           rn.ptr(dbs), C.c_double(float(B * H * W)), C.c_float(1e-3), 1, 2, 2, H, W, Cc, rn.ptr(duh),
+                                           rn.stream_ptr()), 'dx')
+    outs.append(duh)
+  assert np.abs(torch.cat(outs).cpu().numpy() - du.cpu().numpy()).max() < 1e-5
+
+
+def test_two_trainers_do_not_share_step_caches(cuda):
+  """The per-step caches (packed filters, padded biases, packed LSTM weights) belong to the TrainStep: two
+  trainers whose steps interleave give the losses they give alone."""
+  import full_model
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6)
+  P2 = ora.random_params(opt, 9)
+  for k in P2:
+    if ra_is_w(k):
+      P2[k] = (P2[k] * 0.6).astype(np.float32)
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'aug': False}
+  alone = []
+  for PP in (P, P2):
+    m = full_model.get_model(opt).load_weights(PP)
+    alone.append([float(m.run(['loss', 'train_step'], feed)[0]) for _ in range(3)])
+  ma, mb = full_model.get_model(opt).load_weights(P), full_model.get_model(opt).load_weights(P2)
+  inter = [[], []]
+  for _ in range(3):
+    inter[0].append(float(ma.run(['loss', 'train_step'], feed)[0]))
+    inter[1].append(float(mb.run(['loss', 'train_step'], feed)[0]))
+  assert inter == alone and ma.trainer._pack is not mb.trainer._pack
