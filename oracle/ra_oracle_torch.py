@@ -249,6 +249,16 @@ def _forward(opt, Pnp, x, d_in, y_in, requires_grad):
           inter = (x1 < x2) * (y1 < y2) * (x2 - x1) * (y2 - y1)
           iou_t = (inter / ((ba[..., 1] - ta[..., 1]) * (ba[..., 0] - ta[..., 0]) +
                             (bb[..., 1] - tb[..., 1]) * (bb[..., 0] - tb[..., 0]) - inter))
+          # the same IoU on the autograd tape: the reference stacks these per-timestep rows into the [B,T,T] matrix
+          # its box matching AND its box loss use (full_model.py:931-934), differentiable through the corners
+          tat, bat = (ctr - size / 2.0)[:, None, :], (ctr + size / 2.0)[:, None, :]
+          tbt, bbt = t64(tb), t64(bb)
+          y1t, x1t = torch.maximum(tat[..., 0], tbt[..., 0]), torch.maximum(tat[..., 1], tbt[..., 1])
+          y2t, x2t = torch.minimum(bat[..., 0], bbt[..., 0]), torch.minimum(bat[..., 1], bbt[..., 1])
+          it = (x1t < x2t).to(DT) * (y1t < y2t).to(DT) * (x2t - x1t) * (y2t - y1t)
+          outs.setdefault('iou_box_steps', []).append(
+              (it / ((bat[..., 1] - tat[..., 1]) * (bat[..., 0] - tat[..., 0]) +
+                     (bbt[..., 1] - tbt[..., 1]) * (bbt[..., 0] - tbt[..., 0]) - it))[:, None, :])
         else:
           a = attn_box.detach().numpy()
           iou_t = ora.f_inter(a, K['box_gt']) / ora.f_union(a, K['box_gt'], eps=1e-5)
@@ -325,14 +335,17 @@ def loss_head(opt, fwd, y_gt, s_gt):
     return t64(ora.f_segm_match(iou.detach().numpy(), s_gt.numpy()))
 
   out = {}
-  iou_box = iou_pairwise(fwd['attn_box'], box_gt)
+  iou_box = fwd['iou_box_steps'] if 'iou_box_steps' in fwd else iou_pairwise(fwd['attn_box'], box_gt)  # :928-936
   m_box = match_of(iou_box)
   cnt_box = torch.clamp(m_box.sum(dim=(1, 2)), min=1.0)
-  out['iou_soft_box'] = ((iou_box * m_box).sum(dim=(1, 2)) / cnt_box).sum() / B
+  fixed = bool(ora._opt(opt, 'fixed_order', False))
+  # fixed order: f_iou(pairwise=False) summed over ALL T, unmasked, over the identity match's count (:922-924,941-945)
+  masked = lambda iou, m: torch.diagonal(iou, dim1=1, dim2=2).sum(dim=1) if fixed else (iou * m).sum(dim=(1, 2))
+  out['iou_soft_box'] = (masked(iou_box, m_box) / cnt_box).sum() / B
   iou = iou_pairwise(fwd['y_out'], y_gt)
   m = match_of(iou)
   cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
-  out['iou_soft'] = ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B
+  out['iou_soft'] = (masked(iou, m) / cnt).sum() / B
   s_out = fwd['s_out']
   s_min = torch.cummin(s_out, dim=1)[0]                                   # modellib.py:40-53
   s_max = torch.flip(torch.cummax(torch.flip(s_out, [1]), dim=1)[0], [1])  # :56-68

@@ -1009,7 +1009,7 @@ class TrainStep(object):
       ctr_gtn, size_gtn, knob_box, knob_segm = self._knob_setup(y_gt, knobs)
       ysel = torch.empty((B, H, W), device=dev)
     canvas = torch.zeros((B, H, W, 1), device=dev)
-    stats, y_list, s_list, box_list, cn_list, ls_list = {}, [], [], [], [], []
+    stats, y_list, s_list, box_list, cn_list, ls_list, iou_box_steps = {}, [], [], [], [], [], []
     dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
     head_flags = (1 if d['squash'] else 0) | (2 if d['fixed_var'] else 0) | (4 if d['dynamic_var'] else 0) | (8 if d['fixed_gamma'] else 0)
     for tt in range(T):
@@ -1032,9 +1032,10 @@ class TrainStep(object):
         else:
           if opt.get('use_iou_box', False):  # IoU of the box corners (modellib.f_iou_box, full_model.py:750-754)
             import modellib
-            cd, sd = ctr.detach(), size.detach()
-            iou_t = modellib.f_iou_box((cd - sd / 2.0)[:, None], (cd + sd / 2.0)[:, None], gt_corners[:, :, 0:2],
-                                       gt_corners[:, :, 2:4]).contiguous()
+            iou_row = modellib.f_iou_box((ctr - size / 2.0)[:, None], (ctr + size / 2.0)[:, None], gt_corners[:, :, 0:2],
+                                         gt_corners[:, :, 2:4])
+            iou_box_steps.append(iou_row[:, None, :])  # the row of the [B,T,T] matrix the box matching and loss use (:931-934)
+            iou_t = iou_row.detach().contiguous()
           else:
             iou_t = ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
           gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
@@ -1075,20 +1076,26 @@ class TrainStep(object):
     y_out, s_out = torch.stack(y_list, dim=1), torch.cat(s_list, dim=1)
     attn_box = torch.stack(box_list, dim=1)
     # ---- losses (full_model.py:913-1035), box_loss_fn = segm_loss_fn = 'iou'.  With the knob the
-    # reference stacks the per-timestep box IoUs (:931-934): the same numbers as the pairwise f_iou.
+    # reference stacks the per-timestep box IoUs (:931-934): for use_iou_box = False (f_inter / f_union of the
+    # predicted box against every GT box) the same numbers as the pairwise f_iou; with use_iou_box the stacked
+    # corner IoUs (iou_box_steps, differentiable through the corners) are the matrix.
     ident = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
 
-    def matched_iou(a, b):
-      iou = PairIoU.apply(a, b)
+    def matched_iou(a, b, iou=None):
+      iou = PairIoU.apply(a, b) if iou is None else iou
       if fixed:
         m = ident
       else:
         m, st = ops.segm_match(iou.detach(), s_gt)
         statuses.append(st)  # checked by the caller once the step has run (no host sync in here)
       cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
+      if fixed:  # f_iou(pairwise=False) summed over ALL T, unmasked, over the identity match's count (full_model.py:922-945,985-1007)
+        return (torch.diagonal(iou, dim1=1, dim2=2).sum(dim=1) / cnt).sum() / B, m
       return ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B, m
 
     statuses = []
+    # with the knob and use_iou_box the boxes are matched and scored on the stacked per-timestep corner IoUs
+    iou_box_rows = torch.cat(iou_box_steps, dim=1).contiguous() if len(iou_box_steps) == T else None
     # the two matchings are independent and each is one wave per image for milliseconds (dense soft-IoU
     # matrices early in training): the box matching runs on a side stream under the mask matching
     if self.match_side_stream:
@@ -1096,11 +1103,11 @@ class TrainStep(object):
       side = _side_stream(dev)
       side.wait_stream(cur)
       with torch.cuda.stream(side):
-        iou_box, m_box = matched_iou(attn_box, box_gt)
+        iou_box, m_box = matched_iou(attn_box, box_gt, iou_box_rows)
       iou_soft, m = matched_iou(y_out, y_gt)
       cur.wait_stream(side)
     else:
-      iou_box, m_box = matched_iou(attn_box, box_gt)
+      iou_box, m_box = matched_iou(attn_box, box_gt, iou_box_rows)
       iou_soft, m = matched_iou(y_out, y_gt)
     box_loss, segm_loss = -iou_box, -iou_soft
     blf = opt.get('box_loss_fn', 'iou')
