@@ -321,6 +321,28 @@ int ra_paste_score_direct_f32(const float *patch, int Cp, int pc, const float *a
                               float *canvas, float *y_out, size_t y_stride_b, int flags,
                               const float *h, int K0, const float *core, int K1, const float *w,
                               const float *bias, float *s_out, size_t s_stride_b, void *stream);
+
+/* Adjoints of the attention resample for the training step (ra_train.AttnExtract / AttnPaste), without the dense
+ * [L,F] filter banks the reference differentiates through (modellib.py:581-641): with E(X) = fy^T X fx,
+ *   RA_RESAMPLE_READ   x_patch = gamma E(img) (full_model.py:788-789): X = img [B,H,W,Cx] channels chan0 .. chan0+C,
+ *                      Q = d x_patch [B,Fh,Fw,Cq]; scale = gamma [B]: out[:, 0:6] are multiplied by it;
+ *                      out[:, 6] = sum E.Q = d gamma.
+ *   RA_RESAMPLE_WRITE  y = sigmoid(exp(rec[8]) fy P fx^T + beta) (full_model.py:810-818): dY, Y [B,H,W] (the upstream
+ *                      gradient and the forward's result), Q = P [B,Fh,Fw,Cq] channel 0; E [B,Fh,Fw,Ce] channel 0
+ *                      receives dP; out[:, 6] = d y_lg_gamma.
+ *   RA_RESAMPLE_BOX    box = sigmoid(rec[7] fy 1 fx^T + beta) (full_model.py:738-741): Q = NULL; div = box_gamma [B]:
+ *                      out[:, 6] = d box_gamma.
+ * out [B,8] = (d ctr_y, d ctr_x, d size_y, d size_x, d lg_var_y, d lg_var_x, the gamma gradient, 0) for the window
+ * parameters of attn_rec [B,RA_ATTN_STRIDE].  ws: ra_resample_bwd_workspace_floats(B, Fh, C) floats (C = 1 for WRITE /
+ * BOX).  Deterministic (fixed-order sums); banded like the forward kernels (weights below e^-30 of the peak dropped). */
+#define RA_RESAMPLE_READ 0
+#define RA_RESAMPLE_WRITE 1
+#define RA_RESAMPLE_BOX 2
+size_t ra_resample_bwd_workspace_floats(int B, int Fh, int C);
+int ra_resample_bwd_f32(int mode, const float *X, int Cx, int chan0, int C, const float *dY, const float *Y,
+                        const float *attn_rec, const float *Q, int Cq, float *E, int Ce, int B, int H, int W, int Fh,
+                        int Fw, const float *scale, int scale_stride, const float *div, int div_stride, float *ws,
+                        size_t ws_floats, float *out, void *stream);
 int ra_attn_box_direct_f32(const float *attn, int B, int H, int W, int Fh, int Fw, float beta,
                            float *box_out, size_t stride_b, void *stream);
 

@@ -9,13 +9,11 @@
 // Same banding rule as ra_attn.hip: taps whose weight is below exp(-30) of the peak are skipped.
 #include <cstdlib>
 
+#include "ra_attn_axis.h"
 #include "ra_common.h"
 
 namespace ra {
 namespace attnd {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr float kBandLog = 30.0f;
 
 // tools/attn_probe.hip builds this file with -DRA_PROBE: thread 0 of every workgroup stamps the 100 MHz
 // wall clock at a few points of the kernel (where the time of a latency-bound kernel goes)
@@ -29,60 +27,6 @@ __device__ long long *ra_probe_buf;
 #else
 #define RA_PROBE_AT(k)
 #endif
-constexpr float kInvSqrt2Pi = 0.3989422804014327f;
-
-struct Axis {  // one axis of one example's filter bank
-  float ctr, step, inv_step, half, inv2var, norm, R;
-  int L, F;
-  __device__ inline float mu(int j) const { return ctr + step * ((float)j - half); }
-  __device__ inline float w(float l, int j) const {  // modellib.py:610-611
-    const float d = l - mu(j);
-    return norm * __expf(-d * d * inv2var);
-  }
-  // pixel band [lo, hi) of tap j
-  __device__ inline void band(int j, int &lo, int &hi) const {
-    const float m = mu(j);
-    float a = ceilf(m - R), c = floorf(m + R) + 1.0f;
-    a = fminf(fmaxf(a, 0.0f), (float)L);
-    c = fminf(fmaxf(c, 0.0f), (float)L);
-    if (!(a == a) || !(c == c)) {
-      a = 0.0f;
-      c = (float)L;
-    }
-    lo = (int)a;
-    hi = (int)c > lo ? (int)c : lo;
-  }
-  // tap range [jlo, jhi) whose band contains pixel l (widened by one tap each side: extra terms
-  // are harmless, missing ones are not)
-  __device__ inline void taps(int l, int &jlo, int &jhi) const {
-    float a = ((float)l - R - ctr) * inv_step + half, c = ((float)l + R - ctr) * inv_step + half;
-    if (!(a == a) || !(c == c) || !(step > 0.0f)) {
-      jlo = 0;
-      jhi = F;
-      return;
-    }
-    a = fminf(fmaxf(floorf(a) - 1.0f, 0.0f), (float)F);
-    c = fminf(fmaxf(ceilf(c) + 2.0f, 0.0f), (float)F);
-    jlo = (int)a;
-    jhi = (int)c;
-  }
-};
-
-__device__ inline Axis make_axis(const float *rec, int axis, int L, int F) {
-  // every workgroup evaluates this on its critical path: single-instruction reciprocal / square roots (1 ulp)
-  Axis A;
-  const float var = __expf(rec[4 + axis]);
-  A.ctr = rec[0 + axis];
-  A.step = (rec[2 + axis] + 1.0f) / (float)F;       // modellib.py:599
-  A.inv_step = __builtin_amdgcn_rcpf(A.step);
-  A.half = ((float)F - 1.0f) / 2.0f;
-  A.inv2var = 0.5f * __builtin_amdgcn_rcpf(var);
-  A.norm = kInvSqrt2Pi * __builtin_amdgcn_rsqf(var);  // 1/sqrt(var)/sqrt(2 pi)
-  A.R = __builtin_amdgcn_sqrtf(2.0f * kBandLog * var);
-  A.L = L;
-  A.F = F;
-  return A;
-}
 
 // ---- extract, row-parallel form ---------------------------------------------------------------------
 // Workgroup = (one tap j, channel group cg, image b).  The tap's row band (2R+1 rows) x the window's
@@ -99,10 +43,6 @@ __device__ inline Axis make_axis(const float *rec, int axis, int L, int F) {
 // multiply-adds through v_readlane (a v_exp costs 16 cycles of a SIMD that holds one or two waves).
 // Work items are dealt to the 8 XCDs in contiguous chunks (workgroup id % 8 = XCD): the taps of one
 // image share almost all their rows, and those re-reads then hit ONE L2.
-__device__ inline float readlane_f(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
 template <int KR>
 __global__ __launch_bounds__(256) void extract_rows_kernel(const float *__restrict__ img, int Ci, int chan0,
                                                             const float *__restrict__ canvas, int canvas_chan,
@@ -564,12 +504,13 @@ __global__ __launch_bounds__(256) void paste_win_kernel(const float *__restrict_
         ja = jlo[r0 + k];
         jb = jhi[r0 + k];
       }
-    const int r = r0 + wv, l = l0 + r;
-    for (int i = lane; i < Fw; i += 64) {
-      float s = 0.0f;
-      for (int jc = ja; jc < jb; jc += 64) {
-        const int nj = (jb - jc) < 64 ? (jb - jc) : 64;
-        const float wl = (lane < nj) ? Ay.w((float)l, jc + lane) : 0.0f;  // tap jc + lane: one v_exp per wave
+    const int r = r0 + wv, l = l0 + r, i = lane;  // Fw <= 64: lane = output column
+    float s = 0.0f;
+    for (int jc = ja; jc < jb; jc += 64) {
+      const int nj = (jb - jc) < 64 ? (jb - jc) : 64;
+      // tap jc + lane: one v_exp per wave, evaluated by ALL lanes (v_readlane below picks any of them)
+      const float wl = (lane < nj) ? Ay.w((float)l, jc + lane) : 0.0f;
+      if (i < Fw) {
         if (MODE == 0) {
           const float *pp = Ps + jc * Fw + i;
           int k = 0;
@@ -585,8 +526,8 @@ __global__ __launch_bounds__(256) void paste_win_kernel(const float *__restrict_
           for (int k = 0; k < nj; ++k) s += readlane_f(wl, k);  // P == 1 (const_ones)
         }
       }
-      V[i * RB + r] = gain * s;
     }
+    if (i < Fw) V[i * RB + r] = gain * s;
   }
   __syncthreads();
   RA_PROBE_AT(3);  // V done
@@ -644,7 +585,7 @@ void launch_paste(int extra_wg, const float *patch, int Cp, int pc, const float 
   const int rb = pg.rows == 8 ? 8 : 4;
   const bool a16 = ((reinterpret_cast<uintptr_t>(y_out) | reinterpret_cast<uintptr_t>(canvas) |
                      reinterpret_cast<uintptr_t>(patch)) & 15) == 0;
-  const bool win_ok = W % 4 == 0 && rb * W <= 4096 && (y_stride_b & 3) == 0 && a16 &&
+  const bool win_ok = W % 4 == 0 && Fw <= 64 && rb * W <= 4096 && (y_stride_b & 3) == 0 && a16 &&
                       (size_t)H * W * 4 < 0x7fffffffu && Fh * Fw % 4 == 0 && Fh * Fw <= 4 * attnd::kPsQuads * 256 &&
                       (MODE == 1 || (canvas && !img && Cp == 1 && pc == 0));
   if (!win_ok) {

@@ -428,6 +428,32 @@ def paste_score_direct(patch, pc, attn, beta, disable_overwrite, y_out, y_stride
         'ra_paste_score_direct_f32')
 
 
+RESAMPLE_READ, RESAMPLE_WRITE, RESAMPLE_BOX = 0, 1, 2
+
+
+def resample_bwd(mode, rec, H, W, Fh, Fw, X=None, chan0=0, C=None, dY=None, Y=None, Q=None, E=None, scale=None, div=None):
+  """ra_resample_bwd_f32 (include/recattend.h): the adjoint of one attention resample straight to the gradients of the
+  window parameters.  Returns out [B,8] = (d ctr_y, d ctr_x, d size_y, d size_x, d lg_var_y, d lg_var_x, d gamma, 0)."""
+  _need_cuda(rec, X, dY, Y, Q, E)  # scale / div: strided [B] views (a column of the record), read with their stride
+  B = rec.shape[0]
+  if mode == RESAMPLE_READ:
+    Cx = X.shape[3]
+    C = Cx - chan0 if C is None else C
+  else:
+    Cx, C = 1, 1
+  lib = rn.lib()
+  nws = lib.ra_resample_bwd_workspace_floats(B, Fh, C)
+  ws = torch.empty(nws, dtype=torch.float32, device=rec.device)
+  out = torch.empty((B, 8), dtype=torch.float32, device=rec.device)
+  sstride = 0 if scale is None else int(scale.stride(0))
+  dstride = 0 if div is None else int(div.stride(0))
+  check(lib.ra_resample_bwd_f32(int(mode), ptr(X), int(Cx), int(chan0), int(C), ptr(dY), ptr(Y), ptr(rec), ptr(Q),
+                                0 if Q is None else int(Q.shape[3]), ptr(E), 0 if E is None else int(E.shape[3]), B, H, W, Fh, Fw,
+                                ptr(scale), sstride, ptr(div), dstride, ptr(ws), nws, ptr(out), rn.stream_ptr()),
+        'ra_resample_bwd_f32')
+  return out
+
+
 def attn_box_direct(attn, H, W, Fh, Fw, beta, out, stride_b):
   _need_cuda(attn)
   check(rn.lib().ra_attn_box_direct_f32(ptr(attn), attn.shape[0], H, W, Fh, Fw, C.c_float(beta),

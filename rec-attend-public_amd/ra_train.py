@@ -207,8 +207,11 @@ def allreduce_sums(t):
 #     flipped packing, backward-weight on MFMA) — ConvBNActPool, csrc/ra_train.hip + ra_conv.hip;
 #   * the pairwise soft IoU of the two losses and its adjoint — PairIoU, csrc/ra_loss.hip;
 #   * the ground-truth boxes and both Hungarian matchings (device solver), clip + Adam;
-#   * the small dense algebra (LSTM / MLP GEMMs, the [L,F] Gaussian filter banks and the
-#     F_y^T X F_x contractions of extract / paste) as library GEMMs + elementwise ops under autograd.
+#   * the attention resample — box, read, write — forward on the decode loop's banded kernels and backward
+#     straight to the window parameters' gradients (AttnExtract / AttnPaste, csrc/ra_attn_train.hip): no dense
+#     [L,F] filter banks, no GEMMs;
+#   * the controller's small dense algebra (LSTM / MLP GEMMs on [B, <= 1024] tensors) as library GEMMs +
+#     elementwise ops under autograd.
 # =====================================================================================================
 import ctypes as _C
 
@@ -722,17 +725,82 @@ def gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw):
   return GaussFilterPair.apply(ctr, size, lg_var, H, W, Fh, Fw)
 
 
-def extract(x, fy, fx):
-  """modellib.extract_patch (modellib.py:615-641): F_y^T X_c F_x per channel; x [B,H,W,C]."""
-  B, H, W, C = x.shape
-  t = torch.bmm(fy.transpose(1, 2), x.reshape(B, H, W * C)).reshape(B, -1, W, C)     # [B,Fh,W,C]
-  t = torch.matmul(t.permute(0, 1, 3, 2), fx[:, None])                                # [B,Fh,C,Fw]
-  return t.permute(0, 1, 3, 2)
+def attn_record(ctr, size, lg_var, attn_gamma=None, box_gamma=None, y_lg_gamma=None):
+  """The [B, RA_ATTN_STRIDE] attention record the resample kernels read (include/recattend.h: 0 ctr_y, 1 ctr_x,
+  2 size_y, 3 size_x, 4 lg_var_y, 5 lg_var_x, 6 attn_gamma, 7 box_gamma, 8 y_lg_gamma) from the training graph's
+  [B,2] / [B] tensors: one launch."""
+  B, dev = ctr.shape[0], ctr.device
+  one = _const('ones', (B, 1), dev, lambda: torch.ones((B, 1), dtype=torch.float32, device=dev))
+  pad = _const('zeros', (B, rn.RA_ATTN_STRIDE - 9), dev, lambda: torch.zeros((B, rn.RA_ATTN_STRIDE - 9), dtype=torch.float32, device=dev))
+  col = lambda g, dflt: dflt if g is None else g.detach().reshape(B, 1)
+  return torch.cat([ctr.detach(), size.detach(), lg_var.detach(), col(attn_gamma, one), col(box_gamma, one),
+                    col(y_lg_gamma, pad[:, :1]), pad], dim=1)
 
 
-def paste(p, fy, fx):
-  """extract_patch(p, F_y^T, F_x^T) of a one-channel patch (full_model.py:810-811): F_y P F_x^T."""
-  return torch.bmm(torch.bmm(fy, p), fx.transpose(1, 2))
+class AttnExtract(torch.autograd.Function):
+  """x_patch = attn_gamma * F_y^T X F_x (modellib.extract_patch, full_model.py:778-789) on the banded HIP kernels: the
+  forward is the decode loop's extract (weights evaluated on the fly from the window parameters), the backward turns
+  d x_patch straight into d (ctr, size, lg_var, attn_gamma) — no [L,F] filter banks, no GEMMs.  X is not differentiated
+  (the canvas gradient is stopped, full_model.py:843-848, and the image is data)."""
+
+  @staticmethod
+  def forward(ctx, x, ctr, size, lg_var, gamma, Fh, Fw):
+    ctx.set_materialize_grads(False)
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    rec = attn_record(ctr, size, lg_var, attn_gamma=gamma)
+    patch = torch.empty((B, Fh, Fw, C), dtype=torch.float32, device=x.device)
+    ops.extract_direct(x, 0, rec, Fh, Fw, C, True, patch)
+    ctx.save_for_backward(x, rec)
+    ctx.dims = (H, W, int(Fh), int(Fw))
+    return patch
+
+  @staticmethod
+  def backward(ctx, g):
+    if g is None:
+      return (None,) * 7
+    x, rec = ctx.saved_tensors
+    H, W, Fh, Fw = ctx.dims
+    out = ops.resample_bwd(ops.RESAMPLE_READ, rec, H, W, Fh, Fw, X=x, Q=g.contiguous(), scale=rec[:, 6])
+    return None, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None
+
+
+class AttnPaste(torch.autograd.Function):
+  """y = sigmoid(gain * F_y P F_x^T - 5) [B,H,W] (full_model.py:810-818 with gain = exp(y_lg_gamma); the attention box
+  :738-741 with P == 1 and gain = box_gamma when `patch` is None) and its adjoint: d patch, d (ctr, size, lg_var) and the
+  gamma gradient from one banded launch."""
+
+  @staticmethod
+  def forward(ctx, patch, ctr, size, lg_var, gamma, H, W, Fh, Fw):
+    ctx.set_materialize_grads(False)
+    B, dev = ctr.shape[0], ctr.device
+    box = patch is None
+    rec = attn_record(ctr, size, lg_var, box_gamma=gamma) if box else attn_record(ctr, size, lg_var, y_lg_gamma=gamma)
+    y = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    if box:
+      ops.attn_box_direct(rec, H, W, Fh, Fw, -5.0, y, H * W)
+      ctx.save_for_backward(rec, y)
+    else:
+      patch = patch.reshape(B, Fh, Fw, 1).contiguous()
+      ops.paste_direct(patch, 0, rec, -5.0, False, y, H * W, H, W)
+      ctx.save_for_backward(rec, y, patch)
+    ctx.dims, ctx.box = (int(H), int(W), int(Fh), int(Fw)), box
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    if g is None:
+      return (None,) * 9
+    H, W, Fh, Fw = ctx.dims
+    if ctx.box:
+      rec, y = ctx.saved_tensors
+      out = ops.resample_bwd(ops.RESAMPLE_BOX, rec, H, W, Fh, Fw, dY=g.contiguous(), Y=y, div=rec[:, 7])
+      dp = None
+    else:
+      rec, y, patch = ctx.saved_tensors
+      dp = torch.empty_like(patch)
+      out = ops.resample_bwd(ops.RESAMPLE_WRITE, rec, H, W, Fh, Fw, dY=g.contiguous(), Y=y, Q=patch, E=dp)
+    return dp, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None
 
 
 def _flat_bn_statistics(trainer):
@@ -1020,10 +1088,8 @@ class TrainStep(object):
       h, co = self._controller(feat.reshape(B, d['G'], -1))
       # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
       cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
-      attn_gamma, y_lg_gamma, box_gamma = ag.reshape(B, 1, 1, 1), ylg.reshape(B, 1, 1), bgm.reshape(B, 1, 1)
-      fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
-      # attention box: extract_patch(ones * gamma, F_y^T, F_x^T) = gamma * rowsum(F_y) (x) rowsum(F_x)
-      box = torch.sigmoid(box_gamma * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
+      # attention box: sigmoid(box_gamma * extract_patch(ones, F_y^T, F_x^T) - 5) (full_model.py:738-741)
+      box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
       if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
         if fixed:
           gmatch = None
@@ -1042,8 +1108,7 @@ class TrainStep(object):
           gsel_box = gmatch
         # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)
         ctr, size = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt])
-        fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
-      x_patch = attn_gamma * extract(inp.detach(), fy, fx)
+      x_patch = AttnExtract.apply(inp.detach(), ctr, size, lg_var, ag, Fh, Fw)
       h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
       core = h_acnn[-1]
       skips = None
@@ -1053,7 +1118,7 @@ class TrainStep(object):
         skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None
                           for i in range(1, d['adcnn_nlayers'])]
       y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
-      y = torch.sigmoid(torch.exp(y_lg_gamma) * paste(y_patch.reshape(B, Fh, Fw) if y_patch.shape[-1] == 1 else y_patch[..., 0], fy, fx) - 5.0)  # [B,H,W]
+      y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)  # [B,H,W]
       if d['disable_overwrite']:
         y = (1.0 - canvas[..., 0]) * y
       s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
@@ -1296,8 +1361,7 @@ class BoxTrainStep(TrainStep):
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, None, stats)[-1]
       h, co = self._controller(feat.reshape(B, d['G'], -1))
       cn, ls, ctr, size, lg_var, _, bgm, _ = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
-      fy, fx = gaussian_filters(ctr, size, lg_var, H, W, Fh, Fw)
-      box = torch.sigmoid(bgm.reshape(B, 1, 1) * fy.sum(dim=2)[:, :, None] * fx.sum(dim=2)[:, None, :] - 5.0)
+      box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
       if fixed:
         gsel = y_gt[:, tt]
       else:

@@ -659,3 +659,53 @@ def test_two_trainers_do_not_share_step_caches(cuda):
     inter[0].append(float(ma.run(['loss', 'train_step'], feed)[0]))
     inter[1].append(float(mb.run(['loss', 'train_step'], feed)[0]))
   assert inter == alone and ma.trainer._pack is not mb.trainer._pack
+
+
+@pytest.mark.parametrize('H,W,C,wide', [(64, 96, 4, False), (128, 128, 8, True), (40, 56, 4, False)])
+def test_banded_resample_adjoints_vs_dense_autograd(cuda, H, W, C, wide):
+  """AttnExtract / AttnPaste (box, read, write on the banded kernels, backward straight to the window parameters:
+  csrc/ra_attn_train.hip) against the reference's formulation — dense [L,F] Gaussian banks, F_y^T X F_x /
+  F_y P F_x^T as matrix products — under torch autograd in float64."""
+  import math
+  g = torch.Generator().manual_seed(H + C)
+  B, Fh, Fw = 3, 16, 12
+  r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+  ctr = torch.stack([r(B) * H * 0.6 + 0.2 * H, r(B) * W * 0.6 + 0.2 * W], dim=1)
+  ctr[0, 0] = 0.03 * H  # a window partly outside the image
+  size = torch.stack([r(B) * H * 0.5 + 8, r(B) * W * 0.5 + 8], dim=1)
+  lgv = (torch.randn(B, 2, generator=g, dtype=torch.float64) * 0.4 + (1.5 if wide else 0.3))
+  gam = r(B) + 0.5
+  x = r(B, H, W, C)
+  P = torch.randn(B, Fh, Fw, generator=g, dtype=torch.float64)
+  wE, wB, wY = torch.randn(B, Fh, Fw, C, generator=g, dtype=torch.float64), torch.randn(B, H, W, generator=g, dtype=torch.float64), \
+      torch.randn(B, H, W, generator=g, dtype=torch.float64)
+
+  def banks(ctr, size, lgv):
+    out = []
+    for ax, (L, F) in enumerate(((H, Fh), (W, Fw))):
+      j = torch.arange(F, dtype=torch.float64)
+      mu = ctr[:, ax, None] + ((size[:, ax, None] + 1.0) / F) * (j[None, :] - (F - 1) / 2.0)
+      dd = torch.arange(L, dtype=torch.float64)[None, :, None] - mu[:, None, :]
+      var = torch.exp(lgv[:, ax])[:, None, None]
+      out.append(torch.exp(-0.5 * dd * dd / var) / (torch.sqrt(var) * math.sqrt(2 * math.pi)))
+    return out
+
+  leaves = [t.clone().requires_grad_(True) for t in (ctr, size, lgv, gam, P)]
+  c64, s64, v64, g64, P64 = leaves
+  fy, fx = banks(c64, s64, v64)
+  e_ref = g64[:, None, None, None] * torch.einsum('blj,blwc,bwi->bjic', fy, x, fx)
+  b_ref = torch.sigmoid(g64[:, None, None] * torch.einsum('blj,bwi->blw', fy, fx) - 5.0)
+  y_ref = torch.sigmoid(torch.exp(g64 - 1.0)[:, None, None] * torch.einsum('blj,bji,bwi->blw', fy, P64, fx) - 5.0)
+  ((e_ref * wE).sum() + (b_ref * wB).sum() + (y_ref * wY).sum()).backward()
+
+  l32 = [t.detach().float().to(cuda).requires_grad_(True) for t in (ctr, size, lgv, gam, P)]
+  c32, s32, v32, g32, P32 = l32
+  e = ra_train.AttnExtract.apply(x.float().to(cuda), c32, s32, v32, g32, Fh, Fw)
+  bx = ra_train.AttnPaste.apply(None, c32, s32, v32, g32, H, W, Fh, Fw)
+  y = ra_train.AttnPaste.apply(P32[..., None], c32, s32, v32, g32 - 1.0, H, W, Fh, Fw)
+  ((e * wE.float().to(cuda)).sum() + (bx * wB.float().to(cuda)).sum() + (y * wY.float().to(cuda)).sum()).backward()
+  for got, ref in ((e, e_ref), (bx, b_ref), (y, y_ref)):
+    assert np.abs(got.detach().cpu().numpy() - ref.detach().numpy()).max() < 3e-5 * max(1.0, float(ref.abs().max()))
+  for name, a, b in zip(('ctr', 'size', 'lg_var', 'gamma', 'patch'), l32, leaves):
+    ga, gb = a.grad.cpu().numpy(), b.grad.numpy()
+    assert np.abs(ga - gb).max() < 1e-4 * max(1.0, np.abs(gb).max()), (name, np.abs(ga - gb).max(), np.abs(gb).max())
