@@ -338,6 +338,23 @@ int ra_paste_score_direct_f32(const float *patch, int Cp, int pc, const float *a
 #define RA_RESAMPLE_READ 0
 #define RA_RESAMPLE_WRITE 1
 #define RA_RESAMPLE_BOX 2
+/* The controller of the training graph (full_model.py:668-689) as one forward and one backward launch per timestep
+ * (ra_train.ControllerFn): feat [B,G,Cf]; Wg [Cf+hid, 4 hid] = the LSTM's [w_x ; w_h] with the gates side by side in the
+ * order i f o u (nnlib.py:641-646), bg [4 hid]; W0 [hid,hid], W1 [hid,G] the two glimpse-MLP layers (ReLU, softmax over
+ * the feature map); Wc [hid,nout] the one-layer controller MLP.  The forward writes h_last [B,hid], co [B,nout] and
+ * `save` (B * ra_ctrl_train_save_floats floats: per iteration xh | gates | c | z1 | map).  The backward takes d h_last /
+ * d co (either may be NULL), writes d feat [B,G,Cf] and the pre-activation gradients dpre [B,iters,4 hid], dz1
+ * [B,iters,hid], dlog [B,iters,G]; the parameter gradients are the caller's GEMMs of the saved layer inputs against
+ * them (one per weight per optimisation step).  ra_ctrl_train_supported: LDS / thread-count limits of the kernels. */
+int ra_ctrl_train_supported(int G, int Cf, int hid, int iters, int nout);
+size_t ra_ctrl_train_save_floats(int G, int Cf, int hid, int iters);
+int ra_ctrl_train_fwd_f32(int B, int G, int Cf, int hid, int iters, int nout, const float *feat, const float *Wg,
+                          const float *bg, const float *W0, const float *b0, const float *W1, const float *b1,
+                          const float *Wc, const float *bc, float *h_last, float *co, float *save, void *stream);
+int ra_ctrl_train_bwd_f32(int B, int G, int Cf, int hid, int iters, int nout, const float *feat, const float *Wg,
+                          const float *W0, const float *W1, const float *Wc, const float *save, const float *dh_last,
+                          const float *dco, float *dfeat, float *dpre, float *dz1, float *dlog, void *stream);
+
 size_t ra_resample_bwd_workspace_floats(int B, int Fh, int C);
 int ra_resample_bwd_f32(int mode, const float *X, int Cx, int chan0, int C, const float *dY, const float *Y,
                         const float *attn_rec, const float *Q, int Cq, float *E, int Ce, int B, int H, int W, int Fh,

@@ -80,6 +80,10 @@ SIGNATURES = {
     'ra_extract_direct_f32': (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_paste_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _I, _P, _Z, _I, _P]),
     'ra_attn_box_direct_f32': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    'ra_ctrl_train_supported': (_I, [_I, _I, _I, _I, _I]),
+    'ra_ctrl_train_save_floats': (_Z, [_I, _I, _I, _I]),
+    'ra_ctrl_train_fwd_f32': (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'ra_ctrl_train_bwd_f32': (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ra_resample_bwd_workspace_floats': (_Z, [_I, _I, _I]),
     'ra_resample_bwd_f32': (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _Z, _P, _P]),
     'ra_extract_patch_dense_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),

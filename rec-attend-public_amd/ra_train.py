@@ -621,6 +621,92 @@ def _dense(g):
   return None if g is None else g.contiguous()
 
 
+class _CtrlStepBuffers(object):
+  """Per-trainer buffers of the fused controller (csrc/ra_ctrl_train.hip): what the forward of each timestep saves,
+  the pre-activation gradients the backward writes, and the end-of-backward pass that turns them into the parameter
+  gradients — the layer inputs of ALL images, glimpse iterations and timesteps of the step against their
+  pre-activation gradients: four GEMMs + four bias sums per optimisation step (the library path issued 960)."""
+
+  def __init__(self, trainer, T, B):
+    d, dev = trainer.d, trainer.bucket.param.device
+    self.trainer, self.T, self.B, self.armed = trainer, T, B, False
+    self.G, self.Cf, self.hid, self.iters = d['G'], trainer.model.dims['ccnn_channels'][-1], d['hid'], d['iters']
+    self.SF = rn.lib().ra_ctrl_train_save_floats(self.G, self.Cf, self.hid, self.iters) // self.iters
+    f = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+    self.save = f(T, B, self.iters, self.SF)
+    self.dpre, self.dz1, self.dlog = f(T, B, self.iters, 4 * self.hid), f(T, B, self.iters, self.hid), f(T, B, self.iters, self.G)
+    self.hfin, self.dco = f(T, B, self.hid), f(T, B, 9)
+    self.gW = f(self.Cf + self.hid, 4 * self.hid)
+
+  def begin_step(self):
+    for t in (self.dpre, self.dz1, self.dlog, self.dco):  # a timestep whose backward does not run must not leave last step's rows
+      t.zero_()
+
+  def __call__(self):  # end of the backward pass: the parameter gradients, into the bucket
+    self.armed = False
+    g, hid, Cf, it = self.trainer.bucket.grad_of, self.hid, self.Cf, self.iters
+    n = self.T * self.B * it
+    rows = self.save.view(n, self.SF)
+    ones = _const('ones', n, rows.device, lambda: torch.ones(n, dtype=torch.float32, device=rows.device))
+    D = self.dpre.view(n, 4 * hid)
+    torch.mm(rows[:, :Cf + hid].t(), D, out=self.gW)
+    nx = Cf
+    for j, k in enumerate('ifou'):
+      cols = slice(j * hid, (j + 1) * hid)
+      g['ctrl_lstm_w_x' + k].add_(self.gW[:nx, cols])
+      g['ctrl_lstm_w_h' + k].add_(self.gW[nx:, cols])
+      g['ctrl_lstm_b_' + k].addmv_(D[:, cols].t(), ones)
+    # glimpse MLP layer 0 reads h after the LSTM of (b, it) = the h half of iteration it + 1's LSTM input
+    sv4 = self.save.view(self.T, self.B, it, self.SF)
+    H0 = sv4[:, :, 1:, Cf:Cf + hid].reshape(-1, hid)
+    DZ = self.dz1[:, :, :-1].reshape(-1, hid)
+    g['glimpse_mlp_w_0'].addmm_(H0.t(), DZ)
+    g['glimpse_mlp_b_0'].addmv_(DZ.t(), ones[:DZ.shape[0]])
+    z1 = rows[:, Cf + hid + 5 * hid:Cf + hid + 6 * hid]
+    DL = self.dlog.view(n, self.G)
+    g['glimpse_mlp_w_1'].addmm_(z1.t(), DL)
+    g['glimpse_mlp_b_1'].addmv_(DL.t(), ones)
+    HF, DC = self.hfin.view(-1, hid), self.dco.view(-1, 9)
+    g['ctrl_mlp_w_0'].addmm_(HF.t(), DC)
+    g['ctrl_mlp_b_0'].addmv_(DC.t(), ones[:DC.shape[0]])
+
+
+class ControllerFn(torch.autograd.Function):
+  """full_model.py:668-689 for one timestep: feat [B,G,Cf] -> (h_last [B,hid], ctrl_out [B,9]) in ONE launch, its
+  adjoint (BPTT over the glimpse iterations) in one more.  The weights are passed as plain tensors: their gradients are
+  formed once per step by the trainer's _CtrlStepBuffers from the rows this function saves."""
+
+  @staticmethod
+  def forward(ctx, feat, Wg, bg, W0, b0, W1, b1, Wc, bc, bufs, tt):
+    ctx.set_materialize_grads(False)
+    feat = feat.contiguous()
+    B, G, Cf = feat.shape
+    hid, iters = bufs.hid, bufs.iters
+    h, co = bufs.hfin[tt], torch.empty((B, 9), dtype=torch.float32, device=feat.device)
+    check(rn.lib().ra_ctrl_train_fwd_f32(B, G, Cf, hid, iters, 9, ptr(feat), ptr(Wg), ptr(bg), ptr(W0), ptr(b0), ptr(W1), ptr(b1),
+                                         ptr(Wc), ptr(bc), ptr(h), ptr(co), ptr(bufs.save[tt]), rn.stream_ptr()), 'ra_ctrl_train_fwd_f32')
+    ctx.save_for_backward(feat, Wg, W0, W1, Wc)
+    ctx.bufs, ctx.tt = bufs, tt
+    return h, co  # h is the trainer's row buffer hfin[tt] (the GEMM input of the controller MLP's gradient): nothing writes it again this step
+
+  @staticmethod
+  def backward(ctx, dh, dco):
+    feat, Wg, W0, W1, Wc = ctx.saved_tensors
+    bufs, tt = ctx.bufs, ctx.tt
+    if not bufs.armed:
+      bufs.armed = True
+      torch.autograd.Variable._execution_engine.queue_callback(bufs)
+    B, G, Cf = feat.shape
+    dfeat = torch.empty_like(feat)
+    if dco is not None:
+      bufs.dco[tt].copy_(dco)
+    check(rn.lib().ra_ctrl_train_bwd_f32(B, G, Cf, bufs.hid, bufs.iters, 9, ptr(feat), ptr(Wg), ptr(W0), ptr(W1), ptr(Wc),
+                                         ptr(bufs.save[tt]), ptr(_dense(dh)), ptr(bufs.dco[tt]) if dco is not None else None,
+                                         ptr(dfeat), ptr(bufs.dpre[tt]), ptr(bufs.dz1[tt]), ptr(bufs.dlog[tt]), rn.stream_ptr()),
+          'ra_ctrl_train_bwd_f32')
+    return (dfeat,) + (None,) * 10
+
+
 class AttnHead(torch.autograd.Function):
   """Controller output [B,>=9] -> (cn, ls, ctr, size, lg_var [B,2], attn_gamma, box_gamma, y_lg_gamma [B]) of
   full_model.py:702-722 / modellib.py:752-764,812-825: one launch forward, one backward (ra_attn_head_f32)."""
@@ -955,11 +1041,33 @@ class TrainStep(object):
       return LinearAcc.apply(x, P[wname], P[bname], g[wname], g[bname])
     return torch.addmm(P[bname], x, P[wname])
 
-  def _controller(self, feat):
+  fuse_controller = True  # the controller of a timestep as one forward and one backward launch
+
+  def _ctrl_buffers(self, B, Cf):
+    """The fused controller's step buffers, or None where the library path has to run: depths other than the run
+    scripts' (2 glimpse-MLP layers, 1 controller-MLP layer), shapes beyond the kernel's LDS, no gradient bucket views."""
+    d, g = self.d, self.bucket.grad_of
+    names = ['glimpse_mlp_w_0', 'glimpse_mlp_b_0', 'glimpse_mlp_w_1', 'glimpse_mlp_b_1', 'ctrl_mlp_w_0', 'ctrl_mlp_b_0'] + \
+        ['ctrl_lstm_%s%s' % (p, k) for p in ('w_x', 'w_h', 'b_') for k in 'ifou']
+    if not (self.fuse_controller and self.fuse_param_grads and d['n_gmlp'] == 2 and d['n_cmlp'] == 1 and all(n in g for n in names) and
+            rn.lib().ra_ctrl_train_supported(d['G'], Cf, d['hid'], d['iters'], 9)):
+      return None
+    cb = getattr(self, '_ctl', None)
+    if cb is None or cb.B != B or cb.T != d['T']:
+      cb = self._ctl = _CtrlStepBuffers(self, d['T'], B)
+    return cb
+
+  def _controller(self, feat, tt=None):
     """full_model.py:668-689 on [B,G,Cf] features: glimpse read-out, LSTM (state = [c|h], zeroed per
     timestep), glimpse MLP (softmax over G), controller MLP."""
     P, d = self.leaves, self.d
     B, G, hid = feat.shape[0], d['G'], d['hid']
+    bufs = self._ctrl_buffers(B, feat.shape[2]) if tt is not None else None
+    if bufs is not None:  # one launch forward, one backward (csrc/ra_ctrl_train.hip)
+      Wg, bg = self._lstm_weights()
+      return ControllerFn.apply(feat, Wg.detach(), bg.detach(), P['glimpse_mlp_w_0'].detach(), P['glimpse_mlp_b_0'].detach(),
+                                P['glimpse_mlp_w_1'].detach(), P['glimpse_mlp_b_1'].detach(), P['ctrl_mlp_w_0'].detach(),
+                                P['ctrl_mlp_b_0'].detach(), bufs, tt)
     dev = feat.device  # constants of the recurrence's start: built once, never written
     c = h = _const('zeros', (B, hid), dev, lambda: torch.zeros((B, hid), device=dev))
     gmap = _const('gmap0', (B, G), dev, lambda: torch.full((B, 1, G), 1.0 / G, device=dev))
@@ -1058,6 +1166,8 @@ class TrainStep(object):
     Cityscapes architectures (full_model.py:165-194)."""
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    if getattr(self, '_ctl', None) is not None:
+      self._ctl.begin_step()
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
@@ -1085,7 +1195,7 @@ class TrainStep(object):
       if inp.shape[3] != d['C0p']:
         inp = _pad_channels(inp)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
-      h, co = self._controller(feat.reshape(B, d['G'], -1))
+      h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
       # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
       cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
       # attention box: sigmoid(box_gamma * extract_patch(ones, F_y^T, F_x^T) - 5) (full_model.py:738-741)
@@ -1343,6 +1453,8 @@ class BoxTrainStep(TrainStep):
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    if getattr(self, '_ctl', None) is not None:
+      self._ctl.begin_step()
     dev = self.bucket.param.device
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
@@ -1359,7 +1471,7 @@ class BoxTrainStep(TrainStep):
     for tt in range(T):
       inp = torch.cat([x, canvas], dim=3)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, None, stats)[-1]
-      h, co = self._controller(feat.reshape(B, d['G'], -1))
+      h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
       cn, ls, ctr, size, lg_var, _, bgm, _ = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
       box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
       if fixed:

@@ -709,3 +709,80 @@ def test_banded_resample_adjoints_vs_dense_autograd(cuda, H, W, C, wide):
   for name, a, b in zip(('ctr', 'size', 'lg_var', 'gamma', 'patch'), l32, leaves):
     ga, gb = a.grad.cpu().numpy(), b.grad.numpy()
     assert np.abs(ga - gb).max() < 1e-4 * max(1.0, np.abs(gb).max()), (name, np.abs(ga - gb).max(), np.abs(gb).max())
+
+
+@pytest.mark.parametrize('knob', [False, True], ids=['plain', 'knob'])
+def test_fused_controller_equals_library_path(cuda, knob):
+  """ControllerFn (one forward + one backward launch per timestep, parameter gradients as four GEMMs per step over the
+  saved rows; csrc/ra_ctrl_train.hip) against the same graph on library GEMMs / element-wise ops under autograd: loss
+  and every gradient.  (The library path itself is checked against the float64 oracle above.)"""
+  import full_model
+  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, **(KNOB_OPT if knob else {}))
+  rng = np.random.RandomState(5)
+  B, T, H, W = 2, 3, 64, 64
+  kd = None
+  if knob:
+    kd = {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in
+          {'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)), 'u_box': rng.rand(B, T, 1),
+           'u_segm': rng.rand(B, T, 1), 'segm_noise': 0.3 * rng.rand(T, B, H, W)}.items()}
+  res = {}
+  for fused in (False, True):
+    m = full_model.get_model(opt).load_weights(P)
+    ts = ra_train.TrainStep(m)
+    ts.fuse_controller = fused
+    for rep in range(2):  # twice: the step buffers are reused, nothing of the first pass may leak into the second
+      ts.bucket.zero_grad()
+      loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd)
+      loss.backward()
+      ra_train.wgrad_join()
+    assert (getattr(ts, '_ctl', None) is not None) == fused
+    res[fused] = (float(loss), {k: ts.bucket.grad_of[k].cpu().numpy().copy() for k in ts.bucket.names})
+  assert abs(res[True][0] - res[False][0]) < 2e-4 * max(1.0, abs(res[False][0]))  # float32 through 3 recurrent timesteps, different summation orders
+  scale = max(np.abs(g).max() for g in res[False][1].values())
+  dots = np.zeros(3)
+  for k, g in res[False][1].items():  # both sides are float32 graphs through ~40 BN / ReLU / pool layers per timestep
+    got = res[True][1][k]
+    err = np.abs(got - g).max()
+    assert err < 0.1 * max(np.abs(g).max(), 1e-2 * scale), (k, err, np.abs(g).max())  # ReLU / pool kinks downstream of a 1e-6 different window flip
+    dots += [float((got * g).sum()), float((got * got).sum()), float((g * g).sum())]
+  cos = dots[0] / np.sqrt(dots[1] * dots[2])
+  assert cos > 0.99999, cos
+  for k in ('ctrl_lstm_w_xi', 'ctrl_lstm_w_hu', 'ctrl_lstm_b_f', 'glimpse_mlp_w_0', 'glimpse_mlp_b_1', 'glimpse_mlp_w_1', 'ctrl_mlp_w_0',
+            'ctrl_mlp_b_0', 'ctrl_cnn_w_7'):  # the controller's own parameters and what feeds it: tight
+    g, got = res[False][1][k], res[True][1][k]
+    assert np.abs(got - g).max() < 1e-3 * max(np.abs(g).max(), 1e-4 * scale), (k, np.abs(got - g).max(), np.abs(g).max())
+
+
+def test_controller_fn_unit_vs_library(cuda):
+  """ControllerFn alone: one timestep's controller on a random feature map, forward outputs and — for random upstream
+  gradients of h and ctrl_out — d feat and every controller parameter's gradient, against the library-GEMM path."""
+  import full_model
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=1.0)
+  rng = np.random.RandomState(2)
+  for k in P:  # livelier controller weights than the 0.01 init: the softmax must not stay uniform
+    if k.startswith(('ctrl_lstm_w', 'glimpse_mlp_w', 'ctrl_mlp_w')):
+      P[k] = (rng.randn(*P[k].shape) * 0.15).astype(np.float32)
+    if k.startswith(('ctrl_lstm_b', 'glimpse_mlp_b', 'ctrl_mlp_b')):
+      P[k] = (rng.randn(*P[k].shape) * 0.1).astype(np.float32)
+  B = 3
+  res = {}
+  for fused in (False, True):
+    m = full_model.get_model(opt).load_weights(P)
+    ts = ra_train.TrainStep(m)
+    ts.fuse_controller = fused
+    d = ts.d
+    feat = torch.tensor(np.random.RandomState(4).rand(B, d['G'], 64).astype(np.float32), device=cuda, requires_grad=True)
+    wh = torch.tensor(np.random.RandomState(5).randn(B, d['hid']).astype(np.float32), device=cuda)
+    wc = torch.tensor(np.random.RandomState(6).randn(B, 9).astype(np.float32), device=cuda)
+    ts.bucket.zero_grad()
+    ts._pack.clear()
+    h, co = ts._controller(feat, 1)
+    ((h * wh).sum() + (co * wc).sum()).backward()
+    names = [k for k in ts.bucket.names if k.startswith(('ctrl_lstm', 'glimpse_mlp', 'ctrl_mlp'))]
+    res[fused] = (h.detach().cpu().numpy(), co.detach().cpu().numpy(), feat.grad.cpu().numpy(),
+                  {k: ts.bucket.grad_of[k].cpu().numpy().copy() for k in names})
+  (h0, c0, f0, g0), (h1, c1, f1, g1) = res[False], res[True]
+  assert np.abs(h1 - h0).max() < 2e-6 and np.abs(c1 - c0).max() < 2e-6 * max(1.0, np.abs(c0).max())
+  assert np.abs(f1 - f0).max() < 1e-5 * max(1.0, np.abs(f0).max()), np.abs(f1 - f0).max()
+  for k in g0:
+    assert np.abs(g1[k] - g0[k]).max() < 2e-5 * max(1.0, np.abs(g0[k]).max()), (k, np.abs(g1[k] - g0[k]).max(), np.abs(g0[k]).max())
