@@ -277,6 +277,42 @@ def test_cfg2_full_size_vs_oracle(cuda):
   print('cfg2 full size: max |dy| = %.2e' % np.abs(out['y_out'] - ref['y_out']).max())
 
 
+def test_cfg2_pipelined_operating_point_vs_oracle(cuda):
+  """The operating point bench.py times — cfg2 (512x512, T=16) at B = 8 through the DecodePipeline with 8 batches
+  submitted on 4 streams (group-shared controller K2b in groups of 4, the pair kernels at their pipeline occupancy,
+  the y_out prefill riding on the first controller-CNN launch) — against the float64 oracle on two images of one of
+  the batches, and bit-identical results for every batch that carries the same images."""
+  import full_model
+  opt = ora.make_opt('cvppp', 512, 512, 16)
+  P = dict(ora.random_params(opt, 101))
+  b = P['ctrl_mlp_b_0'].copy()
+  b[0:2], b[2:4] = [0.1, -0.2], np.log(0.3)
+  P['ctrl_mlp_b_0'] = b
+  for t in range(16):
+    P['attn_dcnn_6_%d_beta' % t] = P['attn_dcnn_6_%d_beta' % t] + 12.0
+  x2, _, _ = _inputs(opt, 2, 102)
+  ref = ora.full_model_forward(opt, P, x2, None, None)
+  rng = np.random.RandomState(7)
+  x8 = rng.rand(8, 512, 512, 3).astype(np.float32)
+  x8[2], x8[5] = x2[0], x2[1]  # the oracle's two images sit at positions 2 and 5 of every batch
+  m = full_model.get_model(opt).load_weights(P)
+  pipe = m.pipeline(8)
+  assert pipe.streams == 4
+  feed = {'x': torch.as_tensor(x8).cuda(), 'phase_train': False}
+  for _ in range(8):
+    pipe.submit(['y_out', 's_out'], feed)
+  outs = []
+  while len(pipe):
+    outs.append(pipe.collect(as_numpy=True))
+  assert pipe.slots[0][0].subs[0].get('ctrl_batch')  # the slots run the group-shared controller
+  y0, s0 = outs[0]
+  for y, s in outs[1:]:
+    assert (y == y0).all() and (s == s0).all()
+  for k, pos in enumerate((2, 5)):
+    assert np.abs(y0[pos] - ref['y_out'][k]).max() < MASK_TOL and np.abs(s0[pos] - ref['s_out'][k]).max() < MASK_TOL
+  assert ref['y_out'].max() > 0.9
+
+
 def test_cfg5_cityscapes_t32(cuda):
   """The cfg5 T=32 variant on the Cityscapes arch (9 semantic classes, skips, dynamic_var)."""
   _check(ora.make_opt('cityscapes', 64, 128, 32), 1, 111, use_graph=True)

@@ -786,3 +786,44 @@ def test_controller_fn_unit_vs_library(cuda):
   assert np.abs(f1 - f0).max() < 1e-5 * max(1.0, np.abs(f0).max()), np.abs(f1 - f0).max()
   for k in g0:
     assert np.abs(g1[k] - g0[k]).max() < 2e-5 * max(1.0, np.abs(g0[k]).max()), (k, np.abs(g1[k] - g0[k]).max(), np.abs(g0[k]).max())
+
+
+def test_cfg4_shapes_training_step_properties(cuda):
+  """BASELINE.json configs[3] at its per-GPU shapes — CVPPP arch, 512x512, T = 16, B = 8, use_knob, the random crop —
+  too large for the float64 oracle, so properties: three optimisation steps (eager, captured, replayed) give finite
+  losses, every parameter moves by at most the learning rate per step, the BN shadows move towards the batch
+  statistics, the fused controller and the banded resample ran, and a captured replay equals the eager step it copies."""
+  import full_model
+  import full_model_train as fmt
+  opt = ora.make_opt('cvppp', 512, 512, 16, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000, **KNOB_OPT)
+  res = {}
+  for graphed in (True, False):
+    torch.manual_seed(3)
+    m = full_model.get_model(opt)
+    w0 = m.state_dict_numpy()
+    rng = np.random.RandomState(11)
+    x, y_gt, s_gt = fmt.synthetic_batch(rng, 8, 512, 512, 16)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'generator': gen, 'aug': dict(off_y=3, off_x=29)}
+    losses = []
+    for k in range(3):
+      if getattr(m, 'trainer', None) is not None:
+        m.trainer.use_graph = graphed
+      else:
+        ra_train.TrainStep.use_graph = graphed
+      losses.append(float(m.run(['loss', 'train_step'], feed)[0]))
+    ra_train.TrainStep.use_graph = True
+    w3 = m.state_dict_numpy()
+    res[graphed] = (losses, w3)
+    assert all(np.isfinite(losses)), losses
+    assert m.trainer._ctl is not None and m.trainer.bucket.global_step == 3
+    moved = 0
+    for k, v in w3.items():
+      assert np.isfinite(v).all(), k
+      if k.endswith('_ema_mean') or k.endswith('_ema_var'):
+        continue
+      assert np.abs(v - w0[k]).max() <= 3.2e-3, k  # three Adam steps of at most lr each (clip +-1, lr 1e-3)
+      moved += int(np.abs(v - w0[k]).max() > 0)
+    assert moved > 200
+    assert np.abs(w3['ctrl_cnn_3_0_ema_var']).max() > 0 and np.abs(w3['attn_dcnn_2_5_ema_mean']).max() > 0
+  assert np.allclose(res[True][0], res[False][0], rtol=2e-4, atol=1e-5), (res[True][0], res[False][0])
