@@ -360,8 +360,6 @@ def main():
                        'eagerly and exit (run under rocprofv3 --pmc; see tools/pmc_traffic.py)')
   ap.add_argument('--pmc-which', default='enc', choices=['enc', 'attn', 'tail'],
                   help='which launch group --pmc-group repeats: the encoder, extract+paste, or the whole tail')
-  ap.add_argument('--fuse-patchnet', action='store_true',
-                  help='tuning aid: the patch net through the phase kernel K4 (RA_PNET_MODE=1: one launch)')
   ap.add_argument('--no-cache-first', action='store_true', help='tuning aid: recompute the whole first layer per timestep')
   ap.add_argument('--no-prefill-ride', action='store_true', help='tuning aid: the per-forward y_out prefill as its own launch instead of riding on the first controller-CNN launch')
   ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
@@ -398,7 +396,6 @@ def main():
   eng.fuse_patch_pairs = args.fuse_patch_pairs
   eng.wino_unfuse = args.wino_unfuse
   eng.pair_wino = not args.no_pair_wino
-  eng.fuse_patchnet = args.fuse_patchnet
   eng.cache_first = not args.no_cache_first
   eng.prefill_ride = not args.no_prefill_ride
   g = torch.Generator().manual_seed(1234 + rank)
@@ -420,7 +417,7 @@ def main():
     for _ in range(args.pmc_group):
       if args.pmc_which == 'enc':
         eng._run_cnn(eng.plan['ccnn'], eng.W['ccnn'], sb['img'], sb['ccnn'], 1, 'ctrl_cnn',
-                     plane=sb.get('canvas'), cache=sb.get('l0cache'))
+                     plane=sb['canvas'], cache=sb.get('l0cache'))
       elif args.pmc_which == 'attn':
         ops.extract_direct(sb['img'], 0, sb['attn'][0], d['Fh'], d['Fw'], d['C0p'], True, sb['x_patch'][0],
                            canvas=sb['canvas'], canvas_chan=d['D'])
@@ -523,7 +520,7 @@ def main():
     def enc_step(step, tt_=1):  # tt_ = 1: the steady-state (cached) form; 0: the first timestep, which fills the cache
       first = step[1]           # ... and carries the once-per-forward prefill of y_out as a rider (ra_engine._launch_pack)
       src = sb['img'] if first == 0 else sb['ccnn'][first - 1]
-      eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], tt_, 'ctrl_cnn', plane=sb.get('canvas'),
+      eng._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], tt_, 'ctrl_cnn', plane=sb['canvas'],
                    cache=sb.get('l0cache'), fill=sb['y_out'] if (tt_ == 0 and first == 0 and rides) else None)
 
     tot_f, per_f = encoder_flops_per_image(d)
@@ -544,7 +541,7 @@ def main():
       enc_us += cache_us / T
     # compulsory HBM bytes of the group as launched: every launch reads its source once and
     # writes its (pooled) output once; the first also reads the canvas plane
-    enc_bytes = 4.0 * sb['canvas'].numel() if 'canvas' in sb else 0.0
+    enc_bytes = 4.0 * sb['canvas'].numel()
     for st_ in eng.plan['ccnn']:
       src_ = sb['img'] if st_[1] == 0 else sb['ccnn'][st_[1] - 1]
       enc_bytes += 4.0 * (src_.numel() + sb['ccnn'][st_[-1]].numel())
@@ -626,7 +623,6 @@ def main():
     # the whole post-encoder tail of one timestep exactly as the forward issues it
     tail_us = graph_time_us(lambda: eng._launch_tail(sb, 1, False, sb['ccnn'][-1]))
     out['tail_us'] = tail_us
-    out['tail_launches'] = 3 if 'pnet_ws' in sb else None
     if 'ctrl_ws' in sb:
       out['controller_us'] = graph_time_us(lambda: ops.controller_split(
           eng.desc, sb['ccnn'][-1], Wt['ctrl_split'], sb['h_last'][0], sb['ctrl_out'][0],

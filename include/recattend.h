@@ -260,45 +260,21 @@ int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat, const floa
 int ra_gaussian_filter_f32(const float *center, const float *size, const float *lg_var, int B,
                            int L, int F, float *out, void *stream);
 
-/* Filter banks + band limits for both axes from the attn records.
- *   fy [B,H,Fh], fx [B,W,Fw]  (same values as ra_gaussian_filter_f32)
- *   band [B][2*(Fh+Fw) + 2*(H+W)] ints: for every filter tap j its pixel range [lo,hi)
- *   outside of which the weight is < exp(-30) of its peak, then for every pixel l the tap
- *   range [jlo,jhi) covering it (y axis first, then x). */
-size_t ra_attn_band_ints(int H, int W, int Fh, int Fw);
-int ra_attn_filters_f32(const float *attn, int B, int H, int W, int Fh, int Fw, float *fy,
-                        float *fx, int *band, void *stream);
-
-/* patch[b,j,i,c] = attn_gamma_b * sum_{l,w} fy[b,l,j] * img[b,l,w,chan0+c] * fx[b,w,i]
- * img [B,H,W,Ci] (Ci % 4 == 0), patch [B,Fh,Fw,Cp] (Cp % 4 == 0, Cp <= Ci - chan0;
- * chan0 % 4 == 0).  use_gamma = 0 skips the attn_gamma factor. */
-int ra_extract_patch_f32(const float *img, int Ci, int chan0, const float *attn, const float *fy,
-                         const float *fx, const int *band, int B, int H, int W, int Fh, int Fw,
-                         int Cp, int use_gamma, float *patch, void *stream);
-
-/* Paste + canvas update (full_model.py:810-818,843-845):
- *   y = sigmoid(exp(y_out_lg_gamma) * (fy P fx^T) + beta);  if disable_overwrite:
- *   y *= (1 - canvas);  y_out[b, :, :] = y;  canvas = max(canvas, y).
- * P = patch[b,:,:,pc] with channel stride Cp.  canvas is channel `canvas_chan` of
- * img [B,H,W,Ci] (updated in place; pass canvas_chan < 0 for no canvas).  y_out points
- * at the [H,W] plane of example 0 and y_stride_b floats separate examples (so a
- * [B,T,H,W] tensor is written in place, full_model.py:855).  u_ws: workspace of
- * B*Fh*W floats. */
-int ra_paste_canvas_f32(const float *patch, int Cp, int pc, const float *attn, const float *fy,
-                        const float *fx, const int *band, int B, int H, int W, int Fh, int Fw,
-                        float beta, int disable_overwrite, float *img, int Ci, int canvas_chan,
-                        float *y_out, size_t y_stride_b, float *u_ws, void *stream);
-
-/* Attention box (full_model.py:738-741, box_model.py:479-482):
- *   box = sigmoid(box_gamma * (fy 1 fx^T) + beta) written like y_out above. */
-int ra_attn_box_f32(const float *attn, const float *fy, const float *fx, const int *band, int B,
-                    int H, int W, int Fh, int Fw, float beta, float *box_out, size_t stride_b,
-                    void *stream);
-
-/* Direct forms of the same three operators: the filter weights are computed on the fly from the
- * attention records (no fy/fx/band tables, no u_ws), so a timestep needs two launches, and the
- * canvas may live in its own plane `canvas` [B,H,W] (then channel canvas_chan of img is ignored /
- * untouched); with canvas == NULL the canvas is channel canvas_chan of img as above. */
+/* The attention resample of the decode loop (K3 extract, K5 paste, the attention box).  The filter weights
+ * (modellib.get_gaussian_filter, modellib.py:581-612) are evaluated on the fly from the attention records: no
+ * [L,F] tables; terms below e^-30 of a tap's peak are dropped.  The canvas may live in its own plane `canvas`
+ * [B,H,W] (then channel canvas_chan of img is ignored / untouched); with canvas == NULL it is channel canvas_chan
+ * of img.
+ *   extract (modellib.extract_patch :615-641, full_model.py:788-789):
+ *     patch[b,j,i,c] = attn_gamma_b * sum_{l,w} fy[b,l,j] * img[b,l,w,chan0+c] * fx[b,w,i]
+ *     img [B,H,W,Ci] (Ci % 4 == 0), patch [B,Fh,Fw,Cp] (Cp % 4 == 0, Cp <= Ci - chan0, chan0 % 4 == 0);
+ *     use_gamma = 0 skips the attn_gamma factor.
+ *   paste (full_model.py:810-818,843-845):
+ *     y = sigmoid(exp(y_out_lg_gamma) * (fy P fx^T) + beta);  if disable_overwrite: y *= (1 - canvas);
+ *     y_out[b] = y;  canvas = max(canvas, y).  P = patch[b,:,:,pc] with channel stride Cp; y_out points at the
+ *     [H,W] plane of example 0 and y_stride_b floats separate examples (a [B,T,H,W] tensor is written in place,
+ *     full_model.py:855).
+ *   box (full_model.py:738-741, box_model.py:479-482): box = sigmoid(box_gamma * (fy 1 fx^T) + beta). */
 int ra_extract_direct_f32(const float *img, int Ci, int chan0, const float *canvas, int canvas_chan,
                           const float *attn, int B, int H, int W, int Fh, int Fw, int Cp,
                           int use_gamma, float *patch, void *stream);
@@ -494,41 +470,6 @@ int ra_random_transform_f32(const float *x, int N, int H, int W, int C, int padd
  * (box_model.py:487-499).  Terms with w == 0 are skipped (0 * x is not evaluated). */
 int ra_weighted_sum_f32(const float *w, const float *y, int B, int T, int HW, float *out,
                         void *stream);
-
-/* ------------------------------------------------------------------------------------
- * K4  the whole patch-sized network of one timestep in ONE launch: attention CNN
- * (nnlib.cnn run_cnn, nnlib.py:214-255) -> attention DCNN (nnlib.dcnn run_dcnn,
- * nnlib.py:339-402, no skip connections) [-> score MLP, full_model.py:794,821-822], i.e.
- * full_model.py:792-807,821-822.  Layers as ra_conv3x3_f32 takes them (packed weights,
- * scale/shift [T][CoutP] per timestep; upsample = stride-2 transposed conv).  16 workgroups
- * per image walk a phase list: layers at one resolution are chained through LDS, phases
- * exchange activations through L2 (write-through stores + a per-image arrival counter).
- * Supported: Cin in {4,8,16,32}, Cout <= 32 (multiple of 4 except the last layer), no
- * second source; B * 16 workgroups must be co-resident (ra_patchnet_supported).  The caller
- * falls back to per-layer ra_conv3x3_f32 launches otherwise.
- *   x [B,Hp,Wp,layers[0].Cin] -> y [B,Ho,Wo,Cout_last];  tt = timestep (row of scale/shift).
- *   score rider (s_out nullable): s_out[b * s_stride_b] = sigmoid([h[b,:K0] | flat(out of layer
- *   core_layer)[b]] . w + bias[0]); the core layer must end a phase (it pools).
- *   ws: ra_patchnet_workspace_bytes() device bytes, zero-filled ONCE when allocated (the kernel
- *   re-arms its counters itself, so HIP-graph replays need no memset); status_dev (nullable)
- *   is set to 1 if a peer workgroup timed out.
- * ---------------------------------------------------------------------------------- */
-typedef struct ra_pnet_layer {
-  const float *wpacked; /* ra_conv_pack_weights output, device */
-  const float *scale;   /* [T][CoutP], device */
-  const float *shift;   /* [T][CoutP], device */
-  int Cin;              /* input channels incl. padding to 4 */
-  int Cout;
-  int upsample;         /* 1: conv2d_transpose stride 2 (nnlib.py:372-376) */
-  int pool;             /* 1 | 2 */
-  int relu;
-} ra_pnet_layer;
-int ra_patchnet_supported(const ra_pnet_layer *layers, int n_layers, int B, int Hp, int Wp);
-size_t ra_patchnet_workspace_bytes(const ra_pnet_layer *layers, int n_layers, int B, int Hp, int Wp);
-int ra_patchnet_f32(const ra_pnet_layer *layers, int n_layers, int core_layer, const float *x,
-                    int B, int Hp, int Wp, int tt, float *y, const float *h, int K0,
-                    const float *w, const float *bias, float *s_out, size_t s_stride_b, void *ws,
-                    size_t ws_bytes, int *status_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Training step (full_model.py:1039-1057).

@@ -1,20 +1,15 @@
-// K3 / K5 — Gaussian (DRAW-style) attention read and write for gfx950.
-//   modellib.get_gaussian_filter  modellib.py:581-612   -> attn_filters / gaussian_filter
-//   modellib.extract_patch        modellib.py:615-641   -> extract_patch (banded), extract_dense
-//   full_model.py:810-818,843-845 (paste, sigmoid, overwrite mask, canvas max) -> paste_u + paste
-//   full_model.py:738-741 / box_model.py:479-482 (attention box)               -> attn_box
-// These are HBM/L2-bound streaming kernels: no MFMA.  The filters are banded (sigma ~ 1-3 px,
-// 48 taps): the dense tables are still materialised (they ARE the reference operator and cost
-// 2 x L x 48 floats per example) but the contractions only walk the rows/cols where a tap's
-// weight is >= exp(-30) of its peak.
+// The literal (dense) operators of the reference's attention and a few element-wise helpers:
+//   modellib.get_gaussian_filter  modellib.py:581-612   -> ra_gaussian_filter_f32 (the [L,F] bank itself)
+//   modellib.extract_patch        modellib.py:615-641   -> ra_extract_patch_dense_f32 (F_y^T X F_x for GIVEN banks)
+//   input packing, canvas max (box_model), affine + activation, max pool.
+// The decode loop and the training step never materialise the banks: their banded kernels (ra_attn_direct.hip,
+// ra_attn_train.hip) evaluate the weights on the fly from the attention record.
 #include "ra_common.h"
 
 namespace ra {
 namespace attn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr float kBandLog = 30.0f;  // weights below exp(-30) * peak are outside the band
 
 // Reference expression order, modellib.py:598-611.
 __device__ inline float tap_mu(float ctr, float size, int F, int j) {
@@ -37,287 +32,6 @@ __global__ void gaussian_filter_kernel(const float *center, const float *size, c
   }
 }
 
-// band layout per example (ints): [ylo F][yhi F][xlo F][xhi F][y_jlo H][y_jhi H][x_jlo W][x_jhi W]
-__host__ __device__ inline size_t band_ints(int H, int W, int Fh, int Fw) {
-  return 2 * (size_t)(Fh + Fw) + 2 * (size_t)(H + W);
-}
-
-constexpr int kFiltRows = 64;  // pixels of one axis per workgroup
-
-// One workgroup = kFiltRows pixels of one axis of one example: their dense filter rows, the
-// tap range covering each of them, and (chunk 0 only) the per-tap pixel band.
-__global__ __launch_bounds__(256) void attn_filters_kernel(const float *attn, int H, int W, int Fh,
-                                                            int Fw, float *fy, float *fx, int *band) {
-  extern __shared__ int s_band[];  // [F lo][F hi]
-  const int b = blockIdx.z, axis = blockIdx.y;
-  const int L = axis ? W : H, F = axis ? Fw : Fh;
-  const int l0 = blockIdx.x * kFiltRows;
-  if (l0 >= L) return;
-  const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
-  const float ctr = rec[0 + axis], size = rec[2 + axis], var = expf(rec[4 + axis]);
-  int *bd = band + (size_t)b * band_ints(H, W, Fh, Fw);
-  int *lo = axis ? bd + 2 * Fh : bd;
-  int *hi = lo + F;
-  int *jlo = bd + 2 * (Fh + Fw) + (axis ? 2 * H : 0);
-  int *jhi = jlo + L;
-  float *tab = axis ? fx + (size_t)b * W * Fw : fy + (size_t)b * H * Fh;
-  int *s_lo = s_band, *s_hi = s_band + F;
-  const float R = sqrtf(2.0f * kBandLog * var);
-  for (int j = threadIdx.x; j < F; j += blockDim.x) {
-    const float mu = tap_mu(ctr, size, F, j);
-    float a = ceilf(mu - R), c = floorf(mu + R) + 1.0f;
-    a = fminf(fmaxf(a, 0.0f), (float)L);
-    c = fminf(fmaxf(c, 0.0f), (float)L);
-    if (!(a == a) || !(c == c)) {  // NaN parameters: keep the whole axis
-      a = 0.0f;
-      c = (float)L;
-    }
-    const int ia = (int)a, ic = (int)c;
-    s_lo[j] = ia;
-    s_hi[j] = ic > ia ? ic : ia;
-    if (blockIdx.x == 0) {
-      lo[j] = s_lo[j];
-      hi[j] = s_hi[j];
-    }
-  }
-  const int nl = (L - l0) < kFiltRows ? (L - l0) : kFiltRows;
-  for (int e = threadIdx.x; e < nl * F; e += blockDim.x) {
-    const int j = e % F, l = l0 + e / F;
-    tab[(size_t)l * F + j] = gauss((float)l, tap_mu(ctr, size, F, j), var);
-  }
-  __syncthreads();
-  // taps covering pixel l: lo/hi are non-decreasing in j, so the set is one contiguous range
-  for (int l = l0 + threadIdx.x; l < l0 + nl; l += blockDim.x) {
-    int a = 0;
-    while (a < F && s_hi[a] <= l) ++a;
-    int c = a;
-    while (c < F && s_lo[c] <= l) ++c;
-    jlo[l] = a;
-    jhi[l] = c;
-  }
-}
-
-// ---- read: patch[b,j,i,c] = gamma * sum_l sum_w fy[l,j] img[l,w,c] fx[w,i] -------------------
-constexpr int kJB = 4;     // filter rows (j) per workgroup
-constexpr int kWC = 256;   // image columns per pass (= threads)
-
-__global__ __launch_bounds__(256) void extract_patch_kernel(const float *img, int Ci, int chan0,
-                                                             const float *attn, const float *fy,
-                                                             const float *fx, const int *band, int H,
-                                                             int W, int Fh, int Fw, int Cp,
-                                                             int use_gamma, float *patch) {
-  __shared__ f32x4 tl[kJB][kWC];
-  const int t = threadIdx.x;
-  const int j0 = blockIdx.x * kJB;
-  const int cg = blockIdx.y;
-  const int b = blockIdx.z;
-  const int nj = (Fh - j0) < kJB ? (Fh - j0) : kJB;
-  const int *bd = band + (size_t)b * band_ints(H, W, Fh, Fw);
-  const int *ylo = bd, *yhi = bd + Fh, *xlo = bd + 2 * Fh, *xhi = bd + 2 * Fh + Fw;
-  const int l0 = ylo[j0], l1 = yhi[j0 + nj - 1];
-  const int w0 = xlo[0], w1 = xhi[Fw - 1];
-  const float *fyb = fy + (size_t)b * H * Fh;
-  const float *fxb = fx + (size_t)b * W * Fw;
-  const float *imb = img + (size_t)b * H * W * Ci + chan0 + 4 * cg;
-
-  // each thread owns up to 2 of the nj*Fw outputs
-  const int nout = nj * Fw;
-  f32x4 P[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-
-  for (int wc = w0; wc < w1; wc += kWC) {
-    const int w = wc + t;
-    f32x4 T[kJB];
-#pragma unroll
-    for (int jj = 0; jj < kJB; ++jj) T[jj] = f32x4{0, 0, 0, 0};
-    if (w < w1) {
-      constexpr int U = 8;  // rows in flight per thread: the loop is latency-, not ALU-bound
-      for (int l = l0; l < l1; l += U) {
-        f32x4 xv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ll = (l + u < l1) ? l + u : l1 - 1;
-          xv[u] = *reinterpret_cast<const f32x4 *>(imb + ((size_t)ll * W + w) * Ci);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (l + u < l1) {
-            const float *wrow = fyb + (size_t)(l + u) * Fh + j0;
-#pragma unroll
-            for (int jj = 0; jj < kJB; ++jj) {
-              const float wt = (jj < nj) ? wrow[jj] : 0.0f;
-              T[jj] += wt * xv[u];
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int jj = 0; jj < kJB; ++jj) tl[jj][t] = T[jj];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int o = t + k * 256;
-      if (o < nout) {
-        const int jj = o / Fw, i = o % Fw;
-        int a = xlo[i] > wc ? xlo[i] : wc;
-        int c = xhi[i] < wc + kWC ? xhi[i] : wc + kWC;
-        c = c < w1 ? c : w1;
-        f32x4 s = P[k];
-        for (int ww = a; ww < c; ++ww) s += fxb[(size_t)ww * Fw + i] * tl[jj][ww - wc];
-        P[k] = s;
-      }
-    }
-    __syncthreads();
-  }
-  const float gamma = use_gamma ? attn[(size_t)b * RA_ATTN_STRIDE + 6] : 1.0f;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int o = t + k * 256;
-    if (o < nout) {
-      const int jj = o / Fw, i = o % Fw;
-      *reinterpret_cast<f32x4 *>(patch + (((size_t)b * Fh + j0 + jj) * Fw + i) * Cp + 4 * cg) =
-          gamma * P[k];
-    }
-  }
-}
-
-// ---- write, stage 1: U[b,j,w] = sum_i P[b,j,i] fx[b,w,i] ---------------------------------------
-__global__ __launch_bounds__(256) void paste_u_kernel(const float *patch, int Cp, int pc,
-                                                       const float *fx, const int *band, int H, int W,
-                                                       int Fh, int Fw, float *u) {
-  extern __shared__ float sp[];  // [kJB][Fw]
-  const int t = threadIdx.x;
-  const int w = blockIdx.x * 256 + t;
-  const int j0 = blockIdx.y * kJB;
-  const int b = blockIdx.z;
-  const int nj = (Fh - j0) < kJB ? (Fh - j0) : kJB;
-  for (int e = t; e < kJB * Fw; e += 256) {
-    const int jj = e / Fw, i = e % Fw;
-    sp[e] = (jj < nj) ? patch[(((size_t)b * Fh + j0 + jj) * Fw + i) * Cp + pc] : 0.0f;
-  }
-  __syncthreads();
-  if (w >= W) return;
-  const int *bd = band + (size_t)b * band_ints(H, W, Fh, Fw);
-  const int *x_jlo = bd + 2 * (Fh + Fw) + 2 * H, *x_jhi = x_jlo + W;
-  const int a = x_jlo[w], c = x_jhi[w];
-  const float *fxw = fx + ((size_t)b * W + w) * Fw;
-  float acc[kJB];
-#pragma unroll
-  for (int jj = 0; jj < kJB; ++jj) acc[jj] = 0.0f;
-  for (int i = a; i < c; ++i) {
-    const float f = fxw[i];
-#pragma unroll
-    for (int jj = 0; jj < kJB; ++jj) acc[jj] += sp[jj * Fw + i] * f;
-  }
-#pragma unroll
-  for (int jj = 0; jj < kJB; ++jj)
-    if (jj < nj) u[((size_t)b * Fh + j0 + jj) * W + w] = acc[jj];
-}
-
-__device__ inline float sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }
-
-// ---- write, stage 2: y = sigmoid(gamma_y * sum_j fy[l,j] U[j,w] + beta) [* (1-canvas)] ---------
-__global__ __launch_bounds__(128) void paste_kernel(const float *u, const float *attn, const float *fy,
-                                                     const int *band, int H, int W, int Fh, int Fw,
-                                                     float beta, int disable_overwrite, float *img,
-                                                     int Ci, int canvas_chan, float *y_out,
-                                                     size_t y_stride_b) {
-  const int l = blockIdx.x;
-  const int b = blockIdx.y;
-  const int *bd = band + (size_t)b * band_ints(H, W, Fh, Fw);
-  const int *y_jlo = bd + 2 * (Fh + Fw), *y_jhi = y_jlo + H;
-  const int a = y_jlo[l], c = y_jhi[l];
-  const float gy = expf(attn[(size_t)b * RA_ATTN_STRIDE + 8]);
-  const float *fyl = fy + ((size_t)b * H + l) * Fh;
-  const float *ub = u + (size_t)b * Fh * W;
-  float *yrow = y_out + (size_t)b * y_stride_b + (size_t)l * W;
-  float *crow = (canvas_chan >= 0) ? img + ((size_t)b * H + l) * W * Ci + canvas_chan : nullptr;
-  const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(yrow) & 15) == 0);
-  if (vec && crow && Ci == 4) {
-    // 16-byte pixel records: read-modify-write the whole record, 4 pixels per thread
-    float *prow = img + ((size_t)b * H + l) * W * 4;
-    for (int w4 = threadIdx.x * 4; w4 < W; w4 += blockDim.x * 4) {
-      f32x4 px[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) px[k] = *reinterpret_cast<const f32x4 *>(prow + (size_t)(w4 + k) * 4);
-      f32x4 s = f32x4{0, 0, 0, 0};
-      for (int j = a; j < c; ++j)
-        s += fyl[j] * *reinterpret_cast<const f32x4 *>(ub + (size_t)j * W + w4);
-      f32x4 y;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float v = sigmoidf(gy * s[k] + beta);
-        // select, not a runtime vector index (that would spill the record to scratch)
-        const float cv = canvas_chan == 0 ? px[k].x : canvas_chan == 1 ? px[k].y
-                       : canvas_chan == 2 ? px[k].z : px[k].w;
-        if (disable_overwrite) v *= (1.0f - cv);
-        const float nv = fmaxf(cv, v);
-        px[k].x = canvas_chan == 0 ? nv : px[k].x;
-        px[k].y = canvas_chan == 1 ? nv : px[k].y;
-        px[k].z = canvas_chan == 2 ? nv : px[k].z;
-        px[k].w = canvas_chan == 3 ? nv : px[k].w;
-        y[k] = v;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(prow + (size_t)(w4 + k) * 4) = px[k];
-      *reinterpret_cast<f32x4 *>(yrow + w4) = y;
-    }
-  } else if (vec) {
-    for (int w4 = threadIdx.x * 4; w4 < W; w4 += blockDim.x * 4) {
-      f32x4 s = f32x4{0, 0, 0, 0};
-      for (int j = a; j < c; ++j)
-        s += fyl[j] * *reinterpret_cast<const f32x4 *>(ub + (size_t)j * W + w4);
-      f32x4 y;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float v = sigmoidf(gy * s[k] + beta);
-        if (crow) {
-          const float cv = crow[(size_t)(w4 + k) * Ci];
-          if (disable_overwrite) v *= (1.0f - cv);
-          crow[(size_t)(w4 + k) * Ci] = fmaxf(cv, v);
-        }
-        y[k] = v;
-      }
-      *reinterpret_cast<f32x4 *>(yrow + w4) = y;
-    }
-  } else {
-    for (int w = threadIdx.x; w < W; w += blockDim.x) {
-      float s = 0.0f;
-      for (int j = a; j < c; ++j) s += fyl[j] * ub[(size_t)j * W + w];
-      float v = sigmoidf(gy * s + beta);
-      if (crow) {
-        const float cv = crow[(size_t)w * Ci];
-        if (disable_overwrite) v *= (1.0f - cv);
-        crow[(size_t)w * Ci] = fmaxf(cv, v);
-      }
-      yrow[w] = v;
-    }
-  }
-}
-
-// ---- attention box: sigmoid(box_gamma * rowsum(fy)[l] * rowsum(fx)[w] + beta) -------------------
-__global__ __launch_bounds__(128) void attn_box_kernel(const float *attn, const float *fy,
-                                                        const float *fx, const int *band, int H, int W,
-                                                        int Fh, int Fw, float beta, float *out,
-                                                        size_t stride_b) {
-  const int l = blockIdx.x;
-  const int b = blockIdx.y;
-  const int *bd = band + (size_t)b * band_ints(H, W, Fh, Fw);
-  const int *y_jlo = bd + 2 * (Fh + Fw), *y_jhi = y_jlo + H;
-  const int *x_jlo = y_jhi + H, *x_jhi = x_jlo + W;
-  const float g = attn[(size_t)b * RA_ATTN_STRIDE + 7];
-  const float *fyl = fy + ((size_t)b * H + l) * Fh;
-  float sy = 0.0f;
-  for (int j = y_jlo[l]; j < y_jhi[l]; ++j) sy += fyl[j];
-  for (int w = threadIdx.x; w < W; w += blockDim.x) {
-    const float *fxw = fx + ((size_t)b * W + w) * Fw;
-    float sx = 0.0f;
-    for (int i = x_jlo[w]; i < x_jhi[w]; ++i) sx += fxw[i];
-    out[(size_t)b * stride_b + (size_t)l * W + w] = sigmoidf(g * sy * sx + beta);
-  }
-}
-
-// ---- generic dense extract_patch with caller filters (operator surface) ------------------------
 constexpr int kDenseChunk = 4096;
 __global__ __launch_bounds__(256) void extract_dense_kernel(const float *x, const float *f_y,
                                                              const float *f_x, int H, int W, int D,
@@ -433,67 +147,6 @@ extern "C" int ra_gaussian_filter_f32(const float *center, const float *size, co
   hipLaunchKernelGGL(attn::gaussian_filter_kernel, dim3(attn::grid_for((size_t)B * L * F, 256)),
                      dim3(256), 0, as_stream(stream), center, size, lg_var, B, L, F, out);
   return launch_status("ra_gaussian_filter_f32");
-}
-
-extern "C" size_t ra_attn_band_ints(int H, int W, int Fh, int Fw) {
-  return attn::band_ints(H, W, Fh, Fw);
-}
-
-extern "C" int ra_attn_filters_f32(const float *attn_rec, int B, int H, int W, int Fh, int Fw,
-                                   float *fy, float *fx, int *band, void *stream) {
-  if (!attn_rec || !fy || !fx || !band || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 || Fw <= 0)
-    return fail(RA_E_INVALID, "ra_attn_filters_f32: bad argument");
-  const int Fm = Fh > Fw ? Fh : Fw, Lm = H > W ? H : W;
-  hipLaunchKernelGGL(attn::attn_filters_kernel, dim3(ceil_div(Lm, attn::kFiltRows), 2, B), dim3(256),
-                     2 * Fm * sizeof(int), as_stream(stream), attn_rec, H, W, Fh, Fw, fy, fx, band);
-  return launch_status("ra_attn_filters_f32");
-}
-
-extern "C" int ra_extract_patch_f32(const float *img, int Ci, int chan0, const float *attn_rec,
-                                    const float *fy, const float *fx, const int *band, int B, int H,
-                                    int W, int Fh, int Fw, int Cp, int use_gamma, float *patch,
-                                    void *stream) {
-  if (!img || !attn_rec || !fy || !fx || !band || !patch || B <= 0 || H <= 0 || W <= 0 || Fh <= 0 ||
-      Fw <= 0)
-    return fail(RA_E_INVALID, "ra_extract_patch_f32: bad argument");
-  if (Ci % 4 || Cp % 4 || chan0 % 4 || chan0 + Cp > Ci || Cp <= 0)
-    return fail(RA_E_SHAPE, "ra_extract_patch_f32: Ci=%d chan0=%d Cp=%d", Ci, chan0, Cp);
-  if (attn::kJB * Fw > 512) return fail(RA_E_SHAPE, "ra_extract_patch_f32: Fw %d > 64", Fw);
-  dim3 grid(ceil_div(Fh, attn::kJB), Cp / 4, B);
-  hipLaunchKernelGGL(attn::extract_patch_kernel, grid, dim3(256), 0, as_stream(stream), img, Ci,
-                     chan0, attn_rec, fy, fx, band, H, W, Fh, Fw, Cp, use_gamma, patch);
-  return launch_status("ra_extract_patch_f32");
-}
-
-extern "C" int ra_paste_canvas_f32(const float *patch, int Cp, int pc, const float *attn_rec,
-                                   const float *fy, const float *fx, const int *band, int B, int H,
-                                   int W, int Fh, int Fw, float beta, int disable_overwrite,
-                                   float *img, int Ci, int canvas_chan, float *y_out,
-                                   size_t y_stride_b, float *u_ws, void *stream) {
-  if (!patch || !attn_rec || !fy || !fx || !band || !y_out || !u_ws || B <= 0 || H <= 0 || W <= 0 ||
-      Fh <= 0 || Fw <= 0 || Cp <= 0 || pc < 0 || pc >= Cp)
-    return fail(RA_E_INVALID, "ra_paste_canvas_f32: bad argument");
-  if (canvas_chan >= 0 && (!img || canvas_chan >= Ci))
-    return fail(RA_E_INVALID, "ra_paste_canvas_f32: canvas channel %d of %d", canvas_chan, Ci);
-  hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(attn::paste_u_kernel, dim3(ceil_div(W, 256), ceil_div(Fh, attn::kJB), B),
-                     dim3(256), attn::kJB * Fw * sizeof(float), st, patch, Cp, pc, fx, band, H, W, Fh,
-                     Fw, u_ws);
-  int rc = launch_status("ra_paste_canvas_f32(u)");
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn::paste_kernel, dim3(H, B), dim3(128), 0, st, u_ws, attn_rec, fy, band, H, W,
-                     Fh, Fw, beta, disable_overwrite, img, Ci, canvas_chan, y_out, y_stride_b);
-  return launch_status("ra_paste_canvas_f32");
-}
-
-extern "C" int ra_attn_box_f32(const float *attn_rec, const float *fy, const float *fx,
-                               const int *band, int B, int H, int W, int Fh, int Fw, float beta,
-                               float *box_out, size_t stride_b, void *stream) {
-  if (!attn_rec || !fy || !fx || !band || !box_out || B <= 0 || H <= 0 || W <= 0)
-    return fail(RA_E_INVALID, "ra_attn_box_f32: bad argument");
-  hipLaunchKernelGGL(attn::attn_box_kernel, dim3(H, B), dim3(128), 0, as_stream(stream), attn_rec, fy,
-                     fx, band, H, W, Fh, Fw, beta, box_out, stride_b);
-  return launch_status("ra_attn_box_f32");
 }
 
 extern "C" int ra_extract_patch_dense_f32(const float *x, const float *f_y, const float *f_x, int B,

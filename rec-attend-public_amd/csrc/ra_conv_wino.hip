@@ -473,404 +473,6 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
   }
 }
 
-// Second form of phase B for ONE block of 16 output channels: WAVE w owns ROW BLOCK w (16 Winograd tiles) and
-// walks all four transform rows p itself — the whole transformed filter is 64 VGPRs at Cin = 16 — so the
-// output transform finishes in registers: no LDS exchange, no barrier inside phase B, the 16 patch values
-// of a (tile, channel) are read once instead of twice, and the pooled result is stored straight from the
-// accumulator layout (lane = output channel, 4 tiles per lane).  Tile 16 x 16 (4 row blocks = 4 waves).
-__global__ __launch_bounds__(256, 2) void conv_pair_wino2_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
-  constexpr int TSY = 16, CINA = 8, CMID = 16, KK = CMID / 4, S = CMID + 2;
-  constexpr int AWY = TSY + 2, IWY = TSY + 4, IWX = TS + 4;
-  constexpr int NPA = AWY * WS, NGA = (NPA + 15) / 16, GPW = (NGA + 3) / 4;
-  constexpr int NPI = IWY * IWX, NIT = (NPI * 2 + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *tinp = lds;                 // [IWY][IWX][8]   records [ksub][cg]
-  float *tin = lds + NPI * CINA;     // [AWY * 18][S]   layer-A output window (+ one group of slack)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 15, ksub = lane >> 4;
-  const int per = tiles_x * tiles_y;
-
-  float bA[9][2];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int cg = 0; cg < 2; ++cg) bA[tap][cg] = a.wpA[(size_t)((tap * 2 + cg) * 4 + ksub) * a.CoutAP + m];
-  const float scA = a.scA[m], shA = a.shA[m];
-  const float loA = a.reluA ? 0.f : -__builtin_inff();
-  // layer B's whole transformed filter: 64 VGPRs, live across phase A (244 VGPRs in all, two workgroups per CU).
-  // From LDS instead (16 KB, one ds_read per MFMA) the kernel fits 168 VGPRs but spills and loses: 41.0 vs 37.8 us.
-  float bw[4][4][KK];  // [p][q][kk]
-#pragma unroll
-  for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) bw[pp][q][kk] = a.wpB[((size_t)((pp * 4 + q) * KK + kk)) * 64 + lane];
-  const float scB = a.scB[m], shB = a.shB[m];
-  const float loB = a.reluB ? 0.f : -__builtin_inff();
-  const int Ho = a.H / 2, Wo = a.W / 2;
-
-  int ain[GPW];
-#pragma unroll
-  for (int s = 0; s < GPW; ++s) {
-    int li = 16 * (wv + 4 * s) + m;
-    if (li >= NPA) li = NPA - 1;
-    const int r = li / WS, c = li - r * WS;
-    ain[s] = (r * IWX + c) * CINA + 2 * ksub;
-  }
-  // phase B: lane m's tile of this wave's row block and its patch origin in the window
-  const int tyi = 2 * wv + (m >> 3), txi = m & 7;
-  const float *pd = tin + ((2 * tyi) * WS + 2 * txi) * S + ksub;
-
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
-  f32x4 pre[NIT];
-  auto fetch = [&](int T) {
-    const int fb = T / per, fr = T - fb * per;
-    const int fy0 = (fr / tiles_x) * TSY - 2, fx0 = (fr % tiles_x) * TS - 2;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int e = tid + 256 * i, cg = e & 1, pix = e >> 1;
-      const int r = pix / IWX, c = pix - r * IWX;
-      const int Y = fy0 + r, X = fx0 + c;
-      const bool ok = (e < NPI * 2) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-      const int off = ok ? (((fb * a.H + Y) * a.W + X) * CINA + 4 * cg) * 4 : 0x7fffffff;
-      pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-    }
-  };
-
-  int tile = blockIdx.x;
-  if (tile < ntiles) fetch(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int b = tile / per, trem = tile - b * per;
-    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    __syncthreads();  // the previous tile's phase B reads of tin are complete (tinp: since its phase A)
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int e = tid + 256 * i, cg = e & 1, pix = e >> 1;
-      if (e < NPI * 2) {
-        float *rec = tinp + pix * CINA + cg;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) rec[2 * ks] = pre[i][ks];
-      }
-    }
-    __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-
-    {  // ---------------- phase A (as conv_pair_wino_mfma) ----------------
-      const int oyA = ty * TSY - 1, oxA = tx * TS - 1;
-      const bool interior = (oyA >= 0) & (oyA + AWY <= a.H) & (oxA >= 0) & (oxA + WS <= a.W);
-      f32x4 acc[GPW];
-#pragma unroll
-      for (int s = 0; s < GPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        f32x2 av[GPW];
-#pragma unroll
-        for (int s = 0; s < GPW; ++s)
-          av[s] = *reinterpret_cast<const f32x2 *>(&tinp[ain[s] + ((tap / 3) * IWX + tap % 3) * CINA]);
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg)
-#pragma unroll
-          for (int s = 0; s < GPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[tap][cg], acc[s], 0, 0, 0);
-      }
-#pragma unroll
-      for (int s = 0; s < GPW; ++s) {
-        const int g = wv + 4 * s;
-        if (g < NGA) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int li = 16 * g + 4 * ksub + r;
-            float o = fmaxf(acc[s][r] * scA + shA, loA);
-            if (!interior) {
-              const int wr = li / WS, wc = li - wr * WS;
-              const int Y = oyA + wr, X = oxA + wc;
-              o = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o : 0.f;
-            }
-            tin[li * S + m] = o;
-          }
-        }
-      }
-    }
-    __syncthreads();
-
-    {  // ---------------- phase B: this wave's row block, all four transform rows, in registers ----------------
-      f32x4 y00 = f32x4{0.f, 0.f, 0.f, 0.f}, y01 = y00, y10 = y00, y11 = y00;
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {  // transform row p: patch rows (ra, rb), r_j = d[ra][j] + sg * d[rb][j]
-        constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
-        const float sg = pp == 1 ? 1.f : -1.f;
-        f32x4 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          float r[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) r[j] = pd[(RA[pp] * WS + j) * S + 4 * kk] + sg * pd[(RB[pp] * WS + j) * S + 4 * kk];
-          const float v[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[pp][q][kk], acc[q], 0, 0, 0);
-        }
-        const f32x4 t0 = acc[0] + acc[1] + acc[2];
-        const f32x4 t1 = acc[1] - acc[2] - acc[3];
-        if (pp < 3) {
-          y00 += t0;
-          y01 += t1;
-        }
-        if (pp == 1) {
-          y10 += t0;
-          y11 += t1;
-        } else if (pp >= 2) {
-          y10 -= t0;
-          y11 -= t1;
-        }
-      }
-      // D rows = tiles 4 * ksub + r of the row block, column m = output channel
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float best = fmaxf(y00[r] * scB + shB, loB);
-        best = fmaxf(best, fmaxf(y01[r] * scB + shB, loB));
-        best = fmaxf(best, fmaxf(y10[r] * scB + shB, loB));
-        best = fmaxf(best, fmaxf(y11[r] * scB + shB, loB));
-        const int tl = 4 * ksub + r;
-        const int oty = ty * 8 + 2 * wv + (tl >> 3), otx = tx * 8 + (tl & 7);
-        a.y[((size_t)(b * Ho + oty) * Wo + otx) * 16 + m] = best;
-      }
-    }
-  }
-}
-
-int launch_pair2(const PWArgs &a, hipStream_t st) {
-  auto kern = conv_pair_wino2_mfma;
-  constexpr size_t lds = (size_t)(20 * 20 * 8 + (18 * WS + 16) * 18) * sizeof(float);
-  static bool attr = false;
-  static int cap = 0;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
-    cap = nb * cu_count();
-    const char *e = getenv("RA_PAIRW_WGS");
-    if (e && atoi(e) > 0) cap = atoi(e);
-    attr = true;
-  }
-  const int tiles_x = a.W / TS, tiles_y = a.H / 16, ntiles = tiles_x * tiles_y * a.B;
-  hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
-  return launch_status("ra_conv_pair_wino_f32");
-}
-
-// Third form: ROLE-SPLIT workgroups of 8 waves.  A wave that runs both phases carries both filter sets (244
-// VGPRs: two waves per SIMD) and every tile is staging -> phase A -> barrier -> phase B in lockstep.  Here
-// waves 0-3 only ever run phase A (direct conv of the NEXT tile into the other half of a double-buffered
-// window) and waves 4-7 only phase B (Winograd of the current tile): each role lives in its own loop, so the
-// register file holds max(A, B) instead of A + B, a SIMD carries four waves of a workgroup pair, and the two
-// phases of consecutive tiles overlap.  Two barriers per tile, executed by both roles (the B role runs one
-// tile behind and one iteration longer; the A role pads with an empty iteration).
-__global__ __launch_bounds__(512, 4) void conv_pair_wino3_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
-  constexpr int TSY = 16, CINA = 8, CMID = 16, KK = CMID / 4, S = CMID + 2;
-  constexpr int AWY = TSY + 2, IWY = TSY + 4, IWX = TS + 4;
-  constexpr int NPA = AWY * WS, NGA = (NPA + 15) / 16, GPW = (NGA + 3) / 4;
-  constexpr int NPI = IWY * IWX, NIT = (NPI * 2 + 255) / 256;
-  constexpr int TINF = (NPA + 16) * S;  // one window buffer (+ one group of slack)
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *tinp = lds;                 // [IWY][IWX][8]   records [ksub][cg]
-  float *tin0 = lds + NPI * CINA;    // two layer-A output windows
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 2, wv = wave & 3, tr = tid & 255;
-  const int m = lane & 15, ksub = lane >> 4;
-  const int per = tiles_x * tiles_y;
-  const int nmine = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-
-  if (role == 0) {
-    // =============================== role A: staging + layer A ===============================
-    float bA[9][2];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int cg = 0; cg < 2; ++cg) bA[tap][cg] = a.wpA[(size_t)((tap * 2 + cg) * 4 + ksub) * a.CoutAP + m];
-    const float scA = a.scA[m], shA = a.shA[m];
-    const float loA = a.reluA ? 0.f : -__builtin_inff();
-    int ain[GPW];
-#pragma unroll
-    for (int s = 0; s < GPW; ++s) {
-      int li = 16 * (wv + 4 * s) + m;
-      if (li >= NPA) li = NPA - 1;
-      const int r = li / WS, c = li - r * WS;
-      ain[s] = (r * IWX + c) * CINA + 2 * ksub;
-    }
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
-    f32x4 pre[NIT];
-    int e_r[NIT], e_c[NIT];  // this thread's staged items: window row / column (tile-invariant)
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int e = tr + 256 * i, pix = e >> 1;
-      e_r[i] = (e < NPI * 2) ? pix / IWX : -(1 << 20);  // never inside the image
-      e_c[i] = pix % IWX;
-    }
-    auto fetch = [&](int T) {
-      const int fb = T / per, fr = T - fb * per;
-      const int fy0 = (fr / tiles_x) * TSY - 2, fx0 = (fr % tiles_x) * TS - 2;
-#pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int Y = fy0 + e_r[i], X = fx0 + e_c[i];
-        const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-        const int off = ok ? (((fb * a.H + Y) * a.W + X) * CINA + 4 * (tr & 1)) * 4 : 0x7fffffff;
-        pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-      }
-    };
-    int tile = blockIdx.x;
-    if (nmine) fetch(tile);
-    for (int it = 0; it <= nmine; ++it, tile += gridDim.x) {
-      if (it < nmine) {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int e = tr + 256 * i, cg = e & 1, pix = e >> 1;
-          if (e < NPI * 2) {
-            float *rec = tinp + pix * CINA + cg;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) rec[2 * ks] = pre[i][ks];
-          }
-        }
-      }
-      __syncthreads();  // barrier 1: the input tile is staged
-      if (it < nmine) {
-        if (it + 1 < nmine) fetch(tile + gridDim.x);
-        const int trem = tile % per, ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        const int oyA = ty * TSY - 1, oxA = tx * TS - 1;
-        const bool interior = (oyA >= 0) & (oyA + AWY <= a.H) & (oxA >= 0) & (oxA + WS <= a.W);
-        float *tin = tin0 + (it & 1) * TINF;
-        constexpr int HG = (GPW + 1) / 2;  // two passes over the wave's groups: half the accumulators and operands live
-#pragma unroll 1
-        for (int s0 = 0; s0 < GPW; s0 += HG) {
-          f32x4 acc[HG];
-          int ai[HG];
-#pragma unroll
-          for (int s = 0; s < HG; ++s) {
-            acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ai[s] = ain[s0 + s < GPW ? s0 + s : GPW - 1];
-          }
-#pragma unroll
-          for (int tap = 0; tap < 9; ++tap) {
-            f32x2 av[HG];
-#pragma unroll
-            for (int s = 0; s < HG; ++s)
-              av[s] = *reinterpret_cast<const f32x2 *>(&tinp[ai[s] + ((tap / 3) * IWX + tap % 3) * CINA]);
-#pragma unroll
-            for (int cg = 0; cg < 2; ++cg)
-#pragma unroll
-              for (int s = 0; s < HG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[tap][cg], acc[s], 0, 0, 0);
-          }
-#pragma unroll
-          for (int s = 0; s < HG; ++s) {
-            const int g = wv + 4 * (s0 + s);
-            if (s0 + s < GPW && g < NGA) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int li = 16 * g + 4 * ksub + r;
-                float o = fmaxf(acc[s][r] * scA + shA, loA);
-                if (!interior) {
-                  const int wr = li / WS, wc = li - wr * WS;
-                  const int Y = oyA + wr, X = oxA + wc;
-                  o = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o : 0.f;
-                }
-                tin[li * S + m] = o;
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();  // barrier 2: window `it & 1` is complete; the other one has been consumed
-    }
-  } else {
-    // =============================== role B: Winograd layer B, one tile behind ===============================
-    float bw[4][4][KK];  // the whole transformed filter of layer B: 64 VGPRs, only this role carries them
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bw[pp][q][kk] = a.wpB[((size_t)((pp * 4 + q) * KK + kk)) * 64 + lane];
-    const float scB = a.scB[m], shB = a.shB[m];
-    const float loB = a.reluB ? 0.f : -__builtin_inff();
-    const int Ho = a.H / 2, Wo = a.W / 2;
-    const int tyi = 2 * wv + (m >> 3), txi = m & 7;
-    const int pdo = ((2 * tyi) * WS + 2 * txi) * S + ksub;
-    int tile = (int)blockIdx.x - (int)gridDim.x;  // the tile of iteration it is the A role's tile of it - 1
-    for (int it = 0; it <= nmine; ++it, tile += gridDim.x) {
-      __syncthreads();  // barrier 1
-      if (it >= 1) {
-        const int b = tile / per, trem = tile - b * per;
-        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        const float *pd = tin0 + ((it - 1) & 1) * TINF + pdo;
-        f32x4 y00 = f32x4{0.f, 0.f, 0.f, 0.f}, y01 = y00, y10 = y00, y11 = y00;
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-          constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
-          const float sg = pp == 1 ? 1.f : -1.f;
-          f32x4 acc[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < KK; ++kk) {
-            float r[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = pd[(RA[pp] * WS + j) * S + 4 * kk] + sg * pd[(RB[pp] * WS + j) * S + 4 * kk];
-            const float v[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[pp][q][kk], acc[q], 0, 0, 0);
-          }
-          const f32x4 t0 = acc[0] + acc[1] + acc[2];
-          const f32x4 t1 = acc[1] - acc[2] - acc[3];
-          if (pp < 3) {
-            y00 += t0;
-            y01 += t1;
-          }
-          if (pp == 1) {
-            y10 += t0;
-            y11 += t1;
-          } else if (pp >= 2) {
-            y10 -= t0;
-            y11 -= t1;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float best = fmaxf(y00[r] * scB + shB, loB);
-          best = fmaxf(best, fmaxf(y01[r] * scB + shB, loB));
-          best = fmaxf(best, fmaxf(y10[r] * scB + shB, loB));
-          best = fmaxf(best, fmaxf(y11[r] * scB + shB, loB));
-          const int tl = 4 * ksub + r;
-          const int oty = ty * 8 + 2 * wv + (tl >> 3), otx = tx * 8 + (tl & 7);
-          a.y[((size_t)(b * Ho + oty) * Wo + otx) * 16 + m] = best;
-        }
-      }
-      __syncthreads();  // barrier 2
-    }
-  }
-}
-
-int launch_pair3(const PWArgs &a, hipStream_t st) {
-  auto kern = conv_pair_wino3_mfma;
-  constexpr size_t lds = (size_t)(20 * 20 * 8 + 2 * (18 * WS + 16) * 18) * sizeof(float);
-  static bool attr = false;
-  static int cap = 0;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 512, lds) != hipSuccess || nb < 1) nb = 1;
-    cap = nb * cu_count();
-    const char *e = getenv("RA_PAIRW_WGS");
-    if (e && atoi(e) > 0) cap = atoi(e);
-    attr = true;
-  }
-  const int tiles_x = a.W / TS, tiles_y = a.H / 16, ntiles = tiles_x * tiles_y * a.B;
-  hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(512), lds, st, a, tiles_x, tiles_y, ntiles);
-  return launch_status("ra_conv_pair_wino_f32");
-}
-
 template <int TSY>
 int launch_pair(const PWArgs &a, hipStream_t st) {
   auto kern = conv_pair_wino_mfma<TSY>;
@@ -993,16 +595,10 @@ extern "C" int ra_conv_pair_wino_f32(const float *x, int B, int H, int W, const 
   a.reluB = reluB;
   a.bytes_x = (int)bytes;
   a.xcd_map = 0;
-  static int form = -1;  // RA_PAIRW_FORM=2|3: tuning aid, the other forms of phase B
-  if (form < 0) {
-    // form 2 (row-block waves, in-register output transform, 244 VGPRs) is the fastest alone (37.6 vs 39.0 us), but form 1
-    // (LDS exchange, 128 VGPRs, 4 workgroups per CU) shares the CUs better with the other decode graphs' kernels:
-    // 49.8k vs 48.9k instance-timesteps/s with four batches in flight — the evaluator's loop decides
-    const char *e = getenv("RA_PAIRW_FORM");
-    form = e ? atoi(e) : 1;
-  }
-  if (form == 3) return wino::launch_pair3(a, as_stream(stream));
-  if (form == 2) return wino::launch_pair2(a, as_stream(stream));
+  // phase B through an LDS exchange (128 VGPRs, 4 workgroups per CU).  Two other forms were built and measured in
+  // round 2 — row-block waves with the output transform in registers (244 VGPRs: 37.6 vs 39.0 us alone, but 48.9k vs
+  // 49.8k instance-timesteps/s with four batches in flight) and role-split 8-wave workgroups (the same) — and removed
+  // (git history: 58353f0, d1e62e4).
   static int tsy = 0;  // RA_PAIRW_TSY=16: tuning aid
   if (!tsy) {
     const char *e = getenv("RA_PAIRW_TSY");

@@ -293,9 +293,7 @@ class Model(dict):
     if name == 'ctrl_rnn_glimpse_map':
       b['gmaps'] = eng.fetch('gmaps')
     if name == 'canvas':
-      if eng.direct_attn:
-        return eng.fetch('canvas').unsqueeze(-1).contiguous()
-      b['img'] = eng.fetch('img')
+      return eng.fetch('canvas').unsqueeze(-1).contiguous()
     a = b['attn']  # [T,B,16]
     if name == 'x_patch':
       xp = tb(b['x_patch'])
@@ -383,7 +381,7 @@ class DecodePipeline(object):
     streams = [torch.cuda.Stream() for _ in range(self.streams)]
     for k in range(self.depth):
       eng = ra_engine.DecodeEngine(proto.d, self.model, box_model=proto.box)
-      for flag in ('direct_attn', 'fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score', 'fuse_patchnet',
+      for flag in ('fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score',
                    'cache_first', 'fill_cache_inline', 'nsub', 'use_graph', 'use_wino', 'wino_unfuse', 'pair_wino', 'prefill_ride'):
         setattr(eng, flag, getattr(proto, flag))
       eng.co_resident = self.co_resident

@@ -5,13 +5,12 @@ replayable as one HIP graph.
 Per output timestep tt (full_model.py:638-848), all on one stream:
    K1 x L   ctrl CNN   conv3x3+bias+BN(tt)+ReLU+pool  (f32 MFMA)      img -> feat [B,G,Cf]
    K2       controller glimpse/LSTM/gMLP x iters, cMLP, attn decode  feat -> attn record
-   K3a      filter banks + band limits                               attn -> fy, fx, band
    K3       extract    gamma * fy^T X fx                             img -> x_patch
    K4 x ..  attn CNN / DCNN (same MFMA conv kernel; transposed packing + zero-stuffing + skip)
    K6       score      sigmoid([h, h_core] w + b)                    -> s_out[:, tt]
    K5       paste      sigmoid(e^g fy P fx^T - 5)(1-canvas), canvas = max -> y_out[:, tt], img
-The canvas is channel D of the packed NHWC image `img` = [x | canvas | d_in | y_in | 0-pad], so
-both the controller CNN and the extract kernel stream one 16-byte-aligned pixel record.
+`img` is the packed NHWC image [x | canvas slot | d_in | y_in | 0-pad]; the canvas itself lives in its own
+[B,H,W] plane that the first controller-CNN layer and the extract kernel substitute for the slot.
 """
 import numpy as np
 import math
@@ -40,14 +39,10 @@ class DecodeEngine(object):
     self._stamp = None
     self._B = None
     self._graphs = {}
-    self.direct_attn = True   # table-free extract / paste kernels + the canvas in its own plane
     self.fuse_pairs = True  # fused two-layer conv launches in the controller CNN where it pays
     self.fuse_patch_pairs = False  # ... and in the patch-sized attention CNN / DCNN (it does not)
     self.ctrl_split = True  # 16-workgroup LDS-stationary controller where supported
     self.fuse_score = True  # score MLP as an extra workgroup of the paste launch
-    # attention CNN + DCNN + score through the phase kernel K4 (ra_patchnet_f32).  Measured on MI355X at
-    # cfg2 it is 11-15 us per timestep SLOWER than the 13 per-layer launches, so off.
-    self.fuse_patchnet = False
     # ... also where that splits a fused pair (the 16 -> 16 layer of L2+L3)?  Measured at cfg2: L2 direct 20.6 +
     # L3 Winograd 22.2 us against 41.8 us fused: no gain, one more launch -> off
     self.wino_unfuse = False
@@ -175,17 +170,6 @@ class DecodeEngine(object):
         sc, sh = fold_all('attn_dcnn', i, cout)
         W['adcnn'].append((_dev(wp, device), sc, sh, cout, d['adcnn_unpool'][i], src))
         prev_c = cout
-    self.pnet = None
-    if not self.box and self.fuse_patchnet and all(lay[5] is None for lay in W['adcnn']) and \
-        all(u in (1, 2) for u in d['adcnn_unpool']):
-      lays = []
-      for i, (wp, sc, sh, cout, pool) in enumerate(W['acnn']):
-        lays.append((wp, sc, sh, d['C0p'] if i == 0 else _r4(d['acnn_channels'][i]), cout, False, pool))
-      for i, (wp, sc, sh, cout, unpool, _) in enumerate(W['adcnn']):
-        lays.append((wp, sc, sh, _r4(d['adcnn_channels'][i]), cout, unpool == 2, 1))
-      meta = [(l[3], l[4], l[5], l[6]) for l in lays]
-      if ops.PatchNet.structurally_supported(meta, d['Fh'], d['Fw'], 1) and d['acnn_pool'][-1] == 2:
-        self.pnet = ops.PatchNet(lays, d['acnn_nlayers'] - 1, d['Fh'], d['Fw'])
     self.W = W
     self.plan = self._make_plan(W)
     self._stamp = stamp
@@ -264,8 +248,7 @@ class DecodeEngine(object):
     for k in range(nsub):
       b = {kk: v[k * Bs:(k + 1) * Bs] for kk, v in g.items() if kk != 'noise'}
       b['img'] = f(Bs, H, W, d['C0p'])
-      if self.direct_attn:
-        b['canvas'] = f(Bs, H, W)
+      b['canvas'] = f(Bs, H, W)
       hh, ww = H, W
       b['ccnn'] = []
       for i in range(d['ccnn_nlayers']):
@@ -275,12 +258,8 @@ class DecodeEngine(object):
       b['ctrl_out'] = f(T, Bs, 9)
       b['gmaps'] = f(T, Bs, d['iters'], d['G'])
       b['attn'] = f(T, Bs, rn.RA_ATTN_STRIDE)
-      b['fy'] = f(Bs, H, Fh)
-      b['fx'] = f(Bs, W, Fw)
-      b['band'] = torch.zeros((Bs, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32,
-                              device=device)
       st0 = self.plan['ccnn'][0]
-      if self.cache_first and self.direct_attn and st0[0] == 'pair' and d['C0p'] == 4 and \
+      if self.cache_first and st0[0] == 'pair' and d['C0p'] == 4 and \
           ops.first_cache_supported(4, d['ccnn_channels'][1], d['ccnn_channels'][2], d['ccnn_pool'][1], H, W):
         b['l0cache'] = ops.first_cache_alloc(Bs, H, W, device)
       # the 16 workgroups of an image exchange through spin-waits, so ALL workgroups of every launch that
@@ -297,8 +276,7 @@ class DecodeEngine(object):
         b['noise'] = f(T, Bs, H, W)
         b['ysel'] = f(Bs, H, W)
         b['match'] = f(Bs, T)
-        if self.direct_attn:
-          b['box1'] = f(Bs, 1, H, W)
+        b['box1'] = f(Bs, 1, H, W)
       else:
         b['x_patch'] = f(T, Bs, Fh, Fw, d['C0p'])
         hh, ww = Fh, Fw
@@ -314,9 +292,6 @@ class DecodeEngine(object):
             b['adcnn'].append(None)
           else:
             b['adcnn'].append(f(Bs, hh, ww, d['adcnn_channels'][i + 1]))
-        b['u_ws'] = f(Bs, Fh, W)
-        if self.pnet is not None and self.direct_attn and self.pnet.supported(Bs):
-          b['pnet_ws'], b['pnet_status'] = self.pnet.workspace(Bs, device)
       subs.append(b)
     self.glob = g
     self.subs = subs
@@ -332,7 +307,7 @@ class DecodeEngine(object):
     parts = [sb[name] for sb in self.subs]
     if len(parts) == 1:
       return parts[0]
-    dim = 0 if name in ('img', 'fy', 'fx', 'canvas') else 1
+    dim = 0 if name in ('img', 'canvas') else 1
     return torch.cat(parts, dim=dim)
 
   def check_status(self):
@@ -389,7 +364,7 @@ class DecodeEngine(object):
   def _launch_encoder(self, b, tt):
     fill = b['y_out'] if (tt == 0 and b.pop('_fill_rider', False)) else None
     return self._run_cnn(self.plan['ccnn'], self.W['ccnn'], b['img'], b['ccnn'], tt, 'ctrl_cnn',
-                         plane=b.get('canvas'), cache=b.get('l0cache'), fill=fill)
+                         plane=b['canvas'], cache=b.get('l0cache'), fill=fill)
 
   def _prefill_rides(self, b):
     """The y_out prefill can travel on the first timestep's cache-filling pair launch."""
@@ -399,18 +374,17 @@ class DecodeEngine(object):
 
   def _launch_pack(self, b):
     ops.pack_input(b['x'], b.get('d_in'), b.get('y_in'), self.d['C0p'], b['img'],
-                   canvas_plane=b.get('canvas'))  # canvas = 0 (full_model.py:239) in the same pass
-    if 'canvas' in b:
-      if not self.box and not self.d['disable_overwrite']:
-        # every pixel outside an attention window is sigmoid(0 - 5) (full_model.py:813-818): fill
-        # once per forward, the per-timestep paste then writes windows only.  Nothing reads y_out before
-        # the first paste, so the fill (134 MB at cfg2, 28 us as a launch of its own) rides on the first
-        # timestep's first controller-CNN launch, which is MFMA-bound and leaves HBM idle (a side stream
-        # was tried: one forked node makes the captured graph 3x slower to replay, 7.6 vs 2.45 ms pipelined)
-        if self._prefill_rides(b):
-          b['_fill_rider'] = True  # _run_cnn, tt == 0: the fill travels on the first controller-CNN launch
-        else:
-          ops.fill(b['y_out'], 1.0 / (1.0 + math.exp(5.0)))
+                   canvas_plane=b['canvas'])  # canvas = 0 (full_model.py:239) in the same pass
+    if not self.box and not self.d['disable_overwrite']:
+      # every pixel outside an attention window is sigmoid(0 - 5) (full_model.py:813-818): fill
+      # once per forward, the per-timestep paste then writes windows only.  Nothing reads y_out before
+      # the first paste, so the fill (134 MB at cfg2, 28 us as a launch of its own) rides on the first
+      # timestep's first controller-CNN launch, which is MFMA-bound and leaves HBM idle (a side stream
+      # was tried: one forked node makes the captured graph 3x slower to replay, 7.6 vs 2.45 ms pipelined)
+      if self._prefill_rides(b):
+        b['_fill_rider'] = True  # _run_cnn, tt == 0: the fill travels on the first controller-CNN launch
+      else:
+        ops.fill(b['y_out'], 1.0 / (1.0 + math.exp(5.0)))
     # the image channels' share of ctrl-CNN layer 0, b['l0cache'], is written by the first timestep's
     # own launch (its canvas is all zero, so the layer's raw sums ARE that share — _run_cnn, tt == 0)
     if 'l0cache' in b and not self.fill_cache_inline:
@@ -428,43 +402,17 @@ class DecodeEngine(object):
       ops.controller(self.desc, src, Wt['ctrl'], b['h_last'][tt], b['ctrl_out'][tt],
                      b['gmaps'][tt], b['attn'][tt])
     self._mark('controller')
-    direct = self.direct_attn
-    if not direct:
-      ops.attn_filters(b['attn'][tt], H, W, Fh, Fw, b['fy'], b['fx'], b['band'])
-      self._mark('filters')
     if want_box or self.box:
-      if direct:
-        ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0,
-                            b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
-        if self.box:  # dense copy of this step's box for the pairwise-IoU kernel
-          ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0, b['box1'].data_ptr(), H * W)
-      else:
-        ops.attn_box(b['attn'][tt], b['fy'], b['fx'], b['band'], H, W, Fh, Fw, -5.0,
-                     b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
+      ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0, b['attn_box'].data_ptr() + tt * H * W * 4, T * H * W)
+      if self.box:  # dense copy of this step's box for the pairwise-IoU kernel
+        ops.attn_box_direct(b['attn'][tt], H, W, Fh, Fw, -5.0, b['box1'].data_ptr(), H * W)
       self._mark('attn_box')
     if self.box:
       self._box_step(b, tt)
       return
     xp = b['x_patch'][tt]
-    if direct:
-      ops.extract_direct(b['img'], 0, b['attn'][tt], Fh, Fw, d['C0p'], True, xp,
-                         canvas=b['canvas'], canvas_chan=d['D'])
-    else:
-      ops.extract_patch(b['img'], 0, b['attn'][tt], b['fy'], b['fx'], b['band'], Fh, Fw,
-                        d['C0p'], True, xp)
+    ops.extract_direct(b['img'], 0, b['attn'][tt], Fh, Fw, d['C0p'], True, xp, canvas=b['canvas'], canvas_chan=d['D'])
     self._mark('extract')
-    if 'pnet_ws' in b:  # K4: attention CNN + DCNN + score in one launch, then the window-only paste
-      src = b['y_out_patch'][tt]
-      self.pnet(xp, tt, src, b['pnet_ws'], b['pnet_status'], h=b['h_last'][tt], sw=Wt['smlp_w'],
-                sb=Wt['smlp_b'], s_out_ptr=b['s_out'].data_ptr() + tt * 4, s_stride_b=T)
-      self._mark('patchnet')
-      flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | \
-          (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
-      ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
-                       b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
-                       flags=flags)
-      self._mark('paste')
-      return
     src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
     core = src
     L = d['acnn_nlayers']
@@ -483,29 +431,22 @@ class DecodeEngine(object):
                     src1=None if sidx is None else skips[sidx], upsample=(unpool == 2), out=out)
       src = out
     self._mark('attn_dcnn')
-    fused_score = direct and self.fuse_score and self.timing is None
+    fused_score = self.fuse_score and self.timing is None
     if not fused_score:
       ops.dense(b['h_last'][tt], Wt['smlp_w'], Wt['smlp_b'], 'sigmoid',
                 b['s_out'].data_ptr() + tt * 4, T, x1=core.view(core.shape[0], -1))
       self._mark('score')
-    if direct:
-      # y_out was prefilled with sigmoid(beta) (_launch_pack) and after the first paste the canvas
-      # is >= sigmoid(beta) everywhere, so only the attention window is touched
-      flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | \
-          (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
-      if fused_score:  # the score MLP rides on the paste launch (one extra workgroup per image)
-        ops.paste_score_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
-                               b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, b['canvas'], flags,
-                               b['h_last'][tt], core.view(core.shape[0], -1), Wt['smlp_w'], Wt['smlp_b'],
-                               b['s_out'].data_ptr() + tt * 4, T)
-      else:
-        ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
-                         b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'],
-                         flags=flags)
+    # y_out was prefilled with sigmoid(beta) (_launch_pack) and after the first paste the canvas
+    # is >= sigmoid(beta) everywhere, so only the attention window is touched
+    flags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | (ops.PASTE_CANVAS_FLOORED if tt > 0 else 0)
+    if fused_score:  # the score MLP rides on the paste launch (one extra workgroup per image)
+      ops.paste_score_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                             b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, b['canvas'], flags,
+                             b['h_last'][tt], core.view(core.shape[0], -1), Wt['smlp_w'], Wt['smlp_b'],
+                             b['s_out'].data_ptr() + tt * 4, T)
     else:
-      ops.paste_canvas(src, 0, b['attn'][tt], b['fy'], b['fx'], b['band'], -5.0,
-                       d['disable_overwrite'], b['img'], d['D'],
-                       b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, b['u_ws'], H, W)
+      ops.paste_direct(src, 0, b['attn'][tt], -5.0, d['disable_overwrite'],
+                       b['y_out'].data_ptr() + tt * H * W * 4, T * H * W, H, W, canvas=b['canvas'], flags=flags)
     self._mark('paste')
 
   def _run_cnn(self, steps, layers, src, bufs, tt, name, plane=None, cache=None, fill=None):
@@ -550,14 +491,11 @@ class DecodeEngine(object):
     K8 kernel, the picked instance as a weighted sum); the arg-max over T values per image is
     [B,T]-sized bookkeeping."""
     d, T = self.d, self.d['T']
-    box = b['box1'] if 'box1' in b else b['attn_box'][:, tt:tt + 1].contiguous()
+    box = b['box1']
     iou = ops.pair_stats(box, b['box_gt'], want=('iou_soft',))['iou_soft']  # f_inter / f_union, [B,1,T]
     ops.greedy_match(iou.view(iou.shape[0], T), out=b['match'])  # matched = 0, modellib.py:365-379
     ops.weighted_sum(b['match'], b['y_gt'], b['ysel'])
-    if 'canvas' in b:
-      ops.canvas_max(b['canvas'].view(b['canvas'].shape + (1,)), 0, b['ysel'], b['noise'][tt])
-    else:
-      ops.canvas_max(b['img'], d['D'], b['ysel'], b['noise'][tt])
+    ops.canvas_max(b['canvas'].view(b['canvas'].shape + (1,)), 0, b['ysel'], b['noise'][tt])
     nsc = d['nsc']
     ops.dense(b['h_last'][tt], self.W['smlp_w'], self.W['smlp_b'],
               'sigmoid' if nsc == 1 else 'softmax', b['s_out'].data_ptr() + tt * nsc * 4,

@@ -32,12 +32,6 @@ class CtrlDesc(C.Structure):
                                       'dynamic_var', 'fixed_gamma')]
 
 
-class PnetLayer(C.Structure):
-  """struct ra_pnet_layer (include/recattend.h)."""
-  _fields_ = [('wpacked', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('Cin', C.c_int),
-              ('Cout', C.c_int), ('upsample', C.c_int), ('pool', C.c_int), ('relu', C.c_int)]
-
-
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -71,12 +65,6 @@ SIGNATURES = {
     'ra_ctrl_batch_workspace_bytes': (_Z, [C.POINTER(CtrlDesc), _I]),
     'ra_controller_batch_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P]),
     'ra_gaussian_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
-    'ra_attn_band_ints': (_Z, [_I, _I, _I, _I]),
-    'ra_attn_filters_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    'ra_extract_patch_f32': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'ra_paste_canvas_f32': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I,
-                                 _I, _P, _Z, _P, _P]),
-    'ra_attn_box_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     'ra_extract_direct_f32': (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_paste_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _I, _P, _Z, _I, _P]),
     'ra_attn_box_direct_f32': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
@@ -144,9 +132,6 @@ SIGNATURES = {
     'ra_conv_pair_fill_cache_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'ra_conv_pair_fill_cache_rider_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _F, _P]),
     'ra_conv_pair_cached_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
-    'ra_patchnet_supported': (_I, [_P, _I, _I, _I, _I]),
-    'ra_patchnet_workspace_bytes': (_Z, [_P, _I, _I, _I, _I]),
-    'ra_patchnet_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _Z, _P, _Z, _P, _P]),
     'ra_greedy_match_f32': (_I, [_P, _I, _I, _P, _P]),
     'ra_paste_score_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _Z, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _P]),
 }

@@ -310,86 +310,12 @@ def conv_pair_cached(cache, plane, plane_chan, wpA, scA, shA, wpB, scB, shB, cou
   return out
 
 
-class PatchNet(object):
-  """K4: the attention CNN + DCNN (+ score) of a timestep as ONE launch (ra_patchnet_f32).
-  layers: [(wpacked, scale [T,CoutP], shift [T,CoutP], Cin, Cout, upsample, pool)] device tensors."""
-
-  def __init__(self, layers, core_layer, Hp, Wp):
-    self.keep = layers  # the device tensors must outlive the descriptor's raw pointers
-    self.n = len(layers)
-    self.arr = (rn.PnetLayer * self.n)()
-    for i, (wp, sc, sh, cin, cout, ups, pool) in enumerate(layers):
-      _need_cuda(wp, sc, sh)
-      self.arr[i] = rn.PnetLayer(ptr(wp), ptr(sc), ptr(sh), int(cin), int(cout), int(bool(ups)), int(pool), 1)
-    self.core_layer, self.Hp, self.Wp = int(core_layer), int(Hp), int(Wp)
-
-  @staticmethod
-  def structurally_supported(layers_meta, Hp, Wp, B):
-    """layers_meta: [(Cin, Cout, upsample, pool)] — usable before any tensor exists."""
-    arr = (rn.PnetLayer * len(layers_meta))()
-    for i, (cin, cout, ups, pool) in enumerate(layers_meta):
-      arr[i] = rn.PnetLayer(None, None, None, int(cin), int(cout), int(bool(ups)), int(pool), 1)
-    return bool(rn.lib().ra_patchnet_supported(arr, len(layers_meta), int(B), int(Hp), int(Wp)))
-
-  def supported(self, B):
-    return bool(rn.lib().ra_patchnet_supported(self.arr, self.n, int(B), self.Hp, self.Wp))
-
-  def workspace(self, B, device):
-    nb = rn.lib().ra_patchnet_workspace_bytes(self.arr, self.n, int(B), self.Hp, self.Wp)
-    return (torch.zeros((nb + 7) // 8, dtype=torch.int64, device=device),
-            torch.zeros(1, dtype=torch.int32, device=device))
-
-  def __call__(self, x, tt, y, ws, status, h=None, sw=None, sb=None, s_out_ptr=None, s_stride_b=0):
-    _need_cuda(x, y, h, sw, sb)
-    B = x.shape[0]
-    check(rn.lib().ra_patchnet_f32(self.arr, self.n, self.core_layer, ptr(x), B, self.Hp, self.Wp, int(tt),
-                                   ptr(y), ptr(h), 0 if h is None else h.shape[1], ptr(sw), ptr(sb),
-                                   ptr(s_out_ptr), int(s_stride_b), ptr(ws), ws.numel() * 8, ptr(status),
-                                   rn.stream_ptr()), 'ra_patchnet_f32')
-
-
 def controller(desc, feat, wp, h_last, ctrl_out, gmaps, attn):
   _need_cuda(feat, wp, h_last, ctrl_out, gmaps, attn)
   B = feat.shape[0]
   check(rn.lib().ra_controller_f32(C.byref(desc), ptr(feat), ptr(wp), B, ptr(h_last),
                                    ptr(ctrl_out), ptr(gmaps), ptr(attn), rn.stream_ptr()),
         'ra_controller_f32')
-
-
-def band_ints(H, W, Fh, Fw):
-  return rn.lib().ra_attn_band_ints(H, W, Fh, Fw)
-
-
-def attn_filters(attn, H, W, Fh, Fw, fy, fx, band):
-  _need_cuda(attn, fy, fx)
-  check(rn.lib().ra_attn_filters_f32(ptr(attn), attn.shape[0], H, W, Fh, Fw, ptr(fy), ptr(fx),
-                                     ptr(band), rn.stream_ptr()), 'ra_attn_filters_f32')
-
-
-def extract_patch(img, chan0, attn, fy, fx, band, Fh, Fw, Cp, use_gamma, patch):
-  _need_cuda(img, attn, fy, fx, patch)
-  B, H, W, Ci = img.shape
-  check(rn.lib().ra_extract_patch_f32(ptr(img), Ci, chan0, ptr(attn), ptr(fy), ptr(fx),
-                                      ptr(band), B, H, W, Fh, Fw, Cp, int(use_gamma), ptr(patch),
-                                      rn.stream_ptr()), 'ra_extract_patch_f32')
-
-
-def paste_canvas(patch, pc, attn, fy, fx, band, beta, disable_overwrite, img, canvas_chan, y_out,
-                 y_stride_b, u_ws, H, W):
-  _need_cuda(patch, attn, fy, fx, img, u_ws)
-  B, Fh, Fw, Cp = patch.shape
-  Ci = 0 if img is None else img.shape[3]
-  check(rn.lib().ra_paste_canvas_f32(ptr(patch), Cp, pc, ptr(attn), ptr(fy), ptr(fx), ptr(band),
-                                     B, H, W, Fh, Fw, C.c_float(beta), int(disable_overwrite),
-                                     ptr(img), Ci, canvas_chan, ptr(y_out), y_stride_b,
-                                     ptr(u_ws), rn.stream_ptr()), 'ra_paste_canvas_f32')
-
-
-def attn_box(attn, fy, fx, band, H, W, Fh, Fw, beta, out, stride_b):
-  _need_cuda(attn, fy, fx)
-  check(rn.lib().ra_attn_box_f32(ptr(attn), ptr(fy), ptr(fx), ptr(band), attn.shape[0], H, W,
-                                 Fh, Fw, C.c_float(beta), ptr(out), stride_b, rn.stream_ptr()),
-        'ra_attn_box_f32')
 
 
 def extract_direct(img, chan0, attn, Fh, Fw, Cp, use_gamma, patch, canvas=None, canvas_chan=-1):

@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
   assert rc == -1 and b'bad argument' in lib.ra_last_error_string()
   rc = lib.ra_hungarian_f32(None, 1, 2, 2, None, None, None)
   assert rc == -1
-  assert lib.ra_attn_band_ints(512, 512, 48, 48) == 2 * 96 + 2 * 1024
+  assert lib.ra_resample_bwd_workspace_floats(8, 48, 4) == 8 * 48 * 8 and lib.ra_ctrl_train_supported(256, 64, 256, 5, 9) == 1
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -312,75 +312,24 @@ def _attn_rec(B, H, W, rng, big_var=False):
   return rec
 
 
-def _filters(cuda, rec, H, W, Fh=48, Fw=48):
-  B = rec.shape[0]
-  fy = torch.zeros((B, H, Fh), dtype=torch.float32, device=cuda)
-  fx = torch.zeros((B, W, Fw), dtype=torch.float32, device=cuda)
-  band = torch.zeros((B, ops.band_ints(H, W, Fh, Fw)), dtype=torch.int32, device=cuda)
-  ops.attn_filters(dev(rec, cuda), H, W, Fh, Fw, fy, fx, band)
-  return fy, fx, band
-
-
-@pytest.mark.parametrize('H,W,big', [(128, 128, False), (96, 160, True), (512, 512, False)])
-def test_filters_extract_paste(cuda, H, W, big):
+@pytest.mark.parametrize('H,W,big', [(128, 128, False), (96, 160, True)])
+def test_dense_attention_operators(cuda, H, W, big):
+  """The literal operators of modellib — get_gaussian_filter (the [L,F] bank) and extract_patch for given banks —
+  against the oracle (the decode loop and the training step use the banded on-the-fly kernels instead)."""
   rng = np.random.RandomState(H + W)
   B, C = 3, 8
   rec = _attn_rec(B, H, W, rng, big)
-  # box partly outside the image
-  rec[0, 0], rec[0, 1] = 0.02 * H, 0.97 * W
-  fy, fx, band = _filters(cuda, rec, H, W)
+  rec[0, 0], rec[0, 1] = 0.02 * H, 0.97 * W  # box partly outside the image
   r64 = rec.astype(np.float64)
   fy_ref = ora.get_gaussian_filter(r64[:, 0], r64[:, 2], r64[:, 4], H, 48)
   fx_ref = ora.get_gaussian_filter(r64[:, 1], r64[:, 3], r64[:, 5], W, 48)
-  torch.cuda.synchronize()
+  fy = ops.gaussian_filter(dev(rec[:, 0], cuda), dev(rec[:, 2], cuda), dev(rec[:, 4], cuda), H, 48)
+  fx = ops.gaussian_filter(dev(rec[:, 1], cuda), dev(rec[:, 3], cuda), dev(rec[:, 5], cuda), W, 48)
   assert relerr(fy.cpu().numpy(), fy_ref) < 1e-4 and relerr(fx.cpu().numpy(), fx_ref) < 1e-4
-  # dense operator too
-  g = ops.gaussian_filter(dev(rec[:, 0], cuda), dev(rec[:, 2], cuda), dev(rec[:, 4], cuda), H, 48)
-  assert relerr(g.cpu().numpy(), fy_ref) < 1e-4
-  # extract
   img = rng.rand(B, H, W, C).astype(np.float32)
-  patch = torch.zeros((B, 48, 48, C), dtype=torch.float32, device=cuda)
-  ops.extract_patch(dev(img, cuda), 0, dev(rec, cuda), fy, fx, band, 48, 48, C, True, patch)
-  ref = r64[:, 6].reshape(-1, 1, 1, 1) * ora.extract_patch(img.astype(np.float64), fy_ref, fx_ref, C)
-  torch.cuda.synchronize()
-  assert np.abs(patch.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
-  # generic dense operator with the same filters
+  ref = ora.extract_patch(img.astype(np.float64), fy_ref, fx_ref, C)
   pd = ops.extract_patch_dense(dev(img, cuda), fy, fx)
-  assert np.abs(pd.cpu().numpy() * r64[:, 6].reshape(-1, 1, 1, 1) - ref).max() < \
-      2e-5 * max(1.0, np.abs(ref).max())
-  # paste + canvas, two consecutive steps on the same canvas
-  P = rng.randn(B, 48, 48, 1).astype(np.float32)
-  canvas0 = rng.uniform(0, 0.6, (B, H, W, 1)).astype(np.float32)
-  for overwrite in (True, False):
-    imgc = img.copy()
-    imgc[..., 3:4] = canvas0
-    dimg = dev(imgc, cuda)
-    y_out = torch.zeros((B, 2, H, W), dtype=torch.float32, device=cuda)
-    u_ws = torch.zeros((B, 48, W), dtype=torch.float32, device=cuda)
-    ops.paste_canvas(dev(P, cuda), 0, dev(rec, cuda), fy, fx, band, -5.0, overwrite, dimg, 3,
-                     y_out.data_ptr() + H * W * 4, 2 * H * W, u_ws, H, W)
-    torch.cuda.synchronize()
-    yy = ora.extract_patch(P.astype(np.float64), np.transpose(fy_ref, (0, 2, 1)),
-                           np.transpose(fx_ref, (0, 2, 1)), 1)
-    yy = ora.sigmoid(np.exp(r64[:, 8]).reshape(-1, 1, 1, 1) * yy - 5.0)
-    if overwrite:
-      yy = yy * (1 - canvas0.astype(np.float64))
-    cref = np.maximum(yy, canvas0)
-    got = y_out.cpu().numpy()
-    assert (got[:, 0] == 0).all()
-    assert np.abs(got[:, 1] - yy[..., 0]).max() < 1e-5
-    gimg = dimg.cpu().numpy()
-    assert np.abs(gimg[..., 3] - cref[..., 0]).max() < 1e-5
-    assert (gimg[..., [0, 1, 2, 4, 5, 6, 7]] == imgc[..., [0, 1, 2, 4, 5, 6, 7]]).all()
-  # attention box
-  box = torch.zeros((B, H, W), dtype=torch.float32, device=cuda)
-  ops.attn_box(dev(rec, cuda), fy, fx, band, H, W, 48, 48, -5.0, box, H * W)
-  ones = np.ones((B, 48, 48, 1))
-  bref = ora.sigmoid(ora.extract_patch(ones * r64[:, 7].reshape(-1, 1, 1, 1),
-                                       np.transpose(fy_ref, (0, 2, 1)),
-                                       np.transpose(fx_ref, (0, 2, 1)), 1) - 5.0)
-  torch.cuda.synchronize()
-  assert np.abs(box.cpu().numpy() - bref[..., 0]).max() < 2e-5
+  assert np.abs(pd.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize('H,W,big', [(128, 128, False), (96, 160, True), (512, 512, False)])
@@ -497,37 +446,6 @@ def test_dense_pool_affine_pack(cuda):
   ref = np.concatenate([xi, np.zeros((2, 8, 8, 1), np.float32), di, yi,
                         np.zeros((2, 8, 8, 3), np.float32)], 3)
   assert (packed.cpu().numpy() == ref).all()
-
-
-@pytest.mark.parametrize('case', [dict(H=96, W=128, T=2, B=3), dict(H=64, W=64, T=2, B=2, filter_height=32, filter_width=32),
-                                  dict(H=64, W=96, T=2, B=16)],
-                         ids=['patch48_b3', 'patch32_b2', 'patch48_b16'])
-def test_patchnet_fused_vs_per_layer(cuda, case):
-  """K4 (attention CNN + DCNN + score in one launch, 16 workgroups per image exchanging through
-  L2) against the per-layer launches of the same kernels' arithmetic, and against the oracle."""
-  import full_model
-  case = dict(case)
-  H, W, T, B = case.pop('H'), case.pop('W'), case.pop('T'), case.pop('B')
-  opt = ora.make_opt('cvppp', H, W, T, **case)
-  P = ora.random_params(opt, 5)
-  x = np.random.RandomState(6).rand(B, H, W, 3).astype(np.float32)
-  names = ['y_out_patch', 's_out', 'y_out']
-  res = {}
-  for fused in (True, False):
-    m = full_model.get_model(opt).load_weights(P)
-    m.engine.fuse_patchnet = fused
-    for rep in range(3):  # replays: the in-kernel counter re-arm
-      res[fused] = m.run(names, {'x': x, 'phase_train': False}, as_numpy=True)
-    if fused and 'filter_height' not in case:  # the 32x32 patch exceeds the LDS budget: per-layer fallback
-      assert 'pnet_ws' in m.engine.subs[0]
-      assert int(m.engine.subs[0]['pnet_status'].item()) == 0
-    if not fused:
-      assert 'pnet_ws' not in m.engine.subs[0]
-  for a, b in zip(res[True], res[False]):
-    assert np.abs(a - b).max() < 1e-4
-  ref = ora.full_model_forward(opt, P, x[:2])
-  assert np.abs(res[True][0][:2] - ref['y_out_patch']).max() < 1e-3
-  assert np.abs(res[True][1][:2] - ref['s_out']).max() < 1e-3
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 96), (1, 128, 160), (3, 48, 80)])
@@ -655,18 +573,6 @@ def test_conv_winograd(cuda, B, H, W, Ci, Co, pool, relu):
 @pytest.mark.parametrize('B,H,W', [(2, 32, 48), (1, 16, 16), (8, 256, 256)])
 def test_conv_pair_winograd(cuda, B, H, W):
   _pair_winograd_case(cuda, B, H, W)
-
-
-def test_conv_pair_winograd_other_forms(cuda):
-  """The row-block form (2) and the role-split form (3) of the same kernel (the default is the
-  exchange-through-LDS form 1), in fresh processes (the form is read from RA_PAIRW_FORM once per process)."""
-  import os, subprocess, sys
-  for form in ('2', '3'):
-    env = dict(os.environ, RA_PAIRW_FORM=form)
-    code = ('import sys; sys.path[:0] = %r; import torch, test_kernels_gpu as t; '
-            '[t._pair_winograd_case(torch.device("cuda"), *c) for c in ((2, 32, 48), (3, 64, 64))]; print("ok")' % (sys.path[:6],))
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
 
 
 def _pair_winograd_case(cuda, B, H, W):

@@ -77,16 +77,14 @@ def main():
   if want('controller'):
     res['controller'] = (timeit(lambda: ops.controller(eng.desc, src, Wt['ctrl'], b['h_last'][0],
                                                        b['ctrl_out'][0], b['gmaps'][0], b['attn'][0])), 0)
-  if want('filters'):
-    res['filters'] = (timeit(lambda: ops.attn_filters(b['attn'][0], H, W, 48, 48, b['fy'], b['fx'], b['band'])), 0)
   if want('extract'):
-    us = timeit(lambda: ops.extract_patch(b['img'], 0, b['attn'][0], b['fy'], b['fx'], b['band'], 48, 48,
-                                          d['C0p'], True, b['x_patch'][0]))
+    us = timeit(lambda: ops.extract_direct(b['img'], 0, b['attn'][0], 48, 48, d['C0p'], True, b['x_patch'][0],
+                                           canvas=b['canvas'], canvas_chan=d['D']))
     res['extract'] = (us, 0)
   if want('paste'):
     pt = b['y_out_patch'][0]
-    us = timeit(lambda: ops.paste_canvas(pt, 0, b['attn'][0], b['fy'], b['fx'], b['band'], -5.0, False,
-                                         b['img'], d['D'], b['y_out'].data_ptr(), T * H * W, b['u_ws'], H, W))
+    us = timeit(lambda: ops.paste_direct(pt, 0, b['attn'][0], -5.0, False, b['y_out'].data_ptr(), T * H * W, H, W,
+                                         canvas=b['canvas'], flags=ops.PASTE_Y_PREFILLED | ops.PASTE_CANVAS_FLOORED))
     res['paste'] = (us, (S * S * 12.0 * B) / us / 1e3)
   if want('patch'):
     s2 = b['x_patch'][0]
