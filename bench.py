@@ -107,6 +107,28 @@ def pmc_traffic(images, size, name='r03_pmc_encoder_traffic.json'):
   return None
 
 
+def mfma_busy():
+  """Group MFMA-busy fraction of the controller-CNN kernels from the newest committed SQ counter pass
+  (profiles/r0x_pmc_sq_mfma_per_kernel.csv: per-kernel means per dispatch): sum of SQ_VALU_MFMA_BUSY_CYCLES over
+  sum of GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs, each kernel weighted by its launches per timestep."""
+  import csv
+  for rnd in ('r03', 'r02', 'r01'):
+    path = os.path.join(ROOT, 'profiles', rnd + '_pmc_sq_mfma_per_kernel.csv')
+    if not os.path.exists(path):
+      continue
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r['kernel'] for k in ('ra::cpair::', 'ra::wino::', 'ra::conv::conv3x3_mfma<16, 1, 4, 2, 1, false>'))
+            and 'conv_pair8_mfma<4, false>' not in r['kernel']]
+    if not rows:
+      continue
+    base = min(int(r['dispatches']) for r in rows)
+    busy = sum(float(r['SQ_VALU_MFMA_BUSY_CYCLES']) * round(int(r['dispatches']) / base) for r in rows)
+    avail = sum(float(r['GRBM_GUI_ACTIVE']) / 8.0 * 1024.0 * round(int(r['dispatches']) / base) for r in rows)
+    return {'frac': busy / avail, 'source': 'profiles/%s_pmc_sq_mfma_per_kernel.csv' % rnd,
+            'per_kernel': {r['kernel'].split('(')[0].replace('void ', ''): float(r['SQ_VALU_MFMA_BUSY_CYCLES']) / (float(r['GRBM_GUI_ACTIVE']) / 8.0 * 1024.0)
+                           for r in rows}}
+  return None
+
+
 def _cgroup_cpus():
   """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a
   container often sees every host core in os.cpu_count() but is scheduled on far fewer)."""
@@ -551,7 +573,7 @@ def main():
                   'launches per timestep per sub-batch of %d images)' % (d['ccnn_nlayers'],
                                                                        len(eng.plan['ccnn']), Bs),
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(Bs, S),
+        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(Bs, S), 'mfma_busy': mfma_busy(),
         'traffic_note': 'HBM bytes per launch group from committed rocprofv3 --pmc passes '
                         '(profiles/r0x_pmc_encoder_traffic.json; FETCH_SIZE x2 gfx950 correction + '
                         'WRITE_SIZE); null if no pass matches this shape',
