@@ -284,7 +284,7 @@ def ops_group(eng):
   return ra_ops.ctrl_batch_group(eng.desc, eng.subs[0]['img'].shape[0])
 
 
-def train_steps(rank, world, B, T, S, steps, warmup, sync_bn=False):
+def train_steps(rank, world, B, T, S, steps, warmup, sync_bn=False, dtype='f32'):
   """`steps` timed optimisation steps at BASELINE.json configs[3]'s per-GPU shapes (every rank takes part: the
   gradient all-reduce is inside the step).  Returns (elapsed seconds (max over ranks), last loss, model)."""
   import full_model
@@ -294,7 +294,7 @@ def train_steps(rank, world, B, T, S, steps, warmup, sync_bn=False):
   opt.update(use_knob=True, knob_base=1.0, knob_decay=0.9, steps_per_knob_decay=300, knob_box_offset=300,
              knob_segm_offset=500, knob_use_timescale=True, gt_box_ctr_noise=0.05, gt_box_pad_noise=0.1,
              gt_segm_noise=0.3, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000,
-             sync_bn=bool(sync_bn), seed=1234)
+             sync_bn=bool(sync_bn), seed=1234, compute_dtype='bf16' if dtype == 'bf16' else 'float32')
   model = full_model.get_model(opt, is_training=True)
   rng = np.random.RandomState(1234 + rank)
   x, y_gt, s_gt = fmt.synthetic_batch(rng, B, S, S, T)
@@ -311,15 +311,19 @@ def train_steps(rank, world, B, T, S, steps, warmup, sync_bn=False):
   return ra_dist.max_over_ranks(time.perf_counter() - t0), float(loss), model
 
 
-def train_object(rank, world, B, T, S, steps=3):
+DTYPE_NOTE = {'f32': 'float32 throughout',
+              'bf16': 'conv forward / data / filter gradients with bf16 operands on the bf16 MFMA, float32 accumulation; '
+                      'master weights, Adam state, activations, BatchNorm and the loss float32'}
+
+
+def train_object(rank, world, B, T, S, steps=3, dtype='f32'):
   """The `train` object of the default line: the training step timed by the same process."""
   import ra_dist
-  elapsed, loss, model = train_steps(rank, world, B, T, S, steps, 2)
+  elapsed, loss, model = train_steps(rank, world, B, T, S, steps, 2, dtype=dtype)
   obj = {'workload': 'cfg4 shapes: CVPPP-arch full_model TRAINING step, %dx%d, T=%d, B=%d per GPU (global %d), use_knob, in-graph '
-                     'random crop, data-parallel with one flat-bucket all-reduce; float32 (the bf16 variant is not built)'
-                     % (S, S, T, B, B * world),
+                     'random crop, data-parallel with one flat-bucket all-reduce; %s' % (S, S, T, B, B * world, DTYPE_NOTE[dtype]),
          'steps': steps, 'ms_per_step': 1e3 * elapsed / steps, 'value': world * B * T * steps / elapsed,
-         'unit': 'instance-timesteps/s', 'dtype': 'f32', 'final_loss': loss, 'grad_bucket_floats': int(model.trainer.bucket.n),
+         'unit': 'instance-timesteps/s', 'dtype': dtype, 'final_loss': loss, 'grad_bucket_floats': int(model.trainer.bucket.n),
          'hip_graph': bool(model.trainer.use_graph), 'fused_controller': getattr(model.trainer, '_ctl', None) is not None,
          'ranks_in_communicator': ra_dist.comm_size()}
   del model
@@ -329,18 +333,19 @@ def train_object(rank, world, B, T, S, steps=3):
 
 def bench_train(args, rank, world, B, T, S):
   """One step = augmentation + forward (BN batch statistics, GT knobs) + both matchings + backward + gradient
-  all-reduce + clip/Adam on B synthetic CVPPP-shaped images per GPU.  float32 throughout: the
-  bf16 variant BASELINE.json's configs[3] names is not built."""
+  all-reduce + clip/Adam on B synthetic CVPPP-shaped images per GPU.  --dtype f32 (the reference's arithmetic) or
+  bf16 (BASELINE.json configs[3]: model_opt['compute_dtype'] = 'bf16')."""
   import ra_dist
-  elapsed, loss, model = train_steps(rank, world, B, T, S, args.steps, args.warmup, sync_bn=args.sync_bn)
+  elapsed, loss, model = train_steps(rank, world, B, T, S, args.steps, args.warmup, sync_bn=args.sync_bn, dtype=args.dtype)
   if rank == 0:
     print(json.dumps({
         'metric': 'training instance-timesteps/sec (forward + backward + all-reduce + Adam), whole job',
         'value': world * B * T * args.steps / elapsed, 'unit': 'instance-timesteps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'cfg4 shapes: CVPPP-arch full_model TRAINING step, %dx%d, T=%d, B=%d per GPU '
-                               '(global %d), use_knob, data-parallel with one flat-bucket all-reduce' % (S, S, T, B, B * world),
+                               '(global %d), use_knob, data-parallel with one flat-bucket all-reduce; %s'
+                               % (S, S, T, B, B * world, DTYPE_NOTE[args.dtype]),
                    'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
                    'grad_bucket_floats': int(model.trainer.bucket.n),
                    'bn_moments': 'whole batch (sync_bn)' if model.trainer.sync_bn else 'per-rank shard',
@@ -388,6 +393,7 @@ def main():
                   help='cfg2 (default) = the headline workload; cfg3 / cfg5 = the KITTI two-stage and Cityscapes '
                        'configurations of BASELINE.json as their own JSON lines')
   ap.add_argument('--sync_bn', action='store_true', help='--train: BatchNorm moments over the whole data-parallel batch')
+  ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="--train: the conv layers' operand type (model_opt['compute_dtype'])")
   ap.add_argument('--no-train-object', action='store_true', help='skip the `train` object (3 timed training steps) of the default line')
   ap.add_argument('--train', action='store_true',
                   help='time the TRAINING step instead (BASELINE.json configs[3] shapes: B images per GPU, '
@@ -502,12 +508,14 @@ def main():
                  'output': 'y_out + s_out copied to pinned host memory (PCIe inclusive)' if args.host_output else 'left in HBM'},
   }
 
-  train_obj = None
+  train_obj = train_bf16 = None
   if not args.no_train_object:
     train_obj = train_object(rank, world, B, T, S)  # every rank: the step holds the gradient all-reduce
+    train_bf16 = train_object(rank, world, B, T, S, dtype='bf16')
   if rank == 0:
     if train_obj is not None:
       out['train'] = train_obj
+      out['train_bf16'] = train_bf16
     # ---- roofline objects: the launch groups exactly as the product issues them (one
     # sub-batch of Bs images), each captured alone in a HIP graph and replayed between two HIP
     # events on the launch stream, so host launch overhead does not pollute kernel time ----

@@ -106,6 +106,15 @@ int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, 
                    int Cout, int relu, int pool, const float *plane, int plane_chan, float *y,
                    void *stream);
 
+/* Mixed precision for the training step (model_opt['compute_dtype'] = 'bf16'; the reference trains in float32 —
+ * this is an extension behind its option dictionary): the same layer with bf16 OPERANDS — pixels and weights are
+ * rounded to bf16 (round-to-nearest-even) on their way from LDS / registers into v_mfma_f32_16x16x16_bf16 — and
+ * float32 accumulation, epilogue and tensors. */
+int ra_conv3x3_bf16ops_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws,
+                           int upsample, const float *wpacked, const float *scale, const float *shift,
+                           int Cout, int relu, int pool, const float *plane, int plane_chan, float *y,
+                           void *stream);
+
 /* Two consecutive layers fused in one launch (the intermediate activation stays in LDS):
  *   A: conv3x3 + scale/shift [+ReLU], no pool, optional zero-stuffed (stride-2 transposed) input
  *   B: conv3x3 + scale/shift [+ReLU] + max-pool poolB
@@ -534,6 +543,15 @@ int ra_conv3x3_wgrad_f32(const float *x, int Cin, int B, int Hs, int Ws, int ups
 int ra_conv3x3_wgrad_acc_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
                              const float *du, int Cout, float *ws, size_t ws_floats, const int *chan_map,
                              int cin_w, int transposed, float *gw, float *gb, void *stream);
+/* The filter gradient with bf16 operands (x and du rounded to bf16 from LDS, float32 accumulation over the pixels
+ * and float32 partial sums): the mixed-precision counterparts of the two entries above. */
+int ra_conv3x3_wgrad_bf16ops_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
+                                 const float *du, int Cout, float *ws, size_t ws_floats, float *dw,
+                                 float *db, void *stream);
+int ra_conv3x3_wgrad_acc_bf16ops_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
+                                     const float *du, int Cout, float *ws, size_t ws_floats,
+                                     const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
+                                     void *stream);
 int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mean, const float *var,
                                const float *gamma, const float *beta, float eps, int relu, int pool,
                                int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,

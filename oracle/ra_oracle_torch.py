@@ -38,17 +38,64 @@ def t64(a):
   return torch.as_tensor(np.asarray(a, dtype=np.float64)).to(DT)
 
 
+# The product's mixed-precision training mode (model_opt['compute_dtype'] = 'bf16') is an extension the reference does
+# not have.  Its oracle is THIS graph with the conv layers' three products taking bf16-rounded operands — the forward
+# conv(R(x), R(w)), the data gradient convT(R(du), R(w)), the filter / bias gradients corr(R(x), R(du)), sum R(du) —
+# everything else (and every sum) in the oracle's own precision.  R = round to nearest even, as v_cvt_pk_bf16_f32.
+CONV_OPERANDS = None
+
+
+def set_conv_operands(kind):
+  """None (the reference's arithmetic) or 'bf16'."""
+  global CONV_OPERANDS
+  assert kind in (None, 'bf16')
+  CONV_OPERANDS = kind
+
+
+def _bf16_round(t):
+  return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundOperand(torch.autograd.Function):
+  """forward: R(t); backward: the gradient passes (the rounding belongs to the product it feeds, not to t)."""
+
+  @staticmethod
+  def forward(ctx, t):
+    return _bf16_round(t)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g
+
+
+class _RoundGradient(torch.autograd.Function):
+  """forward: identity; backward: R(g) — the layer's output gradient as the backward products read it."""
+
+  @staticmethod
+  def forward(ctx, t):
+    return t.view_as(t)
+
+  @staticmethod
+  def backward(ctx, g):
+    return _bf16_round(g)
+
+
 def conv_same(x, w, b):
   """nnlib.conv2d (nnlib.py:6-12): NHWC x, HWIO w, stride 1, SAME -> NHWC (odd kernels)."""
   k = w.shape[0]
+  if CONV_OPERANDS == 'bf16':
+    x, w = _RoundOperand.apply(x), _RoundOperand.apply(w)
   y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=k // 2)
-  return y.permute(0, 2, 3, 1) + b
+  y = y.permute(0, 2, 3, 1) + b
+  return _RoundGradient.apply(y) if CONV_OPERANDS == 'bf16' else y
 
 
 def deconv_same(x, w, b, stride):
   """nnlib.py:372-376 conv2d_transpose, filter [f,f,out,in], SAME, output = input * stride.
   SURVEY.md §8a trap 2: stride 2, k = 3 is conv_transpose2d(padding=0)[..., :2n, :2n]; stride 1 is
   padding = 1."""
+  if CONV_OPERANDS == 'bf16':
+    x, w = _RoundOperand.apply(x), _RoundOperand.apply(w)
   wt = w.permute(3, 2, 0, 1)  # [in, out, kh, kw]
   xi = x.permute(0, 3, 1, 2)
   if stride == 1:
@@ -56,7 +103,8 @@ def deconv_same(x, w, b, stride):
   else:
     n_h, n_w = x.shape[1] * stride, x.shape[2] * stride
     y = F.conv_transpose2d(xi, wt, stride=stride, padding=0)[:, :, :n_h, :n_w]
-  return y.permute(0, 2, 3, 1) + b
+  y = y.permute(0, 2, 3, 1) + b
+  return _RoundGradient.apply(y) if CONV_OPERANDS == 'bf16' else y
 
 
 def pool(x, r):

@@ -54,6 +54,7 @@ struct Args {
   int bytes0, bytes1, bytes_y;  // tensor sizes for the buffer descriptors (each < 2 GiB)
   const float *plane;           // optional [B,Hs,Ws] plane that REPLACES input channel plane_chan
   int plane_chan, bytes_p;      // (the canvas, kept outside the packed image)
+  int bf16;                     // 1: bf16 operands, float32 accumulation (SWAP layers)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +94,23 @@ struct Geo {
 //   one channel (pool layers: in-register max, one 4-byte store per lane).
 // SWAP = true : weights are the A operand -> a lane's 4 accumulators are 4 consecutive channels of
 //   one pixel (no-pool layers: one 16-byte store per lane instead of four 4-byte stores).
-template <int CK, int NC, int WN, int GX, int GY, bool SWAP>
+// BF16 = true (the training step's mixed-precision mode, model_opt['compute_dtype'] = 'bf16'): the same kernel with
+// bf16 OPERANDS and float32 accumulation — the staged float32 pixels are rounded to bf16 (v_cvt_pk_bf16_f32, RNE)
+// as they leave LDS, the chunk's weights once per chunk, and four k-steps of v_mfma_f32_16x16x4_f32 become ONE
+// v_mfma_f32_16x16x16_bf16 (a lane's 4 k-values = its ksub in the 4 steps: 4 channel groups of a tap for CK = 16,
+// 2 taps x 2 groups for CK = 8, 4 taps for CK = 4; steps beyond the 9 taps carry zero weights).  Tensors in HBM and
+// LDS stay float32; with 1/8 of the matrix-pipe time the kernel is bound by staging, LDS and HBM instead.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+__device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v2, v3}, bf16x2));
+  return __builtin_bit_cast(bf16x4, u32x2{lo, hi});
+}
+
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false>
 __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
   using G = Geo<CK, NC, WN, GX, GY>;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // 2 * G::LDS_FLOATS
@@ -123,6 +140,8 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   f32x4 acc[G::PM][NC];
   float breg[G::KS][NC];
   float bnext[BDB ? G::KS : 1][NC];
+  constexpr int NMF = (G::KS + 3) / 4;  // bf16 MFMAs per chunk and (pixel group, cout group)
+  bf16x4 bpk[BF16 ? NMF : 1][NC];
   // The MFMA is issued as D = W^T-slice x pixels (weights are the A operand), so a lane holds
   // pixel (lane & 15) and, in its 4 accumulator registers, output channels 4*(lane>>4)..+3:
   // the epilogue stores one float4 per lane.  Per-lane epilogue constants, loaded once:
@@ -172,6 +191,19 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       for (int s = 0; s < G::KS; ++s)
 #pragma unroll
         for (int n = 0; n < NC; ++n) breg[s][n] = bnext[s][n];
+    }
+  };
+  auto pack_b = [&]() {  // BF16: the chunk's weights as bf16 quads (k-steps 4f .. 4f+3 of this lane's ksub)
+    if constexpr (BF16) {
+#pragma unroll
+      for (int f = 0; f < NMF; ++f)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+          float w4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w4[j] = (4 * f + j < G::KS) ? breg[(4 * f + j < G::KS) ? 4 * f + j : 0][n] : 0.0f;
+          bpk[f][n] = pack_bf16(w4[0], w4[1], w4[2], w4[3]);
+        }
     }
   };
   auto tile_origin = [&](int T, int &b, int &ty0, int &tx0) {  // wave-uniform (scalar ALU)
@@ -270,6 +302,38 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   };
   auto compute = [&](int buf) {  // MFMA main loop: 9 taps, one wide A read per (tap, group)
     const float *tb = tile + buf * G::LDS_FLOATS;
+    if constexpr (BF16) {
+      constexpr int TPF = 4 / G::NCG;  // taps per bf16 MFMA
+#pragma unroll
+      for (int f = 0; f < NMF; ++f) {
+        bf16x4 apk[G::PM];
+#pragma unroll
+        for (int g = 0; g < G::PM; ++g) {
+          const int gx = g % GX, gy = g / GX;
+          float v4[4];
+#pragma unroll
+          for (int tp = 0; tp < TPF; ++tp) {
+            const int tap = (f * TPF + tp < 9) ? f * TPF + tp : 8;  // beyond the 9 taps: any staged pixel (zero weights)
+            const int ky = tap / 3, kx = tap % 3;
+            const avec av = *reinterpret_cast<const avec *>(&tb[a_base + ((2 * gy + ky) * G::LW + 8 * gx + kx) * G::PIX]);
+#pragma unroll
+            for (int cg = 0; cg < G::NCG; ++cg) {
+              v4[tp * G::NCG + cg] = av[cg];
+            }
+          }
+          apk[g] = pack_bf16(v4[0], v4[1], v4[2], v4[3]);
+        }
+#pragma unroll
+        for (int g = 0; g < G::PM; ++g)
+#pragma unroll
+          for (int n = 0; n < NC; ++n)
+            if constexpr (SWAP)
+              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bpk[f][n], apk[g], acc[g][n], 0, 0, 0);
+            else
+              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(apk[g], bpk[f][n], acc[g][n], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap % 3;
@@ -386,6 +450,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   int T = blockIdx.x, ch = 0, buf = 0;
   if (T >= ntiles) return;
   load_b(0);
+  pack_b();
   load_item(T, 0);
   store_item(0);
   zero_acc();
@@ -408,6 +473,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
     if (nchunks > 1) {
       if constexpr (BDB) swap_b();
       else load_b(nch);
+      pack_b();
     }
     store_item(buf ^ 1);
     __syncthreads();
@@ -417,10 +483,10 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   }
 }
 
-template <int CK, int NC, int WN, int GX, int GY, bool SWAP>
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false>
 int launch_s(const Args &a, int B, hipStream_t st) {
   using G = Geo<CK, NC, WN, GX, GY>;
-  auto kern = conv3x3_mfma<CK, NC, WN, GX, GY, SWAP>;
+  auto kern = conv3x3_mfma<CK, NC, WN, GX, GY, SWAP, BF16>;
   constexpr size_t lds = 2 * G::LDS_FLOATS * sizeof(float);
   static int wgs_per_cu = 0;  // idempotent lazy init
   if (!wgs_per_cu) {
@@ -441,7 +507,11 @@ int launch_s(const Args &a, int B, hipStream_t st) {
 template <int CK, int NC, int WN, int GX, int GY>
 int launch(const Args &a, int B, hipStream_t st) {
   // channel-vector stores pay off when there is no pooling and the channel count allows float4
-  if (a.pool == 1 && (a.Cout & 3) == 0) return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
+  if (a.pool == 1 && (a.Cout & 3) == 0) {
+    if (a.bf16) return launch_s<CK, NC, WN, GX, GY, true, true>(a, B, st);
+    return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
+  }
+  if (a.bf16) return launch_s<CK, NC, WN, GX, GY, false, true>(a, B, st);
   return launch_s<CK, NC, WN, GX, GY, false>(a, B, st);
 }
 
@@ -562,15 +632,15 @@ extern "C" int ra_conv_fold_bn(const float *bias, const float *beta, const float
   return 0;
 }
 
-extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs,
-                              int Ws, int upsample, const float *wpacked, const float *scale,
-                              const float *shift, int Cout, int relu, int pool, const float *plane,
-                              int plane_chan, float *y, void *stream) {
+static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws, int upsample,
+                         const float *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool,
+                         const float *plane, int plane_chan, float *y, void *stream, int bf16) {
   if (!src0 || !wpacked || !scale || !shift || !y || B <= 0 || Hs <= 0 || Ws <= 0 || C0 <= 0 ||
       C1 < 0 || (C1 > 0 && !src1))
     return ra::fail(RA_E_INVALID, "ra_conv3x3_f32: bad argument");
   if (C0 % 4 || C1 % 4) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: C0=%d C1=%d must be %% 4", C0, C1);
   ra::conv::Args a;
+  a.bf16 = bf16;
   a.src0 = src0;
   a.src1 = src1;
   a.wp = wpacked;
@@ -617,4 +687,20 @@ extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int 
     case 8: return ra::conv::dispatch_cout<8>(a, B, st);
     default: return ra::conv::dispatch_cout<4>(a, B, st);
   }
+}
+
+extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs,
+                              int Ws, int upsample, const float *wpacked, const float *scale,
+                              const float *shift, int Cout, int relu, int pool, const float *plane,
+                              int plane_chan, float *y, void *stream) {
+  return conv3x3_entry(src0, C0, src1, C1, B, Hs, Ws, upsample, wpacked, scale, shift, Cout, relu, pool, plane,
+                       plane_chan, y, stream, 0);
+}
+
+extern "C" int ra_conv3x3_bf16ops_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs,
+                                      int Ws, int upsample, const float *wpacked, const float *scale,
+                                      const float *shift, int Cout, int relu, int pool, const float *plane,
+                                      int plane_chan, float *y, void *stream) {
+  return conv3x3_entry(src0, C0, src1, C1, B, Hs, Ws, upsample, wpacked, scale, shift, Cout, relu, pool, plane,
+                       plane_chan, y, stream, 1);
 }

@@ -685,7 +685,19 @@ constexpr int WTH = 8, WTW = 32, WLW = WTW + 2, WLH = WTH + 2;
 // (9 + bias).  PACK = Cin (4 or 8): the M rows are (tap, channel) pairs, 9 * Cin of them in
 // ceil(9 * Cin / 16) tiles — 3 instead of 9 k-step MFMAs per pixel quad for Cin = 4 (where 12 of the 16
 // channel rows were zero), 5 for Cin = 8; a lane reads its row's pixel through a per-tile LDS offset.
-template <int NT, int PACK = 0>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
+// BF16 (compute_dtype = 'bf16'): the staged float32 pixels are rounded to bf16 as they leave LDS and four K steps
+// (16 consecutive pixels of a row) go through ONE v_mfma_f32_16x16x16_bf16; accumulation stays float32.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+__device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v2, v3}, bf16x2));
+  return __builtin_bit_cast(bf16x4, u32x2{lo, hi});
+}
+
+template <int NT, int PACK = 0, bool BF16 = false>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
                                                     int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
                                                     int ntiles, float *part) {
@@ -749,6 +761,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
       const int row = wave * 2 + rr;
+      if constexpr (BF16) {
+#pragma unroll
+        for (int s0 = 0; s0 < WTW / 16; ++s0) {
+          const int col = 16 * s0 + ksub;  // this lane's pixels: col, col + 4, col + 8, col + 12
+          bf16x4 bv[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const float *q = tu + (row * WTW + col) * CP + 16 * n + m;
+            bv[n] = pack_bf16(q[0], q[4 * CP], q[8 * CP], q[12 * CP]);
+          }
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const float *q = tx + (row * WLW + col) * 16 + aoff[t];
+            const bf16x4 av = pack_bf16(q[0], q[64], q[128], q[192]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv[n], acc[t][n], 0, 0, 0);
+          }
+          const bf16x4 one = bf16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[MT][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(one, bv[n], acc[MT][n], 0, 0, 0);
+        }
+        continue;
+      }
 #pragma unroll 2
       for (int s = 0; s < WTW / 4; ++s) {
         const int col = 4 * s + ksub;  // this lane's pixel within the K step
@@ -977,7 +1012,7 @@ namespace {
 // sums are added to gw / gb in the reference layout (chan_map, cin_w, transposed as in wgrad_final_acc_kernel)
 int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du, int Cout, float *ws,
                size_t ws_floats, float *dw, float *db, bool acc, const int *chan_map, int cin_w, int transposed,
-               void *stream) {
+               void *stream, bool bf16 = false) {
   if (!x || !du || !ws || !dw || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
     return fail(RA_E_INVALID, "ra_conv3x3_wgrad_f32: bad argument");
   const int cp = ra_conv_cout_padded(Cout);
@@ -993,16 +1028,20 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
   const size_t lds_red = (size_t)10 * 16 * per * sizeof(float);
   const size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
   hipStream_t st = as_stream(stream);
-#define RA_WGRAD(NT, PACK)                                                                                        \
+#define RA_WGRAD_T(NT, PACK, BF)                                                                                  \
   {                                                                                                               \
     static bool attr = false;                                                                                     \
     if (!attr) {                                                                                                  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<NT, PACK>),                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<NT, PACK, BF>),                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);                         \
       attr = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL((wgrad_kernel<NT, PACK>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, H, \
-                       W, Cout, tiles_x, tiles_y, ntiles, ws);                                                   \
+    hipLaunchKernelGGL((wgrad_kernel<NT, PACK, BF>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, \
+                       H, W, Cout, tiles_x, tiles_y, ntiles, ws);                                                \
+  }
+#define RA_WGRAD(NT, PACK)                                                                                        \
+  {                                                                                                               \
+    if (bf16) RA_WGRAD_T(NT, PACK, true) else RA_WGRAD_T(NT, PACK, false)                                         \
   }
   static int pack_ok = -1;  // RA_WGRAD_PACK=0: tuning aid, channel rows for every Cin
   if (pack_ok < 0) {
@@ -1020,6 +1059,7 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
     default: RA_WGRAD(4, 0) break;
   }
 #undef RA_WGRAD
+#undef RA_WGRAD_T
   const int total = 9 * Cin * Cout + Cout;
   if (acc)
     hipLaunchKernelGGL(wgrad_final_acc_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout,
@@ -1041,6 +1081,19 @@ extern "C" int ra_conv3x3_wgrad_acc_f32(const float *x, int Cin, int B, int Hs, 
   if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_acc_f32: cin_w %d", cin_w);
   return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w, transposed ? 1 : 0,
                     stream);
+}
+
+extern "C" int ra_conv3x3_wgrad_bf16ops_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
+                                            int Cout, float *ws, size_t ws_floats, float *dw, float *db, void *stream) {
+  return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, dw, db, false, nullptr, Cin, 0, stream, true);
+}
+
+extern "C" int ra_conv3x3_wgrad_acc_bf16ops_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
+                                                int Cout, float *ws, size_t ws_floats, const int *chan_map, int cin_w,
+                                                int transposed, float *gw, float *gb, void *stream) {
+  if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_acc_bf16ops_f32: cin_w %d", cin_w);
+  return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w, transposed ? 1 : 0,
+                    stream, true);
 }
 
 extern "C" int ra_lstm_cell_f32(const float *pre, const float *c_prev, int B, int hid, float *h, float *c, float *act,

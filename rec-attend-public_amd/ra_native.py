@@ -50,6 +50,7 @@ SIGNATURES = {
     'ra_conv_pack_weights': (_I, [_P, _I, _I, _I, _P, _I, _P]),
     'ra_conv_fold_bn': (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _P]),
     'ra_conv3x3_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    'ra_conv3x3_bf16ops_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_conv_pair_supported': (_I, [_I, _I, _I]),
     'ra_conv_pair_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_ctrl_packed_floats': (_Z, [C.POINTER(CtrlDesc)]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     'ra_conv_pack_weights_dev': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_conv3x3_wgrad_workspace_floats': (_Z, [_I, _I, _I, _I, _I]),
     'ra_conv3x3_wgrad_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _P, _P]),
+    'ra_conv3x3_wgrad_bf16ops_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _P, _P]),
     'ra_conv_wino_supported': (_I, [_I, _I, _I, _I, _I]),
     'ra_conv_wino_packed_floats': (_Z, [_I, _I]),
     'ra_conv_wino_pack_weights': (_I, [_P, _I, _I, _P]),
@@ -123,6 +125,7 @@ SIGNATURES = {
     'ra_lstm_cell_f32': (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     'ra_lstm_cell_bwd_f32': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     'ra_conv3x3_wgrad_acc_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
+    'ra_conv3x3_wgrad_acc_bf16ops_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
     'ra_bn_act_pool_bwd_acc_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _P]),
     'ra_subsample_odd_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'ra_weighted_sum_multi_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -177,8 +177,9 @@ def controller_batch(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
 
 
 def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample=False,
-            out=None, plane=None, plane_chan=-1):
-  """One fused conv layer.  src0 [B,Hs,Ws,C0] (+ src1 [B,Hs,Ws,C1]) -> [B,Ho,Wo,cout]."""
+            out=None, plane=None, plane_chan=-1, bf16=False):
+  """One fused conv layer.  src0 [B,Hs,Ws,C0] (+ src1 [B,Hs,Ws,C1]) -> [B,Ho,Wo,cout].
+  bf16: bf16 operands on the bf16 MFMA, float32 accumulation (the training step's mixed-precision mode)."""
   _need_cuda(src0, src1, wp, scale, shift, out)
   B, Hs, Ws, C0 = src0.shape
   C1 = 0 if src1 is None else src1.shape[3]
@@ -186,10 +187,10 @@ def conv3x3(src0, wp, scale, shift, cout, relu=True, pool=1, src1=None, upsample
   Ho, Wo = Hs * up // pool, Ws * up // pool
   if out is None:
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=src0.device)
-  check(rn.lib().ra_conv3x3_f32(ptr(src0), C0, ptr(src1), C1, B, Hs, Ws, int(upsample), ptr(wp),
-                                ptr(scale), ptr(shift), int(cout), int(relu), int(pool),
-                                ptr(plane), int(plane_chan), ptr(out), rn.stream_ptr()),
-        'ra_conv3x3_f32')
+  fn = rn.lib().ra_conv3x3_bf16ops_f32 if bf16 else rn.lib().ra_conv3x3_f32
+  check(fn(ptr(src0), C0, ptr(src1), C1, B, Hs, Ws, int(upsample), ptr(wp), ptr(scale), ptr(shift), int(cout),
+           int(relu), int(pool), ptr(plane), int(plane_chan), ptr(out), rn.stream_ptr()),
+        'ra_conv3x3_bf16ops_f32' if bf16 else 'ra_conv3x3_f32')
   return out
 
 

@@ -352,7 +352,7 @@ class ConvBNActPool(torch.autograd.Function):
       if hit is None:
         hit = cache[key] = (b, torch.nn.functional.pad(b.detach(), (0, cp - cout)))
       shift = hit[1]
-    u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2))
+    u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2), bf16=bool(meta.get('bf16')))
     H, W = u.shape[1], u.shape[2]
     use_bn = gamma is not None
     mean = var = None
@@ -395,6 +395,9 @@ class ConvBNActPool(torch.autograd.Function):
     nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, B, H, W)
     wws = _f(nws, device=dev)
     synced = ctx.n_total > 0.0 and ctx.n_total != float(B * H * W)
+    bf = bool(meta.get('bf16'))  # compute_dtype = 'bf16': bf16 operands on the bf16 MFMA, float32 sums and tensors
+    wgrad_acc = rn.lib().ra_conv3x3_wgrad_acc_bf16ops_f32 if bf else rn.lib().ra_conv3x3_wgrad_acc_f32
+    wgrad_out = rn.lib().ra_conv3x3_wgrad_bf16ops_f32 if bf else rn.lib().ra_conv3x3_wgrad_f32
 
     def bn_backward(acc_g, acc_b):
       """dgamma / dbeta / du; with whole-batch statistics the two per-channel sums are all-reduced between the
@@ -435,22 +438,20 @@ class ConvBNActPool(torch.autograd.Function):
         side = _wgrad_stream(dev)
         side.wait_stream(torch.cuda.current_stream())  # du is ready
         with torch.cuda.stream(side):
-          check(rn.lib().ra_conv3x3_wgrad_acc_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
-                                                  ptr(cmap_t), int(cin_w), int(tr), ptr(gw), ptr(gb), rn.stream_ptr()),
-                'ra_conv3x3_wgrad_acc_f32')
+          check(wgrad_acc(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
+                          ptr(cmap_t), int(cin_w), int(tr), ptr(gw), ptr(gb), rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_f32')
         _WGRAD['keep'].extend((x, du, wws))
       else:
-        check(rn.lib().ra_conv3x3_wgrad_acc_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
-                                                ptr(cmap_t), int(cin_w), int(tr), ptr(gw), ptr(gb), rn.stream_ptr()),
-              'ra_conv3x3_wgrad_acc_f32')
+        check(wgrad_acc(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
+                        ptr(cmap_t), int(cin_w), int(tr), ptr(gw), ptr(gb), rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_f32')
       dw = db = None
       dgamma = dbeta = None
     else:
       dgamma, dbeta = bn_backward(None, None)
       # ---- backward-weight (of the SAME conv that ran) + bias
       dWf, db = _f(3, 3, Cx, cout, device=dev), _f(cout, device=dev)
-      check(rn.lib().ra_conv3x3_wgrad_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
-                                          ptr(dWf), ptr(db), rn.stream_ptr()), 'ra_conv3x3_wgrad_f32')
+      check(wgrad_out(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
+                      ptr(dWf), ptr(db), rn.stream_ptr()), 'ra_conv3x3_wgrad_f32')
       if cmap is not None:  # packed kernel channels -> the filter's own input channels
         real = torch.zeros((3, 3, cin_w, cout), dtype=torch.float32, device=dev)
         for c, j in enumerate(cmap):
@@ -469,7 +470,7 @@ class ConvBNActPool(torch.autograd.Function):
       ones = _const('ones', cpb, dev, lambda: torch.ones(cpb, dtype=torch.float32, device=dev))
       zeros = _const('zeros', cpb, dev, lambda: torch.zeros(cpb, dtype=torch.float32, device=dev))
       wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr, ctx.cache)
-      dxr = ops.conv3x3(duc, wpb, ones, zeros, cin_w, relu=False, pool=1)
+      dxr = ops.conv3x3(duc, wpb, ones, zeros, cin_w, relu=False, pool=1, bf16=bf)
       if stride == 2:
         sub = _f(B, Hs, Ws, cin_w, device=dev)
         check(rn.lib().ra_subsample_odd_f32(ptr(dxr), B, Hs, Ws, cin_w, ptr(sub), rn.stream_ptr()),
@@ -954,6 +955,13 @@ class TrainStep(object):
     # one all-reduce backward.  Collectives inside a captured HIP graph have not been exercised on this stack, so
     # the synchronised step runs eagerly.
     self.sync_bn = bool(self.opt.get('sync_bn', False)) and self.world > 1
+    # model_opt['compute_dtype']: 'float32' (the reference's arithmetic) or 'bf16' — the conv layers' forward, data
+    # and filter gradients take bf16 operands on the bf16 MFMA with float32 accumulation; master weights, Adam state,
+    # activations, BatchNorm, the loss and every other kernel stay float32
+    cd = str(self.opt.get('compute_dtype', 'float32')).lower()
+    if cd not in ('float32', 'f32', 'fp32', 'bf16', 'bfloat16'):
+      raise rn.RecAttendError("model_opt['compute_dtype'] = %r: 'float32' or 'bf16'" % cd)
+    self.bf16 = cd in ('bf16', 'bfloat16')
     if self.sync_bn:
       self.use_graph = False
     rank = dist.get_rank() if self.world > 1 else 0
@@ -1001,7 +1009,7 @@ class TrainStep(object):
       key = '%s_%d_%d' % (scope, i, tt)
       meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None,
                   stat_out=self._stat_views.get(key), grads=self._grad_views(scope, i, key, bn), cache=self._pack,
-                  sync_bn=self.sync_bn)
+                  sync_bn=self.sync_bn, bf16=self.bf16)
       x, mean, var = ConvBNActPool.apply(_pad_channels(x) if i else x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -1027,7 +1035,7 @@ class TrainStep(object):
             [-1] * (skp.shape[3] - len(smap))
         x = torch.cat([xp, skp], dim=3)
       meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key),
-                  grads=self._grad_views(scope, i, key, bn), cache=self._pack, sync_bn=self.sync_bn)
+                  grads=self._grad_views(scope, i, key, bn), cache=self._pack, sync_bn=self.sync_bn, bf16=self.bf16)
       x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:

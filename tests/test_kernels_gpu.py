@@ -61,6 +61,81 @@ def test_conv3x3(cuda, B, H, W, Ci, Co, pool, relu):
   assert relerr(y, ref) < 2e-5
 
 
+def _bf16(a):
+  """float32 -> nearest bf16 (ties to even) -> float32: what v_cvt_pk_bf16_f32 does to an operand."""
+  return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().float().numpy()
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,relu', [
+    (2, 32, 32, 4, 8, True), (1, 64, 48, 8, 16, True), (3, 48, 48, 16, 32, True), (2, 24, 24, 32, 32, False),
+    (2, 16, 16, 32, 64, True), (1, 12, 12, 64, 96, True), (1, 20, 36, 24, 16, True), (8, 64, 64, 16, 16, True),
+    (2, 40, 56, 12, 8, True)])
+def test_conv3x3_bf16_operands(cuda, B, H, W, Ci, Co, relu):
+  """ra_conv3x3_bf16ops_f32 (the training step's compute_dtype = 'bf16'): bf16 operands, float32 accumulation.
+  Against the float64 oracle ON THE ROUNDED OPERANDS the bar is float32 round-off (products of two bf16 numbers are
+  exact in float32, only the summation order differs) — that pins the rounding mode and the k-packing; against the
+  oracle on the unrounded operands the bar is the bf16 one: 2^-8 per operand over a 9*Cin-term sum, 1e-2 of the
+  output scale."""
+  rng = np.random.RandomState(B * 1000 + H + Ci + Co)
+  x = rng.randn(B, H, W, Ci).astype(np.float32)
+  w = (rng.randn(3, 3, Ci, Co) / np.sqrt(9 * Ci)).astype(np.float32)
+  b = (rng.randn(Co) * 0.1).astype(np.float32)
+
+  def ref_of(xa, wa):
+    r = ora.conv2d(xa.astype(np.float64), wa.astype(np.float64)) + b
+    return ora.relu(r) if relu else r
+  wp = dev(ops.pack_conv_weights(w), cuda)
+  sc, sh = ops.fold_bn(b, Co, None)
+  y = ops.conv3x3(dev(x, cuda), wp, dev(sc, cuda), dev(sh, cuda), Co, relu=relu, pool=1, bf16=True)
+  y32 = ops.conv3x3(dev(x, cuda), wp, dev(sc, cuda), dev(sh, cuda), Co, relu=relu, pool=1)
+  torch.cuda.synchronize()
+  y, y32 = y.cpu().numpy(), y32.cpu().numpy()
+  assert relerr(y, ref_of(_bf16(x), _bf16(w))) < 2e-5
+  assert relerr(y, ref_of(x, w)) < 1e-2
+  assert np.abs(y - y32).max() > 0  # the bf16 kernel really ran (the float32 one is exact to 2e-5 of the unrounded oracle)
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,ups', [(2, 32, 32, 4, 8, 0), (1, 24, 40, 8, 16, 0), (2, 16, 48, 16, 32, 0),
+                                            (1, 16, 16, 32, 64, 0), (2, 8, 12, 16, 8, 1), (1, 33, 35, 12, 16, 0),
+                                            (1, 16, 16, 64, 96, 0)])
+def test_conv3x3_wgrad_bf16_operands(cuda, B, H, W, Ci, Co, ups):
+  """ra_conv3x3_wgrad_bf16ops_f32: dW[ky,kx,ci,co] = sum over pixels of x[.. + tap, ci] * du[.., co] and db = sum du,
+  with x and du rounded to bf16 (float32 sums).  Same two bars as the forward kernel."""
+  rng = np.random.RandomState(7 * B + H + Ci + Co)
+  Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+  x = rng.randn(B, Hs, Ws, Ci).astype(np.float32)
+  du = rng.randn(B, H, W, Co).astype(np.float32)
+
+  def ref_of(xa, da):
+    xa, da = xa.astype(np.float64), da.astype(np.float64)
+    if ups:  # the conv that ran saw x zero-stuffed at the odd positions (nnlib.dcnn's stride-2 transposed conv)
+      z = np.zeros((B, H, W, Ci))
+      z[:, 1::2, 1::2] = xa
+      xa = z
+    xp = np.pad(xa, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    dw = np.zeros((3, 3, Ci, Co))
+    for ky in range(3):
+      for kx in range(3):
+        dw[ky, kx] = np.einsum('bhwc,bhwd->cd', xp[:, ky:ky + H, kx:kx + W], da)
+    return dw, da.sum(axis=(0, 1, 2))
+  nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Ci, Co, B, H, W)
+  ws = torch.empty(nws, device=cuda)
+  out = {}
+  xd, dud = dev(x, cuda), dev(du, cuda)
+  for name, fn in (('bf16', rn.lib().ra_conv3x3_wgrad_bf16ops_f32), ('f32', rn.lib().ra_conv3x3_wgrad_f32)):
+    dw, db = torch.empty(3, 3, Ci, Co, device=cuda), torch.empty(Co, device=cuda)
+    ops.check(fn(ops.ptr(xd), Ci, B, Hs, Ws, ups, ops.ptr(dud), Co, ops.ptr(ws), nws, ops.ptr(dw), ops.ptr(db),
+                 rn.stream_ptr()), name)
+    torch.cuda.synchronize()
+    out[name] = (dw.cpu().numpy(), db.cpu().numpy())
+  rw, rb = ref_of(_bf16(x), _bf16(du))
+  assert relerr(out['bf16'][0], rw) < 2e-5 and relerr(out['bf16'][1], rb) < 2e-5
+  uw, ub = ref_of(x, du)
+  assert relerr(out['bf16'][0], uw) < 1e-2 and relerr(out['bf16'][1], ub) < 1e-2
+  assert relerr(out['f32'][0], uw) < 2e-5
+  assert np.abs(out['bf16'][0] - out['f32'][0]).max() > 0
+
+
 @pytest.mark.parametrize('B,H,W,Cx,Cs,Co,stride', [
     (2, 6, 6, 32, 0, 32, 2),
     (2, 12, 12, 32, 0, 32, 1),
