@@ -115,6 +115,18 @@ int ra_conv3x3_bf16ops_f32(const float *src0, int C0, const float *src1, int C1,
                            int Cout, int relu, int pool, const float *plane, int plane_chan, float *y,
                            void *stream);
 
+/* The training forward of a BatchNorm layer (nnlib.py:98: tf.nn.moments of the conv output over batch, height, width):
+ * ra_conv3x3_moments_f32 is ra_conv3x3_f32 / _bf16ops_f32 (pool 1, Cout % 4 == 0, no canvas plane) whose epilogue also
+ * leaves per-wave channel sums of its output y BEFORE the ReLU in `part` (ra_conv3x3_moments_part_floats(Cout) floats;
+ * *nparts = records written, a host int); ra_bn_moments_from_partials_f32 combines them (Chan's update, float64) into
+ * mean[C] / var[C] (biased, as tf.nn.moments).  One small launch instead of two more passes over y. */
+size_t ra_conv3x3_moments_part_floats(int Cout);
+int ra_conv3x3_moments_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws,
+                           int upsample, const float *wpacked, const float *scale, const float *shift,
+                           int Cout, int relu, int bf16_operands, float *y, float *part, size_t part_floats,
+                           int *nparts, void *stream);
+int ra_bn_moments_from_partials_f32(const float *part, int nparts, int C, float *mean, float *var, void *stream);
+
 /* Two consecutive layers fused in one launch (the intermediate activation stays in LDS):
  *   A: conv3x3 + scale/shift [+ReLU], no pool, optional zero-stuffed (stride-2 transposed) input
  *   B: conv3x3 + scale/shift [+ReLU] + max-pool poolB
@@ -552,6 +564,18 @@ int ra_conv3x3_wgrad_acc_bf16ops_f32(const float *x, int Cin, int B, int Hs, int
                                      const float *du, int Cout, float *ws, size_t ws_floats,
                                      const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
                                      void *stream);
+/* A layer whose filter is shared by the T timesteps of a training step (every nnlib.cnn / dcnn layer of full_model:
+ * one set of weights, full_model.py:455-535) sums its T filter gradients.  _partial runs only the MFMA pass of
+ * ra_conv3x3_wgrad_f32 and leaves the per-workgroup partial sums in ws (accumulate = 0: overwrite — the layer's
+ * first call of the step; 1: add to what the earlier calls left; same B, H, W, Cin, Cout every time, calls
+ * stream-ordered); _finish_acc reduces them once per layer and step into gw / gb exactly as
+ * ra_conv3x3_wgrad_acc_f32 does.  T - 1 finishing launches per layer less; fixed summation order. */
+int ra_conv3x3_wgrad_partial_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
+                                 const float *du, int Cout, float *ws, size_t ws_floats, int accumulate,
+                                 int bf16_operands, void *stream);
+int ra_conv3x3_wgrad_finish_acc_f32(const float *ws, size_t ws_floats, int Cin, int Cout, int B, int H, int W,
+                                    const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
+                                    void *stream);
 int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mean, const float *var,
                                const float *gamma, const float *beta, float eps, int relu, int pool,
                                int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,

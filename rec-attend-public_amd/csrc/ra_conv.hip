@@ -54,7 +54,9 @@ struct Args {
   int bytes0, bytes1, bytes_y;  // tensor sizes for the buffer descriptors (each < 2 GiB)
   const float *plane;           // optional [B,Hs,Ws] plane that REPLACES input channel plane_chan
   int plane_chan, bytes_p;      // (the canvas, kept outside the packed image)
-  int bf16;                     // 1: bf16 operands, float32 accumulation (SWAP layers)
+  int bf16;                     // 1: bf16 operands, float32 accumulation
+  float *mom_part;              // MOM kernels: per-(workgroup, wave row) channel sums of the pre-activation output
+  int *nparts_out;              // host: the number of partial records the launch writes (grid * WM)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -110,8 +112,14 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
   return __builtin_bit_cast(bf16x4, u32x2{lo, hi});
 }
 
-template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false>
+// MOM = true (training, SWAP layers without pooling): the epilogue also accumulates, per lane, the count, sum and sum
+// of squares of every output value u = acc * scale + shift (BEFORE the ReLU) about a per-wave pivot — the wave's first
+// output of that channel — and the wave leaves one record {n, S1, S2, pivot} per channel in a.mom_part
+// [(workgroup * WM + wave row)][CoutP][4].  tf.nn.moments of the layer (nnlib.py:98) then costs one small finishing
+// launch (ra_bn_moments_from_partials_f32: Chan's combination in float64) instead of two more passes over u.
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false>
 __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
+  static_assert(!MOM || SWAP, "batch moments ride on the channel-vector epilogue");
   using G = Geo<CK, NC, WN, GX, GY>;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // 2 * G::LDS_FLOATS
   constexpr int NPIX = G::LH * G::LW;        // pixel records of one staged chunk
@@ -162,6 +170,13 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.y, a.bytes_y);
   const __amdgpu_buffer_rsrc_t rsp = make_rsrc(a.plane ? a.plane : a.src0, a.plane ? a.bytes_p : 0);
   f32x4 st[NST][G::NCG];
+  f32x4 ms1[MOM ? NC : 1], ms2[MOM ? NC : 1], mpv[MOM ? NC : 1];  // moments about the pivot, per lane
+  float mcnt = 0.f;
+  bool mhave = false;  // the pivots are set by the first tile
+  if constexpr (MOM) {
+#pragma unroll
+    for (int n = 0; n < NC; ++n) ms1[n] = ms2[n] = mpv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   auto zero_acc = [&]() {
 #pragma unroll
@@ -421,6 +436,20 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       for (int g = 0; g < G::PM; ++g) {
         const int gx = g % GX, gy = g / GX;
         f32x4 v = acc[g][n] * sc4[n] + sh4[n];
+        if constexpr (MOM) {
+          if (g == 0 && !mhave) {  // pivot: this wave's first output of the channel (pixel lane 0 of the 16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mpv[n][r] = __shfl(v[r], lane & 48, 64);
+          }
+          const bool okp = (lrow + 2 * gy < a.H) & (lcol + 8 * gx < a.W);
+          const f32x4 d = v - mpv[n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ms1[n][r] += okp ? d[r] : 0.f;
+            ms2[n][r] += okp ? d[r] * d[r] : 0.f;
+          }
+          if (n == 0) mcnt += okp ? 1.f : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
         if (opool == 2) {  // the 2x2 window = lanes 4q..4q+3
@@ -445,6 +474,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
         }
       }
     }
+    mhave = true;
   };
 
   int T = blockIdx.x, ch = 0, buf = 0;
@@ -481,12 +511,32 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
     T = nT;
     ch = nch;
   }
+  if constexpr (MOM) {  // the wave's record: sums over its 16 pixel lanes, one float4 {n, S1, S2, pivot} per channel
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      mcnt += __shfl_xor(mcnt, o, 64);
+#pragma unroll
+      for (int n = 0; n < NC; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ms1[n][r] += __shfl_xor(ms1[n][r], o, 64);
+          ms2[n][r] += __shfl_xor(ms2[n][r], o, 64);
+        }
+    }
+    if ((lane & 15) == 0) {
+      f32x4 *rec = reinterpret_cast<f32x4 *>(a.mom_part) + (size_t)(blockIdx.x * G::WM + wm) * a.CoutP;
+#pragma unroll
+      for (int n = 0; n < NC; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rec[16 * (wn * NC + n) + 4 * ksub + r] = f32x4{mcnt, ms1[n][r], ms2[n][r], mpv[n][r]};
+    }
+  }
 }
 
-template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false>
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false>
 int launch_s(const Args &a, int B, hipStream_t st) {
   using G = Geo<CK, NC, WN, GX, GY>;
-  auto kern = conv3x3_mfma<CK, NC, WN, GX, GY, SWAP, BF16>;
+  auto kern = conv3x3_mfma<CK, NC, WN, GX, GY, SWAP, BF16, MOM>;
   constexpr size_t lds = 2 * G::LDS_FLOATS * sizeof(float);
   static int wgs_per_cu = 0;  // idempotent lazy init
   if (!wgs_per_cu) {
@@ -500,6 +550,7 @@ int launch_s(const Args &a, int B, hipStream_t st) {
   const int ntiles = tiles_x * tiles_y * B;
   const int cap = wgs_per_cu * num_cus();
   const int grid = ntiles < cap ? ntiles : cap;
+  if (a.nparts_out) *a.nparts_out = grid * G::WM;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv3x3_f32");
 }
@@ -508,9 +559,14 @@ template <int CK, int NC, int WN, int GX, int GY>
 int launch(const Args &a, int B, hipStream_t st) {
   // channel-vector stores pay off when there is no pooling and the channel count allows float4
   if (a.pool == 1 && (a.Cout & 3) == 0) {
+    if (a.mom_part) {
+      if (a.bf16) return launch_s<CK, NC, WN, GX, GY, true, true, true>(a, B, st);
+      return launch_s<CK, NC, WN, GX, GY, true, false, true>(a, B, st);
+    }
     if (a.bf16) return launch_s<CK, NC, WN, GX, GY, true, true>(a, B, st);
     return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
   }
+  if (a.mom_part) return ra::fail(RA_E_SHAPE, "ra_conv3x3_moments_f32: needs pool 1 and Cout %% 4 == 0 (Cout %d, pool %d)", a.Cout, a.pool);
   if (a.bf16) return launch_s<CK, NC, WN, GX, GY, false, true>(a, B, st);
   return launch_s<CK, NC, WN, GX, GY, false>(a, B, st);
 }
@@ -634,13 +690,16 @@ extern "C" int ra_conv_fold_bn(const float *bias, const float *beta, const float
 
 static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws, int upsample,
                          const float *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool,
-                         const float *plane, int plane_chan, float *y, void *stream, int bf16) {
+                         const float *plane, int plane_chan, float *y, void *stream, int bf16, float *mom_part = nullptr,
+                         int *nparts = nullptr) {
   if (!src0 || !wpacked || !scale || !shift || !y || B <= 0 || Hs <= 0 || Ws <= 0 || C0 <= 0 ||
       C1 < 0 || (C1 > 0 && !src1))
     return ra::fail(RA_E_INVALID, "ra_conv3x3_f32: bad argument");
   if (C0 % 4 || C1 % 4) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: C0=%d C1=%d must be %% 4", C0, C1);
   ra::conv::Args a;
   a.bf16 = bf16;
+  a.mom_part = mom_part;
+  a.nparts_out = nparts;
   a.src0 = src0;
   a.src1 = src1;
   a.wp = wpacked;
@@ -695,6 +754,21 @@ extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int 
                               int plane_chan, float *y, void *stream) {
   return conv3x3_entry(src0, C0, src1, C1, B, Hs, Ws, upsample, wpacked, scale, shift, Cout, relu, pool, plane,
                        plane_chan, y, stream, 0);
+}
+
+extern "C" size_t ra_conv3x3_moments_part_floats(int Cout) {
+  const int cp = ra_conv_cout_padded(Cout);
+  return (size_t)4 * ra::conv::num_cus() * 4 * cp * 4;  // <= 4 workgroups per CU x 4 wave rows x CoutP records of 4 floats
+}
+
+extern "C" int ra_conv3x3_moments_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws,
+                                      int upsample, const float *wpacked, const float *scale, const float *shift, int Cout,
+                                      int relu, int bf16_operands, float *y, float *part, size_t part_floats, int *nparts,
+                                      void *stream) {
+  if (!part || !nparts || part_floats < ra_conv3x3_moments_part_floats(Cout))
+    return ra::fail(RA_E_WORKSPACE, "ra_conv3x3_moments_f32: partial buffer");
+  return conv3x3_entry(src0, C0, src1, C1, B, Hs, Ws, upsample, wpacked, scale, shift, Cout, relu, 1, nullptr, -1, y, stream,
+                       bf16_operands ? 1 : 0, part, nparts);
 }
 
 extern "C" int ra_conv3x3_bf16ops_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs,

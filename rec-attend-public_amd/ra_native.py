@@ -50,6 +50,9 @@ SIGNATURES = {
     'ra_conv_pack_weights': (_I, [_P, _I, _I, _I, _P, _I, _P]),
     'ra_conv_fold_bn': (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _P]),
     'ra_conv3x3_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    'ra_conv3x3_moments_part_floats': (_Z, [_I]),
+    'ra_conv3x3_moments_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P, _P]),
+    'ra_bn_moments_from_partials_f32': (_I, [_P, _I, _I, _P, _P, _P]),
     'ra_conv3x3_bf16ops_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     'ra_conv_pair_supported': (_I, [_I, _I, _I]),
     'ra_conv_pair_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
@@ -125,6 +128,8 @@ SIGNATURES = {
     'ra_lstm_cell_f32': (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     'ra_lstm_cell_bwd_f32': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     'ra_conv3x3_wgrad_acc_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
+    'ra_conv3x3_wgrad_partial_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _I, _I, _P]),
+    'ra_conv3x3_wgrad_finish_acc_f32': (_I, [_P, _Z, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     'ra_conv3x3_wgrad_acc_bf16ops_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
     'ra_bn_act_pool_bwd_acc_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _P]),
     'ra_subsample_odd_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),

@@ -323,6 +323,32 @@ def _pad_channels(t, mult=4):
   return out
 
 
+EPILOGUE_MOMENTS = {'on': os.environ.get('RA_EPI_MOMENTS', '1') != '0'}  # tuning aid: 0 = the two-pass moments kernels
+
+
+class _DeferredWgrads(dict):
+  """(scope, layer) -> the layer's filter-gradient partial sums of the running backward pass; as the end-of-backward
+  callback it reduces every layer's partials ONCE into the bucket (T - 1 finishing launches per layer less than one
+  per timestep)."""
+  armed = False
+
+  def reset(self):
+    """A new forward pass: nothing of an interrupted backward pass may be added to."""
+    self.armed = False
+    for slot in self.values():
+      slot['used'] = False
+
+  def __call__(self):
+    self.armed = False
+    for slot in self.values():
+      if slot['used']:
+        Cx, cout, B, H, W, _, _, cin_w, tr = slot['shape']
+        check(rn.lib().ra_conv3x3_wgrad_finish_acc_f32(ptr(slot['ws']), slot['ws'].numel(), Cx, cout, B, H, W,
+                                                       ptr(slot['cmap_t']), cin_w, tr, ptr(slot['gw']), ptr(slot['gb']),
+                                                       rn.stream_ptr()), 'ra_conv3x3_wgrad_finish_acc_f32')
+        slot['used'] = False
+
+
 class ConvBNActPool(torch.autograd.Function):
   """One layer of nnlib.cnn (nnlib.py:229-253) or nnlib.dcnn (nnlib.py:362-400) in training mode.
 
@@ -352,15 +378,31 @@ class ConvBNActPool(torch.autograd.Function):
       if hit is None:
         hit = cache[key] = (b, torch.nn.functional.pad(b.detach(), (0, cp - cout)))
       shift = hit[1]
-    u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2), bf16=bool(meta.get('bf16')))
-    H, W = u.shape[1], u.shape[2]
     use_bn = gamma is not None
+    bf = bool(meta.get('bf16'))
     mean = var = None
     if use_bn:
       mean, var = meta['stat_out'] if meta.get('stat_out') is not None else (_f(cout, device=dev), _f(cout, device=dev))
-      ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
-      check(rn.lib().ra_bn_moments_f32(ptr(u), B * H * W, cout, ptr(ws), ws.numel(), ptr(mean), ptr(var),
-                                       rn.stream_ptr()), 'ra_bn_moments_f32')
+    if use_bn and cout % 4 == 0 and EPILOGUE_MOMENTS['on']:
+      # the batch moments ride on the conv epilogue: per-wave channel sums, then one small finishing launch
+      up = 2 if stride == 2 else 1
+      u = _f(B, Hs * up, Ws * up, cout, device=dev)
+      part = _f(rn.lib().ra_conv3x3_moments_part_floats(cout), device=dev)
+      nparts = _C.c_int(0)
+      check(rn.lib().ra_conv3x3_moments_f32(ptr(x), Cx, None, 0, B, Hs, Ws, int(stride == 2), ptr(wp), ptr(scale), ptr(shift),
+                                            cout, 0, int(bf), ptr(u), ptr(part), part.numel(), _C.byref(nparts),
+                                            rn.stream_ptr()), 'ra_conv3x3_moments_f32')
+      check(rn.lib().ra_bn_moments_from_partials_f32(ptr(part), nparts.value, cout, ptr(mean), ptr(var), rn.stream_ptr()),
+            'ra_bn_moments_from_partials_f32')
+      H, W = u.shape[1], u.shape[2]
+    else:
+      u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2), bf16=bf)
+      H, W = u.shape[1], u.shape[2]
+      if use_bn:
+        ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
+        check(rn.lib().ra_bn_moments_f32(ptr(u), B * H * W, cout, ptr(ws), ws.numel(), ptr(mean), ptr(var),
+                                         rn.stream_ptr()), 'ra_bn_moments_f32')
+    if use_bn:
       # whole-batch statistics under data parallelism (nnlib.py:98): one all_gather of (count, mean, var)
       ctx.n_total = sync_moments(mean, var, B * H * W) if meta.get('sync_bn') else 0.0
     y = _f(B, H // pool, W // pool, cout, device=dev)
@@ -434,7 +476,22 @@ class ConvBNActPool(torch.autograd.Function):
       if cmap is not None:
         real = [j for j in cmap if j >= 0]
         assert len(set(real)) == len(real), 'chan_map must be injective (one writer per gradient element)'
-      if _WGRAD['on']:
+      defer = meta.get('wgrad_defer')
+      if defer is not None:
+        # the filter is shared by the step's timesteps: this call only adds its per-workgroup partial sums to the
+        # layer's buffer; the end-of-backward callback (_DeferredWgrads) reduces each layer ONCE
+        if not defer.armed:
+          defer.armed = True
+          torch.autograd.Variable._execution_engine.queue_callback(defer)
+        slot = defer.get(meta['wgrad_key'])
+        if slot is None:
+          slot = defer[meta['wgrad_key']] = dict(ws=_f(nws, device=dev), used=False)
+        shape = (Cx, cout, B, H, W, int(stride == 2), tuple(cmap) if cmap is not None else None, int(cin_w), int(tr))
+        assert slot.setdefault('shape', shape) == shape, 'a deferred filter gradient needs one shape per layer'
+        check(rn.lib().ra_conv3x3_wgrad_partial_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(slot['ws']), nws,
+                                                    int(slot['used']), int(bf), rn.stream_ptr()), 'ra_conv3x3_wgrad_partial_f32')
+        slot.update(used=True, cmap_t=cmap_t, gw=gw, gb=gb)
+      elif _WGRAD['on']:
         side = _wgrad_stream(dev)
         side.wait_stream(torch.cuda.current_stream())  # du is ready
         with torch.cuda.stream(side):
@@ -944,6 +1001,7 @@ class TrainStep(object):
     self.bucket = GradBucket(model)
     self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else int(world)
     self._pack = {}  # this trainer's per-step cache of packed filters / padded biases / packed LSTM weights
+    self._wgrad_parts = _DeferredWgrads()
     self._graphs = {}
     self.leaves = {}
     for k in self.bucket.names:
@@ -1000,6 +1058,8 @@ class TrainStep(object):
     return tuple(g[n] for n in names)
 
   fuse_param_grads = True
+  defer_wgrad = True  # one finishing reduction of the filter gradient per layer and step (not one per timestep)
+
   match_side_stream = os.environ.get('RA_MATCH_SIDE', '1') != '0'  # the box matching under the mask matching (one fork / join)
 
   def _cnn(self, x, scope, n, pools, tt, cmap0, stats):
@@ -1009,7 +1069,8 @@ class TrainStep(object):
       key = '%s_%d_%d' % (scope, i, tt)
       meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None,
                   stat_out=self._stat_views.get(key), grads=self._grad_views(scope, i, key, bn), cache=self._pack,
-                  sync_bn=self.sync_bn, bf16=self.bf16)
+                  sync_bn=self.sync_bn, bf16=self.bf16, wgrad_defer=self._wgrad_parts if self.defer_wgrad else None,
+                  wgrad_key=(scope, i))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x) if i else x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -1035,7 +1096,8 @@ class TrainStep(object):
             [-1] * (skp.shape[3] - len(smap))
         x = torch.cat([xp, skp], dim=3)
       meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key),
-                  grads=self._grad_views(scope, i, key, bn), cache=self._pack, sync_bn=self.sync_bn, bf16=self.bf16)
+                  grads=self._grad_views(scope, i, key, bn), cache=self._pack, sync_bn=self.sync_bn, bf16=self.bf16,
+                  wgrad_defer=self._wgrad_parts if self.defer_wgrad else None, wgrad_key=(scope, i))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -1174,6 +1236,7 @@ class TrainStep(object):
     Cityscapes architectures (full_model.py:165-194)."""
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    self._wgrad_parts.reset()
     if getattr(self, '_ctl', None) is not None:
       self._ctl.begin_step()
     dev = self.bucket.param.device
@@ -1461,6 +1524,7 @@ class BoxTrainStep(TrainStep):
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    self._wgrad_parts.reset()
     if getattr(self, '_ctl', None) is not None:
       self._ctl.begin_step()
     dev = self.bucket.param.device

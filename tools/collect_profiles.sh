@@ -35,11 +35,15 @@ rm -rf $OUT/trace $OUT/trace4 $OUT/pmc_*_f $OUT/pmc_*_w $OUT/pmc_sq
 # the traffic files must be in profiles/ for the bench line to pick them up
 cp $OUT/${R3}_pmc_encoder_traffic.json $OUT/${R3}_pmc_attn_traffic.json profiles/ 2>/dev/null
 timeout 900 python bench.py > $OUT/${R3}_bench_n1.json 2> $OUT/bench.err
-timeout 900 python bench.py --train --steps 4 --warmup 3 > $OUT/${R3}_train_n1.json 2>> $OUT/bench.err
-$R --kernel-trace --stats -d $OUT/trace_train -o t -- python bench.py --train --steps 4 --warmup 2 > $OUT/trace_train.json 2> $OUT/trace_train.log
-cp $(find $OUT/trace_train -name '*kernel_stats.csv' | head -1) $OUT/${R3}_train_kernel_stats.csv
-timeout 60 python tools/kernel_families.py $OUT/${R3}_train_kernel_stats.csv 6 > $OUT/${R3}_train_kernel_families.txt
-rm -rf $OUT/trace_train
+for DT in f32 bf16; do
+  SUF=""; [ $DT = bf16 ] && SUF="_bf16"
+  timeout 900 python bench.py --train --dtype $DT --steps 4 --warmup 3 > $OUT/${R3}_train${SUF}_n1.json 2>> $OUT/bench.err
+  $R --kernel-trace --stats -d $OUT/trace_train -o t -- python bench.py --train --dtype $DT --steps 4 --warmup 2 > $OUT/trace_train.json 2> $OUT/trace_train.log
+  cp $(find $OUT/trace_train -name '*kernel_stats.csv' | head -1) $OUT/${R3}_train${SUF}_kernel_stats.csv
+  # one steady-state step out of the trace (the stats file above also holds model set-up and the eager first step)
+  timeout 120 python tools/kernel_families.py $(find $OUT/trace_train -name '*kernel_trace.csv' | head -1) 30 > $OUT/${R3}_train${SUF}_kernel_families.txt
+  rm -rf $OUT/trace_train
+done
 timeout 900 python bench.py --config cfg3 > $OUT/${R3}_bench_cfg3.json 2>> $OUT/bench.err
 timeout 900 python bench.py --config cfg5 > $OUT/${R3}_bench_cfg5.json 2>> $OUT/bench.err
 timeout 120 tools/bin/attn_probe 8 > $OUT/${R3}_attn_probe.txt 2>&1
