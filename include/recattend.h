@@ -638,6 +638,14 @@ int ra_knob_mix_f32(const float *ctr, const float *size, const float *match, con
 int ra_knob_mix_bwd_f32(const float *g_ctr2, const float *g_size2, const float *knob, int knob_stride, int B,
                         float *d_ctr, float *d_size, void *stream);
 int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
+/* The canvas update of a training timestep (full_model.py:826-848, stop_canvas_grad) and the next timestep's packed
+ * controller-CNN input in one launch: inp_next = inp_prev [B,HW,C] with channel canvas_chan replaced by
+ * max(y_c, canvas), y_c = y [B,HW], or with the ground-truth knob (match [B,T] != NULL)
+ * knob[b] * (g - g * noise) + (1 - knob[b]) * y,  g = sum_t match[b,t] y_gt[b,t,:]  (noise [B,HW] nullable;
+ * knob read at stride knob_stride).  No gradient flows through it. */
+int ra_canvas_step_f32(const float *inp_prev, int C, int canvas_chan, int B, int HW, const float *y,
+                       const float *match, const float *y_gt, int T, const float *noise, const float *knob,
+                       int knob_stride, float *inp_next, void *stream);
 int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
                               int HW, float *out, void *stream);
 

@@ -524,8 +524,51 @@ __global__ __launch_bounds__(256) void weighted_sum_multi_kernel(const float *w,
   *reinterpret_cast<f32x4 *>(out + ((size_t)b * N + n) * HW + e) = acc;
 }
 
+// ---- the canvas of the next timestep (full_model.py:826-848), written straight into the next packed controller-CNN
+// input: per pixel   g = sum_t match[b,t] y_gt[b,t,p];  g -= g * noise[b,p];  y_c = knob[b] g + (1 - knob[b]) y[b,p];
+// canvas' = max(y_c, canvas)   (no knob: y_c = y), every product and sum rounded on its own like the element-wise
+// chain it replaces.  nxt[b,p,:] = prev[b,p,:] with channel `cc` = canvas'.  C in {4, 8, ...}: one float4 group of the
+// pixel holds the canvas; the other groups are copied. ----
+__global__ __launch_bounds__(256) void canvas_step_kernel(const f32x4 *prev, int C4, int cc, int HW, const float *y,
+                                                          const float *match, const float *y_gt, int T, const float *noise,
+                                                          const float *knob, int knob_stride, f32x4 *nxt) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const size_t px = (size_t)b * HW + p;
+  float yc = y[px];
+  if (match) {
+    float g = 0.f;
+    const float *yb = y_gt + (size_t)b * T * HW + p;
+    for (int t = 0; t < T; ++t) {
+      const float wt = match[(size_t)b * T + t];
+      if (wt != 0.f) g = __fadd_rn(g, __fmul_rn(wt, yb[(size_t)t * HW]));  // uniform per image
+    }
+    if (noise) g = __fsub_rn(g, __fmul_rn(g, noise[px]));
+    const float k = knob[(size_t)b * knob_stride];
+    yc = __fadd_rn(__fmul_rn(k, g), __fmul_rn(__fsub_rn(1.0f, k), yc));
+  }
+  const int cg = cc >> 2, cl = cc & 3;
+  for (int q = 0; q < C4; ++q) {
+    f32x4 v = prev[px * C4 + q];
+    if (q == cg) v[cl] = fmaxf(yc, v[cl]);
+    nxt[px * C4 + q] = v;
+  }
+}
+
 }  // namespace train
 }  // namespace ra
+
+extern "C" int ra_canvas_step_f32(const float *inp_prev, int C, int canvas_chan, int B, int HW, const float *y, const float *match,
+                                  const float *y_gt, int T, const float *noise, const float *knob, int knob_stride,
+                                  float *inp_next, void *stream) {
+  if (!inp_prev || !y || !inp_next || B <= 0 || HW <= 0 || C <= 0 || C % 4 || canvas_chan < 0 || canvas_chan >= C ||
+      (match && (!y_gt || !knob || T <= 0 || knob_stride < 1)))
+    return fail(RA_E_INVALID, "ra_canvas_step_f32: bad argument");
+  hipLaunchKernelGGL(train::canvas_step_kernel, dim3(ceil_div(HW, 256), B), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const train::f32x4 *>(inp_prev), C / 4, canvas_chan, HW, y, match, y_gt, T, noise, knob,
+                     knob_stride, reinterpret_cast<train::f32x4 *>(inp_next));
+  return launch_status("ra_canvas_step_f32");
+}
 
 extern "C" size_t ra_bn_workspace_floats(int C) { return (size_t)ra::train::kRedBlocks * 2 * (C > 0 ? C : 1); }
 

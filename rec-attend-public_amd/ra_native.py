@@ -132,6 +132,7 @@ SIGNATURES = {
     'ra_conv3x3_wgrad_finish_acc_f32': (_I, [_P, _Z, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     'ra_conv3x3_wgrad_acc_bf16ops_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
     'ra_bn_act_pool_bwd_acc_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _P]),
+    'ra_canvas_step_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P]),
     'ra_subsample_odd_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'ra_weighted_sum_multi_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'ra_conv_first_cache_supported': (_I, [_I, _I, _I, _I, _I, _I]),

@@ -1256,15 +1256,15 @@ class TrainStep(object):
       if knobs is None:
         knobs = self.draw_knobs(B, generator)
       ctr_gtn, size_gtn, knob_box, knob_segm = self._knob_setup(y_gt, knobs)
-      ysel = torch.empty((B, H, W), device=dev)
     canvas = torch.zeros((B, H, W, 1), device=dev)
     stats, y_list, s_list, box_list, cn_list, ls_list, iou_box_steps = {}, [], [], [], [], [], []
     dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
     head_flags = (1 if d['squash'] else 0) | (2 if d['fixed_var'] else 0) | (4 if d['dynamic_var'] else 0) | (8 if d['fixed_gamma'] else 0)
+    cc = x.shape[3]  # the canvas channel of the packed input
+    inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
+    if inp.shape[3] != d['C0p']:
+      inp = _pad_channels(inp)
     for tt in range(T):
-      inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
-      if inp.shape[3] != d['C0p']:
-        inp = _pad_channels(inp)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
       h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
       # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
@@ -1301,19 +1301,20 @@ class TrainStep(object):
       y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
       y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)  # [B,H,W]
       if d['disable_overwrite']:
-        y = (1.0 - canvas[..., 0]) * y
+        y = (1.0 - inp[..., cc]) * y
       s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
-      y_c = y.detach()
-      if use_knob:  # kick in the (noisy) ground-truth segmentation for the canvas (:826-841)
-        if fixed:
-          gsel = y_gt[:, tt]
-        else:
-          ops.weighted_sum(gmatch, y_gt, ysel)
-          gsel = ysel
-        gsel = gsel - gsel * knobs['segm_noise'][tt]
-        ks = knob_segm[:, tt, :, None]
-        y_c = ks * gsel + (1 - ks) * y_c
-      canvas = torch.maximum(y_c[..., None], canvas)             # stop_canvas_grad (full_model.py:843-848)
+      # canvas <- max(y_c, canvas) with y_c = y, or with the knob: the (noisy) matched ground-truth segmentation mixed in
+      # (:826-848, stop_canvas_grad) — and the next timestep's packed input, in one launch (ra_canvas_step_f32)
+      nxt = torch.empty_like(inp)
+      yd = y.detach().contiguous()
+      if use_knob:
+        noise, ks = knobs['segm_noise'][tt].contiguous(), knob_segm[:, tt]
+        check(rn.lib().ra_canvas_step_f32(ptr(inp), inp.shape[3], cc, B, H * W, ptr(yd), ptr(gsel_box), ptr(y_gt), T, ptr(noise),
+                                          ptr(ks), int(ks.stride(0)), ptr(nxt), rn.stream_ptr()), 'ra_canvas_step_f32')
+      else:
+        check(rn.lib().ra_canvas_step_f32(ptr(inp), inp.shape[3], cc, B, H * W, ptr(yd), None, None, T, None, None, 1, ptr(nxt),
+                                          rn.stream_ptr()), 'ra_canvas_step_f32')
+      inp = nxt
       y_list.append(y)
       s_list.append(s)
       box_list.append(box)
