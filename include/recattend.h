@@ -576,6 +576,15 @@ int ra_conv3x3_wgrad_partial_f32(const float *x, int Cin, int B, int Hs, int Ws,
 int ra_conv3x3_wgrad_finish_acc_f32(const float *ws, size_t ws_floats, int Cin, int Cout, int B, int H, int W,
                                     const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
                                     void *stream);
+/* ... or in ONE pass over the images of all T calls: ra_conv3x3_wgrad_multi_acc_f32 is ra_conv3x3_wgrad_acc_f32 on
+ * nseg * Bseg images read through two device tables of nseg pointers (x [Bseg,Hs,Ws,Cin] and du [Bseg,H,W,Cout] of
+ * each call; workspace for B = nseg * Bseg).  ra_ptr_table writes up to 64 device pointers given as a HOST array into
+ * a device table by a kernel launch, so that the tables can be built inside a captured HIP graph. */
+int ra_ptr_table(const void *const *host_ptrs, int n, void **dev_table, void *stream);
+int ra_conv3x3_wgrad_multi_acc_f32(const void *const *xtab, const void *const *dutab, int nseg, int Cin, int Bseg,
+                                   int Hs, int Ws, int upsample, int Cout, float *ws, size_t ws_floats,
+                                   const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
+                                   int bf16_operands, void *stream);
 int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mean, const float *var,
                                const float *gamma, const float *beta, float eps, int relu, int pool,
                                int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,

@@ -792,7 +792,8 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
 template <int NT, int PACK = 0, bool BF16 = false>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
                                                     int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
-                                                    int ntiles, float *part, int accum) {
+                                                    int ntiles, float *part, int accum, const float *const *xtab,
+                                                    const float *const *dutab, int Bseg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tx = lds;                      // [WLH][WLW][16]   input slice + halo, channel-contiguous
   float *tu = lds + WLH * WLW * 16;     // [WTH][WTW][16*NT] output gradient tile
@@ -822,7 +823,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
   }
   const int per = tiles_x * tiles_y;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int b = tile / per, tr = tile - b * per;
+    int b = tile / per;
+    const int tr = tile - b * per;
+    if (xtab) {  // the images of several calls of the layer (one per timestep): segment tables, Bseg images each
+      const int seg = b / Bseg;
+      x = xtab[seg];
+      du = dutab[seg];
+      b -= seg * Bseg;
+    }
     const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
     __syncthreads();  // the previous tile's MFMA reads are complete
     for (int e = tid; e < WLH * WLW * 4; e += 256) {  // input slice: one float4 (4 channels) per item
@@ -1109,7 +1117,9 @@ namespace {
 // sums are added to gw / gb in the reference layout (chan_map, cin_w, transposed as in wgrad_final_acc_kernel)
 int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du, int Cout, float *ws,
                size_t ws_floats, float *dw, float *db, bool acc, const int *chan_map, int cin_w, int transposed,
-               void *stream, bool bf16 = false, int mode = 0) {  // mode 1 / 2: partials only (overwrite / accumulate)
+               void *stream, bool bf16 = false, int mode = 0,  // mode 1 / 2: partials only (overwrite / accumulate)
+               const float *const *xtab = nullptr, const float *const *dutab = nullptr, int Bseg = 0) {
+  if (xtab) x = du = reinterpret_cast<const float *>(xtab);  // (not read: the tables are)
   if (!x || !du || !ws || (!dw && mode == 0) || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
     return fail(RA_E_INVALID, "ra_conv3x3_wgrad_f32: bad argument");
   const int cp = ra_conv_cout_padded(Cout);
@@ -1134,7 +1144,7 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
       attr = true;                                                                                                \
     }                                                                                                             \
     hipLaunchKernelGGL((wgrad_kernel<NT, PACK, BF>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, \
-                       H, W, Cout, tiles_x, tiles_y, ntiles, ws, mode == 2 ? 1 : 0);                             \
+                       H, W, Cout, tiles_x, tiles_y, ntiles, ws, mode == 2 ? 1 : 0, xtab, dutab, Bseg);          \
   }
 #define RA_WGRAD(NT, PACK)                                                                                        \
   {                                                                                                               \
@@ -1192,6 +1202,43 @@ extern "C" int ra_conv3x3_wgrad_acc_bf16ops_f32(const float *x, int Cin, int B, 
   if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_acc_bf16ops_f32: cin_w %d", cin_w);
   return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w, transposed ? 1 : 0,
                     stream, true);
+}
+
+namespace ra {
+namespace train {
+struct PtrTable {
+  const float *p[64];
+};
+__global__ __launch_bounds__(64) void ptr_table_kernel(const PtrTable t, int n, const float **out) {
+#pragma unroll
+  for (int i = 0; i < 64; ++i)
+    if ((int)threadIdx.x == i && i < n) out[i] = t.p[i];
+}
+}  // namespace train
+}  // namespace ra
+
+// Up to 64 device pointers (a HOST array) -> a device table, as a kernel launch (capturable in a HIP graph, where a
+// host-to-device copy of pageable memory is not): the segment tables of ra_conv3x3_wgrad_multi_acc_f32.
+extern "C" int ra_ptr_table(const void *const *host_ptrs, int n, void **dev_table, void *stream) {
+  if (!host_ptrs || !dev_table || n <= 0 || n > 64) return fail(RA_E_INVALID, "ra_ptr_table: 1..64 pointers");
+  ra::train::PtrTable t{};
+  for (int i = 0; i < n; ++i) t.p[i] = static_cast<const float *>(host_ptrs[i]);
+  hipLaunchKernelGGL(ra::train::ptr_table_kernel, dim3(1), dim3(64), 0, as_stream(stream), t, n,
+                     (const float **)dev_table);
+  return launch_status("ra_ptr_table");
+}
+
+// The filter gradient of a layer over the images of SEVERAL calls (its T timesteps in a training step) in one pass:
+// xtab / dutab are device tables of nseg pointers to the calls' x [Bseg,Hs,Ws,Cin] and du [Bseg,H,W,Cout].
+extern "C" int ra_conv3x3_wgrad_multi_acc_f32(const void *const *xtab, const void *const *dutab, int nseg, int Cin, int Bseg,
+                                              int Hs, int Ws, int upsample, int Cout, float *ws, size_t ws_floats,
+                                              const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
+                                              int bf16_operands, void *stream) {
+  if (!xtab || !dutab || nseg <= 0 || Bseg <= 0) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_multi_acc_f32: bad argument");
+  if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_multi_acc_f32: cin_w %d", cin_w);
+  return wgrad_impl(nullptr, Cin, nseg * Bseg, Hs, Ws, upsample, nullptr, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w,
+                    transposed ? 1 : 0, stream, bf16_operands != 0, 0, reinterpret_cast<const float *const *>(xtab),
+                    reinterpret_cast<const float *const *>(dutab), Bseg);
 }
 
 extern "C" int ra_conv3x3_wgrad_partial_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,

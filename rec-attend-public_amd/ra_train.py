@@ -327,26 +327,38 @@ EPILOGUE_MOMENTS = {'on': os.environ.get('RA_EPI_MOMENTS', '1') != '0'}  # tunin
 
 
 class _DeferredWgrads(dict):
-  """(scope, layer) -> the layer's filter-gradient partial sums of the running backward pass; as the end-of-backward
-  callback it reduces every layer's partials ONCE into the bucket (T - 1 finishing launches per layer less than one
-  per timestep)."""
+  """(scope, layer) -> the (x, du) pairs of the layer's calls in the running backward pass.  A filter shared by the
+  step's T timesteps (every nnlib.cnn / dcnn layer of full_model, full_model.py:455-535) sums T filter gradients; as
+  the end-of-backward callback this object forms each layer's sum in ONE pass over the images of all its calls
+  (ra_conv3x3_wgrad_multi_acc_f32 through two pointer tables): 4 launches per layer and step instead of 2 T, and the
+  patch-sized layers' fixed costs (launch, cross-wave reduction, partial sums) are paid once, not T times."""
   armed = False
 
   def reset(self):
     """A new forward pass: nothing of an interrupted backward pass may be added to."""
     self.armed = False
     for slot in self.values():
-      slot['used'] = False
+      slot['calls'] = []
 
   def __call__(self):
     self.armed = False
     for slot in self.values():
-      if slot['used']:
-        Cx, cout, B, H, W, _, _, cin_w, tr = slot['shape']
-        check(rn.lib().ra_conv3x3_wgrad_finish_acc_f32(ptr(slot['ws']), slot['ws'].numel(), Cx, cout, B, H, W,
-                                                       ptr(slot['cmap_t']), cin_w, tr, ptr(slot['gw']), ptr(slot['gb']),
-                                                       rn.stream_ptr()), 'ra_conv3x3_wgrad_finish_acc_f32')
-        slot['used'] = False
+      calls, slot['calls'] = slot['calls'], []
+      Cx, cout, B, Hs, Ws, H, W, ups, _, cin_w, tr, bf = slot['shape']
+      for k in range(0, len(calls), 64):
+        part = calls[k:k + 64]
+        n = len(part)
+        nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, n * B, H, W)
+        if slot['ws'] is None or slot['ws'].numel() < nws:
+          slot['ws'] = _f(nws, device=slot['tab'].device)
+        tab = slot['tab']
+        for off, col in ((0, 0), (64, 1)):
+          host = (_C.c_void_p * n)(*[c[col].data_ptr() for c in part])
+          check(rn.lib().ra_ptr_table(host, n, tab.data_ptr() + 8 * off, rn.stream_ptr()), 'ra_ptr_table')
+        check(rn.lib().ra_conv3x3_wgrad_multi_acc_f32(tab.data_ptr(), tab.data_ptr() + 8 * 64, n, Cx, B, Hs, Ws, ups, cout,
+                                                      ptr(slot['ws']), slot['ws'].numel(), ptr(slot['cmap_t']), cin_w, tr,
+                                                      ptr(slot['gw']), ptr(slot['gb']), int(bf), rn.stream_ptr()),
+              'ra_conv3x3_wgrad_multi_acc_f32')
 
 
 class ConvBNActPool(torch.autograd.Function):
@@ -434,8 +446,9 @@ class ConvBNActPool(torch.autograd.Function):
     ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
     dgamma, dbeta, du = _f(cout, device=dev), _f(cout, device=dev), torch.empty_like(u)
     grads = meta.get('grads')  # (gw, gb, ggamma, gbeta): views of the flat gradient bucket -> accumulate in-kernel
-    nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, B, H, W)
-    wws = _f(nws, device=dev)
+    deferred = grads is not None and meta.get('wgrad_defer') is not None  # the filter gradient waits for the end of backward
+    nws = 0 if deferred else rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, B, H, W)
+    wws = None if deferred else _f(nws, device=dev)
     synced = ctx.n_total > 0.0 and ctx.n_total != float(B * H * W)
     bf = bool(meta.get('bf16'))  # compute_dtype = 'bf16': bf16 operands on the bf16 MFMA, float32 sums and tensors
     wgrad_acc = rn.lib().ra_conv3x3_wgrad_acc_bf16ops_f32 if bf else rn.lib().ra_conv3x3_wgrad_acc_f32
@@ -485,12 +498,11 @@ class ConvBNActPool(torch.autograd.Function):
           torch.autograd.Variable._execution_engine.queue_callback(defer)
         slot = defer.get(meta['wgrad_key'])
         if slot is None:
-          slot = defer[meta['wgrad_key']] = dict(ws=_f(nws, device=dev), used=False)
-        shape = (Cx, cout, B, H, W, int(stride == 2), tuple(cmap) if cmap is not None else None, int(cin_w), int(tr))
+          slot = defer[meta['wgrad_key']] = dict(calls=[], tab=torch.zeros(128, dtype=torch.int64, device=dev), ws=None)
+        shape = (Cx, cout, B, Hs, Ws, H, W, int(stride == 2), tuple(cmap) if cmap is not None else None, int(cin_w), int(tr), bf)
         assert slot.setdefault('shape', shape) == shape, 'a deferred filter gradient needs one shape per layer'
-        check(rn.lib().ra_conv3x3_wgrad_partial_f32(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(slot['ws']), nws,
-                                                    int(slot['used']), int(bf), rn.stream_ptr()), 'ra_conv3x3_wgrad_partial_f32')
-        slot.update(used=True, cmap_t=cmap_t, gw=gw, gb=gb)
+        slot['calls'].append((x, du))  # nothing is launched here
+        slot.update(cmap_t=cmap_t, gw=gw, gb=gb)
       elif _WGRAD['on']:
         side = _wgrad_stream(dev)
         side.wait_stream(torch.cuda.current_stream())  # du is ready
