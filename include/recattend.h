@@ -428,6 +428,12 @@ size_t ra_pair_stats_workspace_floats(int B, int HW);
 int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
                       size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
                       float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream);
+/* Soft IoU (modellib.f_iou, modellib.py:124-155) of one map per image, box [B,H,W], against the T rectangles
+ * ra_gt_box_f32 fills (params [B,T,8], fields 4..7): iou [B,T] — the row the training graph takes per timestep
+ * (full_model.py:744-758) without reading the T rectangle planes. */
+size_t ra_box_iou_rects_workspace_floats(int B);
+int ra_box_iou_rects_f32(const float *box, const float *params, int B, int T, int H, int W, float *ws,
+                         size_t ws_floats, float *iou, void *stream);
 size_t ra_gt_box_workspace_floats(int B, int T);
 int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, float padding_ratio,
                   float min_padding, float *ws, size_t ws_floats, float *params, float *box,
@@ -565,18 +571,7 @@ int ra_conv3x3_wgrad_acc_bf16ops_f32(const float *x, int Cin, int B, int Hs, int
                                      const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
                                      void *stream);
 /* A layer whose filter is shared by the T timesteps of a training step (every nnlib.cnn / dcnn layer of full_model:
- * one set of weights, full_model.py:455-535) sums its T filter gradients.  _partial runs only the MFMA pass of
- * ra_conv3x3_wgrad_f32 and leaves the per-workgroup partial sums in ws (accumulate = 0: overwrite — the layer's
- * first call of the step; 1: add to what the earlier calls left; same B, H, W, Cin, Cout every time, calls
- * stream-ordered); _finish_acc reduces them once per layer and step into gw / gb exactly as
- * ra_conv3x3_wgrad_acc_f32 does.  T - 1 finishing launches per layer less; fixed summation order. */
-int ra_conv3x3_wgrad_partial_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample,
-                                 const float *du, int Cout, float *ws, size_t ws_floats, int accumulate,
-                                 int bf16_operands, void *stream);
-int ra_conv3x3_wgrad_finish_acc_f32(const float *ws, size_t ws_floats, int Cin, int Cout, int B, int H, int W,
-                                    const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
-                                    void *stream);
-/* ... or in ONE pass over the images of all T calls: ra_conv3x3_wgrad_multi_acc_f32 is ra_conv3x3_wgrad_acc_f32 on
+ * one set of weights, full_model.py:455-535) sums its T filter gradients — in ONE pass over the images of all T calls: ra_conv3x3_wgrad_multi_acc_f32 is ra_conv3x3_wgrad_acc_f32 on
  * nseg * Bseg images read through two device tables of nseg pointers (x [Bseg,Hs,Ws,Cin] and du [Bseg,H,W,Cout] of
  * each call; workspace for B = nseg * Bseg).  ra_ptr_table writes up to 64 device pointers given as a HOST array into
  * a device table by a kernel launch, so that the tables can be built inside a captured HIP graph. */

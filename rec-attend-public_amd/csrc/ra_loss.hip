@@ -265,6 +265,67 @@ __global__ __launch_bounds__(256) void gt_box_fill_kernel(const float *params, i
   }
 }
 
+// ---- soft IoU of ONE map per image against the T filled rectangles of get_gt_box (the training graph's per-timestep
+// f_iou(attn_box, attn_box_gt, pairwise) row, full_model.py:744-758): inter_t = sum of the map inside rectangle t,
+// sum_b = the rectangle's pixel count — one read of the map instead of the map + T rectangle planes.  64 workgroups
+// per image leave partial sums, a second launch adds them in a fixed order. ----
+constexpr int kRectBlocks = 64;  // workgroups per image in the first stage
+__global__ __launch_bounds__(256) void box_iou_rects_kernel(const float *box, const float *params, int T, int H, int W,
+                                                            float *part) {
+  __shared__ float red[4][kMaxT + 1];
+  __shared__ float rect[kMaxT][4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < T * 4) rect[tid >> 2][tid & 3] = params[((size_t)b * T + (tid >> 2)) * 8 + 4 + (tid & 3)];
+  __syncthreads();
+  const float *a = box + (size_t)b * H * W;
+  float acc[kMaxT + 1];
+#pragma unroll
+  for (int t = 0; t <= kMaxT; ++t) acc[t] = 0.f;
+  for (int e = (blockIdx.x * 256 + tid) * 4; e < H * W; e += kRectBlocks * 1024) {  // W % 4 == 0: four pixels of one row
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(a + e);
+    const int yy = e / W, xx = e - yy * W;
+    acc[kMaxT] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t) {
+      if (t < T) {
+        const float ty = rect[t][0], tx = rect[t][1], by = rect[t][2], bx = rect[t][3];
+        if ((float)yy >= ty && (float)yy <= by) {
+          float sx = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sx += ((float)(xx + k) >= tx && (float)(xx + k) <= bx) ? v[k] : 0.f;
+          acc[t] += sx;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t <= kMaxT; ++t) {
+    float s = acc[t];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) red[wave][t] = s;
+  }
+  __syncthreads();
+  if (tid <= kMaxT)
+    part[((size_t)b * kRectBlocks + blockIdx.x) * (kMaxT + 1) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ __launch_bounds__(64) void box_iou_rects_finish_kernel(const float *part, const float *params, int T, int H, int W,
+                                                                  float *iou) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= T) return;
+  float is = 0.f, sa = 0.f;
+  for (int k = 0; k < kRectBlocks; ++k) {  // fixed order
+    is += part[((size_t)b * kRectBlocks + k) * (kMaxT + 1) + t];
+    sa += part[((size_t)b * kRectBlocks + k) * (kMaxT + 1) + kMaxT];
+  }
+  // pixels the fill marks: integers y in [ty, by] and x in [tx, bx] inside the image (gt_box_fill_kernel)
+  const float *p = params + ((size_t)b * T + t) * 8 + 4;
+  const int y0 = (int)fmaxf(ceilf(p[0]), 0.f), y1 = (int)fminf(floorf(p[2]), (float)(H - 1));
+  const int x0 = (int)fmaxf(ceilf(p[1]), 0.f), x1 = (int)fminf(floorf(p[3]), (float)(W - 1));
+  const float sb = (y1 >= y0 && x1 >= x0) ? (float)(y1 - y0 + 1) * (float)(x1 - x0 + 1) : 0.f;
+  iou[(size_t)b * T + t] = is / (sa + sb - is + 1e-5f * (float)(H * W));
+}
+
 // ---- K10: f_segm_match pre/post (modellib.py:395-413) ----
 __global__ void match_pre_kernel(const float *iou, const float *s_gt, int N, int total, float *w) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,6 +552,23 @@ extern "C" int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, floa
   const int gx = ceil_div(H * W, 256 * 4 * 4);
   hipLaunchKernelGGL(loss::gt_box_fill_kernel, dim3(gx, B * T), dim3(256), 0, st, params, H, W, box);
   return launch_status("ra_gt_box_f32");
+}
+
+extern "C" size_t ra_box_iou_rects_workspace_floats(int B) {
+  return B > 0 ? (size_t)B * loss::kRectBlocks * (loss::kMaxT + 1) : 0;
+}
+
+extern "C" int ra_box_iou_rects_f32(const float *box, const float *params, int B, int T, int H, int W, float *ws,
+                                    size_t ws_floats, float *iou, void *stream) {
+  if (!box || !params || !iou || !ws || B <= 0 || T <= 0 || H <= 0 || W <= 0)
+    return fail(RA_E_INVALID, "ra_box_iou_rects_f32: bad argument");
+  if (T > loss::kMaxT || W % 4 || (reinterpret_cast<uintptr_t>(box) & 15))
+    return fail(RA_E_SHAPE, "ra_box_iou_rects_f32: T <= %d, W %% 4 == 0 and a 16-byte aligned map required", loss::kMaxT);
+  if (ws_floats < ra_box_iou_rects_workspace_floats(B)) return fail(RA_E_WORKSPACE, "ra_box_iou_rects_f32: workspace too small");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(loss::box_iou_rects_kernel, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
+  hipLaunchKernelGGL(loss::box_iou_rects_finish_kernel, dim3(B), dim3(64), 0, st, ws, params, T, H, W, iou);
+  return launch_status("ra_box_iou_rects_f32");
 }
 
 extern "C" size_t ra_segm_match_workspace_bytes(int B, int N) {

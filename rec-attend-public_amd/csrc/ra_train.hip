@@ -299,23 +299,23 @@ __global__ __launch_bounds__(256) void chan_final_kernel(const float *part, int 
 // tf.nn.moments from the records the conv epilogue left (ra_conv3x3_moments_f32: {n, S1, S2, pivot} per channel and
 // record, sums of (u - pivot) and (u - pivot)^2): one workgroup per channel; every record becomes (n, mean, M2) and the
 // records are combined by Chan's update in float64 — no E[x^2] - E[x]^2 over the whole batch.
-__global__ __launch_bounds__(256) void moments_from_partials_kernel(const float *part, int nparts, int C, int CP, float *mean,
-                                                                    float *var) {
-  __shared__ double red[256];
+template <int NT>  // threads per channel: 64 (one wave, no barrier) up to 512 records, else 256
+__global__ __launch_bounds__(NT) void moments_from_partials_kernel(const float *part, int nparts, int C, int CP, float *mean,
+                                                                   float *var) {
+  __shared__ double red[4];
   const int c = blockIdx.x, tid = threadIdx.x;
   auto block_sum = [&](double v) {
-    red[tid] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) red[tid] += red[tid + s];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if constexpr (NT > 64) {
+      __syncthreads();  // red is free again
+      if ((tid & 63) == 0) red[tid >> 6] = v;
       __syncthreads();
+      v = (red[0] + red[1]) + (red[2] + red[3]);
     }
-    const double r = red[0];
-    __syncthreads();
-    return r;
+    return v;
   };
   double n = 0.0, sm = 0.0;
-  for (int k = tid; k < nparts; k += 256) {
+  for (int k = tid; k < nparts; k += NT) {
     const f32x4 r = *reinterpret_cast<const f32x4 *>(part + ((size_t)k * CP + c) * 4);
     if (r[0] > 0.f) {
       n += (double)r[0];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void moments_from_partials_kernel(const float 
   }
   const double N = block_sum(n), M = block_sum(sm) / (N > 0.0 ? N : 1.0);
   double m2 = 0.0;
-  for (int k = tid; k < nparts; k += 256) {
+  for (int k = tid; k < nparts; k += NT) {
     const f32x4 r = *reinterpret_cast<const f32x4 *>(part + ((size_t)k * CP + c) * 4);
     if (r[0] > 0.f) {
       const double nk = (double)r[0], mk = (double)r[3] + (double)r[1] / nk, d = mk - M;
@@ -603,7 +603,10 @@ extern "C" int ra_bn_moments_f32(const float *u, size_t npix, int C, float *ws, 
 extern "C" int ra_bn_moments_from_partials_f32(const float *part, int nparts, int C, float *mean, float *var, void *stream) {
   const int cp = ra_conv_cout_padded(C);
   if (!part || !mean || !var || nparts <= 0 || C <= 0 || !cp) return fail(RA_E_INVALID, "ra_bn_moments_from_partials_f32: bad argument");
-  hipLaunchKernelGGL(train::moments_from_partials_kernel, dim3(C), dim3(256), 0, as_stream(stream), part, nparts, C, cp, mean, var);
+  if (nparts <= 512)
+    hipLaunchKernelGGL(train::moments_from_partials_kernel<64>, dim3(C), dim3(64), 0, as_stream(stream), part, nparts, C, cp, mean, var);
+  else
+    hipLaunchKernelGGL(train::moments_from_partials_kernel<256>, dim3(C), dim3(256), 0, as_stream(stream), part, nparts, C, cp, mean, var);
   return launch_status("ra_bn_moments_from_partials_f32");
 }
 
@@ -792,7 +795,7 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
 template <int NT, int PACK = 0, bool BF16 = false>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
                                                     int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
-                                                    int ntiles, float *part, int accum, const float *const *xtab,
+                                                    int ntiles, float *part, const float *const *xtab,
                                                     const float *const *dutab, int Bseg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tx = lds;                      // [WLH][WLW][16]   input slice + halo, channel-contiguous
@@ -931,12 +934,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
     __syncthreads();
   }
   float *dst = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (10 * 16 * CP);
-  // accum: the layer's partials of the step's earlier timesteps stay in `part` (same grid, same slot per workgroup,
-  // launches of one layer are stream-ordered): ONE finishing reduction per layer and step instead of one per call
-  if (accum)
-    for (int e = tid; e < 10 * 16 * CP; e += 256) dst[e] += red[e];
-  else
-    for (int e = tid; e < 10 * 16 * CP; e += 256) dst[e] = red[e];
+  for (int e = tid; e < 10 * 16 * CP; e += 256) dst[e] = red[e];
 }
 
 // dW[tap][ci][co] (= TF [3,3,Cin,Cout]) and db[co] from the partials, fixed order.
@@ -1117,10 +1115,10 @@ namespace {
 // sums are added to gw / gb in the reference layout (chan_map, cin_w, transposed as in wgrad_final_acc_kernel)
 int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du, int Cout, float *ws,
                size_t ws_floats, float *dw, float *db, bool acc, const int *chan_map, int cin_w, int transposed,
-               void *stream, bool bf16 = false, int mode = 0,  // mode 1 / 2: partials only (overwrite / accumulate)
-               const float *const *xtab = nullptr, const float *const *dutab = nullptr, int Bseg = 0) {
+               void *stream, bool bf16 = false, const float *const *xtab = nullptr, const float *const *dutab = nullptr,
+               int Bseg = 0) {
   if (xtab) x = du = reinterpret_cast<const float *>(xtab);  // (not read: the tables are)
-  if (!x || !du || !ws || (!dw && mode == 0) || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
+  if (!x || !du || !ws || !dw || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
     return fail(RA_E_INVALID, "ra_conv3x3_wgrad_f32: bad argument");
   const int cp = ra_conv_cout_padded(Cout);
   if (Cin % 4 || !cp) return fail(RA_E_SHAPE, "ra_conv3x3_wgrad_f32: Cin %d %% 4 or Cout %d", Cin, Cout);
@@ -1144,7 +1142,7 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
       attr = true;                                                                                                \
     }                                                                                                             \
     hipLaunchKernelGGL((wgrad_kernel<NT, PACK, BF>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, \
-                       H, W, Cout, tiles_x, tiles_y, ntiles, ws, mode == 2 ? 1 : 0, xtab, dutab, Bseg);          \
+                       H, W, Cout, tiles_x, tiles_y, ntiles, ws, xtab, dutab, Bseg);                             \
   }
 #define RA_WGRAD(NT, PACK)                                                                                        \
   {                                                                                                               \
@@ -1167,7 +1165,6 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
   }
 #undef RA_WGRAD
 #undef RA_WGRAD_T
-  if (mode != 0) return launch_status("ra_conv3x3_wgrad_partial_f32");
   const int total = 9 * Cin * Cout + Cout;
   if (acc)
     hipLaunchKernelGGL(wgrad_final_acc_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout,
@@ -1237,32 +1234,8 @@ extern "C" int ra_conv3x3_wgrad_multi_acc_f32(const void *const *xtab, const voi
   if (!xtab || !dutab || nseg <= 0 || Bseg <= 0) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_multi_acc_f32: bad argument");
   if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_multi_acc_f32: cin_w %d", cin_w);
   return wgrad_impl(nullptr, Cin, nseg * Bseg, Hs, Ws, upsample, nullptr, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w,
-                    transposed ? 1 : 0, stream, bf16_operands != 0, 0, reinterpret_cast<const float *const *>(xtab),
+                    transposed ? 1 : 0, stream, bf16_operands != 0, reinterpret_cast<const float *const *>(xtab),
                     reinterpret_cast<const float *const *>(dutab), Bseg);
-}
-
-extern "C" int ra_conv3x3_wgrad_partial_f32(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du,
-                                            int Cout, float *ws, size_t ws_floats, int accumulate, int bf16_operands,
-                                            void *stream) {
-  return wgrad_impl(x, Cin, B, Hs, Ws, upsample, du, Cout, ws, ws_floats, nullptr, nullptr, true, nullptr, Cin, 0, stream,
-                    bf16_operands != 0, accumulate ? 2 : 1);
-}
-
-extern "C" int ra_conv3x3_wgrad_finish_acc_f32(const float *ws, size_t ws_floats, int Cin, int Cout, int B, int H, int W,
-                                               const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
-                                               void *stream) {
-  const int cp = ra_conv_cout_padded(Cout);
-  if (!ws || !gw || Cin <= 0 || Cin % 4 || !cp || B <= 0 || H <= 0 || W <= 0 || cin_w <= 0 || (!chan_map && cin_w > Cin))
-    return fail(RA_E_INVALID, "ra_conv3x3_wgrad_finish_acc_f32: bad argument");
-  if (ws_floats < ra_conv3x3_wgrad_workspace_floats(Cin, Cout, B, H, W))
-    return fail(RA_E_WORKSPACE, "ra_conv3x3_wgrad_finish_acc_f32: workspace too small");
-  using namespace ra::train;
-  const int per = cp < 64 ? cp : 64;
-  const int gx = wgrad_grid_x(ceil_div(W, WTW) * ceil_div(H, WTH) * B), chunks = ceil_div(Cin, 16);
-  const int total = 9 * Cin * Cout + Cout;
-  hipLaunchKernelGGL(wgrad_final_acc_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, as_stream(stream), ws, gx, chunks, per,
-                     Cin, Cout, chan_map, cin_w, transposed ? 1 : 0, gw, gb);
-  return launch_status("ra_conv3x3_wgrad_finish_acc_f32");
 }
 
 extern "C" int ra_lstm_cell_f32(const float *pre, const float *c_prev, int B, int hid, float *h, float *c, float *act,

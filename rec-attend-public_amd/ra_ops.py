@@ -562,6 +562,19 @@ def gt_box(y_gt, padding_ratio, min_padding, want_box=True):
   return params, box
 
 
+def box_iou_rects(box, params):
+  """f_iou (soft) of box [B,H,W] against the T rectangles of gt_box's params [B,T,8] -> [B,T]."""
+  box, params = box.contiguous(), params.contiguous()
+  _need_cuda(box, params)
+  B, H, W = box.shape
+  T = params.shape[1]
+  out = torch.empty((B, T), dtype=torch.float32, device=box.device)
+  ws = torch.empty((rn.lib().ra_box_iou_rects_workspace_floats(B),), dtype=torch.float32, device=box.device)
+  check(rn.lib().ra_box_iou_rects_f32(ptr(box), ptr(params), B, T, H, W, ptr(ws), ws.numel(), ptr(out), rn.stream_ptr()),
+        'ra_box_iou_rects_f32')
+  return out
+
+
 def segm_match(iou, s_gt):
   """modellib.f_segm_match (modellib.py:382-415) on device; returns (match [B,N,N], status [B])."""
   iou, s_gt = iou.contiguous(), s_gt.contiguous()

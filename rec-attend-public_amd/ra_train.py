@@ -1296,7 +1296,9 @@ class TrainStep(object):
             iou_box_steps.append(iou_row[:, None, :])  # the row of the [B,T,T] matrix the box matching and loss use (:931-934)
             iou_t = iou_row.detach().contiguous()
           else:
-            iou_t = ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
+            # f_iou of the box against the T ground-truth rectangles: one read of the box (not of the T planes too)
+            iou_t = ops.box_iou_rects(box.detach(), gt_corners) if W % 4 == 0 and T <= 32 else \
+                ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
           gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
           gsel_box = gmatch
         # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)

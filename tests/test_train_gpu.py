@@ -997,3 +997,21 @@ def test_conv_epilogue_moments(cuda, B, H, W, Ci, Co, ups, bf):
   assert (np.abs(mean.cpu().numpy() - rm) < 1e-5 * np.maximum(scale, np.abs(rm))).all(), np.abs(mean.cpu().numpy() - rm) / scale
   assert (np.abs(var.cpu().numpy() - rv) < 1e-5 * rv + 1e-9).all(), np.abs(var.cpu().numpy() - rv) / rv
   assert (np.abs(v2.cpu().numpy() - rv) < 1e-4 * rv + 1e-9).all()
+
+
+@pytest.mark.parametrize('B,T,H,W', [(2, 3, 64, 64), (8, 16, 128, 96), (1, 21, 48, 160)])
+def test_box_iou_against_rectangles(cuda, B, T, H, W):
+  """ra_box_iou_rects_f32 (the per-timestep f_iou row of the training graph, full_model.py:744-758) against the pairwise
+  statistics kernel on the filled rectangles: 1e-5 relative."""
+  import ra_ops as ops
+  rng = np.random.RandomState(T + H)
+  y_gt = np.zeros((B, T, H, W), np.float32)
+  for b in range(B):
+    for t in range(T - 1):  # the last instance stays empty (get_gt_box's fix-up path)
+      y0, x0 = rng.randint(0, H - 8), rng.randint(0, W - 8)
+      y_gt[b, t, y0:y0 + rng.randint(2, H - y0), x0:x0 + rng.randint(2, W - x0)] = 1
+  params, box_gt = ops.gt_box(torch.tensor(y_gt, device=cuda), 0.2, 20.0)
+  box = torch.tensor(rng.rand(B, H, W).astype(np.float32) ** 3, device=cuda)
+  got = ops.box_iou_rects(box, params).cpu().numpy()
+  ref = ops.pair_stats(box[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft'].cpu().numpy().reshape(B, T)
+  assert np.abs(got - ref).max() < 1e-5 * max(1e-3, np.abs(ref).max()), np.abs(got - ref).max()
