@@ -45,6 +45,25 @@ def test_bench_json_line(cuda):
   assert tr['steps'] == 3 and tr['dtype'] == 'f32' and tr['ms_per_step'] > 0 and tr['fused_controller'] and tr['hip_graph']
   assert abs(tr['value'] - 8 * 16 * 1000.0 / tr['ms_per_step']) < 1e-6 * tr['value'] and tr['ranks_in_communicator'] == 1
   assert d['config']['ranks_in_communicator'] == 1
+  tb = d['train_bf16']  # the same step with model_opt['compute_dtype'] = 'bf16', its own dtype field
+  assert tb['dtype'] == 'bf16' and tb['steps'] == 3 and tb['ms_per_step'] > 0 and tb['hip_graph']
+  for t in (tr, tb):
+    rf = t['roofline']
+    assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert abs(rf['achieved'] - rf['bytes_per_step'] / (t['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * rf['achieved']
+
+
+def test_train_layer_bytes_formula():
+  """bench.train_layer_bytes: 3 X + 7 U + 3 Y per layer call, by hand for a two-layer toy network."""
+  sys.path.insert(0, ROOT)
+  import bench
+  opt = dict(ctrl_cnn_depth=[8], ctrl_cnn_pool=[2], filter_height=8, filter_width=8, attn_cnn_depth=[4], attn_cnn_pool=[1],
+             attn_dcnn_depth=[4], attn_dcnn_pool=[2])
+  B, S, T = 2, 16, 3
+  ctrl = 2 * (B * S * S * 4 * 4) + 6 * (B * S * S * 8 * 4) + 3 * (B * S * S * 8 * 4 // 4)        # no data gradient
+  acnn = 3 * (B * 8 * 8 * 4 * 4) + 7 * (B * 8 * 8 * 4 * 4) + 3 * (B * 8 * 8 * 4 * 4)
+  dcnn = 3 * (B * 8 * 8 * 4 * 4) + 7 * (B * 16 * 16 * 4 * 4) + 3 * (B * 16 * 16 * 4 * 4)
+  assert bench.train_layer_bytes(opt, B, S, T) == T * (ctrl + acnn + dcnn)
 
 
 @pytest.mark.gpu
