@@ -116,7 +116,7 @@ def mfma_busy():
     path = os.path.join(ROOT, 'profiles', rnd + '_pmc_sq_mfma_per_kernel.csv')
     if not os.path.exists(path):
       continue
-    rows = [r for r in csv.DictReader(open(path)) if any(k in r['kernel'] for k in ('ra::cpair::', 'ra::wino::', 'ra::conv::conv3x3_mfma<16, 1, 4, 2, 1, false>'))
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r['kernel'] for k in ('ra::cpair::', 'ra::wino::', 'ra::conv::conv3x3_mfma<16, 1, 4, 2, 1, false'))
             and 'conv_pair8_mfma<4, false>' not in r['kernel']]
     if not rows:
       continue
