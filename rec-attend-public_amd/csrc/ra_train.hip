@@ -824,6 +824,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
       aoff[t] = ((t / 3) * WLW + t % 3) * 16 + m;
     }
   }
+  // the channel groups beyond the slice's real channels are zero for the whole launch: written once, not per tile
+  const int ng = (cn + 3) >> 2;
+  if (ng < 4) {
+    for (int e = tid; e < WLH * WLW * 4; e += 256) *reinterpret_cast<f32x4 *>(tx + e * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool vec_du = (Cout & 3) == 0;  // float4 loads of the output gradient
   const int per = tiles_x * tiles_y;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int b = tile / per;
@@ -836,11 +842,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
     }
     const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
     __syncthreads();  // the previous tile's MFMA reads are complete
-    for (int e = tid; e < WLH * WLW * 4; e += 256) {  // input slice: one float4 (4 channels) per item
-      const int c4 = e & 3, pix = e >> 2;
+    for (int e = tid; e < WLH * WLW * ng; e += 256) {  // input slice: one float4 (4 channels) per item
+      const int pix = e / ng, c4 = e - pix * ng;
       const int r = pix / WLW, c = pix - r * WLW;
       const int Y = ty0 + r - 1, X = tx0 + c - 1;
-      bool ok = (Y >= 0) & (Y < H) & (X >= 0) & (X < W) & (4 * c4 < cn);
+      bool ok = (Y >= 0) & (Y < H) & (X >= 0) & (X < W);
       int ys = Y, xs = X;
       if (ups) {
         ok = ok & (Y & 1) & (X & 1);
@@ -851,13 +857,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
       if (ok) v = *reinterpret_cast<const f32x4 *>(x + (((size_t)b * Hs + ys) * Ws + xs) * Cin + c0 + 4 * c4);
       *reinterpret_cast<f32x4 *>(tx + pix * 16 + 4 * c4) = v;
     }
-    for (int e = tid; e < WTH * WTW * CP; e += 256) {  // output-gradient tile, zero beyond Cout / the image
-      const int co = e % CP, pix = e / CP;
-      const int r = pix / WTW, c = pix - r * WTW;
-      const int Y = ty0 + r, X = tx0 + c;
-      float v = 0.f;
-      if (Y < H && X < W && co0 + co < Cout) v = du[(((size_t)b * H + Y) * W + X) * Cout + co0 + co];
-      tu[e] = v;
+    if (vec_du) {
+      for (int e = tid; e < WTH * WTW * (CP / 4); e += 256) {  // output-gradient tile, zero beyond Cout / the image
+        const int c4 = e % (CP / 4), pix = e / (CP / 4);
+        const int r = pix / WTW, c = pix - r * WTW;
+        const int Y = ty0 + r, X = tx0 + c;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (Y < H && X < W && co0 + 4 * c4 < Cout)
+          v = *reinterpret_cast<const f32x4 *>(du + (((size_t)b * H + Y) * W + X) * Cout + co0 + 4 * c4);
+        *reinterpret_cast<f32x4 *>(tu + pix * CP + 4 * c4) = v;
+      }
+    } else {
+      for (int e = tid; e < WTH * WTW * CP; e += 256) {
+        const int co = e % CP, pix = e / CP;
+        const int r = pix / WTW, c = pix - r * WTW;
+        const int Y = ty0 + r, X = tx0 + c;
+        float v = 0.f;
+        if (Y < H && X < W && co0 + co < Cout) v = du[(((size_t)b * H + Y) * W + X) * Cout + co0 + co];
+        tu[e] = v;
+      }
     }
     __syncthreads();
     // this wave's rows: 2 of the 8; K steps of 4 consecutive pixels of a row
