@@ -792,7 +792,10 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
   return __builtin_bit_cast(bf16x4, u32x2{lo, hi});
 }
 
-template <int NT, int PACK = 0, bool BF16 = false>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
+// PRE (Cout % 4 == 0, NT <= 2): the NEXT tile's global loads are issued into registers before the MFMA loop of the
+// current one and written to LDS after it (one staging buffer, two barriers per tile as before): the loads' latency
+// and the HBM stream hide behind the matrix work instead of in front of it.
+template <int NT, int PACK = 0, bool BF16 = false, bool PRE = false>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
                                                     int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
                                                     int ntiles, float *part, const float *const *xtab,
@@ -831,6 +834,65 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
   }
   const bool vec_du = (Cout & 3) == 0;  // float4 loads of the output gradient
   const int per = tiles_x * tiles_y;
+  constexpr int NRX = PRE ? (WLH * WLW * 4 + 255) / 256 : 1, NRU = PRE ? CP / 4 : 1;
+  f32x4 rx[NRX], ru[NRU];
+  auto prefetch = [&](int tile) {  // every load unconditional (clamped address, value selected afterwards)
+    int b = tile / per;
+    const int tr = tile - b * per;
+    const float *xb = x, *ub = du;
+    if (xtab) {
+      const int seg = b / Bseg;
+      xb = xtab[seg];
+      ub = dutab[seg];
+      b -= seg * Bseg;
+    }
+    const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
+#pragma unroll
+    for (int i = 0; i < NRX; ++i) {
+      const int e = tid + 256 * i;
+      const int pix = e / ng, c4 = e - pix * ng;
+      const int r = pix / WLW, c = pix - r * WLW;
+      const int Y = ty0 + r - 1, X = tx0 + c - 1;
+      bool ok = (e < WLH * WLW * ng) & (Y >= 0) & (Y < H) & (X >= 0) & (X < W);
+      int ys = Y, xs = X;
+      if (ups) {
+        ok = ok & (Y & 1) & (X & 1);
+        ys = (Y - 1) >> 1;
+        xs = (X - 1) >> 1;
+      }
+      const size_t off = ok ? (((size_t)b * Hs + ys) * Ws + xs) * Cin + c0 + 4 * c4 : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + off);
+      rx[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NRU; ++i) {
+      const int e = tid + 256 * i;
+      const int c4 = e % (CP / 4), pix = e / (CP / 4);
+      const int r = pix / WTW, c = pix - r * WTW;
+      const int Y = ty0 + r, X = tx0 + c;
+      const bool ok = (Y < H) & (X < W) & (co0 + 4 * c4 < Cout);
+      const size_t off = ok ? (((size_t)b * H + Y) * W + X) * Cout + co0 + 4 * c4 : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(ub + off);
+      ru[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto commit = [&]() {  // the prefetched tile -> LDS
+#pragma unroll
+    for (int i = 0; i < NRX; ++i) {
+      const int e = tid + 256 * i;
+      const int pix = e / ng, c4 = e - pix * ng;
+      if (e < WLH * WLW * ng) *reinterpret_cast<f32x4 *>(tx + pix * 16 + 4 * c4) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NRU; ++i) {
+      const int e = tid + 256 * i;
+      const int c4 = e % (CP / 4), pix = e / (CP / 4);
+      *reinterpret_cast<f32x4 *>(tu + pix * CP + 4 * c4) = ru[i];
+    }
+  };
+  if constexpr (PRE) {
+    if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int b = tile / per;
     const int tr = tile - b * per;
@@ -842,6 +904,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
     }
     const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
     __syncthreads();  // the previous tile's MFMA reads are complete
+    if constexpr (PRE) {
+      commit();
+      __syncthreads();
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);  // in flight across the MFMA loop below
+    } else {
     for (int e = tid; e < WLH * WLW * ng; e += 256) {  // input slice: one float4 (4 channels) per item
       const int pix = e / ng, c4 = e - pix * ng;
       const int r = pix / WLW, c = pix - r * WLW;
@@ -878,6 +945,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
       }
     }
     __syncthreads();
+    }
     // this wave's rows: 2 of the 8; K steps of 4 consecutive pixels of a row
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
@@ -1151,21 +1219,31 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
   const size_t lds_red = (size_t)10 * 16 * per * sizeof(float);
   const size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
   hipStream_t st = as_stream(stream);
-#define RA_WGRAD_T(NT, PACK, BF)                                                                                  \
+#define RA_WGRAD_T(NT, PACK, BF, PRE)                                                                             \
   {                                                                                                               \
     static bool attr = false;                                                                                     \
     if (!attr) {                                                                                                  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<NT, PACK, BF>),                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<NT, PACK, BF, PRE>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);                         \
       attr = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL((wgrad_kernel<NT, PACK, BF>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, ups, \
-                       H, W, Cout, tiles_x, tiles_y, ntiles, ws, xtab, dutab, Bseg);                             \
+    hipLaunchKernelGGL((wgrad_kernel<NT, PACK, BF, PRE>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, \
+                       ups, H, W, Cout, tiles_x, tiles_y, ntiles, ws, xtab, dutab, Bseg);                        \
+  }
+#define RA_WGRAD_P(NT, PACK, BF)                                                                                  \
+  {                                                                                                               \
+    if (NT <= 2 && pre_ok) RA_WGRAD_T(NT, PACK, BF, (NT <= 2)) else RA_WGRAD_T(NT, PACK, BF, false)               \
   }
 #define RA_WGRAD(NT, PACK)                                                                                        \
   {                                                                                                               \
-    if (bf16) RA_WGRAD_T(NT, PACK, true) else RA_WGRAD_T(NT, PACK, false)                                         \
+    if (bf16) RA_WGRAD_P(NT, PACK, true) else RA_WGRAD_P(NT, PACK, false)                                         \
   }
+  static int pre_env = -1;  // RA_WGRAD_PRE=0: tuning aid, no register prefetch of the next tile
+  if (pre_env < 0) {
+    const char *e = getenv("RA_WGRAD_PRE");
+    pre_env = e ? atoi(e) : 1;
+  }
+  const bool pre_ok = pre_env && (Cout & 3) == 0;
   static int pack_ok = -1;  // RA_WGRAD_PACK=0: tuning aid, channel rows for every Cin
   if (pack_ok < 0) {
     const char *e = getenv("RA_WGRAD_PACK");
@@ -1182,6 +1260,7 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
     default: RA_WGRAD(4, 0) break;
   }
 #undef RA_WGRAD
+#undef RA_WGRAD_P
 #undef RA_WGRAD_T
   const int total = 9 * Cin * Cout + Cout;
   if (acc)
