@@ -1023,6 +1023,141 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
   for (int e = tid; e < 10 * 16 * CP; e += 256) dst[e] = red[e];
 }
 
+// ---- the 8-output-channel layers (Cin = 4 or 8: the two full-resolution layers of the controller CNN, the last layers
+// of the attention nets) on v_mfma_f32_4x4x1_16B_f32.  A 16x16x4 tile is 16 output channels wide, so with 8 of them half
+// of every MFMA is padding (and 72 + 1 rows fill 6 tiles of 16): 38 % useful.  The 16-block form multiplies sixteen
+// independent 4x4x1 outer products per instruction at the same flop rate (tools/mfma_4x4.hip: 123-133 TF/s): block b =
+// lane / 4 takes pixel b of a run of 16, lane 4b + j supplies row 4 RB + j of the (tap, channel) rows as the A operand
+// and output channel 4 CB + j as the B operand, and accumulator (RB, CB) collects the 4x4 block of dW for that pixel
+// residue — (9 Cin + 1) / 4 x 2 blocks with no padding but the bias block's three empty rows.  The sixteen pixel
+// residues are added up once at the end (xor-shuffles over the block index).  LDS records are 9 (Cin + 1) floats per
+// pixel so that the sixteen pixels of a read fall into different banks.  Same persistent walk, partial layout and
+// finishing kernels as wgrad_kernel. ----
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const float *x, const float *du, int B, int Hs, int Ws, int H, int W,
+                                                          int tiles_x, int tiles_y, int ntiles, float *part,
+                                                          const float *const *xtab, const float *const *dutab, int Bseg,
+                                                          int CP) {
+  constexpr int SX = CIN + 1, SU = 9, NRB = (9 * CIN + 1 + 3) / 4;  // the last row block = the bias row + 3 empty rows
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tx = lds;                    // [WLH][WLW][SX]
+  float *tu = lds + WLH * WLW * SX;   // [WTH][WTW][SU]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = lane >> 2, j = lane & 3;
+  f32x4 acc[NRB][2];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int aoff[NRB - 1];
+#pragma unroll
+  for (int rb = 0; rb < NRB - 1; ++rb) {
+    const int R = 4 * rb + j, tap = R / CIN, ci = R - tap * CIN;
+    aoff[rb] = ((tap / 3) * WLW + tap % 3) * SX + ci;
+  }
+  const float abias = j == 0 ? 1.0f : 0.0f;
+  const int per = tiles_x * tiles_y;
+  // the next tile's global loads travel in registers across the MFMA phase of the current one (as wgrad_kernel<PRE>)
+  constexpr int NRX = (WLH * WLW * (CIN / 4) + 255) / 256, NRU = WTH * WTW * 2 / 256;
+  f32x4 rx[NRX], ru[NRU];
+  auto prefetch = [&](int tile) {
+    int b = tile / per;
+    const int tr = tile - b * per;
+    const float *xb = x, *ub = du;
+    if (xtab) {
+      const int seg = b / Bseg;
+      xb = xtab[seg];
+      ub = dutab[seg];
+      b -= seg * Bseg;
+    }
+    const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
+#pragma unroll
+    for (int i = 0; i < NRX; ++i) {
+      const int e = tid + 256 * i;
+      const int pix = e / (CIN / 4), c4 = e - pix * (CIN / 4);
+      const int r = pix / WLW, c = pix - r * WLW;
+      const int Y = ty0 + r - 1, X = tx0 + c - 1;
+      const bool ok = (e < WLH * WLW * (CIN / 4)) & (Y >= 0) & (Y < H) & (X >= 0) & (X < W);
+      const size_t off = ok ? (((size_t)b * Hs + Y) * Ws + X) * CIN + 4 * c4 : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + off);
+      rx[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NRU; ++i) {
+      const int e = tid + 256 * i;
+      const int pix = e >> 1, c4 = e & 1;
+      const int r = pix / WTW, c = pix - r * WTW;
+      const int Y = ty0 + r, X = tx0 + c;
+      const bool ok = (Y < H) & (X < W);
+      const size_t off = ok ? (((size_t)b * H + Y) * W + X) * 8 + 4 * c4 : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(ub + off);
+      ru[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's MFMA reads are complete
+#pragma unroll
+    for (int i = 0; i < NRX; ++i) {
+      const int e = tid + 256 * i;
+      const int pix = e / (CIN / 4), c4 = e - pix * (CIN / 4);
+      if (e < WLH * WLW * (CIN / 4)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tx[pix * SX + 4 * c4 + k] = rx[i][k];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NRU; ++i) {
+      const int e = tid + 256 * i;
+      const int pix = e >> 1, c4 = e & 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tu[pix * SU + 4 * c4 + k] = ru[i][k];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {  // this wave's rows 2 wave, 2 wave + 1; two runs of 16 pixels per row
+      const int row = wave * 2 + (g >> 1), px = 16 * (g & 1) + blk;
+      const float *ax = tx + (row * WLW + px) * SX;
+      const float *bu = tu + (row * WTW + px) * SU;
+      const float b0 = bu[j], b1 = bu[4 + j];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        const float a = rb < NRB - 1 ? ax[aoff[rb < NRB - 1 ? rb : 0]] : abias;
+        acc[rb][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b0, acc[rb][0], 0, 0, 0);
+        acc[rb][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b1, acc[rb][1], 0, 0, 0);
+      }
+    }
+  }
+  // the sixteen pixel residues (blocks) of an accumulator are added up by xor-shuffles over the block index; lanes 0..3
+  // then hold D[4 rb + r][4 cb + lane] and put it into the wave's own copy of the partial record
+  __syncthreads();
+  float *red = lds;  // [wave][tap (9 = bias)][channel of the slice (16)][CP], the record as wgrad_kernel writes it
+  for (int e = tid; e < 4 * 10 * 16 * CP; e += 256) red[e] = 0.f;
+  __syncthreads();
+  float *mine = red + wave * (10 * 16 * CP);
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[rb][cb][r];
+        for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        const int R = 4 * rb + r;
+        int slot = -1;
+        if (R < 9 * CIN) {
+          const int tap = R / CIN;
+          slot = tap * 16 + (R - tap * CIN);
+        } else if (R == 9 * CIN) {
+          slot = 9 * 16;
+        }
+        if (slot >= 0 && lane < 4) mine[slot * CP + 4 * cb + lane] = v;
+      }
+  __syncthreads();
+  float *dst = part + (size_t)blockIdx.x * (10 * 16 * CP);
+  for (int e = tid; e < 10 * 16 * CP; e += 256)
+    dst[e] = (red[e] + red[e + 10 * 16 * CP]) + (red[e + 2 * 10 * 16 * CP] + red[e + 3 * 10 * 16 * CP]);
+}
+
 // dW[tap][ci][co] (= TF [3,3,Cin,Cout]) and db[co] from the partials, fixed order.
 __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
                                                           float *dw, float *db) {  // CP = couts per slice
@@ -1250,6 +1385,22 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
     pack_ok = e ? atoi(e) : 1;
   }
   const int pack = (pack_ok && (Cin == 4 || Cin == 8)) ? Cin : 0;
+  static int small_ok = -1;  // RA_WGRAD_SMALL=0: tuning aid, the 16x16x4 form for the 8-output-channel layers too
+  if (small_ok < 0) {
+    const char *e = getenv("RA_WGRAD_SMALL");
+    small_ok = e ? atoi(e) : 1;
+  }
+  const bool small = small_ok && !bf16 && !ups && Cout == 8 && (Cin == 4 || Cin == 8);
+  if (small) {
+    const size_t lds_s = (size_t)(WLH * WLW * (Cin + 1) + WTH * WTW * 9) * sizeof(float);
+    const size_t lds_small = lds_s > 4 * lds_red ? lds_s : 4 * lds_red;  // the four waves' partial records at the end
+    if (Cin == 4)
+      hipLaunchKernelGGL(wgrad_small_kernel<4>, dim3(gx), dim3(256), lds_small, st, x, du, B, Hs, Ws, H, W, tiles_x, tiles_y,
+                         ntiles, ws, xtab, dutab, Bseg, per);
+    else
+      hipLaunchKernelGGL(wgrad_small_kernel<8>, dim3(gx), dim3(256), lds_small, st, x, du, B, Hs, Ws, H, W, tiles_x, tiles_y,
+                         ntiles, ws, xtab, dutab, Bseg, per);
+  } else
   switch (per / 16) {
     case 1:
       if (pack == 4) RA_WGRAD(1, 4) else if (pack == 8) RA_WGRAD(1, 8) else RA_WGRAD(1, 0)
