@@ -235,34 +235,6 @@ def _side_stream(device):
   return _SIDE[k]
 
 
-# Backward-weight off the critical path (OFF: measured slower).  Nothing in the backward pass reads a filter
-# gradient, so the wgrad launches of every layer can go to ONE side stream (they accumulate into the bucket in
-# issue order) and overlap the backward-data / BatchNorm chain of the layers before them, joined before the
-# optimizer; the tensors they read are kept alive until the join.  Inside the captured step that is 640
-# fork / join pairs, and the HIP-graph executor runs such a graph at 156 ms per step against 76 ms for the
-# linear one (the same executor cost that sank the branched decode graphs).
-_WGRAD = {'on': False, 'keep': [], 'stream': {}}
-
-
-def _wgrad_stream(device):
-  k = str(device)
-  if k not in _WGRAD['stream']:
-    _WGRAD['stream'][k] = torch.cuda.Stream(device=device)
-  return _WGRAD['stream'][k]
-
-
-def _wgrad_join(device):
-  if _WGRAD['keep']:
-    torch.cuda.current_stream().wait_stream(_wgrad_stream(device))
-    _WGRAD['keep'] = []
-
-
-def wgrad_join():
-  """After a bare `loss.backward()` on a TrainStep graph: wait for the filter gradients that were issued on
-  the side stream (TrainStep.run does this itself)."""
-  _wgrad_join(torch.device('cuda', torch.cuda.current_device()))
-
-
 _PACK = {}  # the pack cache of callers outside a TrainStep (tests, one-off layer calls); a TrainStep owns its own
 # (TrainStep._pack, handed to the layer functions through meta['cache']): per step, (weight storage, geometry) -> packed
 # filter — the filters are shared by the T timesteps.  forward_loss() clears the trainer's dict (the optimizer writes the
@@ -503,13 +475,6 @@ class ConvBNActPool(torch.autograd.Function):
         assert slot.setdefault('shape', shape) == shape, 'a deferred filter gradient needs one shape per layer'
         slot['calls'].append((x, du))  # nothing is launched here
         slot.update(cmap_t=cmap_t, gw=gw, gb=gb)
-      elif _WGRAD['on']:
-        side = _wgrad_stream(dev)
-        side.wait_stream(torch.cuda.current_stream())  # du is ready
-        with torch.cuda.stream(side):
-          check(wgrad_acc(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
-                          ptr(cmap_t), int(cin_w), int(tr), ptr(gw), ptr(gb), rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_f32')
-        _WGRAD['keep'].extend((x, du, wws))
       else:
         check(wgrad_acc(ptr(x), Cx, B, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws,
                         ptr(cmap_t), int(cin_w), int(tr), ptr(gw), ptr(gb), rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_f32')
@@ -1402,7 +1367,6 @@ class TrainStep(object):
     self.bucket.zero_grad()
     loss, pieces, stats = self.forward_loss(x, y_gt, s_gt, knobs=knobs, generator=generator, **extra)
     loss.backward()
-    _wgrad_join(self.bucket.param.device)  # the side stream's filter gradients are complete
     with torch.no_grad():  # shadow = 0.9 shadow + 0.1 batch statistic (nnlib.py:103-110)
       if set(stats.keys()) == set(self._stat_views.keys()):  # every BN copy ran: one update of the flat buffers
         self.ema.mul_(EMA_DECAY).add_(self.stat, alpha=1 - EMA_DECAY)

@@ -151,7 +151,6 @@ def test_loss_and_every_gradient_vs_oracle_autograd(cuda):
   ts.bucket.zero_grad()
   loss, pieces, st = ts.forward_loss(x, y_gt, s_gt)
   loss.backward()
-  ra_train.wgrad_join()
   for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
     assert abs(float(pieces[k]) - float(head[k])) < 2e-4 * max(1.0, abs(float(head[k]))), k
   assert (pieces['match'].cpu().numpy() == head['match'].numpy()).all()
@@ -227,7 +226,6 @@ def test_knob_mixing_vs_oracle(cuda, step, fixed, ioub):
   ts.bucket.zero_grad()
   loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd)
   loss.backward()
-  ra_train.wgrad_join()
   for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
     assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
   assert (pieces['match'].cpu().numpy() == head['match'].numpy()).all()
@@ -280,7 +278,6 @@ def test_loss_variants_vs_oracle(cuda, over):
   ts.bucket.zero_grad()
   loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt)
   loss.backward()
-  ra_train.wgrad_join()
   for k in ('loss', 'box_loss', 'segm_loss', 'conf_loss'):
     assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
   _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
@@ -307,7 +304,6 @@ def test_box_model_training_vs_oracle(cuda, over):
   ts.bucket.zero_grad()
   loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs={'noise': noise})
   loss.backward()
-  ra_train.wgrad_join()
   for k in ('loss', 'box_loss', 'conf_loss', 'iou_soft_box'):
     assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
   assert (pieces['match_box'].cpu().numpy() == head['match_box'].numpy()).all()
@@ -379,7 +375,6 @@ def test_kitti_arch_training_vs_oracle(cuda, knob):
   kd = None if knobs is None else {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in knobs.items()}
   loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd, d_in=d_in, y_in=y_in)
   loss.backward()
-  ra_train.wgrad_join()
   for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
     assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
   _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
@@ -734,7 +729,6 @@ def test_fused_controller_equals_library_path(cuda, knob):
       ts.bucket.zero_grad()
       loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd)
       loss.backward()
-      ra_train.wgrad_join()
     assert (getattr(ts, '_ctl', None) is not None) == fused
     res[fused] = (float(loss), {k: ts.bucket.grad_of[k].cpu().numpy().copy() for k in ts.bucket.names})
   assert abs(res[True][0] - res[False][0]) < 2e-4 * max(1.0, abs(res[False][0]))  # float32 through 3 recurrent timesteps, different summation orders
@@ -927,7 +921,6 @@ def test_bf16_training_step_vs_emulating_oracle(cuda):
   ts.bucket.zero_grad()
   loss, pieces, st = ts.forward_loss(x, y_gt, s_gt)
   loss.backward()
-  ra_train.wgrad_join()
   for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
     got = float(pieces[k].detach())
     assert abs(got - float(head[k])) < 3e-2 * max(1.0, abs(float(head[k]))), (k, got, float(head[k]))

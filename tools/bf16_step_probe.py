@@ -21,7 +21,7 @@ for (tt, wm, seed) in [(3, 0.6, 3), (2, 0.6, 3), (3, 0.3, 3), (2, 0.3, 3), (3, 0
     ts = ra_train.TrainStep(m)
     ts.bucket.zero_grad()
     loss, pieces, st = ts.forward_loss(x, y_gt, s_gt)
-    loss.backward(); ra_train.wgrad_join()
+    loss.backward()
     wd = float(opt['weight_decay'])
     got_of = lambda k: ts.bucket.grad_of[k].cpu().numpy()
     worst = max(max(T._rel(st[k][0].cpu().numpy(), mv[0].numpy()), T._rel(st[k][1].cpu().numpy(), mv[1].numpy())) for k, mv in stats.items())
