@@ -584,6 +584,14 @@ int ra_bn_act_pool_bwd_acc_f32(const float *u, const float *dy, const float *mea
                                const float *gamma, const float *beta, float eps, int relu, int pool,
                                int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
                                float *dbeta, float *du, float *acc_gamma, float *acc_beta, void *stream);
+/* G calls of one layer (its G timesteps: per-timestep statistics and parameters, nnlib.py:121-127) stacked along the
+ * batch and differentiated in one reduce / final / dx triple: u [G*B,H,W,C], dy [G*B,H/pool,W/pool,C], du like u;
+ * tabs = a DEVICE table of 6 G pointers {mean, var, gamma, beta, gradient-bucket gamma, gradient-bucket beta}[G]
+ * (the last two are added to); dgamma / dbeta [G,C]; ws of G * ra_bn_workspace_floats(C) floats.  C % 4 == 0 and
+ * C / 4 a power of two <= 64 (RA_E_SHAPE otherwise: call the per-group entry). */
+int ra_bn_act_pool_bwd_grouped_f32(const float *u, const float *dy, const void *const *tabs, int G, float eps,
+                                   int relu, int pool, int B, int H, int W, int C, float *ws, size_t ws_floats,
+                                   float *dgamma, float *dbeta, float *du, void *stream);
 /* The same backward in two launches groups, for data-parallel training on WHOLE-batch statistics (nnlib.py:98
  * takes the moments over the whole batch): _reduce writes this rank's sums dbeta / dgamma (and adds them to
  * acc_*, may be NULL); the caller all-reduces the 2C sums; _dx finishes with the summed vectors and the

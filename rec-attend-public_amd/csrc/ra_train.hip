@@ -145,9 +145,16 @@ template <int POOL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const f32x4 *u, const f32x4 *dy, const float *mean,
                                                                const float *var, const float *gamma, const float *beta,
                                                                float eps, int relu, int B, int H, int W, int C4, int lg,
-                                                               float *part) {
+                                                               float *part, const float *const *tabs = nullptr, int G = 1) {
   __shared__ float red[256];
   const int Ho = H / POOL, Wo = W / POOL;
+  if (tabs) {  // group blockIdx.z of G calls of the layer stacked along the batch: its own statistics and parameters
+    const int g = blockIdx.z;
+    mean = tabs[g], var = tabs[G + g], gamma = tabs[2 * G + g], beta = tabs[3 * G + g];
+    u += (size_t)g * B * H * W * C4;
+    dy += (size_t)g * B * Ho * Wo * C4;
+    part += (size_t)g * gridDim.x * gridDim.y * 2 * 4 * C4;
+  }
   const int er = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
   const bool live = er < Wo * C4;
   const int xo = er >> lg, cg = er & (C4 - 1);
@@ -182,8 +189,18 @@ template <int POOL>
 __global__ __launch_bounds__(256) void bn_bwd_dx_v4_kernel(const f32x4 *u, const f32x4 *dy, const float *mean,
                                                            const float *var, const float *gamma, const float *beta,
                                                            const float *dbeta, const float *dgamma, float eps, int relu,
-                                                           int B, int H, int W, int C4, int lg, f32x4 *du, float inv_n) {
+                                                           int B, int H, int W, int C4, int lg, f32x4 *du, float inv_n,
+                                                           const float *const *tabs = nullptr, int G = 1) {
   const int Ho = H / POOL, Wo = W / POOL;
+  if (tabs) {
+    const int g = blockIdx.z;
+    mean = tabs[g], var = tabs[G + g], gamma = tabs[2 * G + g], beta = tabs[3 * G + g];
+    u += (size_t)g * B * H * W * C4;
+    dy += (size_t)g * B * Ho * Wo * C4;
+    du += (size_t)g * B * H * W * C4;
+    dbeta += (size_t)g * 4 * C4;
+    dgamma += (size_t)g * 4 * C4;
+  }
   const int er = blockIdx.x * 256 + threadIdx.x;
   if (er >= Wo * C4) return;
   const int xo = er >> lg, cg = er & (C4 - 1);
@@ -428,9 +445,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *u, cons
   }
 }
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *part, int nblocks, int C, float *dbeta, float *dgamma,
-                                                           float *acc_beta = nullptr, float *acc_gamma = nullptr) {
+                                                           float *acc_beta = nullptr, float *acc_gamma = nullptr,
+                                                           float *const *tabs = nullptr, int G = 1) {
   __shared__ float red[256];
   const int c = blockIdx.x;
+  if (tabs) {
+    const int g = blockIdx.y;
+    part += (size_t)g * nblocks * 2 * C;
+    dbeta += (size_t)g * C;
+    dgamma += (size_t)g * C;
+    acc_gamma = tabs[4 * G + g], acc_beta = tabs[5 * G + g];
+  }
   float t0 = 0.f, t1 = 0.f;
   for (int k = threadIdx.x; k < nblocks; k += 256) {
     t0 += part[((size_t)k * 2) * C + c];
@@ -695,6 +720,43 @@ int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float 
   return launch_status("ra_bn_act_pool_bwd_f32");
 }
 }  // namespace
+
+// G calls of one BatchNorm layer (its G timesteps) stacked along the batch — u [G*B,H,W,C], dy [G*B,H/pool,W/pool,C] — in
+// one reduce / final / dx triple: every group has its own statistics and parameters, read through a device table of
+// 6 G pointers {mean, var, gamma, beta, grad-bucket gamma, grad-bucket beta}[G]; dgamma / dbeta [G,C].
+extern "C" int ra_bn_act_pool_bwd_grouped_f32(const float *u, const float *dy, const void *const *tabs, int G, float eps, int relu,
+                                              int pool, int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
+                                              float *dbeta, float *du, void *stream) {
+  if (!u || !dy || !tabs || !ws || !dgamma || !dbeta || !du || G <= 0 || B <= 0 || H <= 0 || W <= 0 || C <= 0)
+    return fail(RA_E_INVALID, "ra_bn_act_pool_bwd_grouped_f32: bad argument");
+  if ((pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1))) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_grouped_f32: pool");
+  if (ws_floats < (size_t)G * ra_bn_workspace_floats(C)) return fail(RA_E_WORKSPACE, "ra_bn_act_pool_bwd_grouped_f32: workspace too small");
+  const size_t npix = (size_t)B * H * W;
+  const int lg = train::v4_log2(C, npix * C);
+  if (lg < 0 || ceil_div((W / pool) * (C / 4), 256) > train::kRedBlocks || G > 65535)
+    return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_grouped_f32: C %d (needs C %% 4 == 0, C / 4 a power of two <= 64)", C);
+  hipStream_t st = as_stream(stream);
+  const float inv_n = (float)(1.0 / (double)npix);
+  const int C4 = C / 4, rows = B * (H / pool), gx = ceil_div((W / pool) * C4, 256);
+  int gy = train::kRedBlocks / gx;
+  if (gy > rows) gy = rows;
+  const train::f32x4 *u4 = reinterpret_cast<const train::f32x4 *>(u), *dy4 = reinterpret_cast<const train::f32x4 *>(dy);
+  train::f32x4 *du4 = reinterpret_cast<train::f32x4 *>(du);
+  const float *const *ct = reinterpret_cast<const float *const *>(tabs);
+  float *const *mt = reinterpret_cast<float *const *>(const_cast<void *const *>(tabs));
+  const dim3 gr(gx, gy, G), gd(gx, rows < 16384 ? rows : 16384, G);
+  const float *nul = nullptr;
+  if (pool == 2) {
+    hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<2>, gr, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, eps, relu, B, H, W, C4, lg, ws, ct, G);
+    hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C, G), dim3(256), 0, st, ws, gx * gy, C, dbeta, dgamma, (float *)nullptr, (float *)nullptr, mt, G);
+    hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<2>, gd, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, dbeta, dgamma, eps, relu, B, H, W, C4, lg, du4, inv_n, ct, G);
+  } else {
+    hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<1>, gr, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, eps, relu, B, H, W, C4, lg, ws, ct, G);
+    hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C, G), dim3(256), 0, st, ws, gx * gy, C, dbeta, dgamma, (float *)nullptr, (float *)nullptr, mt, G);
+    hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<1>, gd, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, dbeta, dgamma, eps, relu, B, H, W, C4, lg, du4, inv_n, ct, G);
+  }
+  return launch_status("ra_bn_act_pool_bwd_grouped_f32");
+}
 
 extern "C" int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const float *mean, const float *var,
                                       const float *gamma, const float *beta, float eps, int relu, int pool, int B,

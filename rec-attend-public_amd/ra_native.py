@@ -130,6 +130,7 @@ SIGNATURES = {
     'ra_conv3x3_wgrad_acc_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
     'ra_box_iou_rects_workspace_floats': (_Z, [_I]),
     'ra_box_iou_rects_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    'ra_bn_act_pool_bwd_grouped_f32': (_I, [_P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
     'ra_ptr_table': (_I, [_P, _I, _P, _P]),
     'ra_conv3x3_wgrad_multi_acc_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _I, _P]),
     'ra_conv3x3_wgrad_acc_bf16ops_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),

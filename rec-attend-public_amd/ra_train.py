@@ -17,6 +17,7 @@ all-reduces the two per-channel sums, so that normalisation and gradient equal t
 broadcast from rank 0 when a trainer is built (broadcast_state), so ranks start from ONE model whatever
 their random seeds were.
 """
+import contextlib
 import math
 import os
 
@@ -367,10 +368,12 @@ class ConvBNActPool(torch.autograd.Function):
     mean = var = None
     if use_bn:
       mean, var = meta['stat_out'] if meta.get('stat_out') is not None else (_f(cout, device=dev), _f(cout, device=dev))
+    alloc = meta.get('alloc')  # the batched-backward step keeps u / y of a layer's T calls in one [T, ...] slab
+    place = (lambda kind, *shape: alloc(kind, shape)) if alloc is not None else (lambda kind, *shape: _f(*shape, device=dev))
+    up = 2 if stride == 2 else 1
     if use_bn and cout % 4 == 0 and EPILOGUE_MOMENTS['on']:
       # the batch moments ride on the conv epilogue: per-wave channel sums, then one small finishing launch
-      up = 2 if stride == 2 else 1
-      u = _f(B, Hs * up, Ws * up, cout, device=dev)
+      u = place('u', B, Hs * up, Ws * up, cout)
       part = _f(rn.lib().ra_conv3x3_moments_part_floats(cout), device=dev)
       nparts = _C.c_int(0)
       check(rn.lib().ra_conv3x3_moments_f32(ptr(x), Cx, None, 0, B, Hs, Ws, int(stride == 2), ptr(wp), ptr(scale), ptr(shift),
@@ -380,7 +383,8 @@ class ConvBNActPool(torch.autograd.Function):
             'ra_bn_moments_from_partials_f32')
       H, W = u.shape[1], u.shape[2]
     else:
-      u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2), bf16=bf)
+      u = ops.conv3x3(x, wp, scale, shift, cout, relu=False, pool=1, upsample=(stride == 2), bf16=bf,
+                      out=place('u', B, Hs * up, Ws * up, cout))
       H, W = u.shape[1], u.shape[2]
       if use_bn:
         ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
@@ -389,7 +393,7 @@ class ConvBNActPool(torch.autograd.Function):
     if use_bn:
       # whole-batch statistics under data parallelism (nnlib.py:98): one all_gather of (count, mean, var)
       ctx.n_total = sync_moments(mean, var, B * H * W) if meta.get('sync_bn') else 0.0
-    y = _f(B, H // pool, W // pool, cout, device=dev)
+    y = place('y', B, H // pool, W // pool, cout)
     check(rn.lib().ra_bn_act_pool_f32(ptr(u), ptr(mean), ptr(var), ptr(gamma), ptr(beta), _C.c_float(BN_EPS), int(relu),
                                       int(pool), B, H, W, cout, ptr(y), rn.stream_ptr()), 'ra_bn_act_pool_f32')
     ctx.meta, ctx.cmap, ctx.cache = meta, cmap, cache
@@ -522,6 +526,93 @@ class ConvBNActPool(torch.autograd.Function):
         dx = dxr
     use_bn = gamma is not None
     return dx, dw, db, (dgamma if use_bn else None), (dbeta if use_bn else None), None
+
+
+def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf):
+  """Backward-data of ConvBNActPool's conv: the same MFMA conv kernel on the flipped / in-out-swapped packing."""
+  dev = du.device
+  B, Hs, Ws, Cx = x_shape
+  cout = du.shape[3]
+  duc = _pad_channels(du)
+  cd = duc.shape[3]
+  cpb = ops.cout_padded(cin_w)
+  ones = _const('ones', cpb, dev, lambda: torch.ones(cpb, dtype=torch.float32, device=dev))
+  zeros = _const('zeros', cpb, dev, lambda: torch.zeros(cpb, dtype=torch.float32, device=dev))
+  wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr, cache)
+  dxr = ops.conv3x3(duc, wpb, ones, zeros, cin_w, relu=False, pool=1, bf16=bf)
+  if stride == 2:
+    sub = _f(B, Hs, Ws, cin_w, device=dev)
+    check(rn.lib().ra_subsample_odd_f32(ptr(dxr), B, Hs, Ws, cin_w, ptr(sub), rn.stream_ptr()), 'ra_subsample_odd_f32')
+    dxr = sub
+  if cmap is not None:
+    dx = torch.zeros((B, Hs, Ws, Cx), dtype=torch.float32, device=dev)
+    for c, j in enumerate(cmap):
+      if j >= 0:
+        dx[..., c] = dxr[..., j]
+    return dx
+  if Cx != cin_w:
+    dx = torch.zeros((B, Hs, Ws, Cx), dtype=torch.float32, device=dev)
+    dx[..., :cin_w] = dxr
+    return dx
+  return dxr
+
+
+class ConvStackFn(torch.autograd.Function):
+  """The T calls of one conv + BatchNorm + ReLU + pool layer of a training step (its T timesteps: shared filter,
+  per-timestep statistics and BatchNorm parameters, nnlib.py:121-127) as ONE node of the autograd graph.
+
+  The timesteps of full_model are coupled only through the canvas, whose gradient is stopped (full_model.py:843-848),
+  and the controller state starts from zero in each: once the sequential forward has filled the layer's [T, ...] slabs
+  (x, u, y, statistics), the backward passes of the T timesteps are independent and run here stacked along the batch —
+  one grouped BatchNorm backward (ra_bn_act_pool_bwd_grouped_f32), one filter gradient and one data gradient over
+  T * B images instead of T of each.  forward() returns the precomputed y slab."""
+
+  @staticmethod
+  def forward(ctx, X, w, b, info):
+    ctx.set_materialize_grads(False)
+    ctx.info = info
+    ctx.save_for_backward(X, w)
+    return info['Y']
+
+  @staticmethod
+  def backward(ctx, dY):
+    if dY is None:
+      return None, None, None, None
+    X, w = ctx.saved_tensors
+    info = ctx.info
+    G, B, U, dev = info['G'], info['B'], info['U'], X.device
+    tr, stride, pool, relu, cmap, bf = info['transposed'], info['stride'], info['pool'], info['relu'], info['chan_map'], info['bf16']
+    N, Hs, Ws, Cx = X.shape
+    _, H, W, cout = U.shape
+    cin_w = w.shape[3] if tr else w.shape[2]
+    gw, gb = info['gw'], info['gb']
+    dY = dY.contiguous()
+    du = torch.empty_like(U)
+    nbn = rn.lib().ra_bn_workspace_floats(cout)
+    if cout % 4 == 0:
+      dgam, dbet, ws = _f(G, cout, device=dev), _f(G, cout, device=dev), _f(G * nbn, device=dev)
+      check(rn.lib().ra_bn_act_pool_bwd_grouped_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu), int(pool),
+                                                    B, H, W, cout, ptr(ws), ws.numel(), ptr(dgam), ptr(dbet), ptr(du),
+                                                    rn.stream_ptr()), 'ra_bn_act_pool_bwd_grouped_f32')
+    else:  # a channel count the float4 kernels do not take (the one-channel output layer): one call per timestep
+      ws, dgam, dbet = _f(nbn, device=dev), _f(cout, device=dev), _f(cout, device=dev)
+      Ho, Wo = H // pool, W // pool
+      for g, (mean, var, gamma, beta, gg, gbt) in enumerate(info['per_group']):
+        sl = slice(g * B, (g + 1) * B)
+        check(rn.lib().ra_bn_act_pool_bwd_acc_f32(ptr(U[sl]), ptr(dY[sl]), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                                  _C.c_float(BN_EPS), int(relu), int(pool), B, H, W, cout, ptr(ws), ws.numel(),
+                                                  ptr(dgam), ptr(dbet), ptr(du[sl]), ptr(gg), ptr(gbt), rn.stream_ptr()),
+              'ra_bn_act_pool_bwd_acc_f32')
+    cmap_t = _const('cmap', tuple(cmap), dev, lambda: torch.tensor(cmap, dtype=torch.int32, device=dev)) if cmap is not None else None
+    nws = rn.lib().ra_conv3x3_wgrad_workspace_floats(Cx, cout, N, H, W)
+    wws = info['cache'].get(('wgrad_ws', nws))
+    if wws is None:
+      wws = info['cache'][('wgrad_ws', nws)] = _f(nws, device=dev)
+    wgrad = rn.lib().ra_conv3x3_wgrad_acc_bf16ops_f32 if bf else rn.lib().ra_conv3x3_wgrad_acc_f32
+    check(wgrad(ptr(X), Cx, N, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws, ptr(cmap_t), int(cin_w), int(tr), ptr(gw),
+                ptr(gb), rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_f32')
+    dx = _conv_dgrad(du, w, tr, stride, cmap, X.shape, cin_w, info['cache'], bf) if ctx.needs_input_grad[0] else None
+    return dx, None, None, None
 
 
 class PairIoU(torch.autograd.Function):
@@ -717,9 +808,10 @@ class ControllerFn(torch.autograd.Function):
     feat = feat.contiguous()
     B, G, Cf = feat.shape
     hid, iters = bufs.hid, bufs.iters
-    h, co = bufs.hfin[tt], torch.empty((B, 9), dtype=torch.float32, device=feat.device)
+    sel = (lambda t: t.view((-1,) + t.shape[2:])) if tt == 'all' else (lambda t: t[tt])  # 'all': the T timesteps stacked
+    h, co = sel(bufs.hfin), torch.empty((B, 9), dtype=torch.float32, device=feat.device)
     check(rn.lib().ra_ctrl_train_fwd_f32(B, G, Cf, hid, iters, 9, ptr(feat), ptr(Wg), ptr(bg), ptr(W0), ptr(b0), ptr(W1), ptr(b1),
-                                         ptr(Wc), ptr(bc), ptr(h), ptr(co), ptr(bufs.save[tt]), rn.stream_ptr()), 'ra_ctrl_train_fwd_f32')
+                                         ptr(Wc), ptr(bc), ptr(h), ptr(co), ptr(sel(bufs.save)), rn.stream_ptr()), 'ra_ctrl_train_fwd_f32')
     ctx.save_for_backward(feat, Wg, W0, W1, Wc)
     ctx.bufs, ctx.tt = bufs, tt
     return h, co  # h is the trainer's row buffer hfin[tt] (the GEMM input of the controller MLP's gradient): nothing writes it again this step
@@ -733,11 +825,12 @@ class ControllerFn(torch.autograd.Function):
       torch.autograd.Variable._execution_engine.queue_callback(bufs)
     B, G, Cf = feat.shape
     dfeat = torch.empty_like(feat)
+    sel = (lambda t: t.view((-1,) + t.shape[2:])) if tt == 'all' else (lambda t: t[tt])
     if dco is not None:
-      bufs.dco[tt].copy_(dco)
+      sel(bufs.dco).copy_(dco)
     check(rn.lib().ra_ctrl_train_bwd_f32(B, G, Cf, bufs.hid, bufs.iters, 9, ptr(feat), ptr(Wg), ptr(W0), ptr(W1), ptr(Wc),
-                                         ptr(bufs.save[tt]), ptr(_dense(dh)), ptr(bufs.dco[tt]) if dco is not None else None,
-                                         ptr(dfeat), ptr(bufs.dpre[tt]), ptr(bufs.dz1[tt]), ptr(bufs.dlog[tt]), rn.stream_ptr()),
+                                         ptr(sel(bufs.save)), ptr(_dense(dh)), ptr(sel(bufs.dco)) if dco is not None else None,
+                                         ptr(dfeat), ptr(sel(bufs.dpre)), ptr(sel(bufs.dz1)), ptr(sel(bufs.dlog)), rn.stream_ptr()),
           'ra_ctrl_train_bwd_f32')
     return (dfeat,) + (None,) * 10
 
@@ -979,6 +1072,7 @@ class TrainStep(object):
     self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else int(world)
     self._pack = {}  # this trainer's per-step cache of packed filters / padded biases / packed LSTM weights
     self._wgrad_parts = _DeferredWgrads()
+    self._slabs, self._bn_tabs = {}, {}  # the batched-backward step's [T, ...] buffers and per-layer BatchNorm pointer tables
     self._graphs = {}
     self.leaves = {}
     for k in self.bucket.names:
@@ -1047,7 +1141,7 @@ class TrainStep(object):
       meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None,
                   stat_out=self._stat_views.get(key), grads=self._grad_views(scope, i, key, bn), cache=self._pack,
                   sync_bn=self.sync_bn, bf16=self.bf16, wgrad_defer=self._wgrad_parts if self.defer_wgrad else None,
-                  wgrad_key=(scope, i))
+                  wgrad_key=(scope, i), alloc=self._tape_alloc(scope, i, tt, meta_of=(False, 1, pools[i], cmap0 if i == 0 else None)))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x) if i else x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -1074,7 +1168,8 @@ class TrainStep(object):
         x = torch.cat([xp, skp], dim=3)
       meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key),
                   grads=self._grad_views(scope, i, key, bn), cache=self._pack, sync_bn=self.sync_bn, bf16=self.bf16,
-                  wgrad_defer=self._wgrad_parts if self.defer_wgrad else None, wgrad_key=(scope, i))
+                  wgrad_defer=self._wgrad_parts if self.defer_wgrad else None, wgrad_key=(scope, i),
+                  alloc=self._tape_alloc(scope, i, tt, meta_of=(True, unpool[i], 1, cmap)))
       x, mean, var = ConvBNActPool.apply(_pad_channels(x), P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)],
                                          P[key + '_gamma'] if bn else None, P[key + '_beta'] if bn else None, meta)
       if bn:
@@ -1087,6 +1182,100 @@ class TrainStep(object):
     if self.fuse_param_grads and torch.is_grad_enabled() and wname in g and bname in g:
       return LinearAcc.apply(x, P[wname], P[bname], g[wname], g[bname])
     return torch.addmm(P[bname], x, P[wname])
+
+  # ------------------------------------------------------------------ the T timesteps' backward passes, stacked
+  # full_model's timesteps are coupled only through the canvas (gradient stopped, full_model.py:843-848; the controller
+  # state starts from zero in each, :668-689).  So the step runs in two phases: (1) the sequential forward WITHOUT an
+  # autograd tape, every conv layer writing its u / y into [T, ...] slabs; (2) the differentiable graph built ONCE over
+  # T * B stacked images — the conv layers as ConvStackFn nodes over the slabs (no recomputation), the cheap per-image
+  # pieces (controller, attention head, knob, extract, paste, score) re-run stacked — whose backward pass is then one
+  # launch group per layer instead of one per layer and timestep.  Same numbers as the per-timestep graph up to
+  # summation order; tests/test_train_gpu.py compares both with the float64 oracle.
+  batched_backward = os.environ.get('RA_BATCHED_BWD', '1') != '0'
+  _tape = None
+
+  def _batched_ok(self, extra):
+    d, opt = self.d, self.opt
+    c4 = lambda cs: all(c % 4 == 0 for c in cs)
+    return bool(self.batched_backward and torch.is_grad_enabled() and d['use_bn'] and self.fuse_param_grads and
+                self.fuse_controller and not self.sync_bn and not d['add_d_out'] and not extra and
+                not (d['skip_ch'] is not None and any(d['skip_ch'])) and
+                not opt.get('use_iou_box', False) and opt.get('box_loss_fn', 'iou') == 'iou' and
+                c4(self.model.dims['ccnn_channels'][1:]) and c4(opt['attn_cnn_depth']) and c4(opt['attn_dcnn_depth'][:-1]) and
+                self.model.dims['C0p'] % 4 == 0 and d['n_gmlp'] == 2 and d['n_cmlp'] == 1)
+
+  def _slab(self, name, T, shape):
+    """[T, *shape] buffer of the step (one slot per timestep), kept across steps."""
+    t = self._slabs.get(name)
+    if t is None or tuple(t.shape) != (T,) + tuple(shape):
+      t = self._slabs[name] = torch.empty((T,) + tuple(shape), dtype=torch.float32, device=self.bucket.param.device)
+    return t
+
+  def _tape_alloc(self, scope, i, tt, meta_of):
+    """ConvBNActPool's output placement while the sequential phase runs: u / y of layer (scope, i) at timestep tt."""
+    tape = self._tape
+    if tape is None:
+      return None
+    tape['layers'][(scope, i)] = meta_of
+    T = self.d['T']
+    return lambda kind, shape: self._slab('%s_%d_%s' % (scope, i, kind), T, shape)[tt]
+
+  def _bn_tables(self, scope, i):
+    """Device table of 6 T pointers {mean, var, gamma, beta, gradient gamma, gradient beta}[T] of layer (scope, i) (static:
+    the flat statistics buffer and the parameter / gradient bucket never move) + the same as per-timestep tensors."""
+    hit = self._bn_tabs.get((scope, i))
+    if hit is None:
+      T, P, g = self.d['T'], self.leaves, self.bucket.grad_of
+      keys = ['%s_%d_%d' % (scope, i, tt) for tt in range(T)]
+      cols = [[self._stat_views[k][0] for k in keys], [self._stat_views[k][1] for k in keys], [P[k + '_gamma'] for k in keys],
+              [P[k + '_beta'] for k in keys], [g[k + '_gamma'] for k in keys], [g[k + '_beta'] for k in keys]]
+      tab = torch.tensor([t.data_ptr() for col in cols for t in col], dtype=torch.int64).to(self.bucket.param.device)
+      hit = self._bn_tabs[(scope, i)] = (tab, list(zip(*cols)))
+    return hit
+
+  def _stack_layers(self, X, scope, n):
+    """Phase 2: the n layers of a net as ConvStackFn nodes over the slabs the sequential phase filled."""
+    T, P = self.d['T'], self.leaves
+    for i in range(n):
+      tr, stride, pool, cmap = self._tape['layers'][(scope, i)]
+      U, Y = self._slabs['%s_%d_u' % (scope, i)], self._slabs['%s_%d_y' % (scope, i)]
+      tab, per_group = self._bn_tables(scope, i)
+      gw, gb = self.bucket.grad_of['%s_w_%d' % (scope, i)], self.bucket.grad_of['%s_b_%d' % (scope, i)]
+      info = dict(G=T, B=U.shape[1], U=U.view((-1,) + U.shape[2:]), Y=Y.view((-1,) + Y.shape[2:]), transposed=tr, stride=stride,
+                  pool=pool, relu=True, chan_map=cmap, bf16=self.bf16, tabs=tab, per_group=per_group, gw=gw, gb=gb, cache=self._pack)
+      X = ConvStackFn.apply(X, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)], info)
+    return X
+
+  def _stacked_graph(self, inp_slab, matches, knob_box, gt_windows, head_flags, cc):
+    """Phase 2: the differentiable graph of all T timesteps at once, images stacked (t, b).  Returns y_out [B,T,H,W],
+    s_out [B,T], attn_box [B,T,H,W] with their autograd history."""
+    d, P = self.d, self.leaves
+    T, H, W, Fh, Fw = d['T'], d['H'], d['W'], d['Fh'], d['Fw']
+    B = inp_slab.shape[1]
+    N = T * B
+    inp_all = inp_slab.view((N,) + inp_slab.shape[2:])
+    feat = self._stack_layers(inp_all, 'ctrl_cnn', d['ccnn_nlayers'])
+    bufs = self._ctrl_buffers(B, feat.shape[3])
+    Wg, bg = self._lstm_weights()
+    h, co = ControllerFn.apply(feat.reshape(N, d['G'], -1), Wg.detach(), bg.detach(), P['glimpse_mlp_w_0'].detach(),
+                               P['glimpse_mlp_b_0'].detach(), P['glimpse_mlp_w_1'].detach(), P['glimpse_mlp_b_1'].detach(),
+                               P['ctrl_mlp_w_0'].detach(), P['ctrl_mlp_b_0'].detach(), bufs, 'all')
+    cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
+    box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
+    if knob_box is not None:  # the matches of phase 1 are constants of the graph (they were never differentiated)
+      match_all = torch.stack(matches, dim=0).reshape(N, T)
+      rep = lambda t: t.unsqueeze(0).expand((T,) + tuple(t.shape)).reshape((N,) + tuple(t.shape[1:])).contiguous()
+      knob_all = knob_box.reshape(B, T).t().reshape(N).contiguous()
+      ctr, size = KnobMix.apply(ctr, size, match_all, rep(gt_windows[0]), rep(gt_windows[1]), knob_all)
+    x_patch = AttnExtract.apply(inp_all, ctr, size, lg_var, ag, Fh, Fw)
+    core = self._stack_layers(x_patch, 'attn_cnn', d['acnn_nlayers'])
+    y_patch = self._stack_layers(core, 'attn_dcnn', d['adcnn_nlayers'])
+    y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)
+    if d['disable_overwrite']:
+      y = (1.0 - inp_all[..., cc]) * y
+    s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(N, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
+    to_bt = lambda t: t.view((T, B) + tuple(t.shape[1:])).transpose(0, 1).contiguous()
+    return to_bt(y), to_bt(s).reshape(B, T), to_bt(box)
 
   fuse_controller = True  # the controller of a timestep as one forward and one backward launch
 
@@ -1241,66 +1430,85 @@ class TrainStep(object):
     inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
     if inp.shape[3] != d['C0p']:
       inp = _pad_channels(inp)
-    for tt in range(T):
-      feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
-      h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
-      # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
-      cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
-      # attention box: sigmoid(box_gamma * extract_patch(ones, F_y^T, F_x^T) - 5) (full_model.py:738-741)
-      box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
-      if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
-        if fixed:
-          gmatch = None
-          gsel_box = _const('onehot', (B, T, tt), dev, lambda: torch.nn.functional.one_hot(
-              torch.full((B,), tt, device=dev), T).to(torch.float32))
-        else:
-          if opt.get('use_iou_box', False):  # IoU of the box corners (modellib.f_iou_box, full_model.py:750-754)
-            import modellib
-            iou_row = modellib.f_iou_box((ctr - size / 2.0)[:, None], (ctr + size / 2.0)[:, None], gt_corners[:, :, 0:2],
-                                         gt_corners[:, :, 2:4])
-            iou_box_steps.append(iou_row[:, None, :])  # the row of the [B,T,T] matrix the box matching and loss use (:931-934)
-            iou_t = iou_row.detach().contiguous()
+    batched = self._batched_ok(extra) and self._ctrl_buffers(B, self.model.dims['ccnn_channels'][-1]) is not None
+    self._tape = dict(layers={}) if batched else None
+    tape_match = []
+    if batched:  # phase 1 runs without an autograd tape; the packed inputs of the T timesteps live in one slab
+      inp_slab = self._slab('inp', T, tuple(inp.shape))
+      inp_slab[0].copy_(inp)
+      inp = inp_slab[0]
+    with (torch.no_grad() if batched else contextlib.nullcontext()):
+      for tt in range(T):
+        feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
+        h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
+        # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
+        cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
+        # attention box: sigmoid(box_gamma * extract_patch(ones, F_y^T, F_x^T) - 5) (full_model.py:738-741)
+        box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
+        if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
+          if fixed:
+            gmatch = None
+            gsel_box = _const('onehot', (B, T, tt), dev, lambda: torch.nn.functional.one_hot(
+                torch.full((B,), tt, device=dev), T).to(torch.float32))
           else:
-            # f_iou of the box against the T ground-truth rectangles: one read of the box (not of the T planes too)
-            iou_t = ops.box_iou_rects(box.detach(), gt_corners) if W % 4 == 0 and T <= 32 else \
-                ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
-          gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
-          gsel_box = gmatch
-        # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)
-        ctr, size = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt])
-      x_patch = AttnExtract.apply(inp.detach(), ctr, size, lg_var, ag, Fh, Fw)
-      h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
-      core = h_acnn[-1]
-      skips = None
-      if d['skip_ch'] is not None and any(d['skip_ch']):   # full_model.py:798-805: reversed CNN outputs, then x_patch
-        full_a, _ = self.model.engine._chan_map(d['attn_in'])
-        rev = [(hh, None) for hh in h_acnn[::-1][1:]] + [(x_patch, full_a)]
-        skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None
-                          for i in range(1, d['adcnn_nlayers'])]
-      y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
-      y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)  # [B,H,W]
-      if d['disable_overwrite']:
-        y = (1.0 - inp[..., cc]) * y
-      s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
-      # canvas <- max(y_c, canvas) with y_c = y, or with the knob: the (noisy) matched ground-truth segmentation mixed in
-      # (:826-848, stop_canvas_grad) — and the next timestep's packed input, in one launch (ra_canvas_step_f32)
-      nxt = torch.empty_like(inp)
-      yd = y.detach().contiguous()
-      if use_knob:
-        noise, ks = knobs['segm_noise'][tt].contiguous(), knob_segm[:, tt]
-        check(rn.lib().ra_canvas_step_f32(ptr(inp), inp.shape[3], cc, B, H * W, ptr(yd), ptr(gsel_box), ptr(y_gt), T, ptr(noise),
-                                          ptr(ks), int(ks.stride(0)), ptr(nxt), rn.stream_ptr()), 'ra_canvas_step_f32')
-      else:
-        check(rn.lib().ra_canvas_step_f32(ptr(inp), inp.shape[3], cc, B, H * W, ptr(yd), None, None, T, None, None, 1, ptr(nxt),
-                                          rn.stream_ptr()), 'ra_canvas_step_f32')
-      inp = nxt
-      y_list.append(y)
-      s_list.append(s)
-      box_list.append(box)
-      cn_list.append(cn)
-      ls_list.append(ls)
-    y_out, s_out = torch.stack(y_list, dim=1), torch.cat(s_list, dim=1)
-    attn_box = torch.stack(box_list, dim=1)
+            if opt.get('use_iou_box', False):  # IoU of the box corners (modellib.f_iou_box, full_model.py:750-754)
+              import modellib
+              iou_row = modellib.f_iou_box((ctr - size / 2.0)[:, None], (ctr + size / 2.0)[:, None], gt_corners[:, :, 0:2],
+                                           gt_corners[:, :, 2:4])
+              iou_box_steps.append(iou_row[:, None, :])  # the row of the [B,T,T] matrix the box matching and loss use (:931-934)
+              iou_t = iou_row.detach().contiguous()
+            else:
+              # f_iou of the box against the T ground-truth rectangles: one read of the box (not of the T planes too)
+              iou_t = ops.box_iou_rects(box.detach(), gt_corners) if W % 4 == 0 and T <= 32 else \
+                  ops.pair_stats(box.detach()[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft']
+            gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
+            gsel_box = gmatch
+          # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)
+          ctr, size = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt])
+        x_patch = AttnExtract.apply(inp.detach(), ctr, size, lg_var, ag, Fh, Fw)
+        if batched:  # the attention CNN's first input of every timestep, contiguous over T for the stacked filter gradient
+          slot = self._slab('xpatch', T, tuple(x_patch.shape))[tt]
+          slot.copy_(x_patch)
+          x_patch = slot
+          if use_knob:
+            tape_match.append(gsel_box)
+        h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
+        core = h_acnn[-1]
+        skips = None
+        if d['skip_ch'] is not None and any(d['skip_ch']):   # full_model.py:798-805: reversed CNN outputs, then x_patch
+          full_a, _ = self.model.engine._chan_map(d['attn_in'])
+          rev = [(hh, None) for hh in h_acnn[::-1][1:]] + [(x_patch, full_a)]
+          skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None
+                            for i in range(1, d['adcnn_nlayers'])]
+        y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
+        y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)  # [B,H,W]
+        if d['disable_overwrite']:
+          y = (1.0 - inp[..., cc]) * y
+        s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
+        # canvas <- max(y_c, canvas) with y_c = y, or with the knob: the (noisy) matched ground-truth segmentation mixed in
+        # (:826-848, stop_canvas_grad) — and the next timestep's packed input, in one launch (ra_canvas_step_f32)
+        nxt = inp_slab[tt + 1] if (batched and tt + 1 < T) else torch.empty_like(inp)
+        yd = y.detach().contiguous()
+        if use_knob:
+          noise, ks = knobs['segm_noise'][tt].contiguous(), knob_segm[:, tt]
+          check(rn.lib().ra_canvas_step_f32(ptr(inp), inp.shape[3], cc, B, H * W, ptr(yd), ptr(gsel_box), ptr(y_gt), T, ptr(noise),
+                                            ptr(ks), int(ks.stride(0)), ptr(nxt), rn.stream_ptr()), 'ra_canvas_step_f32')
+        else:
+          check(rn.lib().ra_canvas_step_f32(ptr(inp), inp.shape[3], cc, B, H * W, ptr(yd), None, None, T, None, None, 1, ptr(nxt),
+                                            rn.stream_ptr()), 'ra_canvas_step_f32')
+        inp = nxt
+        y_list.append(y)
+        s_list.append(s)
+        box_list.append(box)
+        cn_list.append(cn)
+        ls_list.append(ls)
+    if batched:
+      y_out, s_out, attn_box = self._stacked_graph(inp_slab, tape_match, knob_box if use_knob else None,
+                                                   (ctr_gtn, size_gtn) if use_knob else None, head_flags, cc)
+      self._tape = None
+    else:
+      y_out, s_out = torch.stack(y_list, dim=1), torch.cat(s_list, dim=1)
+      attn_box = torch.stack(box_list, dim=1)
     # ---- losses (full_model.py:913-1035), box_loss_fn = segm_loss_fn = 'iou'.  With the knob the
     # reference stacks the per-timestep box IoUs (:931-934): for use_iou_box = False (f_inter / f_union of the
     # predicted box against every GT box) the same numbers as the pairwise f_iou; with use_iou_box the stacked
