@@ -1008,3 +1008,46 @@ def test_box_iou_against_rectangles(cuda, B, T, H, W):
   got = ops.box_iou_rects(box, params).cpu().numpy()
   ref = ops.pair_stats(box[:, None].contiguous(), box_gt, want=('iou_soft',))['iou_soft'].cpu().numpy().reshape(B, T)
   assert np.abs(got - ref).max() < 1e-5 * max(1e-3, np.abs(ref).max()), np.abs(got - ref).max()
+
+
+def test_stacked_backward_equals_per_timestep_graph(cuda):
+  """TrainStep.batched_backward (the T timesteps' backward passes as one stacked pass per layer: ConvStackFn over the
+  [T, ...] slabs, ra_bn_act_pool_bwd_grouped_f32) against the per-timestep autograd graph on the same weights and
+  knob draws: same loss pieces and matching, every parameter gradient within 2e-4 of the tensor's scale (the sums run
+  in a different order), BatchNorm statistics identical; and the stacked path is the one that ran."""
+  import full_model
+  opt, P, x, y_gt, s_gt = _case(wmul=0.6, **KNOB_OPT)
+  res = {}
+  for mode in (True, False):
+    m = full_model.get_model(opt).load_weights(P)
+    ts = ra_train.TrainStep(m)
+    ts.batched_backward = mode
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    knobs = ts.draw_knobs(x.shape[0], gen)
+    calls = {'n': 0}
+    orig = ra_train.ConvStackFn.forward
+
+    def counting(ctx, *a, _orig=orig):
+      calls['n'] += 1
+      return _orig(ctx, *a)
+    ra_train.ConvStackFn.forward = staticmethod(counting)
+    try:
+      ts.bucket.zero_grad()
+      loss, pieces, st = ts.forward_loss(x, y_gt, s_gt, knobs=knobs)
+      loss.backward()
+    finally:
+      ra_train.ConvStackFn.forward = staticmethod(orig)
+    torch.cuda.synchronize()
+    assert calls['n'] == (21 if mode else 0), calls
+    res[mode] = (float(loss.detach()), pieces['match'].cpu().numpy(), ts.bucket.grad.clone().cpu().numpy(), ts.stat.clone().cpu().numpy(),
+                 {k: ts.bucket.grad_of[k].cpu().numpy().copy() for k in ts.bucket.names})
+  a, b = res[True], res[False]
+  assert abs(a[0] - b[0]) < 1e-6 * max(1.0, abs(b[0])) and (a[1] == b[1]).all()
+  assert np.array_equal(a[3], b[3])
+  gscale = max(np.abs(g).max() for g in b[4].values())
+  for k, g in b[4].items():
+    if _pre_bn_bias(k):  # a bias in front of BatchNorm has zero gradient: both are round-off
+      assert np.abs(a[4][k]).max() < 2e-3 * gscale, k
+      continue
+    err = np.abs(a[4][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
+    assert err < 2e-4, (k, err)
