@@ -1484,7 +1484,8 @@ class TrainStep(object):
         y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)  # [B,H,W]
         if d['disable_overwrite']:
           y = (1.0 - inp[..., cc]) * y
-        s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
+        # (the score is not an input of the next timestep: the stacked graph computes it once for all timesteps)
+        s = None if batched else torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
         # canvas <- max(y_c, canvas) with y_c = y, or with the knob: the (noisy) matched ground-truth segmentation mixed in
         # (:826-848, stop_canvas_grad) — and the next timestep's packed input, in one launch (ra_canvas_step_f32)
         nxt = inp_slab[tt + 1] if (batched and tt + 1 < T) else torch.empty_like(inp)
