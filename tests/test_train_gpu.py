@@ -1051,3 +1051,34 @@ def test_stacked_backward_equals_per_timestep_graph(cuda):
       continue
     err = np.abs(a[4][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
     assert err < 2e-4, (k, err)
+
+
+def test_stacked_step_with_disable_overwrite_vs_oracle(cuda):
+  """disable_overwrite = True (the reference's default, full_model.py:117-120: y *= 1 - canvas) through the stacked
+  training graph: loss pieces and the whole gradient against float64 autograd (cosine; on this three-timestep random
+  network single late-timestep BatchNorm parameters sit at 5-6 % from float64 in BOTH forms of the float32 graph), every
+  parameter gradient within 2e-4 of the per-timestep graph, and the stacked form is what ran."""
+  import full_model
+  opt, P, x, y_gt, s_gt = _case(wmul=0.6, disable_overwrite=True)
+  head, gref, stats = _oracle_grads(opt, P, x, y_gt, s_gt)
+  grads = {}
+  for mode in (True, False):
+    m = full_model.get_model(opt).load_weights(P)
+    ts = ra_train.TrainStep(m)
+    ts.batched_backward = mode
+    assert ts._batched_ok([]) == mode
+    ts.bucket.zero_grad()
+    loss, pieces, st = ts.forward_loss(x, y_gt, s_gt)
+    loss.backward()
+    assert ('ctrl_cnn_0_u' in ts._slabs) == mode
+    for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
+      assert abs(float(pieces[k].detach()) - float(head[k])) < 2e-4 * max(1.0, abs(float(head[k]))), k
+    assert (pieces['match'].cpu().numpy() == head['match'].numpy()).all()
+    grads[mode] = {k: ts.bucket.grad_of[k].cpu().numpy().copy() for k in ts.bucket.names}
+    cos = _grad_cosine(gref, lambda k: grads[mode][k], P, float(opt['weight_decay']))
+    assert cos > 0.9995, (mode, cos)
+  gscale = max(np.abs(g).max() for g in grads[False].values())
+  for k, g in grads[False].items():
+    if not _pre_bn_bias(k):
+      err = np.abs(grads[True][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
+      assert err < 2e-4, (k, err)
