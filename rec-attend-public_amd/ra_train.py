@@ -596,7 +596,6 @@ class ConvStackFn(torch.autograd.Function):
                                                     rn.stream_ptr()), 'ra_bn_act_pool_bwd_grouped_f32')
     else:  # a channel count the float4 kernels do not take (the one-channel output layer): one call per timestep
       ws, dgam, dbet = _f(nbn, device=dev), _f(cout, device=dev), _f(cout, device=dev)
-      Ho, Wo = H // pool, W // pool
       for g, (mean, var, gamma, beta, gg, gbt) in enumerate(info['per_group']):
         sl = slice(g * B, (g + 1) * B)
         check(rn.lib().ra_bn_act_pool_bwd_acc_f32(ptr(U[sl]), ptr(dY[sl]), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
