@@ -20,6 +20,13 @@
 
 #include "ra_common.h"
 
+// This file is compiled three times (Makefile): RA_K1_PART 0 = the decode loop's float32 kernels + every host entry
+// point, 1 = the bf16-operand variants, 2 = float32 with batch moments in the epilogue (the training forward).  The
+// three sets of template instantiations build in parallel; part 0's entry forwards to the other parts' dispatchers.
+#ifndef RA_K1_PART
+#define RA_K1_PART 0
+#endif
+
 namespace ra {
 namespace conv {
 
@@ -555,20 +562,25 @@ int launch_s(const Args &a, int B, hipStream_t st) {
   return launch_status("ra_conv3x3_f32");
 }
 
+namespace {  // the dispatch chain differs between the parts of this file (RA_K1_PART): internal linkage, one per part
 template <int CK, int NC, int WN, int GX, int GY>
 int launch(const Args &a, int B, hipStream_t st) {
   // channel-vector stores pay off when there is no pooling and the channel count allows float4
-  if (a.pool == 1 && (a.Cout & 3) == 0) {
-    if (a.mom_part) {
-      if (a.bf16) return launch_s<CK, NC, WN, GX, GY, true, true, true>(a, B, st);
-      return launch_s<CK, NC, WN, GX, GY, true, false, true>(a, B, st);
-    }
-    if (a.bf16) return launch_s<CK, NC, WN, GX, GY, true, true>(a, B, st);
-    return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
+  const bool swap = a.pool == 1 && (a.Cout & 3) == 0;
+  if (a.mom_part && !swap)
+    return ra::fail(RA_E_SHAPE, "ra_conv3x3_moments_f32: needs pool 1 and Cout %% 4 == 0 (Cout %d, pool %d)", a.Cout, a.pool);
+#if RA_K1_PART == 1  // bf16 operands
+  if (swap) {
+    if (a.mom_part) return launch_s<CK, NC, WN, GX, GY, true, true, true>(a, B, st);
+    return launch_s<CK, NC, WN, GX, GY, true, true>(a, B, st);
   }
-  if (a.mom_part) return ra::fail(RA_E_SHAPE, "ra_conv3x3_moments_f32: needs pool 1 and Cout %% 4 == 0 (Cout %d, pool %d)", a.Cout, a.pool);
-  if (a.bf16) return launch_s<CK, NC, WN, GX, GY, false, true>(a, B, st);
+  return launch_s<CK, NC, WN, GX, GY, false, true>(a, B, st);
+#elif RA_K1_PART == 2  // float32 + batch moments
+  return launch_s<CK, NC, WN, GX, GY, true, false, true>(a, B, st);
+#else
+  if (swap) return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
   return launch_s<CK, NC, WN, GX, GY, false>(a, B, st);
+#endif
 }
 
 // Tile geometry choice: the biggest tile that still yields >= ~2 workgroups per CU, narrow
@@ -613,10 +625,31 @@ int dispatch_cout(const Args &a, int B, hipStream_t st) {
   }
 }
 
+}  // namespace
 inline int chunk_of(int Cin) { return (Cin % 16 == 0) ? 16 : (Cin % 8 == 0) ? 8 : 4; }
+
+// this part's dispatcher (the chain of template choices above); parts 1 and 2 export theirs to part 0's entry
+#if RA_K1_PART == 1
+#define RA_K1_DISPATCH k1_dispatch_bf16
+#elif RA_K1_PART == 2
+#define RA_K1_DISPATCH k1_dispatch_moments
+#else
+#define RA_K1_DISPATCH k1_dispatch_plain
+int k1_dispatch_bf16(const Args &a, int B, hipStream_t st);
+int k1_dispatch_moments(const Args &a, int B, hipStream_t st);
+#endif
+int RA_K1_DISPATCH(const Args &a, int B, hipStream_t st) {
+  switch (chunk_of(a.C0 + a.C1)) {
+    case 16: return dispatch_cout<16>(a, B, st);
+    case 8: return dispatch_cout<8>(a, B, st);
+    default: return dispatch_cout<4>(a, B, st);
+  }
+}
 
 }  // namespace conv
 }  // namespace ra
+
+#if RA_K1_PART == 0
 
 extern "C" int ra_conv_cout_padded(int Cout) {
   if (Cout <= 0) return 0;
@@ -736,16 +769,12 @@ static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, i
     if (plane && (plane_chan < 0 || plane_chan >= C0))
       return ra::fail(RA_E_INVALID, "ra_conv3x3_f32: plane channel %d of %d", plane_chan, C0);
   }
-  const int Cin = C0 + C1;
-  const int CK = ra::conv::chunk_of(Cin);
   // a chunk may not straddle the src0/src1 boundary at finer than 4 channels (always true) but
   // the chunk index arithmetic needs C0 % 4 == 0 only: chunks are resolved per channel group.
   hipStream_t st = ra::as_stream(stream);
-  switch (CK) {
-    case 16: return ra::conv::dispatch_cout<16>(a, B, st);
-    case 8: return ra::conv::dispatch_cout<8>(a, B, st);
-    default: return ra::conv::dispatch_cout<4>(a, B, st);
-  }
+  if (a.bf16) return ra::conv::k1_dispatch_bf16(a, B, st);
+  if (a.mom_part) return ra::conv::k1_dispatch_moments(a, B, st);
+  return ra::conv::k1_dispatch_plain(a, B, st);
 }
 
 extern "C" int ra_conv3x3_f32(const float *src0, int C0, const float *src1, int C1, int B, int Hs,
@@ -778,3 +807,4 @@ extern "C" int ra_conv3x3_bf16ops_f32(const float *src0, int C0, const float *sr
   return conv3x3_entry(src0, C0, src1, C1, B, Hs, Ws, upsample, wpacked, scale, shift, Cout, relu, pool, plane,
                        plane_chan, y, stream, 1);
 }
+#endif  // RA_K1_PART == 0
