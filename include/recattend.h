@@ -35,6 +35,10 @@ extern "C" {
 #define RA_E_HUNG_FLOW (-14)     /* hungarian.cc:184-188 */
 #define RA_E_HUNG_EQUALIZE (-15) /* hungarian.cc:446-450 */
 
+/* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
+ * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
+ * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
+#define RA_ABI_VERSION 102
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);

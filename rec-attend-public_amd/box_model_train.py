@@ -62,11 +62,10 @@ def main(argv=None):
   if hi <= lo:
     raise SystemExit('batch_size %d < world size %d' % (args.batch_size, world))
   data = dict(np.load(args.input)) if args.input else None
-  rng = np.random.RandomState(args.seed + 7919 * rank)
 
   def make_batch(step):
     if data is None:
-      return fmt.synthetic_batch(rng, hi - lo, H, W, T)
+      return fmt.synthetic_batch(np.random.RandomState(fmt.step_seed(args.seed, rank, step)), hi - lo, H, W, T)
     idx = (step * args.batch_size + np.arange(lo, hi)) % data['x'].shape[0]
     return data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
 

@@ -16,7 +16,7 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace ra
 
-extern "C" int ra_version(void) { return 100; }
+extern "C" int ra_version(void) { return RA_ABI_VERSION; }
 extern "C" const char *ra_last_error_string(void) { return ra::g_err; }
 
 // Test aid: leave NaN in the LDS of every CU, so that a kernel which consumes shared memory it

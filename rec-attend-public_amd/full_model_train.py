@@ -76,7 +76,9 @@ def save_checkpoint(path, model):
     out.update({'optim/' + k: v for k, v in tr.state_dict().items()})
   else:
     out['optim/global_step'] = np.asarray(int(model.get('global_step', 0) or 0), dtype=np.int64)
-  np.savez(path, **out)
+  tmp = path + '.tmp.npz'  # written beside and renamed: a crash mid-write must not cost the only checkpoint
+  np.savez(tmp, **out)
+  os.replace(tmp, path)
 
 
 def load_checkpoint(path, model):
@@ -94,6 +96,11 @@ def load_checkpoint(path, model):
   return model
 
 
+def step_seed(seed, rank, step, stream=0):
+  """One seed per (run seed, rank, global step, stream): the random streams are functions of the step."""
+  return (int(seed) + 7919 * int(rank) + 104729 * int(step) + 15485863 * int(stream)) % (2 ** 31 - 1)
+
+
 def train_loop(args, model, model_opt, folder, rank, world, make_batch):
   """experiment.py:220-274 -> Trainer.run_step (full_model_train.py:107), shared with box_model_train.py."""
   import torch
@@ -102,6 +109,10 @@ def train_loop(args, model, model_opt, folder, rank, world, make_batch):
     src = args.restore if args.restore.endswith('.npz') else os.path.join(args.restore, 'weights.npz')
     load_checkpoint(src, model)
     if rank == 0:
+      os.makedirs(folder, exist_ok=True)  # the periodic checkpoints go to `folder`, which need not be where --restore points
+      if not os.path.exists(os.path.join(folder, 'model_opt.yaml')):
+        with open(os.path.join(folder, 'model_opt.yaml'), 'w') as f:
+          yaml.safe_dump(model_opt, f)
       print('restored %s at global_step %d' % (src, model.trainer.bucket.global_step))
   elif rank == 0:
     os.makedirs(folder, exist_ok=True)
@@ -114,10 +125,17 @@ def train_loop(args, model, model_opt, folder, rank, world, make_batch):
   if args.batch_size % world:
     raise SystemExit('batch_size %d is not a multiple of the world size %d (equal shards: the gradient is averaged '
                      'as sum / world)' % (args.batch_size, world))
-  gen = torch.Generator(device='cuda').manual_seed(args.seed + 7919 * rank)  # knob draws: rank-offset
+  gen = torch.Generator(device='cuda')
   start = int(model.get('global_step', 0) or 0)
   t0 = time.time()
   for step in range(start, args.num_steps):
+    # every random stream of a step — knob draws, crop offset / flips (and make_batch's synthetic data) — is seeded from
+    # (seed, rank, step), rank-offset as SURVEY.md §8e asks: a run restored at step k continues the streams of the
+    # uninterrupted run instead of replaying those of its first steps
+    gen.manual_seed(step_seed(args.seed, rank, step, 1))
+    tr = getattr(model, 'trainer', None)
+    if tr is not None and getattr(tr, 'aug_gen', None) is not None:
+      tr.aug_gen.manual_seed(step_seed(args.seed, rank, step, 2))
     x, y_gt, s_gt = make_batch(step)
     feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'generator': gen}
     loss, _ = model.run(['loss', 'train_step'], feed)
@@ -151,11 +169,10 @@ def main(argv=None):
   if hi <= lo:
     raise SystemExit('batch_size %d < world size %d' % (args.batch_size, world))
   data = dict(np.load(args.input)) if args.input else None
-  rng = np.random.RandomState(args.seed + 7919 * rank)       # rank-offset streams
 
   def make_batch(step):
     if data is None:
-      return synthetic_batch(rng, hi - lo, H, W, T)
+      return synthetic_batch(np.random.RandomState(step_seed(args.seed, rank, step)), hi - lo, H, W, T)
     idx = (step * args.batch_size + np.arange(lo, hi)) % data['x'].shape[0]
     return data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
 

@@ -17,6 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
+RA_ABI_VERSION = 102  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_ATTN_STRIDE = 16
 
@@ -167,6 +168,9 @@ def lib():
         raise RecAttendError('librecattend.so lacks symbol %s' % name)
       fn.restype = res
       fn.argtypes = args
+    if handle.ra_version() != RA_ABI_VERSION:
+      raise RecAttendError('librecattend.so has ABI version %d, this binding was written against %d: rebuild it '
+                           '(__graft_entry__.build())' % (handle.ra_version(), RA_ABI_VERSION))
     _lib = handle
   return _lib
 

@@ -1207,8 +1207,17 @@ class TrainStep(object):
     """[T, *shape] buffer of the step (one slot per timestep), kept across steps."""
     t = self._slabs.get(name)
     if t is None or tuple(t.shape) != (T,) + tuple(shape):
+      if t is not None:
+        self._drop_captured_steps()  # a graph captured for another batch shape holds the old slab's address
       t = self._slabs[name] = torch.empty((T,) + tuple(shape), dtype=torch.float32, device=self.bucket.param.device)
     return t
+
+  def _drop_captured_steps(self):
+    """Step-persistent scratch (the [T, ...] slabs, the fused controller's buffers) is shared by every batch shape and
+    its addresses are baked into a captured step: when a new shape makes it move, the steps captured for other shapes
+    must not be replayed again (they would read and write freed memory) — they are re-captured when their shape returns."""
+    for key in [k for k, st in self._graphs.items() if 'graph' in st]:
+      del self._graphs[key]
 
   def _tape_alloc(self, scope, i, tt, meta_of):
     """ConvBNActPool's output placement while the sequential phase runs: u / y of layer (scope, i) at timestep tt."""
@@ -1289,6 +1298,8 @@ class TrainStep(object):
       return None
     cb = getattr(self, '_ctl', None)
     if cb is None or cb.B != B or cb.T != d['T']:
+      if cb is not None:
+        self._drop_captured_steps()
       cb = self._ctl = _CtrlStepBuffers(self, d['T'], B)
     return cb
 

@@ -23,10 +23,15 @@ def test_every_declared_symbol_is_exported():
     assert hasattr(lib, s), s
 
 
+def _header_abi_version():
+  import re
+  return int(re.search(r'#define RA_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'recattend.h')).read()).group(1))
+
+
 def test_binding_table_matches_header():
   assert sorted(rn.SIGNATURES) == _header_symbols()
   rn.lib()  # resolves them all
-  assert rn.lib().ra_version() >= 100
+  assert rn.lib().ra_version() == rn.RA_ABI_VERSION == _header_abi_version()
 
 
 def test_argument_validation_without_gpu():

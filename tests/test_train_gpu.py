@@ -416,6 +416,34 @@ def test_graphed_step_equals_eager_step(cuda):
     assert np.allclose(res[True][1][k], v, rtol=1e-4, atol=1e-6), k
 
 
+def test_graphed_steps_survive_alternating_batch_shapes(cuda):
+  """the step-persistent scratch (the [T, ...] slabs, the fused controller's buffers) is shared by all batch
+  shapes and its addresses are inside a captured step.  Shapes A, A (captured), B, B (scratch moves), A, A again: the
+  graphed run must equal the eager run step for step — a stale graph of shape A replayed after B's reallocation would
+  read and write freed memory."""
+  import full_model
+  import ra_train
+  opt, P, x, y_gt, s_gt = _case(T=2, B=3, wmul=0.6)
+  sel = [slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 1), slice(0, 3), slice(0, 3), slice(0, 1)]
+  res = {}
+  for graphed in (False, True):
+    m = full_model.get_model(opt).load_weights(P)
+    losses = []
+    for k, sl in enumerate(sel):
+      if getattr(m, 'trainer', None) is not None:
+        m.trainer.use_graph = graphed
+      else:
+        ra_train.TrainStep.use_graph = graphed
+      xk = (x * (1.0 - 0.05 * k)).astype(np.float32)
+      loss, _ = m.run(['loss', 'train_step'], {'x': xk[sl], 'y_gt': y_gt[sl], 's_gt': s_gt[sl], 'phase_train': True, 'aug': False})
+      losses.append(float(loss))
+    res[graphed] = (losses, m.state_dict_numpy())
+  ra_train.TrainStep.use_graph = True
+  assert np.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6), (res[True][0], res[False][0])
+  for k, v in res[False][1].items():
+    assert np.allclose(res[True][1][k], v, rtol=1e-4, atol=1e-6), k
+
+
 def test_fused_pointwise_kernels_vs_torch_autograd(cuda):
   """GaussFilter and LSTMCell (one kernel forward, one backward) against the same formulas under
   torch autograd in float64."""
@@ -782,14 +810,17 @@ def test_controller_fn_unit_vs_library(cuda):
     assert np.abs(g1[k] - g0[k]).max() < 2e-5 * max(1.0, np.abs(g0[k]).max()), (k, np.abs(g1[k] - g0[k]).max(), np.abs(g0[k]).max())
 
 
-def test_cfg4_shapes_training_step_properties(cuda):
-  """BASELINE.json configs[3] at its per-GPU shapes — CVPPP arch, 512x512, T = 16, B = 8, use_knob, the random crop —
-  too large for the float64 oracle, so properties: three optimisation steps (eager, captured, replayed) give finite
-  losses, every parameter moves by at most the learning rate per step, the BN shadows move towards the batch
-  statistics, the fused controller and the banded resample ran, and a captured replay equals the eager step it copies."""
+@pytest.mark.parametrize('dtype', ['float32', 'bf16'])
+def test_cfg4_shapes_training_step_properties(cuda, dtype):
+  """BASELINE.json configs[3] at its per-GPU shapes — CVPPP arch, 512x512, T = 16, B = 8, use_knob, the random crop,
+  in float32 AND in the configuration's stated bf16 (model_opt['compute_dtype']) — too large for the float64 oracle, so
+  properties: three optimisation steps (eager, captured, replayed) give finite losses, every parameter moves by at most
+  the learning rate per step, the BN shadows move towards the batch statistics, the fused controller and the banded
+  resample ran, the trainer is in the mode asked for, and a captured replay equals the eager step it copies."""
   import full_model
   import full_model_train as fmt
-  opt = ora.make_opt('cvppp', 512, 512, 16, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000, **KNOB_OPT)
+  opt = ora.make_opt('cvppp', 512, 512, 16, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000,
+                     compute_dtype=dtype, **KNOB_OPT)
   res = {}
   for graphed in (True, False):
     torch.manual_seed(3)
@@ -811,6 +842,8 @@ def test_cfg4_shapes_training_step_properties(cuda):
     res[graphed] = (losses, w3)
     assert all(np.isfinite(losses)), losses
     assert m.trainer._ctl is not None and m.trainer.bucket.global_step == 3
+    assert m.trainer.bf16 == (dtype == 'bf16')
+    assert all(t.dtype == torch.float32 for t in (m.trainer.bucket.param, m.trainer.bucket.m, m.trainer.bucket.v))  # master state
     moved = 0
     for k, v in w3.items():
       assert np.isfinite(v).all(), k
@@ -821,6 +854,52 @@ def test_cfg4_shapes_training_step_properties(cuda):
     assert moved > 200
     assert np.abs(w3['ctrl_cnn_3_0_ema_var']).max() > 0 and np.abs(w3['attn_dcnn_2_5_ema_mean']).max() > 0
   assert np.allclose(res[True][0], res[False][0], rtol=2e-4, atol=1e-5), (res[True][0], res[False][0])
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bf16'])
+def test_full_resolution_controller_cnn_stack_pin(cuda, dtype):
+  """A pin at cfg4's RESOLUTION that no attention decision feeds, so the bar can be tight: the controller CNN of
+  timestep 0 — eight stacked conv + BatchNorm(batch moments, nnlib.py:98) + ReLU + pool layers on concat(x, canvas = 0),
+  512x512, B = 8, training mode — through the product's training forward against the float64 oracle's conv stack
+  (oracle/ra_oracle_torch.cnn, in bf16 mode with the operand roundings of set_conv_operands): every layer's batch mean
+  and variance within 1e-3 of the channel scale."""
+  import full_model
+  H = W = 512
+  B = 8
+  opt = ora.make_opt('cvppp', H, W, 1, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000,
+                     compute_dtype=dtype)
+  P = ora.random_params(opt, 5)
+  for k in P:
+    if ra_is_w(k):
+      P[k] = (P[k] * 0.6).astype(np.float32)
+  rng = np.random.RandomState(6)
+  x = rng.rand(B, H, W, 3).astype(np.float32)
+  y_gt, s_gt = np.zeros((B, 1, H, W), np.float32), np.ones((B, 1), np.float32)
+  y_gt[:, 0, 100:300, 150:380] = 1
+  stats = {}
+  ort.set_conv_operands('bf16' if dtype == 'bf16' else None)
+  ort._BN.update(train=True, stats=stats)
+  try:
+    with torch.no_grad():
+      Pt = {k: ort.t64(v) for k, v in P.items() if k.startswith('ctrl_cnn_')}
+      inp = torch.cat([ort.t64(x), torch.zeros((B, H, W, 1), dtype=torch.float64)], dim=3)
+      feat = ort.cnn(inp, Pt, 'ctrl_cnn', 8, opt['ctrl_cnn_pool'], 0, True)[-1].numpy()
+  finally:
+    ort._BN.update(train=False, stats=None)
+    ort.set_conv_operands(None)
+  m = full_model.get_model(opt).load_weights(P)
+  ts = ra_train.TrainStep(m)
+  assert ts.bf16 == (dtype == 'bf16')
+  with torch.no_grad():
+    _, _, st = ts.forward_loss(x, y_gt, s_gt)
+  worst = 0.0
+  for i in range(8):
+    key = 'ctrl_cnn_%d_0' % i
+    em, ev = _rel(st[key][0].cpu().numpy(), stats[key][0].numpy()), _rel(st[key][1].cpu().numpy(), stats[key][1].numpy())
+    worst = max(worst, em, ev)
+    assert em < 1e-3 and ev < 1e-3, (dtype, key, em, ev)
+  print('controller-CNN stack at 512x512, B=8, %s: worst batch-moment deviation from the float64 oracle %.2e' % (dtype, worst))
+  assert feat.shape == (B, 16, 16, 64)
 
 
 # ---- mixed precision: model_opt['compute_dtype'] = 'bf16' (conv forward / data gradient / filter gradient with
