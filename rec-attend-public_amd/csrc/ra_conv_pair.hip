@@ -538,6 +538,37 @@ struct NGeo {
 #ifndef RA_PAIR8_OCC
 #define RA_PAIR8_OCC 3  // workgroups per CU: 3 x 38.7 KB LDS, <= 168 VGPRs (4 spills)
 #endif
+// tools/pair8_probe.hip builds this file with -DRA_PROBE8: every workgroup accumulates the shader-clock time its
+// wave 0 spends between a few points of the tile loop and leaves the sums in ra_probe8_buf[workgroup][8]
+// (-DRA_P8_NOBAR: the tile loop's barriers dropped — timing only, results wrong).
+#ifdef RA_PROBE8
+__device__ long long *ra_probe8_buf;
+#define RA_P8_DECL long long p8_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p8_t = (long long)__builtin_readcyclecounter(), p8_t0 = (long long)wall_clock64()
+#define RA_P8_AT(k)                                                 \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const long long n_ = (long long)__builtin_readcyclecounter();   \
+    p8_acc[k] += n_ - p8_t;                                         \
+    p8_t = n_;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+#define RA_P8_END                                                                   \
+  do {                                                                              \
+    if (threadIdx.x == 0 && ra_probe8_buf) {                                        \
+      p8_acc[7] = (long long)wall_clock64() - p8_t0;                                \
+      for (int k_ = 0; k_ < 8; ++k_) ra_probe8_buf[(size_t)blockIdx.x * 8 + k_] = p8_acc[k_]; \
+    }                                                                               \
+  } while (0)
+#else
+#define RA_P8_DECL
+#define RA_P8_AT(k)
+#define RA_P8_END
+#endif
+#ifdef RA_P8_NOBAR
+#define RA_P8_SYNC() __builtin_amdgcn_s_waitcnt(0xc07f)  /* lgkmcnt(0) only */
+#else
+#define RA_P8_SYNC() __syncthreads()
+#endif
 // CACHED form (CINA == 4 only): of layer A's input only the canvas channel changes between
 // timesteps (full_model.py:640-661,843-848), so the contribution of the image channels,
 // S[pixel][co] = sum_{tap, ci != canvas} x * W (no bias, no BN), is computed ONCE per forward by
@@ -728,6 +759,7 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
   int tile = t_first;
   TC cur = split(tile), nxt = cur;
   if (tile < t_end) fetch(cur);
+  RA_P8_DECL;
   // the padded groups read LDS this kernel never writes; whatever an earlier kernel left there
   // must not be NaN/Inf (their results are discarded, but keep the arithmetic clean)
   for (int e = tid; e < (IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
@@ -774,7 +806,8 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
         }
       }
     }
-    __syncthreads();
+    RA_P8_SYNC();
+    RA_P8_AT(0);  // staged + barrier
     nxt = advance(cur);
     if (tile + nwx < t_end) fetch(nxt);  // the next tile's loads fly while this one is computed
     if constexpr (!CACHED) {
@@ -807,6 +840,7 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
           acc[s] = f32x4{i0, i0, i0, i0};
         }
       }
+      RA_P8_AT(1);  // layer A's cached sums have arrived (accumulators initialised)
       if constexpr (CACHED) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -873,7 +907,9 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
         }
       }
     }
-    __syncthreads();
+    RA_P8_AT(2);  // phase A computed and written to the LDS tile
+    RA_P8_SYNC();
+    RA_P8_AT(3);  // barrier
 
     // ---------------- phase B: layer B out of tmid, BN + ReLU + 2x2 max-pool -> global ----------------
     {
@@ -916,7 +952,9 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), ry, (int)off, 0, 0);
       }
     }
+    RA_P8_AT(4);  // phase B, pooled and stored
   }
+  RA_P8_END;
   if constexpr (!CACHED) {
     if (rider)  // what rounding left of this workgroup's share (and all of it for a workgroup without tiles)
       for (; r_idx < r_end; r_idx += 256) __builtin_amdgcn_raw_buffer_store_b128(r_bits, rr, r_idx * 16, 0, 0);

@@ -40,7 +40,7 @@ def test_bench_json_line(cuda):
   ra = d['roofline_attn']
   for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'achieved_traffic', 'at_B32', 'launch_floor_us'):
     assert k in ra, k
-  assert ra['bound'] == 'hbm' and 'in_flight' not in ra and 0.2 < ra['frac'] < 1.0 and 'frac' in ra['at_B32']
+  assert ra['bound'] == 'hbm' and 'in_flight' not in ra and 0.2 < ra['frac'] < 1.0 and 'frac_algorithmic' in ra['at_B32'] and set(ra['by_box_size']) == {'0.15', '0.35', '1.00'}
   tr = d['train']  # the training step timed by the same run (cfg4 shapes, 3 steps)
   assert tr['steps'] == 3 and tr['dtype'] == 'f32' and tr['ms_per_step'] > 0 and tr['fused_controller'] and tr['hip_graph']
   assert abs(tr['value'] - 8 * 16 * 1000.0 / tr['ms_per_step']) < 1e-6 * tr['value'] and tr['ranks_in_communicator'] == 1
