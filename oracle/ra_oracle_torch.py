@@ -425,11 +425,12 @@ def loss_head(opt, fwd, y_gt, s_gt):
   return out
 
 
-def box_forward_loss(opt, Pnp, x, y_gt, s_gt, noise, requires_grad=(), phase_train=True, bn_stats=None):
+def box_forward_loss(opt, Pnp, x, y_gt, s_gt, noise, requires_grad=(), phase_train=True, bn_stats=None, d_in=None, y_in=None):
   """box_model.py:403-652 restated differentiably: the controller-only model, its canvas always
   teacher-forced from the greedily matched ground truth times (1 - noise[tt]) (noise [T,B,H,W], the
   draws of :500-502), box loss (matched soft IoU; 'mse' / 'huber' on (centre, log size)) + conf loss
-  (+ the caller adds weight decay).  CVPPP-style inputs (no d_in / y_in)."""
+  (+ the caller adds weight decay).  d_in / y_in: the KITTI / Cityscapes stage-1 inputs, concatenated behind
+  (x, canvas) as box_model.py:404-410 does."""
   _BN['train'], _BN['stats'] = bool(phase_train), bn_stats
   try:
     d = ora.derive(opt, box_model=True)
@@ -442,8 +443,9 @@ def box_forward_loss(opt, Pnp, x, y_gt, s_gt, noise, requires_grad=(), phase_tra
     canvas = torch.zeros((B, H, W, 1), dtype=DT)
     boxes, ss, cns, lss = [], [], [], []
     dims = torch.tensor([H, W], dtype=DT)
+    more = [t64(d_in), t64(y_in)] if d['add_d_out'] else []  # box_model.py:406-409
     for tt in range(T):
-      feat = cnn(torch.cat([x, canvas], dim=3), P, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, d['use_bn'])[-1]
+      feat = cnn(torch.cat([x, canvas] + more, dim=3), P, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, d['use_bn'])[-1]
       feat = feat.reshape(B, G, -1)
       state = torch.zeros((B, 2 * hid), dtype=DT)
       gmap = torch.full((B, G, 1), 1.0 / G, dtype=DT)

@@ -63,11 +63,17 @@ def main(argv=None):
     raise SystemExit('batch_size %d < world size %d' % (args.batch_size, world))
   data = dict(np.load(args.input)) if args.input else None
 
+  add_d = bool(model_opt.get('add_d_out', False))  # run_kitti.sh:45-59: stage 1 trains with --add_d_out --add_y_out
+  nsc = int(model_opt.get('num_semantic_classes', 1))
+
   def make_batch(step):
     if data is None:
-      return fmt.synthetic_batch(np.random.RandomState(fmt.step_seed(args.seed, rank, step)), hi - lo, H, W, T)
+      rng = np.random.RandomState(fmt.step_seed(args.seed, rank, step))
+      b = fmt.synthetic_batch(rng, hi - lo, H, W, T)
+      return b + (dict(zip(('d_in', 'y_in'), fmt.synthetic_extras(rng, hi - lo, H, W, nsc))),) if add_d else b
     idx = (step * args.batch_size + np.arange(lo, hi)) % data['x'].shape[0]
-    return data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
+    b = (data['x'][idx], data['y_gt'][idx], data['s_gt'][idx])
+    return b + ({'d_in': data['d_in'][idx], 'y_in': data['y_in'][idx]},) if add_d else b
 
   fmt.train_loop(args, model, model_opt, folder, rank, world, make_batch)
 

@@ -218,12 +218,12 @@ class Model(dict):
     if 'noise' in feed and 'knobs' not in feed:  # box_model's canvas noise (box_model.py:500-502), as at eval
       feed = dict(feed, knobs={'noise': feed['noise']})
     if 'train_step' in names:
-      extra = {k: feed[k] for k in ('d_in', 'y_in') if feed.get(k) is not None and not self.box_model}
+      extra = {k: feed[k] for k in ('d_in', 'y_in') if feed.get(k) is not None}
       out = tr.run(feed['x'], feed['y_gt'], feed['s_gt'], knobs=feed.get('knobs'), generator=feed.get('generator'),
                    aug=feed.get('aug'), **extra)
     else:
       with torch.no_grad():
-        extra = {k: feed[k] for k in ('d_in', 'y_in') if feed.get(k) is not None and not self.box_model}
+        extra = {k: feed[k] for k in ('d_in', 'y_in') if feed.get(k) is not None}
         _, out, _ = tr.forward_loss(feed['x'], feed['y_gt'], feed['s_gt'], knobs=feed.get('knobs'),
                                     generator=feed.get('generator'), **extra)
       out = dict(out)

@@ -66,6 +66,16 @@ def synthetic_batch(rng, B, H, W, T):
   return x, y, s
 
 
+def synthetic_extras(rng, B, H, W, num_semantic_classes):
+  """d_in / y_in of the KITTI / Cityscapes architectures as SURVEY.md §8d defines the synthetic inputs (the reference
+  feeds fg_model's outputs, data_api/*): d_in = one-hot over the 8 orientation classes of a seeded integer map, y_in =
+  softmax of seeded logits over the semantic classes."""
+  d_in = np.eye(8, dtype=np.float32)[rng.randint(0, 8, (B, H, W))]
+  z = rng.randn(B, H, W, num_semantic_classes).astype(np.float32)
+  e = np.exp(z - z.max(axis=3, keepdims=True))
+  return d_in, (e / e.sum(axis=3, keepdims=True)).astype(np.float32)
+
+
 def save_checkpoint(path, model):
   """Everything utils/saver.py:24-31 saves (tf.all_variables()): the weights with their BN EMA shadows, and — once a
   trainer exists — the Adam slots and global_step.  One .npz; `path` without the optimizer part stays loadable by
@@ -136,8 +146,11 @@ def train_loop(args, model, model_opt, folder, rank, world, make_batch):
     tr = getattr(model, 'trainer', None)
     if tr is not None and getattr(tr, 'aug_gen', None) is not None:
       tr.aug_gen.manual_seed(step_seed(args.seed, rank, step, 2))
-    x, y_gt, s_gt = make_batch(step)
+    batch = make_batch(step)  # (x, y_gt, s_gt[, {d_in, y_in}])
+    x, y_gt, s_gt = batch[:3]
     feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'generator': gen}
+    if len(batch) > 3:
+      feed.update(batch[3])
     loss, _ = model.run(['loss', 'train_step'], feed)
     if rank == 0 and (step % args.steps_per_log == 0 or step == args.num_steps - 1):
       print('step %d  loss %.5f  learn_rate %.2e  %.2f s' % (step, float(loss), ra_train.learn_rate(model_opt, step),
@@ -170,11 +183,17 @@ def main(argv=None):
     raise SystemExit('batch_size %d < world size %d' % (args.batch_size, world))
   data = dict(np.load(args.input)) if args.input else None
 
+  add_d = bool(model_opt.get('add_d_out', False))  # full_model.py:165-194: d_in and y_in, both or neither
+  nsc = int(model_opt.get('num_semantic_classes', 1))
+
   def make_batch(step):
     if data is None:
-      return synthetic_batch(np.random.RandomState(step_seed(args.seed, rank, step)), hi - lo, H, W, T)
+      rng = np.random.RandomState(step_seed(args.seed, rank, step))
+      b = synthetic_batch(rng, hi - lo, H, W, T)
+      return b + (dict(zip(('d_in', 'y_in'), synthetic_extras(rng, hi - lo, H, W, nsc))),) if add_d else b
     idx = (step * args.batch_size + np.arange(lo, hi)) % data['x'].shape[0]
-    return data['x'][idx], data['y_gt'][idx], data['s_gt'][idx]
+    b = (data['x'][idx], data['y_gt'][idx], data['s_gt'][idx])
+    return b + ({'d_in': data['d_in'][idx], 'y_in': data['y_in'][idx]},) if add_d else b
 
   train_loop(args, model, model_opt, folder, rank, world, make_batch)
 

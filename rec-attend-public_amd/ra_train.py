@@ -1707,19 +1707,21 @@ class BoxTrainStep(TrainStep):
     self.model, self.opt, self.d = model, model.opt, model.dims
     if not torch.cuda.is_available():
       raise rn.RecAttendError('the training step needs an MI355X (HIP device); there is no CPU fallback')
-    if self.d['add_d_out']:
-      raise NotImplementedError('box_model training is built for image + canvas inputs (no d_in / y_in)')
     if self.opt.get('box_loss_fn', 'iou') not in ('iou', 'mse', 'huber'):
       raise NotImplementedError("box_loss_fn in ('iou', 'mse', 'huber')")
     self._setup(model, world)
-    self.cmap_c = self.cmap_a = None
+    # the controller CNN reads concat(x, canvas[, d_in, y_in]) (box_model.py:404-410): packed to C0p channels, the
+    # first filter's rows found through the channel map (stage 1 of run_kitti.sh:45-59 trains with --add_d_out --add_y_out)
+    cmap_c, _ = model.engine._chan_map(self.d['ctrl_in'])
+    self.cmap_c = None if cmap_c == list(range(len(cmap_c))) else cmap_c
+    self.cmap_a = None
 
   def draw_knobs(self, B, generator=None):
     """The step's one random draw: the canvas noise U[0, 0.3) (box_model.py:500-502)."""
     d = self.d
     return {'noise': 0.3 * torch.rand((d['T'], B, d['H'], d['W']), generator=generator, device=self.bucket.param.device)}
 
-  def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None):
+  def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None, d_in=None, y_in=None):
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
     self._wgrad_parts.reset()
@@ -1729,6 +1731,11 @@ class BoxTrainStep(TrainStep):
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))).to(
         device=dev, dtype=torch.float32).contiguous()
     x, y_gt, s_gt = as_t(x), as_t(y_gt), as_t(s_gt)
+    extra = []
+    if d['add_d_out']:  # box_model.py:78-131: either both or neither
+      if d_in is None or y_in is None:
+        raise rn.RecAttendError('this architecture feeds d_in and y_in (box_model.py:78-131)')
+      extra = [as_t(d_in), as_t(y_in)]
     B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
     noise = as_t(knobs['noise']) if knobs is not None and 'noise' in knobs else self.draw_knobs(B, generator)['noise']
     fixed = bool(opt.get('fixed_order', False))
@@ -1739,8 +1746,10 @@ class BoxTrainStep(TrainStep):
     dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
     head_flags = (1 if d['squash'] else 0) | (2 if d['fixed_var'] else 0) | (4 if d['dynamic_var'] else 0) | 8
     for tt in range(T):
-      inp = torch.cat([x, canvas], dim=3)
-      feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, None, stats)[-1]
+      inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
+      if inp.shape[3] != d['C0p']:
+        inp = _pad_channels(inp)
+      feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
       h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
       cn, ls, ctr, size, lg_var, _, bgm, _ = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
       box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)

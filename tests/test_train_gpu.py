@@ -1,6 +1,8 @@
 """The training step (full_model.py:913-1057, phase_train = True, use_knob = False) on the HIP
 kernels against torch autograd through the float64 CPU oracle (oracle/ra_oracle_torch.py): loss
 pieces, the gradient of every parameter, three Adam steps and the BatchNorm EMA shadows."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -312,6 +314,60 @@ def test_box_model_training_vs_oracle(cuda, over):
   feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'noise': noise, 'phase_train': True, 'aug': False}
   l = [float(m2.run(['loss', 'train_step'], feed)[0]) for _ in range(3)]
   assert abs(l[0] - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss']))) and l[2] < l[0] and float(m2['global_step']) == 3.0
+
+
+def test_box_model_training_with_d_in_y_in_vs_oracle(cuda):
+  """Stage 1 of the KITTI recipe (run_kitti.sh:45-59: box_model_train.py --add_d_out --add_y_out): box_model's training
+  graph on concat(x, canvas, d_in, y_in) (box_model.py:404-410; 13 input channels through the first filter's channel map):
+  loss pieces, matching and every gradient against the differentiable oracle with the same canvas noise, then the CLI."""
+  import box_model
+  import box_model_train
+  import ra_train
+  import tempfile
+  H, W, T, B = 64, 96, 2, 2
+  full = ora.make_opt('kitti', H, W, T, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000)
+  opt = {k: full[k] for k in box_model_train.BOX_KEYS if k in full}
+  opt.update(attn_box_padding_ratio=0.2, weight_decay=5e-5, use_bn=True, box_loss_fn='iou')
+  P = ora.random_params(opt, 17, box_model=True)
+  for k in P:
+    if ra_is_w(k):
+      P[k] = (P[k] * 0.5).astype(np.float32)
+  assert P['ctrl_cnn_w_0'].shape[2] == 13
+  rng = np.random.RandomState(18)
+  x = rng.rand(B, H, W, 3).astype(np.float32)
+  d_in = np.eye(8, dtype=np.float32)[rng.randint(0, 8, (B, H, W))]
+  y_in = ora.softmax(rng.randn(B, H, W, 1)).astype(np.float32)
+  y_gt, s_gt = np.zeros((B, T, H, W), np.float32), np.ones((B, T), np.float32)
+  y_gt[:, 0, 6:30, 8:40] = 1
+  y_gt[:, 1, 36:56, 50:90] = 1
+  noise = rng.uniform(0, 0.3, (T, B, H, W)).astype(np.float32)
+  keys = [k for k in P if not (k.endswith('_ema_mean') or k.endswith('_ema_var'))]
+  head, Pt = ort.box_forward_loss(opt, P, x, y_gt, s_gt, noise, requires_grad=keys, d_in=d_in, y_in=y_in)
+  (head['loss'] + ort.weight_decay_term(opt, {k: Pt[k] for k in keys})).backward()
+  gref = {k: Pt[k].grad.numpy() if Pt[k].grad is not None else np.zeros(P[k].shape) for k in keys}
+  assert np.abs(gref['ctrl_cnn_w_0'][:, :, 4:, :]).max() > 0  # the extra channels do reach the loss
+  m = box_model.get_model(opt).load_weights(P)
+  ts = ra_train.BoxTrainStep(m)
+  ts.bucket.zero_grad()
+  loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs={'noise': noise}, d_in=d_in, y_in=y_in)
+  loss.backward()
+  for k in ('loss', 'box_loss', 'conf_loss', 'iou_soft_box'):
+    assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
+  assert (pieces['match_box'].cpu().numpy() == head['match_box'].numpy()).all()
+  _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
+  with pytest.raises(Exception):
+    ts.forward_loss(x, y_gt, s_gt, knobs={'noise': noise})  # d_in / y_in are part of this architecture's input
+  m2 = box_model.get_model(opt).load_weights(P)
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'd_in': d_in, 'y_in': y_in, 'noise': noise, 'phase_train': True, 'aug': False}
+  l = [float(m2.run(['loss', 'train_step'], feed)[0]) for _ in range(3)]
+  assert abs(l[0] - float(head['loss'])) < 3e-4 * max(1.0, abs(float(head['loss']))) and l[2] < l[0]
+  with tempfile.TemporaryDirectory() as res:  # the CLI with the run script's flags, synthetic d_in / y_in
+    box_model_train.main(['--results', res, '--model_id', 'bk', '--num_steps', '2', '--batch_size', '2', '--inp_height', '64',
+                          '--inp_width', '96', '--timespan', '2', '--add_d_out', '--add_y_out',
+                          '--ctrl_cnn_filter_size', '3,3,3,3,3,3,3,3', '--ctrl_cnn_depth', '16,16,32,32,64,64,64,64',
+                          '--ctrl_cnn_pool', '2,2,1,2,1,2,1,2'])
+    w = dict(np.load(os.path.join(res, 'bk', 'weights.npz')))
+    assert w['ctrl_cnn_w_0'].shape == (3, 3, 13, 16) and int(w['optim/global_step']) == 2
 
 
 def test_two_stage_cli_box_then_full(cuda, tmp_path, capsys):
