@@ -669,6 +669,10 @@ int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y,
  * the sigmoid(beta) prefill of y_out behind RA_PASTE_Y_PREFILLED, as a library launch so that the
  * captured forward holds no framework kernel. */
 int ra_fill_f32(float *p, size_t n, float value, void *stream);
+/* out[i] = idx[i] >= 0 ? src[idx[i]] : 0 for i < n (device pointers).  The training step re-packs the controller's
+ * weights for the decode loop's kernels once per optimisation step without leaving the device: the host packers
+ * (ra_ctrl_split_pack_weights ...) only move values, so packing arrays of flat-bucket positions once gives the index map. */
+int ra_gather_f32(const float *src, const int *idx, size_t n, float *out, void *stream);
 /* modellib.f_greedy_match with matched == 0 (modellib.py:365-379; box_model.py:487-498):
  * match[b,t] = (score[b,t] == max_t score[b,:]) / #maxima.  score, match [B,T]. */
 int ra_greedy_match_f32(const float *score, int B, int T, float *match, void *stream);

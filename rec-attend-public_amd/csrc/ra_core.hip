@@ -68,8 +68,24 @@ __global__ __launch_bounds__(64) void greedy_match_kernel(const float *score, in
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
   for (int t = lane; t < T; t += 64) match[(size_t)b * T + t] = (score[(size_t)b * T + t] == mx ? 1.f : 0.f) / cnt;
 }
+// out[i] = idx[i] >= 0 ? src[idx[i]] : 0
+__global__ __launch_bounds__(256) void gather_kernel(const float *src, const int *idx, size_t n, float *out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int j = idx[i];
+    out[i] = j >= 0 ? src[j] : 0.f;
+  }
+}
 }  // namespace
 }  // namespace ra
+
+extern "C" int ra_gather_f32(const float *src, const int *idx, size_t n, float *out, void *stream) {
+  if (!src || !idx || !out) return ra::fail(RA_E_INVALID, "ra_gather_f32: null pointer");
+  if (n == 0) return 0;
+  size_t grid = (n + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(ra::gather_kernel, dim3((unsigned)grid), dim3(256), 0, ra::as_stream(stream), src, idx, n, out);
+  return ra::launch_status("ra_gather_f32");
+}
 
 extern "C" int ra_fill_f32(float *p, size_t n, float value, void *stream) {
   if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return ra::fail(RA_E_INVALID, "ra_fill_f32: null / unaligned pointer");

@@ -229,8 +229,8 @@ def _f(*shape, device):
 _SIDE = {}
 
 
-def _side_stream(device):
-  k = str(device)
+def _side_stream(device, which=0):
+  k = (str(device), which)
   if k not in _SIDE:
     _SIDE[k] = torch.cuda.Stream(device=device)
   return _SIDE[k]
@@ -1131,6 +1131,7 @@ class TrainStep(object):
   defer_wgrad = True  # one finishing reduction of the filter gradient per layer and step (not one per timestep)
 
   match_side_stream = os.environ.get('RA_MATCH_SIDE', '1') != '0'  # the box matching under the mask matching (one fork / join)
+  match_merged = os.environ.get('RA_MATCH_MERGED', '1') != '0'  # otherwise: both matchings as one launch of 2 B problems
 
   def _cnn(self, x, scope, n, pools, tt, cmap0, stats):
     P, hs = self.leaves, []
@@ -1286,6 +1287,42 @@ class TrainStep(object):
     return to_bt(y), to_bt(s).reshape(B, T), to_bt(box)
 
   fuse_controller = True  # the controller of a timestep as one forward and one backward launch
+  seq_ctrl_split = os.environ.get('RA_TRAIN_CTRL_SPLIT', '1') != '0'  # stacked step, sequential phase: the decode loop's 16-workgroup controller
+
+  def _seq_controller(self, B):
+    """The sequential phase of the stacked step keeps nothing of the controller but its outputs (the stacked graph re-runs
+    it over all timesteps with the state the backward needs), so it can run the DECODE loop's 16-workgroup controller
+    (csrc/ra_ctrl_split.hip: 63 us per launch against 136 for ra_ctrl_train_fwd_f32's one workgroup per image).  Its
+    weights are packed on the device once per optimisation step: the host packer only moves values, so packing arrays
+    of flat-bucket POSITIONS once gives an index map, and a step's packing is one gather launch.  None where the split
+    form does not apply (descriptor, more than 14 images)."""
+    if not self.seq_ctrl_split:
+      return None
+    sc = getattr(self, '_seqc', None)
+    if sc is None or sc.get('B') != B:
+      d, dev = self.d, self.bucket.param.device
+      Cf = self.model.dims['ccnn_channels'][-1]
+      desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'], d['mlp_dim'], d['H'], d['W'], d['Fh'],
+                                d['Fw'], d['squash'], d['fixed_var'], d['dynamic_var'], d.get('fixed_gamma', True))
+      sc = self._seqc = {'B': B, 'ok': False}
+      if ops.ctrl_split_supported(desc) and B * 16 <= ops.cu_count() - 32:
+        off = self.bucket.offsets
+        pos = lambda k: (off[k][0] + 1 + np.arange(off[k][1], dtype=np.float64)).astype(np.float32).reshape(off[k][2])
+        assert self.bucket.param.numel() < (1 << 24)  # positions are exact in float32
+        lstm = {k: pos('ctrl_lstm_' + k) for k in ('w_xi', 'w_hi', 'b_i', 'w_xf', 'w_hf', 'b_f', 'w_xu', 'w_hu', 'b_u', 'w_xo', 'w_ho', 'b_o')}
+        gm = [(pos('glimpse_mlp_w_%d' % i), pos('glimpse_mlp_b_%d' % i)) for i in range(d['n_gmlp'])]
+        cm = [(pos('ctrl_mlp_w_%d' % i), pos('ctrl_mlp_b_%d' % i)) for i in range(d['n_cmlp'])]
+        imap = ops.pack_ctrl_split_weights(desc, lstm, gm, cm).astype(np.int64) - 1
+        ws, status = ops.ctrl_split_workspace(desc, B, dev)
+        f = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+        sc.update(ok=True, desc=desc, imap=torch.as_tensor(imap.astype(np.int32)).to(dev), wp=f(imap.size), ws=ws, status=status,
+                  h=f(d['T'], B, d['hid']), co=f(d['T'], B, 9), gm=f(B, d['iters'], d['G']), attn=f(B, rn.RA_ATTN_STRIDE), packed_at=None)
+    if not sc['ok']:
+      return None
+    if sc['packed_at'] != self._pack_epoch:  # once per optimisation step (forward_loss bumps the epoch)
+      check(rn.lib().ra_gather_f32(ptr(self.bucket.param), ptr(sc['imap']), sc['imap'].numel(), ptr(sc['wp']), rn.stream_ptr()), 'ra_gather_f32')
+      sc['packed_at'] = self._pack_epoch
+    return sc
 
   def _ctrl_buffers(self, B, Cf):
     """The fused controller's step buffers, or None where the library path has to run: depths other than the run
@@ -1412,6 +1449,7 @@ class TrainStep(object):
     Cityscapes architectures (full_model.py:165-194)."""
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
     self._wgrad_parts.reset()
     if getattr(self, '_ctl', None) is not None:
       self._ctl.begin_step()
@@ -1450,7 +1488,12 @@ class TrainStep(object):
     with (torch.no_grad() if batched else contextlib.nullcontext()):
       for tt in range(T):
         feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
-        h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
+        sc = self._seq_controller(B) if batched else None
+        if sc is not None:  # outputs only: the decode loop's controller (its own h / ctrl_out rows per timestep)
+          h, co = sc['h'][tt], sc['co'][tt]
+          ops.controller_split(sc['desc'], feat.reshape(B, d['G'], -1), sc['wp'], h, co, sc['gm'], sc['attn'], sc['ws'], sc['status'])
+        else:
+          h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
         # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
         cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
         # attention box: sigmoid(box_gamma * extract_patch(ones, F_y^T, F_x^T) - 5) (full_model.py:738-741)
@@ -1526,10 +1569,14 @@ class TrainStep(object):
     # corner IoUs (iou_box_steps, differentiable through the corners) are the matrix.
     ident = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
 
-    def matched_iou(a, b, iou=None):
+    def matched_iou(a, b, iou=None, pre=None):
       iou = PairIoU.apply(a, b) if iou is None else iou
       if fixed:
         m = ident
+      elif pre is not None:  # matched already (both matchings in one launch, below)
+        m, st = pre
+        if st is not None:
+          statuses.append(st)
       else:
         m, st = ops.segm_match(iou.detach(), s_gt)
         statuses.append(st)  # checked by the caller once the step has run (no host sync in here)
@@ -1543,7 +1590,17 @@ class TrainStep(object):
     iou_box_rows = torch.cat(iou_box_steps, dim=1).contiguous() if len(iou_box_steps) == T else None
     # the two matchings are independent and each is one wave per image for milliseconds (dense soft-IoU
     # matrices early in training): the box matching runs on a side stream under the mask matching
-    if self.match_side_stream:
+    if self.match_merged and not fixed and iou_box_rows is None:
+      # The two Hungarian matchings are one wave per problem for milliseconds on the dense soft-IoU matrices of early
+      # training: ONE launch over the 2 B problems (mask and box matrices side by side) instead of one matching under the
+      # other on a side stream — no fork in the captured graph (31.5 -> 30.4 ms per step; starting the matchings early
+      # from the sequential phase's masks on a side stream, under the stacked forward, loses to the fork it needs: 31.1,
+      # and a second fork makes the graph replay 1.5x slower: 47.9 ms)
+      i_soft, i_box = PairIoU.apply(y_out, y_gt), PairIoU.apply(attn_box, box_gt)
+      m2, st2 = ops.segm_match(torch.cat([i_soft.detach(), i_box.detach()], dim=0), torch.cat([s_gt, s_gt], dim=0))
+      iou_box, m_box = matched_iou(attn_box, box_gt, i_box, (m2[B:], None))
+      iou_soft, m = matched_iou(y_out, y_gt, i_soft, (m2[:B], st2))
+    elif self.match_side_stream:
       cur = torch.cuda.current_stream()
       side = _side_stream(dev)
       side.wait_stream(cur)
@@ -1688,6 +1745,12 @@ class TrainStep(object):
     lr = self.bucket.step(world=world)
     for st in out.pop('_match_status', []):  # one host sync per step, after everything has been queued
       ops.check_match_status(st, 'f_segm_match')
+    sc = getattr(self, '_seqc', None)
+    if sc is not None and sc.get('ok') and int(sc['status'].item()) != 0:  # a controller workgroup timed out on its peers
+      sc['status'].zero_()
+      raise rn.RecAttendError('controller_split (sequential phase of the training step): a workgroup waited for a peer that '
+                              'never became resident — is another process using this GPU?  RA_TRAIN_CTRL_SPLIT=0 runs the '
+                              'one-workgroup controller')
     wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
     if self.use_graph:  # the graph's output tensors are rewritten by the next replay: hand out copies of the small ones
       out = {k: (v.clone() if isinstance(v, torch.Tensor) and v.numel() <= 4096 else v) for k, v in out.items()}
@@ -1724,6 +1787,7 @@ class BoxTrainStep(TrainStep):
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None, d_in=None, y_in=None):
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
     self._wgrad_parts.reset()
     if getattr(self, '_ctl', None) is not None:
       self._ctl.begin_step()

@@ -1149,14 +1149,17 @@ def test_stacked_backward_equals_per_timestep_graph(cuda):
   """TrainStep.batched_backward (the T timesteps' backward passes as one stacked pass per layer: ConvStackFn over the
   [T, ...] slabs, ra_bn_act_pool_bwd_grouped_f32) against the per-timestep autograd graph on the same weights and
   knob draws: same loss pieces and matching, every parameter gradient within 2e-4 of the tensor's scale (the sums run
-  in a different order), BatchNorm statistics identical; and the stacked path is the one that ran."""
+  in a different order), BatchNorm statistics identical; and the stacked path is the one that ran.  (Both forms with
+  ra_ctrl_train_fwd_f32 as the sequential phase's controller: the decode loop's 16-workgroup controller the stacked step
+  runs there by default sums in another order, and this random three-timestep network turns a 1e-7 difference in the
+  first window into 2e-3 in a late BatchNorm gradient — two float32 trajectories, not one graph computed two ways.)"""
   import full_model
   opt, P, x, y_gt, s_gt = _case(wmul=0.6, **KNOB_OPT)
   res = {}
   for mode in (True, False):
     m = full_model.get_model(opt).load_weights(P)
     ts = ra_train.TrainStep(m)
-    ts.batched_backward = mode
+    ts.batched_backward, ts.seq_ctrl_split = mode, False
     gen = torch.Generator(device='cuda').manual_seed(5)
     knobs = ts.draw_knobs(x.shape[0], gen)
     calls = {'n': 0}
@@ -1197,15 +1200,15 @@ def test_stacked_step_with_disable_overwrite_vs_oracle(cuda):
   opt, P, x, y_gt, s_gt = _case(wmul=0.6, disable_overwrite=True)
   head, gref, stats = _oracle_grads(opt, P, x, y_gt, s_gt)
   grads = {}
-  for mode in (True, False):
+  for mode in (True, False, 'split'):  # 'split': the stacked step as shipped, the decode loop's controller in its sequential phase
     m = full_model.get_model(opt).load_weights(P)
     ts = ra_train.TrainStep(m)
-    ts.batched_backward = mode
-    assert ts._batched_ok([]) == mode
+    ts.batched_backward, ts.seq_ctrl_split = bool(mode), mode == 'split'
+    assert ts._batched_ok([]) == bool(mode)
     ts.bucket.zero_grad()
     loss, pieces, st = ts.forward_loss(x, y_gt, s_gt)
     loss.backward()
-    assert ('ctrl_cnn_0_u' in ts._slabs) == mode
+    assert ('ctrl_cnn_0_u' in ts._slabs) == bool(mode) and (getattr(ts, '_seqc', None) is not None) == (mode == 'split')
     for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
       assert abs(float(pieces[k].detach()) - float(head[k])) < 2e-4 * max(1.0, abs(float(head[k]))), k
     assert (pieces['match'].cpu().numpy() == head['match'].numpy()).all()
