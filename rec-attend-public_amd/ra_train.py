@@ -557,6 +557,36 @@ def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf):
   return dxr
 
 
+def stack_bn_reduce(info, U, dY):
+  """Synchronised BatchNorm under the stacked backward, first half: the per-channel sums (sum dv, sum dv * xhat) of every
+  timestep group of this rank's shard -> [G, 2 cout]; this rank's own sums also go to the gradient bucket (gamma / beta:
+  the bucket all-reduce sums them over the ranks later)."""
+  G, B, dev = info['G'], info['B'], U.device
+  _, H, W, cout = U.shape
+  ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
+  sums = _f(G, 2 * cout, device=dev)
+  for g, (mean, var, gamma, beta, gg, gbt) in enumerate(info['per_group']):
+    sl = slice(g * B, (g + 1) * B)
+    check(rn.lib().ra_bn_act_pool_bwd_reduce_f32(ptr(U[sl]), ptr(dY[sl]), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                                 _C.c_float(BN_EPS), int(info['relu']), int(info['pool']), B, H, W, cout, ptr(ws),
+                                                 ws.numel(), ptr(sums[g, :cout]), ptr(sums[g, cout:]), ptr(gg), ptr(gbt),
+                                                 rn.stream_ptr()), 'ra_bn_act_pool_bwd_reduce_f32')
+  return sums
+
+
+def stack_bn_dx(info, U, dY, sums, n_total):
+  """... second half: du of every group from the sums of the WHOLE data-parallel batch (n_total elements per channel)."""
+  G, B = info['G'], info['B']
+  _, H, W, cout = U.shape
+  du = torch.empty_like(U)
+  for g, (mean, var, gamma, beta, _, _) in enumerate(info['per_group']):
+    sl = slice(g * B, (g + 1) * B)
+    check(rn.lib().ra_bn_act_pool_bwd_dx_f32(ptr(U[sl]), ptr(dY[sl]), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(sums[g, :cout]),
+                                             ptr(sums[g, cout:]), _C.c_double(n_total), _C.c_float(BN_EPS), int(info['relu']),
+                                             int(info['pool']), B, H, W, cout, ptr(du[sl]), rn.stream_ptr()), 'ra_bn_act_pool_bwd_dx_f32')
+  return du
+
+
 class ConvStackFn(torch.autograd.Function):
   """The T calls of one conv + BatchNorm + ReLU + pool layer of a training step (its T timesteps: shared filter,
   per-timestep statistics and BatchNorm parameters, nnlib.py:121-127) as ONE node of the autograd graph.
@@ -587,14 +617,21 @@ class ConvStackFn(torch.autograd.Function):
     cin_w = w.shape[3] if tr else w.shape[2]
     gw, gb = info['gw'], info['gb']
     dY = dY.contiguous()
-    du = torch.empty_like(U)
     nbn = rn.lib().ra_bn_workspace_floats(cout)
-    if cout % 4 == 0:
+    if info.get('sync_world', 1) > 1:
+      # whole-batch BatchNorm (--sync_bn) under the stacked backward: the T groups' 2 C sums of a layer cross the ranks in
+      # ONE all_reduce (21 collectives per step; the per-timestep graph issued T times as many)
+      sums = stack_bn_reduce(info, U, dY)
+      allreduce_sums(sums)
+      du = stack_bn_dx(info, U, dY, sums, float(info['sync_world']) * B * H * W)
+    elif cout % 4 == 0:
+      du = torch.empty_like(U)
       dgam, dbet, ws = _f(G, cout, device=dev), _f(G, cout, device=dev), _f(G * nbn, device=dev)
       check(rn.lib().ra_bn_act_pool_bwd_grouped_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu), int(pool),
                                                     B, H, W, cout, ptr(ws), ws.numel(), ptr(dgam), ptr(dbet), ptr(du),
                                                     rn.stream_ptr()), 'ra_bn_act_pool_bwd_grouped_f32')
     else:  # a channel count the float4 kernels do not take (the one-channel output layer): one call per timestep
+      du = torch.empty_like(U)
       ws, dgam, dbet = _f(nbn, device=dev), _f(cout, device=dev), _f(cout, device=dev)
       for g, (mean, var, gamma, beta, gg, gbt) in enumerate(info['per_group']):
         sl = slice(g * B, (g + 1) * B)
@@ -1198,7 +1235,7 @@ class TrainStep(object):
     d, opt = self.d, self.opt
     c4 = lambda cs: all(c % 4 == 0 for c in cs)
     return bool(self.batched_backward and torch.is_grad_enabled() and d['use_bn'] and self.fuse_param_grads and
-                self.fuse_controller and not self.sync_bn and not d['add_d_out'] and not extra and
+                self.fuse_controller and not d['add_d_out'] and not extra and
                 not (d['skip_ch'] is not None and any(d['skip_ch'])) and
                 not opt.get('use_iou_box', False) and opt.get('box_loss_fn', 'iou') == 'iou' and
                 c4(self.model.dims['ccnn_channels'][1:]) and c4(opt['attn_cnn_depth']) and c4(opt['attn_dcnn_depth'][:-1]) and
@@ -1251,7 +1288,8 @@ class TrainStep(object):
       tab, per_group = self._bn_tables(scope, i)
       gw, gb = self.bucket.grad_of['%s_w_%d' % (scope, i)], self.bucket.grad_of['%s_b_%d' % (scope, i)]
       info = dict(G=T, B=U.shape[1], U=U.view((-1,) + U.shape[2:]), Y=Y.view((-1,) + Y.shape[2:]), transposed=tr, stride=stride,
-                  pool=pool, relu=True, chan_map=cmap, bf16=self.bf16, tabs=tab, per_group=per_group, gw=gw, gb=gb, cache=self._pack)
+                  pool=pool, relu=True, chan_map=cmap, bf16=self.bf16, tabs=tab, per_group=per_group, gw=gw, gb=gb, cache=self._pack,
+                  sync_world=self.world if self.sync_bn else 1)
       X = ConvStackFn.apply(X, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)], info)
     return X
 

@@ -718,6 +718,67 @@ def test_sync_bn_split_backward_equals_fused(cuda):
   assert np.abs(torch.cat(outs).cpu().numpy() - du.cpu().numpy()).max() < 1e-5
 
 
+def test_sync_bn_stacked_backward_two_shards_equal_whole_batch(cuda):
+  """--sync_bn on the STACKED backward (ConvStackFn with sync_world > 1: per layer the T groups' 2 C sums cross the ranks
+  in ONE all-reduce, 21 collectives per step instead of 21 T): the product's node run for two half-batch "ranks" — their
+  all-reduce replaced by the sum of the two ranks' recorded sums — against the same node on the whole batch: the data
+  gradient of the two shards side by side, and filter / bias / gamma / beta gradients added over the shards."""
+  rng = np.random.RandomState(21)
+  G, Bw, Hs, Ws, cin, cout, pool = 2, 4, 8, 12, 8, 8, 2
+  f = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=cuda)
+  X = rng.randn(G, Bw, Hs, Ws, cin).astype(np.float32)
+  U = rng.randn(G, Bw, Hs, Ws, cout).astype(np.float32)
+  dY = rng.randn(G, Bw, Hs // pool, Ws // pool, cout).astype(np.float32)
+  w = f(rng.randn(3, 3, cin, cout) * 0.2)
+  b = f(np.zeros(cout))
+  gam = [f(rng.uniform(0.5, 1.5, cout)) for _ in range(G)]
+  bet = [f(rng.randn(cout) * 0.1) for _ in range(G)]
+  means = [f(U[g].reshape(-1, cout).mean(0)) for g in range(G)]   # whole-batch moments of each timestep group
+  vars_ = [f(U[g].reshape(-1, cout).var(0)) for g in range(G)]
+
+  def run(sel, sync_world, hook):
+    Bs = len(sel)
+    Xs, Us, dYs = [f(a[:, sel].reshape((G * Bs,) + a.shape[2:])) for a in (X, U, dY)]
+    Xs.requires_grad_(True)
+    gw, gb = torch.zeros_like(w), torch.zeros(cout, device=cuda)
+    gg, gbt = [torch.zeros(cout, device=cuda) for _ in range(G)], [torch.zeros(cout, device=cuda) for _ in range(G)]
+    cols = [means, vars_, gam, bet, gg, gbt]
+    tab = torch.tensor([t.data_ptr() for col in cols for t in col], dtype=torch.int64).to(cuda)
+    info = dict(G=G, B=Bs, U=Us, Y=torch.zeros_like(dYs), transposed=False, stride=1, pool=pool, relu=True, chan_map=None, bf16=False,
+                tabs=tab, per_group=list(zip(*cols)), gw=gw, gb=gb, cache={}, sync_world=sync_world)
+    orig = ra_train.allreduce_sums
+    ra_train.allreduce_sums = hook
+    try:
+      y = ra_train.ConvStackFn.apply(Xs, w, b, info)
+      y.backward(dYs)
+    finally:
+      ra_train.allreduce_sums = orig
+    torch.cuda.synchronize()
+    return Xs.grad.view((G, Bs) + Xs.shape[1:]).cpu().numpy(), [t.cpu().numpy() for t in [gw, gb] + gg + gbt]
+
+  def no_collective(t):
+    raise AssertionError('the whole-batch node must not ask for a collective')
+  dx_ref, p_ref = run([0, 1, 2, 3], 1, no_collective)
+  shards, seen = ([0, 1], [2, 3]), []
+
+  def record(t):
+    seen.append(t.clone())
+    return t
+  for sel in shards:  # what each rank would send
+    run(sel, 2, record)
+  total = seen[0] + seen[1]
+  assert total.shape == (G, 2 * cout)   # ONE collective per layer: all T groups' sums together
+
+  def summed(t):
+    t.copy_(total)
+    return t
+  outs = [run(sel, 2, summed) for sel in shards]
+  dx = np.concatenate([o[0] for o in outs], axis=1)
+  assert np.abs(dx - dx_ref).max() < 2e-5 * max(1.0, np.abs(dx_ref).max()), np.abs(dx - dx_ref).max()
+  for a0, a1, r in zip(outs[0][1], outs[1][1], p_ref):
+    assert np.abs(a0 + a1 - r).max() < 1e-4 * max(1.0, np.abs(r).max()), np.abs(a0 + a1 - r).max()
+
+
 def test_two_trainers_do_not_share_step_caches(cuda):
   """The per-step caches (packed filters, padded biases, packed LSTM weights) belong to the TrainStep: two
   trainers whose steps interleave give the losses they give alone."""
