@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
 RA_ABI_VERSION = 102  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
+RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
 
 

@@ -618,20 +618,24 @@ class ConvStackFn(torch.autograd.Function):
     gw, gb = info['gw'], info['gb']
     dY = dY.contiguous()
     nbn = rn.lib().ra_bn_workspace_floats(cout)
+    rc = 0
     if info.get('sync_world', 1) > 1:
       # whole-batch BatchNorm (--sync_bn) under the stacked backward: the T groups' 2 C sums of a layer cross the ranks in
       # ONE all_reduce (21 collectives per step; the per-timestep graph issued T times as many)
       sums = stack_bn_reduce(info, U, dY)
       allreduce_sums(sums)
       du = stack_bn_dx(info, U, dY, sums, float(info['sync_world']) * B * H * W)
-    elif cout % 4 == 0:
-      du = torch.empty_like(U)
-      dgam, dbet, ws = _f(G, cout, device=dev), _f(G, cout, device=dev), _f(G * nbn, device=dev)
-      check(rn.lib().ra_bn_act_pool_bwd_grouped_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu), int(pool),
-                                                    B, H, W, cout, ptr(ws), ws.numel(), ptr(dgam), ptr(dbet), ptr(du),
-                                                    rn.stream_ptr()), 'ra_bn_act_pool_bwd_grouped_f32')
-    else:  # a channel count the float4 kernels do not take (the one-channel output layer): one call per timestep
-      du = torch.empty_like(U)
+    else:
+      du, rc = torch.empty_like(U), rn.RA_E_SHAPE
+      if cout % 4 == 0:
+        dgam, dbet, ws = _f(G, cout, device=dev), _f(G, cout, device=dev), _f(G * nbn, device=dev)
+        rc = rn.lib().ra_bn_act_pool_bwd_grouped_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu), int(pool),
+                                                     B, H, W, cout, ptr(ws), ws.numel(), ptr(dgam), ptr(dbet), ptr(du), rn.stream_ptr())
+        if rc != rn.RA_E_SHAPE:
+          check(rc, 'ra_bn_act_pool_bwd_grouped_f32')
+    if info.get('sync_world', 1) <= 1 and rc == rn.RA_E_SHAPE:
+      # a channel count the grouped float4 kernel does not take (the one-channel output layer; C / 4 not a power of two,
+      # e.g. the KITTI architecture's 96-channel layer): one call per timestep
       ws, dgam, dbet = _f(nbn, device=dev), _f(cout, device=dev), _f(cout, device=dev)
       for g, (mean, var, gamma, beta, gg, gbt) in enumerate(info['per_group']):
         sl = slice(g * B, (g + 1) * B)
@@ -1232,12 +1236,13 @@ class TrainStep(object):
   _tape = None
 
   def _batched_ok(self, extra):
+    """The stacked step covers every architecture of the run scripts — skip connections, d_in / y_in, use_iou_box, the
+    'mse' / 'huber' box losses, --sync_bn — as long as the layers' channel counts are multiples of 4 (the slabs are the
+    kernels' packed tensors) and the controller has the run scripts' depths (ra_ctrl_train.hip)."""
     d, opt = self.d, self.opt
     c4 = lambda cs: all(c % 4 == 0 for c in cs)
     return bool(self.batched_backward and torch.is_grad_enabled() and d['use_bn'] and self.fuse_param_grads and
-                self.fuse_controller and not d['add_d_out'] and not extra and
-                not (d['skip_ch'] is not None and any(d['skip_ch'])) and
-                not opt.get('use_iou_box', False) and opt.get('box_loss_fn', 'iou') == 'iou' and
+                self.fuse_controller and
                 c4(self.model.dims['ccnn_channels'][1:]) and c4(opt['attn_cnn_depth']) and c4(opt['attn_dcnn_depth'][:-1]) and
                 self.model.dims['C0p'] % 4 == 0 and d['n_gmlp'] == 2 and d['n_cmlp'] == 1)
 
@@ -1279,11 +1284,15 @@ class TrainStep(object):
       hit = self._bn_tabs[(scope, i)] = (tab, list(zip(*cols)))
     return hit
 
-  def _stack_layers(self, X, scope, n):
-    """Phase 2: the n layers of a net as ConvStackFn nodes over the slabs the sequential phase filled."""
+  def _stack_layers(self, X, scope, n, skips=None):
+    """Phase 2: the n layers of a net as ConvStackFn nodes over the slabs the sequential phase filled; returns every
+    layer's output.  skips[i] (dcnn, nnlib.py:365): the tensor concatenated behind layer i's input, as _dcnn packs it."""
     T, P = self.d['T'], self.leaves
+    hs = []
     for i in range(n):
       tr, stride, pool, cmap = self._tape['layers'][(scope, i)]
+      if skips is not None and skips[i] is not None:
+        X = torch.cat([_pad_channels(X), _pad_channels(skips[i])], dim=3)  # the channel map of the sequential phase applies
       U, Y = self._slabs['%s_%d_u' % (scope, i)], self._slabs['%s_%d_y' % (scope, i)]
       tab, per_group = self._bn_tables(scope, i)
       gw, gb = self.bucket.grad_of['%s_w_%d' % (scope, i)], self.bucket.grad_of['%s_b_%d' % (scope, i)]
@@ -1291,9 +1300,10 @@ class TrainStep(object):
                   pool=pool, relu=True, chan_map=cmap, bf16=self.bf16, tabs=tab, per_group=per_group, gw=gw, gb=gb, cache=self._pack,
                   sync_world=self.world if self.sync_bn else 1)
       X = ConvStackFn.apply(X, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)], info)
-    return X
+      hs.append(X)
+    return hs
 
-  def _stacked_graph(self, inp_slab, matches, knob_box, gt_windows, head_flags, cc):
+  def _stacked_graph(self, inp_slab, matches, knob_box, gt_windows, head_flags, cc, gt_corners=None):
     """Phase 2: the differentiable graph of all T timesteps at once, images stacked (t, b).  Returns y_out [B,T,H,W],
     s_out [B,T], attn_box [B,T,H,W] with their autograd history."""
     d, P = self.d, self.leaves
@@ -1301,7 +1311,7 @@ class TrainStep(object):
     B = inp_slab.shape[1]
     N = T * B
     inp_all = inp_slab.view((N,) + inp_slab.shape[2:])
-    feat = self._stack_layers(inp_all, 'ctrl_cnn', d['ccnn_nlayers'])
+    feat = self._stack_layers(inp_all, 'ctrl_cnn', d['ccnn_nlayers'])[-1]
     bufs = self._ctrl_buffers(B, feat.shape[3])
     Wg, bg = self._lstm_weights()
     h, co = ControllerFn.apply(feat.reshape(N, d['G'], -1), Wg.detach(), bg.detach(), P['glimpse_mlp_w_0'].detach(),
@@ -1309,20 +1319,31 @@ class TrainStep(object):
                                P['ctrl_mlp_w_0'].detach(), P['ctrl_mlp_b_0'].detach(), bufs, 'all')
     cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
     box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
+    iou_rows = None
+    if gt_corners is not None:  # use_knob + use_iou_box: the [B,T,T] matrix of corner IoUs the boxes are matched and scored on
+      import modellib          # (modellib.f_iou_box, full_model.py:750-754,931-934), differentiable through the predicted corners
+      gc = gt_corners.unsqueeze(0).expand((T,) + tuple(gt_corners.shape)).reshape((N,) + tuple(gt_corners.shape[1:]))
+      iou_rows = modellib.f_iou_box((ctr - size / 2.0)[:, None], (ctr + size / 2.0)[:, None], gc[:, :, 0:2], gc[:, :, 2:4])
+      iou_rows = iou_rows.view(T, B, T).transpose(0, 1).contiguous()
     if knob_box is not None:  # the matches of phase 1 are constants of the graph (they were never differentiated)
       match_all = torch.stack(matches, dim=0).reshape(N, T)
       rep = lambda t: t.unsqueeze(0).expand((T,) + tuple(t.shape)).reshape((N,) + tuple(t.shape[1:])).contiguous()
       knob_all = knob_box.reshape(B, T).t().reshape(N).contiguous()
       ctr, size = KnobMix.apply(ctr, size, match_all, rep(gt_windows[0]), rep(gt_windows[1]), knob_all)
     x_patch = AttnExtract.apply(inp_all, ctr, size, lg_var, ag, Fh, Fw)
-    core = self._stack_layers(x_patch, 'attn_cnn', d['acnn_nlayers'])
-    y_patch = self._stack_layers(core, 'attn_dcnn', d['adcnn_nlayers'])
+    h_acnn = self._stack_layers(x_patch, 'attn_cnn', d['acnn_nlayers'])
+    core = h_acnn[-1]
+    skips = None
+    if d['skip_ch'] is not None and any(d['skip_ch']):   # full_model.py:798-805: reversed CNN outputs, then x_patch
+      rev = h_acnn[::-1][1:] + [x_patch]
+      skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None for i in range(1, d['adcnn_nlayers'])]
+    y_patch = self._stack_layers(core, 'attn_dcnn', d['adcnn_nlayers'], skips)[-1]
     y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)
     if d['disable_overwrite']:
       y = (1.0 - inp_all[..., cc]) * y
     s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(N, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
     to_bt = lambda t: t.view((T, B) + tuple(t.shape[1:])).transpose(0, 1).contiguous()
-    return to_bt(y), to_bt(s).reshape(B, T), to_bt(box)
+    return to_bt(y), to_bt(s).reshape(B, T), to_bt(box), to_bt(cn), to_bt(ls), iou_rows
 
   fuse_controller = True  # the controller of a timestep as one forward and one backward launch
   seq_ctrl_split = os.environ.get('RA_TRAIN_CTRL_SPLIT', '1') != '0'  # stacked step, sequential phase: the decode loop's 16-workgroup controller
@@ -1594,9 +1615,11 @@ class TrainStep(object):
         box_list.append(box)
         cn_list.append(cn)
         ls_list.append(ls)
+    cn_bt = ls_bt = iou_rows_stacked = None
     if batched:
-      y_out, s_out, attn_box = self._stacked_graph(inp_slab, tape_match, knob_box if use_knob else None,
-                                                   (ctr_gtn, size_gtn) if use_knob else None, head_flags, cc)
+      y_out, s_out, attn_box, cn_bt, ls_bt, iou_rows_stacked = self._stacked_graph(
+          inp_slab, tape_match, knob_box if use_knob else None, (ctr_gtn, size_gtn) if use_knob else None, head_flags, cc,
+          gt_corners if (use_knob and not fixed and opt.get('use_iou_box', False)) else None)
       self._tape = None
     else:
       y_out, s_out = torch.stack(y_list, dim=1), torch.cat(s_list, dim=1)
@@ -1625,7 +1648,7 @@ class TrainStep(object):
 
     statuses = []
     # with the knob and use_iou_box the boxes are matched and scored on the stacked per-timestep corner IoUs
-    iou_box_rows = torch.cat(iou_box_steps, dim=1).contiguous() if len(iou_box_steps) == T else None
+    iou_box_rows = iou_rows_stacked if batched else (torch.cat(iou_box_steps, dim=1).contiguous() if len(iou_box_steps) == T else None)
     # the two matchings are independent and each is one wave per image for milliseconds (dense soft-IoU
     # matrices early in training): the box matching runs on a side stream under the mask matching
     if self.match_merged and not fixed and iou_box_rows is None:
@@ -1656,7 +1679,7 @@ class TrainStep(object):
       gp, _ = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0, want_box=False)
       ctr_gt, size_gt = (gp[:, :, 0:2] + gp[:, :, 2:4]) / 2.0, gp[:, :, 2:4] - gp[:, :, 0:2]
       params_gt = torch.cat([ctr_gt / (dims_hw / 2.0) - 1.0, torch.log(size_gt / dims_hw)], dim=2)
-      params = torch.cat([torch.stack(cn_list, dim=1), torch.stack(ls_list, dim=1)], dim=2)
+      params = torch.cat([cn_bt, ls_bt], dim=2) if batched else torch.cat([torch.stack(cn_list, dim=1), torch.stack(ls_list, dim=1)], dim=2)
       box_loss = modellib.f_match_loss(params, params_gt, m_box, T, modellib.f_squared_err if blf == 'mse' else modellib.f_huber)
     if opt.get('segm_loss_fn', 'iou') == 'wt_cov':  # modellib.f_weighted_coverage (modellib.py:292-302)
       iou_p = PairIoU.apply(y_out, y_gt)

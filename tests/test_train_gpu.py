@@ -1252,6 +1252,59 @@ def test_stacked_backward_equals_per_timestep_graph(cuda):
     assert err < 2e-4, (k, err)
 
 
+@pytest.mark.parametrize('case', ['kitti', 'cityscapes_iou_box_knob', 'cvppp_mse'])
+def test_stacked_step_other_architectures_equal_per_timestep_graph(cuda, case):
+  """The stacked step beyond the CVPPP architecture (round 4): skip connections into the decoder (concat(prev, skip) rebuilt
+  over the stacked layer outputs), the 13 / 21 packed input channels of d_in / y_in, the 96-channel layer (grouped BatchNorm
+  backward falls back to one call per timestep), use_knob + use_iou_box (the corner-IoU matrix rebuilt differentiably over
+  all timesteps) and the 'mse' box loss (centre / log size of the stacked attention head): same loss pieces and matching
+  as the per-timestep autograd graph, every parameter gradient within 2e-4 of the tensor's scale — and the stacked path ran."""
+  import full_model
+  H, W, T, B = 64, 128, 2, 2   # G = 8 glimpse cells: the fused controller's kernels take multiples of 4
+  rng = np.random.RandomState(31)
+  if case == 'cvppp_mse':
+    opt = ora.make_opt('cvppp', H, W, T, base_learn_rate=1e-3, learn_rate_decay=0.96, steps_per_learn_rate_decay=5000, box_loss_fn='mse')
+  else:
+    over = dict(KNOB_OPT, use_iou_box=True) if case.startswith('cityscapes') else {}
+    opt = ora.make_opt('cityscapes' if case.startswith('cityscapes') else 'kitti', H, W, T, base_learn_rate=1e-3, learn_rate_decay=0.96,
+                       steps_per_learn_rate_decay=5000, **over)
+  P = ora.random_params(opt, 32)
+  for k in P:
+    if ra_is_w(k):
+      P[k] = (P[k] * 0.5).astype(np.float32)
+  x = rng.rand(B, H, W, 3).astype(np.float32)
+  extra = {}
+  if opt.get('add_d_out', False):
+    nsc = int(opt.get('num_semantic_classes', 1))
+    extra = dict(d_in=np.eye(8, dtype=np.float32)[rng.randint(0, 8, (B, H, W))], y_in=ora.softmax(rng.randn(B, H, W, nsc)).astype(np.float32))
+  y_gt, s_gt = np.zeros((B, T, H, W), np.float32), np.ones((B, T), np.float32)
+  y_gt[:, 0, 6:30, 8:40] = 1
+  y_gt[:, 1, 36:56, 50:120] = 1
+  res = {}
+  for mode in (True, False):
+    m = full_model.get_model(opt).load_weights(P)
+    ts = ra_train.TrainStep(m)
+    ts.batched_backward, ts.seq_ctrl_split = mode, False
+    assert ts._batched_ok([]) == mode
+    knobs = ts.draw_knobs(B, torch.Generator(device='cuda').manual_seed(5)) if opt.get('use_knob', False) else None
+    ts.bucket.zero_grad()
+    loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=knobs, **extra)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert ('ctrl_cnn_0_u' in ts._slabs) == mode
+    res[mode] = ({k: float(pieces[k].detach()) for k in ('loss', 'box_loss', 'segm_loss', 'conf_loss')}, pieces['match'].cpu().numpy(),
+                 pieces['match_box'].cpu().numpy(), {k: ts.bucket.grad_of[k].cpu().numpy().copy() for k in ts.bucket.names})
+  a, b = res[True], res[False]
+  for k in b[0]:
+    assert abs(a[0][k] - b[0][k]) < 1e-5 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
+  assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
+  gscale = max(np.abs(g).max() for g in b[3].values())
+  for k, g in b[3].items():
+    if not _pre_bn_bias(k):
+      err = np.abs(a[3][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
+      assert err < 2e-4, (k, err)
+
+
 def test_stacked_step_with_disable_overwrite_vs_oracle(cuda):
   """disable_overwrite = True (the reference's default, full_model.py:117-120: y *= 1 - canvas) through the stacked
   training graph: loss pieces and the whole gradient against float64 autograd (cosine; on this three-timestep random
