@@ -994,8 +994,10 @@ def attn_record(ctr, size, lg_var, attn_gamma=None, box_gamma=None, y_lg_gamma=N
 class AttnExtract(torch.autograd.Function):
   """x_patch = attn_gamma * F_y^T X F_x (modellib.extract_patch, full_model.py:778-789) on the banded HIP kernels: the
   forward is the decode loop's extract (weights evaluated on the fly from the window parameters), the backward turns
-  d x_patch straight into d (ctr, size, lg_var, attn_gamma) — no [L,F] filter banks, no GEMMs.  X is not differentiated
-  (the canvas gradient is stopped, full_model.py:843-848, and the image is data)."""
+  d x_patch straight into d (ctr, size, lg_var, attn_gamma) — no [L,F] filter banks, no GEMMs.  X is differentiated only
+  where the caller asks (stop_canvas_grad = False, full_model.py:843-848: the canvas channel of X carries a gradient):
+  d X = gamma F_y dP F_x^T, the reference's own "paste" (extract_patch with the transposed banks, modellib.py:615-641)
+  on the dense-bank operator."""
 
   @staticmethod
   def forward(ctx, x, ctr, size, lg_var, gamma, Fh, Fw):
@@ -1016,7 +1018,13 @@ class AttnExtract(torch.autograd.Function):
     x, rec = ctx.saved_tensors
     H, W, Fh, Fw = ctx.dims
     out = ops.resample_bwd(ops.RESAMPLE_READ, rec, H, W, Fh, Fw, X=x, Q=g.contiguous(), scale=rec[:, 6])
-    return None, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None
+    dx = None
+    if ctx.needs_input_grad[0]:
+      col = lambda k: rec[:, k].contiguous()
+      fyT = ops.gaussian_filter(col(0), col(2), col(4), H, Fh).transpose(1, 2).contiguous()   # [B,Fh,H]
+      fxT = ops.gaussian_filter(col(1), col(3), col(5), W, Fw).transpose(1, 2).contiguous()   # [B,Fw,W]
+      dx = ops.extract_patch_dense((g * rec[:, 6].view(-1, 1, 1, 1)).contiguous(), fyT, fxT)    # [B,H,W,C]
+    return dx, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None
 
 
 class AttnPaste(torch.autograd.Function):
@@ -1091,8 +1099,6 @@ class TrainStep(object):
     d = self.d
     if not torch.cuda.is_available():
       raise rn.RecAttendError('the training step needs an MI355X (HIP device); there is no CPU fallback')
-    if not self.opt.get('stop_canvas_grad', True):
-      raise NotImplementedError('stop_canvas_grad = False (gradient through the canvas) is not built')
     if self.opt.get('box_loss_fn', 'iou') not in ('iou', 'mse', 'huber') or \
         self.opt.get('segm_loss_fn', 'iou') not in ('iou', 'wt_cov'):
       # the reference's other branches cannot run: box 'wt_cov' feeds a scalar to f_weighted_coverage
@@ -1242,7 +1248,7 @@ class TrainStep(object):
     d, opt = self.d, self.opt
     c4 = lambda cs: all(c % 4 == 0 for c in cs)
     return bool(self.batched_backward and torch.is_grad_enabled() and d['use_bn'] and self.fuse_param_grads and
-                self.fuse_controller and
+                self.fuse_controller and bool(opt.get('stop_canvas_grad', True)) and  # a canvas gradient couples the timesteps
                 c4(self.model.dims['ccnn_channels'][1:]) and c4(opt['attn_cnn_depth']) and c4(opt['attn_dcnn_depth'][:-1]) and
                 self.model.dims['C0p'] % 4 == 0 and d['n_gmlp'] == 2 and d['n_cmlp'] == 1)
 
@@ -1534,6 +1540,7 @@ class TrainStep(object):
     dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))
     head_flags = (1 if d['squash'] else 0) | (2 if d['fixed_var'] else 0) | (4 if d['dynamic_var'] else 0) | (8 if d['fixed_gamma'] else 0)
     cc = x.shape[3]  # the canvas channel of the packed input
+    canvas_grad = not bool(opt.get('stop_canvas_grad', True)) and torch.is_grad_enabled()
     inp = torch.cat([x, canvas] + extra, dim=3)   # packed [x | canvas | d_in | y_in], zero-padded to C0p
     if inp.shape[3] != d['C0p']:
       inp = _pad_channels(inp)
@@ -1577,7 +1584,7 @@ class TrainStep(object):
             gsel_box = gmatch
           # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)
           ctr, size = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt])
-        x_patch = AttnExtract.apply(inp.detach(), ctr, size, lg_var, ag, Fh, Fw)
+        x_patch = AttnExtract.apply(inp if canvas_grad else inp.detach(), ctr, size, lg_var, ag, Fh, Fw)
         if batched:  # the attention CNN's first input of every timestep, contiguous over T for the stacked filter gradient
           slot = self._slab('xpatch', T, tuple(x_patch.shape))[tt]
           slot.copy_(x_patch)
@@ -1600,6 +1607,24 @@ class TrainStep(object):
         s = None if batched else torch.sigmoid(self._linear(torch.cat([h, core.reshape(B, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
         # canvas <- max(y_c, canvas) with y_c = y, or with the knob: the (noisy) matched ground-truth segmentation mixed in
         # (:826-848, stop_canvas_grad) — and the next timestep's packed input, in one launch (ra_canvas_step_f32)
+        if canvas_grad:
+          # stop_canvas_grad = False (full_model.py:843-848): canvas = max(y_c, canvas) stays on the autograd tape — its
+          # gradient reaches this timestep's mask (and, through earlier canvases, every mask before it) from the next
+          # controller CNN's first layer, the next extract, and the (1 - canvas) factor of disable_overwrite
+          y_c = y
+          if use_knob:
+            gsel = (gsel_box[:, :, None, None] * y_gt).sum(dim=1)
+            gsel = gsel - gsel * knobs['segm_noise'][tt]
+            ksv = knob_segm[:, tt].reshape(B, 1, 1)
+            y_c = ksv * gsel + (1.0 - ksv) * y
+          canvas_new = torch.maximum(y_c, inp[..., cc])
+          inp = torch.cat([inp[..., :cc], canvas_new[..., None], inp[..., cc + 1:]], dim=3)
+          y_list.append(y)
+          s_list.append(s)
+          box_list.append(box)
+          cn_list.append(cn)
+          ls_list.append(ls)
+          continue
         nxt = inp_slab[tt + 1] if (batched and tt + 1 < T) else torch.empty_like(inp)
         yd = y.detach().contiguous()
         if use_knob:

@@ -238,6 +238,62 @@ def test_knob_mixing_vs_oracle(cuda, step, fixed, ioub):
     assert abs(float(loss0) - float(loss)) > 1e-3
 
 
+@pytest.mark.parametrize('case', ['plain', 'knob_decayed', 'disable_overwrite'])
+def test_canvas_gradient_vs_oracle(cuda, case):
+  """stop_canvas_grad = False (full_model.py:843-848; every run script sets the flag, so this is the branch off the
+  beaten path): canvas = max(y_c, canvas) stays differentiable — its gradient reaches every earlier mask through the
+  next controller CNN's first layer (a data gradient in the packed input's canvas channel), the next extract (d X =
+  gamma F_y dP F_x^T on the dense-bank operator) and disable_overwrite's (1 - canvas) factor.  Loss pieces and the
+  whole gradient against float64 autograd; and the gradient differs from the stopped one (the branch is live)."""
+  import full_model
+  over = dict(stop_canvas_grad=False)
+  if case == 'knob_decayed':
+    over.update(KNOB_OPT)
+  if case == 'disable_overwrite':
+    over.update(disable_overwrite=True)
+  # two timesteps: with three, this random network turns float32 round-off into 11 % in single BatchNorm gradients even
+  # in a plain-torch float32 evaluation of the ORACLE's graph (the canvas gradient adds a path through every later step)
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6, **over)
+  B, T, H, W = 2, 2, 64, 64
+  rng = np.random.RandomState(5)
+  knobs, step = None, 0
+  if case == 'knob_decayed':  # step 5000: knob probabilities 0.2, most draws keep the prediction (a live canvas gradient)
+    step = 5000
+    knobs = {'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)),
+             'u_box': rng.rand(B, T, 1), 'u_segm': rng.rand(B, T, 1), 'segm_noise': 0.3 * rng.rand(T, B, H, W)}
+  keys = [k for k in P if not (k.endswith('_ema_mean') or k.endswith('_ema_var'))]
+
+  def oracle(o):
+    fwd, Pt = ort.forward(o, P, x, requires_grad=keys, phase_train=True, knobs=knobs, y_gt=y_gt, global_step=step)
+    head = ort.loss_head(o, fwd, y_gt, s_gt)
+    (head['loss'] + ort.weight_decay_term(o, {k: Pt[k] for k in keys})).backward()
+    return head, {k: Pt[k].grad.numpy() if Pt[k].grad is not None else np.zeros(P[k].shape) for k in keys}
+  head, gref = oracle(opt)
+  _, gstop = oracle(dict(opt, stop_canvas_grad=True))
+  assert np.abs(gref['ctrl_cnn_w_0'] - gstop['ctrl_cnn_w_0']).max() > 1e-3 * np.abs(gstop['ctrl_cnn_w_0']).max()
+  m = full_model.get_model(opt).load_weights(P)
+  ts = ra_train.TrainStep(m)
+  assert not ts._batched_ok([])   # the canvas gradient couples the timesteps: the per-timestep graph
+  ts.bucket.global_step = step
+  kd = None if knobs is None else {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in knobs.items()}
+  ts.bucket.zero_grad()
+  loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd)
+  loss.backward()
+  for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
+    assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
+  assert (pieces['match'].cpu().numpy() == head['match'].numpy()).all()
+  got_of = lambda k: ts.bucket.grad_of[k].cpu().numpy()
+  _compare_grads(gref, got_of, P, float(opt['weight_decay']))
+  wd = float(opt['weight_decay'])
+  assert _grad_cosine(gref, got_of, P, wd) > _grad_cosine(gstop, got_of, P, wd)  # closer to ITS oracle than to the stopped one
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'aug': False}
+  if kd is not None:
+    feed['knobs'] = kd
+  m2 = full_model.get_model(opt).load_weights(P)
+  losses = [float(m2.run(['loss', 'train_step'], feed)[0]) for _ in range(3)]   # eager, captured, replayed
+  assert all(np.isfinite(losses)), losses
+
+
 CVPPP_FLAGS = ['--ctrl_add_inp', '--ctrl_add_canvas', '--attn_add_inp', '--attn_add_canvas', '--fixed_gamma',
                '--stop_canvas_grad', '--use_knob', '--knob_use_timescale',                       # run_cvppp.sh:44-72
                '--ctrl_cnn_filter_size', '3,3,3,3,3,3,3,3', '--ctrl_cnn_depth', '8,8,16,16,32,32,64,64',
