@@ -492,10 +492,19 @@ int ra_eval_metrics_f32(const float *inter, const float *sum_a, const float *sum
  * draws: zero-pad by `padding`, crop H x W at (off_y, off_x) in [0, 2*padding] (one offset per
  * batch), reverse along H (flip_v) / W (flip_h), then transpose H <-> W (needs H == W).
  * x, out: [N,H,W,C]; instance masks [B,T,H,W] go in as N = B*T, C = 1.  out != x.
- * The colour jitter (:99-103) is not built. */
+ * The colour jitter (:99-103) is ra_colour_jitter_f32 below. */
 int ra_random_transform_f32(const float *x, int N, int H, int W, int C, int padding, int off_y,
                             int off_x, int flip_v, int flip_h, int transpose, float *out,
                             void *stream);
+/* The colour jitter of the same augmentation (image_ops.py:99-103,116-180: random_hue(0.1), random_saturation(0.9, 1.1),
+ * tf.image.random_brightness(0.1), tf.image.random_contrast(0.9, 1.1)) for given draws, one of each per batch: RGB -> HSV,
+ * hue = (hue + hue_delta + 1) mod 1, saturation = clip(saturation * factor, 0, 1), HSV -> RGB, + brightness_delta (no
+ * clipping: float images), then (x - mean) * contrast_factor + mean with the mean of each image and channel.  TensorFlow's
+ * kernels restated from their published algorithm; they cannot be run here.  x, out: [B,HW,3] (out may
+ * be x); ws: ra_colour_jitter_workspace_floats(B) floats. */
+size_t ra_colour_jitter_workspace_floats(int B);
+int ra_colour_jitter_f32(const float *x, int B, int HW, float hue_delta, float saturation_factor, float brightness_delta,
+                         float contrast_factor, float *ws, size_t ws_floats, float *out, void *stream);
 
 /* out[b,p] = sum_t w[b,t] * y[b,t,p]: the ground-truth instance box_model's greedy match picks
  * (box_model.py:487-499).  Terms with w == 0 are skipped (0 * x is not evaluated). */

@@ -566,6 +566,33 @@ def random_transformation(x, padding, off_y, off_x, flip_v=False, flip_h=False, 
   return np.ascontiguousarray(r)
 
 
+def colour_jitter(x, hue, saturation, brightness, contrast):
+  """image_ops.py:99-103 for GIVEN draws on x [B,H,W,3]: random_hue (:116-147, tf.image.adjust_hue: RGB -> HSV, hue =
+  (hue + delta + 1) mod 1, back), random_saturation (:150-180, adjust_saturation: saturation * factor clipped to [0, 1]),
+  tf.image.random_brightness (x + delta; float images are not clipped) and tf.image.random_contrast ((x - mean) * factor +
+  mean, mean per image and channel over H x W).  The colour-space conversions follow TensorFlow's published kernels
+  (core/kernels/colorspace_op.h): they live in TF-0.12, which cannot run here — unpinned like tf.round."""
+  x = np.asarray(x, dtype=np.float64)
+  r, g, b = x[..., 0], x[..., 1], x[..., 2]
+  v = np.maximum(r, np.maximum(g, b))
+  rng_ = v - np.minimum(r, np.minimum(g, b))
+  s = np.where(v > 0, rng_ / np.where(v > 0, v, 1.0), 0.0)
+  with np.errstate(divide='ignore', invalid='ignore'):
+    norm = 1.0 / (6.0 * rng_)
+    h = np.where(r == v, norm * (g - b), np.where(g == v, norm * (b - r) + 2.0 / 6.0, norm * (r - g) + 4.0 / 6.0))
+  h = np.where(rng_ > 0, h, 0.0)
+  h = np.where(h < 0, h + 1.0, h)
+  h = np.mod(h + (hue + 1.0), 1.0)
+  s = np.clip(s * saturation, 0.0, 1.0)
+  d6 = h * 6.0
+  dr = np.clip(np.abs(d6 - 3.0) - 1.0, 0.0, 1.0)
+  dg = np.clip(2.0 - np.abs(d6 - 2.0), 0.0, 1.0)
+  db = np.clip(2.0 - np.abs(d6 - 4.0), 0.0, 1.0)
+  out = np.stack([(1.0 - s + s * dr) * v, (1.0 - s + s * dg) * v, (1.0 - s + s * db) * v], axis=-1) + brightness
+  mean = out.mean(axis=(1, 2), keepdims=True)
+  return (out - mean) * contrast + mean
+
+
 # --------------------------------------------------------------------------------------
 # model option handling shared by both graphs
 # --------------------------------------------------------------------------------------

@@ -269,6 +269,95 @@ extern "C" int ra_random_transform_f32(const float *x, int N, int H, int W, int 
   return launch_status("ra_random_transform_f32");
 }
 
+// ---- colour jitter of the in-graph augmentation (image_ops.py:99-103: random_hue 0.1, random_saturation 0.9..1.1,
+// tf.image.random_brightness 0.1, tf.image.random_contrast 0.9..1.1; one draw of each per batch) ----
+// TensorFlow's kernels, restated from their published algorithm (tensorflow/core/kernels/colorspace_op.h,
+// adjust_contrast_op.cc; python/ops/image_ops.py adjust_hue / adjust_saturation / adjust_brightness): RGB -> HSV, hue =
+// (hue + delta + 1) mod 1, saturation = clip(saturation * factor, 0, 1), HSV -> RGB, + brightness delta (float images are
+// not clipped), then (x - mean) * contrast + mean with the mean of each image and channel over H x W.
+namespace ra {
+namespace eval {
+__device__ inline void hue_sat_pixel(float &r, float &g, float &b, float dh, float sf) {
+  const float v = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b)), range = v - mn;
+  float s = v > 0.f ? range / v : 0.f;
+  const float norm = 1.0f / (6.0f * range);
+  float h = (r == v) ? norm * (g - b) : (g == v) ? norm * (b - r) + 2.0f / 6.0f : norm * (r - g) + 4.0f / 6.0f;
+  h = range > 0.f ? h : 0.f;
+  h = h < 0.f ? h + 1.0f : h;
+  h = fmodf(h + (dh + 1.0f), 1.0f);
+  s = fminf(fmaxf(s * sf, 0.f), 1.f);
+  const float d6 = h * 6.0f, one_s = 1.0f - s;
+  const float dr = fminf(fmaxf(fabsf(d6 - 3.0f) - 1.0f, 0.f), 1.f);
+  const float dg = fminf(fmaxf(2.0f - fabsf(d6 - 2.0f), 0.f), 1.f);
+  const float db = fminf(fmaxf(2.0f - fabsf(d6 - 4.0f), 0.f), 1.f);
+  r = (one_s + s * dr) * v;
+  g = (one_s + s * dg) * v;
+  b = (one_s + s * db) * v;
+}
+
+// pass 1: hue / saturation / brightness per pixel, and this block's per-channel sums -> part[image][block][3]
+__global__ __launch_bounds__(256) void colour_pass1_kernel(const float *x, int HW, float dh, float sf, float db, float *out, float *part) {
+  const int img = blockIdx.y;
+  const float *xi = x + (size_t)img * HW * 3;
+  float *oi = out + (size_t)img * HW * 3;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    float r = xi[3 * p], g = xi[3 * p + 1], b = xi[3 * p + 2];
+    hue_sat_pixel(r, g, b, dh, sf);
+    r += db;
+    g += db;
+    b += db;
+    oi[3 * p] = r;
+    oi[3 * p + 1] = g;
+    oi[3 * p + 2] = b;
+    acc[0] += r;
+    acc[1] += g;
+    acc[2] += b;
+  }
+  __shared__ float sm[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = acc[c];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) part[((size_t)img * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// pass 2: contrast about the image's channel means (the blocks' partial sums added in block order: deterministic)
+__global__ __launch_bounds__(256) void colour_pass2_kernel(float *x, int HW, int nblk, const float *part, float cf) {
+  const int img = blockIdx.y;
+  __shared__ float mean[3];
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += part[((size_t)img * nblk + k) * 3 + threadIdx.x];
+    mean[threadIdx.x] = s / (float)HW;
+  }
+  __syncthreads();
+  float *xi = x + (size_t)img * HW * 3;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < 3 * HW; e += gridDim.x * 256) {
+    const float m = mean[e % 3];
+    xi[e] = (xi[e] - m) * cf + m;
+  }
+}
+}  // namespace eval
+}  // namespace ra
+
+extern "C" size_t ra_colour_jitter_workspace_floats(int B) { return B > 0 ? (size_t)B * 64 * 3 : 0; }
+
+extern "C" int ra_colour_jitter_f32(const float *x, int B, int HW, float hue_delta, float saturation_factor,
+                                    float brightness_delta, float contrast_factor, float *ws, size_t ws_floats, float *out,
+                                    void *stream) {
+  if (!x || !out || !ws || B <= 0 || HW <= 0) return fail(RA_E_INVALID, "ra_colour_jitter_f32: bad argument");
+  if (ws_floats < ra_colour_jitter_workspace_floats(B)) return fail(RA_E_WORKSPACE, "ra_colour_jitter_f32: workspace");
+  const int nblk = 64;
+  hipLaunchKernelGGL(eval::colour_pass1_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), x, HW, hue_delta, saturation_factor,
+                     brightness_delta, out, ws);
+  hipLaunchKernelGGL(eval::colour_pass2_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), out, HW, nblk, ws, contrast_factor);
+  return launch_status("ra_colour_jitter_f32");
+}
+
 // out[b,p] = sum_t w[b,t] * y[b,t,p] — the ground-truth instance picked by box_model's greedy match
 // (box_model.py:487-499: reduce_sum(grd_match * y_gt, 1)).
 namespace ra {

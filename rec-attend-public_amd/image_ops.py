@@ -5,7 +5,8 @@ why the decode loop never calls it.  With phase_train true it draws ONE crop off
 and one flip / transpose decision per batch (:85-97) and applies them to x, y, d, c alike; the
 gather runs in one HIP kernel per tensor (ra_random_transform_f32).  The draws come from a
 torch.Generator so that ranks can offset their streams deterministically.
-The colour jitter (random hue / saturation / brightness / contrast, :99-103) is not built."""
+The colour jitter (:99-103: random hue 0.1, saturation 0.9..1.1, brightness 0.1, contrast 0.9..1.1, one draw of each per
+batch, in that order) follows the crop / flips on x (ra_colour_jitter_f32)."""
 import torch
 
 import nnlib as nn
@@ -15,15 +16,14 @@ import ra_ops as ops
 def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=True, rnd_transpose=True,
                           rnd_colour=False, y=None, d=None, c=None, generator=None, draws=None):
   """x [B,H,W,3], y [B,T,H,W], d [B,H,W,8], c [B,H,W,1] -> dict with the same keys (x, y, d, c).
-  draws: the step's decisions given instead of drawn ({off_y, off_x, flip_v, flip_h, transpose}; tests)."""
+  draws: the step's decisions given instead of drawn ({off_y, off_x, flip_v, flip_h, transpose[, hue, saturation,
+  brightness, contrast]}; tests)."""
   results = {'x': x}
   for k, v in (('y', y), ('d', d), ('c', c)):
     if v is not None:
       results[k] = v
   if not nn._is_train(phase_train):
     return results  # centre slices of the padded tensors: the inputs themselves
-  if rnd_colour:
-    raise NotImplementedError('colour jitter (image_ops.py:99-103, :116-230) is not built')
   if d is not None:  # image_ops.py:42-45
     assert not rnd_vflip, 'Orientation mode is on, no random flips'
     assert not rnd_hflip, 'Orientation mode is on, no random flips'
@@ -42,6 +42,15 @@ def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=Tru
     do_tr = bool(rnd_transpose) and float(u[2]) < 0.5 and d is None
     kw = dict(padding=padding, off_y=int(off[0]), off_x=int(off[1]), flip_v=flip_v, flip_h=flip_h, transpose=do_tr)
   results['x'] = ops.random_transform(x, **kw)
+  if rnd_colour:  # image_ops.py:99-103
+    if draws is not None:
+      col = dict(hue=float(draws.get('hue', 0.0)), saturation=float(draws.get('saturation', 1.0)),
+                 brightness=float(draws.get('brightness', 0.0)), contrast=float(draws.get('contrast', 1.0)))
+    else:
+      u4 = torch.rand(4, generator=generator)
+      col = dict(hue=float(-0.1 + 0.2 * u4[0]), saturation=float(0.9 + 0.2 * u4[1]), brightness=float(-0.1 + 0.2 * u4[2]),
+                 contrast=float(0.9 + 0.2 * u4[3]))
+    results['x'] = ops.colour_jitter(results['x'], col['hue'], col['saturation'], col['brightness'], col['contrast'])
   if y is not None:
     B, T, H, W = y.shape
     results['y'] = ops.random_transform(y.reshape(B * T, H, W), **kw).reshape(B, T, H, W)
@@ -49,5 +58,5 @@ def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=Tru
     results['d'] = ops.random_transform(d, **kw)
   if c is not None:
     results['c'] = ops.random_transform(c, **kw)
-  results['_draws'] = kw
+  results['_draws'] = dict(kw, **col) if rnd_colour else kw
   return results

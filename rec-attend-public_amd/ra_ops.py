@@ -688,6 +688,21 @@ def random_transform(x, padding, off_y, off_x, flip_v=False, flip_h=False, trans
   return out
 
 
+def colour_jitter(x, hue_delta, saturation_factor, brightness_delta, contrast_factor):
+  """image_ops.py:99-103 for given draws on x [B,H,W,3] (ra_colour_jitter_f32)."""
+  x = x.contiguous()
+  _need_cuda(x)
+  B, H, W, Cc = x.shape
+  if Cc != 3:
+    raise rn.RecAttendError('colour jitter needs an RGB image (last dimension 3)')
+  out = torch.empty_like(x)
+  n = rn.lib().ra_colour_jitter_workspace_floats(B)
+  ws = torch.empty((n,), dtype=torch.float32, device=x.device)
+  check(rn.lib().ra_colour_jitter_f32(ptr(x), B, H * W, C.c_float(hue_delta), C.c_float(saturation_factor), C.c_float(brightness_delta),
+                                      C.c_float(contrast_factor), ptr(ws), n, ptr(out), rn.stream_ptr()), 'ra_colour_jitter_f32')
+  return out
+
+
 def fill(t, value):
   """t[...] = value as a library launch (keeps framework kernels out of the captured forward)."""
   _need_cuda(t)

@@ -1799,11 +1799,10 @@ class TrainStep(object):
     as_t = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else torch.as_tensor(
         np.asarray(a, dtype=np.float32))).to(device=dev, dtype=torch.float32).contiguous()
     opt = self.opt
-    if opt.get('rnd_colour', False):
-      raise NotImplementedError('colour jitter (image_ops.py:99-103) is not built')
     r = image_ops.random_transformation(
         as_t(x), int(opt.get('padding', 0)), True, rnd_vflip=bool(opt.get('rnd_vflip', False)),
-        rnd_hflip=bool(opt.get('rnd_hflip', False)), rnd_transpose=bool(opt.get('rnd_transpose', False)), y=as_t(y_gt),
+        rnd_hflip=bool(opt.get('rnd_hflip', False)), rnd_transpose=bool(opt.get('rnd_transpose', False)),
+        rnd_colour=bool(opt.get('rnd_colour', False)), y=as_t(y_gt),
         d=as_t(extra.get('d_in')), c=as_t(extra.get('y_in')), generator=self.aug_gen, draws=aug if isinstance(aug, dict) else None)
     extra = dict(extra)
     if 'd' in r:

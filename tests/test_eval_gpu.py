@@ -189,5 +189,14 @@ def test_random_transformation(cuda, H, W, C, pad):
   assert (r['x'].cpu().numpy() == ora.random_transformation(xd.cpu().numpy(), **kw)).all()
   yr = ora.random_transformation(y.cpu().numpy().reshape(8, H, W), **kw).reshape(2, 4, H, W)
   assert (r['y'].cpu().numpy() == yr).all()
-  with pytest.raises(NotImplementedError):
-    image_ops.random_transformation(xd, pad, True, rnd_colour=True)
+  if C == 3:  # the colour jitter (image_ops.py:99-103) on the cropped / flipped image, for given and for drawn factors
+    col = dict(hue=0.07, saturation=1.08, brightness=-0.06, contrast=0.93)
+    r2 = image_ops.random_transformation(xd, pad, True, rnd_transpose=False, rnd_colour=True, y=y, draws=dict(kw, **col))
+    ref = ora.colour_jitter(ora.random_transformation(xd.cpu().numpy(), **dict(kw, transpose=kw['transpose'])), **col)
+    assert np.abs(r2['x'].cpu().numpy() - ref).max() < 2e-6 and (r2['y'].cpu().numpy() == yr).all()
+    r3 = image_ops.random_transformation(xd, pad, True, rnd_transpose=False, rnd_colour=True, generator=torch.Generator().manual_seed(9))
+    d3 = r3['_draws']
+    assert -0.1 <= d3['hue'] <= 0.1 and 0.9 <= d3['saturation'] <= 1.1 and -0.1 <= d3['brightness'] <= 0.1 and 0.9 <= d3['contrast'] <= 1.1
+    ref3 = ora.colour_jitter(ora.random_transformation(xd.cpu().numpy(), **{k: d3[k] for k in kw}),
+                             **{k: d3[k] for k in ('hue', 'saturation', 'brightness', 'contrast')})
+    assert np.abs(r3['x'].cpu().numpy() - ref3).max() < 2e-6
