@@ -311,30 +311,38 @@ def train_steps(rank, world, B, T, S, steps, warmup, sync_bn=False, dtype='f32')
   return ra_dist.max_over_ranks(time.perf_counter() - t0), float(loss), model
 
 
-def train_layer_bytes(opt, B, S, T):
+def train_layer_bytes(opt, B, S, T, bf16_store=False):
   """HBM bytes the conv layers' passes of ONE training step move when every pass reads and writes each of its tensors
   exactly once (float32 tensors in both dtypes — the bf16 mode rounds operands on chip): per layer call
   forward conv (X in, U out) + normalise/ReLU/pool (U in, Y out); backward BatchNorm sums (U, dY in) + its input
   gradient (U, dY in, dU out) + data gradient (dU in, dX out; not for a layer fed by data) + filter gradient (X, dU in)
   = 3 X + 7 U + 3 Y (2 X + 6 U + 3 Y without the data gradient).  The three networks of a timestep (full_model.py:455-535)
-  times T timesteps; the controller, the attention resamples and the loss head are not counted (launch-bound, small)."""
+  times T timesteps; the controller, the attention resamples and the loss head are not counted (launch-bound, small).
+  bf16_store (the bf16 mode's stacked step): U, and Y of every layer but a net's last, are 2 bytes per element where the
+  float4 BatchNorm kernels take the channel count (a multiple of 4, a quarter of it a power of two); a net's first input
+  (the packed image, the extracted patch, the attention CNN's last output) stays float32."""
   r4 = lambda c: -(-c // 4) * 4
   total = 0
+  st_ok = lambda c: bf16_store and c % 4 == 0 and ((c // 4) & (c // 4 - 1)) == 0 and c // 4 <= 64
 
   def net(h, w, cin, depths, pools, transposed, first_has_dgrad):
     nonlocal total
+    sx = 4  # bytes per element of the layer's input
     for i, (co, p) in enumerate(zip(depths, pools)):
       if transposed:
         h, w = h * p, w * p
-      X = B * (h // (p if transposed else 1)) * (w // (p if transposed else 1)) * r4(cin) * 4
-      U = B * h * w * co * 4
+      su = 2 if st_ok(co) else 4
+      sy = 2 if (st_ok(co) and i != len(depths) - 1) else 4
+      X = B * (h // (p if transposed else 1)) * (w // (p if transposed else 1)) * r4(cin) * sx
+      U = B * h * w * co
       if not transposed:
         Y = U // (p * p)
         h, w = h // p, w // p
       else:
         Y = U
+      U, Y = U * su, Y * sy
       total += (3 * X + 7 * U + 3 * Y) if (i or first_has_dgrad) else (2 * X + 6 * U + 3 * Y)
-      cin = co
+      cin, sx = co, sy
     return h, w, cin
   net(S, S, 4, opt['ctrl_cnn_depth'], opt['ctrl_cnn_pool'], False, False)
   F = opt['filter_height']
@@ -343,19 +351,21 @@ def train_layer_bytes(opt, B, S, T):
   return total * T
 
 
-def train_roofline(opt, B, S, T, ms_per_step):
-  nbytes = train_layer_bytes(opt, B, S, T)
+def train_roofline(opt, B, S, T, ms_per_step, bf16_store=False):
+  nbytes = train_layer_bytes(opt, B, S, T, bf16_store)
   ach = nbytes / (ms_per_step * 1e-3) / 1e9
   return {'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
           'bytes_per_step': nbytes,
+          'bf16_storage': bool(bf16_store),
           'note': 'conv-layer passes only, each tensor of a pass moved once (3 X + 7 U + 3 Y per layer call, DESIGN.md §4 '
-                  'training kernels); the whole step time in the denominator: the step is launch-latency bound on the '
-                  'patch-sized layers, not HBM bound'}
+                  'training kernels; with bf16 storage U and Y are 2 bytes per element); the whole step time in the denominator: '
+                  'the step is launch-latency bound on the patch-sized layers, not HBM bound'}
 
 
 DTYPE_NOTE = {'f32': 'float32 throughout',
-              'bf16': 'conv forward / data / filter gradients with bf16 operands on the bf16 MFMA, float32 accumulation; '
-                      'master weights, Adam state, activations, BatchNorm and the loss float32'}
+              'bf16': 'conv forward / data / filter gradients with bf16 operands on the bf16 MFMA, float32 accumulation, and '
+                      'the conv layers\' U / Y / dY / dU stored as bf16 between their passes; BatchNorm statistics, master weights, '
+                      'Adam state, the controller, the attention resamples and the loss float32'}
 
 
 def train_object(rank, world, B, T, S, steps=3, dtype='f32'):
@@ -368,7 +378,7 @@ def train_object(rank, world, B, T, S, steps=3, dtype='f32'):
          'unit': 'instance-timesteps/s', 'dtype': dtype, 'final_loss': loss, 'grad_bucket_floats': int(model.trainer.bucket.n),
          'hip_graph': bool(model.trainer.use_graph), 'fused_controller': getattr(model.trainer, '_ctl', None) is not None,
          'ranks_in_communicator': ra_dist.comm_size(),
-         'roofline': train_roofline(model.opt, B, S, T, 1e3 * elapsed / steps)}
+         'roofline': train_roofline(model.opt, B, S, T, 1e3 * elapsed / steps, bool(getattr(model.trainer, 'bf16_store', False)))}
   del model
   torch.cuda.empty_cache()
   return obj
@@ -393,7 +403,7 @@ def bench_train(args, rank, world, B, T, S):
                    'grad_bucket_floats': int(model.trainer.bucket.n),
                    'bn_moments': 'whole batch (sync_bn)' if model.trainer.sync_bn else 'per-rank shard',
                    'ranks_in_communicator': ra_dist.comm_size()},
-        'roofline': train_roofline(model.opt, B, S, T, 1e3 * elapsed / args.steps),
+        'roofline': train_roofline(model.opt, B, S, T, 1e3 * elapsed / args.steps, bool(getattr(model.trainer, 'bf16_store', False))),
         'final_loss': float(loss)}))
   if world > 1:
     ra_dist.barrier()

@@ -119,6 +119,34 @@ int ra_conv3x3_bf16ops_f32(const float *src0, int C0, const float *src1, int C1,
                            int Cout, int relu, int pool, const float *plane, int plane_chan, float *y,
                            void *stream);
 
+/* ---- bf16 STORAGE of the tensors between the conv layers' passes (model_opt['compute_dtype'] = 'bf16'; an extension: the
+ * reference trains in float32, full_model.py:1039-1057).  On top of the bf16-operand kernels above, the pre-activation
+ * outputs U, the activations Y and the gradients dY / dU are kept as bf16 in HBM (2 bytes per element, round to nearest
+ * even on the way out, exact on the way in); BatchNorm statistics, sums, parameter gradients, master weights and Adam
+ * state stay float32.  Tensors in bf16 are `void *`. ---- */
+/* conv3x3 with bf16 operands; store_flags bit 0: src0 / src1 hold bf16, bit 1: y is written as bf16.  part != NULL: the
+ * batch moments of the float32 accumulators as ra_conv3x3_moments_f32 (pool 1, Cout % 4 == 0); part == NULL: `pool` as given. */
+int ra_conv3x3_bf16_f32(const void *src0, int C0, const void *src1, int C1, int B, int Hs, int Ws, int upsample,
+                        const float *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool, void *y,
+                        float *part, size_t part_floats, int *nparts, int store_flags, void *stream);
+/* ra_bn_act_pool_f32 with flags bit 0: u stored as bf16, bit 1: y written as bf16 (0, 1, 3; C % 4 == 0, C / 4 a power of two). */
+int ra_bn_act_pool_bf16_f32(const void *u, const float *mean, const float *var, const float *gamma, const float *beta, float eps,
+                            int relu, int pool, int B, int H, int W, int C, void *y, int flags, void *stream);
+/* ra_bn_act_pool_bwd_acc_f32 / ra_bn_act_pool_bwd_grouped_f32 with flags bit 0: u read and du written as bf16, bit 1: dy read
+ * as bf16 (0, 1, 3). */
+int ra_bn_act_pool_bwd_acc_bf16_f32(const void *u, const void *dy, const float *mean, const float *var, const float *gamma,
+                                    const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *ws,
+                                    size_t ws_floats, float *dgamma, float *dbeta, void *du, float *acc_gamma, float *acc_beta,
+                                    int flags, void *stream);
+int ra_bn_act_pool_bwd_grouped_bf16_f32(const void *u, const void *dy, const void *const *tabs, int G, float eps, int relu, int pool,
+                                        int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta,
+                                        void *du, int flags, void *stream);
+/* ra_conv3x3_wgrad_acc_bf16ops_f32 with fmt bit 0: x stored as bf16, bit 1: du stored as bf16.  (The multi-call form
+ * ra_conv3x3_wgrad_multi_acc_f32 takes the same two bits shifted up by one in its bf16_operands argument.) */
+int ra_conv3x3_wgrad_acc_bf16_f32(const void *x, int Cin, int B, int Hs, int Ws, int upsample, const void *du, int Cout, float *ws,
+                                  size_t ws_floats, const int *chan_map, int cin_w, int transposed, float *gw, float *gb, int fmt,
+                                  void *stream);
+
 /* The training forward of a BatchNorm layer (nnlib.py:98: tf.nn.moments of the conv output over batch, height, width):
  * ra_conv3x3_moments_f32 is ra_conv3x3_f32 / _bf16ops_f32 (pool 1, Cout % 4 == 0, no canvas plane) whose epilogue also
  * leaves per-wave channel sums of its output y BEFORE the ReLU in `part` (ra_conv3x3_moments_part_floats(Cout) floats;

@@ -46,10 +46,22 @@ CONV_OPERANDS = None
 
 
 def set_conv_operands(kind):
-  """None (the reference's arithmetic) or 'bf16'."""
+  """None (the reference's arithmetic), 'bf16' (bf16 operands of the three conv products) or 'bf16s' (the same, and the
+  tensors between the conv layers' passes STORED as bf16, as the product's stacked training step keeps them: the
+  pre-activation output U after its batch moments were taken, the activation Y of every layer but a net's last, and the
+  gradients dY / dU — where the layer's channel count is one the product's float4 BatchNorm kernels take)."""
   global CONV_OPERANDS
-  assert kind in (None, 'bf16')
+  assert kind in (None, 'bf16', 'bf16s')
   CONV_OPERANDS = kind
+
+
+def _rounds_operands():
+  return CONV_OPERANDS in ('bf16', 'bf16s')
+
+
+def _stores_bf16(cout):
+  c4 = cout // 4
+  return CONV_OPERANDS == 'bf16s' and cout % 4 == 0 and c4 & (c4 - 1) == 0 and c4 <= 64
 
 
 def _bf16_round(t):
@@ -83,18 +95,18 @@ class _RoundGradient(torch.autograd.Function):
 def conv_same(x, w, b):
   """nnlib.conv2d (nnlib.py:6-12): NHWC x, HWIO w, stride 1, SAME -> NHWC (odd kernels)."""
   k = w.shape[0]
-  if CONV_OPERANDS == 'bf16':
+  if _rounds_operands():
     x, w = _RoundOperand.apply(x), _RoundOperand.apply(w)
   y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=k // 2)
   y = y.permute(0, 2, 3, 1) + b
-  return _RoundGradient.apply(y) if CONV_OPERANDS == 'bf16' else y
+  return _RoundGradient.apply(y) if _rounds_operands() else y
 
 
 def deconv_same(x, w, b, stride):
   """nnlib.py:372-376 conv2d_transpose, filter [f,f,out,in], SAME, output = input * stride.
   SURVEY.md §8a trap 2: stride 2, k = 3 is conv_transpose2d(padding=0)[..., :2n, :2n]; stride 1 is
   padding = 1."""
-  if CONV_OPERANDS == 'bf16':
+  if _rounds_operands():
     x, w = _RoundOperand.apply(x), _RoundOperand.apply(w)
   wt = w.permute(3, 2, 0, 1)  # [in, out, kh, kw]
   xi = x.permute(0, 3, 1, 2)
@@ -104,7 +116,7 @@ def deconv_same(x, w, b, stride):
     n_h, n_w = x.shape[1] * stride, x.shape[2] * stride
     y = F.conv_transpose2d(xi, wt, stride=stride, padding=0)[:, :, :n_h, :n_w]
   y = y.permute(0, 2, 3, 1) + b
-  return _RoundGradient.apply(y) if CONV_OPERANDS == 'bf16' else y
+  return _RoundGradient.apply(y) if _rounds_operands() else y
 
 
 def pool(x, r):
@@ -123,12 +135,23 @@ def bn_eval(x, P, key):
 def bn_train(x, P, key, stats):
   """nnlib.batch_norm, training branch (nnlib.py:98-112): moments over (B, H, W) with the biased
   variance, differentiated through; the (mean, var) pair is recorded for the EMA update
-  shadow = 0.9 shadow + 0.1 value (nnlib.py:103-110)."""
+  shadow = 0.9 shadow + 0.1 value (nnlib.py:103-110).  'bf16s': the moments are those of the conv's float32 output, the
+  value normalised is its bf16 STORED form."""
   mean = x.mean(dim=(0, 1, 2))
   var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
   if stats is not None:
     stats[key] = (mean.detach(), var.detach())
+  if _stores_bf16(x.shape[-1]):
+    x = _RoundOperand.apply(x)
   return (x - mean) * torch.rsqrt(var + 1e-3) * P[key + '_gamma'] + P[key + '_beta']
+
+
+def _store_y(x, last):
+  """'bf16s': a layer's activation is stored as bf16 (and so is its gradient on the way back), except a net's last
+  output, which float32 kernels read (the controller, the score MLP / decoder input, the paste)."""
+  if _BN['train'] and not last and _stores_bf16(x.shape[-1]):
+    return _RoundGradient.apply(_RoundOperand.apply(x))
+  return x
 
 
 _BN = {'train': False, 'stats': None}
@@ -145,7 +168,7 @@ def cnn(x, P, scope, n, pools, tt, use_bn):
     h = conv_same(x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)])
     if use_bn:
       h = bn(h, P, '%s_%d_%d' % (scope, i, tt))
-    x = pool(torch.relu(h), pools[i])
+    x = _store_y(pool(torch.relu(h), pools[i]), i == n - 1)
     hs.append(x)
   return hs
 
@@ -159,7 +182,7 @@ def dcnn(x, P, scope, n, unpool, tt, skip, use_bn):
     h = deconv_same(x, P['%s_w_%d' % (scope, i)], P['%s_b_%d' % (scope, i)], unpool[i])
     if use_bn:
       h = bn(h, P, '%s_%d_%d' % (scope, i, tt))
-    x = torch.relu(h)
+    x = _store_y(torch.relu(h), i == n - 1)
     hs.append(x)
   return hs
 

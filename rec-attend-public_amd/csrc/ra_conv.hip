@@ -62,6 +62,7 @@ struct Args {
   const float *plane;           // optional [B,Hs,Ws] plane that REPLACES input channel plane_chan
   int plane_chan, bytes_p;      // (the canvas, kept outside the packed image)
   int bf16;                     // 1: bf16 operands, float32 accumulation
+  int in_bf16, out_bf16;        // bf16 kernels only: src0 / src1, respectively y, are STORED as bf16 (2 bytes per element)
   float *mom_part;              // MOM kernels: per-(workgroup, wave row) channel sums of the pre-activation output
   int *nparts_out;              // host: the number of partial records the launch writes (grid * WM)
 };
@@ -110,6 +111,12 @@ struct Geo {
 // 2 taps x 2 groups for CK = 8, 4 taps for CK = 4; steps beyond the 9 taps carry zero weights).  Tensors in HBM and
 // LDS stay float32; with 1/8 of the matrix-pipe time the kernel is bound by staging, LDS and HBM instead.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+// four bf16 values stored in 8 bytes -> float32 (exact)
+__device__ inline f32x4 bf16x4_to_f32(u32x2s p) {
+  return f32x4{__builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xffff0000u),
+               __builtin_bit_cast(float, p.y << 16), __builtin_bit_cast(float, p.y & 0xffff0000u)};
+}
 __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -267,6 +274,13 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
         const bool ok = (rel_r[i] >= ylo) & (rel_r[i] < yhi) & (rel_c[i] >= xlo) & (rel_c[i] < xhi);
         // out-of-image pixels read past the descriptor's range: the buffer unit returns zeros,
         // so the SAME padding costs no branch
+        if (BF16 && a.in_bf16) {  // uniform: the tensor is stored as bf16 (8 bytes per channel quad)
+          const int off = ok ? (base + off0[i]) * 2 : kOOB;
+#pragma unroll
+          for (int cg = 0; cg < G::NCG; ++cg)
+            st[i][cg] = bf16x4_to_f32(__builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs0, off, 8 * cg, 0)));
+          continue;
+        }
         const int off = ok ? (base + off0[i]) * 4 : kOOB;
 #pragma unroll
         for (int cg = 0; cg < G::NCG; ++cg)
@@ -283,6 +297,11 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       for (int cg = 0; cg < G::NCG; ++cg) {
         const int chan = ch * CK + cg * 4;  // uniform
         if (chan < a.C0) {
+          if (BF16 && a.in_bf16) {
+            const int off = ok ? (pbase * a.C0 + off0[i] + chan) * 2 : kOOB;
+            st[i][cg] = bf16x4_to_f32(__builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs0, off, 0, 0)));
+            continue;
+          }
           const int off = ok ? (pbase * a.C0 + off0[i] + chan) * 4 : kOOB;
           st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
           if (a.plane && chan == (a.plane_chan & ~3)) {  // uniform: the canvas lives in its own plane
@@ -294,6 +313,9 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
             st[i][cg].z = slot == 2 ? pv : st[i][cg].z;
             st[i][cg].w = slot == 3 ? pv : st[i][cg].w;
           }
+        } else if (BF16 && a.in_bf16) {
+          const int off = ok ? (pbase * a.C1 + off1[i] + chan - a.C0) * 2 : kOOB;
+          st[i][cg] = bf16x4_to_f32(__builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs1, off, 0, 0)));
         } else {
           const int off = ok ? (pbase * a.C1 + off1[i] + chan - a.C0) * 4 : kOOB;
           st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
@@ -382,6 +404,14 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       }
     }
   };
+  auto store1 = [&](float v, int elem_off_or_oob_bytes4) {  // one output value; the offset comes in float32 bytes (or kOOB)
+    if (BF16 && a.out_bf16) {
+      const bf16x4 pk4 = pack_bf16(v, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_raw_buffer_store_b16(pk4.x, rsy, elem_off_or_oob_bytes4 == kOOB ? kOOB : elem_off_or_oob_bytes4 >> 1, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, elem_off_or_oob_bytes4, 0, 0);
+    }
+  };
   const int opool = a.pool;  // 1 or 2
   const bool vec_ok = (a.Cout & 3) == 0;
   const float lo = a.relu ? 0.f : -__builtin_inff();  // ReLU as one v_max, no flag test per value
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
             const float o = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), lo);
             const bool ok = co_ok & ((row0 >> 1) < a.Ho) & ((col0 >> 1) < a.Wo);
             const int boff = ok ? (obase + (gy * a.Wo + 4 * gx) * a.Cout) * 4 : kOOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsy, boff, 0, 0);
+            store1(o, boff);
           }
         }
       } else {
@@ -425,7 +455,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
             for (int r = 0; r < 4; ++r) {
               const bool ok = co_ok & (row0 + (r >> 1) < a.Ho) & (col0 + (r & 1) < a.Wo);
               const int boff = ok ? (obase + ((2 * gy + (r >> 1)) * a.Wo + 8 * gx + (r & 1)) * a.Cout) * 4 : kOOB;
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsy, boff, 0, 0);
+              store1(v[r], boff);
             }
           }
         }
@@ -470,13 +500,18 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
         const bool ok = pool_lane & (prow < a.Ho) & (pcol < a.Wo);
         const int off = obase + ((2 / opool) * gy * a.Wo + (8 / opool) * gx) * a.Cout;
         if (vec_ok) {
-          const int boff = (ok & (co0 < a.Cout)) ? off * 4 : kOOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, boff, 0, 0);
+          if (BF16 && a.out_bf16) {  // four channels = 8 bytes (RNE, as the operand rounding)
+            const int boff = (ok & (co0 < a.Cout)) ? off * 2 : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, pack_bf16(v[0], v[1], v[2], v[3])), rsy, boff, 0, 0);
+          } else {
+            const int boff = (ok & (co0 < a.Cout)) ? off * 4 : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, boff, 0, 0);
+          }
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int boff = (ok & (co0 + r < a.Cout)) ? (off + r) * 4 : kOOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsy, boff, 0, 0);
+            store1(v[r], boff);
           }
         }
       }
@@ -724,13 +759,16 @@ extern "C" int ra_conv_fold_bn(const float *bias, const float *beta, const float
 static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws, int upsample,
                          const float *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool,
                          const float *plane, int plane_chan, float *y, void *stream, int bf16, float *mom_part = nullptr,
-                         int *nparts = nullptr) {
+                         int *nparts = nullptr, int store_flags = 0) {
   if (!src0 || !wpacked || !scale || !shift || !y || B <= 0 || Hs <= 0 || Ws <= 0 || C0 <= 0 ||
       C1 < 0 || (C1 > 0 && !src1))
     return ra::fail(RA_E_INVALID, "ra_conv3x3_f32: bad argument");
   if (C0 % 4 || C1 % 4) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: C0=%d C1=%d must be %% 4", C0, C1);
   ra::conv::Args a;
   a.bf16 = bf16;
+  a.in_bf16 = (bf16 && (store_flags & 1)) ? 1 : 0;
+  a.out_bf16 = (bf16 && (store_flags & 2)) ? 1 : 0;
+  if (store_flags && (!bf16 || plane)) return ra::fail(RA_E_INVALID, "ra_conv3x3_bf16_f32: bf16 storage needs the bf16-operand kernels, no canvas plane");
   a.mom_part = mom_part;
   a.nparts_out = nparts;
   a.src0 = src0;
@@ -756,8 +794,8 @@ static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, i
   a.Ho = a.H / pool;
   a.Wo = a.W / pool;
   {
-    const size_t n0 = (size_t)B * Hs * Ws * C0 * 4, n1 = (size_t)B * Hs * Ws * C1 * 4,
-                 ny = (size_t)B * a.Ho * a.Wo * Cout * 4;
+    const size_t n0 = (size_t)B * Hs * Ws * C0 * (a.in_bf16 ? 2 : 4), n1 = (size_t)B * Hs * Ws * C1 * (a.in_bf16 ? 2 : 4),
+                 ny = (size_t)B * a.Ho * a.Wo * Cout * (a.out_bf16 ? 2 : 4);
     if (n0 >= (1ull << 31) || n1 >= (1ull << 31) || ny >= (1ull << 31))
       return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: a tensor exceeds 2 GiB (32-bit buffer offsets)");
     a.bytes0 = (int)n0;
@@ -806,5 +844,20 @@ extern "C" int ra_conv3x3_bf16ops_f32(const float *src0, int C0, const float *sr
                                       int plane_chan, float *y, void *stream) {
   return conv3x3_entry(src0, C0, src1, C1, B, Hs, Ws, upsample, wpacked, scale, shift, Cout, relu, pool, plane,
                        plane_chan, y, stream, 1);
+}
+
+// The bf16 mode's layers between themselves (model_opt['compute_dtype'] = 'bf16', DESIGN.md "Mixed precision"): bf16
+// operands as ra_conv3x3_bf16ops_f32 / ra_conv3x3_moments_f32(bf16_operands = 1), and the tensors STORED as bf16 —
+// store_flags bit 0: src0 / src1 hold bf16 values (2 bytes each), bit 1: y is written as bf16 (round to nearest even; the
+// batch moments of `part` are taken from the float32 accumulators, before the rounding).  part = NULL: no moments (pool as
+// given); part != NULL: as ra_conv3x3_moments_f32 (pool 1, Cout % 4 == 0).
+extern "C" int ra_conv3x3_bf16_f32(const void *src0, int C0, const void *src1, int C1, int B, int Hs, int Ws, int upsample,
+                                   const float *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool,
+                                   void *y, float *part, size_t part_floats, int *nparts, int store_flags, void *stream) {
+  if (part && (!nparts || part_floats < ra_conv3x3_moments_part_floats(Cout)))
+    return ra::fail(RA_E_WORKSPACE, "ra_conv3x3_bf16_f32: partial buffer");
+  return conv3x3_entry(static_cast<const float *>(src0), C0, static_cast<const float *>(src1), C1, B, Hs, Ws, upsample, wpacked, scale,
+                       shift, Cout, relu, part ? 1 : pool, nullptr, -1, static_cast<float *>(y), stream, 1, part, part ? nparts : nullptr,
+                       store_flags);
 }
 #endif  // RA_K1_PART == 0

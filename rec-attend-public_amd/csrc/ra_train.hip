@@ -8,6 +8,8 @@
 // (grad_scale = 1 / world after the RCCL sum) folded in — one pass over five arrays, HBM-bound.
 // TF's Adam: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 //            p -= lr_t * m / (sqrt(v) + eps)        (epsilon outside the bias correction).
+#include <type_traits>
+
 #include "ra_common.h"
 
 namespace ra {
@@ -38,6 +40,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
 // Summation order is fixed (no atomics): bit-reproducible.
 struct BnConst {
   f32x4 mu, g, be, rstd;
+};
+// Storage of a channel quad: float32 (16 bytes) or, in the bf16 mode's tensors between the conv layers' passes
+// (model_opt['compute_dtype'] = 'bf16'), bf16 (8 bytes; loads are exact, stores round to nearest even as v_cvt_pk_bf16_f32).
+typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
+template <bool BF>
+struct Q4 {
+  typedef f32x4 T;
+  static __device__ inline f32x4 ld(const T *p, size_t i) { return p[i]; }
+  static __device__ inline void st(T *p, size_t i, const f32x4 v) { p[i] = v; }
+};
+template <>
+struct Q4<true> {
+  typedef u32x2q T;
+  static __device__ inline f32x4 ld(const T *p, size_t i) {
+    const u32x2q q = p[i];
+    return f32x4{__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
+                 __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xffff0000u)};
+  }
+  static __device__ inline void st(T *p, size_t i, const f32x4 v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    p[i] = u32x2q{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.x, v.y}, bf16x2)),
+                  __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.z, v.w}, bf16x2))};
+  }
 };
 __device__ inline BnConst bn_const(const float *mean, const float *var, const float *gamma, const float *beta, float eps,
                                    int c0) {
@@ -84,17 +110,18 @@ __global__ __launch_bounds__(256) void chan_sum_v4_kernel(const f32x4 *u, int n4
 }
 
 // the window of one thread: POOL x POOL pixels x 4 channels
-template <int POOL>
-__device__ inline void load_window(const f32x4 *u, int b, int yo, int xo, int H, int W, int C4, int cg, f32x4 (&w)[POOL * POOL]) {
+template <int POOL, bool UB = false>
+__device__ inline void load_window(const typename Q4<UB>::T *u, int b, int yo, int xo, int H, int W, int C4, int cg,
+                                   f32x4 (&w)[POOL * POOL]) {
 #pragma unroll
   for (int k = 0; k < POOL * POOL; ++k)
-    w[k] = u[((b * H + yo * POOL + (k / POOL)) * W + xo * POOL + (k % POOL)) * C4 + cg];
+    w[k] = Q4<UB>::ld(u, ((b * H + yo * POOL + (k / POOL)) * W + xo * POOL + (k % POOL)) * C4 + cg);
 }
 
-template <int POOL>
-__global__ __launch_bounds__(256) void bn_act_pool_v4_kernel(const f32x4 *u, const float *mean, const float *var,
+template <int POOL, bool UB = false, bool YB = false>
+__global__ __launch_bounds__(256) void bn_act_pool_v4_kernel(const typename Q4<UB>::T *u, const float *mean, const float *var,
                                                              const float *gamma, const float *beta, float eps, int relu,
-                                                             int B, int H, int W, int C4, int lg, f32x4 *y) {
+                                                             int B, int H, int W, int C4, int lg, typename Q4<YB>::T *y) {
   const int Ho = H / POOL, Wo = W / POOL;
   const int er = blockIdx.x * 256 + threadIdx.x;
   if (er >= Wo * C4) return;
@@ -104,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_v4_kernel(const f32x4 *u, con
   for (int row = blockIdx.y; row < B * Ho; row += gridDim.y) {
     const int b = row / Ho, yo = row - b * Ho;
     f32x4 w[POOL * POOL];
-    load_window<POOL>(u, b, yo, xo, H, W, C4, cg, w);
+    load_window<POOL, UB>(u, b, yo, xo, H, W, C4, cg, w);
     f32x4 best;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -113,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_v4_kernel(const f32x4 *u, con
       for (int q = 0; q < POOL * POOL; ++q) m = fmaxf(m, fmaxf((w[q][i] - k.mu[i]) * k.g[i] + k.be[i], lo));
       best[i] = m;
     }
-    y[(row * Wo + xo) * C4 + cg] = best;
+    Q4<YB>::st(y, (row * Wo + xo) * C4 + cg, best);
   }
 }
 
@@ -141,8 +168,8 @@ __device__ inline void window_grad(const f32x4 (&w)[POOL * POOL], const f32x4 dy
   }
 }
 
-template <int POOL>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const f32x4 *u, const f32x4 *dy, const float *mean,
+template <int POOL, bool UB = false, bool DB = false>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const typename Q4<UB>::T *u, const typename Q4<DB>::T *dy, const float *mean,
                                                                const float *var, const float *gamma, const float *beta,
                                                                float eps, int relu, int B, int H, int W, int C4, int lg,
                                                                float *part, const float *const *tabs = nullptr, int G = 1) {
@@ -165,8 +192,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const f32x4 *u, c
     for (int row = blockIdx.y; row < B * Ho; row += gridDim.y) {
       const int b = row / Ho, yo = row - b * Ho;
       f32x4 w[POOL * POOL], dv[POOL * POOL], xh[POOL * POOL];
-      load_window<POOL>(u, b, yo, xo, H, W, C4, cg, w);
-      window_grad<POOL>(w, dy[(row * Wo + xo) * C4 + cg], k, lo, relu, dv, xh);
+      load_window<POOL, UB>(u, b, yo, xo, H, W, C4, cg, w);
+      window_grad<POOL>(w, Q4<DB>::ld(dy, (row * Wo + xo) * C4 + cg), k, lo, relu, dv, xh);
 #pragma unroll
       for (int q = 0; q < POOL * POOL; ++q) {
         s0 += dv[q];
@@ -185,11 +212,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const f32x4 *u, c
   }
 }
 
-template <int POOL>
-__global__ __launch_bounds__(256) void bn_bwd_dx_v4_kernel(const f32x4 *u, const f32x4 *dy, const float *mean,
+template <int POOL, bool UB = false, bool DB = false>
+__global__ __launch_bounds__(256) void bn_bwd_dx_v4_kernel(const typename Q4<UB>::T *u, const typename Q4<DB>::T *dy, const float *mean,
                                                            const float *var, const float *gamma, const float *beta,
                                                            const float *dbeta, const float *dgamma, float eps, int relu,
-                                                           int B, int H, int W, int C4, int lg, f32x4 *du, float inv_n,
+                                                           int B, int H, int W, int C4, int lg, typename Q4<UB>::T *du, float inv_n,
                                                            const float *const *tabs = nullptr, int G = 1) {
   const int Ho = H / POOL, Wo = W / POOL;
   if (tabs) {
@@ -215,12 +242,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_v4_kernel(const f32x4 *u, const
   for (int row = blockIdx.y; row < B * Ho; row += gridDim.y) {
     const int b = row / Ho, yo = row - b * Ho;
     f32x4 w[POOL * POOL], dv[POOL * POOL], xh[POOL * POOL];
-    load_window<POOL>(u, b, yo, xo, H, W, C4, cg, w);
-    window_grad<POOL>(w, dy[(row * Wo + xo) * C4 + cg], k, lo, relu, dv, xh);
+    load_window<POOL, UB>(u, b, yo, xo, H, W, C4, cg, w);
+    window_grad<POOL>(w, Q4<DB>::ld(dy, (row * Wo + xo) * C4 + cg), k, lo, relu, dv, xh);
 #pragma unroll
     for (int q = 0; q < POOL * POOL; ++q) {
       const f32x4 r = var ? k.g * (dv[q] - db - xh[q] * dg) : dv[q];
-      du[((b * H + yo * POOL + (q / POOL)) * W + xo * POOL + (q % POOL)) * C4 + cg] = r;
+      Q4<UB>::st(du, ((b * H + yo * POOL + (q / POOL)) * W + xo * POOL + (q % POOL)) * C4 + cg, r);
     }
   }
 }
@@ -635,25 +662,52 @@ extern "C" int ra_bn_moments_from_partials_f32(const float *part, int nparts, in
   return launch_status("ra_bn_moments_from_partials_f32");
 }
 
-extern "C" int ra_bn_act_pool_f32(const float *u, const float *mean, const float *var, const float *gamma,
-                                  const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *y,
-                                  void *stream) {
+namespace {
+template <int POOL, bool UB, bool YB>
+void launch_bn_act_pool_v4(dim3 g4, hipStream_t st, const void *u, const float *mean, const float *var, const float *gamma,
+                           const float *beta, float eps, int relu, int B, int H, int W, int C4, int lg, void *y) {
+  hipLaunchKernelGGL((train::bn_act_pool_v4_kernel<POOL, UB, YB>), g4, dim3(256), 0, st,
+                     reinterpret_cast<const typename train::Q4<UB>::T *>(u), mean, var, gamma, beta, eps, relu, B, H, W, C4, lg,
+                     reinterpret_cast<typename train::Q4<YB>::T *>(y));
+}
+// flags: bit 0 = u is stored as bf16, bit 1 = y is written as bf16 (only combinations the bf16 mode produces: 0, 1, 3)
+int bn_act_pool_impl(const void *u, const float *mean, const float *var, const float *gamma, const float *beta, float eps, int relu,
+                     int pool, int B, int H, int W, int C, void *y, int flags, void *stream) {
   if (!u || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(RA_E_INVALID, "ra_bn_act_pool_f32: bad argument");
   if ((pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1))) return fail(RA_E_SHAPE, "ra_bn_act_pool_f32: pool");
   const size_t total = (size_t)B * (H / pool) * (W / pool) * C;
   if (const int lg = train::v4_log2(C, (size_t)B * H * W * C); lg >= 0) {
     const int C4 = C / 4, rows = B * (H / pool);
     const dim3 g4(ceil_div((W / pool) * C4, 256), rows < 16384 ? rows : 16384);
-    const train::f32x4 *u4 = reinterpret_cast<const train::f32x4 *>(u);
-    train::f32x4 *y4 = reinterpret_cast<train::f32x4 *>(y);
-    if (pool == 2)
-      hipLaunchKernelGGL(train::bn_act_pool_v4_kernel<2>, g4, dim3(256), 0, as_stream(stream), u4, mean, var, gamma, beta, eps,
-                         relu, B, H, W, C4, lg, y4);
-    else
-      hipLaunchKernelGGL(train::bn_act_pool_v4_kernel<1>, g4, dim3(256), 0, as_stream(stream), u4, mean, var, gamma, beta, eps,
-                         relu, B, H, W, C4, lg, y4);
+    hipStream_t st = as_stream(stream);
+#define RA_BNF(P, UB, YB) launch_bn_act_pool_v4<P, UB, YB>(g4, st, u, mean, var, gamma, beta, eps, relu, B, H, W, C4, lg, y)
+    if (flags == 0) { if (pool == 2) RA_BNF(2, false, false); else RA_BNF(1, false, false); }
+    else if (flags == 1) { if (pool == 2) RA_BNF(2, true, false); else RA_BNF(1, true, false); }
+    else if (flags == 3) { if (pool == 2) RA_BNF(2, true, true); else RA_BNF(1, true, true); }
+    else return fail(RA_E_INVALID, "ra_bn_act_pool_bf16_f32: flags %d", flags);
+#undef RA_BNF
     return launch_status("ra_bn_act_pool_f32");
   }
+  if (flags) return fail(RA_E_SHAPE, "ra_bn_act_pool_bf16_f32: bf16 storage needs C %% 4 == 0 with C / 4 a power of two (C %d)", C);
+  return -1000;  // the generic float32 kernel (the caller below)
+}
+}  // namespace
+
+extern "C" int ra_bn_act_pool_bf16_f32(const void *u, const float *mean, const float *var, const float *gamma, const float *beta,
+                                       float eps, int relu, int pool, int B, int H, int W, int C, void *y, int flags, void *stream) {
+  const int rc = bn_act_pool_impl(u, mean, var, gamma, beta, eps, relu, pool, B, H, W, C, y, flags, stream);
+  if (rc != -1000) return rc;
+  return ra_bn_act_pool_f32(static_cast<const float *>(u), mean, var, gamma, beta, eps, relu, pool, B, H, W, C, static_cast<float *>(y), stream);
+}
+
+extern "C" int ra_bn_act_pool_f32(const float *u, const float *mean, const float *var, const float *gamma,
+                                  const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *y,
+                                  void *stream) {
+  {
+    const int rc = bn_act_pool_impl(u, mean, var, gamma, beta, eps, relu, pool, B, H, W, C, y, 0, stream);
+    if (rc != -1000) return rc;
+  }
+  const size_t total = (size_t)B * (H / pool) * (W / pool) * C;
   size_t grid = (total + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(train::bn_act_pool_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), u, mean, var, gamma,
@@ -665,10 +719,42 @@ namespace {
 // stages: 1 = the two reductions (dbeta, dgamma over THIS call's pixels), 2 = du from dbeta / dgamma and the count
 // they were summed over (n_total; 0 = this call's B*H*W).  Data-parallel training with whole-batch statistics
 // runs stage 1, all-reduces the 2C sums, then stage 2 with the global count (ra_train.ConvBNActPool).
+// the v4 kernels of one (or G stacked) BatchNorm backward call(s), for one storage format (UB: u and du bf16, DB: dy bf16)
+template <int POOL, bool UB, bool DB>
+void launch_bn_bwd_v4(int stages, dim3 gr, dim3 gd, hipStream_t st, const void *u, const void *dy, const float *mean, const float *var,
+                      const float *gamma, const float *beta, float eps, int relu, int B, int H, int W, int C, int C4, int lg, float *ws,
+                      int nblk, float *dbeta, float *dgamma, float *acc_beta, float *acc_gamma, void *du, float inv_n,
+                      const float *const *ct = nullptr, float *const *mt = nullptr, int G = 1) {
+  typedef typename train::Q4<UB>::T TU;
+  typedef typename train::Q4<DB>::T TD;
+  const TU *u4 = reinterpret_cast<const TU *>(u);
+  const TD *dy4 = reinterpret_cast<const TD *>(dy);
+  if (stages & 1) {
+    hipLaunchKernelGGL((train::bn_bwd_reduce_v4_kernel<POOL, UB, DB>), gr, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, eps, relu, B,
+                       H, W, C4, lg, ws, ct, G);
+    if (ct)
+      hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C, G), dim3(256), 0, st, ws, nblk, C, dbeta, dgamma, (float *)nullptr,
+                         (float *)nullptr, mt, G);
+    else
+      hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, nblk, C, dbeta, dgamma, acc_beta, acc_gamma);
+  }
+  if (stages & 2)
+    hipLaunchKernelGGL((train::bn_bwd_dx_v4_kernel<POOL, UB, DB>), gd, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, dbeta, dgamma,
+                       eps, relu, B, H, W, C4, lg, reinterpret_cast<TU *>(du), inv_n, ct, G);
+}
+template <typename... A>
+int dispatch_bn_bwd_v4(int pool, int flags, A... a) {
+  if (flags == 0) { if (pool == 2) launch_bn_bwd_v4<2, false, false>(a...); else launch_bn_bwd_v4<1, false, false>(a...); }
+  else if (flags == 1) { if (pool == 2) launch_bn_bwd_v4<2, true, false>(a...); else launch_bn_bwd_v4<1, true, false>(a...); }
+  else if (flags == 3) { if (pool == 2) launch_bn_bwd_v4<2, true, true>(a...); else launch_bn_bwd_v4<1, true, true>(a...); }
+  else return fail(RA_E_INVALID, "ra_bn_act_pool_bwd: storage flags %d", flags);
+  return 0;
+}
+
 int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float *var, const float *gamma,
                 const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *ws,
                 size_t ws_floats, float *dgamma, float *dbeta, float *du, float *acc_gamma, float *acc_beta,
-                void *stream, int stages = 3, double n_total = 0.0) {
+                void *stream, int stages = 3, double n_total = 0.0, int flags = 0) {
   if (!u || !dy || !dgamma || !dbeta || ((stages & 1) && !ws) || ((stages & 2) && !du) || B <= 0 || H <= 0 || W <= 0 || C <= 0)
     return fail(RA_E_INVALID, "ra_bn_act_pool_bwd_f32: bad argument");
   if (C > 256) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_f32: C %d > 256", C);
@@ -681,28 +767,14 @@ int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float 
     const int C4 = C / 4, rows = B * (H / pool), gx = ceil_div((W / pool) * C4, 256);
     int gy = train::kRedBlocks / gx;
     if (gy > rows) gy = rows;
-    const train::f32x4 *u4 = reinterpret_cast<const train::f32x4 *>(u), *dy4 = reinterpret_cast<const train::f32x4 *>(dy);
-    train::f32x4 *du4 = reinterpret_cast<train::f32x4 *>(du);
     const dim3 gr(gx, gy), gd(gx, rows < 16384 ? rows : 16384);
-    if (stages & 1) {
-      if (pool == 2)
-        hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<2>, gr, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, eps, relu, B, H,
-                           W, C4, lg, ws);
-      else
-        hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<1>, gr, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, eps, relu, B, H,
-                           W, C4, lg, ws);
-      hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C), dim3(256), 0, st, ws, gx * gy, C, dbeta, dgamma, acc_beta, acc_gamma);
-    }
-    if (stages & 2) {
-      if (pool == 2)
-        hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<2>, gd, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, dbeta, dgamma, eps,
-                           relu, B, H, W, C4, lg, du4, inv_n);
-      else
-        hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<1>, gd, dim3(256), 0, st, u4, dy4, mean, var, gamma, beta, dbeta, dgamma, eps,
-                           relu, B, H, W, C4, lg, du4, inv_n);
-    }
+    if (const int rc = dispatch_bn_bwd_v4(pool, flags, stages, gr, gd, st, (const void *)u, (const void *)dy, mean, var, gamma, beta, eps, relu,
+                                          B, H, W, C, C4, lg, ws, gx * gy, dbeta, dgamma, acc_beta, acc_gamma, (void *)du, inv_n,
+                                          (const float *const *)nullptr, (float *const *)nullptr, 1))
+      return rc;
     return launch_status("ra_bn_act_pool_bwd_f32");
   }
+  if (flags) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd: bf16 storage needs C %% 4 == 0 with C / 4 a power of two (C %d)", C);
   const int lanes = 256 / C;
   int nb = (int)((npix + lanes - 1) / lanes);
   if (nb > train::kRedBlocks) nb = train::kRedBlocks;
@@ -724,9 +796,9 @@ int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float 
 // G calls of one BatchNorm layer (its G timesteps) stacked along the batch — u [G*B,H,W,C], dy [G*B,H/pool,W/pool,C] — in
 // one reduce / final / dx triple: every group has its own statistics and parameters, read through a device table of
 // 6 G pointers {mean, var, gamma, beta, grad-bucket gamma, grad-bucket beta}[G]; dgamma / dbeta [G,C].
-extern "C" int ra_bn_act_pool_bwd_grouped_f32(const float *u, const float *dy, const void *const *tabs, int G, float eps, int relu,
-                                              int pool, int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
-                                              float *dbeta, float *du, void *stream) {
+static int bn_bwd_grouped_impl(const void *u, const void *dy, const void *const *tabs, int G, float eps, int relu, int pool, int B,
+                               int H, int W, int C, float *ws, size_t ws_floats, float *dgamma, float *dbeta, void *du, int flags,
+                               void *stream) {
   if (!u || !dy || !tabs || !ws || !dgamma || !dbeta || !du || G <= 0 || B <= 0 || H <= 0 || W <= 0 || C <= 0)
     return fail(RA_E_INVALID, "ra_bn_act_pool_bwd_grouped_f32: bad argument");
   if ((pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1))) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_grouped_f32: pool");
@@ -740,22 +812,36 @@ extern "C" int ra_bn_act_pool_bwd_grouped_f32(const float *u, const float *dy, c
   const int C4 = C / 4, rows = B * (H / pool), gx = ceil_div((W / pool) * C4, 256);
   int gy = train::kRedBlocks / gx;
   if (gy > rows) gy = rows;
-  const train::f32x4 *u4 = reinterpret_cast<const train::f32x4 *>(u), *dy4 = reinterpret_cast<const train::f32x4 *>(dy);
-  train::f32x4 *du4 = reinterpret_cast<train::f32x4 *>(du);
   const float *const *ct = reinterpret_cast<const float *const *>(tabs);
   float *const *mt = reinterpret_cast<float *const *>(const_cast<void *const *>(tabs));
   const dim3 gr(gx, gy, G), gd(gx, rows < 16384 ? rows : 16384, G);
   const float *nul = nullptr;
-  if (pool == 2) {
-    hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<2>, gr, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, eps, relu, B, H, W, C4, lg, ws, ct, G);
-    hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C, G), dim3(256), 0, st, ws, gx * gy, C, dbeta, dgamma, (float *)nullptr, (float *)nullptr, mt, G);
-    hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<2>, gd, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, dbeta, dgamma, eps, relu, B, H, W, C4, lg, du4, inv_n, ct, G);
-  } else {
-    hipLaunchKernelGGL(train::bn_bwd_reduce_v4_kernel<1>, gr, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, eps, relu, B, H, W, C4, lg, ws, ct, G);
-    hipLaunchKernelGGL(train::bn_bwd_final_kernel, dim3(C, G), dim3(256), 0, st, ws, gx * gy, C, dbeta, dgamma, (float *)nullptr, (float *)nullptr, mt, G);
-    hipLaunchKernelGGL(train::bn_bwd_dx_v4_kernel<1>, gd, dim3(256), 0, st, u4, dy4, nul, nul, nul, nul, dbeta, dgamma, eps, relu, B, H, W, C4, lg, du4, inv_n, ct, G);
-  }
+  if (const int rc = dispatch_bn_bwd_v4(pool, flags, 3, gr, gd, st, u, dy, nul, nul, nul, nul, eps, relu, B, H, W, C, C4, lg, ws, gx * gy,
+                                        dbeta, dgamma, (float *)nullptr, (float *)nullptr, du, inv_n, ct, mt, G))
+    return rc;
   return launch_status("ra_bn_act_pool_bwd_grouped_f32");
+}
+
+extern "C" int ra_bn_act_pool_bwd_grouped_f32(const float *u, const float *dy, const void *const *tabs, int G, float eps, int relu,
+                                              int pool, int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
+                                              float *dbeta, float *du, void *stream) {
+  return bn_bwd_grouped_impl(u, dy, tabs, G, eps, relu, pool, B, H, W, C, ws, ws_floats, dgamma, dbeta, du, 0, stream);
+}
+
+// The bf16 mode's forms (model_opt['compute_dtype'] = 'bf16'): flags bit 0 = u is read and du written as bf16, bit 1 = dy is
+// read as bf16 (0, 1 or 3); float32 statistics, sums and parameter gradients.
+extern "C" int ra_bn_act_pool_bwd_grouped_bf16_f32(const void *u, const void *dy, const void *const *tabs, int G, float eps, int relu,
+                                                   int pool, int B, int H, int W, int C, float *ws, size_t ws_floats, float *dgamma,
+                                                   float *dbeta, void *du, int flags, void *stream) {
+  return bn_bwd_grouped_impl(u, dy, tabs, G, eps, relu, pool, B, H, W, C, ws, ws_floats, dgamma, dbeta, du, flags, stream);
+}
+
+extern "C" int ra_bn_act_pool_bwd_acc_bf16_f32(const void *u, const void *dy, const float *mean, const float *var, const float *gamma,
+                                               const float *beta, float eps, int relu, int pool, int B, int H, int W, int C, float *ws,
+                                               size_t ws_floats, float *dgamma, float *dbeta, void *du, float *acc_gamma,
+                                               float *acc_beta, int flags, void *stream) {
+  return bn_bwd_impl(static_cast<const float *>(u), static_cast<const float *>(dy), mean, var, gamma, beta, eps, relu, pool, B, H, W, C, ws,
+                     ws_floats, dgamma, dbeta, static_cast<float *>(du), acc_gamma, acc_beta, stream, 3, 0.0, flags);
 }
 
 extern "C" int ra_bn_act_pool_bwd_f32(const float *u, const float *dy, const float *mean, const float *var,
@@ -857,11 +943,27 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
 // PRE (Cout % 4 == 0, NT <= 2): the NEXT tile's global loads are issued into registers before the MFMA loop of the
 // current one and written to LDS after it (one staging buffer, two barriers per tile as before): the loads' latency
 // and the HBM stream hide behind the matrix work instead of in front of it.
+// four consecutive elements at element offset `off` of a tensor stored as float32 or (bf: the bf16 mode's storage) bf16
+__device__ inline f32x4 ld4_fmt(const float *base, size_t off, bool bf) {
+  if (bf) {
+    const u32x2q q = *reinterpret_cast<const u32x2q *>(reinterpret_cast<const char *>(base) + off * 2);
+    return f32x4{__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
+                 __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xffff0000u)};
+  }
+  return *reinterpret_cast<const f32x4 *>(base + off);
+}
+
+__device__ inline float ld1_fmt(const float *base, size_t off, bool bf) {
+  if (bf) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(base)[off] << 16);
+  return base[off];
+}
 template <int NT, int PACK = 0, bool BF16 = false, bool PRE = false>  // NT: output channels per workgroup / 16; blockIdx.z selects a 16*NT-wide slice of Cout
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float *du, int B, int Hs, int Ws, int Cin,
                                                     int ups, int H, int W, int Cout, int tiles_x, int tiles_y,
                                                     int ntiles, float *part, const float *const *xtab,
-                                                    const float *const *dutab, int Bseg) {
+                                                    const float *const *dutab, int Bseg, int fmt) {
+  // fmt (BF16 kernels only): bit 0 = x is stored as bf16, bit 1 = du is stored as bf16
+  const bool xbf = BF16 && (fmt & 1), ubf = BF16 && (fmt & 2);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tx = lds;                      // [WLH][WLW][16]   input slice + halo, channel-contiguous
   float *tu = lds + WLH * WLW * 16;     // [WTH][WTW][16*NT] output gradient tile
@@ -909,34 +1011,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
       b -= seg * Bseg;
     }
     const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
+    auto load_x = [&](auto bf) {  // the storage format is uniform: ONE test around the whole unrolled loop
 #pragma unroll
-    for (int i = 0; i < NRX; ++i) {
-      const int e = tid + 256 * i;
-      const int pix = e / ng, c4 = e - pix * ng;
-      const int r = pix / WLW, c = pix - r * WLW;
-      const int Y = ty0 + r - 1, X = tx0 + c - 1;
-      bool ok = (e < WLH * WLW * ng) & (Y >= 0) & (Y < H) & (X >= 0) & (X < W);
-      int ys = Y, xs = X;
-      if (ups) {
-        ok = ok & (Y & 1) & (X & 1);
-        ys = (Y - 1) >> 1;
-        xs = (X - 1) >> 1;
+      for (int i = 0; i < NRX; ++i) {
+        const int e = tid + 256 * i;
+        const int pix = e / ng, c4 = e - pix * ng;
+        const int r = pix / WLW, c = pix - r * WLW;
+        const int Y = ty0 + r - 1, X = tx0 + c - 1;
+        bool ok = (e < WLH * WLW * ng) & (Y >= 0) & (Y < H) & (X >= 0) & (X < W);
+        int ys = Y, xs = X;
+        if (ups) {
+          ok = ok & (Y & 1) & (X & 1);
+          ys = (Y - 1) >> 1;
+          xs = (X - 1) >> 1;
+        }
+        const size_t off = ok ? (((size_t)b * Hs + ys) * Ws + xs) * Cin + c0 + 4 * c4 : 0;
+        const f32x4 v = ld4_fmt(xb, off, decltype(bf)::value);
+        rx[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const size_t off = ok ? (((size_t)b * Hs + ys) * Ws + xs) * Cin + c0 + 4 * c4 : 0;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + off);
-      rx[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    };
+    auto load_u = [&](auto bf) {
 #pragma unroll
-    for (int i = 0; i < NRU; ++i) {
-      const int e = tid + 256 * i;
-      const int c4 = e % (CP / 4), pix = e / (CP / 4);
-      const int r = pix / WTW, c = pix - r * WTW;
-      const int Y = ty0 + r, X = tx0 + c;
-      const bool ok = (Y < H) & (X < W) & (co0 + 4 * c4 < Cout);
-      const size_t off = ok ? (((size_t)b * H + Y) * W + X) * Cout + co0 + 4 * c4 : 0;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(ub + off);
-      ru[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+      for (int i = 0; i < NRU; ++i) {
+        const int e = tid + 256 * i;
+        const int c4 = e % (CP / 4), pix = e / (CP / 4);
+        const int r = pix / WTW, c = pix - r * WTW;
+        const int Y = ty0 + r, X = tx0 + c;
+        const bool ok = (Y < H) & (X < W) & (co0 + 4 * c4 < Cout);
+        const size_t off = ok ? (((size_t)b * H + Y) * W + X) * Cout + co0 + 4 * c4 : 0;
+        const f32x4 v = ld4_fmt(ub, off, decltype(bf)::value);
+        ru[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    if (xbf) load_x(std::true_type{}); else load_x(std::false_type{});
+    if (ubf) load_u(std::true_type{}); else load_u(std::false_type{});
   };
   auto commit = [&]() {  // the prefetched tile -> LDS
 #pragma unroll
@@ -983,7 +1091,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
         xs = (X - 1) >> 1;
       }
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4 *>(x + (((size_t)b * Hs + ys) * Ws + xs) * Cin + c0 + 4 * c4);
+      if (ok) v = ld4_fmt(x, (((size_t)b * Hs + ys) * Ws + xs) * Cin + c0 + 4 * c4, xbf);
       *reinterpret_cast<f32x4 *>(tx + pix * 16 + 4 * c4) = v;
     }
     if (vec_du) {
@@ -993,7 +1101,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
         const int Y = ty0 + r, X = tx0 + c;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (Y < H && X < W && co0 + 4 * c4 < Cout)
-          v = *reinterpret_cast<const f32x4 *>(du + (((size_t)b * H + Y) * W + X) * Cout + co0 + 4 * c4);
+          v = ld4_fmt(du, (((size_t)b * H + Y) * W + X) * Cout + co0 + 4 * c4, ubf);
         *reinterpret_cast<f32x4 *>(tu + pix * CP + 4 * c4) = v;
       }
     } else {
@@ -1002,7 +1110,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
         const int r = pix / WTW, c = pix - r * WTW;
         const int Y = ty0 + r, X = tx0 + c;
         float v = 0.f;
-        if (Y < H && X < W && co0 + co < Cout) v = du[(((size_t)b * H + Y) * W + X) * Cout + co0 + co];
+        if (Y < H && X < W && co0 + co < Cout) v = ld1_fmt(du, (((size_t)b * H + Y) * W + X) * Cout + co0 + co, ubf);
         tu[e] = v;
       }
     }
@@ -1399,7 +1507,8 @@ namespace {
 int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du, int Cout, float *ws,
                size_t ws_floats, float *dw, float *db, bool acc, const int *chan_map, int cin_w, int transposed,
                void *stream, bool bf16 = false, const float *const *xtab = nullptr, const float *const *dutab = nullptr,
-               int Bseg = 0) {
+               int Bseg = 0, int fmt = 0) {
+  if (fmt && !bf16) return fail(RA_E_INVALID, "ra_conv3x3_wgrad: bf16 storage needs the bf16-operand kernels");
   if (xtab) x = du = reinterpret_cast<const float *>(xtab);  // (not read: the tables are)
   if (!x || !du || !ws || !dw || B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0)
     return fail(RA_E_INVALID, "ra_conv3x3_wgrad_f32: bad argument");
@@ -1425,7 +1534,7 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
       attr = true;                                                                                                \
     }                                                                                                             \
     hipLaunchKernelGGL((wgrad_kernel<NT, PACK, BF, PRE>), dim3(gx, chunks, slices), dim3(256), lds, st, x, du, B, Hs, Ws, Cin, \
-                       ups, H, W, Cout, tiles_x, tiles_y, ntiles, ws, xtab, dutab, Bseg);                        \
+                       ups, H, W, Cout, tiles_x, tiles_y, ntiles, ws, xtab, dutab, Bseg, fmt);                   \
   }
 #define RA_WGRAD_P(NT, PACK, BF)                                                                                  \
   {                                                                                                               \
@@ -1511,6 +1620,15 @@ extern "C" int ra_conv3x3_wgrad_acc_bf16ops_f32(const float *x, int Cin, int B, 
                     stream, true);
 }
 
+// ... and with the tensors stored as bf16 (the bf16 mode's layers between themselves): fmt bit 0 = x, bit 1 = du
+extern "C" int ra_conv3x3_wgrad_acc_bf16_f32(const void *x, int Cin, int B, int Hs, int Ws, int upsample, const void *du, int Cout,
+                                             float *ws, size_t ws_floats, const int *chan_map, int cin_w, int transposed, float *gw,
+                                             float *gb, int fmt, void *stream) {
+  if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_acc_bf16_f32: cin_w %d", cin_w);
+  return wgrad_impl(static_cast<const float *>(x), Cin, B, Hs, Ws, upsample, static_cast<const float *>(du), Cout, ws, ws_floats, gw, gb,
+                    true, chan_map, cin_w, transposed ? 1 : 0, stream, true, nullptr, nullptr, 0, fmt & 3);
+}
+
 namespace ra {
 namespace train {
 struct PtrTable {
@@ -1537,6 +1655,7 @@ extern "C" int ra_ptr_table(const void *const *host_ptrs, int n, void **dev_tabl
 
 // The filter gradient of a layer over the images of SEVERAL calls (its T timesteps in a training step) in one pass:
 // xtab / dutab are device tables of nseg pointers to the calls' x [Bseg,Hs,Ws,Cin] and du [Bseg,H,W,Cout].
+// bf16_operands: bit 0 = bf16 operands on the bf16 MFMA; with it, bit 1 = the x tensors are stored as bf16, bit 2 = the du tensors.
 extern "C" int ra_conv3x3_wgrad_multi_acc_f32(const void *const *xtab, const void *const *dutab, int nseg, int Cin, int Bseg,
                                               int Hs, int Ws, int upsample, int Cout, float *ws, size_t ws_floats,
                                               const int *chan_map, int cin_w, int transposed, float *gw, float *gb,
@@ -1544,8 +1663,8 @@ extern "C" int ra_conv3x3_wgrad_multi_acc_f32(const void *const *xtab, const voi
   if (!xtab || !dutab || nseg <= 0 || Bseg <= 0) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_multi_acc_f32: bad argument");
   if (cin_w <= 0 || (!chan_map && cin_w > Cin)) return fail(RA_E_INVALID, "ra_conv3x3_wgrad_multi_acc_f32: cin_w %d", cin_w);
   return wgrad_impl(nullptr, Cin, nseg * Bseg, Hs, Ws, upsample, nullptr, Cout, ws, ws_floats, gw, gb, true, chan_map, cin_w,
-                    transposed ? 1 : 0, stream, bf16_operands != 0, reinterpret_cast<const float *const *>(xtab),
-                    reinterpret_cast<const float *const *>(dutab), Bseg);
+                    transposed ? 1 : 0, stream, (bf16_operands & 1) != 0, reinterpret_cast<const float *const *>(xtab),
+                    reinterpret_cast<const float *const *>(dutab), Bseg, (bf16_operands >> 1) & 3);
 }
 
 extern "C" int ra_lstm_cell_f32(const float *pre, const float *c_prev, int B, int hid, float *h, float *c, float *act,

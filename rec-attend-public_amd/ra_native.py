@@ -45,6 +45,11 @@ SIGNATURES = {
     'ra_last_error_string': (C.c_char_p, []),
     'ra_debug_poison_lds': (_I, [_P]),
     'ra_gather_f32': (_I, [_P, _P, _Z, _P, _P]),
+    'ra_conv3x3_bf16_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P, _I, _P]),
+    'ra_bn_act_pool_bf16_f32': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    'ra_bn_act_pool_bwd_acc_bf16_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _I, _P]),
+    'ra_bn_act_pool_bwd_grouped_bf16_f32': (_I, [_P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _I, _P]),
+    'ra_conv3x3_wgrad_acc_bf16_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P, _I, _I, _P, _P, _I, _P]),
     'ra_colour_jitter_workspace_floats': (_Z, [_I]),
     'ra_colour_jitter_f32': (_I, [_P, _I, _I, _F, _F, _F, _F, _P, _Z, _P, _P]),
     'ra_hungarian_f32': (_I, [_P, _I, _I, _I, _P, _P, _P]),

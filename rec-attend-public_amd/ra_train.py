@@ -371,6 +371,36 @@ class ConvBNActPool(torch.autograd.Function):
     alloc = meta.get('alloc')  # the batched-backward step keeps u / y of a layer's T calls in one [T, ...] slab
     place = (lambda kind, *shape: alloc(kind, shape)) if alloc is not None else (lambda kind, *shape: _f(*shape, device=dev))
     up = 2 if stride == 2 else 1
+    if meta.get('bf16_store') and alloc is not None and use_bn and not meta.get('sync_bn'):
+      # bf16 mode, stacked step: u and y live in HBM as bf16 where the float4 BatchNorm kernels take the channel count (else
+      # float32; y also float32 where a float32 kernel reads it next: meta['y_f32']); the statistics come from the conv's
+      # float32 accumulators, before the rounding.  Forward only: the stacked graph's nodes hold the backward.
+      assert bf and not torch.is_grad_enabled()
+      st_ok = cout % 4 == 0 and (cout // 4) & (cout // 4 - 1) == 0 and cout // 4 <= 64 and EPILOGUE_MOMENTS['on']
+      ud = torch.bfloat16 if st_ok else torch.float32
+      yd = torch.bfloat16 if (st_ok and not meta.get('y_f32')) else torch.float32
+      u = alloc('u', (B, Hs * up, Ws * up, cout), ud)
+      H, W = u.shape[1], u.shape[2]
+      xin = 1 if x.dtype == torch.bfloat16 else 0
+      if cout % 4 == 0 and EPILOGUE_MOMENTS['on']:
+        part = _f(rn.lib().ra_conv3x3_moments_part_floats(cout), device=dev)
+        nparts = _C.c_int(0)
+        check(rn.lib().ra_conv3x3_bf16_f32(ptr(x), Cx, None, 0, B, Hs, Ws, int(stride == 2), ptr(wp), ptr(scale), ptr(shift), cout, 0, 1,
+                                           ptr(u), ptr(part), part.numel(), _C.byref(nparts), xin | (2 if st_ok else 0),
+                                           rn.stream_ptr()), 'ra_conv3x3_bf16_f32')
+        check(rn.lib().ra_bn_moments_from_partials_f32(ptr(part), nparts.value, cout, ptr(mean), ptr(var), rn.stream_ptr()),
+              'ra_bn_moments_from_partials_f32')
+      else:  # a channel count without epilogue moments (the one-channel output layer): float32 u, two-pass moments
+        check(rn.lib().ra_conv3x3_bf16_f32(ptr(x), Cx, None, 0, B, Hs, Ws, int(stride == 2), ptr(wp), ptr(scale), ptr(shift), cout, 0, 1,
+                                           ptr(u), None, 0, None, xin, rn.stream_ptr()), 'ra_conv3x3_bf16_f32')
+        ws = _f(rn.lib().ra_bn_workspace_floats(cout), device=dev)
+        check(rn.lib().ra_bn_moments_f32(ptr(u), B * H * W, cout, ptr(ws), ws.numel(), ptr(mean), ptr(var), rn.stream_ptr()),
+              'ra_bn_moments_f32')
+      y = alloc('y', (B, H // pool, W // pool, cout), yd)
+      check(rn.lib().ra_bn_act_pool_bf16_f32(ptr(u), ptr(mean), ptr(var), ptr(gamma), ptr(beta), _C.c_float(BN_EPS), int(relu), int(pool),
+                                             B, H, W, cout, ptr(y), (1 if st_ok else 0) | (2 if yd == torch.bfloat16 else 0),
+                                             rn.stream_ptr()), 'ra_bn_act_pool_bf16_f32')
+      return y, mean, var
     if use_bn and cout % 4 == 0 and EPILOGUE_MOMENTS['on']:
       # the batch moments ride on the conv epilogue: per-wave channel sums, then one small finishing launch
       u = place('u', B, Hs * up, Ws * up, cout)
@@ -528,9 +558,12 @@ class ConvBNActPool(torch.autograd.Function):
     return dx, dw, db, (dgamma if use_bn else None), (dbeta if use_bn else None), None
 
 
-def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf):
-  """Backward-data of ConvBNActPool's conv: the same MFMA conv kernel on the flipped / in-out-swapped packing."""
+def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf, out_dtype=torch.float32):
+  """Backward-data of ConvBNActPool's conv: the same MFMA conv kernel on the flipped / in-out-swapped packing.  In the bf16
+  mode's stacked step du may be stored as bf16 and the result takes the input tensor's storage type (out_dtype)."""
   dev = du.device
+  if du.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
+    return _conv_dgrad_bf16(du, w, tr, stride, cmap, x_shape, cin_w, cache, out_dtype)
   B, Hs, Ws, Cx = x_shape
   cout = du.shape[3]
   duc = _pad_channels(du)
@@ -552,6 +585,43 @@ def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf):
     return dx
   if Cx != cin_w:
     dx = torch.zeros((B, Hs, Ws, Cx), dtype=torch.float32, device=dev)
+    dx[..., :cin_w] = dxr
+    return dx
+  return dxr
+
+
+def _conv_dgrad_bf16(du, w, tr, stride, cmap, x_shape, cin_w, cache, out_dtype):
+  dev = du.device
+  B, Hs, Ws, Cx = x_shape
+  cout = du.shape[3]
+  assert cout % 4 == 0 or du.dtype == torch.float32  # bf16 du exists only behind the float4 BatchNorm kernels
+  duc = _pad_channels(du)
+  cd = duc.shape[3]
+  cpb = ops.cout_padded(cin_w)
+  ones = _const('ones', cpb, dev, lambda: torch.ones(cpb, dtype=torch.float32, device=dev))
+  zeros = _const('zeros', cpb, dev, lambda: torch.zeros(cpb, dtype=torch.float32, device=dev))
+  wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr, cache)
+  H, W = du.shape[1], du.shape[2]
+  dxr = torch.empty((B, H, W, cin_w), dtype=out_dtype, device=dev)
+  flags = (1 if du.dtype == torch.bfloat16 else 0) | (2 if out_dtype == torch.bfloat16 else 0)
+  check(rn.lib().ra_conv3x3_bf16_f32(ptr(duc), cd, None, 0, B, H, W, 0, ptr(wpb), ptr(ones), ptr(zeros), cin_w, 0, 1, ptr(dxr), None, 0,
+                                     None, flags, rn.stream_ptr()), 'ra_conv3x3_bf16_f32')
+  if stride == 2:  # the transposed conv's stride: keep the odd positions (whole pixels: the element type does not matter)
+    sub = torch.empty((B, Hs, Ws, cin_w), dtype=out_dtype, device=dev)
+    if out_dtype == torch.bfloat16:
+      assert cin_w % 2 == 0
+      check(rn.lib().ra_subsample_odd_f32(ptr(dxr), B, Hs, Ws, cin_w // 2, ptr(sub), rn.stream_ptr()), 'ra_subsample_odd_f32')
+    else:
+      check(rn.lib().ra_subsample_odd_f32(ptr(dxr), B, Hs, Ws, cin_w, ptr(sub), rn.stream_ptr()), 'ra_subsample_odd_f32')
+    dxr = sub
+  if cmap is not None:
+    dx = torch.zeros((B, Hs, Ws, Cx), dtype=out_dtype, device=dev)
+    for c, j in enumerate(cmap):
+      if j >= 0:
+        dx[..., c] = dxr[..., j]
+    return dx
+  if Cx != cin_w:
+    dx = torch.zeros((B, Hs, Ws, Cx), dtype=out_dtype, device=dev)
     dx[..., :cin_w] = dxr
     return dx
   return dxr
@@ -627,11 +697,17 @@ class ConvStackFn(torch.autograd.Function):
       du = stack_bn_dx(info, U, dY, sums, float(info['sync_world']) * B * H * W)
     else:
       du, rc = torch.empty_like(U), rn.RA_E_SHAPE
+      sflags = (1 if U.dtype == torch.bfloat16 else 0) | (2 if dY.dtype == torch.bfloat16 else 0)  # the bf16 mode's storage
       if cout % 4 == 0:
         dgam, dbet, ws = _f(G, cout, device=dev), _f(G, cout, device=dev), _f(G * nbn, device=dev)
-        rc = rn.lib().ra_bn_act_pool_bwd_grouped_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu), int(pool),
-                                                     B, H, W, cout, ptr(ws), ws.numel(), ptr(dgam), ptr(dbet), ptr(du), rn.stream_ptr())
-        if rc != rn.RA_E_SHAPE:
+        if sflags:
+          rc = rn.lib().ra_bn_act_pool_bwd_grouped_bf16_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu),
+                                                            int(pool), B, H, W, cout, ptr(ws), ws.numel(), ptr(dgam), ptr(dbet), ptr(du),
+                                                            sflags, rn.stream_ptr())
+        else:
+          rc = rn.lib().ra_bn_act_pool_bwd_grouped_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu), int(pool),
+                                                       B, H, W, cout, ptr(ws), ws.numel(), ptr(dgam), ptr(dbet), ptr(du), rn.stream_ptr())
+        if rc != rn.RA_E_SHAPE or sflags:
           check(rc, 'ra_bn_act_pool_bwd_grouped_f32')
     if info.get('sync_world', 1) <= 1 and rc == rn.RA_E_SHAPE:
       # a channel count the grouped float4 kernel does not take (the one-channel output layer; C / 4 not a power of two,
@@ -648,10 +724,15 @@ class ConvStackFn(torch.autograd.Function):
     wws = info['cache'].get(('wgrad_ws', nws))
     if wws is None:
       wws = info['cache'][('wgrad_ws', nws)] = _f(nws, device=dev)
-    wgrad = rn.lib().ra_conv3x3_wgrad_acc_bf16ops_f32 if bf else rn.lib().ra_conv3x3_wgrad_acc_f32
-    check(wgrad(ptr(X), Cx, N, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws, ptr(cmap_t), int(cin_w), int(tr), ptr(gw),
-                ptr(gb), rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_f32')
-    dx = _conv_dgrad(du, w, tr, stride, cmap, X.shape, cin_w, info['cache'], bf) if ctx.needs_input_grad[0] else None
+    wfmt = (1 if X.dtype == torch.bfloat16 else 0) | (2 if du.dtype == torch.bfloat16 else 0)
+    if wfmt:
+      check(rn.lib().ra_conv3x3_wgrad_acc_bf16_f32(ptr(X), Cx, N, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws, ptr(cmap_t),
+                                                   int(cin_w), int(tr), ptr(gw), ptr(gb), wfmt, rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_bf16_f32')
+    else:
+      wgrad = rn.lib().ra_conv3x3_wgrad_acc_bf16ops_f32 if bf else rn.lib().ra_conv3x3_wgrad_acc_f32
+      check(wgrad(ptr(X), Cx, N, Hs, Ws, int(stride == 2), ptr(du), cout, ptr(wws), nws, ptr(cmap_t), int(cin_w), int(tr), ptr(gw),
+                  ptr(gb), rn.stream_ptr()), 'ra_conv3x3_wgrad_acc_f32')
+    dx = _conv_dgrad(du, w, tr, stride, cmap, X.shape, cin_w, info['cache'], bf, X.dtype) if ctx.needs_input_grad[0] else None
     return dx, None, None, None
 
 
@@ -1137,6 +1218,9 @@ class TrainStep(object):
     if cd not in ('float32', 'f32', 'fp32', 'bf16', 'bfloat16'):
       raise rn.RecAttendError("model_opt['compute_dtype'] = %r: 'float32' or 'bf16'" % cd)
     self.bf16 = cd in ('bf16', 'bfloat16')
+    # ... and, in the stacked step, U / Y / dY / dU of the conv layers STORED as bf16 between their passes (half the bytes of
+    # the HBM-bound BatchNorm, data-gradient and filter-gradient passes); RA_BF16_STORE=0: operands only, float32 tensors
+    self.bf16_store = False
     if self.sync_bn:
       self.use_graph = False
     rank = dist.get_rank() if self.world > 1 else 0
@@ -1186,6 +1270,7 @@ class TrainStep(object):
       bn = self.d['use_bn']
       key = '%s_%d_%d' % (scope, i, tt)
       meta = dict(transposed=False, stride=1, pool=pools[i], relu=True, chan_map=cmap0 if i == 0 else None,
+                  bf16_store=self.bf16_store, y_f32=(i == n - 1),  # the net's last output feeds float32 kernels (controller, score, dcnn)
                   stat_out=self._stat_views.get(key), grads=self._grad_views(scope, i, key, bn), cache=self._pack,
                   sync_bn=self.sync_bn, bf16=self.bf16, wgrad_defer=self._wgrad_parts if self.defer_wgrad else None,
                   wgrad_key=(scope, i), alloc=self._tape_alloc(scope, i, tt, meta_of=(False, 1, pools[i], cmap0 if i == 0 else None)))
@@ -1208,12 +1293,13 @@ class TrainStep(object):
       if skips is not None and skips[i] is not None:
         sk, smap = skips[i]
         prev_c = x.shape[3]
-        xp, skp = _pad_channels(x), _pad_channels(sk)
+        xp, skp = _pad_channels(x), _pad_channels(sk if sk.dtype == x.dtype else sk.to(x.dtype))
         smap = list(range(sk.shape[3])) if smap is None else smap
         cmap = list(range(prev_c)) + [-1] * (xp.shape[3] - prev_c) + [prev_c + m if m >= 0 else -1 for m in smap] + \
             [-1] * (skp.shape[3] - len(smap))
         x = torch.cat([xp, skp], dim=3)
       meta = dict(transposed=True, stride=unpool[i], pool=1, relu=True, chan_map=cmap, stat_out=self._stat_views.get(key),
+                  bf16_store=self.bf16_store, y_f32=(i == n - 1),
                   grads=self._grad_views(scope, i, key, bn), cache=self._pack, sync_bn=self.sync_bn, bf16=self.bf16,
                   wgrad_defer=self._wgrad_parts if self.defer_wgrad else None, wgrad_key=(scope, i),
                   alloc=self._tape_alloc(scope, i, tt, meta_of=(True, unpool[i], 1, cmap)))
@@ -1252,13 +1338,13 @@ class TrainStep(object):
                 c4(self.model.dims['ccnn_channels'][1:]) and c4(opt['attn_cnn_depth']) and c4(opt['attn_dcnn_depth'][:-1]) and
                 self.model.dims['C0p'] % 4 == 0 and d['n_gmlp'] == 2 and d['n_cmlp'] == 1)
 
-  def _slab(self, name, T, shape):
+  def _slab(self, name, T, shape, dtype=torch.float32):
     """[T, *shape] buffer of the step (one slot per timestep), kept across steps."""
     t = self._slabs.get(name)
-    if t is None or tuple(t.shape) != (T,) + tuple(shape):
+    if t is None or tuple(t.shape) != (T,) + tuple(shape) or t.dtype != dtype:
       if t is not None:
         self._drop_captured_steps()  # a graph captured for another batch shape holds the old slab's address
-      t = self._slabs[name] = torch.empty((T,) + tuple(shape), dtype=torch.float32, device=self.bucket.param.device)
+      t = self._slabs[name] = torch.empty((T,) + tuple(shape), dtype=dtype, device=self.bucket.param.device)
     return t
 
   def _drop_captured_steps(self):
@@ -1275,7 +1361,7 @@ class TrainStep(object):
       return None
     tape['layers'][(scope, i)] = meta_of
     T = self.d['T']
-    return lambda kind, shape: self._slab('%s_%d_%s' % (scope, i, kind), T, shape)[tt]
+    return lambda kind, shape, dtype=torch.float32: self._slab('%s_%d_%s' % (scope, i, kind), T, shape, dtype)[tt]
 
   def _bn_tables(self, scope, i):
     """Device table of 6 T pointers {mean, var, gamma, beta, gradient gamma, gradient beta}[T] of layer (scope, i) (static:
@@ -1298,7 +1384,8 @@ class TrainStep(object):
     for i in range(n):
       tr, stride, pool, cmap = self._tape['layers'][(scope, i)]
       if skips is not None and skips[i] is not None:
-        X = torch.cat([_pad_channels(X), _pad_channels(skips[i])], dim=3)  # the channel map of the sequential phase applies
+        sk = skips[i] if skips[i].dtype == X.dtype else skips[i].to(X.dtype)
+        X = torch.cat([_pad_channels(X), _pad_channels(sk)], dim=3)  # the channel map of the sequential phase applies
       U, Y = self._slabs['%s_%d_u' % (scope, i)], self._slabs['%s_%d_y' % (scope, i)]
       tab, per_group = self._bn_tables(scope, i)
       gw, gb = self.bucket.grad_of['%s_w_%d' % (scope, i)], self.bucket.grad_of['%s_b_%d' % (scope, i)]
@@ -1352,6 +1439,7 @@ class TrainStep(object):
     return to_bt(y), to_bt(s).reshape(B, T), to_bt(box), to_bt(cn), to_bt(ls), iou_rows
 
   fuse_controller = True  # the controller of a timestep as one forward and one backward launch
+  bf16_storage = os.environ.get('RA_BF16_STORE', '1') != '0'  # bf16 mode, stacked step: U / Y / dY / dU stored as bf16 (False: operands only)
   seq_ctrl_split = os.environ.get('RA_TRAIN_CTRL_SPLIT', '1') != '0'  # stacked step, sequential phase: the decode loop's 16-workgroup controller
 
   def _seq_controller(self, B):
@@ -1546,6 +1634,7 @@ class TrainStep(object):
       inp = _pad_channels(inp)
     batched = self._batched_ok(extra) and self._ctrl_buffers(B, self.model.dims['ccnn_channels'][-1]) is not None
     self._tape = dict(layers={}) if batched else None
+    self.bf16_store = bool(batched and self.bf16 and not self.sync_bn and self.bf16_storage)
     tape_match = []
     if batched:  # phase 1 runs without an autograd tape; the packed inputs of the T timesteps live in one slab
       inp_slab = self._slab('inp', T, tuple(inp.shape))

@@ -64,6 +64,13 @@ def test_train_layer_bytes_formula():
   acnn = 3 * (B * 8 * 8 * 4 * 4) + 7 * (B * 8 * 8 * 4 * 4) + 3 * (B * 8 * 8 * 4 * 4)
   dcnn = 3 * (B * 8 * 8 * 4 * 4) + 7 * (B * 16 * 16 * 4 * 4) + 3 * (B * 16 * 16 * 4 * 4)
   assert bench.train_layer_bytes(opt, B, S, T) == T * (ctrl + acnn + dcnn)
+  # bf16 storage: U of every layer 2 bytes; every net here has ONE layer, whose output stays float32 (float32 readers)
+  ctrl_s = 2 * (B * S * S * 4 * 4) + 6 * (B * S * S * 8 * 2) + 3 * (B * S * S * 8 * 4 // 4)
+  acnn_s = 3 * (B * 8 * 8 * 4 * 4) + 7 * (B * 8 * 8 * 4 * 2) + 3 * (B * 8 * 8 * 4 * 4)
+  dcnn_s = 3 * (B * 8 * 8 * 4 * 4) + 7 * (B * 16 * 16 * 4 * 2) + 3 * (B * 16 * 16 * 4 * 4)
+  assert bench.train_layer_bytes(opt, B, S, T, True) == T * (ctrl_s + acnn_s + dcnn_s)
+  full = bench.make_opt('cvppp', 512, 512, 16)
+  assert 0.5 < bench.train_layer_bytes(full, 8, 512, 16, True) / bench.train_layer_bytes(full, 8, 512, 16) < 0.56
 
 
 @pytest.mark.gpu
