@@ -107,11 +107,21 @@ struct Geo {
 // BF16 = true (the training step's mixed-precision mode, model_opt['compute_dtype'] = 'bf16'): the same kernel with
 // bf16 OPERANDS and float32 accumulation — the staged float32 pixels are rounded to bf16 (v_cvt_pk_bf16_f32, RNE)
 // as they leave LDS, the chunk's weights once per chunk, and four k-steps of v_mfma_f32_16x16x4_f32 become ONE
-// v_mfma_f32_16x16x16_bf16 (a lane's 4 k-values = its ksub in the 4 steps: 4 channel groups of a tap for CK = 16,
+// v_mfma_f32_16x16x32_bf16 (gfx950's K = 32 form: two quads of 4 k-values per lane; a quad = the lane's ksub in 4 k-steps:
+// 4 channel groups of a tap for CK = 16,
 // 2 taps x 2 groups for CK = 8, 4 taps for CK = 4; steps beyond the 9 taps carry zero weights).  Tensors in HBM and
 // LDS stay float32; with 1/8 of the matrix-pipe time the kernel is bound by staging, LDS and HBM instead.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+// gfx950's K = 32 form, v_mfma_f32_16x16x32_bf16: a lane holds 8 bf16 per operand.  Two of the K = 16 quads side by side:
+// slot j of A-lane (m, kb) meets slot j of B-lane (n, kb), so ANY assignment of k-values to slots that both operands share
+// is a valid contraction — here slots 0..3 = the first quad's k-steps, 4..7 = the second's.
+typedef short bf16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ inline f32x4 mfma32(bf16x4 a0, bf16x4 a1, bf16x4 b0, bf16x4 b1, f32x4 c) {
+  const bf16x8s A = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), B = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), c, 0, 0, 0);
+}
 // four bf16 values stored in 8 bytes -> float32 (exact)
 __device__ inline f32x4 bf16x4_to_f32(u32x2s p) {
   return f32x4{__builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xffff0000u),
@@ -347,34 +357,40 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   auto compute = [&](int buf) {  // MFMA main loop: 9 taps, one wide A read per (tap, group)
     const float *tb = tile + buf * G::LDS_FLOATS;
     if constexpr (BF16) {
-      constexpr int TPF = 4 / G::NCG;  // taps per bf16 MFMA
+      constexpr int TPF = 4 / G::NCG;  // taps per bf16 quad (4 k-steps of this lane's ksub)
+      auto quad = [&](int f, int g) {  // the A operand's quad f of pixel group g (beyond the chunk's k-steps: zeros)
+        if (f >= NMF) return bf16x4{0, 0, 0, 0};
+        const int gx = g % GX, gy = g / GX;
+        float v4[4];
 #pragma unroll
-      for (int f = 0; f < NMF; ++f) {
-        bf16x4 apk[G::PM];
+        for (int tp = 0; tp < TPF; ++tp) {
+          const int tap = (f * TPF + tp < 9) ? f * TPF + tp : 8;  // beyond the 9 taps: any staged pixel (zero weights)
+          const int ky = tap / 3, kx = tap % 3;
+          const avec av = *reinterpret_cast<const avec *>(&tb[a_base + ((2 * gy + ky) * G::LW + 8 * gx + kx) * G::PIX]);
+#pragma unroll
+          for (int cg = 0; cg < G::NCG; ++cg) v4[tp * G::NCG + cg] = av[cg];
+        }
+        return pack_bf16(v4[0], v4[1], v4[2], v4[3]);
+      };
+      // two quads per v_mfma_f32_16x16x32_bf16 (the CDNA4 form; CDNA3's K = 16 form took one)
+#pragma unroll
+      for (int f = 0; f < NMF; f += 2) {
+        bf16x4 a0[G::PM], a1[G::PM];
 #pragma unroll
         for (int g = 0; g < G::PM; ++g) {
-          const int gx = g % GX, gy = g / GX;
-          float v4[4];
-#pragma unroll
-          for (int tp = 0; tp < TPF; ++tp) {
-            const int tap = (f * TPF + tp < 9) ? f * TPF + tp : 8;  // beyond the 9 taps: any staged pixel (zero weights)
-            const int ky = tap / 3, kx = tap % 3;
-            const avec av = *reinterpret_cast<const avec *>(&tb[a_base + ((2 * gy + ky) * G::LW + 8 * gx + kx) * G::PIX]);
-#pragma unroll
-            for (int cg = 0; cg < G::NCG; ++cg) {
-              v4[tp * G::NCG + cg] = av[cg];
-            }
-          }
-          apk[g] = pack_bf16(v4[0], v4[1], v4[2], v4[3]);
+          a0[g] = quad(f, g);
+          a1[g] = quad(f + 1, g);
         }
 #pragma unroll
         for (int g = 0; g < G::PM; ++g)
 #pragma unroll
-          for (int n = 0; n < NC; ++n)
+          for (int n = 0; n < NC; ++n) {
+            const bf16x4 b1 = f + 1 < NMF ? bpk[f + 1 < NMF ? f + 1 : 0][n] : bf16x4{0, 0, 0, 0};
             if constexpr (SWAP)
-              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bpk[f][n], apk[g], acc[g][n], 0, 0, 0);
+              acc[g][n] = mfma32(bpk[f][n], b1, a0[g], a1[g], acc[g][n]);
             else
-              acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(apk[g], bpk[f][n], acc[g][n], 0, 0, 0);
+              acc[g][n] = mfma32(a0[g], a1[g], bpk[f][n], b1, acc[g][n]);
+          }
       }
       return;
     }

@@ -929,7 +929,7 @@ constexpr int WTH = 8, WTW = 32, WLW = WTW + 2, WLH = WTH + 2;
 // ceil(9 * Cin / 16) tiles — 3 instead of 9 k-step MFMAs per pixel quad for Cin = 4 (where 12 of the 16
 // channel rows were zero), 5 for Cin = 8; a lane reads its row's pixel through a per-tile LDS offset.
 // BF16 (compute_dtype = 'bf16'): the staged float32 pixels are rounded to bf16 as they leave LDS and four K steps
-// (16 consecutive pixels of a row) go through ONE v_mfma_f32_16x16x16_bf16; accumulation stays float32.
+// (32 consecutive pixels of a row) go through ONE v_mfma_f32_16x16x32_bf16 (the gfx950 form); accumulation stays float32.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1121,25 +1121,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *x, const float 
     for (int rr = 0; rr < 2; ++rr) {
       const int row = wave * 2 + rr;
       if constexpr (BF16) {
+        // v_mfma_f32_16x16x32_bf16 (gfx950): a lane's 8 k-values = its pixels col, col + 4, ..., col + 28 of the row (two of
+        // the K = 16 form's quads; slot j of the A lane meets slot j of the B lane, so any shared assignment contracts right)
+        static_assert(WTW % 32 == 0, "32 pixels of a row per MFMA");
+        typedef short bf16x8s __attribute__((ext_vector_type(8)));
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        auto cat8 = [](bf16x4 lo, bf16x4 hi) { return __builtin_bit_cast(bf16x8, (bf16x8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); };
 #pragma unroll
-        for (int s0 = 0; s0 < WTW / 16; ++s0) {
-          const int col = 16 * s0 + ksub;  // this lane's pixels: col, col + 4, col + 8, col + 12
-          bf16x4 bv[NT];
+        for (int s0 = 0; s0 < WTW / 32; ++s0) {
+          const int col = 32 * s0 + ksub;
+          bf16x8 bv[NT];
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             const float *q = tu + (row * WTW + col) * CP + 16 * n + m;
-            bv[n] = pack_bf16(q[0], q[4 * CP], q[8 * CP], q[12 * CP]);
+            bv[n] = cat8(pack_bf16(q[0], q[4 * CP], q[8 * CP], q[12 * CP]), pack_bf16(q[16 * CP], q[20 * CP], q[24 * CP], q[28 * CP]));
           }
 #pragma unroll
           for (int t = 0; t < MT; ++t) {
             const float *q = tx + (row * WLW + col) * 16 + aoff[t];
-            const bf16x4 av = pack_bf16(q[0], q[64], q[128], q[192]);
+            const bf16x8 av = cat8(pack_bf16(q[0], q[64], q[128], q[192]), pack_bf16(q[256], q[320], q[384], q[448]));
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv[n], acc[t][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[n], acc[t][n], 0, 0, 0);
           }
-          const bf16x4 one = bf16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80};
+          const bf16x4 one4 = bf16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80};
+          const bf16x8 one = cat8(one4, one4);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[MT][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(one, bv[n], acc[MT][n], 0, 0, 0);
+          for (int n = 0; n < NT; ++n) acc[MT][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, bv[n], acc[MT][n], 0, 0, 0);
         }
         continue;
       }
