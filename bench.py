@@ -261,7 +261,7 @@ def bench_other(args, rank, world, name):
   elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
   for _, pipe in pipes:
     for eng_k, _ in pipe.slots:
-      eng_k.check_status()
+      eng_k.check_status(recover=False)
   if rank == 0:
     print(json.dumps({
         'metric': 'instance-timesteps/sec, %s (whole job)' % name, 'value': world * B * T * args.steps / elapsed,
@@ -547,7 +547,7 @@ def main():
   elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
   value = world * B * T * args.steps / elapsed
   for eng_k, _ in pipe.slots:  # a controller workgroup that timed out on its peers would have produced garbage: fail loudly
-    eng_k.check_status()
+    eng_k.check_status(recover=False)
 
   out = {
       'metric': 'instance-timesteps/sec, full_model forward 512x512 T=16 (whole job; pipelined throughput: %d batches in flight '

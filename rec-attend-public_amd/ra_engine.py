@@ -310,16 +310,39 @@ class DecodeEngine(object):
     dim = 0 if name in ('img', 'canvas') else 1
     return torch.cat(parts, dim=dim)
 
-  def check_status(self):
+  def check_status(self, recover=True):
     """After the forward has finished: the 16-workgroup controller's status words.  Non-zero means a
-    workgroup waited for a peer that never became resident (ra_ctrl_split.hip, kSpinLimit): the
-    outputs of that forward are garbage, so raise instead of returning them."""
+    workgroup waited for a peer that never became resident (ra_ctrl_split.hip, kSpinLimit: something
+    else held the CUs the residency rule counted on) and the outputs of that forward are garbage.
+    recover: decode the same inputs again, synchronously, on the one-workgroup controller (no
+    cross-workgroup waits at all) — this engine keeps that controller from then on — and warn; False:
+    raise.  Returns True when a recovery ran."""
+    bad = False
     for sb in self.subs:
       st = sb.get('ctrl_status')
       if st is not None and int(st.item()) != 0:
         st.zero_()
-        raise rn.RecAttendError('controller_split: a workgroup timed out waiting for its peers (the launch was '
-                                'not fully resident); decode with engine.ctrl_split = False')
+        bad = True
+    if not bad:
+      return False
+    if not recover:
+      raise rn.RecAttendError('controller_split: a workgroup timed out waiting for its peers (the launch was '
+                              'not fully resident); decode with engine.ctrl_split = False')
+    import warnings
+    warnings.warn('controller_split: a workgroup timed out waiting for its peers (the launch was not fully resident: is '
+                  'something else using this GPU?); the batch is decoded again on the one-workgroup controller, which this '
+                  'engine keeps from now on')
+    torch.cuda.synchronize()
+    keep = {k: self.glob[k].clone() for k in ('x', 'd_in', 'y_in', 'y_gt', 'noise') if k in self.glob}
+    want_box = getattr(self, '_last_want_box', False)
+    self.ctrl_split = False
+    self._stamp = None   # prepare() again: split_ok becomes False
+    self._B = None       # alloc() again: no exchange workspace, so _launch_tail takes ra_controller_f32
+    self._graphs = {}
+    self.forward(keep['x'], d_in=keep.get('d_in'), y_in=keep.get('y_in'), y_gt=keep.get('y_gt'), noise=keep.get('noise'),
+                 want_box=want_box)
+    torch.cuda.synchronize()
+    return True
 
   # ------------------------------------------------------------------ launch sequence
   def _mark(self, name):
@@ -529,6 +552,7 @@ class DecodeEngine(object):
       for k, sb in enumerate(self.subs):
         sb['noise'].copy_(b['noise'][:, k * Bs:(k + 1) * Bs])
         sb['box_gt'] = ops.gt_box(sb['y_gt'].contiguous(), float(self.d['attn_box_padding_ratio']), 10.0)[1]
+    self._last_want_box = bool(want_box)
     graphable = self.use_graph and self.timing is None
     if not graphable:
       self._launch_all(want_box)

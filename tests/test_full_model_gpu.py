@@ -355,6 +355,36 @@ def test_box_model_softmax_score(cuda):
   assert out['s_out'].shape == (2, 3, 9) and abs(float(out['s_out'][0, 0].sum()) - 1.0) < 1e-5
 
 
+def test_starved_split_controller_recovers_on_one_workgroup_form(cuda):
+  """the 16-workgroup controller relies on all its workgroups being resident; a launch that is not (another
+  process on the GPU) times out and flags its status word.  model.run and the pipeline's collect() then decode the same
+  inputs again on the one-workgroup controller (no cross-workgroup waits) instead of raising or returning garbage, and the
+  engine keeps that form.  Simulated by flagging the status word after a healthy forward."""
+  import warnings
+  import full_model
+  opt = ora.make_opt('cvppp', 128, 128, 3)
+  P = ora.random_params(opt, 43)
+  m = full_model.get_model(opt).load_weights(P)
+  x = np.random.RandomState(6).rand(2, 128, 128, 3).astype(np.float32)
+  good = m.run(['y_out', 's_out'], {'x': x, 'phase_train': False}, as_numpy=True)
+  eng = m.engine
+  assert 'ctrl_ws' in eng.subs[0]  # the split form ran
+  eng.subs[0]['y_out'].fill_(7.0)  # "garbage"
+  eng.subs[0]['ctrl_status'].fill_(1)
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    assert eng.check_status() is True
+  assert any('one-workgroup controller' in str(x_.message) for x_ in w)
+  assert 'ctrl_ws' not in eng.subs[0] and eng.ctrl_split is False
+  y2, s2 = eng.fetch('y_out').cpu().numpy(), eng.fetch('s_out').cpu().numpy()
+  assert np.abs(y2 - good[0]).max() < 1e-4 and np.abs(s2 - good[1]).max() < 1e-4  # another summation order, the same masks
+  again = m.run(['y_out', 's_out'], {'x': x, 'phase_train': False}, as_numpy=True)  # and it stays on that form
+  assert np.array_equal(again[0], y2) and eng.check_status() is False
+  with pytest.raises(Exception):
+    eng.subs[0]['ctrl_status'] = torch.ones(1, dtype=torch.int32, device=cuda)
+    eng.check_status(recover=False)
+
+
 def test_decode_pipeline_matches_lone_run(cuda):
   """Batches in flight on their own HIP streams (full_model.DecodePipeline, the evaluator's loop)
   return, batch for batch, exactly what a lone model.run returns — including a ragged last
