@@ -93,18 +93,32 @@ def seed_weights(model, seed):
   model['ctrl_mlp_b_0'].copy_(b)
 
 
-def pmc_traffic(images, size, name='r03_pmc_encoder_traffic.json'):
+ROUNDS = ('r04', 'r03', 'r02', 'r01')
+
+
+def pmc_traffic(images, size, name='r03_pmc_encoder_traffic.json', want_source=False):
   """HBM bytes per launch group measured with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE
   passes over `bench.py --pmc-group REPS [--pmc-which attn]`, summarised by tools/pmc_traffic.py);
-  the newest committed round's file that matches this shape."""
-  for rnd in ('r03', 'r02', 'r01'):
+  the newest committed round's file that matches this shape.  want_source: also which file, and whether the library
+  and bench.py it was collected with are the ones running now (the counters are replayed, not measured in this run:
+  gpurun refuses --pmc next to a trace, and a --pmc pass is its own process)."""
+  import hashlib
+  for rnd in ROUNDS:
     path = os.path.join(ROOT, 'profiles', rnd + name[3:])
     if not os.path.exists(path):
       continue
     rec = json.load(open(path))
     if rec.get('images') == images and rec.get('size') == size:
-      return rec['hbm_bytes_per_launch_group']
-  return None
+      if not want_source:
+        return rec['hbm_bytes_per_launch_group']
+      sha = lambda p: hashlib.sha256(open(p, 'rb').read()).hexdigest()[:16] if os.path.exists(p) else None
+      now = {'bench_py_sha16': sha(os.path.join(ROOT, 'bench.py')),
+             'librecattend_sha16': sha(os.path.join(ROOT, 'rec-attend-public_amd', 'librecattend.so'))}
+      got = rec.get('collected_with')
+      return rec['hbm_bytes_per_launch_group'], {
+          'file': 'profiles/' + os.path.basename(path), 'collected_with': got,
+          'same_library_as_this_run': None if not got else got.get('librecattend_sha16') == now['librecattend_sha16']}
+  return (None, None) if want_source else None
 
 
 def mfma_busy():
@@ -112,7 +126,7 @@ def mfma_busy():
   (profiles/r0x_pmc_sq_mfma_per_kernel.csv: per-kernel means per dispatch): sum of SQ_VALU_MFMA_BUSY_CYCLES over
   sum of GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs, each kernel weighted by its launches per timestep."""
   import csv
-  for rnd in ('r03', 'r02', 'r01'):
+  for rnd in ROUNDS:
     path = os.path.join(ROOT, 'profiles', rnd + '_pmc_sq_mfma_per_kernel.csv')
     if not os.path.exists(path):
       continue
@@ -635,12 +649,13 @@ def main():
       src_ = sb['img'] if st_[1] == 0 else sb['ccnn'][st_[1] - 1]
       enc_bytes += 4.0 * (src_.numel() + sb['ccnn'][st_[-1]].numel())
     achieved = tot_f * Bs / (enc_us * 1e-6) / 1e12
+    enc_traffic, enc_traffic_src = pmc_traffic(Bs, S, want_source=True)
     out['roofline'] = {
         'kernel': 'ra::cpair::conv_pair8_mfma / conv_pair_persist_mfma + ra::wino::conv_wino_mfma + ra::conv::conv3x3_mfma (controller CNN: %d layers in %d '
                   'launches per timestep per sub-batch of %d images)' % (d['ccnn_nlayers'],
                                                                        len(eng.plan['ccnn']), Bs),
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(Bs, S), 'mfma_busy': mfma_busy(),
+        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': enc_traffic, 'traffic_source': enc_traffic_src, 'mfma_busy': mfma_busy(),
         'traffic_note': 'HBM bytes per launch group from committed rocprofv3 --pmc passes '
                         '(profiles/r0x_pmc_encoder_traffic.json; FETCH_SIZE x2 gfx950 correction + '
                         'WRITE_SIZE); null if no pass matches this shape',
@@ -690,12 +705,12 @@ def main():
     fill_us = graph_time_us(prefill, reps=10, inner=2) if (prefilled and not rides) else 0.0
     group_us = attn_us + fill_us / T
     attn_bytes = float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs
-    attn_traffic = pmc_traffic(Bs, S, 'r03_pmc_attn_traffic.json')
+    attn_traffic, attn_traffic_src = pmc_traffic(Bs, S, 'r03_pmc_attn_traffic.json', want_source=True)
     out['roofline_attn'] = {
         'kernel': 'ra::attnd::extract_rows_kernel + paste_win_kernel (+ 1/T of the per-forward fills) — attention '
                   'resample, one sub-batch of %d images' % Bs, 'bound': 'hbm',
         'achieved': attn_bytes / (group_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-        'frac': attn_bytes / (group_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': attn_traffic,
+        'frac': attn_bytes / (group_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': attn_traffic, 'traffic_source': attn_traffic_src,
         'achieved_traffic': None if attn_traffic is None else attn_traffic / (group_us * 1e-6) / 1e9,
         'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': group_us,
         'extract_paste_us': attn_us, 'fills_us_per_forward': fill_us,

@@ -2,11 +2,11 @@
 # Round profiles on the GPU box: kernel-trace stats of a bench run, then SEPARATE --pmc passes
 # (gpurun refuses --pmc combined with trace domains other than --kernel-trace/--stats) for the HBM
 # traffic of the encoder group and of the extract+paste pair and for the SQ MFMA-busy counters.
-# Everything lands in gpurun_out/$1/ named $2_* (default r03); the summaries to commit are copied into
+# Everything lands in gpurun_out/$1/ named $2_* (default r04); the summaries to commit are copied into
 # profiles/ by hand.  Every command runs under `timeout`.
 set -u
 OUT=gpurun_out/${1:-prof}
-R3=${2:-r03}
+R3=${2:-r04}
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
@@ -47,5 +47,6 @@ done
 timeout 900 python bench.py --config cfg3 > $OUT/${R3}_bench_cfg3.json 2>> $OUT/bench.err
 timeout 900 python bench.py --config cfg5 > $OUT/${R3}_bench_cfg5.json 2>> $OUT/bench.err
 timeout 120 tools/bin/attn_probe 8 > $OUT/${R3}_attn_probe.txt 2>&1
+timeout 120 tools/bin/pair8_probe 8 > $OUT/${R3}_pair8_probe.txt 2>&1
 timeout 120 tools/bin/lat_probe 256 > $OUT/${R3}_lat_probe.txt 2>&1
 ls -la $OUT

@@ -13,7 +13,16 @@ controller-CNN kernels (ra::conv::*, ra::cpair::*) launched AFTER the warm-up fo
 the forward pass launches each of them a known number of times, which is subtracted by taking the
 last REPS x launches_per_group dispatches of the run.
 """
-import csv, json, sys
+import csv, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_stamp():
+  """What the counters were collected with: bench.py reports whether the file it replays still matches the build."""
+  sha = lambda p: hashlib.sha256(open(p, 'rb').read()).hexdigest()[:16] if os.path.exists(p) else None
+  return {'bench_py_sha16': sha(os.path.join(ROOT, 'bench.py')),
+          'librecattend_sha16': sha(os.path.join(ROOT, 'rec-attend-public_amd', 'librecattend.so'))}
 
 
 KEYS = ['ra::conv::', 'ra::cpair::', 'ra::wino::']
@@ -54,6 +63,7 @@ def main():
       'hbm_bytes_per_launch_group': fetch_kib * 1024 * 2 + write_kib * 1024,
       'correction': 'FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE x1',
       'per_kernel_mean_kib': {'FETCH_SIZE': fk, 'WRITE_SIZE': wk},
+      'collected_with': build_stamp(),
   }
   json.dump(rec, open(out, 'w'), indent=1)
   print(json.dumps(rec)[:600])
