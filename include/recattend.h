@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 102
+#define RA_ABI_VERSION 103
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -710,6 +710,16 @@ int ra_fill_f32(float *p, size_t n, float value, void *stream);
  * weights for the decode loop's kernels once per optimisation step without leaving the device: the host packers
  * (ra_ctrl_split_pack_weights ...) only move values, so packing arrays of flat-bucket positions once gives the index map. */
 int ra_gather_f32(const float *src, const int *idx, size_t n, float *out, void *stream);
+/* C [M, N] += A^T B (and bias [N] += the column sums of B) over the rows k < K of the row-major A [K, M] (row stride lda)
+ * and B [K, N] (ldb): the parameter gradients tf.gradients forms for the controller's dense layers (nnlib.mlp /
+ * nnlib.lstm, full_model.py:668-689) from a step's layer inputs (A) and pre-activation gradients (B) of every
+ * (timestep, image, glimpse iteration) — K is a few hundred rows, the output wide.  k_period > 0 skips the rows with
+ * k % k_period == k_period - 1 (the last glimpse iteration of an image feeds no next one).  seg == NULL: plain C (row stride
+ * ldc), bias or NULL.  seg != NULL: a DEVICE table of 3 * ceil(N / col_block) pointers, [rows < row_split | rows >=
+ * row_split | bias] x column block (NULL entries skipped): every block is its own dense [rows, col_block] tensor — the
+ * LSTM's eight weight and four bias parameters of the flat gradient bucket; row_split % 16 == col_block % 16 == 0. */
+int ra_gemm_tn_acc_f32(const float *A, int lda, const float *B, int ldb, int K, int M, int N, int k_period, float *C, int ldc,
+                       float *bias, const void *const *seg, int row_split, int col_block, void *stream);
 /* modellib.f_greedy_match with matched == 0 (modellib.py:365-379; box_model.py:487-498):
  * match[b,t] = (score[b,t] == max_t score[b,:]) / #maxima.  score, match [B,T]. */
 int ra_greedy_match_f32(const float *score, int B, int T, float *match, void *stream);

@@ -519,6 +519,99 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float *u, const fl
   }
 }
 
+// ---- small tensors (the one-channel output layer of the deconvolution net: B x 48 x 48 values per timestep): the
+// whole BatchNorm backward of a call — both sums, dbeta / dgamma and du — in ONE workgroup per call; G calls (a layer's
+// timesteps) = G workgroups of one launch.  1024 % C == 0 keeps a thread on one channel; fixed-shape LDS tree.
+constexpr int kSmallThreads = 1024;
+constexpr size_t kSmallElems = 65536;  // per group
+inline bool small_ok(int C, size_t elems, int which = 1) {
+  static int on = -1;  // RA_BN_SMALL=0: the multi-launch forms; 2: only the moments, 3: only the backward (debugging aids)
+  if (on < 0) {
+    const char *e = getenv("RA_BN_SMALL");
+    on = e ? atoi(e) : 1;
+  }
+  return (on == 1 || on == which) && C >= 1 && C <= 64 && (C & (C - 1)) == 0 && elems <= kSmallElems;
+}
+__global__ __launch_bounds__(kSmallThreads) void bn_bwd_small_kernel(const float *u, const float *dy, const float *mean, const float *var,
+                                                                    const float *gamma, const float *beta, float eps, int relu, int pool,
+                                                                    int B, int H, int W, int C, float *dbeta, float *dgamma,
+                                                                    float *acc_beta, float *acc_gamma, float *du, float inv_n,
+                                                                    const float *const *tabs, int G) {
+  __shared__ float r0[kSmallThreads], r1[kSmallThreads];
+  const int g_ = blockIdx.x, tid = threadIdx.x, c = tid % C;
+  const size_t total = (size_t)B * H * W * C;
+  if (tabs) {
+    mean = tabs[g_], var = tabs[G + g_], gamma = tabs[2 * G + g_], beta = tabs[3 * G + g_];
+    acc_gamma = const_cast<float *>(tabs[4 * G + g_]), acc_beta = const_cast<float *>(tabs[5 * G + g_]);
+    u += (size_t)g_ * total;
+    dy += (size_t)g_ * (total / (pool * pool));
+    du += (size_t)g_ * total;
+    dbeta += (size_t)g_ * C, dgamma += (size_t)g_ * C;
+  }
+  const float rstd = var ? rsqrtf(var[c] + eps) : 1.f, mu = mean ? mean[c] : 0.f;
+  const float g = (gamma ? gamma[c] : 1.f) * rstd, sh = beta ? beta[c] : 0.f;
+  const float lo = relu ? 0.f : -__builtin_inff();
+  float s0 = 0.f, s1 = 0.f;
+  for (size_t e = tid; e < total; e += kSmallThreads) {
+    size_t r = e / C;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H), b = (int)(r / H);
+    float dv, xhat;
+    bwd_point(u, dy, g, sh, mu, rstd, lo, relu, pool, b, yy, xx, H, W, C, c, dv, xhat);
+    s0 += dv;
+    s1 += dv * xhat;
+  }
+  r0[tid] = s0, r1[tid] = s1;
+  __syncthreads();
+  for (int o = kSmallThreads / 2; o >= C; o >>= 1) {
+    if (tid < o) r0[tid] += r0[tid + o], r1[tid] += r1[tid + o];
+    __syncthreads();
+  }
+  const float db = r0[c], dg = r1[c];
+  if (tid < C) {
+    dbeta[c] = db, dgamma[c] = dg;
+    if (acc_beta) acc_beta[c] += db;
+    if (acc_gamma) acc_gamma[c] += dg;
+  }
+  for (size_t e = tid; e < total; e += kSmallThreads) {
+    size_t r = e / C;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H), b = (int)(r / H);
+    float dv, xhat;
+    bwd_point(u, dy, g, sh, mu, rstd, lo, relu, pool, b, yy, xx, H, W, C, c, dv, xhat);
+    du[e] = var ? g * (dv - db * inv_n - xhat * dg * inv_n) : dv;
+  }
+}
+// tf.nn.moments of a small tensor in one launch: mean, then the mean of the squared deviations about it
+__global__ __launch_bounds__(kSmallThreads) void moments_small_kernel(const float *u, size_t total, int C, float inv_n, float *mean,
+                                                                     float *var) {
+  __shared__ float red[kSmallThreads];
+  const int tid = threadIdx.x, c = tid % C;
+  auto chan_sum = [&](float v) {
+    red[tid] = v;
+    __syncthreads();
+    for (int o = kSmallThreads / 2; o >= C; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const float r = red[c];
+    __syncthreads();
+    return r;
+  };
+  float s = 0.f;
+  for (size_t e = tid; e < total; e += kSmallThreads) s += u[e];
+  const float mu = chan_sum(s) * inv_n;
+  s = 0.f;
+  for (size_t e = tid; e < total; e += kSmallThreads) {
+    const float d = u[e] - mu;
+    s += d * d;
+  }
+  const float v = chan_sum(s) * inv_n;
+  if (tid < C) mean[c] = mu, var[c] = v;
+}
+
 // ---- device-side weight repack (the host form is ra_conv_pack_weights) ----
 __global__ void pack_weights_kernel(const float *w, int Cin_w, int Cout, int Cin, const int *chan_map, int tr, int CK,
                                     int cp, float *out) {
@@ -631,6 +724,10 @@ extern "C" int ra_bn_moments_f32(const float *u, size_t npix, int C, float *ws, 
   if (ws_floats < ra_bn_workspace_floats(C)) return fail(RA_E_WORKSPACE, "ra_bn_moments_f32: workspace too small");
   hipStream_t st = as_stream(stream);
   const float inv_n = 1.f / (float)npix;
+  if (train::small_ok(C, npix * C, 2)) {
+    hipLaunchKernelGGL(train::moments_small_kernel, dim3(1), dim3(train::kSmallThreads), 0, st, u, npix * C, C, inv_n, mean, var);
+    return launch_status("ra_bn_moments_f32");
+  }
   if (const int lg = train::v4_log2(C, npix * C); lg >= 0) {
     const int C4 = C / 4, n4 = (int)(npix * C4);
     int nb4 = ceil_div(n4, 256);
@@ -775,6 +872,11 @@ int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float 
     return launch_status("ra_bn_act_pool_bwd_f32");
   }
   if (flags) return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd: bf16 storage needs C %% 4 == 0 with C / 4 a power of two (C %d)", C);
+  if (stages == 3 && train::small_ok(C, npix * C, 3)) {
+    hipLaunchKernelGGL(train::bn_bwd_small_kernel, dim3(1), dim3(train::kSmallThreads), 0, st, u, dy, mean, var, gamma, beta, eps, relu,
+                       pool, B, H, W, C, dbeta, dgamma, acc_beta, acc_gamma, du, inv_n, (const float *const *)nullptr, 1);
+    return launch_status("ra_bn_act_pool_bwd_f32");
+  }
   const int lanes = 256 / C;
   int nb = (int)((npix + lanes - 1) / lanes);
   if (nb > train::kRedBlocks) nb = train::kRedBlocks;
@@ -805,6 +907,13 @@ static int bn_bwd_grouped_impl(const void *u, const void *dy, const void *const 
   if (ws_floats < (size_t)G * ra_bn_workspace_floats(C)) return fail(RA_E_WORKSPACE, "ra_bn_act_pool_bwd_grouped_f32: workspace too small");
   const size_t npix = (size_t)B * H * W;
   const int lg = train::v4_log2(C, npix * C);
+  if (lg < 0 && flags == 0 && G <= 65535 && train::small_ok(C, npix * C, 3)) {  // one workgroup per group (the one-channel output layer)
+    hipLaunchKernelGGL(train::bn_bwd_small_kernel, dim3(G), dim3(train::kSmallThreads), 0, as_stream(stream), static_cast<const float *>(u),
+                       static_cast<const float *>(dy), (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                       (const float *)nullptr, eps, relu, pool, B, H, W, C, dbeta, dgamma, (float *)nullptr, (float *)nullptr,
+                       static_cast<float *>(du), (float)(1.0 / (double)npix), reinterpret_cast<const float *const *>(tabs), G);
+    return launch_status("ra_bn_act_pool_bwd_grouped_f32");
+  }
   if (lg < 0 || ceil_div((W / pool) * (C / 4), 256) > train::kRedBlocks || G > 65535)
     return fail(RA_E_SHAPE, "ra_bn_act_pool_bwd_grouped_f32: C %d (needs C %% 4 == 0, C / 4 a power of two <= 64)", C);
   hipStream_t st = as_stream(stream);

@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 102  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 103  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -45,6 +45,7 @@ SIGNATURES = {
     'ra_last_error_string': (C.c_char_p, []),
     'ra_debug_poison_lds': (_I, [_P]),
     'ra_gather_f32': (_I, [_P, _P, _Z, _P, _P]),
+    'ra_gemm_tn_acc_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     'ra_conv3x3_bf16_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P, _I, _P]),
     'ra_bn_act_pool_bf16_f32': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     'ra_bn_act_pool_bwd_acc_bf16_f32': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _I, _P]),

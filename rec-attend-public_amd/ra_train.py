@@ -222,7 +222,12 @@ BN_EPS = ops.BN_EPS
 EMA_DECAY = 0.9  # 1 - 0.1 * phase_train (nnlib.py:103-104)
 
 
+_POISON = os.environ.get('RA_POISON')  # a debugging aid: every scratch tensor starts as this value (e.g. "nan") instead of stale memory
+
+
 def _f(*shape, device):
+  if _POISON:
+    return torch.full(shape, float(_POISON), dtype=torch.float32, device=device)
   return torch.empty(shape, dtype=torch.float32, device=device)
 
 
@@ -243,12 +248,84 @@ _PACK = {}  # the pack cache of callers outside a TrainStep (tests, one-off laye
 # cannot be handed the pack of a freed tensor whose address was reused, nor one that predates an in-place update.
 
 
+class _PackCache(dict):
+  """A TrainStep's per-step cache of packed filters (cleared by every forward_loss), plus the step's PRE-PACKED filters:
+  the device packer only moves values, so packing an array of flat-bucket POSITIONS once per (layer, geometry) gives an
+  index map, and every later step packs all of its filters and pads all of its biases with ONE gather launch over the
+  parameter bucket (ra_gather_f32) instead of one pack launch (+ a fill and a copy for a padded bias) per layer and
+  direction.  A geometry seen for the first time takes the per-layer launch and joins the map for the next step."""
+
+  def __init__(self, trainer):
+    super().__init__()
+    self.tr = trainer
+    self.entries, self.pending = {}, []   # key -> (start, n) in self.wp; [(key, index map)] waiting for the next refresh
+    self.imap = self.wp = None
+    self.filled = -1                        # the pack epoch self.wp holds
+
+  def _where(self, t):
+    """Offset (in floats) of a contiguous float32 parameter inside the bucket, or None."""
+    par = self.tr.bucket.param
+    off = t.data_ptr() - par.data_ptr()
+    if t.dtype != torch.float32 or not t.is_contiguous() or off < 0 or off % 4 or off // 4 + t.numel() > par.numel():
+      return None
+    return off // 4
+
+  def _positions(self, t, off):
+    assert self.tr.bucket.param.numel() < (1 << 24)  # positions (+1; 0 = "no source") are exact in float32
+    return (torch.arange(t.numel(), device=t.device, dtype=torch.float32) + float(off + 1)).reshape(t.shape)
+
+  def lookup(self, key, t, make_map):
+    """key: the packing's geometry; t: the parameter; make_map(positions) -> packed positions.  The packed values of
+    this step, or None (first sight of the geometry, or a tensor outside the bucket: the caller packs as before)."""
+    off = self._where(t)
+    if off is None or not getattr(self.tr, 'prepack', True):
+      return None
+    key = (off, t.numel()) + key
+    hit = self.entries.get(key)
+    if hit is not None:
+      return self.wp[hit[0]:hit[0] + hit[1]] if self.filled == self.tr._pack_epoch else None
+    if all(k != key for k, _ in self.pending) and not torch.cuda.is_current_stream_capturing():
+      with torch.no_grad():
+        self.pending.append((key, (make_map(self._positions(t, off)).reshape(-1) - 1.0).to(torch.int32)))
+    return None
+
+  def merge(self):
+    """Take in the geometries met since the last merge.  Never inside a stream capture: the index map is built by eager
+    launches from tensors that are freed here (a captured copy of those launches would re-read freed memory at every
+    replay); TrainStep._graphed merges before it captures."""
+    if self.pending and not torch.cuda.is_current_stream_capturing():
+      self.tr._drop_captured_steps()  # the buffers below move
+      n0 = 0 if self.imap is None else self.imap.numel()
+      maps = ([self.imap] if n0 else [])
+      for key, m in self.pending:
+        pad = (-m.numel()) % 4       # 16-byte aligned views
+        self.entries[key] = (n0, m.numel())
+        maps.append(torch.nn.functional.pad(m, (0, pad), value=-1))
+        n0 += m.numel() + pad
+      self.imap = torch.cat(maps)
+      self.wp = torch.empty(n0, dtype=torch.float32, device=self.imap.device)
+      self.pending = []
+
+  def refresh(self):
+    """Once per optimisation step, after the epoch moved: this step's packed filters and padded biases, one gather."""
+    self.merge()
+    if self.imap is not None and getattr(self.tr, 'prepack', True):
+      check(rn.lib().ra_gather_f32(ptr(self.tr.bucket.param), ptr(self.imap), self.imap.numel(), ptr(self.wp), rn.stream_ptr()),
+            'ra_gather_f32')
+      self.filled = self.tr._pack_epoch
+
+
 def _pack_dev(w, cin_w, cout, cin, cmap_t, transposed, cache=None):
   cache = _PACK if cache is None else cache
   key = (w.data_ptr(), w._version, int(cin_w), int(cout), int(cin), 0 if cmap_t is None else cmap_t.data_ptr(), bool(transposed))
   hit = cache.get(key)
   if hit is not None:
     return hit[1]
+  if isinstance(cache, _PackCache):
+    pre = cache.lookup(('w',) + key[2:], w, lambda pos: _pack_dev_now(pos, cin_w, cout, cin, cmap_t, transposed))
+    if pre is not None:
+      cache[key] = (w, pre)
+      return pre
   out = _pack_dev_now(w, cin_w, cout, cin, cmap_t, transposed)
   cache[key] = (w, out)
   return out
@@ -361,7 +438,9 @@ class ConvBNActPool(torch.autograd.Function):
       key = ('shift', b.data_ptr(), b._version, cp)
       hit = cache.get(key)
       if hit is None:
-        hit = cache[key] = (b, torch.nn.functional.pad(b.detach(), (0, cp - cout)))
+        pre = cache.lookup(('b', cp), b.detach(), lambda pos: torch.nn.functional.pad(pos, (0, cp - cout))) \
+            if isinstance(cache, _PackCache) else None
+        hit = cache[key] = (b, pre if pre is not None else torch.nn.functional.pad(b.detach(), (0, cp - cout)))
       shift = hit[1]
     use_bn = gamma is not None
     bf = bool(meta.get('bf16'))
@@ -698,7 +777,7 @@ class ConvStackFn(torch.autograd.Function):
     else:
       du, rc = torch.empty_like(U), rn.RA_E_SHAPE
       sflags = (1 if U.dtype == torch.bfloat16 else 0) | (2 if dY.dtype == torch.bfloat16 else 0)  # the bf16 mode's storage
-      if cout % 4 == 0:
+      if cout % 4 == 0 or not sflags:  # (a small one-channel layer: one workgroup per timestep of the same launch)
         dgam, dbet, ws = _f(G, cout, device=dev), _f(G, cout, device=dev), _f(G * nbn, device=dev)
         if sflags:
           rc = rn.lib().ra_bn_act_pool_bwd_grouped_bf16_f32(ptr(U), ptr(dY), ptr(info['tabs']), G, _C.c_float(BN_EPS), int(relu),
@@ -893,6 +972,23 @@ class _CtrlStepBuffers(object):
     self.armed = False
     g, hid, Cf, it = self.trainer.bucket.grad_of, self.hid, self.Cf, self.iters
     n = self.T * self.B * it
+    SF, G = self.SF, self.G
+    if Cf % 16 == 0 and hid % 16 == 0 and getattr(self.trainer, 'own_gemm', True):
+      # four launches of the library's short-K GEMM (csrc/ra_gemm.hip): the bias gradients ride along as one more output row,
+      # and the LSTM's product lands directly in its eight weight / four bias tensors through a pointer table
+      if getattr(self, '_seg', None) is None:
+        self._seg = torch.tensor([g['ctrl_lstm_w_x' + k].data_ptr() for k in 'ifou'] + [g['ctrl_lstm_w_h' + k].data_ptr() for k in 'ifou'] +
+                                 [g['ctrl_lstm_b_' + k].data_ptr() for k in 'ifou'], dtype=torch.int64, device=self.save.device)
+      base, f4 = self.save.data_ptr(), 4
+      gemm = lambda *a: check(rn.lib().ra_gemm_tn_acc_f32(*a, rn.stream_ptr()), 'ra_gemm_tn_acc_f32')
+      gemm(base, SF, ptr(self.dpre), 4 * hid, n, Cf + hid, 4 * hid, 0, None, 0, None, ptr(self._seg), Cf, hid)
+      # glimpse MLP layer 0 reads h after the LSTM of (b, it) = the h half of iteration it + 1's LSTM input: A one row ahead of
+      # B, the last iteration of every image skipped
+      gemm(base + f4 * (SF + Cf), SF, ptr(self.dz1), hid, n - 1, hid, hid, it, ptr(g['glimpse_mlp_w_0']), hid, ptr(g['glimpse_mlp_b_0']),
+           None, 0, 0)
+      gemm(base + f4 * (Cf + 6 * hid), SF, ptr(self.dlog), G, n, hid, G, 0, ptr(g['glimpse_mlp_w_1']), G, ptr(g['glimpse_mlp_b_1']), None, 0, 0)
+      gemm(ptr(self.hfin), hid, ptr(self.dco), 9, self.T * self.B, hid, 9, 0, ptr(g['ctrl_mlp_w_0']), 9, ptr(g['ctrl_mlp_b_0']), None, 0, 0)
+      return
     rows = self.save.view(n, self.SF)
     ones = _const('ones', n, rows.device, lambda: torch.ones(n, dtype=torch.float32, device=rows.device))
     D = self.dpre.view(n, 4 * hid)
@@ -1197,7 +1293,7 @@ class TrainStep(object):
     import torch.distributed as dist
     self.bucket = GradBucket(model)
     self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else int(world)
-    self._pack = {}  # this trainer's per-step cache of packed filters / padded biases / packed LSTM weights
+    self._pack = _PackCache(self)  # this trainer's per-step cache of packed filters / padded biases / packed LSTM weights
     self._wgrad_parts = _DeferredWgrads()
     self._slabs, self._bn_tabs = {}, {}  # the batched-backward step's [T, ...] buffers and per-layer BatchNorm pointer tables
     self._graphs = {}
@@ -1603,6 +1699,7 @@ class TrainStep(object):
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
     self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
+    self._pack.refresh()  # this step's packed filters and padded biases: one gather over the parameter bucket
     self._wgrad_parts.reset()
     if getattr(self, '_ctl', None) is not None:
       self._ctl.begin_step()
@@ -1812,6 +1909,8 @@ class TrainStep(object):
 
   # ------------------------------------------------------------------ one optimisation step
   use_graph = True  # capture forward + backward + EMA of a repeated step shape in one HIP graph
+  prepack = os.environ.get('RA_PREPACK', '1') != '0'    # every filter packed / bias padded by ONE gather per step (_PackCache); False: one launch per layer
+  own_gemm = os.environ.get('RA_OWN_GEMM', '1') != '0'   # the controller's parameter-gradient products on ra_gemm_tn_acc_f32; False: torch.mm / addmm / addmv
 
   def _grads_and_stats(self, x, y_gt, s_gt, knobs, generator, extra):
     """zero_grad + forward + backward + BN EMA update: everything of a step that is pure device work."""
@@ -1858,6 +1957,7 @@ class TrainStep(object):
       st['knobs'] = {k: v.clone() for k, v in knobs.items()}
       st['sched'] = torch.tensor(sched, dtype=torch.float32, device=dev)
       self._sched = st['sched']
+      self._pack.merge()  # the eager first step met every filter geometry: the captured step packs them with one gather
       torch.cuda.synchronize()
       g = torch.cuda.CUDAGraph()
       with rn.quiet_capture(), torch.cuda.graph(g):
@@ -1962,6 +2062,7 @@ class BoxTrainStep(TrainStep):
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
     self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
+    self._pack.refresh()
     self._wgrad_parts.reset()
     if getattr(self, '_ctl', None) is not None:
       self._ctl.begin_step()

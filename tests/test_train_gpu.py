@@ -253,7 +253,11 @@ def test_canvas_gradient_vs_oracle(cuda, case):
     over.update(disable_overwrite=True)
   # two timesteps: with three, this random network turns float32 round-off into 11 % in single BatchNorm gradients even
   # in a plain-torch float32 evaluation of the ORACLE's graph (the canvas gradient adds a path through every later step)
-  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6, **over)
+  # and a weight draw with no ReLU / max-pool kink within float32 round-off of flipping: with seed 3 a ONE-ulp change of the
+  # output layer's batch mean at timestep 0 (a different summation order) moved single BatchNorm gradients of timestep 1 by
+  # 29 % — in either direction of the change the float64 oracle cannot say which side float32 should land on
+  # (tools/step_sequence.py era probe: seeds 5 and 9 agree to 0.4 % / 1.4 % with every summation order tried)
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6, seed=5, **over)
   B, T, H, W = 2, 2, 64, 64
   rng = np.random.RandomState(5)
   knobs, step = None, 0
@@ -913,7 +917,7 @@ def test_fused_controller_equals_library_path(cuda, knob):
   saved rows; csrc/ra_ctrl_train.hip) against the same graph on library GEMMs / element-wise ops under autograd: loss
   and every gradient.  (The library path itself is checked against the float64 oracle above.)"""
   import full_model
-  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, **(KNOB_OPT if knob else {}))
+  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, seed=5, **(KNOB_OPT if knob else {}))  # (seed: see test_canvas_gradient_vs_oracle)
   rng = np.random.RandomState(5)
   B, T, H, W = 2, 3, 64, 64
   kd = None
