@@ -118,6 +118,9 @@ __device__ inline void load_window(const typename Q4<UB>::T *u, int b, int yo, i
     w[k] = Q4<UB>::ld(u, ((b * H + yo * POOL + (k / POOL)) * W + xo * POOL + (k % POOL)) * C4 + cg);
 }
 
+template <int POOL>
+constexpr int kRowsPerIter = POOL == 1 ? 4 : 1;  // output rows a thread of the float4 BatchNorm kernels handles per loop iteration
+
 template <int POOL, bool UB = false, bool YB = false>
 __global__ __launch_bounds__(256) void bn_act_pool_v4_kernel(const typename Q4<UB>::T *u, const float *mean, const float *var,
                                                              const float *gamma, const float *beta, float eps, int relu,
@@ -128,19 +131,31 @@ __global__ __launch_bounds__(256) void bn_act_pool_v4_kernel(const typename Q4<U
   const int xo = er >> lg, cg = er & (C4 - 1);
   const BnConst k = bn_const(mean, var, gamma, beta, eps, 4 * cg);
   const float lo = relu ? 0.f : -__builtin_inff();
-  for (int row = blockIdx.y; row < B * Ho; row += gridDim.y) {
-    const int b = row / Ho, yo = row - b * Ho;
-    f32x4 w[POOL * POOL];
-    load_window<POOL, UB>(u, b, yo, xo, H, W, C4, cg, w);
-    f32x4 best;
+  // kRowsPerIter<POOL> rows per iteration, every load issued before the first use: a thread of the unpooled form moved 16
+  // bytes per round trip (3.5 TB/s on the full-resolution layers; the pooled form's four loads per thread ran at 5.7)
+  constexpr int RU = kRowsPerIter<POOL>;
+  const int rows = B * Ho;
+  for (int row0 = blockIdx.y * RU; row0 < rows; row0 += gridDim.y * RU) {
+    f32x4 w[RU][POOL * POOL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float m = -__builtin_inff();
+    for (int r = 0; r < RU; ++r)
+      if (row0 + r < rows) {
+        const int b = (row0 + r) / Ho, yo = (row0 + r) - b * Ho;
+        load_window<POOL, UB>(u, b, yo, xo, H, W, C4, cg, w[r]);
+      }
 #pragma unroll
-      for (int q = 0; q < POOL * POOL; ++q) m = fmaxf(m, fmaxf((w[q][i] - k.mu[i]) * k.g[i] + k.be[i], lo));
-      best[i] = m;
-    }
-    Q4<YB>::st(y, (row * Wo + xo) * C4 + cg, best);
+    for (int r = 0; r < RU; ++r)
+      if (row0 + r < rows) {
+        f32x4 best;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float m = -__builtin_inff();
+#pragma unroll
+          for (int q = 0; q < POOL * POOL; ++q) m = fmaxf(m, fmaxf((w[r][q][i] - k.mu[i]) * k.g[i] + k.be[i], lo));
+          best[i] = m;
+        }
+        Q4<YB>::st(y, ((row0 + r) * Wo + xo) * C4 + cg, best);
+      }
   }
 }
 
@@ -239,16 +254,29 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_v4_kernel(const typename Q4<UB>
     db[i] = dbeta[4 * cg + i] * inv_n;
     dg[i] = dgamma[4 * cg + i] * inv_n;
   }
-  for (int row = blockIdx.y; row < B * Ho; row += gridDim.y) {
-    const int b = row / Ho, yo = row - b * Ho;
-    f32x4 w[POOL * POOL], dv[POOL * POOL], xh[POOL * POOL];
-    load_window<POOL, UB>(u, b, yo, xo, H, W, C4, cg, w);
-    window_grad<POOL>(w, Q4<DB>::ld(dy, (row * Wo + xo) * C4 + cg), k, lo, relu, dv, xh);
+  constexpr int RU = kRowsPerIter<POOL>;
+  const int rows = B * Ho;
+  for (int row0 = blockIdx.y * RU; row0 < rows; row0 += gridDim.y * RU) {
+    f32x4 w[RU][POOL * POOL], dyv[RU];
 #pragma unroll
-    for (int q = 0; q < POOL * POOL; ++q) {
-      const f32x4 r = var ? k.g * (dv[q] - db - xh[q] * dg) : dv[q];
-      Q4<UB>::st(du, ((b * H + yo * POOL + (q / POOL)) * W + xo * POOL + (q % POOL)) * C4 + cg, r);
-    }
+    for (int r = 0; r < RU; ++r)
+      if (row0 + r < rows) {
+        const int b = (row0 + r) / Ho, yo = (row0 + r) - b * Ho;
+        load_window<POOL, UB>(u, b, yo, xo, H, W, C4, cg, w[r]);
+        dyv[r] = Q4<DB>::ld(dy, ((row0 + r) * Wo + xo) * C4 + cg);
+      }
+#pragma unroll
+    for (int r = 0; r < RU; ++r)
+      if (row0 + r < rows) {
+        const int b = (row0 + r) / Ho, yo = (row0 + r) - b * Ho;
+        f32x4 dv[POOL * POOL], xh[POOL * POOL];
+        window_grad<POOL>(w[r], dyv[r], k, lo, relu, dv, xh);
+#pragma unroll
+        for (int q = 0; q < POOL * POOL; ++q) {
+          const f32x4 rr = var ? k.g * (dv[q] - db - xh[q] * dg) : dv[q];
+          Q4<UB>::st(du, ((b * H + yo * POOL + (q / POOL)) * W + xo * POOL + (q % POOL)) * C4 + cg, rr);
+        }
+      }
   }
 }
 
@@ -775,7 +803,8 @@ int bn_act_pool_impl(const void *u, const float *mean, const float *var, const f
   const size_t total = (size_t)B * (H / pool) * (W / pool) * C;
   if (const int lg = train::v4_log2(C, (size_t)B * H * W * C); lg >= 0) {
     const int C4 = C / 4, rows = B * (H / pool);
-    const dim3 g4(ceil_div((W / pool) * C4, 256), rows < 16384 ? rows : 16384);
+    const int ry = ceil_div(rows, pool == 1 ? train::kRowsPerIter<1> : train::kRowsPerIter<2>);
+    const dim3 g4(ceil_div((W / pool) * C4, 256), ry < 16384 ? ry : 16384);
     hipStream_t st = as_stream(stream);
 #define RA_BNF(P, UB, YB) launch_bn_act_pool_v4<P, UB, YB>(g4, st, u, mean, var, gamma, beta, eps, relu, B, H, W, C4, lg, y)
     if (flags == 0) { if (pool == 2) RA_BNF(2, false, false); else RA_BNF(1, false, false); }
@@ -864,7 +893,8 @@ int bn_bwd_impl(const float *u, const float *dy, const float *mean, const float 
     const int C4 = C / 4, rows = B * (H / pool), gx = ceil_div((W / pool) * C4, 256);
     int gy = train::kRedBlocks / gx;
     if (gy > rows) gy = rows;
-    const dim3 gr(gx, gy), gd(gx, rows < 16384 ? rows : 16384);
+    const int ry = ceil_div(rows, pool == 1 ? train::kRowsPerIter<1> : train::kRowsPerIter<2>);
+    const dim3 gr(gx, gy), gd(gx, ry < 16384 ? ry : 16384);
     if (const int rc = dispatch_bn_bwd_v4(pool, flags, stages, gr, gd, st, (const void *)u, (const void *)dy, mean, var, gamma, beta, eps, relu,
                                           B, H, W, C, C4, lg, ws, gx * gy, dbeta, dgamma, acc_beta, acc_gamma, (void *)du, inv_n,
                                           (const float *const *)nullptr, (float *const *)nullptr, 1))
@@ -923,7 +953,8 @@ static int bn_bwd_grouped_impl(const void *u, const void *dy, const void *const 
   if (gy > rows) gy = rows;
   const float *const *ct = reinterpret_cast<const float *const *>(tabs);
   float *const *mt = reinterpret_cast<float *const *>(const_cast<void *const *>(tabs));
-  const dim3 gr(gx, gy, G), gd(gx, rows < 16384 ? rows : 16384, G);
+  const int ry = ceil_div(rows, pool == 1 ? train::kRowsPerIter<1> : train::kRowsPerIter<2>);
+  const dim3 gr(gx, gy, G), gd(gx, ry < 16384 ? ry : 16384, G);
   const float *nul = nullptr;
   if (const int rc = dispatch_bn_bwd_v4(pool, flags, 3, gr, gd, st, u, dy, nul, nul, nul, nul, eps, relu, B, H, W, C, C4, lg, ws, gx * gy,
                                         dbeta, dgamma, (float *)nullptr, (float *)nullptr, du, inv_n, ct, mt, G))
