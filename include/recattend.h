@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 103
+#define RA_ABI_VERSION 104
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -460,6 +460,12 @@ size_t ra_pair_stats_workspace_floats(int B, int HW);
 int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
                       size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
                       float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream);
+/* ra_pair_stats_f32 with a's planes addressed through strides (in floats, multiples of 4): a[img][row] starts at
+ * img * a_img + row * a_row.  The training step keeps the masks of its T timesteps timestep-major ([T,B,H,W]: a_img = H*W,
+ * a_row = B*H*W) — the pairwise IoU reads them in place instead of through a transposed copy. */
+int ra_pair_stats_strided_f32(const float *a, size_t a_img, size_t a_row, const float *b, int B, int N, int M, int HW, float *ws,
+                              size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard, float *sum_a, float *sum_b,
+                              float *inter, float *sum_a_hard, void *stream);
 /* Soft IoU (modellib.f_iou, modellib.py:124-155) of one map per image, box [B,H,W], against the T rectangles
  * ra_gt_box_f32 fills (params [B,T,8], fields 4..7): iou [B,T] — the row the training graph takes per timestep
  * (full_model.py:744-758) without reading the T rectangle planes. */
@@ -701,6 +707,9 @@ int ra_canvas_step_f32(const float *inp_prev, int C, int canvas_chan, int B, int
                        int knob_stride, float *inp_next, void *stream);
 int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T,
                               int HW, float *out, void *stream);
+/* ... with out[b][n] written at b * o_img + n * o_row (floats, multiples of 4): the gradient of timestep-major masks. */
+int ra_weighted_sum_multi_strided_f32(const float *w, const float *bias, const float *y, int B, int N, int T, int HW,
+                                      float *out, size_t o_img, size_t o_row, void *stream);
 
 /* p[0..n) = value (p 16-byte aligned): the canvas reset `canvas = zeros` (full_model.py:239) and
  * the sigmoid(beta) prefill of y_out behind RA_PASTE_Y_PREFILLED, as a library launch so that the

@@ -27,11 +27,11 @@ constexpr int kPartFloats = 2 * kMaxT * kMaxT + 3 * kMaxT;  // per-(image, chunk
 // partial record layout: [soft inter NxM (32x32)][hard inter][sum a (32)][sum a>0.5][sum b]
 template <int NI, int NJ>
 __global__ __launch_bounds__(256) void pair_stats_kernel(const float *a, const float *b, int N, int M,
-                                                          int HW, int nchunks, float *part) {
+                                                          int HW, int nchunks, float *part, size_t a_img, size_t a_row) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int chunk = blockIdx.x, img = blockIdx.y;
-  const float *ab = a + (size_t)img * N * HW, *bb = b + (size_t)img * M * HW;
+  const float *ab = a + (size_t)img * a_img, *bb = b + (size_t)img * M * HW;  // a[img][row] at img * a_img + row * a_row
   f32x4 accs[NI][NJ], acch[NI][NJ];
   float sa[NI], sah[NI], sb[NJ];
 #pragma unroll
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(const float *a, const f
       const bool ok = (px < HW) & (p0 < px_end);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
-        xa[i][u] = (ok && 16 * i + r < N) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(16 * i + r) * HW + px)
+        xa[i][u] = (ok && 16 * i + r < N) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(16 * i + r) * a_row + px)
                                           : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
@@ -494,9 +494,9 @@ extern "C" size_t ra_pair_stats_workspace_floats(int B, int HW) {
   return (size_t)B * (loss::nchunks_for(HW) + 1) * loss::kPartFloats;  // chunk records + totals
 }
 
-extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
-                                 size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
-                                 float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream) {
+static int pair_stats_impl(const float *a, size_t a_img, size_t a_row, const float *b, int B, int N, int M, int HW, float *ws,
+                           size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
+                           float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream) {
   if (!a || !b || !ws || B <= 0 || N <= 0 || M <= 0 || HW <= 0)
     return fail(RA_E_INVALID, "ra_pair_stats_f32: bad argument");
   if (N > loss::kMaxT || M > loss::kMaxT || HW % 4)
@@ -511,13 +511,13 @@ extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, i
   const dim3 grid(nch, B);
   const int ni = N > 16 ? 2 : 1, nj = M > 16 ? 2 : 1;
   if (ni == 1 && nj == 1)
-    hipLaunchKernelGGL((loss::pair_stats_kernel<1, 1>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+    hipLaunchKernelGGL((loss::pair_stats_kernel<1, 1>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws, a_img, a_row);
   else if (ni == 2 && nj == 2)
-    hipLaunchKernelGGL((loss::pair_stats_kernel<2, 2>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+    hipLaunchKernelGGL((loss::pair_stats_kernel<2, 2>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws, a_img, a_row);
   else if (ni == 1)
-    hipLaunchKernelGGL((loss::pair_stats_kernel<1, 2>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+    hipLaunchKernelGGL((loss::pair_stats_kernel<1, 2>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws, a_img, a_row);
   else
-    hipLaunchKernelGGL((loss::pair_stats_kernel<2, 1>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws);
+    hipLaunchKernelGGL((loss::pair_stats_kernel<2, 1>), grid, dim3(256), 0, st, a, b, N, M, HW, nch, ws, a_img, a_row);
   int rc = launch_status("ra_pair_stats_f32");
   if (rc) return rc;
   float *tot = ws + (size_t)B * nch * loss::kPartFloats;
@@ -526,6 +526,23 @@ extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, i
   hipLaunchKernelGGL(loss::pair_stats_finish_kernel, dim3(B), dim3(256), 0, st, tot, N, M, HW, iou_soft, iou_hard,
                      dice_hard, sum_a, sum_b, inter, sum_a_hard);
   return launch_status("ra_pair_stats_f32");
+}
+
+extern "C" int ra_pair_stats_f32(const float *a, const float *b, int B, int N, int M, int HW, float *ws,
+                                 size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard,
+                                 float *sum_a, float *sum_b, float *inter, float *sum_a_hard, void *stream) {
+  return pair_stats_impl(a, (size_t)N * HW, (size_t)HW, b, B, N, M, HW, ws, ws_floats, iou_soft, iou_hard, dice_hard, sum_a, sum_b, inter,
+                         sum_a_hard, stream);
+}
+
+// the same with a's planes addressed through strides (floats): a[img][row] starts at img * a_img + row * a_row — the
+// training step's masks of all timesteps lie timestep-major ([T,B,H,W]: a_img = H*W, a_row = B*H*W), no transposed copy
+extern "C" int ra_pair_stats_strided_f32(const float *a, size_t a_img, size_t a_row, const float *b, int B, int N, int M, int HW, float *ws,
+                                         size_t ws_floats, float *iou_soft, float *iou_hard, float *dice_hard, float *sum_a, float *sum_b,
+                                         float *inter, float *sum_a_hard, void *stream) {
+  if ((a_img | a_row) & 3) return fail(RA_E_SHAPE, "ra_pair_stats_strided_f32: strides must be multiples of 4 floats");
+  return pair_stats_impl(a, a_img, a_row, b, B, N, M, HW, ws, ws_floats, iou_soft, iou_hard, dice_hard, sum_a, sum_b, inter, sum_a_hard,
+                         stream);
 }
 
 extern "C" size_t ra_gt_box_workspace_floats(int B, int T) {

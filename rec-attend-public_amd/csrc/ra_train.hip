@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void subsample_odd_kernel(const float *x, int 
 // ---- out[b,n,p] = sum_t w[b,n,t] * y[b,t,p] + bias[b,n]: the adjoint of the pairwise soft IoU ----
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void weighted_sum_multi_kernel(const float *w, const float *bias, const float *y, int N,
-                                                                 int T, int HW, float *out) {
+                                                                 int T, int HW, float *out, size_t o_img, size_t o_row) {
   const int b = blockIdx.z, n = blockIdx.y;
   const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (e >= HW) return;
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void weighted_sum_multi_kernel(const float *w,
     const float wt = w[((size_t)b * N + n) * T + t];
     if (wt != 0.f) acc += wt * *reinterpret_cast<const f32x4 *>(yb + (size_t)t * HW);  // uniform per (b, n)
   }
-  *reinterpret_cast<f32x4 *>(out + ((size_t)b * N + n) * HW + e) = acc;
+  *reinterpret_cast<f32x4 *>(out + (size_t)b * o_img + (size_t)n * o_row + e) = acc;
 }
 
 // ---- the canvas of the next timestep (full_model.py:826-848), written straight into the next packed controller-CNN
@@ -1037,14 +1037,22 @@ extern "C" int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, 
   return launch_status("ra_subsample_odd_f32");
 }
 
+extern "C" int ra_weighted_sum_multi_strided_f32(const float *w, const float *bias, const float *y, int B, int N, int T, int HW,
+                                                 float *out, size_t o_img, size_t o_row, void *stream);
 extern "C" int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y, int B, int N, int T, int HW,
                                          float *out, void *stream) {
+  return ra_weighted_sum_multi_strided_f32(w, bias, y, B, N, T, HW, out, (size_t)N * HW, (size_t)HW, stream);
+}
+// out[b][n] at b * o_img + n * o_row (floats): the gradient of timestep-major masks is written timestep-major
+extern "C" int ra_weighted_sum_multi_strided_f32(const float *w, const float *bias, const float *y, int B, int N, int T, int HW,
+                                                 float *out, size_t o_img, size_t o_row, void *stream) {
+  if ((o_img | o_row) & 3) return fail(RA_E_SHAPE, "ra_weighted_sum_multi_strided_f32: strides must be multiples of 4 floats");
   if (!w || !y || !out || B <= 0 || N <= 0 || T <= 0 || HW <= 0)
     return fail(RA_E_INVALID, "ra_weighted_sum_multi_f32: bad argument");
   if (HW % 4 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15))
     return fail(RA_E_SHAPE, "ra_weighted_sum_multi_f32: H*W %% 4 and 16-byte aligned tensors required");
   hipLaunchKernelGGL(train::weighted_sum_multi_kernel, dim3(ceil_div(HW, 1024), N, B), dim3(256), 0, as_stream(stream), w,
-                     bias, y, N, T, HW, out);
+                     bias, y, N, T, HW, out, o_img, o_row);
   return launch_status("ra_weighted_sum_multi_f32");
 }
 

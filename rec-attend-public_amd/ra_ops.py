@@ -526,12 +526,16 @@ STAT_NAMES = ('loss', 'box_loss', 'segm_loss', 'conf_loss', 'iou_soft', 'iou_sof
               'count_acc', 'dic', 'dic_abs')  # RA_STAT_* order
 
 
-def pair_stats(a, b, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_a', 'sum_b')):
+def pair_stats(a, b, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_a', 'sum_b'), a_tmajor=False):
   """One pass over a [B,N,H,W] and b [B,M,H,W]: pairwise soft IoU, IoU / DICE of (a > 0.5), and
-  the per-instance sums (modellib.f_iou / f_dice pairwise=True, full_model.py:981,1064-1073)."""
+  the per-instance sums (modellib.f_iou / f_dice pairwise=True, full_model.py:981,1064-1073).
+  a_tmajor: a is stored [N,B,H,W] (the training step's timestep-major masks), read in place through strides."""
   a, b = a.contiguous(), b.contiguous()
   _need_cuda(a, b)
-  B, N, H, W = a.shape
+  if a_tmajor:
+    N, B, H, W = a.shape
+  else:
+    B, N, H, W = a.shape
   M = b.shape[1]
   dev = a.device
   n = rn.lib().ra_pair_stats_workspace_floats(B, H * W)
@@ -540,6 +544,11 @@ def pair_stats(a, b, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_a', 'sum_b'
   for k, shp in (('iou_soft', (B, N, M)), ('iou_hard', (B, N, M)), ('dice_hard', (B, N, M)),
                  ('sum_a', (B, N)), ('sum_b', (B, M)), ('inter', (B, N, M)), ('sum_a_hard', (B, N))):
     out[k] = torch.empty(shp, dtype=torch.float32, device=dev) if k in want else None
+  if a_tmajor:
+    check(rn.lib().ra_pair_stats_strided_f32(ptr(a), H * W, B * H * W, ptr(b), B, N, M, H * W, ptr(ws), n, ptr(out['iou_soft']),
+                                             ptr(out['iou_hard']), ptr(out['dice_hard']), ptr(out['sum_a']), ptr(out['sum_b']),
+                                             ptr(out['inter']), ptr(out['sum_a_hard']), rn.stream_ptr()), 'ra_pair_stats_strided_f32')
+    return out
   check(rn.lib().ra_pair_stats_f32(ptr(a), ptr(b), B, N, M, H * W, ptr(ws), n, ptr(out['iou_soft']),
                                    ptr(out['iou_hard']), ptr(out['dice_hard']), ptr(out['sum_a']),
                                    ptr(out['sum_b']), ptr(out['inter']), ptr(out['sum_a_hard']),

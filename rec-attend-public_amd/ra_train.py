@@ -817,15 +817,16 @@ class ConvStackFn(torch.autograd.Function):
 
 class PairIoU(torch.autograd.Function):
   """modellib.f_iou(a, b, pairwise=True) (modellib.py:124-155) with its gradient in a: one
-  streaming MFMA pass forward (K8), one weighted-sum pass backward."""
+  streaming MFMA pass forward (K8), one weighted-sum pass backward.  tmajor: a (and its gradient) lie [N,B,H,W] — the
+  stacked training step's masks, timestep-major as its sequential phase wrote them; read and written through strides."""
 
   @staticmethod
-  def forward(ctx, a, b):
+  def forward(ctx, a, b, tmajor=False):
     a, b = a.contiguous(), b.contiguous()
-    st = ops.pair_stats(a, b, want=('iou_soft', 'inter', 'sum_a', 'sum_b'))
+    st = ops.pair_stats(a, b, want=('iou_soft', 'inter', 'sum_a', 'sum_b'), a_tmajor=tmajor)
     ctx.save_for_backward(b, st['inter'], st['sum_a'], st['sum_b'])
     ctx.hw = a.shape[2] * a.shape[3]
-    ctx.shape = a.shape
+    ctx.shape, ctx.tmajor = a.shape, bool(tmajor)
     return st['iou_soft']
 
   @staticmethod
@@ -834,11 +835,17 @@ class PairIoU(torch.autograd.Function):
     U = sa[:, :, None] + sb[:, None, :] - I + 1e-5 * ctx.hw
     c1 = (g * (U + I) / (U * U)).contiguous()     # d iou / d a_p = b_p (U + I) / U^2 - I / U^2
     c0 = (-(g * I / (U * U)).sum(dim=2)).contiguous()
+    if ctx.tmajor:
+      N, B, H, W = ctx.shape
+      out = torch.empty((N, B, H, W), dtype=torch.float32, device=g.device)
+      check(rn.lib().ra_weighted_sum_multi_strided_f32(ptr(c1), ptr(c0), ptr(b), B, N, b.shape[1], H * W, ptr(out), H * W, B * H * W,
+                                                       rn.stream_ptr()), 'ra_weighted_sum_multi_strided_f32')
+      return out, None, None
     B, N, H, W = ctx.shape
     out = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
     check(rn.lib().ra_weighted_sum_multi_f32(ptr(c1), ptr(c0), ptr(b), B, N, b.shape[1], H * W, ptr(out),
                                              rn.stream_ptr()), 'ra_weighted_sum_multi_f32')
-    return out, None
+    return out, None, None
 
 
 class LSTMCell(torch.autograd.Function):
@@ -1177,13 +1184,18 @@ class AttnExtract(torch.autograd.Function):
   on the dense-bank operator."""
 
   @staticmethod
-  def forward(ctx, x, ctr, size, lg_var, gamma, Fh, Fw):
+  def forward(ctx, x, ctr, size, lg_var, gamma, Fh, Fw, out=None, pre=None):
+    """out: where the patch is written (a [T, ...] slab's slice); pre: the patch, computed before (the stacked step's
+    sequential phase ran this extract timestep by timestep: its graph node only needs the backward)."""
     ctx.set_materialize_grads(False)
     x = x.contiguous()
     B, H, W, C = x.shape
     rec = attn_record(ctr, size, lg_var, attn_gamma=gamma)
-    patch = torch.empty((B, Fh, Fw, C), dtype=torch.float32, device=x.device)
-    ops.extract_direct(x, 0, rec, Fh, Fw, C, True, patch)
+    if pre is not None:
+      patch = pre[0]   # (wrapped in a list: a tensor argument returned as the output would be seen as an in-place pass-through)
+    else:
+      patch = out if out is not None else torch.empty((B, Fh, Fw, C), dtype=torch.float32, device=x.device)
+      ops.extract_direct(x, 0, rec, Fh, Fw, C, True, patch)
     ctx.save_for_backward(x, rec)
     ctx.dims = (H, W, int(Fh), int(Fw))
     return patch
@@ -1191,7 +1203,7 @@ class AttnExtract(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g):
     if g is None:
-      return (None,) * 7
+      return (None,) * 9
     x, rec = ctx.saved_tensors
     H, W, Fh, Fw = ctx.dims
     out = ops.resample_bwd(ops.RESAMPLE_READ, rec, H, W, Fh, Fw, X=x, Q=g.contiguous(), scale=rec[:, 6])
@@ -1201,7 +1213,7 @@ class AttnExtract(torch.autograd.Function):
       fyT = ops.gaussian_filter(col(0), col(2), col(4), H, Fh).transpose(1, 2).contiguous()   # [B,Fh,H]
       fxT = ops.gaussian_filter(col(1), col(3), col(5), W, Fw).transpose(1, 2).contiguous()   # [B,Fw,W]
       dx = ops.extract_patch_dense((g * rec[:, 6].view(-1, 1, 1, 1)).contiguous(), fyT, fxT)    # [B,H,W,C]
-    return dx, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None
+    return dx, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None
 
 
 class AttnPaste(torch.autograd.Function):
@@ -1210,18 +1222,21 @@ class AttnPaste(torch.autograd.Function):
   gamma gradient from one banded launch."""
 
   @staticmethod
-  def forward(ctx, patch, ctr, size, lg_var, gamma, H, W, Fh, Fw):
+  def forward(ctx, patch, ctr, size, lg_var, gamma, H, W, Fh, Fw, out=None, pre=None):
+    """out / pre: as AttnExtract's (the plane(s) to write into; the planes computed before)."""
     ctx.set_materialize_grads(False)
     B, dev = ctr.shape[0], ctr.device
     box = patch is None
     rec = attn_record(ctr, size, lg_var, box_gamma=gamma) if box else attn_record(ctr, size, lg_var, y_lg_gamma=gamma)
-    y = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    y = pre[0] if pre is not None else (out if out is not None else torch.empty((B, H, W), dtype=torch.float32, device=dev))
     if box:
-      ops.attn_box_direct(rec, H, W, Fh, Fw, -5.0, y, H * W)
+      if pre is None:
+        ops.attn_box_direct(rec, H, W, Fh, Fw, -5.0, y, H * W)
       ctx.save_for_backward(rec, y)
     else:
       patch = patch.reshape(B, Fh, Fw, 1).contiguous()
-      ops.paste_direct(patch, 0, rec, -5.0, False, y, H * W, H, W)
+      if pre is None:
+        ops.paste_direct(patch, 0, rec, -5.0, False, y, H * W, H, W)
       ctx.save_for_backward(rec, y, patch)
     ctx.dims, ctx.box = (int(H), int(W), int(Fh), int(Fw)), box
     return y
@@ -1229,7 +1244,7 @@ class AttnPaste(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g):
     if g is None:
-      return (None,) * 9
+      return (None,) * 11
     H, W, Fh, Fw = ctx.dims
     if ctx.box:
       rec, y = ctx.saved_tensors
@@ -1239,7 +1254,7 @@ class AttnPaste(torch.autograd.Function):
       rec, y, patch = ctx.saved_tensors
       dp = torch.empty_like(patch)
       out = ops.resample_bwd(ops.RESAMPLE_WRITE, rec, H, W, Fh, Fw, dY=g.contiguous(), Y=y, Q=patch, E=dp)
-    return dp, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None
+    return dp, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None, None, None
 
 
 def _flat_bn_statistics(trainer):
@@ -1507,7 +1522,9 @@ class TrainStep(object):
                                P['glimpse_mlp_b_0'].detach(), P['glimpse_mlp_w_1'].detach(), P['glimpse_mlp_b_1'].detach(),
                                P['ctrl_mlp_w_0'].detach(), P['ctrl_mlp_b_0'].detach(), bufs, 'all')
     cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
-    box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
+    # the planes the sequential phase computed (same window parameters, timestep by timestep): the nodes only add the backward
+    pre = (lambda name, shape: [self._slab(name, T, shape).view((N,) + shape[1:])]) if self.reuse_attn_planes else (lambda name, shape: None)
+    box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw, None, pre('box', (B, H, W)))
     iou_rows = None
     if gt_corners is not None:  # use_knob + use_iou_box: the [B,T,T] matrix of corner IoUs the boxes are matched and scored on
       import modellib          # (modellib.f_iou_box, full_model.py:750-754,931-934), differentiable through the predicted corners
@@ -1519,7 +1536,7 @@ class TrainStep(object):
       rep = lambda t: t.unsqueeze(0).expand((T,) + tuple(t.shape)).reshape((N,) + tuple(t.shape[1:])).contiguous()
       knob_all = knob_box.reshape(B, T).t().reshape(N).contiguous()
       ctr, size = KnobMix.apply(ctr, size, match_all, rep(gt_windows[0]), rep(gt_windows[1]), knob_all)
-    x_patch = AttnExtract.apply(inp_all, ctr, size, lg_var, ag, Fh, Fw)
+    x_patch = AttnExtract.apply(inp_all, ctr, size, lg_var, ag, Fh, Fw, None, pre('xpatch', (B, Fh, Fw, inp_all.shape[3])))
     h_acnn = self._stack_layers(x_patch, 'attn_cnn', d['acnn_nlayers'])
     core = h_acnn[-1]
     skips = None
@@ -1527,14 +1544,16 @@ class TrainStep(object):
       rev = h_acnn[::-1][1:] + [x_patch]
       skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None for i in range(1, d['adcnn_nlayers'])]
     y_patch = self._stack_layers(core, 'attn_dcnn', d['adcnn_nlayers'], skips)[-1]
-    y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)
+    y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw, None, pre('ymask', (B, H, W)))
     if d['disable_overwrite']:
       y = (1.0 - inp_all[..., cc]) * y
     s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(N, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
     to_bt = lambda t: t.view((T, B) + tuple(t.shape[1:])).transpose(0, 1).contiguous()
-    return to_bt(y), to_bt(s).reshape(B, T), to_bt(box), to_bt(cn), to_bt(ls), iou_rows
+    # the masks and boxes stay timestep-major [T,B,H,W]: the pairwise IoU reads them (and writes their gradient) through strides
+    return y.view(T, B, H, W), to_bt(s).reshape(B, T), box.view(T, B, H, W), to_bt(cn), to_bt(ls), iou_rows
 
   fuse_controller = True  # the controller of a timestep as one forward and one backward launch
+  reuse_attn_planes = True  # stacked step: box / patch / mask planes of the sequential phase feed the stacked graph (no second forward)
   bf16_storage = os.environ.get('RA_BF16_STORE', '1') != '0'  # bf16 mode, stacked step: U / Y / dY / dU stored as bf16 (False: operands only)
   seq_ctrl_split = os.environ.get('RA_TRAIN_CTRL_SPLIT', '1') != '0'  # stacked step, sequential phase: the decode loop's 16-workgroup controller
 
@@ -1749,7 +1768,8 @@ class TrainStep(object):
         # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
         cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
         # attention box: sigmoid(box_gamma * extract_patch(ones, F_y^T, F_x^T) - 5) (full_model.py:738-741)
-        box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
+        keep = batched and self.reuse_attn_planes  # the planes go straight into the [T, ...] slabs the stacked graph reads
+        box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw, self._slab('box', T, (B, H, W))[tt] if keep else None)
         if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
           if fixed:
             gmatch = None
@@ -1770,13 +1790,11 @@ class TrainStep(object):
             gsel_box = gmatch
           # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)
           ctr, size = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt])
-        x_patch = AttnExtract.apply(inp if canvas_grad else inp.detach(), ctr, size, lg_var, ag, Fh, Fw)
-        if batched:  # the attention CNN's first input of every timestep, contiguous over T for the stacked filter gradient
-          slot = self._slab('xpatch', T, tuple(x_patch.shape))[tt]
-          slot.copy_(x_patch)
-          x_patch = slot
-          if use_knob:
-            tape_match.append(gsel_box)
+        # (batched: the attention CNN's first input of every timestep, contiguous over T for the stacked filter gradient)
+        x_patch = AttnExtract.apply(inp if canvas_grad else inp.detach(), ctr, size, lg_var, ag, Fh, Fw,
+                                    self._slab('xpatch', T, (B, Fh, Fw, inp.shape[3]))[tt] if batched else None)
+        if batched and use_knob:
+          tape_match.append(gsel_box)
         h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
         core = h_acnn[-1]
         skips = None
@@ -1786,7 +1804,8 @@ class TrainStep(object):
           skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None
                             for i in range(1, d['adcnn_nlayers'])]
         y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
-        y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw)  # [B,H,W]
+        y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw,
+                            self._slab('ymask', T, (B, H, W))[tt] if keep else None)  # [B,H,W]
         if d['disable_overwrite']:
           y = (1.0 - inp[..., cc]) * y
         # (the score is not an input of the next timestep: the stacked graph computes it once for all timesteps)
@@ -1839,10 +1858,11 @@ class TrainStep(object):
     # reference stacks the per-timestep box IoUs (:931-934): for use_iou_box = False (f_inter / f_union of the
     # predicted box against every GT box) the same numbers as the pairwise f_iou; with use_iou_box the stacked
     # corner IoUs (iou_box_steps, differentiable through the corners) are the matrix.
+    tm = bool(batched)  # the stacked graph's masks / boxes are timestep-major [T,B,H,W] (PairIoU reads them through strides)
     ident = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
 
     def matched_iou(a, b, iou=None, pre=None):
-      iou = PairIoU.apply(a, b) if iou is None else iou
+      iou = PairIoU.apply(a, b, tm) if iou is None else iou
       if fixed:
         m = ident
       elif pre is not None:  # matched already (both matchings in one launch, below)
@@ -1868,7 +1888,7 @@ class TrainStep(object):
       # other on a side stream — no fork in the captured graph (31.5 -> 30.4 ms per step; starting the matchings early
       # from the sequential phase's masks on a side stream, under the stacked forward, loses to the fork it needs: 31.1,
       # and a second fork makes the graph replay 1.5x slower: 47.9 ms)
-      i_soft, i_box = PairIoU.apply(y_out, y_gt), PairIoU.apply(attn_box, box_gt)
+      i_soft, i_box = PairIoU.apply(y_out, y_gt, tm), PairIoU.apply(attn_box, box_gt, tm)
       m2, st2 = ops.segm_match(torch.cat([i_soft.detach(), i_box.detach()], dim=0), torch.cat([s_gt, s_gt], dim=0))
       iou_box, m_box = matched_iou(attn_box, box_gt, i_box, (m2[B:], None))
       iou_soft, m = matched_iou(y_out, y_gt, i_soft, (m2[:B], st2))
@@ -1893,7 +1913,7 @@ class TrainStep(object):
       params = torch.cat([cn_bt, ls_bt], dim=2) if batched else torch.cat([torch.stack(cn_list, dim=1), torch.stack(ls_list, dim=1)], dim=2)
       box_loss = modellib.f_match_loss(params, params_gt, m_box, T, modellib.f_squared_err if blf == 'mse' else modellib.f_huber)
     if opt.get('segm_loss_fn', 'iou') == 'wt_cov':  # modellib.f_weighted_coverage (modellib.py:292-302)
-      iou_p = PairIoU.apply(y_out, y_gt)
+      iou_p = PairIoU.apply(y_out, y_gt, tm)
       sg = ops.pair_stats(y_gt, y_gt, want=('sum_b',))['sum_b']
       wts = sg / (sg.sum(dim=1, keepdim=True) + (sg == 0).to(sg.dtype))
       segm_loss = -(iou_p.max(dim=1)[0] * wts).sum() / B
@@ -1903,7 +1923,7 @@ class TrainStep(object):
     conf = (-ms * torch.log(s_min + 1e-5) - (1 - ms) * torch.log(1 - s_max + 1e-5)).sum() / B / T
     loss = box_loss + segm_loss + float(opt.get('loss_mix_ratio', 1.0)) * conf
     pieces = {'loss': loss, 'box_loss': box_loss, 'segm_loss': segm_loss, 'conf_loss': conf, 'iou_soft': iou_soft,
-              'iou_soft_box': iou_box, 'match': m, 'match_box': m_box, 'y_out': y_out, 's_out': s_out,
+              'iou_soft_box': iou_box, 'match': m, 'match_box': m_box, 'y_out': y_out.transpose(0, 1) if tm else y_out, 's_out': s_out,
               '_match_status': statuses}
     return loss, pieces, stats
 

@@ -190,3 +190,50 @@ def test_controller_parameter_gradients_own_gemm_equals_library(cuda):
   for k, v in res[False][1].items():
     a, b = res[True][1][k].cpu().numpy(), v.cpu().numpy()
     assert np.abs(a - b).max() <= 2e-5 * max(1e-3, np.abs(b).max()), (k, np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_pairwise_iou_reads_timestep_major_masks_in_place(cuda):
+  """PairIoU(tmajor=True) on a [N,B,H,W] tensor against PairIoU on its [B,N,H,W] transposed copy: the same kernels through
+  strides — IoU matrix and gradient bit for bit (ra_pair_stats_strided_f32 / ra_weighted_sum_multi_strided_f32)."""
+  import ra_train
+  rng = np.random.RandomState(0)
+  N, B, M, H, W = 5, 3, 4, 16, 24
+  a_t = torch.tensor(rng.rand(N, B, H, W).astype(np.float32), device=cuda, requires_grad=True)
+  a_b = a_t.detach().transpose(0, 1).contiguous().requires_grad_(True)
+  b = torch.tensor((rng.rand(B, M, H, W) > 0.6).astype(np.float32), device=cuda)
+  g = torch.tensor(rng.randn(B, N, M).astype(np.float32), device=cuda)
+  i_t = ra_train.PairIoU.apply(a_t, b, True)
+  i_b = ra_train.PairIoU.apply(a_b, b)
+  assert torch.equal(i_t, i_b)
+  (i_t * g).sum().backward()
+  (i_b * g).sum().backward()
+  assert torch.equal(a_t.grad.transpose(0, 1), a_b.grad)
+
+
+def test_stacked_step_reuses_the_sequential_phase_planes(cuda):
+  """The stacked graph's box / patch / mask nodes take the planes the sequential phase wrote (no second forward of the
+  extract and the two pastes): same loss and gradients as recomputing them — bit for bit when both phases run the same
+  controller kernel."""
+  import full_model
+  import ra_train
+  from test_train_gpu import _case, KNOB_OPT
+  opt, P, x, y_gt, s_gt = _case(T=3, B=2, wmul=0.6, seed=5, **KNOB_OPT)
+  res = {}
+  for reuse in (True, False):
+    m = full_model.get_model(opt).load_weights(P)
+    ts = ra_train.TrainStep(m)
+    ts.reuse_attn_planes, ts.seq_ctrl_split = reuse, False
+    assert ts._batched_ok([])
+    ts.bucket.zero_grad()
+    rng = np.random.RandomState(5)
+    B, T, H, W = 2, 3, 64, 64
+    kd = {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in
+          {'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)), 'u_box': rng.rand(B, T, 1),
+           'u_segm': rng.rand(B, T, 1), 'segm_noise': 0.3 * rng.rand(T, B, H, W)}.items()}
+    loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd)
+    loss.backward()
+    res[reuse] = (float(loss), pieces['y_out'].detach().cpu().numpy().copy(), {k: v.cpu().numpy().copy() for k, v in ts.bucket.grad_of.items()})
+  assert res[True][0] == res[False][0]
+  assert res[True][1].shape == (2, 3, 64, 64) and np.array_equal(res[True][1], res[False][1])
+  for k, v in res[False][2].items():
+    assert np.array_equal(res[True][2][k], v), k
