@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 104
+#define RA_ABI_VERSION 105
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -684,7 +684,11 @@ int ra_gauss_filter_strided_bwd_f32(const float *ctr, const float *size, const f
  *   ra_knob_mix_f32    the ground-truth knob on the window (full_model.py:744-773): p2 = knob m + (1 - knob) p for
  *                      centre and size, m = sum_t match[b][t] gt[b][t][:]; knob [B] with element stride knob_stride,
  *                      ctr / size rows row_stride floats apart (fields of the head's record); outputs dense [B,2].
- *   ra_knob_mix_bwd_f32   d p = (1 - knob) g (g nullable). */
+ *   ra_knob_mix_bwd_f32   d p = (1 - knob) g (g nullable).
+ *   ra_attn_head_rec_f32 / ra_knob_mix_rec_f32   the same, also writing the window as the resample kernels' attention
+ *                      record [B][RA_ATTN_STRIDE] (ctr, size, lg_var, attn_gamma, box_gamma, y_lg_gamma, zeros; the knob
+ *                      form copies attn_rec with the mixed centre and size): every resample kernel reads only its own
+ *                      gamma column, so ONE record serves the box, the extract and the paste of a timestep. */
 int ra_attn_head_f32(const float *ctrl_out, int stride, int B, int H, int W, int Fh, int Fw, int flags,
                      float *out, void *stream);
 int ra_attn_head_bwd_f32(const float *ctrl_out, int stride, const float *out, const float *g_cn,
@@ -696,6 +700,11 @@ int ra_knob_mix_f32(const float *ctr, const float *size, const float *match, con
                     float *ctr2, float *size2, void *stream);
 int ra_knob_mix_bwd_f32(const float *g_ctr2, const float *g_size2, const float *knob, int knob_stride, int B,
                         float *d_ctr, float *d_size, void *stream);
+int ra_attn_head_rec_f32(const float *ctrl_out, int stride, int B, int H, int W, int Fh, int Fw, int flags,
+                         float *out, float *attn_rec, void *stream);
+int ra_knob_mix_rec_f32(const float *ctr, const float *size, const float *match, const float *ctr_gt,
+                        const float *size_gt, const float *knob, int knob_stride, int row_stride, int B, int T,
+                        float *ctr2, float *size2, const float *attn_rec, float *attn_rec2, void *stream);
 int ra_subsample_odd_f32(const float *x, int B, int H, int W, int C, float *y, void *stream);
 /* The canvas update of a training timestep (full_model.py:826-848, stop_canvas_grad) and the next timestep's packed
  * controller-CNN input in one launch: inp_next = inp_prev [B,HW,C] with channel canvas_chan replaced by

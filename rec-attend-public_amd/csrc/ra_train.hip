@@ -1878,7 +1878,7 @@ constexpr int kHeadStride = 16;  // floats per image in the head's output record
 // record: [0,1] cn  [2,3] ls  [4,5] ctr  [6,7] size  [8,9] lg_var  [10] attn_gamma  [11] box_gamma  [12] y_lg_gamma
 __device__ inline float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch.nn.functional.softplus
 __global__ __launch_bounds__(64) void attn_head_kernel(const float *co, int sco, int B, float H, float W, float Fh, float Fw,
-                                                       int flags, float *out) {
+                                                       int flags, float *out, float *arec) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   const float *c = co + (size_t)b * sco;
@@ -1901,6 +1901,14 @@ __global__ __launch_bounds__(64) void attn_head_kernel(const float *co, int sco,
   o[10] = fixed_gamma ? 1.f : expf(c[6]);
   o[11] = expf(c[7]);
   o[12] = fixed_gamma ? 2.f : c[8];
+  if (arec) {  // the same window as the resample kernels' attention record (ctr, size, lg_var, the three gammas, zeros)
+    float *r = arec + (size_t)b * RA_ATTN_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) r[k] = o[4 + k], r[2 + k] = o[6 + k], r[4 + k] = o[8 + k];
+    r[6] = o[10], r[7] = o[11], r[8] = o[12];
+#pragma unroll
+    for (int k = 9; k < RA_ATTN_STRIDE; ++k) r[k] = 0.f;
+  }
 }
 // g_*: gradients of the record's fields, each nullable (no gradient = zero), dense [B,2] / [B]
 __global__ __launch_bounds__(64) void attn_head_bwd_kernel(const float *co, int sco, const float *out, const float *g_cn,
@@ -1933,7 +1941,7 @@ __global__ __launch_bounds__(64) void attn_head_bwd_kernel(const float *co, int 
 // p2 = kb m + (1 - kb) p for the window centre and size, m = sum_t match[b][t] gt[b][t][:] (the matched noisy GT box)
 __global__ __launch_bounds__(64) void knob_mix_kernel(const float *ctr, const float *size, const float *match, const float *ctr_gt,
                                                       const float *size_gt, const float *kb, int skb, int sp, int B, int T,
-                                                      float *ctr2, float *size2) {
+                                                      float *ctr2, float *size2, const float *arec, float *arec2) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   float mc[2] = {0.f, 0.f}, ms[2] = {0.f, 0.f};
@@ -1950,6 +1958,14 @@ __global__ __launch_bounds__(64) void knob_mix_kernel(const float *ctr, const fl
     ctr2[2 * b + i] = k * mc[i] + (1.0f - k) * ctr[(size_t)b * sp + i];
     size2[2 * b + i] = k * ms[i] + (1.0f - k) * size[(size_t)b * sp + i];
   }
+  if (arec2) {  // the attention record with the mixed window (variance and gammas as predicted)
+    const float *r = arec + (size_t)b * RA_ATTN_STRIDE;
+    float *r2 = arec2 + (size_t)b * RA_ATTN_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r2[i] = ctr2[2 * b + i], r2[2 + i] = size2[2 * b + i];
+#pragma unroll
+    for (int i = 4; i < RA_ATTN_STRIDE; ++i) r2[i] = r[i];
+  }
 }
 __global__ __launch_bounds__(64) void knob_mix_bwd_kernel(const float *g_ctr2, const float *g_size2, const float *kb, int skb, int B,
                                                           float *d_ctr, float *d_size) {
@@ -1965,12 +1981,16 @@ __global__ __launch_bounds__(64) void knob_mix_bwd_kernel(const float *g_ctr2, c
 }  // namespace train
 }  // namespace ra
 
-extern "C" int ra_attn_head_f32(const float *ctrl_out, int stride, int B, int H, int W, int Fh, int Fw, int flags, float *out,
-                                void *stream) {
+extern "C" int ra_attn_head_rec_f32(const float *ctrl_out, int stride, int B, int H, int W, int Fh, int Fw, int flags, float *out,
+                                    float *attn_rec, void *stream) {
   if (!ctrl_out || !out || B <= 0 || stride < 9) return fail(RA_E_INVALID, "ra_attn_head_f32: bad argument");
   hipLaunchKernelGGL(train::attn_head_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), ctrl_out, stride, B, (float)H,
-                     (float)W, (float)Fh, (float)Fw, flags, out);
+                     (float)W, (float)Fh, (float)Fw, flags, out, attn_rec);
   return launch_status("ra_attn_head_f32");
+}
+extern "C" int ra_attn_head_f32(const float *ctrl_out, int stride, int B, int H, int W, int Fh, int Fw, int flags, float *out,
+                                void *stream) {
+  return ra_attn_head_rec_f32(ctrl_out, stride, B, H, W, Fh, Fw, flags, out, nullptr, stream);
 }
 extern "C" int ra_attn_head_bwd_f32(const float *ctrl_out, int stride, const float *out, const float *g_cn, const float *g_ls,
                                     const float *g_ctr, const float *g_size, const float *g_lg_var, const float *g_attn_gamma,
@@ -1982,14 +2002,20 @@ extern "C" int ra_attn_head_bwd_f32(const float *ctrl_out, int stride, const flo
                      d_ctrl_out);
   return launch_status("ra_attn_head_bwd_f32");
 }
+extern "C" int ra_knob_mix_rec_f32(const float *ctr, const float *size, const float *match, const float *ctr_gt, const float *size_gt,
+                                   const float *knob, int knob_stride, int row_stride, int B, int T, float *ctr2, float *size2,
+                                   const float *attn_rec, float *attn_rec2, void *stream) {
+  if (!ctr || !size || !match || !ctr_gt || !size_gt || !knob || !ctr2 || !size2 || B <= 0 || T <= 0 || row_stride < 2 ||
+      (attn_rec2 && !attn_rec))
+    return fail(RA_E_INVALID, "ra_knob_mix_f32: bad argument");
+  hipLaunchKernelGGL(train::knob_mix_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), ctr, size, match, ctr_gt, size_gt,
+                     knob, knob_stride, row_stride, B, T, ctr2, size2, attn_rec, attn_rec2);
+  return launch_status("ra_knob_mix_f32");
+}
 extern "C" int ra_knob_mix_f32(const float *ctr, const float *size, const float *match, const float *ctr_gt, const float *size_gt,
                                const float *knob, int knob_stride, int row_stride, int B, int T, float *ctr2, float *size2,
                                void *stream) {
-  if (!ctr || !size || !match || !ctr_gt || !size_gt || !knob || !ctr2 || !size2 || B <= 0 || T <= 0 || row_stride < 2)
-    return fail(RA_E_INVALID, "ra_knob_mix_f32: bad argument");
-  hipLaunchKernelGGL(train::knob_mix_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), ctr, size, match, ctr_gt, size_gt,
-                     knob, knob_stride, row_stride, B, T, ctr2, size2);
-  return launch_status("ra_knob_mix_f32");
+  return ra_knob_mix_rec_f32(ctr, size, match, ctr_gt, size_gt, knob, knob_stride, row_stride, B, T, ctr2, size2, nullptr, nullptr, stream);
 }
 extern "C" int ra_knob_mix_bwd_f32(const float *g_ctr2, const float *g_size2, const float *knob, int knob_stride, int B,
                                    float *d_ctr, float *d_size, void *stream) {

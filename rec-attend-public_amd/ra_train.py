@@ -1069,18 +1069,22 @@ class AttnHead(torch.autograd.Function):
     co = co if (co.dim() == 2 and co.stride(1) == 1) else co.contiguous()
     B = co.shape[0]
     rec = torch.empty((B, 16), dtype=torch.float32, device=co.device)
-    check(rn.lib().ra_attn_head_f32(ptr(co), int(co.stride(0)), B, int(H), int(W), int(Fh), int(Fw), int(flags), ptr(rec),
-                                    rn.stream_ptr()), 'ra_attn_head_f32')
+    # arec: the same window as the resample kernels' attention record (every kernel reads only its own gamma column, so
+    # one record serves the box, the extract and the paste: no torch.cat per use)
+    arec = torch.empty((B, rn.RA_ATTN_STRIDE), dtype=torch.float32, device=co.device)
+    check(rn.lib().ra_attn_head_rec_f32(ptr(co), int(co.stride(0)), B, int(H), int(W), int(Fh), int(Fw), int(flags), ptr(rec),
+                                        ptr(arec), rn.stream_ptr()), 'ra_attn_head_rec_f32')
     ctx.save_for_backward(co, rec)
     ctx.meta = (int(H), int(W), int(flags))
-    return rec[:, 0:2], rec[:, 2:4], rec[:, 4:6], rec[:, 6:8], rec[:, 8:10], rec[:, 10], rec[:, 11], rec[:, 12]
+    ctx.mark_non_differentiable(arec)
+    return rec[:, 0:2], rec[:, 2:4], rec[:, 4:6], rec[:, 6:8], rec[:, 8:10], rec[:, 10], rec[:, 11], rec[:, 12], arec
 
   @staticmethod
   def backward(ctx, *gs):
     co, rec = ctx.saved_tensors
     H, W, flags = ctx.meta
     B = co.shape[0]
-    gs = [_dense(g) for g in gs]
+    gs = [_dense(g) for g in gs[:8]]
     dco = torch.empty((B, co.shape[1]), dtype=torch.float32, device=co.device)
     if co.shape[1] != 9:
       dco.zero_()
@@ -1097,7 +1101,8 @@ class KnobMix(torch.autograd.Function):
   + (1 - knob) * prediction, the matched box being sum_t match[b][t] gt[b][t] — one launch each way."""
 
   @staticmethod
-  def forward(ctx, ctr, size, match, ctr_gt, size_gt, knob):
+  def forward(ctx, ctr, size, match, ctr_gt, size_gt, knob, arec=None):
+    """arec: the head's attention record; the third output is that record with the mixed window (None without it)."""
     ctx.set_materialize_grads(False)
     B, T = match.shape
     if not (ctr.stride(1) == 1 and size.stride(1) == 1 and ctr.stride(0) == size.stride(0)):
@@ -1105,21 +1110,24 @@ class KnobMix(torch.autograd.Function):
     knob = knob.reshape(B, -1)[:, 0]
     ctr2 = torch.empty((B, 2), dtype=torch.float32, device=ctr.device)
     size2 = torch.empty_like(ctr2)
-    check(rn.lib().ra_knob_mix_f32(ptr(ctr), ptr(size), ptr(match.contiguous()), ptr(ctr_gt.contiguous()), ptr(size_gt.contiguous()),
-                                   ptr(knob), int(knob.stride(0)), int(ctr.stride(0)), B, T, ptr(ctr2), ptr(size2), rn.stream_ptr()),
-          'ra_knob_mix_f32')
+    arec2 = None if arec is None else torch.empty_like(arec)
+    check(rn.lib().ra_knob_mix_rec_f32(ptr(ctr), ptr(size), ptr(match.contiguous()), ptr(ctr_gt.contiguous()), ptr(size_gt.contiguous()),
+                                       ptr(knob), int(knob.stride(0)), int(ctr.stride(0)), B, T, ptr(ctr2), ptr(size2), ptr(arec),
+                                       ptr(arec2), rn.stream_ptr()), 'ra_knob_mix_rec_f32')
     ctx.save_for_backward(knob)
-    return ctr2, size2
+    if arec2 is not None:
+      ctx.mark_non_differentiable(arec2)
+    return ctr2, size2, arec2
 
   @staticmethod
-  def backward(ctx, g_ctr, g_size):
+  def backward(ctx, g_ctr, g_size, _g_rec=None):
     knob, = ctx.saved_tensors
     B = knob.shape[0]
     d_ctr = torch.empty((B, 2), dtype=torch.float32, device=knob.device)
     d_size = torch.empty_like(d_ctr)
     check(rn.lib().ra_knob_mix_bwd_f32(ptr(_dense(g_ctr)), ptr(_dense(g_size)), ptr(knob), int(knob.stride(0)), B, ptr(d_ctr),
                                        ptr(d_size), rn.stream_ptr()), 'ra_knob_mix_bwd_f32')
-    return d_ctr, d_size, None, None, None, None
+    return d_ctr, d_size, None, None, None, None, None
 
 
 class GaussFilterPair(torch.autograd.Function):
@@ -1184,13 +1192,14 @@ class AttnExtract(torch.autograd.Function):
   on the dense-bank operator."""
 
   @staticmethod
-  def forward(ctx, x, ctr, size, lg_var, gamma, Fh, Fw, out=None, pre=None):
+  def forward(ctx, x, ctr, size, lg_var, gamma, Fh, Fw, out=None, pre=None, rec=None):
     """out: where the patch is written (a [T, ...] slab's slice); pre: the patch, computed before (the stacked step's
-    sequential phase ran this extract timestep by timestep: its graph node only needs the backward)."""
+    sequential phase ran this extract timestep by timestep: its graph node only needs the backward); rec: the attention
+    record of (ctr, size, lg_var, gamma) where the caller has it ([record], AttnHead / KnobMix write one)."""
     ctx.set_materialize_grads(False)
     x = x.contiguous()
     B, H, W, C = x.shape
-    rec = attn_record(ctr, size, lg_var, attn_gamma=gamma)
+    rec = attn_record(ctr, size, lg_var, attn_gamma=gamma) if rec is None else rec[0]
     if pre is not None:
       patch = pre[0]   # (wrapped in a list: a tensor argument returned as the output would be seen as an in-place pass-through)
     else:
@@ -1203,7 +1212,7 @@ class AttnExtract(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g):
     if g is None:
-      return (None,) * 9
+      return (None,) * 10
     x, rec = ctx.saved_tensors
     H, W, Fh, Fw = ctx.dims
     out = ops.resample_bwd(ops.RESAMPLE_READ, rec, H, W, Fh, Fw, X=x, Q=g.contiguous(), scale=rec[:, 6])
@@ -1213,7 +1222,7 @@ class AttnExtract(torch.autograd.Function):
       fyT = ops.gaussian_filter(col(0), col(2), col(4), H, Fh).transpose(1, 2).contiguous()   # [B,Fh,H]
       fxT = ops.gaussian_filter(col(1), col(3), col(5), W, Fw).transpose(1, 2).contiguous()   # [B,Fw,W]
       dx = ops.extract_patch_dense((g * rec[:, 6].view(-1, 1, 1, 1)).contiguous(), fyT, fxT)    # [B,H,W,C]
-    return dx, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None
+    return dx, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None, None
 
 
 class AttnPaste(torch.autograd.Function):
@@ -1222,12 +1231,15 @@ class AttnPaste(torch.autograd.Function):
   gamma gradient from one banded launch."""
 
   @staticmethod
-  def forward(ctx, patch, ctr, size, lg_var, gamma, H, W, Fh, Fw, out=None, pre=None):
-    """out / pre: as AttnExtract's (the plane(s) to write into; the planes computed before)."""
+  def forward(ctx, patch, ctr, size, lg_var, gamma, H, W, Fh, Fw, out=None, pre=None, rec=None):
+    """out / pre / rec: as AttnExtract's (the plane(s) to write into; the planes computed before; the attention record)."""
     ctx.set_materialize_grads(False)
     B, dev = ctr.shape[0], ctr.device
     box = patch is None
-    rec = attn_record(ctr, size, lg_var, box_gamma=gamma) if box else attn_record(ctr, size, lg_var, y_lg_gamma=gamma)
+    if rec is not None:
+      rec = rec[0]
+    else:
+      rec = attn_record(ctr, size, lg_var, box_gamma=gamma) if box else attn_record(ctr, size, lg_var, y_lg_gamma=gamma)
     y = pre[0] if pre is not None else (out if out is not None else torch.empty((B, H, W), dtype=torch.float32, device=dev))
     if box:
       if pre is None:
@@ -1244,7 +1256,7 @@ class AttnPaste(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g):
     if g is None:
-      return (None,) * 11
+      return (None,) * 12
     H, W, Fh, Fw = ctx.dims
     if ctx.box:
       rec, y = ctx.saved_tensors
@@ -1254,7 +1266,7 @@ class AttnPaste(torch.autograd.Function):
       rec, y, patch = ctx.saved_tensors
       dp = torch.empty_like(patch)
       out = ops.resample_bwd(ops.RESAMPLE_WRITE, rec, H, W, Fh, Fw, dY=g.contiguous(), Y=y, Q=patch, E=dp)
-    return dp, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None, None, None
+    return dp, out[:, 0:2], out[:, 2:4], out[:, 4:6], out[:, 6], None, None, None, None, None, None, None
 
 
 def _flat_bn_statistics(trainer):
@@ -1521,10 +1533,10 @@ class TrainStep(object):
     h, co = ControllerFn.apply(feat.reshape(N, d['G'], -1), Wg.detach(), bg.detach(), P['glimpse_mlp_w_0'].detach(),
                                P['glimpse_mlp_b_0'].detach(), P['glimpse_mlp_w_1'].detach(), P['glimpse_mlp_b_1'].detach(),
                                P['ctrl_mlp_w_0'].detach(), P['ctrl_mlp_b_0'].detach(), bufs, 'all')
-    cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
+    cn, ls, ctr, size, lg_var, ag, bgm, ylg, arec = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
     # the planes the sequential phase computed (same window parameters, timestep by timestep): the nodes only add the backward
     pre = (lambda name, shape: [self._slab(name, T, shape).view((N,) + shape[1:])]) if self.reuse_attn_planes else (lambda name, shape: None)
-    box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw, None, pre('box', (B, H, W)))
+    box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw, None, pre('box', (B, H, W)), [arec])
     iou_rows = None
     if gt_corners is not None:  # use_knob + use_iou_box: the [B,T,T] matrix of corner IoUs the boxes are matched and scored on
       import modellib          # (modellib.f_iou_box, full_model.py:750-754,931-934), differentiable through the predicted corners
@@ -1535,8 +1547,8 @@ class TrainStep(object):
       match_all = torch.stack(matches, dim=0).reshape(N, T)
       rep = lambda t: t.unsqueeze(0).expand((T,) + tuple(t.shape)).reshape((N,) + tuple(t.shape[1:])).contiguous()
       knob_all = knob_box.reshape(B, T).t().reshape(N).contiguous()
-      ctr, size = KnobMix.apply(ctr, size, match_all, rep(gt_windows[0]), rep(gt_windows[1]), knob_all)
-    x_patch = AttnExtract.apply(inp_all, ctr, size, lg_var, ag, Fh, Fw, None, pre('xpatch', (B, Fh, Fw, inp_all.shape[3])))
+      ctr, size, arec = KnobMix.apply(ctr, size, match_all, rep(gt_windows[0]), rep(gt_windows[1]), knob_all, arec)
+    x_patch = AttnExtract.apply(inp_all, ctr, size, lg_var, ag, Fh, Fw, None, pre('xpatch', (B, Fh, Fw, inp_all.shape[3])), [arec])
     h_acnn = self._stack_layers(x_patch, 'attn_cnn', d['acnn_nlayers'])
     core = h_acnn[-1]
     skips = None
@@ -1544,7 +1556,7 @@ class TrainStep(object):
       rev = h_acnn[::-1][1:] + [x_patch]
       skips = [None] + [rev[i - 1] if (i - 1 < len(rev) and d['skip_ch'][i]) else None for i in range(1, d['adcnn_nlayers'])]
     y_patch = self._stack_layers(core, 'attn_dcnn', d['adcnn_nlayers'], skips)[-1]
-    y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw, None, pre('ymask', (B, H, W)))
+    y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw, None, pre('ymask', (B, H, W)), [arec])
     if d['disable_overwrite']:
       y = (1.0 - inp_all[..., cc]) * y
     s = torch.sigmoid(self._linear(torch.cat([h, core.reshape(N, -1)], dim=1), 'score_mlp_w_0', 'score_mlp_b_0'))
@@ -1766,10 +1778,10 @@ class TrainStep(object):
         else:
           h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
         # controller output -> window centre / size / variance and the three gammas (modellib.py:752-764,812-825): one launch
-        cn, ls, ctr, size, lg_var, ag, bgm, ylg = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
+        cn, ls, ctr, size, lg_var, ag, bgm, ylg, arec = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
         # attention box: sigmoid(box_gamma * extract_patch(ones, F_y^T, F_x^T) - 5) (full_model.py:738-741)
         keep = batched and self.reuse_attn_planes  # the planes go straight into the [T, ...] slabs the stacked graph reads
-        box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw, self._slab('box', T, (B, H, W))[tt] if keep else None)
+        box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw, self._slab('box', T, (B, H, W))[tt] if keep else None, None, [arec])
         if use_knob:  # kick in the (noisy) ground-truth box; lg_var keeps the PREDICTED size (:702-709 run earlier)
           if fixed:
             gmatch = None
@@ -1789,10 +1801,10 @@ class TrainStep(object):
             gmatch = ops.greedy_match(iou_t.view(B, T))              # matched set is never accumulated (:589,756)
             gsel_box = gmatch
           # (ctr, size) <- knob * matched noisy GT box + (1 - knob) * prediction: one launch (ra_knob_mix_f32)
-          ctr, size = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt])
+          ctr, size, arec = KnobMix.apply(ctr, size, gsel_box, ctr_gtn, size_gtn, knob_box[:, tt], arec)
         # (batched: the attention CNN's first input of every timestep, contiguous over T for the stacked filter gradient)
         x_patch = AttnExtract.apply(inp if canvas_grad else inp.detach(), ctr, size, lg_var, ag, Fh, Fw,
-                                    self._slab('xpatch', T, (B, Fh, Fw, inp.shape[3]))[tt] if batched else None)
+                                    self._slab('xpatch', T, (B, Fh, Fw, inp.shape[3]))[tt] if batched else None, None, [arec])
         if batched and use_knob:
           tape_match.append(gsel_box)
         h_acnn = self._cnn(x_patch, 'attn_cnn', d['acnn_nlayers'], d['acnn_pool'], tt, self.cmap_a, stats)
@@ -1805,7 +1817,7 @@ class TrainStep(object):
                             for i in range(1, d['adcnn_nlayers'])]
         y_patch = self._dcnn(core, 'attn_dcnn', d['adcnn_nlayers'], d['adcnn_unpool'], tt, stats, skips)
         y = AttnPaste.apply(y_patch if y_patch.shape[-1] == 1 else y_patch[..., 0:1], ctr, size, lg_var, ylg, H, W, Fh, Fw,
-                            self._slab('ymask', T, (B, H, W))[tt] if keep else None)  # [B,H,W]
+                            self._slab('ymask', T, (B, H, W))[tt] if keep else None, None, [arec])  # [B,H,W]
         if d['disable_overwrite']:
           y = (1.0 - inp[..., cc]) * y
         # (the score is not an input of the next timestep: the stacked graph computes it once for all timesteps)
@@ -2110,7 +2122,7 @@ class BoxTrainStep(TrainStep):
         inp = _pad_channels(inp)
       feat = self._cnn(inp, 'ctrl_cnn', d['ccnn_nlayers'], d['ccnn_pool'], tt, self.cmap_c, stats)[-1]
       h, co = self._controller(feat.reshape(B, d['G'], -1), tt)
-      cn, ls, ctr, size, lg_var, _, bgm, _ = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
+      cn, ls, ctr, size, lg_var, _, bgm, _, _ = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
       box = AttnPaste.apply(None, ctr, size, lg_var, bgm, H, W, Fh, Fw)
       if fixed:
         gsel = y_gt[:, tt]

@@ -650,8 +650,13 @@ def test_attention_head_and_knob_vs_torch_autograd(cuda, flags):
 
   f = lambda t: t.detach().float().to(cuda)
   co32 = f(co).requires_grad_(True)
-  cn_, ls_, ctr_, size_, lv_, ag_, bg_, ylg_ = ra_train.AttnHead.apply(co32, H, W, Fh, Fw, flags)
-  c2, s2 = ra_train.KnobMix.apply(ctr_, size_, f(match), f(ctr_gt), f(size_gt), f(knob)[:, 1])
+  cn_, ls_, ctr_, size_, lv_, ag_, bg_, ylg_, arec = ra_train.AttnHead.apply(co32, H, W, Fh, Fw, flags)
+  c2, s2, arec2 = ra_train.KnobMix.apply(ctr_, size_, f(match), f(ctr_gt), f(size_gt), f(knob)[:, 1], arec)
+  # the attention records the two kernels write = the record torch.cat builds from the same fields (one for all three gammas)
+  with torch.no_grad():
+    want = ra_train.attn_record(ctr_, size_, lv_, attn_gamma=ag_, box_gamma=bg_, y_lg_gamma=ylg_)
+    assert torch.equal(arec, want) and not arec.requires_grad
+    assert torch.equal(arec2, ra_train.attn_record(c2, s2, lv_, attn_gamma=ag_, box_gamma=bg_, y_lg_gamma=ylg_))
   fy_, fx_ = ra_train.gaussian_filters(c2, s2, lv_, H, W, Fh, Fw)
   fy0_, _ = ra_train.gaussian_filters(ctr_, size_, lv_, H, W, Fh, Fw)
   wsd = f(ws)
