@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 105
+#define RA_ABI_VERSION 106
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -676,6 +676,23 @@ int ra_gauss_filter_strided_bwd_f32(const float *ctr, const float *size, const f
                                     int stride_ctr, int stride_size, int stride_lg_var, const float *g,
                                     int B, int L, int NF, float *dctr, float *dsize, float *dlg_var,
                                     int stride_grad, void *stream);
+/* The scalar head of the training loss with box_loss_fn = segm_loss_fn = 'iou' (full_model.py:913-1035) in one launch each
+ * way.  iou_s / iou_b: the pairwise soft IoU of the masks / attention boxes against the ground truth [B,T,T] (pred, gt);
+ * m_s / m_b: their matchings (f_segm_match); s_out [B,T]: the scores.
+ *   ra_loss_head_f32      pieces[0..5] = loss, box_loss, segm_loss, conf_loss, iou_soft, iou_soft_box, where
+ *                         iou = mean_b sum(iou * m) / max(sum m, 1), conf = sum(-ms log(cummin s + 1e-5) - (1 - ms)
+ *                         log(1 - reverse-cummax s + 1e-5)) / B / T with ms = sum_gt m_s, loss = -iou_box - iou_soft +
+ *                         mix * conf.
+ *   ra_loss_head_bwd_f32  g (device scalar, NULL = 1): d loss upstream.  Writes the coefficients of the two pairwise-IoU
+ *                         adjoints, c1 [B,T,T] / c0 [B,T] for ra_weighted_sum_multi_f32 (from inter / sum_a / sum_b of
+ *                         ra_pair_stats_f32, HW = pixels per plane), and d s_out [B,T] (the cumulative extrema route their
+ *                         gradient to the positions torch.cummin / cummax report). */
+int ra_loss_head_f32(const float *iou_s, const float *iou_b, const float *m_s, const float *m_b, const float *s_out, int B, int T,
+                     float mix, float *pieces, void *stream);
+int ra_loss_head_bwd_f32(const float *g, const float *m_s, const float *m_b, const float *s_out, const float *inter_s,
+                         const float *sum_a_s, const float *sum_b_s, const float *inter_b, const float *sum_a_b,
+                         const float *sum_b_b, int B, int T, int HW, float mix, float *c1_s, float *c0_s, float *c1_b,
+                         float *c0_b, float *d_s_out, void *stream);
 /* The attention head of the training graph in one launch each way (it is scalar math on nine numbers per image):
  *   ra_attn_head_f32   ctrl_out [B][stride >= 9] -> out [B][16] = cn[2] ls[2] ctr[2] size[2] lg_var[2] attn_gamma
  *                      box_gamma y_lg_gamma (full_model.py:702-722, modellib.py:752-764,812-825); flags: 1 squash

@@ -484,6 +484,124 @@ __global__ __launch_bounds__(64) void loss_stats_final_kernel(const float *parti
 
 inline int nchunks_for(int HW) { return ceil_div(HW, kChunkPx); }
 
+
+// ---- the scalar head of the training loss (full_model.py:913-1035, box_loss_fn = segm_loss_fn = 'iou') in one launch each
+// way: matched soft IoU of masks and boxes, the confidence loss on the cumulative min / max of the scores, their mix — and,
+// backward, the coefficient tensors of the two pairwise-IoU adjoints (PairIoU.backward's c1 / c0) and d s_out.  One wave
+// per image, fixed summation order.  iou / inter [B,T,T], sum_a / sum_b [B,T], match [B,T,T] (pred, gt), s_out [B,T].
+struct LossHeadArgs {
+  const float *iou_s, *iou_b, *m_s, *m_b, *s_out;
+  const float *inter_s, *sa_s, *sb_s, *inter_b, *sa_b, *sb_b;  // backward only
+  const float *g;                                              // backward: upstream gradient of `loss` (device scalar) or null = 1
+  int B, T, HW;
+  float mix;
+  float *pieces;    // forward: [6 + 3 B]: loss, box_loss, segm_loss, conf, iou_soft, iou_box, then per image (iou_s, iou_b, conf)
+  float *c1_s, *c0_s, *c1_b, *c0_b, *ds;  // backward
+};
+__device__ inline float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// the image's count-normalised matched IoU: sum(iou * m) / max(sum m, 1); cnt returned through *cnt
+__device__ inline float matched_mean(const float *iou, const float *m, int n, int lane, float *cnt) {
+  float sm = 0.f, si = 0.f;
+  for (int e = lane; e < n; e += 64) {
+    sm += m[e];
+    si += iou[e] * m[e];
+  }
+  sm = wave_sum(sm), si = wave_sum(si);
+  const float c = fmaxf(sm, 1.0f);
+  *cnt = c;
+  return si / c;
+}
+// s_min[t] = min_{t' <= t} s[t'] with torch.cummin's index (the LAST position of the minimum so far); s_max[t] = the max of
+// s[t..T) as flip(cummax(flip(s))) computes it (index: the FIRST position of the maximum among t..T-1 scanning from the end,
+// i.e. the smallest t' >= t holding it)
+__device__ inline void cum_ext(const float *s, int T, int t, float &smin, int &imin, float &smax, int &imax) {
+  smin = s[0], imin = 0;
+  for (int k = 1; k <= t; ++k)
+    if (s[k] <= smin) smin = s[k], imin = k;
+  smax = s[T - 1], imax = T - 1;
+  for (int k = T - 2; k >= t; --k)
+    if (s[k] >= smax) smax = s[k], imax = k;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void loss_head_kernel(LossHeadArgs a) {
+  __shared__ float per[3][256];        // forward: per-image (iou_s, iou_b, conf)
+  __shared__ float coef[4][2][64];     // backward, per wave: the two per-timestep coefficients of d s_out
+  __shared__ int idx[4][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = a.T, TT = T * T;
+  const float invB = 1.0f / (float)a.B, g = (BWD && a.g) ? a.g[0] : 1.0f;
+  for (int b = wave; b < a.B; b += 4) {
+    const float *ms_ = a.m_s + (size_t)b * TT, *mb_ = a.m_b + (size_t)b * TT, *s = a.s_out + (size_t)b * T;
+    float cnt_s, cnt_b;
+    const float is = matched_mean(a.iou_s + (size_t)b * TT, ms_, TT, lane, &cnt_s);
+    const float ib = matched_mean(a.iou_b + (size_t)b * TT, mb_, TT, lane, &cnt_b);
+    float smin = 0.f, smax = 0.f, msum = 0.f;
+    int imin = 0, imax = 0;
+    if (lane < T) {
+      cum_ext(s, T, lane, smin, imin, smax, imax);
+      for (int m = 0; m < T; ++m) msum += ms_[lane * T + m];
+    }
+    if constexpr (!BWD) {
+      float cf = lane < T ? (-msum * logf(smin + 1e-5f) - (1.0f - msum) * logf(1.0f - smax + 1e-5f)) : 0.f;
+      cf = wave_sum(cf);
+      if (lane == 0) per[0][b] = is, per[1][b] = ib, per[2][b] = cf;
+    } else {
+      // d loss / d iou = -m / cnt / B (both heads); PairIoU's adjoint: U = sa + sb - I + 1e-5 HW, c1 = G (U + I) / U^2,
+      // c0[n] = -sum_m G I / U^2
+      for (int h = 0; h < 2; ++h) {
+        const float *mm = h ? mb_ : ms_, *I = (h ? a.inter_b : a.inter_s) + (size_t)b * TT;
+        const float *sa = (h ? a.sa_b : a.sa_s) + (size_t)b * T, *sb = (h ? a.sb_b : a.sb_s) + (size_t)b * T;
+        float *c1 = (h ? a.c1_b : a.c1_s) + (size_t)b * TT, *c0 = (h ? a.c0_b : a.c0_s) + (size_t)b * T;
+        const float sc = -g * invB / (h ? cnt_b : cnt_s);
+        for (int e = lane; e < TT; e += 64) {
+          const int n = e / T, m = e - n * T;
+          const float U = sa[n] + sb[m] - I[e] + 1e-5f * (float)a.HW;
+          c1[e] = sc * mm[e] * (U + I[e]) / (U * U);
+        }
+        if (lane < T) {
+          float acc = 0.f;
+          for (int m = 0; m < T; ++m) {
+            const int e = lane * T + m;
+            const float U = sa[lane] + sb[m] - I[e] + 1e-5f * (float)a.HW;
+            acc += sc * mm[e] * I[e] / (U * U);
+          }
+          c0[lane] = -acc;
+        }
+      }
+      // d conf / d s: each timestep's two terms go to the positions the cumulative min / max took their values from
+      const float k = g * a.mix * invB / (float)T;
+      if (lane < T) {
+        coef[wave][0][lane] = -k * msum / (smin + 1e-5f);
+        coef[wave][1][lane] = k * (1.0f - msum) / (1.0f - smax + 1e-5f);
+        idx[wave][0][lane] = imin, idx[wave][1][lane] = imax;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      if (lane < T) {
+        float d = 0.f;
+        for (int t = 0; t < T; ++t) {
+          if (idx[wave][0][t] == lane) d += coef[wave][0][t];
+          if (idx[wave][1][t] == lane) d += coef[wave][1][t];
+        }
+        a.ds[(size_t)b * T + lane] = d;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if constexpr (!BWD) {
+    __syncthreads();
+    if (tid == 0) {
+      float is = 0.f, ib = 0.f, cf = 0.f;
+      for (int b = 0; b < a.B; ++b) is += per[0][b], ib += per[1][b], cf += per[2][b];
+      is *= invB, ib *= invB;
+      cf = cf * invB / (float)T;
+      a.pieces[0] = -ib - is + a.mix * cf;
+      a.pieces[1] = -ib, a.pieces[2] = -is, a.pieces[3] = cf, a.pieces[4] = is, a.pieces[5] = ib;
+    }
+  }
+}
 }  // namespace loss
 }  // namespace ra
 
@@ -637,4 +755,31 @@ extern "C" int ra_loss_stats_f32(const float *iou_soft, const float *iou_hard, c
   hipLaunchKernelGGL(loss::loss_stats_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), ws, B, T, segm_loss_fn,
                      loss_mix_ratio, out);
   return launch_status("ra_loss_stats_f32");
+}
+
+/* see include/recattend.h */
+extern "C" int ra_loss_head_f32(const float *iou_s, const float *iou_b, const float *m_s, const float *m_b, const float *s_out, int B, int T,
+                                float mix, float *pieces, void *stream) {
+  if (!iou_s || !iou_b || !m_s || !m_b || !s_out || !pieces || B <= 0 || T <= 0) return fail(RA_E_INVALID, "ra_loss_head_f32: bad argument");
+  if (B > 256 || T > 64) return fail(RA_E_SHAPE, "ra_loss_head_f32: B %d (max 256), T %d (max 64)", B, T);
+  loss::LossHeadArgs a{};
+  a.iou_s = iou_s, a.iou_b = iou_b, a.m_s = m_s, a.m_b = m_b, a.s_out = s_out, a.B = B, a.T = T, a.mix = mix, a.pieces = pieces;
+  hipLaunchKernelGGL(loss::loss_head_kernel<false>, dim3(1), dim3(256), 0, as_stream(stream), a);
+  return launch_status("ra_loss_head_f32");
+}
+extern "C" int ra_loss_head_bwd_f32(const float *g, const float *m_s, const float *m_b, const float *s_out, const float *inter_s,
+                                    const float *sum_a_s, const float *sum_b_s, const float *inter_b, const float *sum_a_b,
+                                    const float *sum_b_b, int B, int T, int HW, float mix, float *c1_s, float *c0_s, float *c1_b,
+                                    float *c0_b, float *d_s_out, void *stream) {
+  if (!m_s || !m_b || !s_out || !inter_s || !sum_a_s || !sum_b_s || !inter_b || !sum_a_b || !sum_b_b || !c1_s || !c0_s || !c1_b || !c0_b ||
+      !d_s_out || B <= 0 || T <= 0 || HW <= 0)
+    return fail(RA_E_INVALID, "ra_loss_head_bwd_f32: bad argument");
+  if (B > 256 || T > 64) return fail(RA_E_SHAPE, "ra_loss_head_bwd_f32: B %d (max 256), T %d (max 64)", B, T);
+  loss::LossHeadArgs a{};
+  // (the matched means only need the matches here: the IoU pointers may alias them)
+  a.iou_s = m_s, a.iou_b = m_b, a.m_s = m_s, a.m_b = m_b, a.s_out = s_out, a.inter_s = inter_s, a.sa_s = sum_a_s, a.sb_s = sum_b_s;
+  a.inter_b = inter_b, a.sa_b = sum_a_b, a.sb_b = sum_b_b, a.g = g, a.B = B, a.T = T, a.HW = HW, a.mix = mix;
+  a.c1_s = c1_s, a.c0_s = c0_s, a.c1_b = c1_b, a.c0_b = c0_b, a.ds = d_s_out;
+  hipLaunchKernelGGL(loss::loss_head_kernel<true>, dim3(1), dim3(256), 0, as_stream(stream), a);
+  return launch_status("ra_loss_head_bwd_f32");
 }

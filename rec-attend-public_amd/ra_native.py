@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 105  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 106  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -131,6 +131,8 @@ SIGNATURES = {
     'ra_conv_pair_wino_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     'ra_gauss_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_gauss_filter_bwd_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'ra_loss_head_f32': (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
+    'ra_loss_head_bwd_f32': (_I, [_P] * 10 + [_I, _I, _I, _F] + [_P] * 6),
     'ra_attn_head_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_attn_head_rec_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'ra_attn_head_bwd_f32': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

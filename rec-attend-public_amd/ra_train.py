@@ -848,6 +848,53 @@ class PairIoU(torch.autograd.Function):
     return out, None, None
 
 
+class LossHead(torch.autograd.Function):
+  """The scalar head of the loss with the 'iou' box and mask losses (full_model.py:913-1035) as ONE launch each way
+  (ra_loss_head_f32): matched soft IoUs, the confidence loss on the cumulative extrema of the scores, their mix; backward,
+  the coefficient tensors of the two pairwise-IoU adjoints and d s_out in one launch, then the two weighted-sum passes that
+  are the gradients of the masks and the boxes.  Replaces ~75 element-wise / reduction / scan launches of the autograd
+  graph it stands for.  st_s / st_b: ops.pair_stats of (masks, y_gt) / (boxes, box_gt); m_s / m_b: their matchings."""
+
+  @staticmethod
+  def forward(ctx, y_out, attn_box, s_out, y_gt, box_gt, st_s, st_b, m_s, m_b, tmajor, mix):
+    B, T = s_out.shape
+    s_out = s_out.contiguous()
+    buf = torch.empty(8, dtype=torch.float32, device=s_out.device)
+    check(rn.lib().ra_loss_head_f32(ptr(st_s['iou_soft']), ptr(st_b['iou_soft']), ptr(m_s), ptr(m_b), ptr(s_out), B, T, float(mix), ptr(buf),
+                                    rn.stream_ptr()), 'ra_loss_head_f32')
+    ctx.save_for_backward(y_gt, box_gt, s_out, m_s, m_b, st_s['inter'], st_s['sum_a'], st_s['sum_b'], st_b['inter'], st_b['sum_a'],
+                          st_b['sum_b'])
+    ctx.meta = (bool(tmajor), float(mix), tuple(y_out.shape), tuple(attn_box.shape))
+    pieces = buf[1:6]
+    ctx.mark_non_differentiable(pieces)
+    return buf[0], pieces   # loss; (box_loss, segm_loss, conf_loss, iou_soft, iou_soft_box)
+
+  @staticmethod
+  def backward(ctx, g, _gp):
+    y_gt, box_gt, s_out, m_s, m_b, I_s, sa_s, sb_s, I_b, sa_b, sb_b = ctx.saved_tensors
+    tm, mix, ysh, bsh = ctx.meta
+    B, T = s_out.shape
+    dev = s_out.device
+    H, W = ysh[2], ysh[3]
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    c1s, c0s, c1b, c0b, ds = f(B, T, T), f(B, T), f(B, T, T), f(B, T), f(B, T)
+    g = g.contiguous()
+    check(rn.lib().ra_loss_head_bwd_f32(ptr(g), ptr(m_s), ptr(m_b), ptr(s_out), ptr(I_s), ptr(sa_s), ptr(sb_s), ptr(I_b), ptr(sa_b),
+                                        ptr(sb_b), B, T, H * W, mix, ptr(c1s), ptr(c0s), ptr(c1b), ptr(c0b), ptr(ds), rn.stream_ptr()),
+          'ra_loss_head_bwd_f32')
+    outs = []
+    for c1, c0, gt, sh in ((c1s, c0s, y_gt, ysh), (c1b, c0b, box_gt, bsh)):
+      out = torch.empty(sh, dtype=torch.float32, device=dev)
+      if tm:   # [N,B,H,W]: written through strides
+        check(rn.lib().ra_weighted_sum_multi_strided_f32(ptr(c1), ptr(c0), ptr(gt), B, T, gt.shape[1], H * W, ptr(out), H * W, B * H * W,
+                                                         rn.stream_ptr()), 'ra_weighted_sum_multi_strided_f32')
+      else:
+        check(rn.lib().ra_weighted_sum_multi_f32(ptr(c1), ptr(c0), ptr(gt), B, T, gt.shape[1], H * W, ptr(out), rn.stream_ptr()),
+              'ra_weighted_sum_multi_f32')
+      outs.append(out)
+    return outs[0], outs[1], ds, None, None, None, None, None, None, None, None
+
+
 class LSTMCell(torch.autograd.Function):
   """Pointwise half of nnlib.lstm's cell (nnlib.py:641-646): pre [B,4*hid] in gate order (i, f, o, u)."""
 
@@ -1565,6 +1612,7 @@ class TrainStep(object):
     return y.view(T, B, H, W), to_bt(s).reshape(B, T), box.view(T, B, H, W), to_bt(cn), to_bt(ls), iou_rows
 
   fuse_controller = True  # the controller of a timestep as one forward and one backward launch
+  fused_loss_head = os.environ.get('RA_LOSS_HEAD', '1') != '0'  # the scalar loss head as one launch each way (LossHead); False: the autograd graph of element-wise ops
   reuse_attn_planes = True  # stacked step: box / patch / mask planes of the sequential phase feed the stacked graph (no second forward)
   bf16_storage = os.environ.get('RA_BF16_STORE', '1') != '0'  # bf16 mode, stacked step: U / Y / dY / dU stored as bf16 (False: operands only)
   seq_ctrl_split = os.environ.get('RA_TRAIN_CTRL_SPLIT', '1') != '0'  # stacked step, sequential phase: the decode loop's 16-workgroup controller
@@ -1894,6 +1942,20 @@ class TrainStep(object):
     iou_box_rows = iou_rows_stacked if batched else (torch.cat(iou_box_steps, dim=1).contiguous() if len(iou_box_steps) == T else None)
     # the two matchings are independent and each is one wave per image for milliseconds (dense soft-IoU
     # matrices early in training): the box matching runs on a side stream under the mask matching
+    blf0, slf0 = opt.get('box_loss_fn', 'iou'), opt.get('segm_loss_fn', 'iou')
+    if self.match_merged and self.fused_loss_head and not fixed and iou_box_rows is None and blf0 == 'iou' and slf0 == 'iou' and \
+        B <= 256 and T <= 32:
+      # the whole scalar head in one launch each way (LossHead): the IoU matrices, ONE launch for both matchings, the head
+      want = ('iou_soft', 'inter', 'sum_a', 'sum_b')
+      y_gt_c, box_gt_c = y_gt.contiguous(), box_gt.contiguous()
+      st_s = ops.pair_stats(y_out.detach(), y_gt_c, want=want, a_tmajor=tm)
+      st_b = ops.pair_stats(attn_box.detach(), box_gt_c, want=want, a_tmajor=tm)
+      m2, st2 = ops.segm_match(torch.cat([st_s['iou_soft'], st_b['iou_soft']], dim=0), torch.cat([s_gt, s_gt], dim=0))
+      m, m_box = m2[:B], m2[B:]
+      loss, pv = LossHead.apply(y_out, attn_box, s_out, y_gt_c, box_gt_c, st_s, st_b, m, m_box, tm, float(opt.get('loss_mix_ratio', 1.0)))
+      pieces = {'loss': loss, 'box_loss': pv[0], 'segm_loss': pv[1], 'conf_loss': pv[2], 'iou_soft': pv[3], 'iou_soft_box': pv[4],
+                'match': m, 'match_box': m_box, 'y_out': y_out.transpose(0, 1) if tm else y_out, 's_out': s_out, '_match_status': [st2]}
+      return loss, pieces, stats
     if self.match_merged and not fixed and iou_box_rows is None:
       # The two Hungarian matchings are one wave per problem for milliseconds on the dense soft-IoU matrices of early
       # training: ONE launch over the 2 B problems (mask and box matrices side by side) instead of one matching under the

@@ -237,3 +237,38 @@ def test_stacked_step_reuses_the_sequential_phase_planes(cuda):
   assert res[True][1].shape == (2, 3, 64, 64) and np.array_equal(res[True][1], res[False][1])
   for k, v in res[False][2].items():
     assert np.array_equal(res[True][2][k], v), k
+
+
+@pytest.mark.parametrize('batched', [True, False])
+def test_loss_head_one_launch_equals_autograd_graph(cuda, batched):
+  """LossHead (ra_loss_head_f32 / _bwd_f32: matched IoUs, confidence loss on the cumulative extrema, the two pairwise-IoU
+  adjoints' coefficients, d s_out) against the graph of element-wise / scan / reduction ops it replaces: every loss piece
+  and every gradient — stacked step (timestep-major masks) and per-timestep graph."""
+  import full_model
+  import ra_train
+  from test_train_gpu import _case, KNOB_OPT
+  opt, P, x, y_gt, s_gt = _case(T=3, B=2, wmul=0.6, seed=5, **(KNOB_OPT if batched else dict(stop_canvas_grad=False)))
+  rng = np.random.RandomState(5)
+  B, T, H, W = 2, 3, 64, 64
+  kd = None
+  if batched:
+    kd = {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in
+          {'pad': rng.uniform(0.1, 0.3, (B, T, 1)), 'shift': rng.uniform(-0.05, 0.05, (B, T, 2)), 'u_box': rng.rand(B, T, 1),
+           'u_segm': rng.rand(B, T, 1), 'segm_noise': 0.3 * rng.rand(T, B, H, W)}.items()}
+  res = {}
+  for fused in (True, False):
+    m = full_model.get_model(opt).load_weights(P)
+    ts = ra_train.TrainStep(m)
+    ts.fused_loss_head, ts.seq_ctrl_split = fused, False
+    assert bool(ts._batched_ok([])) == batched
+    ts.bucket.zero_grad()
+    loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt, knobs=kd)
+    loss.backward()
+    res[fused] = ({k: float(pieces[k]) for k in ('loss', 'box_loss', 'segm_loss', 'conf_loss', 'iou_soft', 'iou_soft_box')},
+                  pieces['match'].cpu().numpy().copy(), {k: v.cpu().numpy().copy() for k, v in ts.bucket.grad_of.items()})
+  for k, v in res[False][0].items():
+    assert abs(res[True][0][k] - v) < 2e-6 * max(1.0, abs(v)), (k, res[True][0][k], v)
+  assert np.array_equal(res[True][1], res[False][1])
+  scale = max(np.abs(g).max() for g in res[False][2].values())
+  for k, g in res[False][2].items():
+    assert np.abs(res[True][2][k] - g).max() < 2e-5 * max(np.abs(g).max(), 1e-3 * scale), (k, np.abs(res[True][2][k] - g).max(), np.abs(g).max())
