@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.y, a.bytes_y);
   const __amdgpu_buffer_rsrc_t rsp = make_rsrc(a.plane ? a.plane : a.src0, a.plane ? a.bytes_p : 0);
   f32x4 st[NST][G::NCG];
+  u32x2s straw[BF16 ? NST : 1][BF16 ? G::NCG : 1];  // bf16 input: the loaded bits, untouched until store_item (any use at the load
+                                                    // makes the compiler wait for each load before it issues the next)
   f32x4 ms1[MOM ? NC : 1], ms2[MOM ? NC : 1], mpv[MOM ? NC : 1];  // moments about the pivot, per lane
   float mcnt = 0.f;
   bool mhave = false;  // the pivots are set by the first tile
@@ -273,9 +275,12 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   // single source, no zero-stuffing, no canvas plane: the common case, kept free of per-element
   // flag tests (they are wave-uniform, but inside the unrolled loops each becomes a branch)
   const bool simple = !a.ups && a.C1 == 0 && a.plane == nullptr;
+  int org_b = 0, org_ty0 = 0, org_tx0 = 0;     // origin of the tile load_item staged last (the NEXT tile inside the loop)
+  int cur_b = 0, cur_ty0 = 0, cur_tx0 = 0;     // origin of the tile being computed: two scalar divisions per tile, not four
   auto load_item = [&](int T, int ch) {  // global -> registers (input tile + halo of one chunk)
     int b, ty0, tx0;
     tile_origin(T, b, ty0, tx0);
+    org_b = b, org_ty0 = ty0, org_tx0 = tx0;
     const int ylo = -ty0, yhi = a.H - ty0, xlo = -tx0, xhi = a.W - tx0;
     if (simple) {
       const int base = ((b * a.Hs + ty0) * a.Ws + tx0) * a.C0 + ch * CK;  // scalar
@@ -287,8 +292,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
         if (BF16 && a.in_bf16) {  // uniform: the tensor is stored as bf16 (8 bytes per channel quad)
           const int off = ok ? (base + off0[i]) * 2 : kOOB;
 #pragma unroll
-          for (int cg = 0; cg < G::NCG; ++cg)
-            st[i][cg] = bf16x4_to_f32(__builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs0, off, 8 * cg, 0)));
+          for (int cg = 0; cg < G::NCG; ++cg) straw[i][cg] = __builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs0, off, 8 * cg, 0));
           continue;
         }
         const int off = ok ? (base + off0[i]) * 4 : kOOB;
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
         if (chan < a.C0) {
           if (BF16 && a.in_bf16) {
             const int off = ok ? (pbase * a.C0 + off0[i] + chan) * 2 : kOOB;
-            st[i][cg] = bf16x4_to_f32(__builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs0, off, 0, 0)));
+            straw[i][cg] = __builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs0, off, 0, 0));
             continue;
           }
           const int off = ok ? (pbase * a.C0 + off0[i] + chan) * 4 : kOOB;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
           }
         } else if (BF16 && a.in_bf16) {
           const int off = ok ? (pbase * a.C1 + off1[i] + chan - a.C0) * 2 : kOOB;
-          st[i][cg] = bf16x4_to_f32(__builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs1, off, 0, 0)));
+          straw[i][cg] = __builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rs1, off, 0, 0));
         } else {
           const int off = ok ? (pbase * a.C1 + off1[i] + chan - a.C0) * 4 : kOOB;
           st[i][cg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
@@ -335,6 +339,13 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   };
   auto store_item = [&](int buf) {  // registers -> LDS buffer, transposed to [ksub][cg]
     float *tb = tile + buf * G::LDS_FLOATS;
+    if (BF16 && a.in_bf16) {  // (uniform) the staged values still are the loaded bf16 bits: widened only here, after the MFMA
+                              // loop they flew across — widening at the load put the wait for them in front of that loop
+#pragma unroll
+      for (int i = 0; i < NST; ++i)
+#pragma unroll
+        for (int cg = 0; cg < G::NCG; ++cg) st[i][cg] = bf16x4_to_f32(straw[i][cg]);
+    }
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int e = tid + 256 * i;
@@ -431,9 +442,8 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   const int opool = a.pool;  // 1 or 2
   const bool vec_ok = (a.Cout & 3) == 0;
   const float lo = a.relu ? 0.f : -__builtin_inff();  // ReLU as one v_max, no flag test per value
-  auto epilogue = [&](int T) {  // scale/shift (bias + BN), ReLU, 2x2 max-pool, store
-    int b, ty0, tx0;
-    tile_origin(T, b, ty0, tx0);
+  auto epilogue = [&](int) {  // scale/shift (bias + BN), ReLU, 2x2 max-pool, store
+    const int b = cur_b, ty0 = cur_ty0, tx0 = cur_tx0;
     if constexpr (!SWAP) {  // lane = channel co_lane; registers r = window element (dy,dx) of pixel group qo
       const int wrow0 = ty0 + wm * G::WR, lcol0 = tx0 + 2 * qo;
       if (opool == 2) {
@@ -478,57 +488,43 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       }
       return;
     }
+    // SWAP layers never pool and always have Cout % 4 == 0 (the dispatch's condition for this form): one 16- or 8-byte
+    // store per lane and pixel group, no window maximum, no division by the pool size (a run-time divisor cost two integer
+    // divisions per pixel group here: a third of the epilogue's instructions)
     const int lrow = ty0 + wm * G::WR + dy;  // conv row / col of this lane's pixel in group 0
     const int lcol = tx0 + 2 * q + dx;
-    const bool pool_lane = (opool == 1) | ((dy | dx) == 0);  // after pooling one lane of 4 stores
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       const int co0 = 16 * (wn * NC + n) + 4 * ksub;
-      const int obase = ((b * a.Ho + lrow / opool) * a.Wo + lcol / opool) * a.Cout + co0;
+      const int obase = ((b * a.Ho + lrow) * a.Wo + lcol) * a.Cout + co0;
+      const bool co_ok = co0 < a.Cout;
 #pragma unroll
       for (int g = 0; g < G::PM; ++g) {
         const int gx = g % GX, gy = g / GX;
         f32x4 v = acc[g][n] * sc4[n] + sh4[n];
+        const bool okp = (lrow + 2 * gy < a.H) & (lcol + 8 * gx < a.W);
         if constexpr (MOM) {
           if (g == 0 && !mhave) {  // pivot: this wave's first output of the channel (pixel lane 0 of the 16)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mpv[n][r] = __shfl(v[r], lane & 48, 64);
           }
-          const bool okp = (lrow + 2 * gy < a.H) & (lcol + 8 * gx < a.W);
-          const f32x4 d = v - mpv[n];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ms1[n][r] += okp ? d[r] : 0.f;
-            ms2[n][r] += okp ? d[r] * d[r] : 0.f;
-          }
-          if (n == 0) mcnt += okp ? 1.f : 0.f;
+          // whole-vector form (packed float32 adds / FMAs): the pixel's weight 1 / 0 multiplies d instead of selecting it
+          // per element — 8 packed operations per pixel group where the selects took 26 scalar ones
+          const float wgt = okp ? 1.f : 0.f;
+          const f32x4 d = (v - mpv[n]) * f32x4{wgt, wgt, wgt, wgt};
+          ms1[n] += d;
+          ms2[n] += d * d;
+          if (n == 0) mcnt += wgt;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
-        if (opool == 2) {  // the 2x2 window = lanes 4q..4q+3
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = fmaxf(v[r], quad_swap<0xB1>(v[r]));  // lanes ^1  (quad_perm [1,0,3,2])
-            v[r] = fmaxf(v[r], quad_swap<0x4E>(v[r]));  // lanes ^2  (quad_perm [2,3,0,1])
-          }
-        }
-        const int prow = (lrow + 2 * gy) / opool, pcol = (lcol + 8 * gx) / opool;
-        const bool ok = pool_lane & (prow < a.Ho) & (pcol < a.Wo);
-        const int off = obase + ((2 / opool) * gy * a.Wo + (8 / opool) * gx) * a.Cout;
-        if (vec_ok) {
-          if (BF16 && a.out_bf16) {  // four channels = 8 bytes (RNE, as the operand rounding)
-            const int boff = (ok & (co0 < a.Cout)) ? off * 2 : kOOB;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, pack_bf16(v[0], v[1], v[2], v[3])), rsy, boff, 0, 0);
-          } else {
-            const int boff = (ok & (co0 < a.Cout)) ? off * 4 : kOOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, boff, 0, 0);
-          }
+        const int off = obase + (2 * gy * a.Wo + 8 * gx) * a.Cout;
+        if (BF16 && a.out_bf16) {  // four channels = 8 bytes (RNE, as the operand rounding)
+          const int boff = (okp & co_ok) ? off * 2 : kOOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, pack_bf16(v[0], v[1], v[2], v[3])), rsy, boff, 0, 0);
         } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int boff = (ok & (co0 + r < a.Cout)) ? (off + r) * 4 : kOOB;
-            store1(v[r], boff);
-          }
+          const int boff = (okp & co_ok) ? off * 4 : kOOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, boff, 0, 0);
         }
       }
     }
@@ -540,6 +536,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   load_b(0);
   pack_b();
   load_item(T, 0);
+  cur_b = org_b, cur_ty0 = org_ty0, cur_tx0 = org_tx0;
   store_item(0);
   zero_acc();
   __syncthreads();
@@ -568,6 +565,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
     buf ^= 1;
     T = nT;
     ch = nch;
+    cur_b = org_b, cur_ty0 = org_ty0, cur_tx0 = org_tx0;
   }
   if constexpr (MOM) {  // the wave's record: sums over its 16 pixel lanes, one float4 {n, S1, S2, pivot} per channel
 #pragma unroll

@@ -922,9 +922,11 @@ def test_fused_controller_equals_library_path(cuda, knob):
   saved rows; csrc/ra_ctrl_train.hip) against the same graph on library GEMMs / element-wise ops under autograd: loss
   and every gradient.  (The library path itself is checked against the float64 oracle above.)"""
   import full_model
-  opt, P, x, y_gt, s_gt = _case(T=3, wmul=0.6, seed=5, **(KNOB_OPT if knob else {}))  # (seed: see test_canvas_gradient_vs_oracle)
+  # two timesteps and a weight draw away from ReLU / pool kinks (see test_canvas_gradient_vs_oracle): the two sides differ by
+  # float32 summation order in the controller, and every further timestep multiplies what a flipped kink does to single tensors
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6, seed=5, **(KNOB_OPT if knob else {}))
   rng = np.random.RandomState(5)
-  B, T, H, W = 2, 3, 64, 64
+  B, T, H, W = 2, 2, 64, 64
   kd = None
   if knob:
     kd = {k: torch.tensor(v, dtype=torch.float32, device=cuda) for k, v in
@@ -941,7 +943,7 @@ def test_fused_controller_equals_library_path(cuda, knob):
       loss.backward()
     assert (getattr(ts, '_ctl', None) is not None) == fused
     res[fused] = (float(loss), {k: ts.bucket.grad_of[k].cpu().numpy().copy() for k in ts.bucket.names})
-  assert abs(res[True][0] - res[False][0]) < 2e-4 * max(1.0, abs(res[False][0]))  # float32 through 3 recurrent timesteps, different summation orders
+  assert abs(res[True][0] - res[False][0]) < 2e-4 * max(1.0, abs(res[False][0]))  # float32 through recurrent timesteps, different summation orders
   scale = max(np.abs(g).max() for g in res[False][1].values())
   dots = np.zeros(3)
   for k, g in res[False][1].items():  # both sides are float32 graphs through ~40 BN / ReLU / pool layers per timestep

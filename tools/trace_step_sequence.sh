@@ -1,9 +1,12 @@
+# One steady-state training step under rocprofv3: the kernel families (tools/kernel_families.py) and the launch sequence
+# (tools/step_sequence.py).  usage: bash tools/trace_step_sequence.sh [out-dir under gpurun_out] [extra bench.py flags]
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/seq
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/seq/tr -o t -- python bench.py --train --steps 3 --warmup 2 > gpurun_out/seq/b.json 2> gpurun_out/seq/err.txt
-f=$(find gpurun_out/seq/tr -name '*kernel_trace.csv' | head -1)
-python tools/step_sequence.py $f > gpurun_out/seq/sequence.txt
-python tools/kernel_families.py $f 80 > gpurun_out/seq/families.txt
-rm -rf gpurun_out/seq/tr
-tail -3 gpurun_out/seq/b.json | cut -c1-300
+out=gpurun_out/${1:-seq}
+shift
+mkdir -p $out
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/tr -o t -- python bench.py --train --steps 3 --warmup 2 "$@" > $out/b.json 2> $out/err.txt
+f=$(find $out/tr -name '*kernel_trace.csv' | head -1)
+python tools/step_sequence.py $f > $out/sequence.txt
+python tools/kernel_families.py $f 80 > $out/families.txt
+rm -rf $out/tr
