@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 106
+#define RA_ABI_VERSION 107
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -383,6 +383,24 @@ int ra_ctrl_train_fwd_f32(int B, int G, int Cf, int hid, int iters, int nout, co
 int ra_ctrl_train_bwd_f32(int B, int G, int Cf, int hid, int iters, int nout, const float *feat, const float *Wg,
                           const float *W0, const float *W1, const float *Wc, const float *save, const float *dh_last,
                           const float *dco, float *dfeat, float *dpre, float *dz1, float *dlog, void *stream);
+/* The same for any depth of the two MLPs (full_model.py:350-352,382-384; up to 4 layers each): the glimpse MLP is n_glimpse
+ * layers [hid] * n_glimpse + [G] (ReLU on all but the last), the controller MLP n_ctrl layers [hid] + [mlp_dim] * (n_ctrl - 1) +
+ * [nout].  gW / gb / cW / cb: HOST arrays of device pointers, one per layer.  save: B * ra_ctrl_train_save_floats_n floats
+ * (per iteration xh | gates | c | the glimpse MLP's (n_glimpse - 1) hidden layers | map); save_c [B, (n_ctrl - 1) mlp_dim]: the
+ * controller MLP's hidden layers (NULL for one layer).  The backward writes the pre-activation gradients of every dense
+ * layer: dpre, dlog as above, dzg = (n_glimpse - 1) layers of [B, iters, hid] dzg_stride floats apart, dzc = (n_ctrl - 1)
+ * layers of [B, mlp_dim] dzc_stride apart. */
+int ra_ctrl_train_supported_n(int G, int Cf, int hid, int iters, int nout, int n_glimpse, int n_ctrl, int mlp_dim);
+size_t ra_ctrl_train_save_floats_n(int G, int Cf, int hid, int iters, int n_glimpse);
+int ra_ctrl_train_fwd_n_f32(int B, int G, int Cf, int hid, int iters, int nout, int n_glimpse, int n_ctrl, int mlp_dim,
+                            const float *feat, const float *Wg, const float *bg, const float *const *gW,
+                            const float *const *gb, const float *const *cW, const float *const *cb, float *h_last,
+                            float *co, float *save, float *save_c, void *stream);
+int ra_ctrl_train_bwd_n_f32(int B, int G, int Cf, int hid, int iters, int nout, int n_glimpse, int n_ctrl, int mlp_dim,
+                            const float *feat, const float *Wg, const float *const *gW, const float *const *cW,
+                            const float *save, const float *save_c, const float *dh_last, const float *dco, float *dfeat,
+                            float *dpre, float *dlog, float *dzg, size_t dzg_stride, float *dzc, size_t dzc_stride,
+                            void *stream);
 
 size_t ra_resample_bwd_workspace_floats(int B, int Fh, int C);
 int ra_resample_bwd_f32(int mode, const float *X, int Cx, int chan0, int C, const float *dY, const float *Y,

@@ -7,8 +7,9 @@
 // writes the pre-activation gradients of every dense layer.  Parameter gradients are NOT formed here: they are
 // sums over images, iterations and timesteps of (layer input)^T (pre-activation gradient), i.e. ONE GEMM per weight
 // matrix per optimisation step over the saved rows (ra_train.ControllerFn: four addmm_ per step instead of 960
-// launches).  Architecture: num_glimpse_mlp_layers = 2, num_ctrl_mlp_layers = 1 (every run script); other depths
-// keep the library path.
+// launches).  Any depth of the two MLPs up to kMaxL layers each (full_model.py:350-352,382-384: the glimpse MLP is
+// n_g layers [hid] * n_g + [G], ReLU on all but the last, whose softmax is the next glimpse map; the controller MLP is
+// n_c layers [hid] + [mlp] * (n_c - 1) + [nout], ReLU on all but the last); every run script uses 2 and 1.
 #include "ra_common.h"
 
 namespace ra {
@@ -18,8 +19,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 
+constexpr int kMaxL = 4;  // layers per MLP
 struct Dims {
   int G, Cf, hid, iters, nout;  // nout = 9 controller outputs
+  int n_g, n_c, mlp;            // glimpse-MLP layers, controller-MLP layers, controller-MLP hidden width
 };
 
 __device__ inline float sigm(float z) { return 1.0f / (1.0f + expf(-z)); }
@@ -70,6 +73,9 @@ __device__ void gemv_rows(const float *v, int N, const float *__restrict__ W, in
   __syncthreads();
 }
 
+__host__ __device__ inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+__host__ __device__ inline int va_floats(const Dims &d) { return max3(4 * d.hid, 2 * d.hid + d.G, 2 * d.mlp); }
+
 __device__ float block_reduce(float v, bool is_max, float *red) {
   const int t = threadIdx.x;
 #pragma unroll
@@ -87,17 +93,19 @@ __device__ float block_reduce(float v, bool is_max, float *red) {
 }
 
 // Saved per (image, iteration), floats:  xh [Cf + hid] | act [4 hid] (i, f, o, u after their nonlinearities) |
-// c [hid] | z1 [hid] (glimpse-MLP hidden layer after ReLU) | gm [G] (the map this iteration READ with)
-__host__ __device__ inline int save_floats(const Dims &d) { return (d.Cf + d.hid) + 4 * d.hid + d.hid + d.hid + d.G; }
+// c [hid] | z [(n_g - 1) hid] (the glimpse MLP's hidden layers after their ReLUs) | gm [G] (the map this iteration READ with).
+// Per image (save_c): the controller MLP's hidden layers after their ReLUs [(n_c - 1) mlp].
+__host__ __device__ inline int save_floats(const Dims &d) { return (d.Cf + d.hid) + 4 * d.hid + d.hid + (d.n_g - 1) * d.hid + d.G; }
 
 struct FwdArgs {
   Dims d;
   const float *feat;                       // [B, G, Cf]
   const float *Wg, *bg;                    // [Cf + hid, 4 hid] gate order i f o u, [4 hid]
-  const float *W0, *b0, *W1, *b1;          // [hid, hid], [hid], [hid, G], [G]
-  const float *Wc, *bc;                    // [hid, nout], [nout]
+  const float *gW[kMaxL], *gb[kMaxL];      // glimpse MLP: [hid, hid] ... [hid, G]
+  const float *cW[kMaxL], *cb[kMaxL];      // controller MLP: [hid, mlp] [mlp, mlp] ... [., nout]
   float *h_last, *co;                      // [B, hid], [B, nout]
   float *save;                             // [B, iters, save_floats]
+  float *save_c;                           // [B, (n_c - 1) mlp] (null for n_c == 1)
 };
 
 __global__ __launch_bounds__(kThreads) void ctrl_fwd_kernel(const FwdArgs a) {
@@ -107,8 +115,8 @@ __global__ __launch_bounds__(kThreads) void ctrl_fwd_kernel(const FwdArgs a) {
   float *red = smem;                         // 16 * 4 hid
   float *xh = red + 16 * 4 * hid;            // [Cf + hid]
   float *cst = xh + Cf + hid;                // [hid]
-  float *va = cst + hid;                     // [4 hid]
-  float *gm = va + 4 * hid;                  // [G]
+  float *va = cst + hid;                     // [va_floats]: the gates; the MLPs' ping-pong buffers and logits
+  float *gm = va + va_floats(d);             // [G]
   float *fl = gm + G;                        // [G * Cf]
   const float *fsrc = a.feat + (size_t)b * G * Cf;
   for (int e = t * 4; e < G * Cf; e += kThreads * 4) *reinterpret_cast<f32x4 *>(fl + e) = *reinterpret_cast<const f32x4 *>(fsrc + e);
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void ctrl_fwd_kernel(const FwdArgs a) {
   const int SF = save_floats(d);
   for (int it = 0; it < d.iters; ++it) {
     float *sv = a.save + ((size_t)b * d.iters + it) * SF;
-    float *sv_act = sv + (Cf + hid), *sv_c = sv_act + 4 * hid, *sv_z1 = sv_c + hid, *sv_gm = sv_z1 + hid;
+    float *sv_act = sv + (Cf + hid), *sv_c = sv_act + 4 * hid, *sv_z = sv_c + hid, *sv_gm = sv_z + (d.n_g - 1) * hid;
     for (int g = t; g < G; g += kThreads) sv_gm[g] = gm[g];
     {  // glimpse[c] = sum_g feat[g, c] map[g]
       const int parts = kThreads / Cf, c = t % Cf, part = t / Cf;
@@ -153,15 +161,21 @@ __global__ __launch_bounds__(kThreads) void ctrl_fwd_kernel(const FwdArgs a) {
     }
     __syncthreads();
     if (it < d.iters - 1) {
-      gemv_cols(xh + Cf, hid, a.W0, hid, a.b0, va, red);
-      for (int n = t; n < hid; n += kThreads) {
-        const float z = fmaxf(va[n], 0.0f);
-        va[n] = z;
-        sv_z1[n] = z;
+      // glimpse MLP: hidden layers ping-pong between va[0, hid) and va[hid, 2 hid); the logits go to va + 2 hid
+      const float *vin = xh + Cf;
+      for (int l = 0; l + 1 < d.n_g; ++l) {
+        float *vo = va + (l & 1) * hid;
+        gemv_cols(vin, hid, a.gW[l], hid, a.gb[l], vo, red);
+        for (int n = t; n < hid; n += kThreads) {
+          const float z = fmaxf(vo[n], 0.0f);
+          vo[n] = z;
+          sv_z[l * hid + n] = z;
+        }
+        __syncthreads();
+        vin = vo;
       }
-      __syncthreads();
-      gemv_cols(va, hid, a.W1, G, a.b1, va + hid, red);
-      float *lg = va + hid;
+      float *lg = va + 2 * hid;
+      gemv_cols(vin, hid, a.gW[d.n_g - 1], G, a.gb[d.n_g - 1], lg, red);
       float mx = -3.0e38f;
       for (int n = t; n < G; n += kThreads) mx = fmaxf(mx, lg[n]);
       mx = block_reduce(mx, true, red);
@@ -175,29 +189,48 @@ __global__ __launch_bounds__(kThreads) void ctrl_fwd_kernel(const FwdArgs a) {
       for (int n = t; n < G; n += kThreads) gm[n] = lg[n] / sum;
       __syncthreads();
     } else {
-      for (int n = t; n < hid; n += kThreads) sv_z1[n] = 0.0f;
+      for (int n = t; n < (d.n_g - 1) * hid; n += kThreads) sv_z[n] = 0.0f;
     }
   }
-  // controller MLP (one layer): co = h Wc + bc
+  // controller MLP: hidden layers (ReLU) through gemv_cols, then co = v Wc + bc
   if (t < hid) a.h_last[(size_t)b * hid + t] = xh[Cf + t];
+  const float *vin = xh + Cf;
+  int K = hid;
+  for (int l = 0; l + 1 < d.n_c; ++l) {
+    float *vo = va + (l & 1) * d.mlp;
+    gemv_cols(vin, K, a.cW[l], d.mlp, a.cb[l], vo, red);
+    for (int n = t; n < d.mlp; n += kThreads) {
+      const float z = fmaxf(vo[n], 0.0f);
+      vo[n] = z;
+      a.save_c[((size_t)b * (d.n_c - 1) + l) * d.mlp + n] = z;
+    }
+    __syncthreads();
+    vin = vo;
+    K = d.mlp;
+  }
   {  // a wave per output, pairwise reduction (a 256-term serial sum costs half a digit the window position amplifies)
     const int lane = t & 63, wv = t >> 6;
+    const float *Wl = a.cW[d.n_c - 1], *bl = a.cb[d.n_c - 1];
     for (int n = wv; n < d.nout; n += kWaves) {
       float s = 0.0f;
-      for (int k = lane; k < hid; k += 64) s += xh[Cf + k] * a.Wc[(size_t)k * d.nout + n];
+      for (int k = lane; k < K; k += 64) s += vin[k] * Wl[(size_t)k * d.nout + n];
       s = wave_sum(s);
-      if (lane == 0) a.co[(size_t)b * d.nout + n] = s + a.bc[n];
+      if (lane == 0) a.co[(size_t)b * d.nout + n] = s + bl[n];
     }
   }
 }
 
 struct BwdArgs {
   Dims d;
-  const float *feat, *Wg, *W0, *W1, *Wc;
-  const float *save;                  // from the forward
+  const float *feat, *Wg;
+  const float *gW[kMaxL], *cW[kMaxL];
+  const float *save, *save_c;         // from the forward
   const float *dh_last, *dco;         // [B, hid] (may be null), [B, nout] (may be null)
   float *dfeat;                       // [B, G, Cf]
-  float *dpre, *dz1, *dlog;           // [B, iters, 4 hid], [B, iters, hid], [B, iters, G]: pre-activation gradients
+  float *dpre, *dlog;                 // [B, iters, 4 hid], [B, iters, G]: pre-activation gradients
+  float *dzg;                         // [n_g - 1][rows][B, iters, hid]: the glimpse MLP's hidden layers (stride dzg_stride floats per layer)
+  float *dzc;                         // [n_c - 1][.][B, mlp]: the controller MLP's hidden layers (stride dzc_stride)
+  size_t dzg_stride, dzc_stride;
 };
 
 __global__ __launch_bounds__(kThreads) void ctrl_bwd_kernel(const BwdArgs a) {
@@ -210,8 +243,10 @@ __global__ __launch_bounds__(kThreads) void ctrl_bwd_kernel(const BwdArgs a) {
   float *dp = dc + hid;               // [4 hid]  d pre (gates)
   float *dxh = dp + 4 * hid;          // [Cf + hid]
   float *dgm = dxh + Cf + hid;        // [G]   d map of the iteration just processed (read by the previous one's softmax)
-  float *vt = dgm + G;                // [max(hid, G)] scratch
-  float *fl = vt + (hid > G ? hid : G);  // [G * Cf] feature map
+  const int VT = max3(hid, G, d.mlp);
+  float *vt = dgm + G;                // [max(hid, G, mlp)] scratch
+  float *sc2 = vt + VT;               // [max(hid, mlp)] scratch
+  float *fl = sc2 + (hid > d.mlp ? hid : d.mlp);  // [G * Cf] feature map
   float *dfl = fl + G * Cf;           // [G * Cf] d feat
   const float *fsrc = a.feat + (size_t)b * G * Cf;
   for (int e = t * 4; e < G * Cf; e += kThreads * 4) {
@@ -223,22 +258,47 @@ __global__ __launch_bounds__(kThreads) void ctrl_bwd_kernel(const BwdArgs a) {
     dc[e] = 0.0f;
   }
   __syncthreads();
-  if (a.dco && t < hid) {  // co = h Wc + bc
-    float s = 0.0f;
-    for (int n = 0; n < d.nout; ++n) s += a.Wc[(size_t)t * d.nout + n] * a.dco[(size_t)b * d.nout + n];
-    dh[t] += s;
+  if (a.dco) {  // controller MLP backward: co = v Wc + bc behind (n_c - 1) ReLU layers
+    const int Kl = d.n_c == 1 ? hid : d.mlp;
+    const float *Wl = a.cW[d.n_c - 1];
+    float *dv = d.n_c == 1 ? dxh : vt;  // d (input of the last layer); dxh is free until the loop below
+    for (int k = t; k < Kl; k += kThreads) {
+      float s = 0.0f;
+      for (int n = 0; n < d.nout; ++n) s += Wl[(size_t)k * d.nout + n] * a.dco[(size_t)b * d.nout + n];
+      dv[k] = s;
+    }
+    __syncthreads();
+    for (int l = d.n_c - 2; l >= 0; --l) {  // vt holds d (output of hidden layer l)
+      const float *zc = a.save_c + ((size_t)b * (d.n_c - 1) + l) * d.mlp;
+      float *o = a.dzc + (size_t)l * a.dzc_stride + (size_t)b * d.mlp;
+      for (int n = t; n < d.mlp; n += kThreads) {
+        const float v = zc[n] > 0.0f ? vt[n] : 0.0f;
+        vt[n] = v;
+        o[n] = v;
+      }
+      __syncthreads();
+      if (l > 0) {
+        gemv_rows(vt, d.mlp, a.cW[l], d.mlp, sc2, false);  // d (output of hidden layer l - 1)
+        for (int n = t; n < d.mlp; n += kThreads) vt[n] = sc2[n];
+        __syncthreads();
+      } else {
+        gemv_rows(vt, d.mlp, a.cW[0], hid, dxh, false);
+      }
+    }
+    for (int k = t; k < hid; k += kThreads) dh[k] += dxh[k];
+    __syncthreads();
   }
-  __syncthreads();
   const int SF = save_floats(d);
   for (int it = d.iters - 1; it >= 0; --it) {
     const float *sv = a.save + ((size_t)b * d.iters + it) * SF;
-    const float *sv_act = sv + (Cf + hid), *sv_c = sv_act + 4 * hid, *sv_z1 = sv_c + hid, *sv_gm = sv_z1 + hid;
+    const float *sv_act = sv + (Cf + hid), *sv_c = sv_act + 4 * hid, *sv_z = sv_c + hid, *sv_gm = sv_z + (d.n_g - 1) * hid;
     float *o_dpre = a.dpre + ((size_t)b * d.iters + it) * 4 * hid;
-    float *o_dz1 = a.dz1 + ((size_t)b * d.iters + it) * hid, *o_dlog = a.dlog + ((size_t)b * d.iters + it) * G;
+    float *o_dlog = a.dlog + ((size_t)b * d.iters + it) * G;
+    const size_t zrow = ((size_t)b * d.iters + it) * hid;  // this (image, iteration)'s row in every dzg layer
     if (it < d.iters - 1) {
       // the glimpse MLP behind this iteration's LSTM produced the map iteration it + 1 read with (saved there);
       // dgm holds that map's gradient.  softmax: dlog = gm (dgm - sum gm dgm)
-      const float *gm_next = a.save + ((size_t)b * d.iters + it + 1) * SF + (Cf + hid) + 4 * hid + hid + hid;
+      const float *gm_next = a.save + ((size_t)b * d.iters + it + 1) * SF + (Cf + hid) + 4 * hid + hid + (d.n_g - 1) * hid;
       float dot = 0.0f;
       for (int n = t; n < G; n += kThreads) dot += gm_next[n] * dgm[n];
       dot = block_reduce(dot, false, red);
@@ -248,17 +308,29 @@ __global__ __launch_bounds__(kThreads) void ctrl_bwd_kernel(const BwdArgs a) {
         o_dlog[n] = v;
       }
       __syncthreads();
-      gemv_rows(vt, G, a.W1, hid, dxh, false);  // d z1 [hid] (dxh as scratch)
-      for (int k = t; k < hid; k += kThreads) {
-        const float v = sv_z1[k] > 0.0f ? dxh[k] : 0.0f;
-        vt[k] = v;
-        o_dz1[k] = v;
+      // back through the glimpse MLP: d (input of the last layer), then each hidden layer's ReLU and weights
+      if (d.n_g == 1) {
+        gemv_rows(vt, G, a.gW[0], hid, dh, true);  // one layer: logits = h W + b
+      } else {
+        gemv_rows(vt, G, a.gW[d.n_g - 1], hid, dxh, false);  // d z_{n_g-2} (dxh as scratch)
+        for (int l = d.n_g - 2; l >= 0; --l) {
+          float *o_dz = a.dzg + (size_t)l * a.dzg_stride + zrow;
+          for (int k = t; k < hid; k += kThreads) {
+            const float v = sv_z[l * hid + k] > 0.0f ? dxh[k] : 0.0f;
+            vt[k] = v;
+            o_dz[k] = v;
+          }
+          __syncthreads();
+          if (l > 0)
+            gemv_rows(vt, hid, a.gW[l], hid, dxh, false);  // d z_{l-1}
+          else
+            gemv_rows(vt, hid, a.gW[0], hid, dh, true);    // d h += W0 d z0pre
+        }
       }
-      __syncthreads();
-      gemv_rows(vt, hid, a.W0, hid, dh, true);  // d h += W0 d z1pre
     } else {
       for (int n = t; n < G; n += kThreads) o_dlog[n] = 0.0f;
-      for (int k = t; k < hid; k += kThreads) o_dz1[k] = 0.0f;
+      for (int l = 0; l + 1 < d.n_g; ++l)
+        for (int k = t; k < hid; k += kThreads) a.dzg[(size_t)l * a.dzg_stride + zrow + k] = 0.0f;
     }
     // LSTM cell backward (nnlib.py:641-646)
     if (t < hid) {
@@ -308,34 +380,59 @@ __global__ __launch_bounds__(kThreads) void ctrl_bwd_kernel(const BwdArgs a) {
 using namespace ra;
 
 namespace {
-size_t fwd_lds_floats(int G, int Cf, int hid) { return (size_t)16 * 4 * hid + (Cf + hid) + hid + 4 * hid + G + (size_t)G * Cf; }
-size_t bwd_lds_floats(int G, int Cf, int hid) {
-  return (size_t)64 + 2 * hid + 4 * hid + (Cf + hid) + G + (hid > G ? hid : G) + (size_t)2 * G * Cf;
+using ra::ctrlt::Dims;
+size_t fwd_lds_floats(const Dims &d) {
+  return (size_t)16 * 4 * d.hid + (d.Cf + d.hid) + d.hid + ra::ctrlt::va_floats(d) + d.G + (size_t)d.G * d.Cf;
 }
-bool ctrl_train_dims_ok(int G, int Cf, int hid, int iters, int nout) {
-  return G > 0 && Cf > 0 && hid > 0 && iters > 0 && nout > 0 && nout <= 64 && (G % 4) == 0 && (Cf % 4) == 0 && (hid % 4) == 0 &&
-         4 * hid <= 1024 && G <= 1024 && Cf <= 1024 && fwd_lds_floats(G, Cf, hid) * 4 <= 160 * 1024 &&
-         bwd_lds_floats(G, Cf, hid) * 4 <= 160 * 1024;
+size_t bwd_lds_floats(const Dims &d) {
+  return (size_t)64 + 2 * d.hid + 4 * d.hid + (d.Cf + d.hid) + d.G + ra::ctrlt::max3(d.hid, d.G, d.mlp) + (d.hid > d.mlp ? d.hid : d.mlp) +
+         (size_t)2 * d.G * d.Cf;
+}
+bool ctrl_train_dims_ok(const Dims &d) {
+  return d.G > 0 && d.Cf > 0 && d.hid > 0 && d.iters > 0 && d.nout > 0 && d.nout <= 64 && (d.G % 4) == 0 && (d.Cf % 4) == 0 &&
+         (d.hid % 4) == 0 && 4 * d.hid <= 1024 && d.G <= 1024 && d.G <= 4 * d.hid && d.Cf <= 1024 && d.n_g >= 1 &&
+         d.n_g <= ra::ctrlt::kMaxL && d.n_c >= 1 && d.n_c <= ra::ctrlt::kMaxL &&
+         (d.n_c == 1 || (d.mlp > 0 && (d.mlp % 4) == 0 && d.mlp <= 4 * d.hid)) && fwd_lds_floats(d) * 4 <= 160 * 1024 &&
+         bwd_lds_floats(d) * 4 <= 160 * 1024;
+}
+Dims dims_of(int G, int Cf, int hid, int iters, int nout, int n_g, int n_c, int mlp) {
+  return Dims{G, Cf, hid, iters, nout, n_g, n_c, n_c > 1 ? mlp : 4};
 }
 }  // namespace
 
+extern "C" int ra_ctrl_train_supported_n(int G, int Cf, int hid, int iters, int nout, int n_glimpse, int n_ctrl, int mlp_dim) {
+  return ctrl_train_dims_ok(dims_of(G, Cf, hid, iters, nout, n_glimpse, n_ctrl, mlp_dim)) ? 1 : 0;
+}
 extern "C" int ra_ctrl_train_supported(int G, int Cf, int hid, int iters, int nout) {
-  return ctrl_train_dims_ok(G, Cf, hid, iters, nout) ? 1 : 0;
+  return ra_ctrl_train_supported_n(G, Cf, hid, iters, nout, 2, 1, 0);
 }
 
-extern "C" size_t ra_ctrl_train_save_floats(int G, int Cf, int hid, int iters) {
-  ctrlt::Dims d{G, Cf, hid, iters, 9};
-  return (size_t)iters * ctrlt::save_floats(d);
+extern "C" size_t ra_ctrl_train_save_floats_n(int G, int Cf, int hid, int iters, int n_glimpse) {
+  return (size_t)iters * ctrlt::save_floats(dims_of(G, Cf, hid, iters, 9, n_glimpse, 1, 0));
 }
+extern "C" size_t ra_ctrl_train_save_floats(int G, int Cf, int hid, int iters) { return ra_ctrl_train_save_floats_n(G, Cf, hid, iters, 2); }
 
-extern "C" int ra_ctrl_train_fwd_f32(int B, int G, int Cf, int hid, int iters, int nout, const float *feat, const float *Wg,
-                                     const float *bg, const float *W0, const float *b0, const float *W1, const float *b1,
-                                     const float *Wc, const float *bc, float *h_last, float *co, float *save, void *stream) {
-  if (!feat || !Wg || !bg || !W0 || !b0 || !W1 || !b1 || !Wc || !bc || !h_last || !co || !save || B <= 0)
+// Any depth: gW / gb (n_glimpse host pointers to device tensors), cW / cb (n_ctrl); save_c [B, (n_ctrl - 1) mlp_dim] (NULL
+// for one controller-MLP layer).
+extern "C" int ra_ctrl_train_fwd_n_f32(int B, int G, int Cf, int hid, int iters, int nout, int n_glimpse, int n_ctrl, int mlp_dim,
+                                       const float *feat, const float *Wg, const float *bg, const float *const *gW,
+                                       const float *const *gb, const float *const *cW, const float *const *cb, float *h_last,
+                                       float *co, float *save, float *save_c, void *stream) {
+  const Dims d = dims_of(G, Cf, hid, iters, nout, n_glimpse, n_ctrl, mlp_dim);
+  if (!feat || !Wg || !bg || !gW || !gb || !cW || !cb || !h_last || !co || !save || B <= 0 || (n_ctrl > 1 && !save_c))
     return fail(RA_E_INVALID, "ra_ctrl_train_fwd_f32: bad argument");
-  if (!ctrl_train_dims_ok(G, Cf, hid, iters, nout)) return fail(RA_E_SHAPE, "ra_ctrl_train_fwd_f32: unsupported dimensions");
-  ctrlt::FwdArgs a{{G, Cf, hid, iters, nout}, feat, Wg, bg, W0, b0, W1, b1, Wc, bc, h_last, co, save};
-  const size_t lds = fwd_lds_floats(G, Cf, hid) * sizeof(float);
+  if (!ctrl_train_dims_ok(d)) return fail(RA_E_SHAPE, "ra_ctrl_train_fwd_f32: unsupported dimensions");
+  ctrlt::FwdArgs a{};
+  a.d = d, a.feat = feat, a.Wg = Wg, a.bg = bg, a.h_last = h_last, a.co = co, a.save = save, a.save_c = save_c;
+  for (int l = 0; l < n_glimpse; ++l) {
+    if (!gW[l] || !gb[l]) return fail(RA_E_INVALID, "ra_ctrl_train_fwd_f32: null glimpse-MLP layer %d", l);
+    a.gW[l] = gW[l], a.gb[l] = gb[l];
+  }
+  for (int l = 0; l < n_ctrl; ++l) {
+    if (!cW[l] || !cb[l]) return fail(RA_E_INVALID, "ra_ctrl_train_fwd_f32: null controller-MLP layer %d", l);
+    a.cW[l] = cW[l], a.cb[l] = cb[l];
+  }
+  const size_t lds = fwd_lds_floats(d) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctrlt::ctrl_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -345,15 +442,37 @@ extern "C" int ra_ctrl_train_fwd_f32(int B, int G, int Cf, int hid, int iters, i
   return launch_status("ra_ctrl_train_fwd_f32");
 }
 
-extern "C" int ra_ctrl_train_bwd_f32(int B, int G, int Cf, int hid, int iters, int nout, const float *feat, const float *Wg,
-                                     const float *W0, const float *W1, const float *Wc, const float *save,
-                                     const float *dh_last, const float *dco, float *dfeat, float *dpre, float *dz1, float *dlog,
-                                     void *stream) {
-  if (!feat || !Wg || !W0 || !W1 || !Wc || !save || !dfeat || !dpre || !dz1 || !dlog || B <= 0)
+extern "C" int ra_ctrl_train_fwd_f32(int B, int G, int Cf, int hid, int iters, int nout, const float *feat, const float *Wg,
+                                     const float *bg, const float *W0, const float *b0, const float *W1, const float *b1,
+                                     const float *Wc, const float *bc, float *h_last, float *co, float *save, void *stream) {
+  const float *gW[2] = {W0, W1}, *gb[2] = {b0, b1}, *cW[1] = {Wc}, *cb[1] = {bc};
+  return ra_ctrl_train_fwd_n_f32(B, G, Cf, hid, iters, nout, 2, 1, 0, feat, Wg, bg, gW, gb, cW, cb, h_last, co, save, nullptr, stream);
+}
+
+// dzg: [n_glimpse - 1] layers, dzg_stride floats apart, each [B, iters, hid]; dzc: [n_ctrl - 1] layers, dzc_stride apart, each
+// [B, mlp_dim] (NULL where the depth has no hidden layer).
+extern "C" int ra_ctrl_train_bwd_n_f32(int B, int G, int Cf, int hid, int iters, int nout, int n_glimpse, int n_ctrl, int mlp_dim,
+                                       const float *feat, const float *Wg, const float *const *gW, const float *const *cW,
+                                       const float *save, const float *save_c, const float *dh_last, const float *dco, float *dfeat,
+                                       float *dpre, float *dlog, float *dzg, size_t dzg_stride, float *dzc, size_t dzc_stride,
+                                       void *stream) {
+  const Dims d = dims_of(G, Cf, hid, iters, nout, n_glimpse, n_ctrl, mlp_dim);
+  if (!feat || !Wg || !gW || !cW || !save || !dfeat || !dpre || !dlog || B <= 0 || (n_glimpse > 1 && !dzg) ||
+      (n_ctrl > 1 && (!dzc || !save_c)))
     return fail(RA_E_INVALID, "ra_ctrl_train_bwd_f32: bad argument");
-  if (!ctrl_train_dims_ok(G, Cf, hid, iters, nout)) return fail(RA_E_SHAPE, "ra_ctrl_train_bwd_f32: unsupported dimensions");
-  ctrlt::BwdArgs a{{G, Cf, hid, iters, nout}, feat, Wg, W0, W1, Wc, save, dh_last, dco, dfeat, dpre, dz1, dlog};
-  const size_t lds = bwd_lds_floats(G, Cf, hid) * sizeof(float);
+  if (!ctrl_train_dims_ok(d)) return fail(RA_E_SHAPE, "ra_ctrl_train_bwd_f32: unsupported dimensions");
+  ctrlt::BwdArgs a{};
+  a.d = d, a.feat = feat, a.Wg = Wg, a.save = save, a.save_c = save_c, a.dh_last = dh_last, a.dco = dco, a.dfeat = dfeat;
+  a.dpre = dpre, a.dlog = dlog, a.dzg = dzg, a.dzc = dzc, a.dzg_stride = dzg_stride, a.dzc_stride = dzc_stride;
+  for (int l = 0; l < n_glimpse; ++l) {
+    if (!gW[l]) return fail(RA_E_INVALID, "ra_ctrl_train_bwd_f32: null glimpse-MLP layer %d", l);
+    a.gW[l] = gW[l];
+  }
+  for (int l = 0; l < n_ctrl; ++l) {
+    if (!cW[l]) return fail(RA_E_INVALID, "ra_ctrl_train_bwd_f32: null controller-MLP layer %d", l);
+    a.cW[l] = cW[l];
+  }
+  const size_t lds = bwd_lds_floats(d) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctrlt::ctrl_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -361,4 +480,13 @@ extern "C" int ra_ctrl_train_bwd_f32(int B, int G, int Cf, int hid, int iters, i
   }
   hipLaunchKernelGGL(ctrlt::ctrl_bwd_kernel, dim3(B), dim3(ctrlt::kThreads), lds, as_stream(stream), a);
   return launch_status("ra_ctrl_train_bwd_f32");
+}
+
+extern "C" int ra_ctrl_train_bwd_f32(int B, int G, int Cf, int hid, int iters, int nout, const float *feat, const float *Wg,
+                                     const float *W0, const float *W1, const float *Wc, const float *save,
+                                     const float *dh_last, const float *dco, float *dfeat, float *dpre, float *dz1, float *dlog,
+                                     void *stream) {
+  const float *gW[2] = {W0, W1}, *cW[1] = {Wc};
+  return ra_ctrl_train_bwd_n_f32(B, G, Cf, hid, iters, nout, 2, 1, 0, feat, Wg, gW, cW, save, nullptr, dh_last, dco, dfeat, dpre, dlog, dz1, 0,
+                                 nullptr, 0, stream);
 }

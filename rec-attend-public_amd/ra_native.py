@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 106  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 107  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -85,6 +85,10 @@ SIGNATURES = {
     'ra_attn_box_direct_f32': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     'ra_ctrl_train_supported': (_I, [_I, _I, _I, _I, _I]),
     'ra_ctrl_train_save_floats': (_Z, [_I, _I, _I, _I]),
+    'ra_ctrl_train_supported_n': (_I, [_I] * 8),
+    'ra_ctrl_train_save_floats_n': (_Z, [_I] * 5),
+    'ra_ctrl_train_fwd_n_f32': (_I, [_I] * 9 + [_P] * 12),
+    'ra_ctrl_train_bwd_n_f32': (_I, [_I] * 9 + [_P] * 12 + [_Z, _P, _Z, _P]),
     'ra_ctrl_train_fwd_f32': (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ra_ctrl_train_bwd_f32': (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ra_resample_bwd_workspace_floats': (_Z, [_I, _I, _I]),

@@ -1011,15 +1011,22 @@ class _CtrlStepBuffers(object):
     d, dev = trainer.d, trainer.bucket.param.device
     self.trainer, self.T, self.B, self.armed = trainer, T, B, False
     self.G, self.Cf, self.hid, self.iters = d['G'], trainer.model.dims['ccnn_channels'][-1], d['hid'], d['iters']
-    self.SF = rn.lib().ra_ctrl_train_save_floats(self.G, self.Cf, self.hid, self.iters) // self.iters
+    self.n_g, self.n_c, self.mlp = int(d['n_gmlp']), int(d['n_cmlp']), int(d.get('mlp_dim', 0) or 0)
+    self.SF = rn.lib().ra_ctrl_train_save_floats_n(self.G, self.Cf, self.hid, self.iters, self.n_g) // self.iters
     f = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
     self.save = f(T, B, self.iters, self.SF)
-    self.dpre, self.dz1, self.dlog = f(T, B, self.iters, 4 * self.hid), f(T, B, self.iters, self.hid), f(T, B, self.iters, self.G)
+    self.dpre, self.dlog = f(T, B, self.iters, 4 * self.hid), f(T, B, self.iters, self.G)
+    # pre-activation gradients of the MLPs' hidden layers, layer-major: glimpse [n_g - 1][T, B, iters, hid], controller
+    # [n_c - 1][T, B, mlp]; what the controller MLP's hidden layers put out [T, B, (n_c - 1) mlp]
+    self.dzg = f(max(self.n_g - 1, 1), T, B, self.iters, self.hid)
+    self.dz1 = self.dzg[0]
+    self.dzc = f(max(self.n_c - 1, 1), T, B, max(self.mlp, 1))
+    self.save_c = f(T, B, max((self.n_c - 1) * self.mlp, 1))
     self.hfin, self.dco = f(T, B, self.hid), f(T, B, 9)
     self.gW = f(self.Cf + self.hid, 4 * self.hid)
 
   def begin_step(self):
-    for t in (self.dpre, self.dz1, self.dlog, self.dco):  # a timestep whose backward does not run must not leave last step's rows
+    for t in (self.dpre, self.dzg, self.dzc, self.dlog, self.dco):  # a timestep whose backward does not run must not leave last step's rows
       t.zero_()
 
   def __call__(self):  # end of the backward pass: the parameter gradients, into the bucket
@@ -1027,21 +1034,32 @@ class _CtrlStepBuffers(object):
     g, hid, Cf, it = self.trainer.bucket.grad_of, self.hid, self.Cf, self.iters
     n = self.T * self.B * it
     SF, G = self.SF, self.G
+    n_g, n_c, mlp, TB = self.n_g, self.n_c, self.mlp, self.T * self.B
     if Cf % 16 == 0 and hid % 16 == 0 and getattr(self.trainer, 'own_gemm', True):
-      # four launches of the library's short-K GEMM (csrc/ra_gemm.hip): the bias gradients ride along as one more output row,
-      # and the LSTM's product lands directly in its eight weight / four bias tensors through a pointer table
+      # one launch of the library's short-K GEMM per dense layer (csrc/ra_gemm.hip): the bias gradients ride along as one
+      # more output row, and the LSTM's product lands directly in its eight weight / four bias tensors through a pointer table
       if getattr(self, '_seg', None) is None:
         self._seg = torch.tensor([g['ctrl_lstm_w_x' + k].data_ptr() for k in 'ifou'] + [g['ctrl_lstm_w_h' + k].data_ptr() for k in 'ifou'] +
                                  [g['ctrl_lstm_b_' + k].data_ptr() for k in 'ifou'], dtype=torch.int64, device=self.save.device)
       base, f4 = self.save.data_ptr(), 4
       gemm = lambda *a: check(rn.lib().ra_gemm_tn_acc_f32(*a, rn.stream_ptr()), 'ra_gemm_tn_acc_f32')
       gemm(base, SF, ptr(self.dpre), 4 * hid, n, Cf + hid, 4 * hid, 0, None, 0, None, ptr(self._seg), Cf, hid)
-      # glimpse MLP layer 0 reads h after the LSTM of (b, it) = the h half of iteration it + 1's LSTM input: A one row ahead of
-      # B, the last iteration of every image skipped
-      gemm(base + f4 * (SF + Cf), SF, ptr(self.dz1), hid, n - 1, hid, hid, it, ptr(g['glimpse_mlp_w_0']), hid, ptr(g['glimpse_mlp_b_0']),
-           None, 0, 0)
-      gemm(base + f4 * (Cf + 6 * hid), SF, ptr(self.dlog), G, n, hid, G, 0, ptr(g['glimpse_mlp_w_1']), G, ptr(g['glimpse_mlp_b_1']), None, 0, 0)
-      gemm(ptr(self.hfin), hid, ptr(self.dco), 9, self.T * self.B, hid, 9, 0, ptr(g['ctrl_mlp_w_0']), 9, ptr(g['ctrl_mlp_b_0']), None, 0, 0)
+      zcol = lambda l: base + f4 * (Cf + 6 * hid + l * hid)     # hidden layer l of the glimpse MLP inside a saved row
+      last_w, last_b = g['glimpse_mlp_w_%d' % (n_g - 1)], g['glimpse_mlp_b_%d' % (n_g - 1)]
+      if n_g == 1:   # logits = h W + b: h after the LSTM of (b, it) = the h half of iteration it + 1's LSTM input
+        gemm(base + f4 * (SF + Cf), SF, ptr(self.dlog), G, n - 1, hid, G, it, ptr(last_w), G, ptr(last_b), None, 0, 0)
+      else:
+        # layer 0 reads that h: A one row ahead of B, the last iteration of every image skipped
+        gemm(base + f4 * (SF + Cf), SF, ptr(self.dzg[0]), hid, n - 1, hid, hid, it, ptr(g['glimpse_mlp_w_0']), hid, ptr(g['glimpse_mlp_b_0']),
+             None, 0, 0)
+        for l in range(1, n_g - 1):  # hidden layer l reads hidden layer l - 1 of the same (image, iteration)
+          gemm(zcol(l - 1), SF, ptr(self.dzg[l]), hid, n, hid, hid, 0, ptr(g['glimpse_mlp_w_%d' % l]), hid, ptr(g['glimpse_mlp_b_%d' % l]),
+               None, 0, 0)
+        gemm(zcol(n_g - 2), SF, ptr(self.dlog), G, n, hid, G, 0, ptr(last_w), G, ptr(last_b), None, 0, 0)
+      for l in range(n_c):  # controller MLP: [hid] + [mlp] * (n_c - 1) + [9]
+        A, lda, K = (ptr(self.hfin), hid, hid) if l == 0 else (self.save_c.data_ptr() + f4 * (l - 1) * mlp, (n_c - 1) * mlp, mlp)
+        Bm, N = (ptr(self.dco), 9) if l == n_c - 1 else (ptr(self.dzc[l]), mlp)
+        gemm(A, lda, Bm, N, TB, K, N, 0, ptr(g['ctrl_mlp_w_%d' % l]), N, ptr(g['ctrl_mlp_b_%d' % l]), None, 0, 0)
       return
     rows = self.save.view(n, self.SF)
     ones = _const('ones', n, rows.device, lambda: torch.ones(n, dtype=torch.float32, device=rows.device))
@@ -1053,57 +1071,70 @@ class _CtrlStepBuffers(object):
       g['ctrl_lstm_w_x' + k].add_(self.gW[:nx, cols])
       g['ctrl_lstm_w_h' + k].add_(self.gW[nx:, cols])
       g['ctrl_lstm_b_' + k].addmv_(D[:, cols].t(), ones)
-    # glimpse MLP layer 0 reads h after the LSTM of (b, it) = the h half of iteration it + 1's LSTM input
+    # the glimpse MLP's first layer reads h after the LSTM of (b, it) = the h half of iteration it + 1's LSTM input
     sv4 = self.save.view(self.T, self.B, it, self.SF)
     H0 = sv4[:, :, 1:, Cf:Cf + hid].reshape(-1, hid)
-    DZ = self.dz1[:, :, :-1].reshape(-1, hid)
-    g['glimpse_mlp_w_0'].addmm_(H0.t(), DZ)
-    g['glimpse_mlp_b_0'].addmv_(DZ.t(), ones[:DZ.shape[0]])
-    z1 = rows[:, Cf + hid + 5 * hid:Cf + hid + 6 * hid]
     DL = self.dlog.view(n, self.G)
-    g['glimpse_mlp_w_1'].addmm_(z1.t(), DL)
-    g['glimpse_mlp_b_1'].addmv_(DL.t(), ones)
-    HF, DC = self.hfin.view(-1, hid), self.dco.view(-1, 9)
-    g['ctrl_mlp_w_0'].addmm_(HF.t(), DC)
-    g['ctrl_mlp_b_0'].addmv_(DC.t(), ones[:DC.shape[0]])
+    for l in range(n_g):
+      A = H0 if l == 0 else rows[:, Cf + 6 * hid + (l - 1) * hid:Cf + 6 * hid + l * hid]
+      Bm = DL if l == n_g - 1 else self.dzg[l].reshape(n, hid)
+      if l == 0:
+        Bm = Bm.view(self.T, self.B, it, -1)[:, :, :-1].reshape(-1, Bm.shape[1])
+      g['glimpse_mlp_w_%d' % l].addmm_(A.t(), Bm)
+      g['glimpse_mlp_b_%d' % l].addmv_(Bm.t(), ones[:Bm.shape[0]])
+    HF = self.hfin.view(-1, hid)
+    for l in range(n_c):
+      A = HF if l == 0 else self.save_c.view(TB, -1)[:, (l - 1) * mlp:l * mlp]
+      Bm = self.dco.view(-1, 9) if l == n_c - 1 else self.dzc[l].reshape(TB, mlp)
+      g['ctrl_mlp_w_%d' % l].addmm_(A.t(), Bm)
+      g['ctrl_mlp_b_%d' % l].addmv_(Bm.t(), ones[:TB])
 
 
 class ControllerFn(torch.autograd.Function):
   """full_model.py:668-689 for one timestep: feat [B,G,Cf] -> (h_last [B,hid], ctrl_out [B,9]) in ONE launch, its
-  adjoint (BPTT over the glimpse iterations) in one more.  The weights are passed as plain tensors: their gradients are
-  formed once per step by the trainer's _CtrlStepBuffers from the rows this function saves."""
+  adjoint (BPTT over the glimpse iterations) in one more; any depth of the glimpse and controller MLPs (up to 4 layers
+  each).  The weights are passed as plain tensors (gws = the glimpse MLP's [(w, b), ...], cws = the controller MLP's): their
+  gradients are formed once per step by the trainer's _CtrlStepBuffers from the rows this function saves."""
 
   @staticmethod
-  def forward(ctx, feat, Wg, bg, W0, b0, W1, b1, Wc, bc, bufs, tt):
+  def forward(ctx, feat, Wg, bg, gws, cws, bufs, tt):
     ctx.set_materialize_grads(False)
     feat = feat.contiguous()
     B, G, Cf = feat.shape
     hid, iters = bufs.hid, bufs.iters
     sel = (lambda t: t.view((-1,) + t.shape[2:])) if tt == 'all' else (lambda t: t[tt])  # 'all': the T timesteps stacked
     h, co = sel(bufs.hfin), torch.empty((B, 9), dtype=torch.float32, device=feat.device)
-    check(rn.lib().ra_ctrl_train_fwd_f32(B, G, Cf, hid, iters, 9, ptr(feat), ptr(Wg), ptr(bg), ptr(W0), ptr(b0), ptr(W1), ptr(b1),
-                                         ptr(Wc), ptr(bc), ptr(h), ptr(co), ptr(sel(bufs.save)), rn.stream_ptr()), 'ra_ctrl_train_fwd_f32')
-    ctx.save_for_backward(feat, Wg, W0, W1, Wc)
+    arr = lambda ts: (_C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    check(rn.lib().ra_ctrl_train_fwd_n_f32(B, G, Cf, hid, iters, 9, bufs.n_g, bufs.n_c, bufs.mlp, ptr(feat), ptr(Wg), ptr(bg),
+                                           arr([w for w, _ in gws]), arr([b for _, b in gws]), arr([w for w, _ in cws]),
+                                           arr([b for _, b in cws]), ptr(h), ptr(co), ptr(sel(bufs.save)),
+                                           ptr(sel(bufs.save_c)) if bufs.n_c > 1 else None, rn.stream_ptr()), 'ra_ctrl_train_fwd_n_f32')
+    ctx.save_for_backward(feat, Wg, *([w for w, _ in gws] + [w for w, _ in cws]))
     ctx.bufs, ctx.tt = bufs, tt
     return h, co  # h is the trainer's row buffer hfin[tt] (the GEMM input of the controller MLP's gradient): nothing writes it again this step
 
   @staticmethod
   def backward(ctx, dh, dco):
-    feat, Wg, W0, W1, Wc = ctx.saved_tensors
+    feat, Wg = ctx.saved_tensors[:2]
     bufs, tt = ctx.bufs, ctx.tt
+    gW, cW = ctx.saved_tensors[2:2 + bufs.n_g], ctx.saved_tensors[2 + bufs.n_g:]
     if not bufs.armed:
       bufs.armed = True
       torch.autograd.Variable._execution_engine.queue_callback(bufs)
     B, G, Cf = feat.shape
     dfeat = torch.empty_like(feat)
     sel = (lambda t: t.view((-1,) + t.shape[2:])) if tt == 'all' else (lambda t: t[tt])
+    lsel = (lambda t: t.view((t.shape[0], -1) + t.shape[3:])) if tt == 'all' else (lambda t: t[:, tt])  # layer-major buffers
     if dco is not None:
       sel(bufs.dco).copy_(dco)
-    check(rn.lib().ra_ctrl_train_bwd_f32(B, G, Cf, bufs.hid, bufs.iters, 9, ptr(feat), ptr(Wg), ptr(W0), ptr(W1), ptr(Wc),
-                                         ptr(sel(bufs.save)), ptr(_dense(dh)), ptr(sel(bufs.dco)) if dco is not None else None,
-                                         ptr(dfeat), ptr(sel(bufs.dpre)), ptr(sel(bufs.dz1)), ptr(sel(bufs.dlog)), rn.stream_ptr()),
-          'ra_ctrl_train_bwd_f32')
-    return (dfeat,) + (None,) * 10
+    arr = lambda ts: (_C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    dzg, dzc = lsel(bufs.dzg), lsel(bufs.dzc)
+    check(rn.lib().ra_ctrl_train_bwd_n_f32(B, G, Cf, bufs.hid, bufs.iters, 9, bufs.n_g, bufs.n_c, bufs.mlp, ptr(feat), ptr(Wg), arr(gW), arr(cW),
+                                           ptr(sel(bufs.save)), ptr(sel(bufs.save_c)) if bufs.n_c > 1 else None, ptr(_dense(dh)),
+                                           ptr(sel(bufs.dco)) if dco is not None else None, ptr(dfeat), ptr(sel(bufs.dpre)),
+                                           ptr(sel(bufs.dlog)), ptr(dzg) if bufs.n_g > 1 else None, int(dzg.stride(0)),
+                                           ptr(dzc) if bufs.n_c > 1 else None, int(dzc.stride(0)), rn.stream_ptr()), 'ra_ctrl_train_bwd_n_f32')
+    return (dfeat,) + (None,) * 6
 
 
 class AttnHead(torch.autograd.Function):
@@ -1500,13 +1531,15 @@ class TrainStep(object):
   def _batched_ok(self, extra):
     """The stacked step covers every architecture of the run scripts — skip connections, d_in / y_in, use_iou_box, the
     'mse' / 'huber' box losses, --sync_bn — as long as the layers' channel counts are multiples of 4 (the slabs are the
-    kernels' packed tensors) and the controller has the run scripts' depths (ra_ctrl_train.hip)."""
+    kernels' packed tensors) and the controller fits the fused kernels (ra_ctrl_train.hip: up to 4 layers per MLP)."""
     d, opt = self.d, self.opt
     c4 = lambda cs: all(c % 4 == 0 for c in cs)
     return bool(self.batched_backward and torch.is_grad_enabled() and d['use_bn'] and self.fuse_param_grads and
                 self.fuse_controller and bool(opt.get('stop_canvas_grad', True)) and  # a canvas gradient couples the timesteps
                 c4(self.model.dims['ccnn_channels'][1:]) and c4(opt['attn_cnn_depth']) and c4(opt['attn_dcnn_depth'][:-1]) and
-                self.model.dims['C0p'] % 4 == 0 and d['n_gmlp'] == 2 and d['n_cmlp'] == 1)
+                self.model.dims['C0p'] % 4 == 0 and
+                rn.lib().ra_ctrl_train_supported_n(d['G'], self.model.dims['ccnn_channels'][-1], d['hid'], d['iters'], 9, int(d['n_gmlp']),
+                                                   int(d['n_cmlp']), int(d.get('mlp_dim', 0) or 0)))
 
   def _slab(self, name, T, shape, dtype=torch.float32):
     """[T, *shape] buffer of the step (one slot per timestep), kept across steps."""
@@ -1577,9 +1610,8 @@ class TrainStep(object):
     feat = self._stack_layers(inp_all, 'ctrl_cnn', d['ccnn_nlayers'])[-1]
     bufs = self._ctrl_buffers(B, feat.shape[3])
     Wg, bg = self._lstm_weights()
-    h, co = ControllerFn.apply(feat.reshape(N, d['G'], -1), Wg.detach(), bg.detach(), P['glimpse_mlp_w_0'].detach(),
-                               P['glimpse_mlp_b_0'].detach(), P['glimpse_mlp_w_1'].detach(), P['glimpse_mlp_b_1'].detach(),
-                               P['ctrl_mlp_w_0'].detach(), P['ctrl_mlp_b_0'].detach(), bufs, 'all')
+    h, co = ControllerFn.apply(feat.reshape(N, d['G'], -1), Wg.detach(), bg.detach(), self._mlp_weights('glimpse_mlp', d['n_gmlp']),
+                               self._mlp_weights('ctrl_mlp', d['n_cmlp']), bufs, 'all')
     cn, ls, ctr, size, lg_var, ag, bgm, ylg, arec = AttnHead.apply(co, H, W, Fh, Fw, head_flags)
     # the planes the sequential phase computed (same window parameters, timestep by timestep): the nodes only add the backward
     pre = (lambda name, shape: [self._slab(name, T, shape).view((N,) + shape[1:])]) if self.reuse_attn_planes else (lambda name, shape: None)
@@ -1653,13 +1685,15 @@ class TrainStep(object):
     return sc
 
   def _ctrl_buffers(self, B, Cf):
-    """The fused controller's step buffers, or None where the library path has to run: depths other than the run
-    scripts' (2 glimpse-MLP layers, 1 controller-MLP layer), shapes beyond the kernel's LDS, no gradient bucket views."""
+    """The fused controller's step buffers, or None where the library path has to run: shapes beyond the kernel's LDS or
+    its four layers per MLP, no gradient bucket views."""
     d, g = self.d, self.bucket.grad_of
-    names = ['glimpse_mlp_w_0', 'glimpse_mlp_b_0', 'glimpse_mlp_w_1', 'glimpse_mlp_b_1', 'ctrl_mlp_w_0', 'ctrl_mlp_b_0'] + \
+    names = ['glimpse_mlp_%s_%d' % (p, l) for l in range(d['n_gmlp']) for p in 'wb'] + \
+        ['ctrl_mlp_%s_%d' % (p, l) for l in range(d['n_cmlp']) for p in 'wb'] + \
         ['ctrl_lstm_%s%s' % (p, k) for p in ('w_x', 'w_h', 'b_') for k in 'ifou']
-    if not (self.fuse_controller and self.fuse_param_grads and d['n_gmlp'] == 2 and d['n_cmlp'] == 1 and all(n in g for n in names) and
-            rn.lib().ra_ctrl_train_supported(d['G'], Cf, d['hid'], d['iters'], 9)):
+    if not (self.fuse_controller and self.fuse_param_grads and all(n in g for n in names) and
+            rn.lib().ra_ctrl_train_supported_n(d['G'], Cf, d['hid'], d['iters'], 9, int(d['n_gmlp']), int(d['n_cmlp']),
+                                               int(d.get('mlp_dim', 0) or 0))):
       return None
     cb = getattr(self, '_ctl', None)
     if cb is None or cb.B != B or cb.T != d['T']:
@@ -1667,6 +1701,11 @@ class TrainStep(object):
         self._drop_captured_steps()
       cb = self._ctl = _CtrlStepBuffers(self, d['T'], B)
     return cb
+
+  def _mlp_weights(self, scope, n):
+    """[(w, b), ...] of an MLP's n layers, detached (ControllerFn's plain-tensor arguments)."""
+    P = self.leaves
+    return [(P['%s_w_%d' % (scope, l)].detach(), P['%s_b_%d' % (scope, l)].detach()) for l in range(n)]
 
   def _controller(self, feat, tt=None):
     """full_model.py:668-689 on [B,G,Cf] features: glimpse read-out, LSTM (state = [c|h], zeroed per
@@ -1676,9 +1715,8 @@ class TrainStep(object):
     bufs = self._ctrl_buffers(B, feat.shape[2]) if tt is not None else None
     if bufs is not None:  # one launch forward, one backward (csrc/ra_ctrl_train.hip)
       Wg, bg = self._lstm_weights()
-      return ControllerFn.apply(feat, Wg.detach(), bg.detach(), P['glimpse_mlp_w_0'].detach(), P['glimpse_mlp_b_0'].detach(),
-                                P['glimpse_mlp_w_1'].detach(), P['glimpse_mlp_b_1'].detach(), P['ctrl_mlp_w_0'].detach(),
-                                P['ctrl_mlp_b_0'].detach(), bufs, tt)
+      return ControllerFn.apply(feat, Wg.detach(), bg.detach(), self._mlp_weights('glimpse_mlp', d['n_gmlp']),
+                                self._mlp_weights('ctrl_mlp', d['n_cmlp']), bufs, tt)
     dev = feat.device  # constants of the recurrence's start: built once, never written
     c = h = _const('zeros', (B, hid), dev, lambda: torch.zeros((B, hid), device=dev))
     gmap = _const('gmap0', (B, G), dev, lambda: torch.full((B, 1, G), 1.0 / G, device=dev))

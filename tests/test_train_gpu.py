@@ -959,11 +959,13 @@ def test_fused_controller_equals_library_path(cuda, knob):
     assert np.abs(got - g).max() < 1e-3 * max(np.abs(g).max(), 1e-4 * scale), (k, np.abs(got - g).max(), np.abs(g).max())
 
 
-def test_controller_fn_unit_vs_library(cuda):
+@pytest.mark.parametrize('n_g,n_c', [(2, 1), (1, 1), (3, 2), (4, 3)])
+def test_controller_fn_unit_vs_library(cuda, n_g, n_c):
   """ControllerFn alone: one timestep's controller on a random feature map, forward outputs and — for random upstream
-  gradients of h and ctrl_out — d feat and every controller parameter's gradient, against the library-GEMM path."""
+  gradients of h and ctrl_out — d feat and every controller parameter's gradient, against the library-GEMM path; at the
+  run scripts' depths (2 glimpse-MLP layers, 1 controller-MLP layer) and at others (full_model.py:350-352,382-384)."""
   import full_model
-  opt, P, x, y_gt, s_gt = _case(T=2, wmul=1.0)
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=1.0, num_glimpse_mlp_layers=n_g, num_ctrl_mlp_layers=n_c, ctrl_mlp_dim=48)
   rng = np.random.RandomState(2)
   for k in P:  # livelier controller weights than the 0.01 init: the softmax must not stay uniform
     if k.startswith(('ctrl_lstm_w', 'glimpse_mlp_w', 'ctrl_mlp_w')):
@@ -977,6 +979,7 @@ def test_controller_fn_unit_vs_library(cuda):
     ts = ra_train.TrainStep(m)
     ts.fuse_controller = fused
     d = ts.d
+    assert (d['n_gmlp'], d['n_cmlp']) == (n_g, n_c) and (ts._ctrl_buffers(B, 64) is not None) == fused
     feat = torch.tensor(np.random.RandomState(4).rand(B, d['G'], 64).astype(np.float32), device=cuda, requires_grad=True)
     wh = torch.tensor(np.random.RandomState(5).randn(B, d['hid']).astype(np.float32), device=cuda)
     wc = torch.tensor(np.random.RandomState(6).randn(B, 9).astype(np.float32), device=cuda)

@@ -272,3 +272,23 @@ def test_loss_head_one_launch_equals_autograd_graph(cuda, batched):
   scale = max(np.abs(g).max() for g in res[False][2].values())
   for k, g in res[False][2].items():
     assert np.abs(res[True][2][k] - g).max() < 2e-5 * max(np.abs(g).max(), 1e-3 * scale), (k, np.abs(res[True][2][k] - g).max(), np.abs(g).max())
+
+
+def test_stacked_step_at_other_mlp_depths_vs_oracle(cuda):
+  """The stacked training step with 3 glimpse-MLP and 2 controller-MLP layers (full_model.py:350-352,382-384; the run
+  scripts use 2 and 1): the fused controller kernels and their per-layer parameter-gradient GEMMs against float64 autograd."""
+  import full_model
+  import ra_train
+  from test_train_gpu import _case, _oracle_grads, _compare_grads
+  opt, P, x, y_gt, s_gt = _case(T=2, B=2, wmul=0.6, seed=5, num_glimpse_mlp_layers=3, num_ctrl_mlp_layers=2, ctrl_mlp_dim=48)
+  head, gref, _ = _oracle_grads(opt, P, x, y_gt, s_gt)
+  m = full_model.get_model(opt).load_weights(P)
+  ts = ra_train.TrainStep(m)
+  assert ts._batched_ok([]) and (ts.d['n_gmlp'], ts.d['n_cmlp']) == (3, 2)
+  ts.bucket.zero_grad()
+  loss, pieces, _ = ts.forward_loss(x, y_gt, s_gt)
+  loss.backward()
+  assert ts._ctl is not None and ts._ctl.n_g == 3 and ts._ctl.n_c == 2
+  for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
+    assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
+  _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
