@@ -1597,39 +1597,47 @@ __global__ __launch_bounds__(256) void gauss_filter_bwd_kernel(const float *ctr,
 // The same reduction, ADDED to the filter's gradient in the reference's own layout (the gradient
 // bucket): [3,3,cin_w,Cout], or [3,3,Cout,cin_w] with the taps flipped for a transposed (dcnn) layer;
 // chan_map sends a packed kernel channel to its filter row (-1: padding).  One writer per element.
-__global__ __launch_bounds__(256) void wgrad_final_acc_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
-                                                              const int *chan_map, int cin_w, int transposed, float *gw,
-                                                              float *gb) {
-  const int total = 9 * Cin * Cout + Cout;
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (e >= total) return;
-  int tap, ci, co;
-  if (e < 9 * Cin * Cout) {
-    co = e % Cout;
-    ci = (e / Cout) % Cin;
-    tap = e / (Cout * Cin);
-  } else {
-    tap = 9;
-    ci = 0;
-    co = e - 9 * Cin * Cout;
-  }
-  const int j = tap == 9 ? 0 : (chan_map ? chan_map[ci] : (ci < cin_w ? ci : -1));
-  if (j < 0) return;  // wave-uniform
-  const int chunk = ci / 16, cl = ci % 16, slice = co / CP, cs = co % CP;
+// COALESCED reads: a lane owns one element of the record (64 consecutive floats per wave load), the four waves of a
+// workgroup split the partial records and meet in LDS in a fixed order.  The wave-per-element form (wgrad_final_kernel) gives
+// every lane its own record — 64 separate 4-byte loads per instruction: 96 / 107 us for the 64-channel layers' 2 048 records.
+// grid (ceil(160 CP / 64), nchunks, slices).
+__global__ __launch_bounds__(256) void wgrad_final_acc_rows_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
+                                                                   const int *chan_map, int cin_w, int transposed, float *gw,
+                                                                   float *gb) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rec = 160 * CP;
+  const int r = blockIdx.x * 64 + lane, chunk = blockIdx.y, slice = blockIdx.z;
   float s = 0.f;
-  for (int k = lane; k < nwg; k += 64)
-    s += part[((((size_t)slice * nchunks + chunk) * nwg + k) * 10 + tap) * 16 * CP + cl * CP + cs];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) {
-    if (tap == 9) {
-      if (gb) gb[co] += s;
-    } else {
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      const size_t idx = transposed ? ((size_t)((2 - ky) * 3 + (2 - kx)) * Cout + co) * cin_w + j
-                                    : ((size_t)(ky * 3 + kx) * cin_w + j) * Cout + co;
-      gw[idx] += s;
+  if (r < rec) {
+    const float *p = part + ((size_t)slice * nchunks + chunk) * nwg * rec + r;
+    int k = wave;
+    for (; k + 28 < nwg; k += 32) {  // eight loads in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 4 * u) * rec];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; k < nwg; k += 4) s += p[(size_t)k * rec];
   }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0 || r >= rec) return;
+  s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  const int tap = r / (16 * CP), cl = (r / CP) & 15, cs = r % CP;
+  const int ci = chunk * 16 + cl, co = slice * CP + cs;
+  if (co >= Cout) return;
+  if (tap == 9) {
+    if (gb && chunk == 0 && cl == 0) gb[co] += s;
+    return;
+  }
+  if (ci >= Cin) return;
+  const int j = chan_map ? chan_map[ci] : (ci < cin_w ? ci : -1);
+  if (j < 0) return;
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  const size_t idx = transposed ? ((size_t)((2 - ky) * 3 + (2 - kx)) * Cout + co) * cin_w + j
+                                : ((size_t)(ky * 3 + kx) * cin_w + j) * Cout + co;
+  gw[idx] += s;
 }
 
 }  // namespace train
@@ -1658,7 +1666,7 @@ extern "C" size_t ra_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int B, in
 
 namespace {
 // acc == false: dw / db are written in the kernel's own [3,3,Cin,Cout] / [Cout] layout; acc == true: the
-// sums are added to gw / gb in the reference layout (chan_map, cin_w, transposed as in wgrad_final_acc_kernel)
+// sums are added to gw / gb in the reference layout (chan_map, cin_w, transposed as in wgrad_final_acc_rows_kernel)
 int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, const float *du, int Cout, float *ws,
                size_t ws_floats, float *dw, float *db, bool acc, const int *chan_map, int cin_w, int transposed,
                void *stream, bool bf16 = false, const float *const *xtab = nullptr, const float *const *dutab = nullptr,
@@ -1741,8 +1749,8 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
 #undef RA_WGRAD_T
   const int total = 9 * Cin * Cout + Cout;
   if (acc)
-    hipLaunchKernelGGL(wgrad_final_acc_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout,
-                       chan_map, cin_w, transposed, dw, db);
+    hipLaunchKernelGGL(wgrad_final_acc_rows_kernel, dim3(ceil_div(160 * per, 64), chunks, slices), dim3(256), 0, st, ws, gx, chunks, per, Cin,
+                       Cout, chan_map, cin_w, transposed, dw, db);
   else
     hipLaunchKernelGGL(wgrad_final_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, ws, gx, chunks, per, Cin, Cout, dw, db);
   return launch_status("ra_conv3x3_wgrad_f32");
