@@ -433,6 +433,32 @@ __device__ __forceinline__ int rematch_wave(Scratch &g, int nx, int ny, float *M
 // res) stays in LDS and is updated along the path exactly as before; the masks are derived from it.
 // One wave's LDS operations execute in issue order, so only the compiler needs a fence.
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+// Inclusive scans over the 64 lanes on the DPP data path (row_shr 1, 2, 4, 8 inside the rows of 16, then the row_bcast15 /
+// row_bcast31 steps that carry a row's total into the following rows): 12 VALU instructions where six __shfl_up steps were
+// six dependent ds_bpermute round trips.  Lanes without a source take 0, the identity of both operations.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned dpp0(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xf, false);
+}
+__device__ __forceinline__ unsigned scan_or64(unsigned x) {
+  x |= dpp0<0x111, 0xf>(x);
+  x |= dpp0<0x112, 0xf>(x);
+  x |= dpp0<0x114, 0xf>(x);
+  x |= dpp0<0x118, 0xf>(x);
+  x |= dpp0<0x142, 0xa>(x);  // row_bcast15 -> rows 1, 3
+  x |= dpp0<0x143, 0xc>(x);  // row_bcast31 -> rows 2, 3
+  return x;
+}
+__device__ __forceinline__ int scan_add64(int v) {
+  unsigned x = (unsigned)v;
+  x += dpp0<0x111, 0xf>(x);
+  x += dpp0<0x112, 0xf>(x);
+  x += dpp0<0x114, 0xf>(x);
+  x += dpp0<0x118, 0xf>(x);
+  x += dpp0<0x142, 0xa>(x);
+  x += dpp0<0x143, 0xc>(x);
+  return (int)x;
+}
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long x, int l) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l);
@@ -544,11 +570,9 @@ __device__ __forceinline__ int augment_wave64(Scratch &g, float cap_max, int lan
 __device__ __forceinline__ int augment_wave64c(Scratch &g, float cap_max, int lane, unsigned long long &adj) {
   const int n = g.n, dst = n - 1;
   const int R = g.ring_n;
-  ring_int *last = g.ring + R;  // [64]: lane of this round's last pusher of node u, -1 = none
   unsigned long long marks = 0;
   int parent = -1;
   if (lane == 0) g.ring[0] = 0;  // the source
-  last[lane] = -1;
   int qh = 0, qt = 1, it = 0;
   bool reached = false;
   while (qt > qh) {
@@ -563,37 +587,32 @@ __device__ __forceinline__ int augment_wave64c(Scratch &g, float cap_max, int la
     const int kstop = sink ? (int)__builtin_ctzll(sink) : 64;  // lane of the first pop of the sink
     const int npop = kstop < len ? kstop + 1 : len;
     unsigned long long pm = lane < npop ? 1ull << v : 0ull;  // -> marks added by the pops at lanes <= this one
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned lo = __shfl_up((unsigned)pm, d), hi = __shfl_up((unsigned)(pm >> 32), d);
-      if (lane >= d) pm |= ((unsigned long long)hi << 32) | lo;
-    }
+    pm = ((unsigned long long)scan_or64((unsigned)(pm >> 32)) << 32) | scan_or64((unsigned)pm);
     const unsigned long long row = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(adj >> 32), v) << 32) |
                                    (unsigned)__shfl((int)(unsigned)adj, v);
     const unsigned long long m = (valid && lane < kstop) ? (row & ~(marks | pm)) : 0ull;
     const int cnt = __popcll(m);
-    int off = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(off, d);
-      if (lane >= d) off += t;
-    }
+    int off = scan_add64(cnt);
     const int total = __builtin_amdgcn_readlane(off, 63);
     off -= cnt;
     if (qt + total - (qh + npop) > R) return augment_wave64(g, cap_max, lane, adj);
-    unsigned long long mm = m;
-    for (int pos = qt + off; mm; ++pos) {  // ascending u, like the serial scan
-      const int u = (int)__builtin_ctzll(mm);
-      mm &= mm - 1;
-      g.ring[pos & (R - 1)] = u;
-      __hip_atomic_fetch_max(&last[u], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    lds_order();
-    const int lk = last[lane];
-    const int pv = __shfl(v, lk < 0 ? 0 : lk);
-    if (lk >= 0) {
-      parent = pv;  // later pushers overwrite
-      last[lane] = -1;
+    // one uniform pass over the nodes anybody pushes this round (ascending u, like the serial scan): a pusher appends u
+    // behind its earlier pushes; the LAST pushing lane's node becomes u's parent (later pushers overwrite) — a ballot and
+    // two scalar reads per node instead of an LDS max per (lane, node) and a shuffle
+    unsigned long long U = ((unsigned long long)__builtin_amdgcn_readlane((int)scan_or64((unsigned)(m >> 32)), 63) << 32) |
+                           (unsigned)__builtin_amdgcn_readlane((int)scan_or64((unsigned)m), 63);
+    int pos = qt + off;
+    while (U) {
+      const int u = (int)__builtin_ctzll(U);
+      U &= U - 1;
+      const bool has = (m >> u) & 1ull;
+      const unsigned long long bm = __ballot(has);
+      if (has) {
+        g.ring[pos & (R - 1)] = u;
+        ++pos;
+      }
+      const int pv = __builtin_amdgcn_readlane(v, 63 - (int)__builtin_clzll(bm));
+      if (lane == u) parent = pv;
     }
     marks |= readlane64(pm, npop - 1);
     qh += npop;
