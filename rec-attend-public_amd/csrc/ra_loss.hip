@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void gt_box_fill_kernel(const float *params, i
 // sum_b = the rectangle's pixel count — one read of the map instead of the map + T rectangle planes.  64 workgroups
 // per image leave partial sums, a second launch adds them in a fixed order. ----
 constexpr int kRectBlocks = 64;  // workgroups per image in the first stage
+template <int TM>  // the unrolled rectangle count: the smallest of 8 / 16 / 32 that holds T (the loop body is predicated, not skipped)
 __global__ __launch_bounds__(256) void box_iou_rects_kernel(const float *box, const float *params, int T, int H, int W,
                                                             float *part) {
   __shared__ float red[4][kMaxT + 1];
@@ -278,15 +279,15 @@ __global__ __launch_bounds__(256) void box_iou_rects_kernel(const float *box, co
   if (tid < T * 4) rect[tid >> 2][tid & 3] = params[((size_t)b * T + (tid >> 2)) * 8 + 4 + (tid & 3)];
   __syncthreads();
   const float *a = box + (size_t)b * H * W;
-  float acc[kMaxT + 1];
+  float acc[TM + 1];
 #pragma unroll
-  for (int t = 0; t <= kMaxT; ++t) acc[t] = 0.f;
+  for (int t = 0; t <= TM; ++t) acc[t] = 0.f;
   for (int e = (blockIdx.x * 256 + tid) * 4; e < H * W; e += kRectBlocks * 1024) {  // W % 4 == 0: four pixels of one row
     const f32x4 v = *reinterpret_cast<const f32x4 *>(a + e);
     const int yy = e / W, xx = e - yy * W;
-    acc[kMaxT] += (v[0] + v[1]) + (v[2] + v[3]);
+    acc[TM] += (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t) {
+    for (int t = 0; t < TM; ++t) {
       if (t < T) {
         const float ty = rect[t][0], tx = rect[t][1], by = rect[t][2], bx = rect[t][3];
         if ((float)yy >= ty && (float)yy <= by) {
@@ -299,13 +300,13 @@ __global__ __launch_bounds__(256) void box_iou_rects_kernel(const float *box, co
     }
   }
 #pragma unroll
-  for (int t = 0; t <= kMaxT; ++t) {
+  for (int t = 0; t <= TM; ++t) {
     float s = acc[t];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) red[wave][t] = s;
+    if (lane == 0) red[wave][t == TM ? kMaxT : t] = s;
   }
   __syncthreads();
-  if (tid <= kMaxT)
+  if (tid <= kMaxT && (tid < TM || tid == kMaxT))
     part[((size_t)b * kRectBlocks + blockIdx.x) * (kMaxT + 1) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
@@ -701,7 +702,12 @@ extern "C" int ra_box_iou_rects_f32(const float *box, const float *params, int B
     return fail(RA_E_SHAPE, "ra_box_iou_rects_f32: T <= %d, W %% 4 == 0 and a 16-byte aligned map required", loss::kMaxT);
   if (ws_floats < ra_box_iou_rects_workspace_floats(B)) return fail(RA_E_WORKSPACE, "ra_box_iou_rects_f32: workspace too small");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(loss::box_iou_rects_kernel, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
+  if (T <= 8)
+    hipLaunchKernelGGL(loss::box_iou_rects_kernel<8>, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
+  else if (T <= 16)
+    hipLaunchKernelGGL(loss::box_iou_rects_kernel<16>, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
+  else
+    hipLaunchKernelGGL(loss::box_iou_rects_kernel<32>, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
   hipLaunchKernelGGL(loss::box_iou_rects_finish_kernel, dim3(B), dim3(64), 0, st, ws, params, T, H, W, iou);
   return launch_status("ra_box_iou_rects_f32");
 }
