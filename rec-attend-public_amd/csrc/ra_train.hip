@@ -399,8 +399,10 @@ __global__ __launch_bounds__(NT) void moments_from_partials_kernel(const float *
   for (int k = tid; k < nparts; k += NT) {
     const f32x4 r = *reinterpret_cast<const f32x4 *>(part + ((size_t)k * CP + c) * 4);
     if (r[0] > 0.f) {
-      const double nk = (double)r[0], mk = (double)r[3] + (double)r[1] / nk, d = mk - M;
-      m2 += ((double)r[2] - (double)r[1] * (double)r[1] / nk) + nk * d * d;
+      // (S2 - S1^2 / n) + n (pivot + S1 / n - M)^2 = S2 + n d^2 + 2 d S1 with d = pivot - M: the S1^2 / n terms cancel — no
+      // float64 division per record
+      const double d = (double)r[3] - M;
+      m2 += (double)r[2] + (double)r[0] * d * d + 2.0 * d * (double)r[1];
     }
   }
   const double M2 = block_sum(m2);
