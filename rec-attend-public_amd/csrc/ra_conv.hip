@@ -440,7 +440,6 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
     }
   };
   const int opool = a.pool;  // 1 or 2
-  const bool vec_ok = (a.Cout & 3) == 0;
   const float lo = a.relu ? 0.f : -__builtin_inff();  // ReLU as one v_max, no flag test per value
   auto epilogue = [&](int) {  // scale/shift (bias + BN), ReLU, 2x2 max-pool, store
     const int b = cur_b, ty0 = cur_ty0, tx0 = cur_tx0;
@@ -770,6 +769,14 @@ extern "C" int ra_conv_fold_bn(const float *bias, const float *beta, const float
   return 0;
 }
 
+namespace ra {
+namespace conv8 {
+bool takes(int Cin, int Cout, int in_bf16, int B, int H, int W);
+int run(const void *x, int Cin, int in_bf16, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu,
+        void *y, int out_bf16, float *part, int *nparts, int cus, hipStream_t st);
+}  // namespace conv8
+}  // namespace ra
+
 static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, int B, int Hs, int Ws, int upsample,
                          const float *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool,
                          const float *plane, int plane_chan, float *y, void *stream, int bf16, float *mom_part = nullptr,
@@ -824,6 +831,10 @@ static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, i
   // a chunk may not straddle the src0/src1 boundary at finer than 4 channels (always true) but
   // the chunk index arithmetic needs C0 % 4 == 0 only: chunks are resolved per channel group.
   hipStream_t st = ra::as_stream(stream);
+  // bf16 mode, eight output channels at full resolution: the bf16-LDS kernel (ra_conv8.hip)
+  if (a.bf16 && !C1 && !a.ups && pool == 1 && !plane && ra::conv8::takes(C0, Cout, a.in_bf16, B, a.H, a.W))
+    return ra::conv8::run(src0, C0, a.in_bf16, B, a.H, a.W, wpacked, scale, shift, relu, y, a.out_bf16, mom_part, nparts,
+                          ra::conv::num_cus(), st);
   if (a.bf16) return ra::conv::k1_dispatch_bf16(a, B, st);
   if (a.mom_part) return ra::conv::k1_dispatch_moments(a, B, st);
   return ra::conv::k1_dispatch_plain(a, B, st);
