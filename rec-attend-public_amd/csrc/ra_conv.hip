@@ -140,7 +140,7 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
 // of squares of every output value u = acc * scale + shift (BEFORE the ReLU) about a per-wave pivot — the wave's first
 // output of that channel — and the wave leaves one record {n, S1, S2, pivot} per channel in a.mom_part
 // [(workgroup * WM + wave row)][CoutP][4].  tf.nn.moments of the layer (nnlib.py:98) then costs one small finishing
-// launch (ra_bn_moments_from_partials_f32: Chan's combination in float64) instead of two more passes over u.
+// launch (ra_bn_moments_from_partials_f32: the records re-based onto one reference in float64) instead of two more passes over u.
 template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false>
 __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
   static_assert(!MOM || SWAP, "batch moments ride on the channel-vector epilogue");
