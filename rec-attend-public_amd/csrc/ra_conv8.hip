@@ -242,6 +242,154 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
   }
 }
 
+// ---- float32 mode: the same tile, exact float32 on v_mfma_f32_4x4x1_16B_f32 ----
+// K1's 16x16x4 tile pads 8 output channels to 16 (half of every MFMA is zero rows; measured 50 % of the float32 matrix
+// rate at that).  The 16-block form has no padding to give away: a block is 4 output channels x 4 pixels x ONE k-value,
+// 16 blocks = 2 channel quads x 8 pixel quads = 32 pixels x 8 channels per instruction (8 cycles, the same 64 FLOP/clk).
+//   A: lane (blk, j) = the weight of channel 4 (blk & 1) + j at this (tap, ci) — 9 Cin registers for the whole launch;
+//   B: lane (blk, j) = pixel 4 (blk >> 1) + j: one ds_read_b128 = 4 input channels = 4 k-steps; the wave computes TWO output
+//      rows from each read (input row i is tap row i of output row 0 and tap row i - 1 of row 1): 12 x Cin/4 reads per
+//      18 Cin MFMAs, so LDS stays under the matrix pipe;
+//   D: lane = 4 consecutive channels of its pixel: one 16-byte store, every lane active.
+template <int CIN, bool MOM>
+__global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
+  constexpr int PB = CIN * 4;    // LDS bytes per pixel
+  constexpr int IPP = CIN / 4;   // 16-byte items per pixel
+  constexpr int NITEM = NPIX * IPP;
+  constexpr int NIT = (NITEM + 255) / 256;
+  // the tile goes from HBM straight into LDS (buffer_load_dwordx4 ... lds: wave-uniform base + 16 bytes per lane, which IS
+  // the tile's layout in item order; lanes past the image or the tile read the descriptor's out-of-range zero): no staging
+  // registers (24 at Cin = 8, where the 72 weight registers already decide the occupancy) and no ds_write pass
+  constexpr int LDSB = (NITEM + 63) / 64 * 1024;  // whole 64-lane pieces
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][LDSB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 3, coq = (lane >> 2) & 1, pix = 4 * (lane >> 3) + j;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.x), 0, a.bytes_x, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes_y, 0x00020000);
+  float w[9][CIN];  // K1's packed order [tap][ci][CoutP = 16]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) w[t][ci] = a.wp[(t * CIN + ci) * 16 + 4 * coq + j];
+  const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(a.scale + 4 * coq);
+  const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(a.shift + 4 * coq);
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  const int lanebase = (2 * wave * LW + pix) * PB;
+
+  int org_b = 0, org_ty = 0, org_tx = 0;
+  auto load_tile = [&](int T, int buf) {
+    const int tx = T % a.ntx, r = T / a.ntx;
+    const int ty = r % a.nty, b = r / a.nty;
+    org_b = b, org_ty = ty * TH, org_tx = tx * TW;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (256 * it + 64 * wave >= NITEM) continue;  // wave-uniform
+      const int i = tid + 256 * it;
+      const int p = i / IPP, sub = i % IPP;
+      const int row = p / LW, col = p - row * LW;
+      const int gy = org_ty - 1 + row, gx = org_tx - 1 + col;
+      const bool ok = (i < NITEM) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
+      const int off = ok ? (((b * a.H + gy) * a.W + gx) * CIN * 4 + sub * 16) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void *)(&lds[buf][(256 * it + 64 * wave) * 16]), 16,
+                                               off, 0, 0, 0);
+    }
+  };
+
+  f32x4 ms1 = {0.f, 0.f, 0.f, 0.f}, ms2 = ms1, mpv = ms1;
+  float mcnt = 0.f;
+  bool mhave = false;
+
+  int T = blockIdx.x, buf = 0;
+  if (T >= a.ntiles) return;
+  load_tile(T, 0);
+  int cur_b = org_b, cur_ty = org_ty, cur_tx = org_tx;
+  __syncthreads();
+  while (true) {
+    const int nT = T + gridDim.x;
+    const bool has_next = nT < a.ntiles;
+    if (has_next) load_tile(nT, buf ^ 1);  // in flight across the MFMAs; the barrier below waits for it
+    const unsigned char *base = &lds[buf][lanebase];
+    const bool interior = (cur_ty + TH <= a.H) & (cur_tx + TW <= a.W);
+#pragma unroll
+    for (int gx = 0; gx < 2; ++gx) {
+      // two accumulators per output row (even / odd input channel): the first and last input rows feed ONE output row, and
+      // a chain of dependent 2-pass MFMAs would wait on its own result
+      f32x4 acc2[2][2];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc2[o >> 1][o & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // 12 steps (input row, tap column), the next step's pixels read while this step's MFMAs issue; the fence after every
+      // step keeps the scheduler from hoisting all 12 x Cin/4 LDS reads above the first MFMA (+56 registers)
+      f32x4 xv[2][IPP];
+      auto fetch = [&](int st, f32x4 *dst) {
+        const int ir = st / 3, kx = st % 3;
+#pragma unroll
+        for (int h = 0; h < IPP; ++h) dst[h] = *reinterpret_cast<const f32x4 *>(base + (ir * LW + 32 * gx + kx) * PB + 16 * h);
+      };
+      fetch(0, xv[0]);
+#pragma unroll
+      for (int st = 0; st < 12; ++st) {
+        const int ir = st / 3, kx = st % 3;
+        if (st + 1 < 12) fetch(st + 1, xv[(st + 1) & 1]);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+          for (int orow = 0; orow < 2; ++orow) {
+            const int ky = ir - orow;
+            if (ky < 0 || ky > 2) continue;
+            acc2[orow][ci & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[ky * 3 + kx][ci], xv[st & 1][ci / 4][ci % 4], acc2[orow][ci & 1], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const f32x4 acc[2] = {acc2[0][0] + acc2[0][1], acc2[1][0] + acc2[1][1]};
+      const int col = cur_tx + 32 * gx + pix;
+#pragma unroll
+      for (int orow = 0; orow < 2; ++orow) {
+        const int row = cur_ty + 2 * wave + orow;
+        f32x4 v = acc[orow] * sc4 + sh4;
+        const bool okp = interior || ((row < a.H) & (col < a.W));
+        if constexpr (MOM) {
+          if (gx == 0 && orow == 0 && !mhave) {  // pivot: the wave's first output of the channel (pixel 0: lanes 0 and 4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mpv[r] = __shfl(v[r], lane & 4, 64);
+          }
+          const float wgt = okp ? 1.f : 0.f;
+          const f32x4 d = (v - mpv) * f32x4{wgt, wgt, wgt, wgt};
+          ms1 += d;
+          ms2 += d * d;
+          mcnt += wgt;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
+        const int off = ((cur_b * a.H + row) * a.W + col) * 8 + 4 * coq;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, okp ? off * 4 : kOOB, 0, 0);
+      }
+      mhave = true;
+    }
+    if (!has_next) break;
+    __syncthreads();
+    buf ^= 1;
+    T = nT;
+    cur_b = org_b, cur_ty = org_ty, cur_tx = org_tx;
+  }
+  if constexpr (MOM) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {  // over the 32 pixels (lane bits 0-1 and 3-5); bit 2 = the channel quad
+      if (o == 4) continue;
+      mcnt += __shfl_xor(mcnt, o, 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ms1[r] += __shfl_xor(ms1[r], o, 64);
+        ms2[r] += __shfl_xor(ms2[r], o, 64);
+      }
+    }
+    if ((lane & ~4) == 0) {
+      f32x4 *rec = reinterpret_cast<f32x4 *>(a.part) + (size_t)(blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rec[4 * coq + r] = f32x4{mcnt, ms1[r], ms2[r], mpv[r]};
+    }
+  }
+}
+
 template <int CIN, bool INB>
 static int launch(const Args &a, int grid, hipStream_t st) {
   if (a.part)
@@ -268,20 +416,36 @@ bool takes(int Cin, int Cout, int in_bf16, int B, int H, int W) {
   return (size_t)B * H * W >= (size_t)64 * 64 * 8;  // K1's tiles fill the chip better on small launches
 }
 
+bool takes_f32(int Cin, int Cout, int B, int H, int W) {
+  if (!enabled() || Cout != 8 || (Cin != 4 && Cin != 8)) return false;
+  return (size_t)B * H * W >= (size_t)64 * 64 * 8;
+}
+
 int run(const void *x, int Cin, int in_bf16, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu,
         void *y, int out_bf16, float *part, int *nparts, int cus, hipStream_t st) {
   Args a;
   a.x = x, a.wp = wp, a.scale = scale, a.shift = shift, a.y = y, a.part = part;
   a.B = B, a.H = H, a.W = W, a.relu = relu, a.out_bf16 = out_bf16;
-  a.bytes_x = (int)((size_t)B * H * W * Cin * (in_bf16 ? 2 : 4));
+  a.bytes_x = (int)((size_t)B * H * W * Cin * (in_bf16 > 0 ? 2 : 4));  // in_bf16 < 0: the float32 kernels
   a.bytes_y = (int)((size_t)B * H * W * 8 * (out_bf16 ? 2 : 4));
   a.ntx = ceil_div(W, TW), a.nty = ceil_div(H, TH);
   const long long nt = (long long)B * a.ntx * a.nty;
   if (nt >= (1ll << 31)) return fail(RA_E_SHAPE, "ra_conv3x3_bf16_f32: tile count");
   a.ntiles = (int)nt;
-  const int cap = 4 * cus;  // the moment records' buffer holds 4 workgroups per CU x 4 waves
+  // the moment records' buffer holds 4 workgroups per CU x 4 waves; the float32 kernel at Cin = 8 keeps 3 resident (LDS)
+  const int cap = (in_bf16 < 0 && Cin == 8 ? 3 : 4) * cus;
   const int grid = a.ntiles < cap ? a.ntiles : cap;
   if (nparts) *nparts = grid * 4;
+  if (in_bf16 < 0) {  // float32 mode
+    void (*kern)(const Args) = Cin == 4 ? (a.part ? conv8f_kernel<4, true> : conv8f_kernel<4, false>)
+                                        : (a.part ? conv8f_kernel<8, true> : conv8f_kernel<8, false>);
+    int per_cu = 0;  // registers decide (72 weights per lane at Cin = 8): ask the runtime, the moment buffer's 4 at most
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int gridf = a.ntiles < (per_cu < 4 ? per_cu : 4) * cus ? a.ntiles : (per_cu < 4 ? per_cu : 4) * cus;
+    if (nparts) *nparts = gridf * 4;
+    hipLaunchKernelGGL(kern, dim3(gridf), dim3(256), 0, st, a);
+    return launch_status("ra_conv3x3_f32 (8-channel form)");
+  }
   if (Cin == 4) return launch<4, false>(a, grid, st);
   if (Cin == 16) return launch<16, true>(a, grid, st);
   return in_bf16 ? launch<8, true>(a, grid, st) : launch<8, false>(a, grid, st);

@@ -53,3 +53,35 @@ def test_conv8_vs_float64(cuda, cin, in_bf, relu):
         flat = want_pre.reshape(-1, cout)
         np.testing.assert_allclose(mean.cpu().numpy(), flat.mean(0).cpu().numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(var.cpu().numpy(), flat.var(0, unbiased=False).cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize('cin', [4, 8])
+@pytest.mark.parametrize('relu', [0, 1])
+def test_conv8_float32_vs_float64(cuda, cin, relu):
+  """float32 mode: the 16-block MFMA form (v_mfma_f32_4x4x1_16B_f32, no padded output channels) — exact float32 products,
+  compared with a float64 convolution of the same float32 operands."""
+  rng = np.random.RandomState(100 + cin)
+  B, H, W, cout = 3, 77, 150, 8
+  x = torch.tensor(rng.randn(B, H, W, cin).astype(np.float32), device=cuda)
+  w = (rng.randn(3, 3, cin, cout) * 0.2).astype(np.float32)
+  wp = torch.tensor(ops.pack_conv_weights(w), device=cuda)
+  cp = ops.cout_padded(cout)
+  sc, sh = torch.ones(cp, device=cuda), torch.tensor(rng.randn(cp).astype(np.float32) * 0.1, device=cuda)
+  want = _ref(x.double(), w.astype(np.float64), sh, relu)
+  want_pre = _ref(x.double(), w.astype(np.float64), sh, 0)
+  lib = rn.lib()
+  npf = lib.ra_conv3x3_moments_part_floats(cout)
+  y = torch.full((B, H, W, cout), 7.0, device=cuda)
+  rn.check(lib.ra_conv3x3_f32(rn.ptr(x), cin, None, 0, B, H, W, 0, rn.ptr(wp), rn.ptr(sc), rn.ptr(sh), cout, relu, 1, None, -1, rn.ptr(y),
+                              rn.stream_ptr()), 'plain')
+  assert float((y.double() - want).abs().max()) < 2e-5
+  y2 = torch.full((B, H, W, cout), 7.0, device=cuda)
+  part, n1 = torch.zeros(npf, device=cuda), C.c_int(0)
+  rn.check(lib.ra_conv3x3_moments_f32(rn.ptr(x), cin, None, 0, B, H, W, 0, rn.ptr(wp), rn.ptr(sc), rn.ptr(sh), cout, relu, 0, rn.ptr(y2),
+                                      rn.ptr(part), npf, C.byref(n1), rn.stream_ptr()), 'moments')
+  assert torch.equal(y2, y)
+  mean, var = torch.empty(cout, device=cuda), torch.empty(cout, device=cuda)
+  rn.check(lib.ra_bn_moments_from_partials_f32(rn.ptr(part), n1.value, cout, rn.ptr(mean), rn.ptr(var), rn.stream_ptr()), 'moments')
+  flat = want_pre.reshape(-1, cout)
+  np.testing.assert_allclose(mean.cpu().numpy(), flat.mean(0).cpu().numpy(), rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(var.cpu().numpy(), flat.var(0, unbiased=False).cpu().numpy(), rtol=1e-5)

@@ -53,4 +53,6 @@ timeout 120 tools/bin/lat_probe 256 > $OUT/${R3}_lat_probe.txt 2>&1
 { for shp in "8 8 512 512 8" "4 8 512 512 8" "16 16 256 256 8" "32 32 128 128 8"; do echo "== Cin Cout H W B = $shp"; timeout 120 python tools/conv_shape_bench.py $shp 2>&1 | grep " us "; done; } > $OUT/${R3}_conv_shape_bench.txt
 timeout 300 python tools/hungarian_step_probe.py 2>&1 | tail -3 > $OUT/${R3}_hungarian_step_probe.txt
 [ -x tools/bin/xcd_barrier_probe ] && { timeout 60 tools/bin/xcd_barrier_probe 48; timeout 60 tools/bin/xcd_barrier_probe 16; } > $OUT/${R3}_xcd_barrier_probe.txt 2>&1
+
+[ -x tools/bin/mfma_rate_probe ] && timeout 60 tools/bin/mfma_rate_probe > $OUT/${R3}_mfma_rate_probe.txt 2>&1
 ls -la $OUT
