@@ -251,6 +251,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
 //      rows from each read (input row i is tap row i of output row 0 and tap row i - 1 of row 1): 12 x Cin/4 reads per
 //      18 Cin MFMAs, so LDS stays under the matrix pipe;
 //   D: lane = 4 consecutive channels of its pixel: one 16-byte store, every lane active.
+// Measured (tools/mfma_rate_probe.hip): the 16-block form issues every 14 cycles from one wave and every ~11.4 per SIMD
+// with four, not the 8 of its 2 passes: 110 TFLOP/s chip.  Also measured and not kept: the same tile on the vector unit
+// (a lane = a pixel column, 4 v_pk_fma_f32 per (tap, ci, pixel) with the filter pair in scalar registers — no padding and
+// no MFMA issue gap on paper): hipcc serialises the s_load_dwordx8 of the filter against lgkmcnt(0) every 16 packed FMAs
+// (hoisted out of the tile loop the 576 values spill), 43.5 us against this kernel's 38.9 at 8 -> 8, 512 x 512 x 8.
 template <int CIN, bool MOM>
 __global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
   constexpr int PB = CIN * 4;    // LDS bytes per pixel
