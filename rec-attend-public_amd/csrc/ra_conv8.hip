@@ -252,10 +252,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
 //      18 Cin MFMAs, so LDS stays under the matrix pipe;
 //   D: lane = 4 consecutive channels of its pixel: one 16-byte store, every lane active.
 // Measured (tools/mfma_rate_probe.hip): the 16-block form issues every 14 cycles from one wave and every ~11.4 per SIMD
-// with four, not the 8 of its 2 passes: 110 TFLOP/s chip.  Also measured and not kept: the same tile on the vector unit
-// (a lane = a pixel column, 4 v_pk_fma_f32 per (tap, ci, pixel) with the filter pair in scalar registers — no padding and
-// no MFMA issue gap on paper): hipcc serialises the s_load_dwordx8 of the filter against lgkmcnt(0) every 16 packed FMAs
-// (hoisted out of the tile loop the 576 values spill), 43.5 us against this kernel's 38.9 at 8 -> 8, 512 x 512 x 8.
+// with four, not the 8 of its 2 passes: 110 TFLOP/s chip.  Where the 39 us at 8 -> 8, 512 x 512 x 8 go: built with
+// -DRA_C8_SKIP (one MFMA per LDS read kept, 1/8 of them) the same launch takes 25 us = 5.4 TB/s, the HBM roofline of the
+// shape; the 4 600 MFMAs per SIMD are 22-27 us at 11.4-14 cycles; three waves per SIMD (72 weight registers per lane)
+// overlap the two only partly.  Also measured and not kept: the same tile on the vector unit (a lane = a pixel column, 4
+// v_pk_fma_f32 per (tap, ci, pixel) with the filter pair in scalar registers — no padding, no MFMA issue gap on paper).
+// Left to hipcc the filter's s_loads either hoist out of the tile loop and spill (576 values) or serialise against
+// lgkmcnt(0) every 16 packed FMAs: 43.5 us; issued one step ahead from inline asm (wait lgkmcnt(0), issue the next 32
+// values into the other register set, 32 FMAs): 39.0 us — the same as this kernel, and equal to it on cache-resident
+// sizes too (51 against 48 TFLOP/s at 2 images), so the simpler matrix form stays.
 template <int CIN, bool MOM>
 __global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
   constexpr int PB = CIN * 4;    // LDS bytes per pixel
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
     if (has_next) load_tile(nT, buf ^ 1);  // in flight across the MFMAs; the barrier below waits for it
     const unsigned char *base = &lds[buf][lanebase];
     const bool interior = (cur_ty + TH <= a.H) & (cur_tx + TW <= a.W);
+    f32x4 accs[2][2];  // [pixel group][output row]
 #pragma unroll
     for (int gx = 0; gx < 2; ++gx) {
       // two accumulators per output row (even / odd input channel): the first and last input rows feed ONE output row, and
@@ -341,11 +347,22 @@ __global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
           for (int orow = 0; orow < 2; ++orow) {
             const int ky = ir - orow;
             if (ky < 0 || ky > 2) continue;
+#ifdef RA_C8_SKIP  // measuring aid: the tile loop without its MFMAs (one per LDS read keeps the reads alive)
+            if (ci % 4 == 0 && orow == (ir == 3))
+#endif
             acc2[orow][ci & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[ky * 3 + kx][ci], xv[st & 1][ci / 4][ci % 4], acc2[orow][ci & 1], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      const f32x4 acc[2] = {acc2[0][0] + acc2[0][1], acc2[1][0] + acc2[1][1]};
+      accs[gx][0] = acc2[0][0] + acc2[0][1];
+      accs[gx][1] = acc2[1][0] + acc2[1][1];
+    }
+    // the barrier BEFORE the stores: its vmcnt(0) (the next tile's HBM -> LDS loads) would otherwise also wait for this
+    // tile's stores to be acknowledged — gfx9 counts loads and stores in one counter — once per tile, with nothing to hide it
+    if (has_next) __syncthreads();
+#pragma unroll
+    for (int gx = 0; gx < 2; ++gx) {
+      const f32x4 *acc = accs[gx];
       const int col = cur_tx + 32 * gx + pix;
 #pragma unroll
       for (int orow = 0; orow < 2; ++orow) {
@@ -371,7 +388,6 @@ __global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
       mhave = true;
     }
     if (!has_next) break;
-    __syncthreads();
     buf ^= 1;
     T = nT;
     cur_b = org_b, cur_ty = org_ty, cur_tx = org_tx;

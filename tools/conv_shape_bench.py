@@ -11,6 +11,8 @@ import numpy as np
 import torch
 
 import ra_native as rn
+if os.environ.get('RA_LIB'):  # A/B: another build of the library (same ABI)
+  rn.LIB_PATH = os.environ['RA_LIB']
 import ra_ops as ops
 
 cin, cout, H, W, B = [int(v) for v in sys.argv[1:6]]

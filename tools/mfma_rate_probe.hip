@@ -29,7 +29,7 @@ int main() {
     hipLaunchKernelGGL(k<1>, dim3(256), dim3(256 * waves), 0, 0, out, cyc, n);
     hipDeviceSynchronize();
     long long h[2]; hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
-    printf("%d wave(s) per SIMD: 4x4x1_16B %.1f clock ticks per MFMA per wave, 16x16x4 %.1f (s_memtime ticks, 100 MHz: x shader clock / 100 MHz for cycles)\n",
+    printf("%d wave(s) per SIMD: 4x4x1_16B %.1f shader cycles per MFMA per wave, 16x16x4 %.1f (s_memrealtime-free: __builtin_readcyclecounter)\n",
            waves, (double)h[0] / (4.0 * n), (double)h[1] / (4.0 * n));
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
