@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 107
+#define RA_ABI_VERSION 108
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -494,6 +494,18 @@ size_t ra_gt_box_workspace_floats(int B, int T);
 int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, float padding_ratio,
                   float min_padding, float *ws, size_t ws_floats, float *params, float *box,
                   void *stream);
+
+/*
+ * ra_knob_setup_f32 — the training step's noisy ground-truth attention and knob masks from the partials ra_gt_box_f32
+ * left in ITS workspace (same B, T; the call must come after it on the stream): modellib.get_gt_attn with per-instance
+ * padding ratio pad [B,T] and centre shift [B,T,2] (full_model.py:567-577; modellib.py:688-701) -> ctr, size [B,T,2]
+ * (an empty instance: top-left 0, bottom-right 2 * min_padding), and knob_box / knob_segm [B,T] = (u <= min(sched[k] *
+ * scale_t, 1)), scale_t = 1 + log(1 + 3 t) with timescale (full_model.py:596-625); sched = 2 device floats (the
+ * probabilities of this step).  One launch on B T numbers; float32 operations in the element-wise form's order.
+ */
+int ra_knob_setup_f32(const float *gt_box_ws, int B, int T, const float *pad, const float *shift, const float *u_box,
+                      const float *u_segm, const float *sched, float min_padding, int timescale, float *ctr, float *size,
+                      float *knob_box, float *knob_segm, void *stream);
 size_t ra_segm_match_workspace_bytes(int B, int N);
 int ra_segm_match_f32(const float *iou, const float *s_gt, int B, int N, void *ws, size_t ws_bytes,
                       float *match, int *status, void *stream);

@@ -249,6 +249,41 @@ __global__ void gt_box_finish_kernel(const float *partial, int ninst, float pad_
   }
 }
 
+// ---- the step's noisy ground-truth attention and knob masks (modellib.get_gt_attn with per-instance padding / centre
+// shift, full_model.py:567-577, and the Bernoulli knobs of :596-625) from the min / max / sum partials ra_gt_box_f32 left
+// in its workspace: one thread per instance, the float32 operations in the order the element-wise form takes them
+// (no contraction).  Replaces a second reduction over y_gt, a pairwise-statistics pass (for "instance not empty") and
+// ~28 element-wise launches on B T numbers.
+__global__ void knob_setup_kernel(const float *partial, int ninst, int T, const float *pad, const float *shift, const float *u_box,
+                                  const float *u_segm, const float *sched, float min_pad, int timescale, float *ctr, float *size,
+                                  float *kbox, float *ksegm) {
+  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= ninst) return;
+  const float *q = partial + (size_t)inst * kGtSplit * 5;
+  float tl[2] = {q[0], q[1]}, br[2] = {q[2], q[3]}, sum = q[4];
+  for (int s = 1; s < kGtSplit; ++s) {
+    tl[0] = fminf(tl[0], q[s * 5 + 0]);
+    tl[1] = fminf(tl[1], q[s * 5 + 1]);
+    br[0] = fmaxf(br[0], q[s * 5 + 2]);
+    br[1] = fmaxf(br[1], q[s * 5 + 3]);
+    sum += q[s * 5 + 4];
+  }
+  const float nz = sum > 0.f ? 1.f : 0.f;
+  const float far = __fmul_rn(1.f - nz, 2.f * min_pad);
+  for (int k = 0; k < 2; ++k) {
+    const float sz = br[k] - tl[k];
+    const float padv = fmaxf(__fmul_rn(pad[inst], sz), min_pad);
+    const float sh = __fmul_rn(shift[inst * 2 + k], sz);
+    const float tln = __fmul_rn(__fsub_rn(__fadd_rn(tl[k], sh), padv), nz);
+    const float brn = __fadd_rn(__fmul_rn(nz, __fadd_rn(__fadd_rn(br[k], sh), padv)), far);
+    ctr[inst * 2 + k] = __fadd_rn(tln, brn) / 2.f;
+    size[inst * 2 + k] = __fsub_rn(brn, tln);
+  }
+  const float scale = timescale ? 1.f + logf(1.f + (float)(inst % T) * 3.f) : 1.f;
+  kbox[inst] = u_box[inst] <= fminf(__fmul_rn(sched[0], scale), 1.f) ? 1.f : 0.f;
+  ksegm[inst] = u_segm[inst] <= fminf(__fmul_rn(sched[1], scale), 1.f) ? 1.f : 0.f;
+}
+
 __global__ __launch_bounds__(256) void gt_box_fill_kernel(const float *params, int H, int W, float *box) {
   const int inst = blockIdx.y;
   const float *p = params + (size_t)inst * 8;
@@ -688,6 +723,16 @@ extern "C" int ra_gt_box_f32(const float *y_gt, int B, int T, int H, int W, floa
   const int gx = ceil_div(H * W, 256 * 4 * 4);
   hipLaunchKernelGGL(loss::gt_box_fill_kernel, dim3(gx, B * T), dim3(256), 0, st, params, H, W, box);
   return launch_status("ra_gt_box_f32");
+}
+
+extern "C" int ra_knob_setup_f32(const float *gt_box_ws, int B, int T, const float *pad, const float *shift, const float *u_box,
+                                 const float *u_segm, const float *sched, float min_padding, int timescale, float *ctr, float *size,
+                                 float *knob_box, float *knob_segm, void *stream) {
+  if (!gt_box_ws || !pad || !shift || !u_box || !u_segm || !sched || !ctr || !size || !knob_box || !knob_segm || B <= 0 || T <= 0)
+    return fail(RA_E_INVALID, "ra_knob_setup_f32: bad argument");
+  hipLaunchKernelGGL(loss::knob_setup_kernel, dim3(ceil_div(B * T, 64)), dim3(64), 0, as_stream(stream), gt_box_ws, B * T, T, pad, shift,
+                     u_box, u_segm, sched, min_padding, timescale, ctr, size, knob_box, knob_segm);
+  return launch_status("ra_knob_setup_f32");
 }
 
 extern "C" size_t ra_box_iou_rects_workspace_floats(int B) {

@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 107  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 108  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -105,6 +105,7 @@ SIGNATURES = {
     'ra_pair_stats_strided_f32': (_I, [_P, _Z, _Z, _P, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ra_gt_box_workspace_floats': (_Z, [_I, _I]),
     'ra_gt_box_f32': (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _Z, _P, _P, _P]),
+    'ra_knob_setup_f32': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     'ra_segm_match_workspace_bytes': (_Z, [_I, _I]),
     'ra_segm_match_f32': (_I, [_P, _P, _I, _I, _P, _Z, _P, _P, _P]),
     'ra_loss_stats_workspace_floats': (_Z, [_I]),

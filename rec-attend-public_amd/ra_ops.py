@@ -556,8 +556,9 @@ def pair_stats(a, b, want=('iou_soft', 'iou_hard', 'dice_hard', 'sum_a', 'sum_b'
   return out
 
 
-def gt_box(y_gt, padding_ratio, min_padding, want_box=True):
-  """modellib.get_gt_box (modellib.py:663-701), center_shift_ratio = 0: params [B,T,8], box."""
+def gt_box(y_gt, padding_ratio, min_padding, want_box=True, want_ws=False):
+  """modellib.get_gt_box (modellib.py:663-701), center_shift_ratio = 0: params [B,T,8], box (want_ws: also the
+  workspace holding the min / max / sum partials, which knob_setup reads)."""
   y_gt = y_gt.contiguous()
   _need_cuda(y_gt)
   B, T, H, W = y_gt.shape
@@ -568,7 +569,20 @@ def gt_box(y_gt, padding_ratio, min_padding, want_box=True):
   check(rn.lib().ra_gt_box_f32(ptr(y_gt), B, T, H, W, C.c_float(padding_ratio),
                                C.c_float(min_padding), ptr(ws), n, ptr(params), ptr(box),
                                rn.stream_ptr()), 'ra_gt_box_f32')
-  return params, box
+  return (params, box, ws) if want_ws else (params, box)
+
+
+def knob_setup(gt_ws, B, T, pad, shift, u_box, u_segm, sched, min_padding, timescale):
+  """The step's noisy ground-truth attention (ctr, size [B,T,2]) and knob masks [B,T,1] from gt_box's partials: one launch
+  (full_model.py:567-577,596-625)."""
+  pad, shift, u_box, u_segm, sched = (t.contiguous() for t in (pad, shift, u_box, u_segm, sched))
+  _need_cuda(gt_ws, pad, shift, u_box, u_segm, sched)
+  dev = gt_ws.device
+  ctr, size = torch.empty((B, T, 2), dtype=torch.float32, device=dev), torch.empty((B, T, 2), dtype=torch.float32, device=dev)
+  kb, ks = torch.empty((B, T, 1), dtype=torch.float32, device=dev), torch.empty((B, T, 1), dtype=torch.float32, device=dev)
+  check(rn.lib().ra_knob_setup_f32(ptr(gt_ws), B, T, ptr(pad), ptr(shift), ptr(u_box), ptr(u_segm), ptr(sched), C.c_float(min_padding),
+                                   int(bool(timescale)), ptr(ctr), ptr(size), ptr(kb), ptr(ks), rn.stream_ptr()), 'ra_knob_setup_f32')
+  return ctr, size, kb, ks
 
 
 def box_iou_rects(box, params):

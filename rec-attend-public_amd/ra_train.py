@@ -1781,13 +1781,25 @@ class TrainStep(object):
     return {'pad': pr - pn + 2 * pn * u(B, T, 1), 'shift': -cn + 2 * cn * u(B, T, 2), 'u_box': u(B, T, 1),
             'u_segm': u(B, T, 1), 'segm_noise': float(opt['gt_segm_noise']) * u(T, B, H, W)}
 
-  def _knob_setup(self, y_gt, knobs):
+  fused_knob_setup = os.environ.get('RA_KNOB_SETUP', '1') != '0'  # one launch on gt_box's partials (ra_knob_setup_f32)
+
+  def _knob_setup(self, y_gt, knobs, gt_ws=None):
     """Noisy GT attention (modellib.get_gt_attn with tensor padding / centre shift,
-    full_model.py:567-577) and the knob masks (:596-625) at the current global step."""
+    full_model.py:567-577) and the knob masks (:596-625) at the current global step.  gt_ws: the workspace of the
+    step's ops.gt_box call (same y_gt, min_padding = padding + 4): the fused form reads its min / max / sum partials
+    instead of reducing y_gt twice more and chaining ~28 element-wise launches."""
     d, opt = self.d, self.opt
     T = d['T']
     dev = y_gt.device
     mp = float(opt['padding']) + 4.0
+    if gt_ws is not None and self.fused_knob_setup:
+      sched = getattr(self, '_sched', None)
+      if sched is None:
+        step = self.bucket.global_step
+        sched = torch.tensor([knob_prob(opt, step, opt['knob_box_offset']), knob_prob(opt, step, opt['knob_segm_offset'])],
+                             dtype=torch.float32, device=dev)
+      return ops.knob_setup(gt_ws, y_gt.shape[0], T, knobs['pad'], knobs['shift'], knobs['u_box'], knobs['u_segm'], sched, mp,
+                            opt.get('knob_use_timescale', False))
     raw, _ = ops.gt_box(y_gt, 0.0, 0.0, want_box=False)          # raw min / max indices (0 for empty instances)
     tl, br = raw[:, :, 0:2], raw[:, :, 2:4]
     nz = (ops.pair_stats(y_gt, y_gt, want=('sum_b',))['sum_b'] > 0).to(torch.float32)[:, :, None]
@@ -1832,11 +1844,11 @@ class TrainStep(object):
     B, T, H, W, Fh, Fw = x.shape[0], d['T'], d['H'], d['W'], d['Fh'], d['Fw']
     use_knob = bool(opt.get('use_knob', False))
     fixed = bool(opt.get('fixed_order', False))
-    gt_corners, box_gt = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0)
+    gt_corners, box_gt, gt_ws = ops.gt_box(y_gt, float(opt['attn_box_padding_ratio']), float(opt['padding']) + 4.0, want_ws=True)
     if use_knob:
       if knobs is None:
         knobs = self.draw_knobs(B, generator)
-      ctr_gtn, size_gtn, knob_box, knob_segm = self._knob_setup(y_gt, knobs)
+      ctr_gtn, size_gtn, knob_box, knob_segm = self._knob_setup(y_gt, knobs, gt_ws)
     canvas = torch.zeros((B, H, W, 1), device=dev)
     stats, y_list, s_list, box_list, cn_list, ls_list, iou_box_steps = {}, [], [], [], [], [], []
     dims_hw = _const('dims', (H, W), dev, lambda: torch.tensor([H, W], dtype=torch.float32, device=dev))

@@ -292,3 +292,38 @@ def test_stacked_step_at_other_mlp_depths_vs_oracle(cuda):
   for k in ('loss', 'iou_soft', 'iou_soft_box', 'conf_loss'):
     assert abs(float(pieces[k]) - float(head[k])) < 3e-4 * max(1.0, abs(float(head[k]))), k
   _compare_grads(gref, lambda k: ts.bucket.grad_of[k].cpu().numpy(), P, float(opt['weight_decay']))
+
+
+def test_knob_setup_fused_equals_elementwise(cuda):
+  """ra_knob_setup_f32 (one launch on ra_gt_box_f32's partials) against the element-wise form of TrainStep._knob_setup
+  (full_model.py:567-577,596-625): same float32 operations in the same order -> identical, including empty instances."""
+  import ra_ops as ops
+  import ra_train as rt
+  rng = np.random.RandomState(7)
+  B, T, H, W = 3, 6, 40, 56
+  y = np.zeros((B, T, H, W), np.float32)
+  for b in range(B):
+    for t in range(T - 1 - b):  # the last instances of every image stay empty
+      y0, x0 = rng.randint(0, H - 12), rng.randint(0, W - 12)
+      y[b, t, y0:y0 + rng.randint(3, 12), x0:x0 + rng.randint(3, 12)] = 1.0
+  y_gt = torch.tensor(y, device=cuda)
+  u = lambda *s: torch.tensor(rng.rand(*s).astype(np.float32), device=cuda)
+  knobs = {'pad': 0.1 + 0.2 * u(B, T, 1), 'shift': -0.05 + 0.1 * u(B, T, 2), 'u_box': u(B, T, 1), 'u_segm': u(B, T, 1)}
+
+  class Stub:
+    d = {'T': T}
+    fused_knob_setup = True
+    _sched = None
+
+    class bucket:
+      global_step = 700
+
+  for timescale in (False, True):
+    Stub.opt = dict(padding=16, knob_use_timescale=timescale, knob_base=1.0, knob_decay=0.9, steps_per_knob_decay=300,
+                    knob_box_offset=300, knob_segm_offset=500)
+    _, _, ws = ops.gt_box(y_gt, 0.25, 20.0, want_box=False, want_ws=True)
+    fused = rt.TrainStep._knob_setup(Stub, y_gt, knobs, ws)
+    plain = rt.TrainStep._knob_setup(Stub, y_gt, knobs, None)
+    for a, b, name in zip(fused, plain, ('ctr', 'size', 'knob_box', 'knob_segm')):
+      assert a.shape == b.shape and torch.equal(a, b), (name, timescale, float((a - b).abs().max()))
+    assert 0 < float(fused[2].sum()) + float(fused[3].sum())  # the knobs are not all off at this step
