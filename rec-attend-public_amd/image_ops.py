@@ -14,10 +14,12 @@ import ra_ops as ops
 
 
 def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=True, rnd_transpose=True,
-                          rnd_colour=False, y=None, d=None, c=None, generator=None, draws=None):
+                          rnd_colour=False, y=None, d=None, c=None, generator=None, draws=None, out=None):
   """x [B,H,W,3], y [B,T,H,W], d [B,H,W,8], c [B,H,W,1] -> dict with the same keys (x, y, d, c).
   draws: the step's decisions given instead of drawn ({off_y, off_x, flip_v, flip_h, transpose[, hue, saturation,
-  brightness, contrast]}; tests)."""
+  brightness, contrast]}; tests).  out: {x, y, d, c} tensors of the inputs' shapes to write the transformed tensors into
+  (the captured training step's static input buffers: no copy afterwards)."""
+  out = out or {}
   results = {'x': x}
   for k, v in (('y', y), ('d', d), ('c', c)):
     if v is not None:
@@ -41,7 +43,7 @@ def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=Tru
     flip_v = bool(rnd_vflip) and float(u[1]) < 0.5 and d is None
     do_tr = bool(rnd_transpose) and float(u[2]) < 0.5 and d is None
     kw = dict(padding=padding, off_y=int(off[0]), off_x=int(off[1]), flip_v=flip_v, flip_h=flip_h, transpose=do_tr)
-  results['x'] = ops.random_transform(x, **kw)
+  results['x'] = ops.random_transform(x, out=None if rnd_colour else out.get('x'), **kw)
   if rnd_colour:  # image_ops.py:99-103
     if draws is not None:
       col = dict(hue=float(draws.get('hue', 0.0)), saturation=float(draws.get('saturation', 1.0)),
@@ -53,10 +55,13 @@ def random_transformation(x, padding, phase_train, rnd_vflip=True, rnd_hflip=Tru
     results['x'] = ops.colour_jitter(results['x'], col['hue'], col['saturation'], col['brightness'], col['contrast'])
   if y is not None:
     B, T, H, W = y.shape
-    results['y'] = ops.random_transform(y.reshape(B * T, H, W), **kw).reshape(B, T, H, W)
+    oy = out.get('y')
+    results['y'] = ops.random_transform(y.reshape(B * T, H, W), out=None if oy is None else oy.reshape(B * T, H, W), **kw).reshape(B, T, H, W)
+    if oy is not None:
+      results['y'] = oy
   if d is not None:
-    results['d'] = ops.random_transform(d, **kw)
+    results['d'] = ops.random_transform(d, out=out.get('d'), **kw)
   if c is not None:
-    results['c'] = ops.random_transform(c, **kw)
+    results['c'] = ops.random_transform(c, out=out.get('c'), **kw)
   results['_draws'] = dict(kw, **col) if rnd_colour else kw
   return results

@@ -697,14 +697,16 @@ def eval_metrics(y_bin, y_gt, s_gt, fg_a=None, fg_b=None):
   return {'iou_pairwise': iou, 'stats': stats, 'inst': inst, 'sizes': main['sum_a']}
 
 
-def random_transform(x, padding, off_y, off_x, flip_v=False, flip_h=False, transpose=False):
-  """image_ops.random_transformation for given draws on x [N,H,W,C] (or [N,H,W] planes)."""
+def random_transform(x, padding, off_y, off_x, flip_v=False, flip_h=False, transpose=False, out=None):
+  """image_ops.random_transformation for given draws on x [N,H,W,C] (or [N,H,W] planes); out: a contiguous tensor of x's
+  shape to write into (not x itself)."""
   x = x.contiguous()
-  _need_cuda(x)
+  _need_cuda(x, out)
   shape = x.shape
   N, H, W = shape[0], shape[1], shape[2]
   Cc = shape[3] if x.dim() == 4 else 1
-  out = torch.empty_like(x)
+  if out is None or tuple(out.shape) != tuple(shape) or not out.is_contiguous() or out.dtype != x.dtype or out.data_ptr() == x.data_ptr():
+    out = torch.empty_like(x)
   check(rn.lib().ra_random_transform_f32(ptr(x), N, H, W, Cc, int(padding), int(off_y), int(off_x),
                                          int(bool(flip_v)), int(bool(flip_h)), int(bool(transpose)),
                                          ptr(out), rn.stream_ptr()), 'ra_random_transform_f32')

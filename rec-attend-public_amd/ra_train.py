@@ -1769,17 +1769,31 @@ class TrainStep(object):
     return hit
 
   # ------------------------------------------------------------------ forward + loss
-  def draw_knobs(self, B, generator=None):
+  def draw_knobs(self, B, generator=None, out=None):
     """The random draws of one training step (full_model.py:567-577,612-625,829-831): GT-box padding
     and centre noise, the two Bernoulli knobs, the per-timestep segmentation noise.  One generator
-    per rank (seeded rank-offset by the caller) keeps data-parallel ranks decorrelated."""
+    per rank (seeded rank-offset by the caller) keeps data-parallel ranks decorrelated.
+    out: the captured step's static buffers — the [T,B,H,W] noise plane is drawn straight into its buffer
+    (uniform_(0, a) = a * rand bit for bit, same generator consumption: one launch instead of draw + scale + a 134 MB copy
+    at cfg4), the B T-sized draws are copied."""
     d, opt = self.d, self.opt
     dev = self.bucket.param.device
     T, H, W = d['T'], d['H'], d['W']
     u = lambda *s: torch.rand(s, generator=generator, device=dev)
     pr, pn, cn = float(opt['attn_box_padding_ratio']), float(opt['gt_box_pad_noise']), float(opt['gt_box_ctr_noise'])
-    return {'pad': pr - pn + 2 * pn * u(B, T, 1), 'shift': -cn + 2 * cn * u(B, T, 2), 'u_box': u(B, T, 1),
-            'u_segm': u(B, T, 1), 'segm_noise': float(opt['gt_segm_noise']) * u(T, B, H, W)}
+    small = {'pad': pr - pn + 2 * pn * u(B, T, 1), 'shift': -cn + 2 * cn * u(B, T, 2), 'u_box': u(B, T, 1), 'u_segm': u(B, T, 1)}
+    if out is None:
+      small['segm_noise'] = float(opt['gt_segm_noise']) * u(T, B, H, W)
+      return small
+    for k, v in small.items():
+      out[k].copy_(v)
+    out['segm_noise'].uniform_(0.0, float(opt['gt_segm_noise']), generator=generator)
+    return out
+
+  def knob_shapes(self, B):
+    d = self.d
+    return {'pad': (B, d['T'], 1), 'shift': (B, d['T'], 2), 'u_box': (B, d['T'], 1), 'u_segm': (B, d['T'], 1),
+            'segm_noise': (d['T'], B, d['H'], d['W'])}
 
   fused_knob_setup = os.environ.get('RA_KNOB_SETUP', '1') != '0'  # one launch on gt_box's partials (ra_knob_setup_f32)
 
@@ -2070,6 +2084,22 @@ class TrainStep(object):
           self.model[key + '_ema_var'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * var)
     return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in pieces.items()}
 
+  def _static_inputs(self, x, y_gt, s_gt, knobs, extra):
+    """The captured step's static input buffers for these shapes ({x, y, d, c} as image_ops names them), or None: the
+    augmentation then writes into them and _graphed finds nothing to copy."""
+    use_knob = bool(self.opt.get('use_knob', False)) or isinstance(self, BoxTrainStep)
+    shp = {'x': x, 'y_gt': y_gt, 's_gt': s_gt}
+    shp.update({k: v for k, v in extra.items() if v is not None})
+    try:
+      ins = tuple((k, tuple(np.shape(v) if not isinstance(v, torch.Tensor) else v.shape)) for k, v in sorted(shp.items()))
+      ks = {k: tuple(v.shape) for k, v in knobs.items()} if knobs is not None else (self.knob_shapes(np.shape(x)[0]) if use_knob else {})
+    except Exception:
+      return None
+    st = self._graphs.get(ins + tuple(sorted(ks.items())))
+    if st is None or 'graph' not in st:
+      return None
+    return {'x': st['ins']['x'], 'y': st['ins']['y_gt'], 'd': st['ins'].get('d_in'), 'c': st['ins'].get('y_in')}
+
   def _graphed(self, x, y_gt, s_gt, knobs, generator, extra):
     """The same work as _grads_and_stats, replayed from a HIP graph.  A training step issues ~24 000
     kernels (16 timesteps x 40 layers x forward / backward pieces plus the dense glue under autograd);
@@ -2083,8 +2113,15 @@ class TrainStep(object):
     ins = {'x': as_t(x), 'y_gt': as_t(y_gt), 's_gt': as_t(s_gt)}
     ins.update({k: as_t(v) for k, v in extra.items() if v is not None})
     use_knob = bool(self.opt.get('use_knob', False)) or isinstance(self, BoxTrainStep)
+    in_place = False
     if knobs is None and use_knob:
-      knobs = self.draw_knobs(ins['x'].shape[0], generator)
+      # a captured step of this shape exists: draw straight into its static buffers
+      kkey = tuple((k, tuple(v.shape)) for k, v in sorted(ins.items())) + tuple(sorted(self.knob_shapes(ins['x'].shape[0]).items()))
+      st0 = self._graphs.get(kkey)
+      if st0 is not None and 'graph' in st0:
+        knobs, in_place = self.draw_knobs(ins['x'].shape[0], generator, out=st0['knobs']), True
+      else:
+        knobs = self.draw_knobs(ins['x'].shape[0], generator)
     knobs = {k: as_t(v) for k, v in (knobs or {}).items()}
     key = tuple((k, tuple(v.shape)) for k, v in sorted(ins.items())) + tuple((k, tuple(v.shape)) for k, v in sorted(knobs.items()))
     st = self._graphs.get(key)
@@ -2111,14 +2148,16 @@ class TrainStep(object):
       st['graph'] = g
     else:
       for k, v in ins.items():
-        st['ins'][k].copy_(v)
-      for k, v in knobs.items():
-        st['knobs'][k].copy_(v)
+        if v.data_ptr() != st['ins'][k].data_ptr():  # the augmentation wrote into the static buffer
+          st['ins'][k].copy_(v)
+      if not in_place:
+        for k, v in knobs.items():
+          st['knobs'][k].copy_(v)
       st['sched'].copy_(torch.tensor(sched, dtype=torch.float32), non_blocking=False)
     st['graph'].replay()
     return dict(st['out'])
 
-  def augment(self, x, y_gt, extra, aug=None):
+  def augment(self, x, y_gt, extra, aug=None, out=None):
     """The in-graph augmentation in front of the training graph (full_model.py:203-232, box_model.py: the same
     call): img.random_transformation on x, y_gt[, d_in, y_in] with phase_train true — ONE crop offset in
     [0, 2 * padding) per batch after zero padding, and the flip / transpose decisions model_opt switches on
@@ -2136,7 +2175,8 @@ class TrainStep(object):
         as_t(x), int(opt.get('padding', 0)), True, rnd_vflip=bool(opt.get('rnd_vflip', False)),
         rnd_hflip=bool(opt.get('rnd_hflip', False)), rnd_transpose=bool(opt.get('rnd_transpose', False)),
         rnd_colour=bool(opt.get('rnd_colour', False)), y=as_t(y_gt),
-        d=as_t(extra.get('d_in')), c=as_t(extra.get('y_in')), generator=self.aug_gen, draws=aug if isinstance(aug, dict) else None)
+        d=as_t(extra.get('d_in')), c=as_t(extra.get('y_in')), generator=self.aug_gen, draws=aug if isinstance(aug, dict) else None,
+        out=out)
     extra = dict(extra)
     if 'd' in r:
       extra['d_in'] = r['d']
@@ -2149,11 +2189,11 @@ class TrainStep(object):
     """loss + train_step: augmentation, backward into the flat bucket, one all-reduce, clip + Adam, BN EMA update.
     The reported `loss` excludes nothing the reference includes except the weight-decay terms, which
     enter through their gradient (wd * w) inside the optimizer kernel."""
-    x, y_gt, extra = self.augment(x, y_gt, extra, aug)
     if knobs is not None:
       dev = self.bucket.param.device
       knobs = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32))).to(
           device=dev, dtype=torch.float32) for k, v in knobs.items()}
+    x, y_gt, extra = self.augment(x, y_gt, extra, aug, self._static_inputs(x, y_gt, s_gt, knobs, extra) if self.use_graph else None)
     if self.use_graph:
       out = self._graphed(x, y_gt, s_gt, knobs, generator, extra)
     else:
@@ -2197,10 +2237,18 @@ class BoxTrainStep(TrainStep):
     self.cmap_c = None if cmap_c == list(range(len(cmap_c))) else cmap_c
     self.cmap_a = None
 
-  def draw_knobs(self, B, generator=None):
-    """The step's one random draw: the canvas noise U[0, 0.3) (box_model.py:500-502)."""
+  def draw_knobs(self, B, generator=None, out=None):
+    """The step's one random draw: the canvas noise U[0, 0.3) (box_model.py:500-502); out: drawn into the captured
+    step's static buffer."""
     d = self.d
+    if out is not None:
+      out['noise'].uniform_(0.0, 0.3, generator=generator)
+      return out
     return {'noise': 0.3 * torch.rand((d['T'], B, d['H'], d['W']), generator=generator, device=self.bucket.param.device)}
+
+  def knob_shapes(self, B):
+    d = self.d
+    return {'noise': (d['T'], B, d['H'], d['W'])}
 
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None, d_in=None, y_in=None):
     P, d, opt = self.leaves, self.d, self.opt

@@ -327,3 +327,29 @@ def test_knob_setup_fused_equals_elementwise(cuda):
     for a, b, name in zip(fused, plain, ('ctr', 'size', 'knob_box', 'knob_segm')):
       assert a.shape == b.shape and torch.equal(a, b), (name, timescale, float((a - b).abs().max()))
     assert 0 < float(fused[2].sum()) + float(fused[3].sum())  # the knobs are not all off at this step
+
+
+def test_draw_knobs_in_place_equals_fresh(cuda):
+  """The captured step's random draws written into its static buffers (the noise plane by uniform_(0, a)) against the
+  fresh tensors of draw_knobs: same generator state -> the same bits (full_model.py:567-577,829-831)."""
+  import ra_train as rt
+
+  class Stub:
+    d = {'T': 5, 'H': 24, 'W': 40}
+    opt = dict(attn_box_padding_ratio=0.2, gt_box_pad_noise=0.1, gt_box_ctr_noise=0.05, gt_segm_noise=0.3)
+
+    class bucket:
+      param = torch.zeros(1, device=cuda)
+
+  B = 3
+  g = torch.Generator(device=cuda)
+  g.manual_seed(99)
+  fresh = rt.TrainStep.draw_knobs(Stub, B, g)
+  shapes = rt.TrainStep.knob_shapes(Stub, B)
+  assert {k: tuple(v.shape) for k, v in fresh.items()} == shapes
+  out = {k: torch.full(s, -1.0, device=cuda) for k, s in shapes.items()}
+  g.manual_seed(99)
+  got = rt.TrainStep.draw_knobs(Stub, B, g, out=out)
+  for k in fresh:
+    assert torch.equal(got[k], fresh[k]), k
+  assert float(fresh['segm_noise'].max()) < 0.3 and float(fresh['segm_noise'].min()) >= 0.0
