@@ -260,7 +260,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
 // Left to hipcc the filter's s_loads either hoist out of the tile loop and spill (576 values) or serialise against
 // lgkmcnt(0) every 16 packed FMAs: 43.5 us; issued one step ahead from inline asm (wait lgkmcnt(0), issue the next 32
 // values into the other register set, 32 FMAs): 39.0 us — the same as this kernel, and equal to it on cache-resident
-// sizes too (51 against 48 TFLOP/s at 2 images), so the simpler matrix form stays.
+// sizes too (51 against 48 TFLOP/s at 2 images), so the simpler matrix form stays.  A third inner loop — v_mfma_f32_16x16x4
+// with the 16 rows = 2 output rows x 8 channels over the four input rows they see (24 k-steps per 16 pixels x 2 rows, 9/12
+// useful, one ds_read_b128 per 4 MFMAs, 24 filter registers instead of 72) — also took 39.5 us, and 42 us with three LDS
+// tiles and the loads two tiles ahead (counted vmcnt, raw s_barrier).  Three loops with 22-31 us of arithmetic each land on
+// the same 39: the launch behaves like the SUM of most of its memory pipeline (25 us, measured with the arithmetic
+// compiled out) and its arithmetic, not their maximum, whatever the prefetch distance; not understood, not pursued.
 template <int CIN, bool MOM>
 __global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
   constexpr int PB = CIN * 4;    // LDS bytes per pixel
