@@ -773,6 +773,9 @@ namespace ra {
 namespace conv8 {
 bool takes(int Cin, int Cout, int in_bf16, int B, int H, int W);
 bool takes_f32(int Cin, int Cout, int B, int H, int W);
+bool takes16_f32(int Cin, int Cout, int B, int H, int W);
+int run16_f32(const void *x, int Cin, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu, void *y,
+              float *part, int *nparts, int cus, hipStream_t st);
 int run(const void *x, int Cin, int in_bf16, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu,
         void *y, int out_bf16, float *part, int *nparts, int cus, hipStream_t st);
 }  // namespace conv8
@@ -840,6 +843,8 @@ static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, i
   // float32, eight output channels at full resolution (training: forward with moments, data gradients): the 16-block MFMA form
   if (!C1 && !a.ups && pool == 1 && !plane && ra::conv8::takes_f32(C0, Cout, B, a.H, a.W))
     return ra::conv8::run(src0, C0, -1, B, a.H, a.W, wpacked, scale, shift, relu, y, 0, mom_part, nparts, ra::conv::num_cus(), st);
+  if (!C1 && !a.ups && pool == 1 && !plane && ra::conv8::takes16_f32(C0, Cout, B, a.H, a.W))  // 16 channels at half resolution
+    return ra::conv8::run16_f32(src0, C0, B, a.H, a.W, wpacked, scale, shift, relu, y, mom_part, nparts, ra::conv::num_cus(), st);
   if (a.mom_part) return ra::conv::k1_dispatch_moments(a, B, st);
   return ra::conv::k1_dispatch_plain(a, B, st);
 }

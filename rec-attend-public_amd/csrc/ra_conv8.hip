@@ -416,6 +416,138 @@ __global__ __launch_bounds__(256) void conv8f_kernel(const Args a) {
   }
 }
 
+// ---- float32 mode, SIXTEEN output channels (the controller CNN's half-resolution layers: 8 -> 16 and 16 -> 16 at 256 x 256) ----
+// K1 runs these at half of the float32 matrix rate (33.8 us for 16 -> 16 at 256 x 256 x 8: 2.4 GFLOP).  Same tile scheme as
+// the 8-channel kernels (HBM -> LDS directly, double-buffered, persistent), v_mfma_f32_16x16x4_f32 with A = the filter
+// (16 channels x 4 k-values, held in registers: 4 * ceil(9 Cin / 16) per lane) and B = 16 consecutive pixels.  The k-slots
+// of a group of four MFMAs are laid out so that ONE ds_read_b128 per lane feeds all four: slot (m, kq) = channel
+// 4 (kq % QP) + m of tap TPG g + kq / QP (QP = Cin / 4 quads per pixel, TPG = 16 / Cin taps per group; Cin = 8 pads its
+// ninth tap's group with zero weights: 20 MFMAs per 16 pixels for 18).  D lane (px, q) = channels 4q .. 4q + 3 of pixel px.
+constexpr int TW2 = 32, LW2 = TW2 + 2, NPIX2 = LW2 * LH;
+template <int CIN, bool MOM>
+__global__ __launch_bounds__(256) void conv16_kernel(const Args a) {
+  constexpr int PB = CIN * 4;
+  constexpr int IPP = CIN / 4;
+  constexpr int NITEM = NPIX2 * IPP;
+  constexpr int NIT = (NITEM + 255) / 256;
+  constexpr int LDSB = (NITEM + 63) / 64 * 1024;
+  constexpr int QP = CIN / 4, TPG = 4 / QP, NG = (9 + TPG - 1) / TPG;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][LDSB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, px = lane & 15, q = lane >> 4;
+  const int csel = q % QP, tsel = q / QP;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.x), 0, a.bytes_x, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes_y, 0x00020000);
+  float wreg[NG][4];  // A operand: row = output channel (lane & 15), k-slot (m, q)
+  int toff[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int tap = TPG * g + tsel, t = tap < 9 ? tap : 0;
+    toff[g] = ((t / 3) * LW2 + t % 3) * PB + 16 * csel;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) wreg[g][m] = tap < 9 ? a.wp[(tap * CIN + 4 * csel + m) * 16 + px] : 0.f;
+  }
+  const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(a.scale + 4 * q);
+  const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(a.shift + 4 * q);
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  const int lanebase = (2 * wave * LW2 + px) * PB;
+
+  int org_b = 0, org_ty = 0, org_tx = 0;
+  auto load_tile = [&](int T, int buf) {
+    const int tx = T % a.ntx, r = T / a.ntx;
+    const int ty = r % a.nty, b = r / a.nty;
+    org_b = b, org_ty = ty * TH, org_tx = tx * TW2;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (256 * it + 64 * wave >= NITEM) continue;  // wave-uniform
+      const int i = tid + 256 * it;
+      const int p = i / IPP, sub = i % IPP;
+      const int row = p / LW2, col = p - row * LW2;
+      const int gy = org_ty - 1 + row, gx = org_tx - 1 + col;
+      const bool ok = (i < NITEM) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
+      const int off = ok ? (((b * a.H + gy) * a.W + gx) * CIN * 4 + sub * 16) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void *)(&lds[buf][(256 * it + 64 * wave) * 16]), 16,
+                                               off, 0, 0, 0);
+    }
+  };
+
+  f32x4 ms1 = {0.f, 0.f, 0.f, 0.f}, ms2 = ms1, mpv = ms1;
+  float mcnt = 0.f;
+  bool mhave = false;
+
+  int T = blockIdx.x, buf = 0;
+  if (T >= a.ntiles) return;
+  load_tile(T, 0);
+  int cur_b = org_b, cur_ty = org_ty, cur_tx = org_tx;
+  __syncthreads();
+  while (true) {
+    const int nT = T + gridDim.x;
+    const bool has_next = nT < a.ntiles;
+    if (has_next) load_tile(nT, buf ^ 1);  // in flight across the MFMAs; the barrier below waits for it
+    const unsigned char *base = &lds[buf][lanebase];
+    f32x4 acc[4];  // [row of the wave's two][16-pixel group of the row's two]
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a 16x16x4 result is ready after 40 cycles, the same accumulator's next instruction may issue after 32: the four
+    // accumulators take turns
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      f32x4 xv[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) xv[o] = *reinterpret_cast<const f32x4 *>(base + toff[g] + ((o >> 1) * LW2 + 16 * (o & 1)) * PB);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g][m], xv[o][m], acc[o], 0, 0, 0);
+    }
+    if (has_next) __syncthreads();  // ahead of the stores: its vmcnt(0) is for the next tile's loads
+    {
+      const bool interior = (cur_ty + TH <= a.H) & (cur_tx + TW2 <= a.W);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int row = cur_ty + 2 * wave + (o >> 1), col = cur_tx + 16 * (o & 1) + px;
+        f32x4 v = acc[o] * sc4 + sh4;
+        const bool okp = interior || ((row < a.H) & (col < a.W));
+        if constexpr (MOM) {
+          if (o == 0 && !mhave) {  // pivot: the wave's first output of the channel (pixel 0 of the lane's quarter)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mpv[r] = __shfl(v[r], lane & 48, 64);
+          }
+          const float wgt = okp ? 1.f : 0.f;
+          const f32x4 d = (v - mpv) * f32x4{wgt, wgt, wgt, wgt};
+          ms1 += d;
+          ms2 += d * d;
+          mcnt += wgt;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
+        const int off = ((cur_b * a.H + row) * a.W + col) * 16 + 4 * q;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, okp ? off * 4 : kOOB, 0, 0);
+      }
+      mhave = true;
+    }
+    if (!has_next) break;
+    buf ^= 1;
+    T = nT;
+    cur_b = org_b, cur_ty = org_ty, cur_tx = org_tx;
+  }
+  if constexpr (MOM) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {  // over the 16 pixels; lane bits 4-5 = the channel quad
+      mcnt += __shfl_xor(mcnt, o, 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ms1[r] += __shfl_xor(ms1[r], o, 64);
+        ms2[r] += __shfl_xor(ms2[r], o, 64);
+      }
+    }
+    if (px == 0) {
+      f32x4 *rec = reinterpret_cast<f32x4 *>(a.part) + (size_t)(blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rec[4 * q + r] = f32x4{mcnt, ms1[r], ms2[r], mpv[r]};
+    }
+  }
+}
+
 template <int CIN, bool INB>
 static int launch(const Args &a, int grid, hipStream_t st) {
   if (a.part)
@@ -445,6 +577,33 @@ bool takes(int Cin, int Cout, int in_bf16, int B, int H, int W) {
 bool takes_f32(int Cin, int Cout, int B, int H, int W) {
   if (!enabled() || Cout != 8 || (Cin != 4 && Cin != 8)) return false;
   return (size_t)B * H * W >= (size_t)64 * 64 * 8;
+}
+
+bool takes16_f32(int Cin, int Cout, int B, int H, int W) {
+  if (!enabled() || Cout != 16 || (Cin != 8 && Cin != 16)) return false;
+  return (size_t)B * H * W >= (size_t)64 * 64 * 8;
+}
+
+int run16_f32(const void *x, int Cin, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu, void *y,
+              float *part, int *nparts, int cus, hipStream_t st) {
+  Args a;
+  a.x = x, a.wp = wp, a.scale = scale, a.shift = shift, a.y = y, a.part = part;
+  a.B = B, a.H = H, a.W = W, a.relu = relu, a.out_bf16 = 0;
+  a.bytes_x = (int)((size_t)B * H * W * Cin * 4);
+  a.bytes_y = (int)((size_t)B * H * W * 16 * 4);
+  a.ntx = ceil_div(W, TW2), a.nty = ceil_div(H, TH);
+  const long long nt = (long long)B * a.ntx * a.nty;
+  if (nt >= (1ll << 31)) return fail(RA_E_SHAPE, "ra_conv3x3_f32: tile count");
+  a.ntiles = (int)nt;
+  void (*kern)(const Args) = Cin == 8 ? (part ? conv16_kernel<8, true> : conv16_kernel<8, false>)
+                                      : (part ? conv16_kernel<16, true> : conv16_kernel<16, false>);
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  const int cap = (per_cu < 4 ? per_cu : 4) * cus;  // the moment records' buffer holds 4 workgroups per CU x 4 waves
+  const int grid = a.ntiles < cap ? a.ntiles : cap;
+  if (nparts) *nparts = grid * 4;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+  return launch_status("ra_conv3x3_f32 (16-channel form)");
 }
 
 int run(const void *x, int Cin, int in_bf16, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu,

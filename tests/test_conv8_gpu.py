@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _ref(x64, w, sh, relu):
   y = torch.nn.functional.conv2d(x64.permute(0, 3, 1, 2), torch.tensor(w, dtype=torch.float64, device=x64.device).permute(3, 2, 0, 1), padding=1)
-  y = y.permute(0, 2, 3, 1) + sh.double()[:8]
+  y = y.permute(0, 2, 3, 1) + sh.double()[:y.shape[1]]
   return torch.clamp_min(y, 0.0) if relu else y
 
 
@@ -55,13 +55,14 @@ def test_conv8_vs_float64(cuda, cin, in_bf, relu):
         np.testing.assert_allclose(var.cpu().numpy(), flat.var(0, unbiased=False).cpu().numpy(), rtol=1e-5)
 
 
-@pytest.mark.parametrize('cin', [4, 8])
+@pytest.mark.parametrize('cin,cout', [(4, 8), (8, 8), (8, 16), (16, 16)])
 @pytest.mark.parametrize('relu', [0, 1])
-def test_conv8_float32_vs_float64(cuda, cin, relu):
-  """float32 mode: the 16-block MFMA form (v_mfma_f32_4x4x1_16B_f32, no padded output channels) — exact float32 products,
-  compared with a float64 convolution of the same float32 operands."""
-  rng = np.random.RandomState(100 + cin)
-  B, H, W, cout = 3, 77, 150, 8
+def test_conv8_float32_vs_float64(cuda, cin, cout, relu):
+  """float32 mode: 8 output channels on the 16-block MFMA form (v_mfma_f32_4x4x1_16B_f32, no padded output channels), 16 on
+  conv16_kernel (16x16x4 with one ds_read_b128 per four MFMAs) — exact float32 products, compared with a float64
+  convolution of the same float32 operands."""
+  rng = np.random.RandomState(100 + cin + cout)
+  B, H, W = 3, 77, 150
   x = torch.tensor(rng.randn(B, H, W, cin).astype(np.float32), device=cuda)
   w = (rng.randn(3, 3, cin, cout) * 0.2).astype(np.float32)
   wp = torch.tensor(ops.pack_conv_weights(w), device=cuda)
