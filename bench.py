@@ -322,7 +322,9 @@ def train_steps(rank, world, B, T, S, steps, warmup, sync_bn=False, dtype='f32')
   for _ in range(steps):
     loss, _ = model.run(['loss', 'train_step'], feed)
   ra_dist.barrier()
-  return ra_dist.max_over_ranks(time.perf_counter() - t0), float(loss), model
+  dt = ra_dist.max_over_ranks(time.perf_counter() - t0)
+  model.trainer.flush_status()  # run() checks a step's solver statuses one step late: the last step's now
+  return dt, float(loss), model
 
 
 def train_layer_bytes(opt, B, S, T, bf16_store=False):

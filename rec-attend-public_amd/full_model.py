@@ -240,6 +240,7 @@ class Model(dict):
         raise NotImplementedError('output %r is not available from the training graph' % n)
     if as_numpy:
       torch.cuda.synchronize()
+      tr.flush_status()  # numpy outputs = the synchronous sess.run: this step's solver statuses are checked now
       res = [r.detach().cpu().numpy() if isinstance(r, torch.Tensor) else r for r in res]
     return res[0] if single else res
 

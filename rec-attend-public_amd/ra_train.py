@@ -1442,6 +1442,7 @@ class TrainStep(object):
   def state_dict(self):
     """Everything a restart needs beyond Model.state_dict_numpy() (weights + EMA shadows): Adam m / v per parameter
     and global_step (learn-rate staircase, knob schedules)."""
+    self.flush_status()  # a checkpoint is not written over a step whose matching failed
     return self.bucket.state_dict()
 
   def load_state_dict(self, state, strict=True):
@@ -2084,6 +2085,27 @@ class TrainStep(object):
           self.model[key + '_ema_var'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * var)
     return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in pieces.items()}
 
+  def _check_status(self, rec):
+    ev, host, n_match = rec
+    ev.synchronize()
+    h = host.clone()
+    if n_match:
+      ops.check_match_status(h[:n_match], 'f_segm_match')
+    if h.numel() > n_match and int(h[n_match:].abs().max()) != 0:  # a controller workgroup timed out on its peers
+      sc = getattr(self, '_seqc', None)
+      if sc is not None:
+        sc['status'].zero_()
+      raise rn.RecAttendError('controller_split (sequential phase of the training step): a workgroup waited for a peer that '
+                              'never became resident — is another process using this GPU?  RA_TRAIN_CTRL_SPLIT=0 runs the '
+                              'one-workgroup controller')
+
+  def flush_status(self):
+    """Check the solver / controller statuses of the LAST step now (run() checks each step's record one step late)."""
+    rec = getattr(self, '_status_pending', None)
+    self._status_pending = None
+    if rec is not None:
+      self._check_status(rec)
+
   def _static_inputs(self, x, y_gt, s_gt, knobs, extra):
     """The captured step's static input buffers for these shapes ({x, y, d, c} as image_ops names them), or None: the
     augmentation then writes into them and _graphed finds nothing to copy."""
@@ -2153,7 +2175,14 @@ class TrainStep(object):
       if not in_place:
         for k, v in knobs.items():
           st['knobs'][k].copy_(v)
-      st['sched'].copy_(torch.tensor(sched, dtype=torch.float32), non_blocking=False)
+      # pinned and asynchronous: a pageable source made this copy wait for the PREVIOUS step on the stream — a host sync
+      # per step with the GPU idle behind it.  Four buffers in rotation: the status check keeps the host at most one
+      # step ahead of the device, so a buffer is never rewritten while its copy is still queued.
+      ring = st.setdefault('sched_host', [torch.empty(2, dtype=torch.float32).pin_memory() for _ in range(4)])
+      st['sched_i'] = (st.get('sched_i', -1) + 1) % len(ring)
+      hb = ring[st['sched_i']]
+      hb[0], hb[1] = float(sched[0]), float(sched[1])
+      st['sched'].copy_(hb, non_blocking=True)
     st['graph'].replay()
     return dict(st['out'])
 
@@ -2201,14 +2230,32 @@ class TrainStep(object):
       out = self._grads_and_stats(x, y_gt, s_gt, knobs, generator, extra)
     world = self.bucket.allreduce()
     lr = self.bucket.step(world=world)
-    for st in out.pop('_match_status', []):  # one host sync per step, after everything has been queued
-      ops.check_match_status(st, 'f_segm_match')
+    # The solver / controller statuses of this step go to pinned host memory behind the step on the stream; what is CHECKED
+    # here is the previous step's record, which landed long ago: no host sync per step (three of them, with the GPU idle
+    # while the host prepared the next step, were 0.1-0.4 ms of a 24 ms step).  A failed matching therefore raises one step
+    # late; flush_status() checks the record of the last step (full_model.run with numpy outputs, checkpointing and the
+    # bench call it).
+    sts = [st.reshape(-1).to(torch.int32) for st in out.pop('_match_status', [])]
     sc = getattr(self, '_seqc', None)
-    if sc is not None and sc.get('ok') and int(sc['status'].item()) != 0:  # a controller workgroup timed out on its peers
-      sc['status'].zero_()
-      raise rn.RecAttendError('controller_split (sequential phase of the training step): a workgroup waited for a peer that '
-                              'never became resident — is another process using this GPU?  RA_TRAIN_CTRL_SPLIT=0 runs the '
-                              'one-workgroup controller')
+    n_match = sum(int(t.numel()) for t in sts)
+    if sc is not None and sc.get('ok'):
+      sts.append(sc['status'].reshape(-1).to(torch.int32))
+    prev = getattr(self, '_status_pending', None)
+    self._status_pending = None
+    if sts:
+      dev_st = torch.cat(sts) if len(sts) > 1 else sts[0]
+      host = getattr(self, '_status_host', None)
+      if host is None or host.numel() != dev_st.numel():
+        host = self._status_host = torch.empty(dev_st.numel(), dtype=torch.int32).pin_memory()
+      ev = torch.cuda.Event()
+      if prev is not None:
+        self._check_status(prev)  # before its pinned buffer is overwritten by this step's copy
+        prev = None
+      host.copy_(dev_st, non_blocking=True)
+      ev.record()
+      self._status_pending = (ev, host, n_match)
+    if prev is not None:
+      self._check_status(prev)
     wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
     if self.use_graph:  # the graph's output tensors are rewritten by the next replay: hand out copies of the small ones
       out = {k: (v.clone() if isinstance(v, torch.Tensor) and v.numel() <= 4096 else v) for k, v in out.items()}
