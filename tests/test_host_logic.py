@@ -197,3 +197,39 @@ def test_decode_pipeline_host_contract():
   if not torch.cuda.is_available():
     with pytest.raises(RecAttendError):
       pipe.submit(['y_out'], {'x': np.zeros((1, 32, 32, 3), np.float32)})
+
+
+def test_deferred_status_check_raises_on_flush():
+  """TrainStep checks a step's solver statuses one step late, from a pinned host record; flush_status() checks the last
+  record now: a negative matching code raises (hungarian.cc's LOG(FATAL) cases), a timed-out controller workgroup raises,
+  clean records pass and are consumed."""
+  import torch
+  import ra_native as rn
+  import ra_train as rt
+
+  class Ev:
+    def synchronize(self):
+      pass
+
+  class Stub:
+    _seqc = None
+    _status_pending = None
+    _check_status = rt.TrainStep._check_status
+    flush_status = rt.TrainStep.flush_status
+
+  s = Stub()
+  s._status_pending = (Ev(), torch.zeros(17, dtype=torch.int32), 16)
+  s.flush_status()
+  assert s._status_pending is None
+  s.flush_status()  # nothing pending: a no-op
+  bad = torch.zeros(17, dtype=torch.int32)
+  bad[3] = -2
+  s._status_pending = (Ev(), bad, 16)
+  with pytest.raises(rn.RecAttendError):
+    s.flush_status()
+  assert s._status_pending is None
+  ctl = torch.zeros(17, dtype=torch.int32)
+  ctl[16] = 1
+  s._status_pending = (Ev(), ctl, 16)
+  with pytest.raises(rn.RecAttendError):
+    s.flush_status()
