@@ -777,7 +777,7 @@ bool takes16_f32(int Cin, int Cout, int B, int H, int W);
 int run16_f32(const void *x, int Cin, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu, void *y,
               float *part, int *nparts, int cus, hipStream_t st);
 int run(const void *x, int Cin, int in_bf16, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu,
-        void *y, int out_bf16, float *part, int *nparts, int cus, hipStream_t st);
+        void *y, int out_bf16, float *part, int *nparts, int cus, hipStream_t st, int Cout);
 }  // namespace conv8
 }  // namespace ra
 
@@ -838,11 +838,11 @@ static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, i
   // bf16 mode, eight output channels at full resolution: the bf16-LDS kernel (ra_conv8.hip)
   if (a.bf16 && !C1 && !a.ups && pool == 1 && !plane && ra::conv8::takes(C0, Cout, a.in_bf16, B, a.H, a.W))
     return ra::conv8::run(src0, C0, a.in_bf16, B, a.H, a.W, wpacked, scale, shift, relu, y, a.out_bf16, mom_part, nparts,
-                          ra::conv::num_cus(), st);
+                          ra::conv::num_cus(), st, Cout);
   if (a.bf16) return ra::conv::k1_dispatch_bf16(a, B, st);
   // float32, eight output channels at full resolution (training: forward with moments, data gradients): the 16-block MFMA form
   if (!C1 && !a.ups && pool == 1 && !plane && ra::conv8::takes_f32(C0, Cout, B, a.H, a.W))
-    return ra::conv8::run(src0, C0, -1, B, a.H, a.W, wpacked, scale, shift, relu, y, 0, mom_part, nparts, ra::conv::num_cus(), st);
+    return ra::conv8::run(src0, C0, -1, B, a.H, a.W, wpacked, scale, shift, relu, y, 0, mom_part, nparts, ra::conv::num_cus(), st, 8);
   if (!C1 && !a.ups && pool == 1 && !plane && ra::conv8::takes16_f32(C0, Cout, B, a.H, a.W))  // 16 channels at half resolution
     return ra::conv8::run16_f32(src0, C0, B, a.H, a.W, wpacked, scale, shift, relu, y, mom_part, nparts, ra::conv::num_cus(), st);
   if (a.mom_part) return ra::conv::k1_dispatch_moments(a, B, st);

@@ -57,7 +57,7 @@ struct Map {
   __device__ static int ci(int kb, int j) { return CIN == 4 ? (j & 3) : CIN == 8 ? j : 8 * (kb & 1) + j; }
 };
 
-template <int CIN, bool INB, bool MOM>
+template <int CIN, bool INB, bool MOM, int COUT = 8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 || (CIN == 8 && !INB)) ? 3 : 4, 4))) void conv8_kernel(const Args a) {
   constexpr int PB = CIN * 2;                    // LDS bytes per pixel
   constexpr int ESZ = INB ? 2 : 4;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int tap = Map<CIN>::tap(m, kb, j), ci = Map<CIN>::ci(kb, j);
-      w[j] = (px < 8 && tap < 9) ? a.wp[(tap * CIN + ci) * 16 + px] : 0.f;
+      w[j] = (px < COUT && tap < 9) ? a.wp[(tap * CIN + ci) * 16 + px] : 0.f;
     }
     wreg[m] = __builtin_convertvector(w, bf16x8);
   }
@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
     }
   }
   const int lanebase = (2 * wave * LW + px) * PB;
-  const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(a.scale + 4 * (kb & 1));  // after the epilogue's lane swap: channels 4 (kb & 1) ..
-  const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(a.shift + 4 * (kb & 1));
+  // COUT = 8: after the epilogue's lane swap a lane owns channels 4 (kb & 1) ..; COUT = 16: channels 4 kb .. (no padding rows)
+  const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(a.scale + 4 * (COUT == 16 ? kb : (kb & 1)));
+  const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(a.shift + 4 * (COUT == 16 ? kb : (kb & 1)));
   const float lo = a.relu ? 0.f : -__builtin_inff();
 
   u32x4 raw[NIT];
@@ -168,6 +169,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
       // keep the scheduler from hoisting every group's LDS reads above the first MFMA (40 x 4 registers at Cin = 16)
       if (NMF * (g + 1) % 10 == 0 || (NMF < 5 && (g & 3) == 3)) __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (COUT == 16) {
+      // sixteen output channels: every D row is a channel — lane (px, kb) owns channels 4 kb .. + 3 of pixel px in each of
+      // the wave's 8 groups, one 8-byte (bf16) or 16-byte store per group
+      const bool interior = (cur_ty + TH <= a.H) & (cur_tx + TW <= a.W);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int row = cur_ty + 2 * wave + (g >> 2), col = cur_tx + 16 * (g & 3) + px;
+        f32x4 v = acc[g] * sc4 + sh4;
+        const bool okp = interior || ((row < a.H) & (col < a.W));
+        if constexpr (MOM) {
+          if (g == 0 && !mhave) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mpv[r] = __shfl(v[r], lane & 48, 64);
+          }
+          const float wgt = okp ? 1.f : 0.f;
+          const f32x4 d = (v - mpv) * f32x4{wgt, wgt, wgt, wgt};
+          ms1 += d;
+          ms2 += d * d;
+          mcnt += wgt;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
+        const int off = ((cur_b * a.H + row) * a.W + col) * 16 + 4 * kb;
+        if (a.out_bf16)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])}, rsy, okp ? off * 2 : kOOB, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, okp ? off * 4 : kOOB, 0, 0);
+      }
+      mhave = true;
+    } else
     // epilogue.  Half of a D tile is padding (output channels 8..15, lanes kb >= 2): v_permlane32_swap moves the wave's
     // SECOND row's channels into those lanes, so that one pass with all 64 lanes active finishes two groups: lane
     // (px, kb) owns channels 4 (kb & 1) .. + 3 of pixel (row + (kb >> 1), col + px).
@@ -222,6 +253,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 16 
     buf ^= 1;
     T = nT;
     cur_b = org_b, cur_ty = org_ty, cur_tx = org_tx;
+  }
+  if constexpr (MOM && COUT == 16) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {  // over the 16 pixels; lane bits 4-5 = the channel quad
+      mcnt += __shfl_xor(mcnt, o, 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ms1[r] += __shfl_xor(ms1[r], o, 64);
+        ms2[r] += __shfl_xor(ms2[r], o, 64);
+      }
+    }
+    if (px == 0) {
+      f32x4 *rec = reinterpret_cast<f32x4 *>(a.part) + (size_t)(blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rec[4 * kb + r] = f32x4{mcnt, ms1[r], ms2[r], mpv[r]};
+    }
+    return;
   }
   if constexpr (MOM) {
 #pragma unroll
@@ -548,13 +596,13 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Args a) {
   }
 }
 
-template <int CIN, bool INB>
+template <int CIN, bool INB, int COUT = 8>
 static int launch(const Args &a, int grid, hipStream_t st) {
   if (a.part)
-    hipLaunchKernelGGL((conv8_kernel<CIN, INB, true>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv8_kernel<CIN, INB, true, COUT>), dim3(grid), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv8_kernel<CIN, INB, false>), dim3(grid), dim3(256), 0, st, a);
-  return launch_status("ra_conv3x3_bf16_f32 (8-channel form)");
+    hipLaunchKernelGGL((conv8_kernel<CIN, INB, false, COUT>), dim3(grid), dim3(256), 0, st, a);
+  return launch_status("ra_conv3x3_bf16_f32 (8- / 16-channel form)");
 }
 
 bool enabled() {
@@ -569,8 +617,8 @@ bool enabled() {
 // 1 when the shape is this kernel's (the caller has already checked: bf16 operands, one source, no transposed stride, no
 // pooling, no canvas plane)
 bool takes(int Cin, int Cout, int in_bf16, int B, int H, int W) {
-  if (!enabled() || Cout != 8) return false;
-  if (!((Cin == 4 && !in_bf16) || Cin == 8 || (Cin == 16 && in_bf16))) return false;
+  if (!enabled() || (Cout != 8 && Cout != 16)) return false;
+  if (!((Cin == 4 && !in_bf16 && Cout == 8) || Cin == 8 || (Cin == 16 && in_bf16))) return false;
   return (size_t)B * H * W >= (size_t)64 * 64 * 8;  // K1's tiles fill the chip better on small launches
 }
 
@@ -607,12 +655,12 @@ int run16_f32(const void *x, int Cin, int B, int H, int W, const float *wp, cons
 }
 
 int run(const void *x, int Cin, int in_bf16, int B, int H, int W, const float *wp, const float *scale, const float *shift, int relu,
-        void *y, int out_bf16, float *part, int *nparts, int cus, hipStream_t st) {
+        void *y, int out_bf16, float *part, int *nparts, int cus, hipStream_t st, int Cout) {
   Args a;
   a.x = x, a.wp = wp, a.scale = scale, a.shift = shift, a.y = y, a.part = part;
   a.B = B, a.H = H, a.W = W, a.relu = relu, a.out_bf16 = out_bf16;
   a.bytes_x = (int)((size_t)B * H * W * Cin * (in_bf16 > 0 ? 2 : 4));  // in_bf16 < 0: the float32 kernels
-  a.bytes_y = (int)((size_t)B * H * W * 8 * (out_bf16 ? 2 : 4));
+  a.bytes_y = (int)((size_t)B * H * W * Cout * (out_bf16 ? 2 : 4));
   a.ntx = ceil_div(W, TW), a.nty = ceil_div(H, TH);
   const long long nt = (long long)B * a.ntx * a.nty;
   if (nt >= (1ll << 31)) return fail(RA_E_SHAPE, "ra_conv3x3_bf16_f32: tile count");
@@ -630,6 +678,10 @@ int run(const void *x, int Cin, int in_bf16, int B, int H, int W, const float *w
     if (nparts) *nparts = gridf * 4;
     hipLaunchKernelGGL(kern, dim3(gridf), dim3(256), 0, st, a);
     return launch_status("ra_conv3x3_f32 (8-channel form)");
+  }
+  if (Cout == 16) {
+    if (Cin == 16) return launch<16, true, 16>(a, grid, st);
+    return in_bf16 ? launch<8, true, 16>(a, grid, st) : launch<8, false, 16>(a, grid, st);
   }
   if (Cin == 4) return launch<4, false>(a, grid, st);
   if (Cin == 16) return launch<16, true>(a, grid, st);

@@ -20,11 +20,11 @@ def _ref(x64, w, sh, relu):
   return torch.clamp_min(y, 0.0) if relu else y
 
 
-@pytest.mark.parametrize('cin,in_bf', [(4, 0), (8, 0), (8, 1), (16, 1)])
+@pytest.mark.parametrize('cin,in_bf,cout', [(4, 0, 8), (8, 0, 8), (8, 1, 8), (16, 1, 8), (8, 0, 16), (8, 1, 16), (16, 1, 16)])
 @pytest.mark.parametrize('relu', [0, 1])
-def test_conv8_vs_float64(cuda, cin, in_bf, relu):
-  rng = np.random.RandomState(10 * cin + in_bf)
-  B, H, W, cout = 3, 77, 150, 8  # ragged against the 8 x 64 tile
+def test_conv8_vs_float64(cuda, cin, in_bf, cout, relu):
+  rng = np.random.RandomState(10 * cin + in_bf + cout)
+  B, H, W = 3, 77, 150  # ragged against the 8 x 64 tile
   x = torch.tensor(rng.randn(B, H, W, cin).astype(np.float32), device=cuda)
   xb = x.to(torch.bfloat16)
   xin = xb if in_bf else x
