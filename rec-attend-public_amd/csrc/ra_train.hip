@@ -1482,6 +1482,134 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const float *x, con
     dst[e] = (red[e] + red[e + 10 * 16 * CP]) + (red[e + 2 * 10 * 16 * CP] + red[e + 3 * 10 * 16 * CP]);
 }
 
+// The filter gradient of the 8-output-channel full-resolution layers, third form.  wgrad_small_kernel (the 16-block MFMA)
+// stages its tiles through registers with ~400 vector instructions per wave and tile, holds 38 accumulator tiles per lane
+// (two waves per SIMD) and runs at 2.1-2.5 TB/s.  Measured on a first rewrite (transposed channel planes in LDS, one
+// ds_read_b128 per four MFMAs): the launch is the SUM of its staging (190 us with 3/4 of the MFMAs compiled out) and its
+// MFMAs (183 us) — vector instructions and MFMAs of a SIMD do not overlap (tools/mfma_valu.hip), and every workgroup of a
+// CU is in the same phase.  So this form takes the vector instructions out of the staging: both tiles go HBM -> LDS
+// directly (buffer_load_dwordx4 ... lds, pixel-major as they lie in memory, double-buffered, ONE barrier per tile), and
+// the operands are read from there with scalar ds_reads: v_mfma_f32_16x16x4_f32 with M rows = (tap, ci) pairs + the bias
+// row (A = 1), N = the 8 output channels (columns 8..15 repeat them and are dropped), k-slot (i, kq) = pixel 4 kq + i of a
+// run of 16.  5 (Cin = 8) or 3 (Cin = 4) accumulator tiles.  Partial record per workgroup as wgrad_kernel writes it
+// ([tap (9 = bias)][16][CP]): the same final reduction.
+template <int CIN>
+__global__ __launch_bounds__(256) void wgrad8_kernel(const float *x, const float *du, int B, int Hs, int Ws, int H, int W, int tiles_x,
+                                                     int tiles_y, int ntiles, float *part, const float *const *xtab,
+                                                     const float *const *dutab, int Bseg, int CP) {
+  constexpr int NR = 9 * CIN + 1, NT = (NR + 15) / 16;  // rows: (tap, ci) pairs + bias; M tiles
+  constexpr int IPX = CIN / 4;                           // 16-byte items per x pixel
+  constexpr int NIX = WLH * WLW * IPX, NIU = WTH * WTW * 2;
+  constexpr int XB = (NIX + 63) / 64 * 1024, UB = NIU * 16;  // bytes of one x / dU tile in LDS (whole 64-lane pieces)
+  constexpr int NITX = (NIX + 255) / 256, NITU = NIU / 256;
+  constexpr int kOOB = 0x7fffffff;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];  // [2][XB + UB], then reused for the reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kq = lane >> 4;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int aoff[NT];  // float offset of row R = 16 t + n inside the x tile, for pixel 4 kq of a run starting at tile column 0
+  bool abias[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int R = 16 * t + n, Rc = R < 9 * CIN ? R : 0, tap = Rc / CIN, ci = Rc - tap * CIN;
+    aoff[t] = ((tap / 3) * WLW + tap % 3 + 4 * kq) * CIN + ci;
+    abias[t] = R == 9 * CIN;
+  }
+  const int boff = 4 * kq * 8 + (n & 7);
+  const int per = tiles_x * tiles_y;
+  const size_t seg_imgs = xtab ? (size_t)Bseg : (size_t)B;
+  const int bytes_x = (int)(seg_imgs * Hs * Ws * CIN * 4), bytes_u = (int)(seg_imgs * H * W * 8 * 4);
+  auto load_tile = [&](int tile, int buf) {
+    int b = tile / per;
+    const int tr = tile - b * per;
+    const float *xb = x, *ub = du;
+    if (xtab) {
+      const int seg = b / Bseg;
+      xb = xtab[seg];
+      ub = dutab[seg];
+      b -= seg * Bseg;
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xb), 0, bytes_x, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ub), 0, bytes_u, 0x00020000);
+    const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
+    unsigned char *dst = ldsb + buf * (XB + UB);
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      if (256 * it + 64 * wave >= NIX) continue;  // wave-uniform
+      const int e = tid + 256 * it;
+      const int pix = e / IPX, c4 = e - pix * IPX;
+      const int r = pix / WLW, c = pix - r * WLW;
+      const int Y = ty0 + r - 1, X = tx0 + c - 1;
+      const bool ok = (e < NIX) & ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W);
+      const int off = ok ? ((b * Hs + Y) * Ws + X) * CIN * 4 + 16 * c4 : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void *)(dst + (256 * it + 64 * wave) * 16), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NITU; ++it) {
+      const int e = tid + 256 * it;
+      const int pix = e >> 1, c4 = e & 1;
+      const int r = pix / WTW, c = pix - r * WTW;
+      const int Y = ty0 + r, X = tx0 + c;
+      const bool ok = (Y < H) & (X < W);
+      const int off = ok ? ((b * H + Y) * W + X) * 32 + 16 * c4 : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void *)(dst + XB + (256 * it + 64 * wave) * 16), 16, off, 0, 0, 0);
+    }
+  };
+  int buf = 0;
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x, 0);
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool has_next = tile + (int)gridDim.x < ntiles;
+    if (has_next) load_tile(tile + gridDim.x, buf ^ 1);  // in flight across the MFMAs; the barrier below waits for it
+    const float *xs = reinterpret_cast<const float *>(ldsb + buf * (XB + UB));
+    const float *us = reinterpret_cast<const float *>(ldsb + buf * (XB + UB) + XB);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // this wave's rows 2 wave, 2 wave + 1; two runs of 16 pixels per row
+      const int row = wave * 2 + (g >> 1), c0 = 16 * (g & 1);
+      float bv[4], av[NT][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] = us[(row * WTW + c0 + i) * 8 + boff];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[t][i] = abias[t] ? 1.f : xs[(row * WLW + c0 + i) * CIN + aoff[t]];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)  // consecutive MFMAs on different accumulators: no wait for a dependent result
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][i], bv[i], acc[t], 0, 0, 0);
+    }
+    __syncthreads();  // the next tile has landed (vmcnt(0)) and every wave is done reading this one
+    buf ^= 1;
+  }
+  // D lane (n, q): rows 16 t + 4 q + r, column n (= output channel for n < 8).  The four waves saw different pixels: summed
+  // through LDS in a fixed order.
+  float *red = reinterpret_cast<float *>(ldsb);  // [wave][tap (9 = bias)][16][CP]
+  for (int e = tid; e < 4 * 10 * 16 * CP; e += 256) red[e] = 0.f;
+  __syncthreads();
+  float *mine = red + wave * (10 * 16 * CP);
+  if (n < 8) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int R = 16 * t + 4 * kq + r;
+        int slot = -1;
+        if (R < 9 * CIN) {
+          const int tap = R / CIN;
+          slot = tap * 16 + (R - tap * CIN);
+        } else if (R == 9 * CIN) {
+          slot = 9 * 16;
+        }
+        if (slot >= 0) mine[slot * CP + n] = acc[t][r];
+      }
+  }
+  __syncthreads();
+  float *dstp = part + (size_t)blockIdx.x * (10 * 16 * CP);
+  for (int e = tid; e < 10 * 16 * CP; e += 256)
+    dstp[e] = (red[e] + red[e + 10 * 16 * CP]) + (red[e + 2 * 10 * 16 * CP] + red[e + 3 * 10 * 16 * CP]);
+}
+
 // dW[tap][ci][co] (= TF [3,3,Cin,Cout]) and db[co] from the partials, fixed order.
 __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
                                                           float *dw, float *db) {  // CP = couts per slice
@@ -1724,7 +1852,22 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
     small_ok = e ? atoi(e) : 1;
   }
   const bool small = small_ok && !bf16 && !ups && Cout == 8 && (Cin == 4 || Cin == 8);
-  if (small) {
+  static int t8_ok = -1;  // RA_WGRAD8=0: tuning aid, the 16-block form (wgrad_small_kernel) instead of the transposed-tile one
+  if (t8_ok < 0) {
+    const char *e = getenv("RA_WGRAD8");
+    t8_ok = e ? atoi(e) : 1;
+  }
+  const size_t seg_bytes = (size_t)(xtab ? Bseg : B) * H * W * 8 * 4;  // the larger of the two tensors of a segment
+  if (small && t8_ok && seg_bytes < (1ull << 31) && Hs == H && Ws == W) {
+    const size_t lds_s = 2 * (size_t)(((WLH * WLW * (Cin / 4) + 63) / 64) * 1024 + WTH * WTW * 32);
+    const size_t lds_8 = lds_s > 4 * lds_red ? lds_s : 4 * lds_red;
+    if (Cin == 4)
+      hipLaunchKernelGGL(wgrad8_kernel<4>, dim3(gx), dim3(256), lds_8, st, x, du, B, Hs, Ws, H, W, tiles_x, tiles_y, ntiles, ws, xtab,
+                         dutab, Bseg, per);
+    else
+      hipLaunchKernelGGL(wgrad8_kernel<8>, dim3(gx), dim3(256), lds_8, st, x, du, B, Hs, Ws, H, W, tiles_x, tiles_y, ntiles, ws, xtab,
+                         dutab, Bseg, per);
+  } else if (small) {
     const size_t lds_s = (size_t)(WLH * WLW * (Cin + 1) + WTH * WTW * 9) * sizeof(float);
     const size_t lds_small = lds_s > 4 * lds_red ? lds_s : 4 * lds_red;  // the four waves' partial records at the end
     if (Cin == 4)
