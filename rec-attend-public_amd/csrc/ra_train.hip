@@ -1573,11 +1573,20 @@ __global__ __launch_bounds__(256) void wgrad8_kernel(const float *x, const float
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[t][i] = abias[t] ? 1.f : xs[(row * WLW + c0 + i) * CIN + aoff[t]];
+        for (int i = 0; i < 4; ++i) {
+          av[t][i] = xs[(row * WLW + c0 + i) * CIN + aoff[t]];
+          if (t == NT - 1 && abias[t]) av[t][i] = 1.f;  // the bias row lives in the last tile only: one select per value there
+        }
+#ifdef RA_W8_SKIP  // measuring aid: one MFMA per tile and group instead of four (the LDS reads stay)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32((av[t][0] + av[t][1]) + (av[t][2] + av[t][3]), (bv[0] + bv[1]) + (bv[2] + bv[3]), acc[t], 0, 0, 0);
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i)  // consecutive MFMAs on different accumulators: no wait for a dependent result
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][i], bv[i], acc[t], 0, 0, 0);
+#endif
     }
     __syncthreads();  // the next tile has landed (vmcnt(0)) and every wave is done reading this one
     buf ^= 1;
