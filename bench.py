@@ -562,6 +562,21 @@ def main():
   barrier()
   elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)
   value = world * B * T * args.steps / elapsed
+  # SURVEY 8(d)'s protocol beside the contract's mean: the MEDIAN time per batch in the steady state, fill and drain of the
+  # pipeline excluded — the host clock at every completion (retire() returns when the oldest batch has finished); a
+  # window of `streams` consecutive completions is one batch per stream, so (t[i + w] - t[i]) / w is a per-batch time
+  n_steady = max(24, 3 * pipe.depth)
+  done = []
+  for _ in range(pipe.depth):
+    pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output)
+  for _ in range(n_steady):
+    pipe.retire()
+    done.append(time.perf_counter())
+    pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output)
+  pipe.drain()
+  wdw = max(1, int(pipe.streams))
+  gaps = [(done[i + wdw] - done[i]) / wdw for i in range(wdw, len(done) - wdw)]
+  steady_ms = 1e3 * ra_dist.max_over_ranks(float(np.median(gaps)))
   for eng_k, _ in pipe.slots:  # a controller workgroup that timed out on its peers would have produced garbage: fail loudly
     eng_k.check_status(recover=False)
 
@@ -578,6 +593,9 @@ def main():
                  'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no collective' % world,
                  'ranks_in_communicator': ra_dist.comm_size(),
                  'hip_graph': bool(eng.use_graph), 'batches_in_flight': pipe.depth,
+                 'steady_ms_per_step_median': steady_ms, 'steady_value_median': world * B * T / (steady_ms * 1e-3),
+                 'steady_protocol': 'median over %d completions of the time per batch in the steady state of the pipeline '
+                                    '(fill and drain excluded; windows of %d consecutive completions)' % (n_steady, wdw),
                  'lone_batch_ms': lone_ms, 'lone_batch_value': B * T / (lone_ms * 1e-3),
                  'lone_batch_protocol': 'median of 21 forwards, each bracketed by a device synchronize', 'input': 'host (PCIe inclusive)' if args.host_input else 'resident in HBM',
                  'output': 'y_out + s_out copied to pinned host memory (PCIe inclusive)' if args.host_output else 'left in HBM'},
@@ -717,6 +735,7 @@ def main():
         'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': group_us,
         'extract_paste_us': attn_us, 'fills_us_per_forward': fill_us,
         'by_box_size': by_box,
+        'frac_window_is_image': by_box['1.00']['frac_algorithmic'], 'frac_small_box_0.15': by_box['0.15']['frac_algorithmic'],
         'y_out_prefill': ('rides on the first timestep\'s first controller-CNN launch (MFMA-bound, HBM idle): its cost is '
                           'inside roofline.first_layer_cache.us_per_forward') if rides else 'its own launch, inside fills_us_per_forward',
         'launch_floor_us': graph_time_us(lambda: ops.fill(sb['attn'][0][:1, :4], 0.0)),
@@ -777,6 +796,30 @@ def main():
       ops.hungarian(wm_d)
     torch.cuda.synchronize()
     out['hungarian_us_per_problem'] = 1e6 * (time.perf_counter() - t0) / (5 * B)
+    out['hungarian_us_per_problem_note'] = 'toy matrices (a planted permutation + 5 % noise), B problems per launch; the ' \
+        'representative figure is hungarian_cfg4_step'
+    # ... and on the matrices a real cfg4 training step produces (tests/golden/hungarian_cfg4_step.npz: the 2 B = 16 mask + box
+    # problems of one step of a freshly initialised model, near-uniform IoUs — the regime the 1e-6 quantisation exists for)
+    fx = os.path.join(ROOT, 'tests', 'golden', 'hungarian_cfg4_step.npz')
+    if os.path.exists(fx):
+      step_w = torch.as_tensor(np.load(fx)['weights']).cuda()
+      n_p = int(step_w.shape[0])
+
+      def hung_us(w, reps=5):
+        ops.hungarian(w)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+          ops.hungarian(w)
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t1) / reps
+      launch = hung_us(step_w)
+      single = [hung_us(step_w[k:k + 1].contiguous(), 3) for k in range(n_p)]
+      out['hungarian_cfg4_step'] = {
+          'problems': n_p, 'shape': list(step_w.shape[1:]), 'launch_us': launch, 'us_per_problem_in_launch': launch / n_p,
+          'us_per_problem_alone_median': float(np.median(single)), 'us_per_problem_alone_max': float(np.max(single)),
+          'note': 'one wave per problem, all problems of the step in ONE launch (its duration = the slowest problem, '
+                  'which is what the training step waits for); alone = one problem per launch'}
     out['config']['sub_batches'] = len(eng.subs)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(opt, 1234)

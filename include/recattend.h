@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 108
+#define RA_ABI_VERSION 109
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -587,6 +587,15 @@ int ra_weighted_sum_f32(const float *w, const float *y, int B, int T, int HW, fl
 int ra_adam_step_f32(float *params, const float *grads, float *m, float *v, const float *wd_coef,
                      size_t n, float lr_t, float beta1, float beta2, float eps, float clip,
                      float grad_scale, void *stream);
+/* The same update, applied ONLY IF none of the step's device status words says "failed": the first n_solver words are
+ * Hungarian-solver return codes (negative = the reference's LOG(FATAL) cases, hungarian.cc:126,148,158,187,448; 1 = the
+ * outer cap, where the reference carries on with the partial matching, :363-377 — not a failure), the n_other words behind
+ * them fail when non-zero (the split controller's time-out word, another rank's failure flag).  A training loop that reads
+ * those words one step late (no host sync per step) can then never have applied a failed step's gradients.  status
+ * nullable with both counts 0 (= ra_adam_step_f32). */
+int ra_adam_step_guarded_f32(float *params, const float *grads, float *m, float *v, const float *wd_coef,
+                             size_t n, float lr_t, float beta1, float beta2, float eps, float clip,
+                             float grad_scale, const int *status, int n_solver, int n_other, void *stream);
 
 /* Train-mode layer pieces of nnlib.cnn / nnlib.dcnn (nnlib.py:229-253,362-400 with
  * phase_train = True).  The convolution itself is ra_conv3x3_f32 with scale = 1, shift = bias,

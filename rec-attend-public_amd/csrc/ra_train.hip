@@ -18,7 +18,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, const float *wd,
                                                    size_t n, float lr_t, float b1, float b2, float eps, float clip,
-                                                   float gscale) {
+                                                   float gscale, const int *status, int n_solver, int n_other) {
+  // the guarded form: a NEGATIVE solver status of this step (a matching that hit one of the reference's LOG(FATAL) caps; 1 =
+  // the outer cap, where the reference logs and carries on with the partial matching, hungarian.cc:363-377) or any NON-ZERO
+  // other word (a controller workgroup that timed out, another rank's failure flag) and the update is NOT applied —
+  // parameters and moments stay as they are.  The words are uniform across the grid (scalar loads), written by launches
+  // earlier on the stream.
+  for (int k = 0; k < n_solver; ++k)
+    if (status[k] < 0) return;
+  for (int k = 0; k < n_other; ++k)
+    if (status[n_solver + k] != 0) return;
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float pi = p[i];
@@ -302,8 +311,22 @@ extern "C" int ra_adam_step_f32(float *params, const float *grads, float *m, flo
   size_t grid = (n + 255) / 256;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(train::adam_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), params, grads, m, v,
-                     wd_coef, n, lr_t, beta1, beta2, eps, clip, grad_scale);
+                     wd_coef, n, lr_t, beta1, beta2, eps, clip, grad_scale, (const int *)nullptr, 0, 0);
   return launch_status("ra_adam_step_f32");
+}
+
+extern "C" int ra_adam_step_guarded_f32(float *params, const float *grads, float *m, float *v, const float *wd_coef,
+                                        size_t n, float lr_t, float beta1, float beta2, float eps, float clip,
+                                        float grad_scale, const int *status, int n_solver, int n_other, void *stream) {
+  if (!params || !grads || !m || !v) return fail(RA_E_INVALID, "ra_adam_step_guarded_f32: null pointer");
+  if (n_solver < 0 || n_other < 0 || (n_solver + n_other > 0 && !status))
+    return fail(RA_E_INVALID, "ra_adam_step_guarded_f32: status words");
+  if (n == 0) return 0;
+  size_t grid = (n + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(train::adam_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), params, grads, m, v,
+                     wd_coef, n, lr_t, beta1, beta2, eps, clip, grad_scale, status, n_solver, n_other);
+  return launch_status("ra_adam_step_guarded_f32");
 }
 
 // =================================================================================================

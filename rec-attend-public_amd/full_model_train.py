@@ -136,6 +136,8 @@ def train_loop(args, model, model_opt, folder, rank, world, make_batch):
     raise SystemExit('batch_size %d is not a multiple of the world size %d (equal shards: the gradient is averaged '
                      'as sum / world)' % (args.batch_size, world))
   gen = torch.Generator(device='cuda')
+  if getattr(model, 'trainer', None) is None:  # before the loop, as load_checkpoint does: the first step's augmentation stream
+    model.trainer = (ra_train.BoxTrainStep if model.box_model else ra_train.TrainStep)(model)  # is seeded like every other's
   start = int(model.get('global_step', 0) or 0)
   t0 = time.time()
   for step in range(start, args.num_steps):
@@ -157,6 +159,7 @@ def train_loop(args, model, model_opt, folder, rank, world, make_batch):
                                                              time.time() - t0))
     if rank == 0 and args.save_ckpt and (step + 1) % args.steps_per_ckpt == 0:
       save_checkpoint(ckpt, model)
+  model.trainer.flush_status()  # every rank: the last step's solver / controller statuses are checked one step late
   ra_dist.barrier()
   if rank == 0:
     os.makedirs(folder, exist_ok=True)

@@ -6,8 +6,16 @@ torch CUDA tensors in NHWC, and each closure launches HIP kernels from librecatt
 through the C ABI (ra_ops).  Constructors register their weights into `model` exactly like
 the reference (`'{scope}_w_{i}'`, `'{scope}_{i}_{copy}_{beta,gamma,ema_mean,ema_var}'`, ...).
 
-Eval mode (`phase_train=False`) only: batch-moment BatchNorm and the backward pass are the
-training step, which SURVEY.md §8(f) ranks after the forward path; asking for them raises.
+`phase_train=False`: the decode loop's fused eval kernels (EMA statistics folded into the conv
+epilogue).  `phase_train=True` (round 5): the training step's kernels behind the same closures —
+each cnn / dcnn layer is one `ra_train.ConvBNActPool` node (conv with the batch moments in its
+epilogue, BN + ReLU + pool on the batch statistics, MFMA backward-data / backward-weight, the
+statistics differentiated through), `batch_norm` is `ra_train.BatchNormTrain`, and every call
+moves the copy's EMA shadows by `shadow = decay shadow + (1 - decay) value`, `decay = 1 - 0.1
+phase_train` (nnlib.py:103-110).  Gradients are torch autograd's: mark the registered tensors
+(`model[...]`) with `requires_grad_()` and differentiate the closures' outputs — the counterpart
+of `tf.gradients` over the reference graph.  The optimisation step of full_model (`ra_train.TrainStep`)
+runs the same kernels without going through these closures.
 """
 import numpy as np
 import torch
@@ -36,11 +44,15 @@ def _is_train(phase_train):
   return bool(phase_train)
 
 
-def _no_training(phase_train, what):
-  if _is_train(phase_train):
-    raise NotImplementedError(
-        '%s: phase_train=True (batch-moment BatchNorm / training step) is not built yet — '
-        'SURVEY.md §8(f) rank 2; only the eval-mode forward path exists.' % what)
+EMA_DECAY_TRAIN = 0.9  # decay = 1 - 0.1 * phase_train (nnlib.py:103-104)
+
+
+def _ema_update(shadow_mean, shadow_var, mean, var):
+  """ema.apply([batch_mean, batch_var]) of a training call (nnlib.py:105-110): the copy's shadows move towards the
+  batch statistics; not differentiated (the shadows are assigned, nnlib.py:121-127)."""
+  with torch.no_grad():
+    shadow_mean.mul_(EMA_DECAY_TRAIN).add_(mean, alpha=1.0 - EMA_DECAY_TRAIN)
+    shadow_var.mul_(EMA_DECAY_TRAIN).add_(var, alpha=1.0 - EMA_DECAY_TRAIN)
 
 
 def truncated_normal_initializer(stddev=0.01, seed=None):
@@ -124,9 +136,14 @@ def _bn_register(model, scope2, n_out, init_beta=None, init_gamma=None):
 
 def batch_norm(x, n_out, phase_train, scope='bn', scope2='bn', affine=True, init_beta=None,
                init_gamma=None, frozen=False, model=None):
-  """nnlib.py:65-128 in eval mode: gamma*(x-ema_mean)/sqrt(ema_var+1e-3)+beta."""
-  _no_training(phase_train, 'batch_norm')
+  """nnlib.py:65-128.  Eval: gamma*(x-ema_mean)/sqrt(ema_var+1e-3)+beta.  Training: the same with the batch moments
+  over (B,H,W) (biased variance, differentiated through), and the EMA shadows updated (nnlib.py:98-112)."""
   beta, gamma, mean, var = _bn_register(model, scope2, n_out, init_beta, init_gamma)
+  if _is_train(phase_train):
+    import ra_train as rt
+    y, bmean, bvar = rt.BatchNormTrain.apply(x, gamma, beta)
+    _ema_update(mean, var, bmean, bvar)
+    return y
   sc, sh = ops.fold_bn(None, n_out, (beta, gamma, mean, var))
   return ops.affine_act(x.contiguous(), torch.from_numpy(sc[:n_out].copy()).to(x.device),
                         torch.from_numpy(sh[:n_out].copy()).to(x.device))
@@ -213,15 +230,41 @@ def cnn(f, ch, pool, act, use_bn, phase_train=None, wd=None, scope='cnn', model=
         _dev(a, x_like) for a in ops.fold_bn(b[ii], ch[ii + 1], bn)))
     return wp, sc, sh
 
-  def run_cnn(x, copy_idx=None):
-    _no_training(phase_train, 'cnn')
-    cp = copy[0] if copy_idx is None else copy_idx
+  def run_cnn_train(x, cp):
+    """phase_train = True: per layer conv + b -> BN on the batch moments -> ReLU -> max-pool as one autograd node on the
+    training step's kernels; the copy's EMA shadows move (nnlib.py:229-253 with :98-112)."""
+    import ra_train as rt
     h = [None] * nlayers
     prev = x
+    stats = run_cnn.batch_stats = {}
+    for ii in range(nlayers):
+      if pool[ii] > 2:
+        raise RecAttendError('cnn: pool ratio %d not fused (path uses 1 or 2)' % pool[ii])
+      meta = dict(transposed=False, stride=1, pool=pool[ii] if pool[ii] > 1 else 1, relu=act[ii] is not None,
+                  chan_map=None)
+      bn = _bn(ii, cp) if use_bn[ii] else None
+      y, mean, var = rt.ConvBNActPool.apply(rt._pad_channels(prev), w[ii], b[ii], bn[1] if bn else None,
+                                            bn[0] if bn else None, meta)
+      if bn:
+        _ema_update(bn[2], bn[3], mean, var)
+        stats['{}_{}_{}'.format(scope, ii, cp)] = (mean, var)
+      h[ii] = prev = y
+    return h
+
+  def run_cnn(x, copy_idx=None):
+    cp = copy[0] if copy_idx is None else copy_idx
     for ii in range(nlayers):
       if act[ii] is not None and act[ii] is not relu_fn and getattr(act[ii], '__name__',
                                                                      '') != 'relu':
         raise RecAttendError('cnn: only relu / None activations are fused')
+    if _is_train(phase_train):
+      h = run_cnn_train(x, cp)
+      if copy_idx is None:
+        copy[0] += 1
+      return h
+    h = [None] * nlayers
+    prev = x
+    for ii in range(nlayers):
       cin = prev.shape[3]
       if cin % 4:
         prev = torch.nn.functional.pad(prev, (0, 4 - cin % 4))
@@ -305,9 +348,44 @@ def dcnn(f, ch, pool, act, use_bn, skip_ch=None, phase_train=None, wd=None, scop
         _dev(a, x_like) for a in ops.fold_bn(b[ii], ch[ii + 1], bn)))
     return wp, sc, sh
 
+  def run_dcnn_train(x, skip, cp):
+    """phase_train = True: [concat(prev, skip)] -> conv2d_transpose + b -> BN on the batch moments -> ReLU, one autograd
+    node per layer on the training step's kernels (nnlib.py:362-400 with :98-112).  The concat is ONE packed kernel
+    input whose chan_map sends every packed channel to its row of the [3,3,out,in] filter."""
+    import ra_train as rt
+    h = [None] * nlayers
+    prev = x
+    stats = run_dcnn.batch_stats = {}
+    for ii in range(nlayers):
+      if pool[ii] not in (1, 2):
+        raise RecAttendError('dcnn: unpool ratio %d not built' % pool[ii])
+      sk = skip[ii] if skip is not None else None
+      cmap = None
+      if sk is not None:
+        n_prev, n_skip = prev.shape[3], sk.shape[3]
+        xp, skp = rt._pad_channels(prev), rt._pad_channels(sk)
+        cmap = list(range(n_prev)) + [-1] * (xp.shape[3] - n_prev) + [n_prev + k for k in range(n_skip)] + \
+            [-1] * (skp.shape[3] - n_skip)
+        if cmap == list(range(len(cmap))):
+          cmap = None
+        prev = torch.cat([xp, skp], dim=3)
+      meta = dict(transposed=True, stride=pool[ii], pool=1, relu=act[ii] is not None, chan_map=cmap)
+      bn = _bn(ii, cp) if use_bn[ii] else None
+      y, mean, var = rt.ConvBNActPool.apply(rt._pad_channels(prev), w[ii], b[ii], bn[1] if bn else None,
+                                            bn[0] if bn else None, meta)
+      if bn:
+        _ema_update(bn[2], bn[3], mean, var)
+        stats['{}_{}_{}'.format(scope, ii, cp)] = (mean, var)
+      h[ii] = prev = y
+    return h
+
   def run_dcnn(x, skip=None, copy_idx=None):
-    _no_training(phase_train, 'dcnn')
     cp = copy[0] if copy_idx is None else copy_idx
+    if _is_train(phase_train):
+      h = run_dcnn_train(x, skip, cp)
+      if copy_idx is None:
+        copy[0] += 1
+      return h
     h = [None] * nlayers
     prev = x
     for ii in range(nlayers):
@@ -336,9 +414,12 @@ def dcnn(f, ch, pool, act, use_bn, skip_ch=None, phase_train=None, wd=None, scop
 
 
 def dropout(x, keep_prob, phase_train):
-  """nnlib.py:407-411: identity at eval."""
-  _no_training(phase_train, 'dropout')
-  return x
+  """nnlib.py:405-409: tf.nn.dropout(x, keep) with keep = 1 at eval (identity) and keep_prob in training (kept values
+  scaled by 1 / keep_prob; the mask is torch's generator's draw — the reference's is TF's, neither is reproducible from
+  the other)."""
+  if not _is_train(phase_train) or keep_prob is None or float(keep_prob) >= 1.0:
+    return x
+  return torch.nn.functional.dropout(x, p=1.0 - float(keep_prob), training=True)
 
 
 _ACT_CODE = {None: None, 'relu': 'relu', 'sigmoid': 'sigmoid', 'softmax': 'softmax',
@@ -388,9 +469,33 @@ def mlp(dims, act, add_bias=True, dropout_keep=None, phase_train=None, wd=None, 
       if add_bias:
         model['{}_b_{}'.format(scope, ii)] = b[ii]
 
+  def run_mlp_train(x, x1=None):
+    """The differentiable form (training graphs): dropout (nnlib.py:484-486), x W + b as one addmm per layer — the
+    library GEMM the training step also uses for [B, <= 1408] x [<= 1408, <= 256] products — and the activation
+    (nnlib.py:487-491)."""
+    h = [None] * nlayers
+    prev = x if x1 is None else torch.cat([x, x1], dim=1)
+    for ii in range(nlayers):
+      if dropout_keep is not None and dropout_keep[ii] is not None:
+        prev = dropout(prev, dropout_keep[ii], phase_train)
+      out = torch.addmm(b[ii], prev, w[ii]) if b[ii] is not None else prev @ w[ii]
+      a = _act_name(act[ii])
+      if a == 'relu':
+        out = torch.relu(out)
+      elif a == 'sigmoid':
+        out = torch.sigmoid(out)
+      elif a == 'tanh':
+        out = torch.tanh(out)
+      elif a == 'softmax':
+        out = torch.softmax(out, dim=1)
+      h[ii] = prev = out
+    return h
+
   def run_mlp(x, x1=None):
     """x1: optional second input whose columns follow x's (fused concat)."""
-    _no_training(phase_train, 'mlp')
+    if _is_train(phase_train) or (torch.is_grad_enabled() and (x.requires_grad or any(
+        t is not None and t.requires_grad for t in w + b))):
+      return run_mlp_train(x, x1)
     h = [None] * nlayers
     prev, extra = x.contiguous(), x1
     for ii in range(nlayers):
@@ -429,7 +534,22 @@ def lstm(inp_dim, hid_dim, wd=None, scope='lstm', model=None, init_weights=None,
     if model is not None:
       model['{}_{}'.format(scope, n)] = P[n]
 
+  def unroll_train(inp, state):
+    """The differentiable cell (a training graph): the four gates as ONE addmm on [w_x; w_h] in gate order (i, f, o, u),
+    the pointwise half and its adjoint on ra_lstm_cell_f32 / _bwd (ra_train.LSTMCell)."""
+    import ra_train as rt
+    c, h = state[:, :hid_dim], state[:, hid_dim:]
+    wcat = torch.cat([torch.cat([P['w_x' + g], P['w_h' + g]], dim=0) for g in 'ifou'], dim=1)
+    bcat = torch.cat([P['b_' + g] for g in 'ifou'])
+    pre = torch.addmm(bcat, torch.cat([inp, h], dim=1), wcat)
+    h2, c2 = rt.LSTMCell.apply(pre, c)
+    g = torch.sigmoid(pre[:, :3 * hid_dim])
+    return torch.cat([c2, h2], dim=1), g[:, :hid_dim], g[:, hid_dim:2 * hid_dim], g[:, 2 * hid_dim:]
+
   def unroll(inp, state):
+    if torch.is_grad_enabled() and (inp.requires_grad or state.requires_grad or any(
+        t.requires_grad for t in P.values())):
+      return unroll_train(inp, state)
     c = state[:, :hid_dim].contiguous()
     h = state[:, hid_dim:].contiguous()
     B = inp.shape[0]

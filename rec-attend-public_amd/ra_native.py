@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 108  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 109  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -118,6 +118,7 @@ SIGNATURES = {
     'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ra_fill_f32': (_I, [_P, _Z, _F, _P]),
     'ra_adam_step_f32': (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P]),
+    'ra_adam_step_guarded_f32': (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
     'ra_bn_workspace_floats': (_Z, [_I]),
     'ra_bn_moments_f32': (_I, [_P, _Z, _I, _P, _Z, _P, _P, _P]),
     'ra_bn_act_pool_f32': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -73,7 +73,11 @@ class GradBucket(object):
       off += (n + 3) & ~3  # 16-byte aligned views
     self.n = off
     self.param = torch.zeros(off, dtype=torch.float32, device=dev)
-    self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+    # four more floats behind the gradients: [off] = "a status word of this step is non-zero on this rank" — it rides on the
+    # bucket's all-reduce, so after the sum every rank knows whether ANY rank's step failed, and the guarded optimizer
+    # kernel skips the update on all of them together (no extra collective)
+    self.grad_full = torch.zeros(off + 4, dtype=torch.float32, device=dev)
+    self.grad = self.grad_full[:off]
     self.m = torch.zeros(off, dtype=torch.float32, device=dev)
     self.v = torch.zeros(off, dtype=torch.float32, device=dev)
     wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
@@ -89,7 +93,7 @@ class GradBucket(object):
     self.global_step = int(model.get('global_step', 0) or 0)
 
   def zero_grad(self):
-    self.grad.zero_()
+    self.grad_full.zero_()
 
   def allreduce(self):
     """One collective per step over the whole bucket (2.3 MiB at the CVPPP arch: latency-bound on
@@ -97,7 +101,7 @@ class GradBucket(object):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
       return 1
-    dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+    dist.all_reduce(self.grad_full, op=dist.ReduceOp.SUM)
     return dist.get_world_size()
 
   def broadcast(self, src=0):
@@ -142,18 +146,29 @@ class GradBucket(object):
     elif strict:
       raise rn.RecAttendError('optimizer state lacks global_step')
 
-  def step(self, world=1, lr=None):
-    """clip(grad / world + wd * w, +-1) -> Adam; increments global_step (full_model.py:1048-1056)."""
+  def step(self, world=1, lr=None, status=None, n_solver=0):
+    """clip(grad / world + wd * w, +-1) -> Adam; increments global_step (full_model.py:1048-1056).  status: an int32
+    device tensor of this step's status words, the first n_solver of them Hungarian-solver codes (failed when
+    negative), the rest failed when non-zero — the update is applied only if none says failed (ra_adam_step_guarded_f32), so a step whose matching failed never reaches the weights even though the host looks at
+    the words one step late."""
     t = self.global_step + 1
     lr = learn_rate(self.opt, self.global_step) if lr is None else lr
     lr_t = lr * math.sqrt(1.0 - BETA2 ** t) / (1.0 - BETA1 ** t)
     if not self.param.is_cuda:
       raise rn.RecAttendError('GradBucket.step runs the HIP optimizer kernel; no CPU fallback')
     import ctypes as C
-    check(rn.lib().ra_adam_step_f32(ptr(self.param), ptr(self.grad), ptr(self.m), ptr(self.v), ptr(self.wd),
-                                    self.n, C.c_float(lr_t), C.c_float(BETA1), C.c_float(BETA2),
-                                    C.c_float(ADAM_EPS), C.c_float(CLIP), C.c_float(1.0 / world),
-                                    rn.stream_ptr()), 'ra_adam_step_f32')
+    if status is not None and status.numel():
+      assert status.dtype == torch.int32 and status.is_contiguous() and status.device == self.param.device
+      check(rn.lib().ra_adam_step_guarded_f32(ptr(self.param), ptr(self.grad), ptr(self.m), ptr(self.v), ptr(self.wd),
+                                              self.n, C.c_float(lr_t), C.c_float(BETA1), C.c_float(BETA2),
+                                              C.c_float(ADAM_EPS), C.c_float(CLIP), C.c_float(1.0 / world),
+                                              ptr(status), int(n_solver), int(status.numel()) - int(n_solver), rn.stream_ptr()),
+            'ra_adam_step_guarded_f32')
+    else:
+      check(rn.lib().ra_adam_step_f32(ptr(self.param), ptr(self.grad), ptr(self.m), ptr(self.v), ptr(self.wd),
+                                      self.n, C.c_float(lr_t), C.c_float(BETA1), C.c_float(BETA2),
+                                      C.c_float(ADAM_EPS), C.c_float(CLIP), C.c_float(1.0 / world),
+                                      rn.stream_ptr()), 'ra_adam_step_f32')
     self.global_step = t
     self.model['global_step'] = float(t)
     eng = getattr(self.model, 'engine', None)
@@ -635,6 +650,44 @@ class ConvBNActPool(torch.autograd.Function):
         dx = dxr
     use_bn = gamma is not None
     return dx, dw, db, (dgamma if use_bn else None), (dbeta if use_bn else None), None
+
+
+class BatchNormTrain(torch.autograd.Function):
+  """nnlib.batch_norm with phase_train = True as an operator of its own (nnlib.py:98-119): tf.nn.moments over (B, H, W),
+  gamma (x - mean) rsqrt(var + 1e-3) + beta, the batch statistics differentiated through.  x [B,H,W,C] float32.
+  Returns (normed, batch mean, batch var); inside nnlib.cnn / dcnn the same kernels run fused behind the conv
+  (ConvBNActPool)."""
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta):
+    ctx.set_materialize_grads(False)
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    dev = x.device
+    mean, var = _f(C, device=dev), _f(C, device=dev)
+    ws = _f(rn.lib().ra_bn_workspace_floats(C), device=dev)
+    check(rn.lib().ra_bn_moments_f32(ptr(x), B * H * W, C, ptr(ws), ws.numel(), ptr(mean), ptr(var), rn.stream_ptr()),
+          'ra_bn_moments_f32')
+    y = torch.empty_like(x)
+    check(rn.lib().ra_bn_act_pool_f32(ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), _C.c_float(BN_EPS), 0, 1, B, H, W, C,
+                                      ptr(y), rn.stream_ptr()), 'ra_bn_act_pool_f32')
+    ctx.save_for_backward(x, mean, var, gamma, beta)
+    ctx.mark_non_differentiable(mean, var)
+    return y, mean, var
+
+  @staticmethod
+  def backward(ctx, dy, _dm, _dv):
+    if dy is None:
+      return None, None, None
+    x, mean, var, gamma, beta = ctx.saved_tensors
+    B, H, W, C = x.shape
+    dev = x.device
+    ws = _f(rn.lib().ra_bn_workspace_floats(C), device=dev)
+    dgamma, dbeta, dx = _f(C, device=dev), _f(C, device=dev), torch.empty_like(x)
+    check(rn.lib().ra_bn_act_pool_bwd_f32(ptr(x), ptr(dy.contiguous()), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                          _C.c_float(BN_EPS), 0, 1, B, H, W, C, ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta),
+                                          ptr(dx), rn.stream_ptr()), 'ra_bn_act_pool_bwd_f32')
+    return dx, dgamma, dbeta
 
 
 def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf, out_dtype=torch.float32):
@@ -2086,18 +2139,34 @@ class TrainStep(object):
     return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in pieces.items()}
 
   def _check_status(self, rec):
-    ev, host, n_match = rec
+    """The status words of one finished step, on the host.  The guarded optimizer kernel has already refused that step's
+    update if any of them was non-zero, so nothing here repairs weights: a failed MATCHING raises (the reference aborts
+    there, hungarian.cc LOG(FATAL)); a controller TIME-OUT (the 16-workgroup form found a peer not resident: something else
+    on the GPU) switches the sequential phase to the one-workgroup controller for good, gives the skipped step's number
+    back and warns; another RANK's failure raises here too, so that no rank walks into the next collective alone."""
+    ev, host, n_match, n_ctrl = rec
     ev.synchronize()
     h = host.clone()
     if n_match:
       ops.check_match_status(h[:n_match], 'f_segm_match')
-    if h.numel() > n_match and int(h[n_match:].abs().max()) != 0:  # a controller workgroup timed out on its peers
+    if n_ctrl and int(h[n_match:n_match + n_ctrl].abs().max()) != 0:  # a controller workgroup timed out on its peers
       sc = getattr(self, '_seqc', None)
-      if sc is not None:
+      if sc is not None and sc.get('status') is not None:
         sc['status'].zero_()
-      raise rn.RecAttendError('controller_split (sequential phase of the training step): a workgroup waited for a peer that '
-                              'never became resident — is another process using this GPU?  RA_TRAIN_CTRL_SPLIT=0 runs the '
-                              'one-workgroup controller')
+      import warnings
+      warnings.warn('controller_split (sequential phase of the training step): a workgroup waited for a peer that never became '
+                    'resident — is another process using this GPU?  That step\'s update was not applied; the trainer runs the '
+                    'one-workgroup controller from now on (RA_TRAIN_CTRL_SPLIT=0 selects it from the start)')
+      self.seq_ctrl_split = False
+      self._seqc = None
+      self._drop_captured_steps()
+      self.bucket.global_step = max(0, self.bucket.global_step - 1)  # the skipped step is taken again
+      self.model['global_step'] = float(self.bucket.global_step)
+      self.skipped_steps = getattr(self, 'skipped_steps', 0) + 1
+      return
+    if h.numel() > n_match + n_ctrl and int(h[n_match + n_ctrl:].abs().max()) != 0:
+      raise rn.RecAttendError('training step: another rank reported a failed matching / controller time-out for this step; the '
+                              'update was skipped on every rank')
 
   def flush_status(self):
     """Check the solver / controller statuses of the LAST step now (run() checks each step's record one step late)."""
@@ -2176,13 +2245,17 @@ class TrainStep(object):
         for k, v in knobs.items():
           st['knobs'][k].copy_(v)
       # pinned and asynchronous: a pageable source made this copy wait for the PREVIOUS step on the stream — a host sync
-      # per step with the GPU idle behind it.  Four buffers in rotation: the status check keeps the host at most one
-      # step ahead of the device, so a buffer is never rewritten while its copy is still queued.
+      # per step with the GPU idle behind it.  Four buffers in rotation, each with the event of the copy that last read it.
       ring = st.setdefault('sched_host', [torch.empty(2, dtype=torch.float32).pin_memory() for _ in range(4)])
+      evs = st.setdefault('sched_ev', [None] * len(ring))
       st['sched_i'] = (st.get('sched_i', -1) + 1) % len(ring)
       hb = ring[st['sched_i']]
+      if evs[st['sched_i']] is not None:  # the copy that last read this buffer has run (with no status words to check —
+        evs[st['sched_i']].synchronize()  # fixed_order and the one-workgroup controller — nothing else holds the host back)
       hb[0], hb[1] = float(sched[0]), float(sched[1])
       st['sched'].copy_(hb, non_blocking=True)
+      evs[st['sched_i']] = torch.cuda.Event()
+      evs[st['sched_i']].record()
     st['graph'].replay()
     return dict(st['out'])
 
@@ -2228,34 +2301,45 @@ class TrainStep(object):
     else:
       self._sched = None
       out = self._grads_and_stats(x, y_gt, s_gt, knobs, generator, extra)
-    world = self.bucket.allreduce()
-    lr = self.bucket.step(world=world)
-    # The solver / controller statuses of this step go to pinned host memory behind the step on the stream; what is CHECKED
-    # here is the previous step's record, which landed long ago: no host sync per step (three of them, with the GPU idle
-    # while the host prepared the next step, were 0.1-0.4 ms of a 24 ms step).  A failed matching therefore raises one step
-    # late; flush_status() checks the record of the last step (full_model.run with numpy outputs, checkpointing and the
-    # bench call it).
+    # The solver / controller statuses of this step gate its update ON THE DEVICE (GradBucket.step(status=...): the optimizer
+    # kernel leaves parameters and moments alone if any word is non-zero) and go to pinned host memory behind the step on the
+    # stream; what the host CHECKS here is the previous step's record — it waits for that step to finish while this step's
+    # graph is already queued behind it, so the GPU does not idle — and it does so BEFORE this step's all-reduce and
+    # optimizer launch are issued: a failed step k raises (or recovers) with the weights exactly as step k found them.
+    # flush_status() checks the record of the last step (full_model.run with numpy outputs, checkpointing, the bench).
     sts = [st.reshape(-1).to(torch.int32) for st in out.pop('_match_status', [])]
     sc = getattr(self, '_seqc', None)
     n_match = sum(int(t.numel()) for t in sts)
+    n_ctrl = 0
     if sc is not None and sc.get('ok'):
       sts.append(sc['status'].reshape(-1).to(torch.int32))
+      n_ctrl = int(sts[-1].numel())
+    inject = getattr(self, '_inject_status', None)  # test hook: a status word forced for ONE step
+    if inject is not None and sts:
+      self._inject_status = None
+      sts[0] = sts[0] + int(inject)
     prev = getattr(self, '_status_pending', None)
     self._status_pending = None
+    if prev is not None:
+      self._check_status(prev)  # also before its pinned buffer is overwritten by this step's copy
+    dev_st = None
     if sts:
-      dev_st = torch.cat(sts) if len(sts) > 1 else sts[0]
+      dev_st = (torch.cat(sts) if len(sts) > 1 else sts[0]).contiguous()
+      if self.world > 1:  # every rank must skip the update if ANY rank failed: the flag rides on the bucket's all-reduce
+        failed = (dev_st[:n_match] < 0).any() | (dev_st[n_match:] != 0).any()
+        self.bucket.grad_full[self.bucket.n] = failed.to(torch.float32)
+    world = self.bucket.allreduce()
+    if dev_st is not None and world > 1:
+      dev_st = torch.cat([dev_st, self.bucket.grad_full[self.bucket.n:self.bucket.n + 1].view(torch.int32)])
+    lr = self.bucket.step(world=world, status=dev_st, n_solver=n_match)
+    if dev_st is not None:
       host = getattr(self, '_status_host', None)
       if host is None or host.numel() != dev_st.numel():
         host = self._status_host = torch.empty(dev_st.numel(), dtype=torch.int32).pin_memory()
       ev = torch.cuda.Event()
-      if prev is not None:
-        self._check_status(prev)  # before its pinned buffer is overwritten by this step's copy
-        prev = None
       host.copy_(dev_st, non_blocking=True)
       ev.record()
-      self._status_pending = (ev, host, n_match)
-    if prev is not None:
-      self._check_status(prev)
+      self._status_pending = (ev, host, n_match, n_ctrl)
     wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
     if self.use_graph:  # the graph's output tensors are rewritten by the next replay: hand out copies of the small ones
       out = {k: (v.clone() if isinstance(v, torch.Tensor) and v.numel() <= 4096 else v) for k, v in out.items()}

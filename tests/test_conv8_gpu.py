@@ -86,3 +86,105 @@ def test_conv8_float32_vs_float64(cuda, cin, cout, relu):
   flat = want_pre.reshape(-1, cout)
   np.testing.assert_allclose(mean.cpu().numpy(), flat.mean(0).cpu().numpy(), rtol=1e-5, atol=1e-6)
   np.testing.assert_allclose(var.cpu().numpy(), flat.var(0, unbiased=False).cpu().numpy(), rtol=1e-5)
+
+
+# ---- the filter gradient of the same layers (csrc/ra_train.hip wgrad8_kernel: Cout = 8, Cin in {4, 8}, float32, both tiles
+# HBM -> LDS directly; wgrad_kernel for the other channel counts) on shapes ragged against its 8 x 32 tiles
+def _wgrad_ref(x, du):
+  """dW[ky,kx,ci,co] = sum over pixels of x[.. + tap, ci] * du[.., co] (SAME padding), db = sum du, in float64 on the device."""
+  xi = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1))
+  B, H, W, Co = du.shape
+  d = du.double()
+  dw = torch.stack([torch.stack([torch.einsum('bhwc,bhwd->cd', xi[:, ky:ky + H, kx:kx + W], d) for kx in range(3)]) for ky in range(3)])
+  return dw, d.sum(dim=(0, 1, 2))
+
+
+def _rel(a, b):
+  return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('cin,cout', [(4, 8), (8, 8), (8, 16), (16, 32), (12, 8)])
+@pytest.mark.parametrize('B,H,W', [(3, 77, 150), (1, 9, 33), (2, 8, 32)])
+def test_wgrad_ragged_vs_float64(cuda, cin, cout, B, H, W):
+  """ra_conv3x3_wgrad_f32 on ragged multi-tile shapes (wgrad8_kernel<4> / <8> for the two 8-output-channel forms; the
+  generic wgrad_kernel beside them), against a float64 correlation of the same float32 operands."""
+  rng = np.random.RandomState(cin * 100 + cout + H)
+  x = torch.tensor(rng.randn(B, H, W, cin).astype(np.float32), device=cuda)
+  du = torch.tensor(rng.randn(B, H, W, cout).astype(np.float32), device=cuda)
+  lib = rn.lib()
+  nws = lib.ra_conv3x3_wgrad_workspace_floats(cin, cout, B, H, W)
+  ws = torch.full((nws,), float('nan'), device=cuda)
+  dw, db = torch.full((3, 3, cin, cout), 7.0, device=cuda), torch.full((cout,), 7.0, device=cuda)
+  rn.check(lib.ra_conv3x3_wgrad_f32(rn.ptr(x), cin, B, H, W, 0, rn.ptr(du), cout, rn.ptr(ws), nws, rn.ptr(dw), rn.ptr(db), rn.stream_ptr()),
+           'wgrad')
+  rw, rb = _wgrad_ref(x, du)
+  assert _rel(dw, rw) < 2e-5 and _rel(db, rb) < 2e-5, (_rel(dw, rw), _rel(db, rb))
+
+
+@pytest.mark.parametrize('cin', [4, 8])
+def test_wgrad8_pointer_table_vs_float64(cuda, cin):
+  """ra_conv3x3_wgrad_multi_acc_f32 — the stacked step's call: the layer's T calls through two device pointer tables
+  (xtab / dutab), the sums ADDED to gw / gb in the reference layout — for the 8-output-channel layers on a ragged shape,
+  segments of 2 images at unrelated addresses."""
+  rng = np.random.RandomState(cin)
+  nseg, Bseg, H, W, cout = 3, 2, 45, 70, 8
+  xs = [torch.tensor(rng.randn(Bseg, H, W, cin).astype(np.float32), device=cuda) for _ in range(nseg)]
+  junk = [torch.full((1000 + 77 * i,), float('nan'), device=cuda) for i in range(nseg)]  # keeps the segments apart
+  dus = [torch.tensor(rng.randn(Bseg, H, W, cout).astype(np.float32), device=cuda) for _ in range(nseg)]
+  lib = rn.lib()
+  tab = torch.zeros(128, dtype=torch.int64, device=cuda)
+  for off, ts in ((0, xs), (64, dus)):
+    host = (C.c_void_p * nseg)(*[t.data_ptr() for t in ts])
+    rn.check(lib.ra_ptr_table(host, nseg, tab.data_ptr() + 8 * off, rn.stream_ptr()), 'ptr_table')
+  nws = lib.ra_conv3x3_wgrad_workspace_floats(cin, cout, nseg * Bseg, H, W)
+  ws = torch.full((nws,), float('nan'), device=cuda)
+  g0w, g0b = rng.randn(3, 3, cin, cout).astype(np.float32), rng.randn(cout).astype(np.float32)
+  gw, gb = torch.tensor(g0w, device=cuda), torch.tensor(g0b, device=cuda)
+  rn.check(lib.ra_conv3x3_wgrad_multi_acc_f32(tab.data_ptr(), tab.data_ptr() + 8 * 64, nseg, cin, Bseg, H, W, 0, cout, rn.ptr(ws), nws,
+                                              None, cin, 0, rn.ptr(gw), rn.ptr(gb), 0, rn.stream_ptr()), 'wgrad_multi')
+  rw, rb = _wgrad_ref(torch.cat(xs), torch.cat(dus))
+  rw, rb = rw + torch.tensor(g0w, device=cuda).double(), rb + torch.tensor(g0b, device=cuda).double()
+  assert _rel(gw, rw) < 2e-5 and _rel(gb, rb) < 2e-5, (_rel(gw, rw), _rel(gb, rb))
+  del junk
+
+
+def test_full_resolution_layer_gradient_pin(cuda):
+  """ONE layer at cfg4's resolution, where conditioning is no excuse: the controller CNN's 8 -> 8 layer (L1: conv + b ->
+  BatchNorm on batch moments -> ReLU -> 2x2 max-pool, nnlib.py:229-253 with :98-112) at 512 x 512, B = 8, through
+  ra_train.ConvBNActPool — data gradient (the MFMA conv on the transposed packing), filter gradient (wgrad8_kernel), BatchNorm
+  backward — against float64 autograd on the device.  Bars: 1e-4 relative (max-abs) for dW, dgamma, dbeta, the output and the
+  statistics; for dx 1e-4 in L2 and at most 1e-5 of the elements off by more than 1e-4 of the scale (a max-pool arg-max or a
+  ReLU sign decided differently in float32 moves single pixels by O(dy), not the sums)."""
+  import ra_train
+  rng = np.random.RandomState(2)
+  B, H, W, cin, cout = 8, 512, 512, 8, 8
+  x = torch.tensor(rng.randn(B, H, W, cin).astype(np.float32), device=cuda)
+  w = torch.tensor((rng.randn(3, 3, cin, cout) * 0.2).astype(np.float32), device=cuda)
+  b = torch.tensor((rng.randn(cout) * 0.1).astype(np.float32), device=cuda)
+  gam = torch.tensor(rng.uniform(0.5, 1.5, cout).astype(np.float32), device=cuda)
+  bet = torch.tensor((rng.randn(cout) * 0.2).astype(np.float32), device=cuda)
+  dy = torch.tensor(rng.randn(B, H // 2, W // 2, cout).astype(np.float32), device=cuda)
+  # float64 reference, on the device (torch = plumbing; the arithmetic under test is the HIP kernels')
+  xr, wr, br, gr, ber = [t.double().requires_grad_(True) for t in (x, w, b, gam, bet)]
+  u = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1) + br
+  mean = u.mean(dim=(0, 1, 2))
+  var = ((u - mean) ** 2).mean(dim=(0, 1, 2))
+  v = torch.relu((u - mean) * torch.rsqrt(var + 1e-3) * gr + ber)
+  yr = torch.nn.functional.max_pool2d(v.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+  (yr * dy.double()).sum().backward()
+  del u, v
+  xd, wd, bd, gd, bed = [t.clone().requires_grad_(True) for t in (x, w, b, gam, bet)]
+  meta = dict(transposed=False, stride=1, pool=2, relu=True, chan_map=None)
+  yd, md, vd = ra_train.ConvBNActPool.apply(xd, wd, bd, gd, bed, meta)
+  (yd * dy).sum().backward()
+  assert _rel(yd.detach(), yr.detach()) < 1e-4
+  assert _rel(md, mean.detach()) < 1e-4 and _rel(vd, var.detach()) < 1e-4
+  errs = {n: _rel(a.grad, r.grad) for n, a, r in (('dw', wd, wr), ('dgamma', gd, gr), ('dbeta', bed, ber))}
+  assert max(errs.values()) < 1e-4, errs
+  diff = (xd.grad.double() - xr.grad)
+  scale = float(xr.grad.abs().max())
+  l2 = float(diff.norm() / xr.grad.norm())
+  frac = float((diff.abs() > 1e-4 * scale).double().mean())
+  print('8->8 layer at 512x512, B=8: dW %.1e dgamma %.1e dbeta %.1e | dx L2 %.1e, outliers %.1e' % (
+      errs['dw'], errs['dgamma'], errs['dbeta'], l2, frac))
+  assert l2 < 1e-4 and frac < 1e-5, (l2, frac)

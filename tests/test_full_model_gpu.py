@@ -383,6 +383,21 @@ def test_starved_split_controller_recovers_on_one_workgroup_form(cuda):
   with pytest.raises(Exception):
     eng.subs[0]['ctrl_status'] = torch.ones(1, dtype=torch.int32, device=cuda)
     eng.check_status(recover=False)
+  # the pipeline's to_host path: the pinned host copies are taken inside submit(), from the starved forward;
+  # collect() must hand back the RE-DECODED outputs, not those copies
+  m2 = full_model.get_model(opt).load_weights(P)
+  pipe = m2.pipeline(1)
+  pipe.submit(['y_out', 's_out'], {'x': torch.as_tensor(x).cuda(), 'phase_train': False}, to_host=True)
+  torch.cuda.synchronize()
+  e2 = pipe.slots[0][0]
+  assert 'ctrl_ws' in e2.subs[0]
+  used, names, single, events = pipe.pending[0]
+  events[0][1][0].fill_(7.0)  # what a starved forward would have left in the pinned buffer
+  e2.subs[0]['ctrl_status'].fill_(1)
+  with warnings.catch_warnings(record=True):
+    warnings.simplefilter('always')
+    y3, s3 = pipe.collect()
+  assert isinstance(y3, np.ndarray) and np.abs(y3 - good[0]).max() < 1e-4 and np.abs(s3 - good[1]).max() < 1e-4
 
 
 def test_decode_pipeline_matches_lone_run(cuda):

@@ -200,9 +200,12 @@ def test_decode_pipeline_host_contract():
 
 
 def test_deferred_status_check_raises_on_flush():
-  """TrainStep checks a step's solver statuses one step late, from a pinned host record; flush_status() checks the last
-  record now: a negative matching code raises (hungarian.cc's LOG(FATAL) cases), a timed-out controller workgroup raises,
-  clean records pass and are consumed."""
+  """TrainStep checks a step's solver statuses one step late, from a pinned host record (the optimizer kernel has already
+  refused a failed step's update on the device); flush_status() checks the last record now: a negative matching code raises
+  (hungarian.cc's LOG(FATAL) cases), another rank's failure flag raises, a timed-out controller workgroup RECOVERS (warns,
+  switches the trainer to the one-workgroup controller, gives the skipped step's number back), clean records pass and are
+  consumed."""
+  import warnings
   import torch
   import ra_native as rn
   import ra_train as rt
@@ -211,25 +214,44 @@ def test_deferred_status_check_raises_on_flush():
     def synchronize(self):
       pass
 
+  class Bucket:
+    global_step = 7
+
   class Stub:
     _seqc = None
     _status_pending = None
+    seq_ctrl_split = True
+    dropped = 0
     _check_status = rt.TrainStep._check_status
     flush_status = rt.TrainStep.flush_status
 
+    def __init__(self):
+      self.bucket, self.model = Bucket(), {}
+
+    def _drop_captured_steps(self):
+      self.dropped += 1
+
   s = Stub()
-  s._status_pending = (Ev(), torch.zeros(17, dtype=torch.int32), 16)
+  s._status_pending = (Ev(), torch.zeros(17, dtype=torch.int32), 16, 1)
   s.flush_status()
   assert s._status_pending is None
   s.flush_status()  # nothing pending: a no-op
   bad = torch.zeros(17, dtype=torch.int32)
   bad[3] = -2
-  s._status_pending = (Ev(), bad, 16)
+  s._status_pending = (Ev(), bad, 16, 1)
   with pytest.raises(rn.RecAttendError):
     s.flush_status()
   assert s._status_pending is None
-  ctl = torch.zeros(17, dtype=torch.int32)
+  ctl = torch.zeros(18, dtype=torch.int32)
   ctl[16] = 1
-  s._status_pending = (Ev(), ctl, 16)
+  s._status_pending = (Ev(), ctl, 16, 1)
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    s.flush_status()
+  assert any('one-workgroup controller' in str(x.message) for x in w)
+  assert s.seq_ctrl_split is False and s.dropped == 1 and s.bucket.global_step == 6 and s.skipped_steps == 1
+  other = torch.zeros(18, dtype=torch.int32)
+  other[17] = 0x3f800000  # the all-reduced float flag 1.0 of another rank, as the optimizer kernel sees it
+  s._status_pending = (Ev(), other, 16, 1)
   with pytest.raises(rn.RecAttendError):
     s.flush_status()

@@ -189,3 +189,39 @@ def test_status_is_checked_on_device(cuda):
   else:
     M, _, _ = ops.hungarian(torch.from_numpy(W).to(cuda))
     assert int(ops.hungarian.last_status.max()) == rc
+
+
+# ---- the matrices a real cfg4 training step produces (tests/golden/hungarian_cfg4_step.npz, written by
+# tests/golden/make_hungarian_step_fixture.py from a capture of tools/hungarian_step_probe.py): 16 problems of 16 x 16 with
+# 8-15 live ground-truth columns and near-uniform IoUs — 1.1-1.8 ms each on the device solver, 50 x the planted-permutation
+# matrices bench.py used to quote alone
+STEP = np.load(os.path.join(HERE, 'golden', 'hungarian_cfg4_step.npz'))
+
+
+def test_cfg4_step_matrices_oracle_and_host():
+  import torch
+  import modellib
+  import ra_oracle as ora
+  iou, s = STEP['iou'], STEP['s_gt']
+  w, mx, my = ora.f_segm_match_precondition(iou, s)
+  assert (w == STEP['weights']).all()
+  rc, m, cx, cy = oracle(w)
+  assert rc == 0 and (m * mx * my == STEP['match']).all()  # the committed answer is the oracle's
+  M, cx2, cy2 = ops.hungarian(w)
+  assert ops.hungarian.last_status == 0
+  assert (M == m).all() and (cx2[..., 0] == cx).all() and (cy2[:, 0, :] == cy).all()  # host product == oracle, bit for bit
+  got = modellib.f_segm_match(torch.from_numpy(iou), torch.from_numpy(s)).numpy()     # through the reference-named caller
+  assert (got == STEP['match']).all()
+  assert (STEP['match'].sum((1, 2)) == s.sum(1)).all()  # every live instance is matched
+
+
+@pytest.mark.gpu
+def test_cfg4_step_matrices_device(cuda):
+  import torch
+  w = torch.from_numpy(STEP['weights']).to(cuda)
+  Md, cxd, cyd = ops.hungarian(w)
+  assert int(ops.hungarian.last_status.max()) == 0
+  rc, m, cx, cy = oracle(STEP['weights'])
+  assert (Md.cpu().numpy() == m).all() and (cxd.cpu().numpy()[..., 0] == cx).all() and (cyd.cpu().numpy()[:, 0, :] == cy).all()
+  match, status = ops.segm_match(torch.from_numpy(STEP['iou']).to(cuda), torch.from_numpy(STEP['s_gt']).to(cuda))
+  assert int(status.abs().max()) == 0 and (match.cpu().numpy() == STEP['match']).all()

@@ -1468,3 +1468,61 @@ def test_stacked_step_with_disable_overwrite_vs_oracle(cuda):
     if not _pre_bn_bias(k):
       err = np.abs(grads[True][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
       assert err < 2e-4, (k, err)
+
+
+def test_failed_status_never_reaches_the_weights(cuda):
+  """a step's solver / controller statuses are read by the host one step late (no sync per step), so the
+  optimizer kernel itself must refuse the update of a step whose status word is non-zero (ra_adam_step_guarded_f32).  A
+  negative status injected into the third step: weights, Adam moments and the step count after the raise are exactly those
+  after step two — neither the failed step nor the one queued behind it has touched them — and flush_status raises when it is
+  the last step that failed.  A controller time-out instead recovers: the step is skipped, the trainer moves to the
+  one-workgroup controller and goes on."""
+  import warnings
+  import full_model
+  from ra_native import RecAttendError
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6)
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'aug': False}
+  m = full_model.get_model(opt).load_weights(P)
+  for _ in range(2):
+    m.run(['loss', 'train_step'], feed)
+  tr = m.trainer
+  tr.flush_status()
+  torch.cuda.synchronize()
+  snap = (tr.bucket.param.clone(), tr.bucket.m.clone(), tr.bucket.v.clone(), tr.bucket.global_step)
+  tr._inject_status = -3  # the third step's first matching "hit an inner cap" (hungarian.cc:126)
+  m.run(['loss', 'train_step'], feed)   # step 3: issued, its update refused on the device; nobody has looked yet
+  torch.cuda.synchronize()
+  assert torch.equal(tr.bucket.param, snap[0]) and torch.equal(tr.bucket.m, snap[1]) and torch.equal(tr.bucket.v, snap[2])
+  with pytest.raises(RecAttendError):
+    m.run(['loss', 'train_step'], feed)  # step 4 notices step 3's record BEFORE its own optimizer launch is issued
+  torch.cuda.synchronize()
+  assert torch.equal(tr.bucket.param, snap[0]) and torch.equal(tr.bucket.m, snap[1]) and torch.equal(tr.bucket.v, snap[2])
+  # ... and as the last step of a run: flush_status raises, the weights stand
+  tr._status_pending = None
+  tr._inject_status = -3
+  m.run(['loss', 'train_step'], feed)
+  with pytest.raises(RecAttendError):
+    tr.flush_status()
+  assert torch.equal(tr.bucket.param, snap[0])
+  # a healthy step moves them again
+  m.run(['loss', 'train_step'], feed)
+  tr.flush_status()
+  assert not torch.equal(tr.bucket.param, snap[0])
+  # ---- a controller time-out (the sequential phase's 16-workgroup controller found a peer not resident)
+  if getattr(tr, '_seqc', None) is not None and tr._seqc.get('ok'):
+    torch.cuda.synchronize()
+    snap2 = (tr.bucket.param.clone(), tr.bucket.global_step)
+    orig = tr._seqc['status']
+    tr._seqc['status'] = torch.ones_like(orig)  # what a timed-out launch leaves
+    m.run(['loss', 'train_step'], feed)
+    tr._seqc['status'] = orig
+    torch.cuda.synchronize()
+    assert torch.equal(tr.bucket.param, snap2[0])  # refused on the device
+    with warnings.catch_warnings(record=True) as w:
+      warnings.simplefilter('always')
+      tr.flush_status()
+    assert any('one-workgroup controller' in str(x_.message) for x_ in w)
+    assert tr.seq_ctrl_split is False and tr.bucket.global_step == snap2[1] and tr.skipped_steps == 1
+    loss, _ = m.run(['loss', 'train_step'], feed)  # goes on, on the one-workgroup controller
+    tr.flush_status()
+    assert np.isfinite(float(loss)) and not torch.equal(tr.bucket.param, snap2[0]) and tr.bucket.global_step == snap2[1] + 1
