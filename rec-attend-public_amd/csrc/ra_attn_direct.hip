@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void extract_rows_kernel(const float *__restri
                                                             const float *__restrict__ canvas, int canvas_chan,
                                                             const float *__restrict__ attn, int H, int W, int Fh, int Fw,
                                                             int Cp, int use_gamma, float *__restrict__ patch,
-                                                            int n_items, int chunk) {
+                                                            int n_items, int chunk, int prio) {
+  raise_prio(prio);
   __shared__ f32x4 red[4][256];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int slot = blockIdx.x >> 3;
@@ -380,8 +381,9 @@ __global__ __launch_bounds__(256) void paste_win_kernel(const float *__restrict_
                                                          const float *__restrict__ attn, int H, int W, int Fh, int Fw,
                                                          float beta, int disable_overwrite, float *__restrict__ canvas,
                                                          float *__restrict__ y_out, size_t y_stride_b, int flags,
-                                                         ScoreArgs sc) {
+                                                         ScoreArgs sc, int prio) {
   static_assert(RB == 4 || RB == 8, "rows per workgroup");
+  raise_prio(prio);
   constexpr int nthr = 256, CVQ = RB;  // blind canvas float4 groups per thread (RB * W <= 4096 floats)
   extern __shared__ f32x4 smem4[];    // Cs [CVQ * 256] float4 | V [Fw][RB] | Ps [Fh * Fw]
   const int l0 = blockIdx.x * RB, b = blockIdx.y, t = threadIdx.x, lane = t & 63;
@@ -599,11 +601,11 @@ void launch_paste(int extra_wg, const float *patch, int Cp, int pc, const float 
   if (rb == 8)
     hipLaunchKernelGGL((attnd::paste_win_kernel<MODE, 8>), dim3(ceil_div(H, 8) + extra_wg, B), dim3(256), lds,
                        as_stream(stream), patch, attn_rec, H, W, Fh, Fw, beta, disable_overwrite, canvas, y_out, y_stride_b,
-                       flags, sc);
+                       flags, sc, tail_prio());
   else
     hipLaunchKernelGGL((attnd::paste_win_kernel<MODE, 4>), dim3(ceil_div(H, 4) + extra_wg, B), dim3(256), lds,
                        as_stream(stream), patch, attn_rec, H, W, Fh, Fw, beta, disable_overwrite, canvas, y_out, y_stride_b,
-                       flags, sc);
+                       flags, sc, tail_prio());
 }
 }  // namespace
 
@@ -617,7 +619,7 @@ extern "C" int ra_extract_direct_f32(const float *img, int Ci, int chan0, const 
   if ((size_t)H * W * Ci * 4 >= 0x7fffffffu) return fail(RA_E_SHAPE, "ra_extract_direct_f32: one image exceeds 2 GiB");
   const int n_items = Fh * (Cp / 4) * B, chunk = ceil_div(n_items, 8);
   hipLaunchKernelGGL((attnd::extract_rows_kernel<4>), dim3(8 * chunk), dim3(256), 0, as_stream(stream), img, Ci, chan0,
-                     canvas, canvas_chan, attn_rec, H, W, Fh, Fw, Cp, use_gamma, patch, n_items, chunk);
+                     canvas, canvas_chan, attn_rec, H, W, Fh, Fw, Cp, use_gamma, patch, n_items, chunk, tail_prio());
   return launch_status("ra_extract_direct_f32");
 }
 

@@ -65,6 +65,7 @@ struct Args {
   int in_bf16, out_bf16;        // bf16 kernels only: src0 / src1, respectively y, are STORED as bf16 (2 bytes per element)
   float *mom_part;              // MOM kernels: per-(workgroup, wave row) channel sums of the pre-activation output
   int *nparts_out;              // host: the number of partial records the launch writes (grid * WM)
+  int prio;                     // wave priority (s_setprio) of a patch-sized launch: the decode loop's latency-bound tail (ra_common.h)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -144,6 +145,7 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
 template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false>
 __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
   static_assert(!MOM || SWAP, "batch moments ride on the channel-vector epilogue");
+  raise_prio(a.prio);
   using G = Geo<CK, NC, WN, GX, GY>;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // 2 * G::LDS_FLOATS
   constexpr int NPIX = G::LH * G::LW;        // pixel records of one staged chunk
@@ -790,6 +792,9 @@ static int conv3x3_entry(const float *src0, int C0, const float *src1, int C1, i
     return ra::fail(RA_E_INVALID, "ra_conv3x3_f32: bad argument");
   if (C0 % 4 || C1 % 4) return ra::fail(RA_E_SHAPE, "ra_conv3x3_f32: C0=%d C1=%d must be %% 4", C0, C1);
   ra::conv::Args a;
+  // patch-sized launches (the attention CNN / decoder on 48 x 48 and below: <= 32 K conv pixels) are links of the decode
+  // loop's serial tail, a few us each, and run beside other batches' controller CNNs in the pipeline
+  a.prio = ((size_t)B * Hs * Ws * (upsample ? 4 : 1) <= 32768) ? ra::tail_prio(2) : 0;
   a.bf16 = bf16;
   a.in_bf16 = (bf16 && (store_flags & 1)) ? 1 : 0;
   a.out_bf16 = (bf16 && (store_flags & 2)) ? 1 : 0;

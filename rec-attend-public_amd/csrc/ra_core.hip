@@ -1,6 +1,7 @@
 // Library-wide bits of librecattend.so: version and the thread-local last-error string.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "ra_common.h"
 
@@ -13,6 +14,16 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+}  // namespace ra
+
+namespace ra {
+int tail_prio(int kind) {  // read on every call (an int parse): tests and A/B probes flip RA_TAIL_PRIO between launches / captures
+  const char *m = getenv("RA_TAIL_PRIO_MASK");
+  if (m && !(atoi(m) & kind)) return 0;
+  const char *e = getenv("RA_TAIL_PRIO");
+  const int v = e ? atoi(e) : 0;  // measured (profiles/r05_tail_prio_probe.txt): no level, on no subset of the kernels, helps
+  return v < 0 ? 0 : (v > 3 ? 3 : v);
 }
 }  // namespace ra
 

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(kThreads) void controller_kernel(const ra_ctrl_desc
                                                                const float *__restrict__ wp,
                                                                float *h_last, float *ctrl_out,
                                                                float *gmaps, float *attn,
-                                                               int feat_in_lds) {
+                                                               int feat_in_lds, int prio) {
+  raise_prio(prio);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Layout L = layout(d);
   const int t = threadIdx.x, b = blockIdx.x;
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(kThreads) void controller_kernel(const ra_ctrl_desc
 // out[b, n] = act(sum_k [x0|x1][b,k] W[k,n] + bias[n]); one workgroup per example.
 __global__ __launch_bounds__(256) void dense_kernel(const float *x0, int K0, const float *x1, int K1,
                                                      const float *W, const float *bias, int N, int act,
-                                                     float *out, size_t out_stride_b) {
+                                                     float *out, size_t out_stride_b, int prio) {
+  raise_prio(prio);
   __shared__ float red[4];
   extern __shared__ float vals[];  // N
   const int t = threadIdx.x, b = blockIdx.x;
@@ -377,7 +379,7 @@ extern "C" int ra_controller_f32(const ra_ctrl_desc *d, const float *feat, const
     attr_set = true;
   }
   hipLaunchKernelGGL(ctrl::controller_kernel, dim3(B), dim3(ctrl::kThreads), bytes, as_stream(stream),
-                     *d, feat, wpacked, h_last, ctrl_out, glimpse_maps, attn, in_lds);
+                     *d, feat, wpacked, h_last, ctrl_out, glimpse_maps, attn, in_lds, tail_prio(1));
   return launch_status("ra_controller_f32");
 }
 
@@ -387,6 +389,6 @@ extern "C" int ra_dense_f32(const float *x0, int K0, const float *x1, int K1, co
   if (!x0 || !W || !out || B <= 0 || N <= 0 || K0 <= 0 || K1 < 0 || (K1 > 0 && !x1) || N > 4096)
     return fail(RA_E_INVALID, "ra_dense_f32: bad argument");
   hipLaunchKernelGGL(ctrl::dense_kernel, dim3(B), dim3(256), N * sizeof(float), as_stream(stream), x0,
-                     K0, x1, K1, W, b, N, act, out, out_stride_b);
+                     K0, x1, K1, W, b, N, act, out, out_stride_b, tail_prio());
   return launch_status("ra_dense_f32");
 }

@@ -176,7 +176,8 @@ __device__ inline int any_gemv(const float *Wm, int n, const float *x, int K, fl
 template <int FR>  // feature registers per thread = ceil(G*Cf / 256)
 __global__ __launch_bounds__(kThreads) void controller_split_kernel(
     const ra_ctrl_desc d, const float *feat, const float *__restrict__ wp, float *h_last,
-    float *ctrl_out, float *gmaps, float *attn, unsigned *ws, int *status) {
+    float *ctrl_out, float *gmaps, float *attn, unsigned *ws, int *status, int prio) {
+  raise_prio(prio);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Layout L = layout(d);
   const int t = threadIdx.x, p = blockIdx.x, b = blockIdx.y;
@@ -378,7 +379,7 @@ int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, flo
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(kP, B), dim3(kThreads), lds, st, d, feat, wp, h_last, ctrl_out,
-                     gmaps, attn, ws, status);
+                     gmaps, attn, ws, status, tail_prio(1));
   return launch_status("ra_controller_split_f32");
 }
 
@@ -497,7 +498,8 @@ template <int FR, int NI>
 __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctrl_desc d, const float *feat,
                                                                     const float *__restrict__ wp, int B, float *h_last,
                                                                     float *ctrl_out, float *gmaps, float *attn,
-                                                                    unsigned *ws, int *status) {
+                                                                    unsigned *ws, int *status, int prio) {
+  raise_prio(prio);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Layout L = layout(d);
   const int t = threadIdx.x, p = blockIdx.x, grp = blockIdx.y;
@@ -705,7 +707,7 @@ int launch_batch(const ra_ctrl_desc &d, const float *feat, const float *wp, int 
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(kP, ceil_div(B, NI)), dim3(kThreads), lds, st, d, feat, wp, B, h_last, ctrl_out, gmaps,
-                     attn, ws, status);
+                     attn, ws, status, tail_prio(1));
   return launch_status("ra_controller_batch_f32");
 }
 
