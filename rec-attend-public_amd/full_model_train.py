@@ -38,6 +38,9 @@ def build_parser():
                  help='write model_opt.yaml + initial weights and stop')
   p.add_argument('--input', default=None, help='.npz with x, y_gt, s_gt (default: synthetic batches)')
   p.add_argument('--seed', type=int, default=1234)
+  p.add_argument('--save_rank_weights', action='store_true',
+                 help='every rank also writes weights_rank<r>.npz (its own weights, EMA shadows and per-step losses) at the end: '
+                      'the data-parallel ranks must hold ONE model — tests/test_distributed_gpu.py checks they do')
   p.add_argument('--sync_bn', action='store_true',
                  help='data parallel: BatchNorm batch moments over the WHOLE batch (nnlib.py:98), one small collective per BN call')
   return p
@@ -136,6 +139,7 @@ def train_loop(args, model, model_opt, folder, rank, world, make_batch):
     raise SystemExit('batch_size %d is not a multiple of the world size %d (equal shards: the gradient is averaged '
                      'as sum / world)' % (args.batch_size, world))
   gen = torch.Generator(device='cuda')
+  losses = []
   if getattr(model, 'trainer', None) is None:  # before the loop, as load_checkpoint does: the first step's augmentation stream
     model.trainer = (ra_train.BoxTrainStep if model.box_model else ra_train.TrainStep)(model)  # is seeded like every other's
   start = int(model.get('global_step', 0) or 0)
@@ -154,12 +158,18 @@ def train_loop(args, model, model_opt, folder, rank, world, make_batch):
     if len(batch) > 3:
       feed.update(batch[3])
     loss, _ = model.run(['loss', 'train_step'], feed)
+    if getattr(args, 'save_rank_weights', False):
+      losses.append(float(loss))
     if rank == 0 and (step % args.steps_per_log == 0 or step == args.num_steps - 1):
       print('step %d  loss %.5f  learn_rate %.2e  %.2f s' % (step, float(loss), ra_train.learn_rate(model_opt, step),
                                                              time.time() - t0))
     if rank == 0 and args.save_ckpt and (step + 1) % args.steps_per_ckpt == 0:
       save_checkpoint(ckpt, model)
   model.trainer.flush_status()  # every rank: the last step's solver / controller statuses are checked one step late
+  if getattr(args, 'save_rank_weights', False):
+    os.makedirs(folder, exist_ok=True)
+    np.savez(os.path.join(folder, 'weights_rank%d.npz' % rank), loss_history=np.asarray(losses, np.float64),
+             ranks_in_communicator=np.asarray(ra_dist.comm_size()), **model.state_dict_numpy())
   ra_dist.barrier()
   if rank == 0:
     os.makedirs(folder, exist_ok=True)

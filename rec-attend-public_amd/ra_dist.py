@@ -19,6 +19,9 @@ def init(backend=None):
   if world > 1 and not torch.distributed.is_initialized():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
+    # RA_DIST_BACKEND overrides the caller's choice: 'gloo' moves CUDA tensors through the host, which lets several ranks
+    # share ONE GPU (tests/test_distributed_gpu.py: the product's collectives on device tensors where no multi-GPU box exists)
+    backend = os.environ.get('RA_DIST_BACKEND') or backend
     if backend is None:
       backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     torch.distributed.init_process_group(backend, rank=rank, world_size=world)

@@ -1,0 +1,123 @@
+"""A REAL two-rank run of the product's training step on the one GPU there is: two processes on device 0
+launched through full_model_train.py, torch.distributed on gloo (it moves CUDA tensors through the host: RA_DIST_BACKEND),
+B = 4 images each — GradBucket.allreduce, TrainStep.broadcast_state, the stacked --sync_bn collectives (all_gather of the
+forward moments, one all_reduce of [T, 2C] sums per layer in the backward) and bench.py's barrier / max-over-ranks on DEVICE
+tensors.  "gloo, one GPU": RCCL over xGMI stays unmeasured (no multi-GPU box is available to the builder)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'rec-attend-public_amd')
+SIZE = ['--inp_height', '64', '--inp_width', '64', '--timespan', '2', '--padding', '0']  # padding 0: no random crop offset
+ARCH = ['--ctrl_cnn_filter_size', '3,3,3,3,3', '--ctrl_cnn_depth', '8,8,16,16,32', '--ctrl_cnn_pool', '2,2,2,2,2', '--attn_cnn_filter_size',
+        '3,3,3', '--attn_cnn_depth', '8,8,16', '--attn_cnn_pool', '2,2,2', '--attn_dcnn_filter_size', '3,3,3,3', '--attn_dcnn_depth',
+        '16,8,8,1', '--attn_dcnn_pool', '2,2,2,1', '--stop_canvas_grad', '--fixed_gamma', '--ctrl_add_inp', '--ctrl_add_canvas',
+        '--attn_add_inp', '--attn_add_canvas', '--base_learn_rate', '0.001']
+
+
+def _run(args, world, port, extra_env=None, script='full_model_train.py', timeout=900):
+  """`world` processes on device 0; returns their CompletedProcess list."""
+  procs = []
+  for r in range(world):
+    env = dict(os.environ)
+    env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               RA_DIST_BACKEND='gloo', RA_TRAIN_CTRL_SPLIT='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # RA_TRAIN_CTRL_SPLIT=0: two processes on one GPU break the 16-workgroup controller's residency rule by construction
+    env.update(extra_env or {})
+    path = os.path.join(PKG, script) if script.endswith('_train.py') else os.path.join(ROOT, script)
+    procs.append(subprocess.Popen([sys.executable, path] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+  outs = []
+  for p in procs:
+    try:
+      o, e = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+      for q in procs:
+        q.kill()
+      raise
+    outs.append((p.returncode, o, e))
+  for rc, o, e in outs:
+    assert rc == 0, (o[-1500:], e[-3000:])
+  return outs
+
+
+def _data(path, n=8, H=64, W=64, T=2):
+  sys.path.insert(0, PKG)
+  import full_model_train as fmt
+  x, y, s = fmt.synthetic_batch(np.random.RandomState(3), n, H, W, T)
+  np.savez(path, x=x, y_gt=y, s_gt=s)
+
+
+def _pre_bn_bias(k):
+  p = k.split('_')
+  return len(p) >= 3 and p[-2] == 'b' and ('cnn' in p or 'dcnn' in p)
+
+
+def test_two_ranks_on_one_gpu_through_the_train_cli(cuda, tmp_path):
+  res, inp = str(tmp_path / 'results'), str(tmp_path / 'data.npz')
+  _data(inp)
+  port = 29600 + os.getpid() % 300
+  common = ['--results', res, '--batch_size', '8', '--input', inp, '--steps_per_log', '1', '--save_rank_weights'] + SIZE + ARCH
+  _run(['--init_only', '--model_id', 'init'] + common, 1, port)          # one initial model for every run below
+  start = ['--restore', os.path.join(res, 'init'), '--num_steps', '2']
+  _run(start + ['--model_id', 'one'] + common, 1, port + 1)               # one process, B = 8
+  _run(start + ['--model_id', 'two'] + common, 2, port + 2)               # two ranks x B = 4, shard BatchNorm
+  _run(start + ['--model_id', 'two_sync', '--sync_bn'] + common, 2, port + 3)  # ... whole-batch BatchNorm (nnlib.py:98)
+  ld = lambda m, r: dict(np.load(os.path.join(res, m, 'weights_rank%d.npz' % r)))
+  one, t0, t1, s0, s1 = ld('one', 0), ld('two', 0), ld('two', 1), ld('two_sync', 0), ld('two_sync', 1)
+  init = dict(np.load(os.path.join(res, 'init', 'weights.npz')))
+  assert int(one['ranks_in_communicator']) == 1 and int(t0['ranks_in_communicator']) == 2 and int(s1['ranks_in_communicator']) == 2
+  keys = [k for k in one if k not in ('loss_history', 'ranks_in_communicator')]
+  wkeys = [k for k in keys if not k.endswith(('_ema_mean', '_ema_var'))]
+  moved = sum(int(np.abs(one[k] - init[k]).max() > 0) for k in wkeys)
+  assert moved > 0.8 * len(wkeys)  # the runs really trained
+  # (ii) the ranks of a data-parallel run hold ONE model: same all-reduced gradient, same optimizer state -> bit-identical weights.
+  #      (Without --sync_bn the EMA shadows follow each rank's own shard statistics and differ; with it they are the same.)
+  for k in wkeys:
+    assert np.array_equal(t0[k], t1[k]), k
+    assert np.array_equal(s0[k], s1[k]), k
+  for k in keys:
+    if k.endswith(('_ema_mean', '_ema_var')):
+      assert np.allclose(s0[k], s1[k], rtol=1e-6, atol=1e-7), k
+  assert any(np.abs(t0[k] - t1[k]).max() > 0 for k in keys if k.endswith('_ema_var'))
+  # (i) --sync_bn = the single-process run on the whole batch: the same losses (each rank's loss is its shard's mean, their
+  #     average the batch's), the same BatchNorm statistics in the EMA shadows, the same update
+  l_one, l_sync = one['loss_history'], 0.5 * (s0['loss_history'] + s1['loss_history'])
+  assert np.allclose(l_one, l_sync, rtol=2e-5, atol=1e-6), (l_one, l_sync)
+  l_shard = 0.5 * (t0['loss_history'] + t1['loss_history'])
+  assert np.abs(l_shard - l_one).max() > 1e-6  # shard statistics are a different normalisation: visibly not the same numbers
+  for k in keys:
+    if k.endswith(('_ema_mean', '_ema_var')):
+      assert np.allclose(s0[k], one[k], rtol=1e-4, atol=1e-6), k
+  # weights: Adam's first steps are lr * g / (|g| + 3e-6) — a gradient element that is itself round-off (a conv bias in front
+  # of BatchNorm has gradient zero; anything below ~1e-5) turns its last bits into a visible fraction of a +-lr step in BOTH
+  # runs.  So: the distance between the two runs against the distance either has moved (2 steps of 1e-3), element-wise.
+  bad5 = bad4 = tot = 0
+  for k in wkeys:
+    if _pre_bn_bias(k):
+      continue
+    d = np.abs(s0[k] - one[k])
+    bad5 += int((d > 1e-5).sum())
+    bad4 += int((d > 1e-4).sum())
+    tot += d.size
+  print('sync_bn two ranks vs one process after 2 steps: %d of %d weights differ by > 1e-5 (%.3f %%), %d by > 1e-4' % (bad5, tot, 100.0 * bad5 / tot, bad4))
+  assert bad5 <= 0.02 * tot and bad4 <= 2e-3 * tot, (bad5, bad4, tot)
+
+
+def test_two_ranks_reach_the_bench_line(cuda):
+  """bench.py --train with two ranks (gloo, both on device 0): the gradient all-reduce inside the step, the barrier and the
+  max-over-ranks time on the N > 1 path; `ranks_in_communicator` = 2 arrives in rank 0's JSON line."""
+  port = 29900 + os.getpid() % 90
+  outs = _run(['--train', '--gpus', '2', '--steps', '2', '--warmup', '2', '--batch', '2', '--size', '128', '--timespan', '3'], 2, port,
+              script='bench.py')
+  line = [l for l in outs[0][1].strip().splitlines() if l.startswith('{')][-1]
+  d = json.loads(line)
+  assert d['n_gpus'] == 2 and d['config']['ranks_in_communicator'] == 2 and d['config']['global_batch'] == 4
+  assert d['value'] > 0 and np.isfinite(d['final_loss']) and d['scaling'] == 'weak'
+  assert not [l for l in outs[1][1].strip().splitlines() if l.startswith('{')]  # only rank 0 prints
