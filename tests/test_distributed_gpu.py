@@ -65,12 +65,14 @@ def test_two_ranks_on_one_gpu_through_the_train_cli(cuda, tmp_path):
   port = 29600 + os.getpid() % 300
   common = ['--results', res, '--batch_size', '8', '--input', inp, '--steps_per_log', '1', '--save_rank_weights'] + SIZE + ARCH
   _run(['--init_only', '--model_id', 'init'] + common, 1, port)          # one initial model for every run below
-  start = ['--restore', os.path.join(res, 'init'), '--num_steps', '2']
-  _run(start + ['--model_id', 'one'] + common, 1, port + 1)               # one process, B = 8
-  _run(start + ['--model_id', 'two'] + common, 2, port + 2)               # two ranks x B = 4, shard BatchNorm
-  _run(start + ['--model_id', 'two_sync', '--sync_bn'] + common, 2, port + 3)  # ... whole-batch BatchNorm (nnlib.py:98)
+  start = lambda n: ['--restore', os.path.join(res, 'init'), '--num_steps', str(n)]
+  _run(start(1) + ['--model_id', 'one'] + common, 1, port + 1)               # one process, B = 8, ONE step: the strict comparison
+  _run(start(1) + ['--model_id', 'one_sync', '--sync_bn'] + common, 2, port + 2)  # two ranks x B = 4, whole-batch BatchNorm (nnlib.py:98)
+  _run(start(3) + ['--model_id', 'two'] + common, 2, port + 3)               # two ranks, shard BatchNorm, three steps (eager, captured, replayed)
+  _run(start(3) + ['--model_id', 'two_sync', '--sync_bn'] + common, 2, port + 4)
   ld = lambda m, r: dict(np.load(os.path.join(res, m, 'weights_rank%d.npz' % r)))
   one, t0, t1, s0, s1 = ld('one', 0), ld('two', 0), ld('two', 1), ld('two_sync', 0), ld('two_sync', 1)
+  q0, q1 = ld('one_sync', 0), ld('one_sync', 1)
   init = dict(np.load(os.path.join(res, 'init', 'weights.npz')))
   assert int(one['ranks_in_communicator']) == 1 and int(t0['ranks_in_communicator']) == 2 and int(s1['ranks_in_communicator']) == 2
   keys = [k for k in one if k not in ('loss_history', 'ranks_in_communicator')]
@@ -86,28 +88,31 @@ def test_two_ranks_on_one_gpu_through_the_train_cli(cuda, tmp_path):
     if k.endswith(('_ema_mean', '_ema_var')):
       assert np.allclose(s0[k], s1[k], rtol=1e-6, atol=1e-7), k
   assert any(np.abs(t0[k] - t1[k]).max() > 0 for k in keys if k.endswith('_ema_var'))
-  # (i) --sync_bn = the single-process run on the whole batch: the same losses (each rank's loss is its shard's mean, their
-  #     average the batch's), the same BatchNorm statistics in the EMA shadows, the same update
-  l_one, l_sync = one['loss_history'], 0.5 * (s0['loss_history'] + s1['loss_history'])
-  assert np.allclose(l_one, l_sync, rtol=2e-5, atol=1e-6), (l_one, l_sync)
+  # (i) --sync_bn = the single-process run on the whole batch, compared after ONE step (a second step starts from weights
+  #     that differ in Adam's round-off-signed elements, and the hard attention amplifies that into 1e-3 of the patch
+  #     statistics): the same loss (each rank's loss is its shard's mean, their average the batch's), the same BatchNorm
+  #     statistics in the EMA shadows, the same update
+  l_one, l_sync = one['loss_history'], 0.5 * (q0['loss_history'] + q1['loss_history'])
+  assert l_one.shape == (1,) and np.allclose(l_one, l_sync, rtol=2e-5, atol=1e-6), (l_one, l_sync)
   l_shard = 0.5 * (t0['loss_history'] + t1['loss_history'])
-  assert np.abs(l_shard - l_one).max() > 1e-6  # shard statistics are a different normalisation: visibly not the same numbers
+  assert abs(l_shard[0] - l_one[0]) > 1e-6  # shard statistics are a different normalisation: visibly not the same numbers
   for k in keys:
     if k.endswith(('_ema_mean', '_ema_var')):
-      assert np.allclose(s0[k], one[k], rtol=1e-4, atol=1e-6), k
+      assert np.allclose(q0[k], one[k], rtol=1e-4, atol=1e-7), k
+      assert np.array_equal(q0[k], q1[k]) or np.allclose(q0[k], q1[k], rtol=1e-6, atol=1e-8), k
   # weights: Adam's first steps are lr * g / (|g| + 3e-6) — a gradient element that is itself round-off (a conv bias in front
   # of BatchNorm has gradient zero; anything below ~1e-5) turns its last bits into a visible fraction of a +-lr step in BOTH
-  # runs.  So: the distance between the two runs against the distance either has moved (2 steps of 1e-3), element-wise.
+  # runs.  So: the distance between the two runs against the distance either has moved (one step of 1e-3), element-wise.
   bad5 = bad4 = tot = 0
   for k in wkeys:
     if _pre_bn_bias(k):
       continue
-    d = np.abs(s0[k] - one[k])
+    d = np.abs(q0[k] - one[k])
     bad5 += int((d > 1e-5).sum())
     bad4 += int((d > 1e-4).sum())
     tot += d.size
-  print('sync_bn two ranks vs one process after 2 steps: %d of %d weights differ by > 1e-5 (%.3f %%), %d by > 1e-4' % (bad5, tot, 100.0 * bad5 / tot, bad4))
-  assert bad5 <= 0.02 * tot and bad4 <= 2e-3 * tot, (bad5, bad4, tot)
+  print('sync_bn two ranks vs one process after 1 step of 1e-3: %d of %d weights differ by > 1e-5 (%.3f %%), %d by > 1e-4' % (bad5, tot, 100.0 * bad5 / tot, bad4))
+  assert bad5 <= 1e-3 * tot and bad4 == 0, (bad5, bad4, tot)  # measured: 0 of 381 530
 
 
 def test_two_ranks_reach_the_bench_line(cuda):
