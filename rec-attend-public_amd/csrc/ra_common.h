@@ -40,7 +40,7 @@ constexpr int kWave = 64;  // CDNA wavefront
 // slots oldest-first: a tail wave's few hundred dependent instructions each queue behind the other waves' 32-cycle MFMAs.
 // s_setprio would let the tail wave issue as soon as the pipe is free.  MEASURED in round 5 and NOT the lever: with
 // RA_TAIL_PRIO=3 on all of them the pipelined rate falls 52.3k -> 50.7k, on any subset (RA_TAIL_PRIO_MASK) it is equal or
-// lower within the run-to-run spread (profiles/r05_tail_prio_probe.txt).  Kept as a measuring aid, default 0 = off.
+// lower within the run-to-run spread (profiles/r05_decode_schedule_probes.txt).  Kept as a measuring aid, default 0 = off.
 int tail_prio(int kind = 4);  // ra_core.hip; kind: 1 = controller, 2 = patch-sized conv, 4 = extract / paste / score (RA_TAIL_PRIO_MASK)
 __device__ __forceinline__ void raise_prio(int p) {
   if (p >= 3) __builtin_amdgcn_s_setprio(3);

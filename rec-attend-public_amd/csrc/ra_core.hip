@@ -22,7 +22,7 @@ int tail_prio(int kind) {  // read on every call (an int parse): tests and A/B p
   const char *m = getenv("RA_TAIL_PRIO_MASK");
   if (m && !(atoi(m) & kind)) return 0;
   const char *e = getenv("RA_TAIL_PRIO");
-  const int v = e ? atoi(e) : 0;  // measured (profiles/r05_tail_prio_probe.txt): no level, on no subset of the kernels, helps
+  const int v = e ? atoi(e) : 0;  // measured (profiles/r05_decode_schedule_probes.txt): no level, on no subset of the kernels, helps
   return v < 0 ? 0 : (v > 3 ? 3 : v);
 }
 }  // namespace ra
