@@ -696,17 +696,48 @@ def main():
     prefilled = not d['disable_overwrite']
     pflags = (ops.PASTE_Y_PREFILLED if prefilled else 0) | ops.PASTE_CANVAS_FLOORED
 
-    def attn_group(bb=sb, n=Bs):
+    def attn_group(bb=sb, n=Bs):  # the two launches of rounds 1-4: extract, paste
       ops.extract_direct(bb['img'][:n], 0, bb['attn'][0][:n], Fh, Fw, d['C0p'], True, bb['x_patch'][0][:n],
                          canvas=bb['canvas'][:n], canvas_chan=d['D'])
       ops.paste_direct(bb['y_out_patch'][0][:n], 0, bb['attn'][0][:n], -5.0, d['disable_overwrite'],
                        bb['y_out'].data_ptr(), T * S * S, S, S, canvas=bb['canvas'][:n], flags=pflags)
 
+    # round 5: the forward issues the extract FUSED with layer 0 of the attention CNN (ra_extract_conv0_f32: one launch for
+    # what were two).  The attention resample's time is then what that launch costs beyond the conv layer it absorbed:
+    #   group = (extract+conv0 launch) + (paste launch) - (the conv0 launch alone, as rounds 1-4 issued it)
+    # all three measured here, in the same graphs-of-8 protocol; `unfused` = extract + paste as separate launches.
+    fused_attn = bool(eng.fuse_extract_conv0 and 'acnn0_plain' in Wt and eng.plan['acnn'][0] == ('single', 0))
+
+    def fused_group(bb=sb, n=Bs, W_=None):
+      W_ = Wt if W_ is None else W_
+      _, sc0, sh0, c0, _ = W_['acnn'][0]
+      ops.extract_conv0(bb['img'][:n], 0, bb['attn'][0][:n], Fh, Fw, True, bb['x_patch'][0][:n], W_['acnn0_plain'], sc0[0], sh0[0], c0,
+                        True, bb['acnn'][0][:n], canvas=bb['canvas'][:n], canvas_chan=d['D'])
+      ops.paste_direct(bb['y_out_patch'][0][:n], 0, bb['attn'][0][:n], -5.0, d['disable_overwrite'],
+                       bb['y_out'].data_ptr(), T * S * S, S, S, canvas=bb['canvas'][:n], flags=pflags)
+
+    def conv0_alone(bb=sb, n=Bs, W_=None):
+      W_ = Wt if W_ is None else W_
+      wp0, sc0, sh0, c0, _ = W_['acnn'][0]
+      ops.conv3x3(bb['x_patch'][0][:n], wp0, sc0[0], sh0[0], c0, relu=True, pool=1, out=bb['acnn'][0][:n])
+
+    def attn_times(bb=sb, n=Bs, W_=None):
+      """{'unfused': extract + paste, 'fused': extract+conv0 + paste, 'conv0': the absorbed launch alone, 'net': the group's time}"""
+      r = {'unfused': graph_time_us(lambda: attn_group(bb, n))}
+      if fused_attn:
+        r['fused'] = graph_time_us(lambda: fused_group(bb, n, W_))
+        r['conv0'] = graph_time_us(lambda: conv0_alone(bb, n, W_))
+        r['net'] = r['fused'] - r['conv0']
+      else:
+        r['net'] = r['unfused']
+      return r
+
     def prefill(bb=sb, ride=rides):  # once per forward: y_out = sigmoid(beta) everywhere, unless that rides on the first
       if not ride:                   # controller-CNN launch (then it is inside roofline.first_layer_cache); the canvas is
         ops.fill(bb['y_out'], 1.0 / (1.0 + np.exp(5.0)))  # zeroed by the input-packing launch
 
-    attn_us = graph_time_us(attn_group)
+    attn_t = attn_times()
+    attn_us = attn_t['net']
     # the kernels are window-only, so their time depends on the attention box: the same group at three box sizes (the
     # headline figures use the bench model's own box, 0.35 of the image side: seed_weights)
     by_box = {}
@@ -717,8 +748,10 @@ def main():
       rec[:, 2], rec[:, 3] = frac * S, frac * S                     # size
       rec[:, 4] = rec[:, 5] = float(np.log(frac * S / Fh))          # lg_var = log(size / F) (full_model.py:702-709)
       sb['attn'][0].copy_(rec)
-      us = graph_time_us(attn_group)
-      by_box['%.2f' % frac] = {'extract_paste_us': us, 'frac_algorithmic': float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs / (us * 1e-6) / 1e9 / PEAK_HBM_GBS}
+      bt = attn_times()
+      us = bt['net']
+      by_box['%.2f' % frac] = {'extract_paste_us': us, 'launches': bt,
+                               'frac_algorithmic': float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs / (us * 1e-6) / 1e9 / PEAK_HBM_GBS}
     sb['attn'][0].copy_(rec_keep)
     # the window-only paste relies on once-per-forward fills: their 1/T share belongs to every timestep's
     # attention-resample time
@@ -734,6 +767,12 @@ def main():
         'achieved_traffic': None if attn_traffic is None else attn_traffic / (group_us * 1e-6) / 1e9,
         'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': group_us,
         'extract_paste_us': attn_us, 'fills_us_per_forward': fill_us,
+        'launches_us': attn_t,
+        'accounting': ('round 5: the extract runs FUSED with layer 0 of the attention CNN (one launch instead of two); the '
+                       "group's time = (extract+conv0 launch + paste launch) - (the conv0 launch alone) = launches_us.fused - "
+                       'launches_us.conv0; launches_us.unfused = extract + paste as the two separate launches of rounds 1-4, '
+                       'frac_unfused the fraction on that time') if fused_attn else 'extract + paste, two launches',
+        'frac_unfused': attn_bytes / ((attn_t['unfused'] + fill_us / T) * 1e-6) / 1e9 / PEAK_HBM_GBS,
         'by_box_size': by_box,
         'frac_window_is_image': by_box['1.00']['frac_algorithmic'], 'frac_small_box_0.15': by_box['0.15']['frac_algorithmic'],
         'y_out_prefill': ('rides on the first timestep\'s first controller-CNN launch (MFMA-bound, HBM idle): its cost is '
@@ -751,10 +790,11 @@ def main():
     m32.engine.forward(torch.rand((32, S, S, 3), generator=g, dtype=torch.float32).cuda())
     s32 = m32.engine.subs[0]
     r32 = m32.engine._prefill_rides(s32)
-    us32 = graph_time_us(lambda: attn_group(s32, 32))
+    t32 = attn_times(s32, 32, m32.engine.W)
+    us32 = t32['net']
     f32us = graph_time_us(lambda: prefill(s32, r32), reps=5, inner=1) if (prefilled and not r32) else 0.0
     by32 = float(S * S * (d['acnn_channels'][0] + 3) * 4) * 32
-    out['roofline_attn']['at_B32'] = {'avg_us_per_launch_group': us32 + f32us / T, 'extract_paste_us': us32,
+    out['roofline_attn']['at_B32'] = {'avg_us_per_launch_group': us32 + f32us / T, 'extract_paste_us': us32, 'launches_us': t32,
                                       'achieved_algorithmic': by32 / ((us32 + f32us / T) * 1e-6) / 1e9,
                                       'frac_algorithmic': by32 / ((us32 + f32us / T) * 1e-6) / 1e9 / PEAK_HBM_GBS,
                                       'note': 'can exceed 1 by construction: the definition counts whole planes, the kernels '

@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 109
+#define RA_ABI_VERSION 110
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -331,6 +331,18 @@ int ra_gaussian_filter_f32(const float *center, const float *size, const float *
 int ra_extract_direct_f32(const float *img, int Ci, int chan0, const float *canvas, int canvas_chan,
                           const float *attn, int B, int H, int W, int Fh, int Fw, int Cp,
                           int use_gamma, float *patch, void *stream);
+/* extract + layer 0 of the attention CNN in ONE launch (full_model.py:788-795; nnlib.py:229-253 for a 3x3 layer without
+ * pooling): x_patch as ra_extract_direct_f32 writes it AND y0[b,j,i,co] = relu?((sum_{ky,kx,c} w0[ky][kx][c][co] *
+ * x_patch[b, j+ky-1, i+kx-1, c]) * scale[co] + shift[co]) (SAME padding; scale / shift = the folded bias + BatchNorm(eval)
+ * of ra_conv_fold_bn).  w0: the layer's filter in the PACKED input's channel order, [3][3][4][Cout] floats (rows of input
+ * channels the model does not feed are zero).  Workgroup (tap j, image) reduces the rows of taps j-1, j, j+1 once — their
+ * bands overlap almost completely — so the conv costs no second launch and no cross-workgroup wait.  Shapes:
+ * ra_extract_conv0_supported (one packed channel group Cp = 4, Fw <= 64, Cout <= 16, pool 1). */
+int ra_extract_conv0_supported(int Cp, int Fh, int Fw, int Cout, int pool);
+int ra_extract_conv0_f32(const float *img, int Ci, int chan0, const float *canvas, int canvas_chan,
+                         const float *attn_rec, int B, int H, int W, int Fh, int Fw, int use_gamma, float *patch,
+                         const float *w0, const float *scale, const float *shift, int Cout, int relu, float *y0,
+                         void *stream);
 /* flags (promises by the caller that let the paste touch only the attention window):
  *   RA_PASTE_Y_PREFILLED     y_out already holds sigmoid(beta) everywhere (ignored with
  *                            disable_overwrite, where untouched pixels are sigmoid(beta)*(1-canvas))

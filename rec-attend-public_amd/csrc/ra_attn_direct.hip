@@ -186,6 +186,186 @@ __global__ __launch_bounds__(256) void extract_rows_kernel(const float *__restri
   RA_PROBE_AT(3);
 }
 
+// ---- extract + the first attention-CNN layer in ONE launch (round 5) --------------------------------------
+// The decode loop's tail is a chain of dependent launches (extract -> 6 conv -> 7 transposed conv -> paste), each
+// ~2.5 us of launch floor.  The first conv layer (nnlib.cnn layer 0 of the attention CNN: 3x3 SAME on the 48 x 48 patch,
+// BN + ReLU, no pooling; full_model.py:792-795, nnlib.py:229-253) needs, for output row j, the patch rows j-1, j, j+1 —
+// and the three taps' row bands overlap almost completely (band 2R+1 = 31 rows against a tap spacing of 3.7 rows at
+// cfg2: the union is 38 rows).  So workgroup (tap j, image b) reduces its rows ONCE with three row-filter weights per
+// row, contracts the three row sums with the column filter, keeps the three patch rows in LDS and evaluates the
+// conv's output row j from them: no second launch and no cross-workgroup hand-over (the neighbours' rows are
+// recomputed, not waited for).  Writes x_patch row j (the model's output; dcnn skip source) and h_acnn[0] row j.
+// Shapes: one packed channel group (Cp = 4: the CVPPP input), Fw <= 64, Cout <= 16.
+template <int KR>
+__global__ __launch_bounds__(256) void extract_conv0_kernel(const float *__restrict__ img, int Ci, int chan0,
+                                                             const float *__restrict__ canvas, int canvas_chan,
+                                                             const float *__restrict__ attn, int H, int W, int Fh, int Fw,
+                                                             int use_gamma, float *__restrict__ patch,
+                                                             const float *__restrict__ w0, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int Cout, int relu,
+                                                             float *__restrict__ y0, int n_items, int chunk) {
+  __shared__ f32x4 red[3][4][256];
+  __shared__ f32x4 p3[3][66];       // patch rows j-1, j, j+1 with one zero column each side (SAME padding)
+  __shared__ float w0s[9 * 4 * 16];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int slot = blockIdx.x >> 3;
+  const int item = (blockIdx.x & 7) * chunk + slot;
+  if (slot >= chunk || item >= n_items) return;
+  const int b = item / Fh, j = item - b * Fh;
+  const float *rec = attn + (size_t)b * RA_ATTN_STRIDE;
+  const Axis Ay = make_axis(rec, 0, H, Fh), Ax = make_axis(rec, 1, W, Fw);
+  int l0d[3], l1d[3], l0u = H, l1u = 0, w0c, w1c, tmp;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int jd = j - 1 + d;
+    l0d[d] = l1d[d] = 0;
+    if (jd >= 0 && jd < Fh) {
+      Ay.band(jd, l0d[d], l1d[d]);
+      l0u = l0d[d] < l0u ? l0d[d] : l0u;
+      l1u = l1d[d] > l1u ? l1d[d] : l1u;
+    }
+  }
+  Ax.band(0, w0c, tmp);
+  Ax.band(Fw - 1, tmp, w1c);
+  for (int e = t; e < 36 * Cout; e += 256) w0s[e] = w0[e];
+  if (t < 6) p3[t >> 1][(t & 1) ? Fw + 1 : 0] = f32x4{0, 0, 0, 0};
+  const bool use_canvas = canvas != nullptr && (canvas_chan >= chan0) && (canvas_chan < chan0 + 4);
+  const int cslot = canvas_chan - chan0;
+  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(img + (size_t)b * H * W * Ci + chan0), 0, (int)((size_t)H * W * Ci * 4 - (size_t)chan0 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(use_canvas ? canvas + (size_t)b * H * W : img), 0, use_canvas ? H * W * 4 : 0, 0x00020000);
+  constexpr int kOOB = 0x7fffffff;
+
+  const int oi = t >> 2, part = t & 3;  // stage 2: output column oi, its band's columns dealt to 4 neighbouring lanes
+  const bool owner = oi < Fw;
+  int bi_lo = 0, bi_hi = 0;
+  if (owner) Ax.band(oi, bi_lo, bi_hi);
+  f32x4 P[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) P[d] = f32x4{0, 0, 0, 0};
+  constexpr int kPre = 8;
+  float fpre[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) fpre[u] = 0.0f;
+
+  for (int cp = w0c; cp < w1c; cp += 256) {
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[d][p] = f32x4{0, 0, 0, 0};
+    for (int rb = l0u; rb < l1u; rb += 4 * KR) {
+      f32x4 xv[KR][4];
+      float cv[KR][4];
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        const int row = rb + 4 * k + wv;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int col = cp + 64 * p + lane;
+          const int pix = (row < l1u && col < w1c) ? row * W + col : -1;
+          xv[k][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, pix >= 0 ? pix * Ci * 4 : kOOB, 0, 0));
+          cv[k][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, pix >= 0 ? pix * 4 : kOOB, 0, 0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {  // under the loads' latency: this thread's first 8 column-filter weights
+        const int ww = bi_lo + part + u * 4;
+        fpre[u] = (owner && ww < bi_hi) ? Ax.w((float)ww, oi) : 0.0f;
+      }
+      // the three taps' row-filter weights of this wave's KR rows: lane k evaluates row rb + 4k + wv (zero outside a tap's band)
+      const int rowl = rb + 4 * lane + wv;
+      float fyv[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) fyv[d] = (lane < KR && rowl >= l0d[d] && rowl < l1d[d]) ? Ay.w((float)rowl, j - 1 + d) : 0.0f;
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        const float wy0 = readlane_f(fyv[0], k), wy1 = readlane_f(fyv[1], k), wy2 = readlane_f(fyv[2], k);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          f32x4 x = xv[k][p];
+          if (use_canvas) {
+            x.x = cslot == 0 ? cv[k][p] : x.x;
+            x.y = cslot == 1 ? cv[k][p] : x.y;
+            x.z = cslot == 2 ? cv[k][p] : x.z;
+            x.w = cslot == 3 ? cv[k][p] : x.w;
+          }
+          acc[0][p] += wy0 * x;
+          acc[1][p] += wy1 * x;
+          acc[2][p] += wy2 * x;
+        }
+      }
+    }
+    __syncthreads();  // the previous column group's stage 2 is done with `red`
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) red[d][wv][64 * p + lane] = acc[d][p];
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; ++d) red[d][0][t] = (red[d][0][t] + red[d][1][t]) + (red[d][2][t] + red[d][3][t]);
+    __syncthreads();
+    if (owner) {
+      const int cend = (cp + 256 < w1c) ? cp + 256 : w1c;
+      const int a = bi_lo > cp ? bi_lo : cp, c = bi_hi < cend ? bi_hi : cend;
+      if (bi_lo >= cp && bi_hi <= cend && bi_hi - bi_lo <= kPre * 4) {  // the usual case: the pre-computed weights
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+          const int ww = bi_lo + part + u * 4;
+          const int wi = (ww < bi_hi ? ww : bi_hi - 1) - cp;
+          const int wj = wi > 0 ? wi : 0;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) P[d] += fpre[u] * red[d][0][wj];
+        }
+      } else {
+        for (int wb = a; wb < c; wb += 16) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ww = wb + u * 4 + part;
+            const int wc = ww < c ? ww : c - 1;
+            const float f = (ww < c) ? Ax.w((float)wc, oi) : 0.0f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) P[d] += f * red[d][0][wc - cp];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      P[d][c] += __shfl_xor(P[d][c], 1);
+      P[d][c] += __shfl_xor(P[d][c], 2);
+    }
+  if (owner && part == 0) {
+    const float gamma = use_gamma ? rec[6] : 1.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) p3[d][oi + 1] = gamma * P[d];
+    *reinterpret_cast<f32x4 *>(patch + (((size_t)b * Fh + j) * Fw + oi) * 4) = gamma * P[1];
+  }
+  __syncthreads();
+  // the conv layer's output row j: u[i, co] = sum_{d, kx, c} w0[d][kx][c][co] * P[j - 1 + d][i + kx - 1][c], BN (folded) + ReLU
+  const float lo = relu ? 0.f : -__builtin_inff();
+  for (int e = t; e < Fw * Cout; e += 256) {
+    const int i = e / Cout, co = e - i * Cout;
+    float u = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const f32x4 pv = p3[d][i + kx];
+        const float *wr = w0s + ((d * 3 + kx) * 4) * Cout + co;
+        u += wr[0] * pv.x;
+        u += wr[Cout] * pv.y;
+        u += wr[2 * Cout] * pv.z;
+        u += wr[3 * Cout] * pv.w;
+      }
+    y0[(((size_t)b * Fh + j) * Fw + i) * Cout + co] = fmaxf(u * scale[co] + shift[co], lo);
+  }
+}
+
 __device__ inline float sigmoidf(float z) { return 1.0f / (1.0f + __expf(-z)); }
 
 // y[b,l,w] = sigmoid(e^g * sum_j sum_i fy(l,j) P[j,i] fx(w,i) + beta) [* (1 - canvas)];
@@ -621,6 +801,34 @@ extern "C" int ra_extract_direct_f32(const float *img, int Ci, int chan0, const 
   hipLaunchKernelGGL((attnd::extract_rows_kernel<4>), dim3(8 * chunk), dim3(256), 0, as_stream(stream), img, Ci, chan0,
                      canvas, canvas_chan, attn_rec, H, W, Fh, Fw, Cp, use_gamma, patch, n_items, chunk, tail_prio());
   return launch_status("ra_extract_direct_f32");
+}
+
+extern "C" int ra_extract_conv0_supported(int Cp, int Fh, int Fw, int Cout, int pool) {
+  return Cp == 4 && Fw >= 1 && Fw <= 64 && Fh >= 1 && Cout >= 1 && Cout <= 16 && pool == 1;
+}
+
+extern "C" int ra_extract_conv0_f32(const float *img, int Ci, int chan0, const float *canvas, int canvas_chan,
+                                    const float *attn_rec, int B, int H, int W, int Fh, int Fw, int use_gamma, float *patch,
+                                    const float *w0, const float *scale, const float *shift, int Cout, int relu, float *y0,
+                                    void *stream) {
+  if (!img || !attn_rec || !patch || !w0 || !scale || !shift || !y0 || B <= 0 || H <= 0 || W <= 0)
+    return fail(RA_E_INVALID, "ra_extract_conv0_f32: bad argument");
+  if (!ra_extract_conv0_supported(4, Fh, Fw, Cout, 1) || Ci % 4 || chan0 % 4 || chan0 + 4 > Ci)
+    return fail(RA_E_SHAPE, "ra_extract_conv0_f32: Ci=%d chan0=%d Fh=%d Fw=%d Cout=%d", Ci, chan0, Fh, Fw, Cout);
+  if ((size_t)H * W * Ci * 4 >= 0x7fffffffu) return fail(RA_E_SHAPE, "ra_extract_conv0_f32: one image exceeds 2 GiB");
+  const int n_items = Fh * B, chunk = ceil_div(n_items, 8);
+  static int kr = 0;  // RA_EXC0_KR=4: tuning aid (rows per wave and load round; 5 covers cfg2's 38-row union in two rounds)
+  if (!kr) {
+    const char *e = getenv("RA_EXC0_KR");
+    kr = (e && atoi(e) == 4) ? 4 : 5;
+  }
+  if (kr == 4)
+    hipLaunchKernelGGL((attnd::extract_conv0_kernel<4>), dim3(8 * chunk), dim3(256), 0, as_stream(stream), img, Ci, chan0, canvas,
+                       canvas_chan, attn_rec, H, W, Fh, Fw, use_gamma, patch, w0, scale, shift, Cout, relu, y0, n_items, chunk);
+  else
+    hipLaunchKernelGGL((attnd::extract_conv0_kernel<5>), dim3(8 * chunk), dim3(256), 0, as_stream(stream), img, Ci, chan0, canvas,
+                       canvas_chan, attn_rec, H, W, Fh, Fw, use_gamma, patch, w0, scale, shift, Cout, relu, y0, n_items, chunk);
+  return launch_status("ra_extract_conv0_f32");
 }
 
 extern "C" int ra_paste_direct_f32(const float *patch, int Cp, int pc, const float *attn_rec, int B, int H,

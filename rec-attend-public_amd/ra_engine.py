@@ -14,6 +14,7 @@ Per output timestep tt (full_model.py:638-848), all on one stream:
 """
 import numpy as np
 import math
+import os
 
 import torch
 
@@ -54,6 +55,9 @@ class DecodeEngine(object):
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.prefill_ride = True  # the once-per-forward y_out prefill rides on the first controller-CNN launch
+    # extract + attention-CNN layer 0 as one launch (ra_extract_conv0_f32, round 5): built, parity-tested and MEASURED SLOWER than
+    # the two launches it replaces (11.8 vs 7.1 + 3.5 us at cfg2, profiles/r05_attn_fusion_probe.txt) — off; RA_FUSE_EXTRACT_CONV0=1 runs it
+    self.fuse_extract_conv0 = os.environ.get('RA_FUSE_EXTRACT_CONV0', '0') == '1'
     self.timing = None  # set to a list to collect (stage, start_event, end_event)
 
   # ------------------------------------------------------------------ weights
@@ -142,6 +146,14 @@ class DecodeEngine(object):
           wp = ops.pack_conv_weights(M['attn_cnn_w_%d' % i], cin_kernel=_r4(cin))
         sc, sh = fold_all('attn_cnn', i, cout)
         W['acnn'].append((_dev(wp, device), sc, sh, cout, d['acnn_pool'][i]))
+        if i == 0 and ops.extract_conv0_supported(d['C0p'], d['Fh'], d['Fw'], cout, d['acnn_pool'][0]):
+          # the layer's filter in the PACKED input's channel order, for the launch that fuses it into the extract
+          w0 = M['attn_cnn_w_0'].detach().cpu().numpy().astype(np.float32)
+          plain = np.zeros((3, 3, d['C0p'], cout), np.float32)
+          for c, m_ in enumerate(cmap_a):
+            if m_ >= 0:
+              plain[:, :, c, :] = w0[:, :, m_, :]
+          W['acnn0_plain'] = _dev(plain, device)
       # DCNN: filter input channels = [prev | skip] (nnlib.py:365); skip sources are
       # [None, h_acnn[L-2], ..., h_acnn[0], x_patch] gated by the reversed skip flags
       # (full_model.py:494-499,798-803)
@@ -434,9 +446,17 @@ class DecodeEngine(object):
       self._box_step(b, tt)
       return
     xp = b['x_patch'][tt]
-    ops.extract_direct(b['img'], 0, b['attn'][tt], Fh, Fw, d['C0p'], True, xp, canvas=b['canvas'], canvas_chan=d['D'])
-    self._mark('extract')
-    src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
+    if self.fuse_extract_conv0 and 'acnn0_plain' in Wt and self.plan['acnn'][0] == ('single', 0):
+      # extract + attention-CNN layer 0 as one launch (ra_extract_conv0_f32): one link less in the tail's launch chain
+      _, sc0, sh0, c0, _ = Wt['acnn'][0]
+      ops.extract_conv0(b['img'], 0, b['attn'][tt], Fh, Fw, True, xp, Wt['acnn0_plain'], sc0[tt], sh0[tt], c0, True, b['acnn'][0],
+                        canvas=b['canvas'], canvas_chan=d['D'])
+      self._mark('extract+attn_cnn_L0')
+      src = self._run_cnn(self.plan['acnn'][1:], Wt['acnn'], b['acnn'][0], b['acnn'], tt, 'attn_cnn')
+    else:
+      ops.extract_direct(b['img'], 0, b['attn'][tt], Fh, Fw, d['C0p'], True, xp, canvas=b['canvas'], canvas_chan=d['D'])
+      self._mark('extract')
+      src = self._run_cnn(self.plan['acnn'], Wt['acnn'], xp, b['acnn'], tt, 'attn_cnn')
     core = src
     L = d['acnn_nlayers']
     skips = [b['acnn'][L - 2 - k] for k in range(L - 1)] + [xp]

@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 109  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 110  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -81,6 +81,8 @@ SIGNATURES = {
     'ra_controller_batch_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P]),
     'ra_gaussian_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_extract_direct_f32': (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_extract_conv0_supported': (_I, [_I, _I, _I, _I, _I]),
+    'ra_extract_conv0_f32': (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     'ra_paste_direct_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _I, _P, _Z, _I, _P]),
     'ra_attn_box_direct_f32': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
     'ra_ctrl_train_supported': (_I, [_I, _I, _I, _I, _I]),

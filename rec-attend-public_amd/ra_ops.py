@@ -327,6 +327,20 @@ def extract_direct(img, chan0, attn, Fh, Fw, Cp, use_gamma, patch, canvas=None, 
                                        rn.stream_ptr()), 'ra_extract_direct_f32')
 
 
+def extract_conv0_supported(Cp, Fh, Fw, cout, pool):
+  return bool(rn.lib().ra_extract_conv0_supported(int(Cp), int(Fh), int(Fw), int(cout), int(pool)))
+
+
+def extract_conv0(img, chan0, attn, Fh, Fw, use_gamma, patch, w0, scale, shift, cout, relu, y0, canvas=None, canvas_chan=-1):
+  """extract_direct + layer 0 of the attention CNN (3x3, BN folded, ReLU, no pool) in one launch (ra_extract_conv0_f32).
+  w0 [3,3,4,cout]: the filter in the packed input's channel order; y0 [B,Fh,Fw,cout]."""
+  _need_cuda(img, attn, patch, canvas, w0, scale, shift, y0)
+  B, H, W, Ci = img.shape
+  check(rn.lib().ra_extract_conv0_f32(ptr(img), Ci, chan0, ptr(canvas), int(canvas_chan), ptr(attn), B, H, W, Fh, Fw,
+                                      int(use_gamma), ptr(patch), ptr(w0), ptr(scale), ptr(shift), int(cout), int(relu), ptr(y0),
+                                      rn.stream_ptr()), 'ra_extract_conv0_f32')
+
+
 PASTE_Y_PREFILLED, PASTE_CANVAS_FLOORED = 1, 2
 
 

@@ -407,6 +407,51 @@ def test_dense_attention_operators(cuda, H, W, big):
   assert np.abs(pd.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('H,W,big,cout,F', [(128, 128, False, 8, 48), (96, 160, True, 8, 48), (512, 512, False, 8, 48),
+                                             (64, 96, False, 16, 48), (128, 128, True, 12, 32)])
+def test_extract_fused_with_first_attention_cnn_layer(cuda, H, W, big, cout, F):
+  """ra_extract_conv0_f32 (round 5): the extract and layer 0 of the attention CNN (3x3 SAME, folded BN, ReLU, no pool) as ONE
+  launch — workgroup (tap j, image) reduces the rows of taps j-1, j, j+1 once and evaluates the conv's output row j from the
+  three patch rows.  Against the float64 oracle (extract_patch, then conv2d + affine + ReLU) and against the two separate
+  product launches; canvas as a plane, a box partly outside the image, wide dynamic_var bands, Cout 8 / 12 / 16, F 48 / 32."""
+  rng = np.random.RandomState(H + 3 * W + cout)
+  B = 3
+  rec = _attn_rec(B, H, W, rng, big)
+  rec[0, 0], rec[0, 1] = 0.02 * H, 0.97 * W
+  r64 = rec.astype(np.float64)
+  fy_ref = ora.get_gaussian_filter(r64[:, 0], r64[:, 2], r64[:, 4], H, F)
+  fx_ref = ora.get_gaussian_filter(r64[:, 1], r64[:, 3], r64[:, 5], W, F)
+  img = rng.rand(B, H, W, 4).astype(np.float32)
+  canvas0 = rng.uniform(0, 0.6, (B, H, W)).astype(np.float32)
+  img_ref = img.copy()
+  img_ref[..., 3] = canvas0
+  w0 = (rng.randn(3, 3, 4, cout) * 0.3).astype(np.float32)
+  w0[:, :, 2, :] = 0  # an input channel the model does not feed: a zero row of the packed-order filter
+  cp = ops.cout_padded(cout)
+  sc = np.ones(cp, np.float32)
+  sh = np.zeros(cp, np.float32)
+  sc[:cout], sh[:cout] = rng.uniform(0.5, 1.5, cout), rng.randn(cout) * 0.2
+  xp_ref = r64[:, 6].reshape(-1, 1, 1, 1) * ora.extract_patch(img_ref.astype(np.float64), fy_ref, fx_ref, 4)
+  y_ref = ora.relu(ora.conv2d(xp_ref, w0.astype(np.float64)) * sc[:cout] + sh[:cout])
+  assert ops.extract_conv0_supported(4, F, F, cout, 1) and not ops.extract_conv0_supported(8, F, F, cout, 1)
+  for plane in (True, False):
+    dimg = dev(img if plane else img_ref, cuda)
+    dcv = dev(canvas0, cuda) if plane else None
+    patch = torch.full((B, F, F, 4), 7.0, dtype=torch.float32, device=cuda)
+    y0 = torch.full((B, F, F, cout), 7.0, dtype=torch.float32, device=cuda)
+    ops.extract_conv0(dimg, 0, dev(rec, cuda), F, F, True, patch, dev(w0, cuda), dev(sc, cuda), dev(sh, cuda), cout, True, y0,
+                      canvas=dcv, canvas_chan=3)
+    torch.cuda.synchronize()
+    assert np.abs(patch.cpu().numpy() - xp_ref).max() < 3e-5 * max(1.0, np.abs(xp_ref).max())
+    assert np.abs(y0.cpu().numpy() - y_ref).max() < 5e-5 * max(1.0, np.abs(y_ref).max()), np.abs(y0.cpu().numpy() - y_ref).max()
+    # ... and the two launches it replaces
+    p2 = torch.zeros_like(patch)
+    ops.extract_direct(dimg, 0, dev(rec, cuda), F, F, 4, True, p2, canvas=dcv, canvas_chan=3)
+    y2 = ops.conv3x3(p2, dev(ops.pack_conv_weights(w0), cuda), dev(sc, cuda), dev(sh, cuda), cout, relu=True, pool=1)
+    assert np.abs(p2.cpu().numpy() - patch.cpu().numpy()).max() < 2e-5 * max(1.0, np.abs(xp_ref).max())
+    assert np.abs(y2.cpu().numpy() - y0.cpu().numpy()).max() < 5e-5 * max(1.0, np.abs(y_ref).max())
+
+
 @pytest.mark.parametrize('H,W,big', [(128, 128, False), (96, 160, True), (512, 512, False)])
 def test_direct_extract_paste_box(cuda, H, W, big):
   """The table-free attention kernels (weights computed on the fly), with the canvas either as a
