@@ -575,11 +575,38 @@ __device__ long long *ra_probe8_buf;
 // first_cache_kernel into the accumulator layout of phase A; per timestep layer A is then
 //   acc = S * scale(tt) + shift(tt)  (+)  3 MFMAs over the 3 x 4 canvas window
 // instead of 12 MFMAs over the 4-channel window, and only the 4-byte canvas plane is staged.
-template <int CINA, bool CACHED>
-__global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
+// SPLIT form (round 5, CACHED only): layer B — 24 of the pair's 27 MFMAs per pixel group — runs on the BF16 matrix pipe at
+// float32 accuracy.  A float32 value is exactly the sum of three bf16 pieces (8 + 8 + 8 mantissa bits), products of bf16
+// numbers are exact in float32, and of the nine piece products of a * b six carry everything above 2^-24 of it (hh, hm, mh,
+// hl, lh, mm): six v_mfma_f32_16x16x32_bf16 per K = 32 block do what eight v_mfma_f32_16x16x4_f32 do, in 41 ns of a SIMD
+// instead of 108 (tools/mfma_split_probe.hip, profiles/r05_mfma_split_probe.txt: K = 576 dot products come out at 1.9e-7 of
+// sum |a b| against 2.3e-7 for the float32 chain).  Phase A writes its output as three bf16 tiles [pixel][8 channels]
+// (hi / mid / lo); a K = 32 block of phase B is one row ky of the 3 x 4 tap window x 8 channels, so a lane's whole A operand
+// of a block and piece is ONE ds_read_b128 (lane kb = window column), and the filter is 3 x 3 x 4 registers per lane.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+__device__ inline unsigned pk_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32: two floats -> two bf16 (RNE), `lo` in the low half
+  typedef float f32x2c __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2c __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2c{lo, hi}, bf16x2c));
+}
+// (a, b) -> three packed bf16 pairs H, M, L with a = a_H + a_M + a_L exactly (every difference below is exact in float32)
+__device__ inline void split3_pair(float a, float b, unsigned &H, unsigned &M, unsigned &L) {
+  H = pk_bf16(a, b);
+  float ra = a - __builtin_bit_cast(float, H << 16), rb = b - __builtin_bit_cast(float, H & 0xffff0000u);
+  M = pk_bf16(ra, rb);
+  ra -= __builtin_bit_cast(float, M << 16);
+  rb -= __builtin_bit_cast(float, M & 0xffff0000u);
+  L = pk_bf16(ra, rb);
+}
+template <int CINA, bool CACHED, bool SPLIT = false>
+__global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = NGeo<CINA>;
   constexpr int NCGA = G::NCGA;
   static_assert(!CACHED || CINA == 4, "cached form: 4 input channels");
+  static_assert(!SPLIT || CACHED, "the split-precision layer B exists for the cached (steady-state) form");
+  constexpr int PLANE_B = G::AHS * G::AW * 16;                 // bytes of one bf16 tile [AHS][AW][8]
+  constexpr int MIDF = SPLIT ? 3 * PLANE_B / 4 : G::MID_FLOATS;  // floats of the intermediate tile(s)
   constexpr int RECA = CACHED ? 1 : CINA;  // floats per staged input pixel
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IN_FLOATS = (G::LH * G::LW * RECA + 3) & ~3;
@@ -637,6 +664,27 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
       }
     }
 
+  // SPLIT: this lane's B operands — block ky, k-slot j = input channel j of window column kb = ksub, column n = (p, co) —
+  // as three bf16 pieces (the BN scale folded in before the split)
+  s16x8 wB[SPLIT ? 3 : 1][SPLIT ? 3 : 1];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int kx = ksub - p;
+      const bool ok = (kx >= 0) & (kx <= 2);
+      const int tap = ok ? ky * 3 + kx : 0;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const float w0 = a.wpB[((tap * 2 + (j >> 2)) * 4 + (j & 3)) * a.CoutBP + co];
+        const float w1 = a.wpB[((tap * 2 + ((j + 1) >> 2)) * 4 + ((j + 1) & 3)) * a.CoutBP + co];
+        unsigned H, M, L;
+        split3_pair(ok ? w0 * scB : 0.f, ok ? w1 * scB : 0.f, H, M, L);
+        wB[ky][0][j] = (short)(H & 0xffffu), wB[ky][0][j + 1] = (short)(H >> 16);
+        wB[ky][1][j] = (short)(M & 0xffffu), wB[ky][1][j + 1] = (short)(M >> 16);
+        wB[ky][2][j] = (short)(L & 0xffffu), wB[ky][2][j + 1] = (short)(L >> 16);
+      }
+    }
+  }
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src), 0, a.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(a.plane ? a.plane : a.src), 0, a.plane ? a.bytes_p : 0, 0x00020000);
@@ -762,7 +810,7 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
   RA_P8_DECL;
   // the padded groups read LDS this kernel never writes; whatever an earlier kernel left there
   // must not be NaN/Inf (their results are discarded, but keep the arithmetic clean)
-  for (int e = tid; e < (IN_FLOATS + G::MID_FLOATS) / 4; e += 256)
+  for (int e = tid; e < (IN_FLOATS + MIDF) / 4; e += 256)
     reinterpret_cast<f32x4 *>(lds)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   // the rider: this workgroup's share of the constant fill, dealt over its tiles
@@ -900,7 +948,24 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
             o[r] = (yok & (X >= 0) & (X < a.W)) ? o[r] : 0.f;
           }
         }
-        if (live) {
+        if constexpr (SPLIT) {
+          // three bf16 tiles [pixel][channel]: this lane's four values are channel co of pixels (row qo, col 2 r + p)
+          unsigned H01, M01, L01, H23, M23, L23;
+          split3_pair(o[0], o[1], H01, M01, L01);
+          split3_pair(o[2], o[3], H23, M23, L23);
+          if (live) {
+            unsigned char *d0 = reinterpret_cast<unsigned char *>(tmid) + ((4 * gr + qo) * G::AW + 8 * gc + p) * 16 + co * 2;
+            const unsigned hs[4] = {H01 & 0xffffu, H01 >> 16, H23 & 0xffffu, H23 >> 16};
+            const unsigned ms[4] = {M01 & 0xffffu, M01 >> 16, M23 & 0xffffu, M23 >> 16};
+            const unsigned ls[4] = {L01 & 0xffffu, L01 >> 16, L23 & 0xffffu, L23 >> 16};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              *reinterpret_cast<unsigned short *>(d0 + r * 32) = (unsigned short)hs[r];
+              *reinterpret_cast<unsigned short *>(d0 + r * 32 + PLANE_B) = (unsigned short)ms[r];
+              *reinterpret_cast<unsigned short *>(d0 + r * 32 + 2 * PLANE_B) = (unsigned short)ls[r];
+            }
+          }
+        } else if (live) {
           float *dst = tmid + (4 * gr * G::AW + 8 * gc) * 8 + lane_mid;
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[r * 16] = o[r];
@@ -921,6 +986,33 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
         gmid[g] = (2 * gy * G::AW + 16 * gx) * 8 + lane_b;
         acc[g] = f32x4{shB, shB, shB, shB};
       }
+      if constexpr (SPLIT) {
+        // lane (m, kb): pixel (row (m & 1) + ky, column 2 (m >> 1) + 1 + kb) of the group, its 8 channels = one 16-byte read
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(tmid);
+        const int lane_px = ((m & 1) * G::AW + 2 * (m >> 1) + 1 + ksub) * 16;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int gh = 0; gh < 2; ++gh) {  // two pixel groups at a time: 24 operand registers in flight instead of 48
+            s16x8 av[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int g = 2 * gh + u;
+              const int gy = 2 * wave + (g >> 1), gx = g & 1;
+              const int off = ((2 * gy + ky) * G::AW + 16 * gx) * 16 + lane_px;
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) av[u][pc] = *reinterpret_cast<const s16x8 *>(tb + off + pc * PLANE_B);
+            }
+            // six piece products per block, smallest first; consecutive MFMAs alternate between the two accumulators
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                acc[2 * gh + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, av[u][PA[t]]),
+                                                                          __builtin_bit_cast(bf16x8v, wB[ky][PB[t]]), acc[2 * gh + u], 0, 0, 0);
+          }
+      } else {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -935,6 +1027,7 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
             for (int g = 0; g < 4; ++g)
               acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][cg], bB[ky * 4 + kxp][cg], acc[g], 0, 0, 0);
         }
+      }
       const int prow0 = (ty0 >> 1) + wave * 2, pcol0 = (tx0 >> 1) + 2 * qo + p;
       const bool whole = ((ty0 >> 1) + G::TH / 2 <= a.Ho) & ((tx0 >> 1) + G::TW / 2 <= a.Wo);  // uniform
       const unsigned tile_y = (unsigned)(((b * a.Ho + prow0) * a.Wo + (tx0 >> 1)) * a.CoutB * 4) + lane_y;
@@ -961,13 +1054,13 @@ __global__ __launch_bounds__(256, CACHED ? 4 : RA_PAIR8_OCC) void conv_pair8_mfm
   }
 }
 
-template <int CINA, bool CACHED = false>
+template <int CINA, bool CACHED = false, bool SPLIT = false>
 int launch8(const PArgs &a_in, int B, hipStream_t st) {
   using G = NGeo<CINA>;
   PArgs a = a_in;
   a.bytes_y = (int)((size_t)B * a.Ho * a.Wo * a.CoutB * sizeof(float));
-  auto kern = conv_pair8_mfma<CINA, CACHED>;
-  constexpr size_t lds = (size_t)(((G::LH * G::LW * (CACHED ? 1 : CINA) + 3) & ~3) + G::MID_FLOATS) * sizeof(float);
+  auto kern = conv_pair8_mfma<CINA, CACHED, SPLIT>;
+  constexpr size_t lds = (size_t)(((G::LH * G::LW * (CACHED ? 1 : CINA) + 3) & ~3) + (SPLIT ? 3 * G::AHS * G::AW * 4 : G::MID_FLOATS)) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1326,5 +1419,11 @@ extern "C" int ra_conv_pair_cached_f32(const float *cache, const float *plane, i
   const size_t cb = (size_t)B * a.cache_rows * a.cache_gx * 64 * sizeof(float);
   if (cb >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_pair_cached_f32: cache exceeds 2 GiB");
   a.bytes_c = (int)cb;
+  static int split = -1;  // RA_PAIR8_SPLIT=0: layer B on the float32 MFMA (rounds 2-4) instead of the split-precision bf16 form
+  if (split < 0) {
+    const char *e = getenv("RA_PAIR8_SPLIT");
+    split = e ? atoi(e) : 1;
+  }
+  if (split) return cpair::launch8<4, true, true>(a, B, as_stream(stream));
   return cpair::launch8<4, true>(a, B, as_stream(stream));
 }
