@@ -446,6 +446,9 @@ def main():
   ap.add_argument('--in-flight', type=int, default=0,
                   help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other; '
                        'default: 8 at cfg2 (on 4 streams), 6 at cfg3 over its two stages, 2 at cfg5)')
+  ap.add_argument('--coalesce', type=int, default=0,
+                  help='consecutively submitted batches one pipeline slot decodes as ONE forward (DecodePipeline(coalesce=...)); '
+                       'default: 2 at cfg2 (four slots of 2 x 8 images for the 8 batches in flight), 1 elsewhere')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
   ap.add_argument('--no-fuse-score', action='store_true', help='tuning aid: score MLP as its own launch')
   ap.add_argument('--host-output', action='store_true',
@@ -544,14 +547,15 @@ def main():
   # the timed region: K steps = K batches through the evaluator's decode pipeline
   # (full_model.DecodePipeline: up to --in-flight batches decode concurrently, each a whole
   # forward of B images on its own HIP graph + stream; every step is a complete forward)
-  pipe = model.pipeline(max(1, args.in_flight), streams=args.streams or None)
+  coalesce = args.coalesce if args.coalesce > 0 else (2 if (args.in_flight >= 2 and B <= 8) else 1)
+  pipe = model.pipeline(max(1, args.in_flight // coalesce), streams=args.streams or None, coalesce=coalesce)
 
   def step():
-    if pipe.full():
+    while pipe.full():
       pipe.retire()
     pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output)
 
-  for _ in range(max(args.warmup, pipe.depth)):  # every slot allocates + captures its graph
+  for _ in range(max(args.warmup, 2 * pipe.depth * coalesce)):  # every slot allocates + captures its graph
     step()
   pipe.drain()
   barrier()
@@ -565,16 +569,17 @@ def main():
   # SURVEY 8(d)'s protocol beside the contract's mean: the MEDIAN time per batch in the steady state, fill and drain of the
   # pipeline excluded — the host clock at every completion (retire() returns when the oldest batch has finished); a
   # window of `streams` consecutive completions is one batch per stream, so (t[i + w] - t[i]) / w is a per-batch time
-  n_steady = max(24, 3 * pipe.depth)
+  n_steady = max(24, 3 * pipe.depth * coalesce)
   done = []
-  for _ in range(pipe.depth):
+  for _ in range(pipe.depth * coalesce):
     pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output)
   for _ in range(n_steady):
-    pipe.retire()
-    done.append(time.perf_counter())
+    while pipe.full():
+      pipe.retire()
+      done.append(time.perf_counter())
     pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output)
   pipe.drain()
-  wdw = max(1, int(pipe.streams))
+  wdw = max(1, int(pipe.streams)) * coalesce  # one launch per stream: that many batches complete per round of the streams
   gaps = [(done[i + wdw] - done[i]) / wdw for i in range(wdw, len(done) - wdw)]
   steady_ms = 1e3 * ra_dist.max_over_ranks(float(np.median(gaps)))
   for eng_k, _ in pipe.slots:  # a controller workgroup that timed out on its peers would have produced garbage: fail loudly
@@ -582,7 +587,7 @@ def main():
 
   out = {
       'metric': 'instance-timesteps/sec, full_model forward 512x512 T=16 (whole job; pipelined throughput: %d batches in flight '
-                'per GPU, fill and drain of the pipeline inside the timed region; config.lone_batch_* = one sync-bracketed forward)' % pipe.depth,
+                'per GPU, fill and drain of the pipeline inside the timed region; config.lone_batch_* = one sync-bracketed forward)' % (pipe.depth * coalesce),
       'value': value, 'unit': 'instance-timesteps/s', 'per_gpu': value / world,
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
@@ -592,7 +597,11 @@ def main():
                  'arch': 'cvppp', 'H': S, 'W': S, 'T': T, 'batch_per_gpu': B,
                  'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no collective' % world,
                  'ranks_in_communicator': ra_dist.comm_size(),
-                 'hip_graph': bool(eng.use_graph), 'batches_in_flight': pipe.depth,
+                 'hip_graph': bool(eng.use_graph), 'batches_in_flight': pipe.depth * coalesce, 'pipeline_slots': pipe.depth,
+                 'batches_per_launch': coalesce,
+                 'pipeline_note': ('each of the %d pipeline slots decodes %d consecutively submitted batches of %d images as ONE forward '
+                                   '(DecodePipeline(coalesce=%d): eval-mode images are independent, every batch is collected on its own); '
+                                   '--coalesce 1 = one batch per slot, the protocol of rounds 2-4' % (pipe.depth, coalesce, B, coalesce)),
                  'steady_ms_per_step_median': steady_ms, 'steady_value_median': world * B * T / (steady_ms * 1e-3),
                  'steady_protocol': 'median over %d completions of the time per batch in the steady state of the pipeline '
                                     '(fill and drain excluded; windows of %d consecutive completions)' % (n_steady, wdw),
@@ -691,6 +700,23 @@ def main():
                     'count (SURVEY 8d), of which %.1f %% is no longer executed per timestep'
                     % (100.0 * 0.75 * per_f[0] / tot_f)},
         'layers': layers}
+
+    if coalesce > 1 and pipe.slots:
+      # what the pipeline's slots really launch: the same group over the images of `coalesce` batches (the figures above are per
+      # batch of 8 images — the unit of the metric, comparable across rounds, and the shape the committed PMC passes ran)
+      reng = pipe.slots[0][0]
+      rsb = reng.subs[0]
+      rB = int(rsb['img'].shape[0])
+
+      def enc_launched():
+        for st_ in reng.plan['ccnn']:
+          src_ = rsb['img'] if st_[1] == 0 else rsb['ccnn'][st_[1] - 1]
+          reng._run_cnn([st_], reng.W['ccnn'], src_, rsb['ccnn'], 1, 'ctrl_cnn', plane=rsb['canvas'], cache=rsb.get('l0cache'))
+      us_l = graph_time_us(enc_launched) + cache_us * rB / Bs / T
+      out['roofline']['as_launched'] = {
+          'images_per_launch': rB, 'avg_us_per_launch_group': us_l, 'flop_per_launch_group': tot_f * rB,
+          'achieved': tot_f * rB / (us_l * 1e-6) / 1e12, 'frac': tot_f * rB / (us_l * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+          'note': 'the pipeline slots decode %d batches per forward (config.batches_per_launch): the same launch group over %d images' % (coalesce, rB)}
 
     Hh = S
     prefilled = not d['disable_overwrite']
@@ -805,7 +831,8 @@ def main():
     tail_us = graph_time_us(lambda: eng._launch_tail(sb, 1, False, sb['ccnn'][-1]))
     out['tail_us'] = tail_us
     if 'ctrl_ws' in sb:
-      out['controller_us'] = graph_time_us(lambda: ops.controller_split(
+      lone_ctrl = ops.controller_batch if sb.get('ctrl_batch') else ops.controller_split  # more than 14 images: the group-shared form
+      out['controller_us'] = graph_time_us(lambda: lone_ctrl(
           eng.desc, sb['ccnn'][-1], Wt['ctrl_split'], sb['h_last'][0], sb['ctrl_out'][0],
           sb['gmaps'][0], sb['attn'][0], sb['ctrl_ws'], sb['ctrl_status']))
       out['controller_status'] = int(sb['ctrl_status'].item())

@@ -201,9 +201,9 @@ class Model(dict):
       res = [r.detach().cpu().numpy() for r in res]
     return res[0] if single else res
 
-  def pipeline(self, depth=4, max_images=None, co_resident=None, streams=None):
-    """`depth` batches of this model in flight (DecodePipeline below)."""
-    return DecodePipeline(self, depth, max_images, co_resident, streams)
+  def pipeline(self, depth=4, max_images=None, co_resident=None, streams=None, coalesce=1):
+    """`depth` slots of this model decoding concurrently (DecodePipeline below), `coalesce` submitted batches per slot."""
+    return DecodePipeline(self, depth, max_images, co_resident, streams, coalesce)
 
   def _run_train(self, names, feed, single, as_numpy):
     """sess.run([loss, train_step], feed{x, y_gt, s_gt, phase_train=True}) (full_model_train.py:107):
@@ -357,24 +357,35 @@ class DecodePipeline(object):
       consume(pipe.collect())
   """
 
-  def __init__(self, model, depth=4, max_images=None, co_resident=None, streams=None):
+  def __init__(self, model, depth=4, max_images=None, co_resident=None, streams=None, coalesce=1):
     """streams: HIP streams the slots are dealt onto, round robin (default min(depth, 4): the GPU runs four
     queues at a time); with depth > streams a slot's batch is queued behind another slot's on the same stream,
     so the stream never waits for the host to notice a finished batch and submit the next.
     co_resident: engines decoding at the same time on this GPU if other pipelines run beside this one
     (default: streams); max_images: a batch with more images is decoded as ceil(B / max_images) near-equal parts,
     each on its own slot, and collect() returns them concatenated (KITTI's batch of 16 as 2 x 8: the
-    16-workgroup controller needs all of a launch's workgroups co-resident, <= 14 images)."""
+    16-workgroup controller needs all of a launch's workgroups co-resident, <= 14 images).
+    coalesce (round 5): that many consecutively submitted batches are decoded by ONE slot as one forward over their
+    images (eval-mode images are independent: a batch's results do not depend on its company); collect() still hands
+    back one batch at a time.  With two batches of 8 per slot the controller CNN's share of a slot's timestep doubles
+    while its latency-bound tail barely grows, and the four streams stop meeting in their tails with nothing for the
+    matrix pipe to do: 53k -> 62k instance-timesteps/s at cfg2 with the same 64 images in flight
+    (profiles/r05_pipeline_coalesce.txt).  A batch waits in the group until it is full; collect() / retire() / drain()
+    of a waiting batch launch the group as it is."""
     if depth < 1:
       raise ValueError('depth must be >= 1')
     if max_images is not None and max_images < 1:
       raise ValueError('max_images must be >= 1')
+    if coalesce < 1:
+      raise ValueError('coalesce must be >= 1')
     self.model, self.depth, self.max_images = model, int(depth), max_images
     self.streams = max(1, min(self.depth, int(streams or 4)))
     self.co_resident = int(co_resident or self.streams)
+    self.coalesce = int(coalesce)
     self.slots = None
     self.free = list(range(self.depth))
-    self.pending = []  # tickets in submission order: (slot indices, names, single, events)
+    self.group = []    # batches waiting for company: tickets whose 'launch' is still None
+    self.pending = []  # tickets in submission order: dict(names, single, feed, to_host, B, launch, lo, hi)
 
   def _make_slots(self):
     proto = self.model.engine
@@ -393,12 +404,16 @@ class DecodePipeline(object):
     return len(self.pending)
 
   def parts(self, B):
-    """How many slots a batch of B images takes."""
+    """How many slots a launch of B images takes."""
     return 1 if not self.max_images else max(1, -(-int(B) // int(self.max_images)))
 
   def full(self, B=None):
-    """No room for another batch (of B images; default: a batch that takes one slot)."""
-    return len(self.free) < (1 if B is None else self.parts(B))
+    """The next submit() (of a batch of B images; default: one that takes one slot) would have to launch, and there is no
+    slot for it: collect() / retire() first.  A batch that only joins the waiting group needs no slot."""
+    if len(self.group) + 1 < self.coalesce:
+      return False
+    waiting = sum(t['B'] for t in self.group)
+    return len(self.free) < self.parts(waiting + (B if B is not None else 1))
 
   def submit(self, outputs, feed, to_host=False):
     """Start decoding one batch (eval outputs only); returns immediately.  to_host: the outputs are also
@@ -415,15 +430,49 @@ class DecodePipeline(object):
     if nn._is_train(feed.get('phase_train', False)):
       raise RecAttendError('DecodePipeline decodes eval batches; training steps go through model.run')
     B = int(feed['x'].shape[0])
-    nparts = self.parts(B)
+    waiting = sum(t['B'] for t in self.group)
+    nparts = self.parts(waiting + B)
     if nparts > self.depth:
       raise RecAttendError('a batch of %d images needs %d slots of <= %d images; the pipeline has %d' %
-                           (B, nparts, self.max_images, self.depth))
+                           (waiting + B, nparts, self.max_images, self.depth))
+    launches = len(self.group) + 1 >= self.coalesce
+    if launches and nparts > len(self.free):
+      raise RecAttendError('%d of %d slots busy: collect() a batch before the next submit()' %
+                           (self.depth - len(self.free), self.depth))
+    if self.group and (self.group[0]['names'] != names or bool(self.group[0]['to_host']) != bool(to_host) or
+                       set(k for k, v in self.group[0]['feed'].items() if v is not None and k != 'phase_train') !=
+                       set(k for k, v in feed.items() if v is not None and k != 'phase_train')):
+      self._launch_group()  # company must want the same outputs from the same kind of feed
+    t = dict(names=names, single=single, feed=feed, to_host=to_host, B=B, launch=None, lo=0, hi=B)
+    self.group.append(t)
+    self.pending.append(t)
+    if len(self.group) >= self.coalesce:
+      self._launch_group()
+
+  def _launch_group(self):
+    """One forward over the images of the waiting batches, on the next free slot(s)."""
+    if not self.group:
+      return
+    members, self.group = self.group, []
+    if self.slots is None:
+      self._make_slots()
+    names, to_host = members[0]['names'], members[0]['to_host']
+    feeds = [m['feed'] for m in members]
+    as_dev = lambda v: v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    if len(members) == 1:
+      feed = feeds[0]
+    else:  # the engines copy their inputs into their own buffers anyway: one concatenation per fed tensor
+      feed = {}
+      for k in ('x', 'd_in', 'y_in', 'y_gt'):
+        if feeds[0].get(k) is not None:
+          feed[k] = torch.cat([as_dev(f[k]).to('cuda', non_blocking=True) for f in feeds], dim=0)
+      if feeds[0].get('noise') is not None:  # box_model: [T, B, H, W]
+        feed['noise'] = torch.cat([as_dev(f['noise']).to('cuda') for f in feeds], dim=1)
+    B = sum(m['B'] for m in members)
+    nparts = self.parts(B)
     if nparts > len(self.free):
       raise RecAttendError('%d of %d slots busy: collect() a batch before the next submit()' %
                            (self.depth - len(self.free), self.depth))
-    if self.slots is None:
-      self._make_slots()
     bounds = [(B * i) // nparts for i in range(nparts + 1)]
     cut = lambda v, lo, hi: None if v is None else v[lo:hi]
     used, events = [], []
@@ -446,52 +495,85 @@ class DecodePipeline(object):
         ev.record(stream)
       used.append(k)
       events.append((ev, host))
-    self.pending.append((used, names, single, events))
+    rec = dict(used=used, events=events, bounds=bounds, refs=len(members), names=names, res=None, checked=False)
+    lo = 0
+    for m in members:
+      m['launch'], m['lo'], m['hi'] = rec, lo, lo + m['B']
+      lo += m['B']
+      m['feed'] = None  # the engines hold their own copies
+
+  def _finish(self, rec):
+    """Wait for a launch; a starved controller is re-decoded (DecodeEngine.check_status) before anything is read."""
+    if rec['checked']:
+      return
+    for k, (ev, host) in zip(rec['used'], rec['events']):
+      eng, stream = self.slots[k]
+      ev.synchronize()
+      redone = eng.check_status()
+      if host is not None and redone:  # the pinned copies were taken from the starved forward: copy the re-decoded outputs over them
+        for h, n in zip(host, rec['names']):
+          h.copy_(self.model._fetch(n, eng))
+        torch.cuda.synchronize()
+    rec['checked'] = True
+
+  def _release(self, rec):
+    rec['refs'] -= 1
+    if rec['refs'] == 0:
+      self.free.extend(rec['used'])
+      rec['res'] = None
 
   def collect(self, as_numpy=False):
     """Results of the OLDEST batch in flight (blocks until it has finished), as model.run returns them."""
     if not self.pending:
       raise RecAttendError('collect() with no batch in flight')
-    used, names, single, events = self.pending.pop(0)
+    if self.pending[0]['launch'] is None:
+      self._launch_group()  # it was still waiting for company
+    t = self.pending.pop(0)
+    rec, names = t['launch'], t['names']
+    self._finish(rec)
+    whole = t['lo'] == 0 and t['hi'] == rec['bounds'][-1]
     parts = []
-    for k, (ev, host) in zip(used, events):
+    for (k, (ev, host)), plo, phi in zip(zip(rec['used'], rec['events']), rec['bounds'][:-1], rec['bounds'][1:]):
+      lo, hi = max(t['lo'], plo) - plo, min(t['hi'], phi) - plo
+      if hi <= lo:
+        continue
       eng, stream = self.slots[k]
-      ev.synchronize()
-      redone = eng.check_status()
+      sl = (lambda r: r) if (whole and len(rec['used']) == 1) else (lambda r: r[lo:hi])
       if host is not None:  # submit(to_host=True): already in pinned host memory
-        if redone:  # the pinned copies were taken from the starved forward: copy the re-decoded outputs over them
-          for h, n in zip(host, names):
-            h.copy_(self.model._fetch(n, eng))
-          torch.cuda.synchronize()
-        res = [h.numpy() for h in host]
+        res = [sl(h.numpy()) for h in host]
         as_numpy = True
       else:
         with torch.cuda.stream(stream):
-          res = [self.model._fetch(n, eng) for n in names]
+          res = [sl(self.model._fetch(n, eng)) for n in names]
           if as_numpy:
             res = [r.detach().cpu().numpy() for r in res]
+          elif rec['refs'] > 1 or not whole:
+            res = [r.clone() for r in res]  # a slice of a buffer the next launch of this slot overwrites
         stream.synchronize()
       parts.append(res)
-      self.free.append(k)
+    self._release(rec)
     if len(parts) == 1:
       res = parts[0]
     elif as_numpy:
       res = [np.concatenate(col, axis=0) for col in zip(*parts)]
     else:
       res = [torch.cat(col, dim=0) for col in zip(*parts)]
-    return res[0] if single else res
+    return res[0] if t['single'] else res
 
   def retire(self):
     """Wait for the OLDEST batch in flight and drop it without fetching (throughput measurement)."""
     if not self.pending:
       raise RecAttendError('retire() with no batch in flight')
-    used, _, _, events = self.pending.pop(0)
-    for ev, _ in events:
+    if self.pending[0]['launch'] is None:
+      self._launch_group()
+    t = self.pending.pop(0)
+    for ev, _ in t['launch']['events']:
       ev.synchronize()
-    self.free.extend(used)
+    self._release(t['launch'])
 
   def drain(self):
     """Wait for every batch in flight without fetching anything (throughput measurement)."""
+    self._launch_group()
     for _, stream in (self.slots or []):
       stream.synchronize()
     self.pending = []

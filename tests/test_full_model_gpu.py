@@ -391,13 +391,71 @@ def test_starved_split_controller_recovers_on_one_workgroup_form(cuda):
   torch.cuda.synchronize()
   e2 = pipe.slots[0][0]
   assert 'ctrl_ws' in e2.subs[0]
-  used, names, single, events = pipe.pending[0]
+  events = pipe.pending[0]['launch']['events']
   events[0][1][0].fill_(7.0)  # what a starved forward would have left in the pinned buffer
   e2.subs[0]['ctrl_status'].fill_(1)
   with warnings.catch_warnings(record=True):
     warnings.simplefilter('always')
     y3, s3 = pipe.collect()
   assert isinstance(y3, np.ndarray) and np.abs(y3 - good[0]).max() < 1e-4 and np.abs(s3 - good[1]).max() < 1e-4
+
+
+def test_decode_pipeline_coalesced_batches_match_lone_runs(cuda):
+  """DecodePipeline(coalesce=2) (round 5): two consecutively submitted batches are decoded by ONE slot as one forward over
+  their images, and collect() still returns them one at a time — each exactly what a lone model.run of that batch returns
+  (eval-mode images are independent).  Ragged batch sizes, an odd batch count (the last one is launched alone by collect()),
+  to_host, a change of the requested outputs inside a group, and parts (max_images) under coalescing."""
+  import full_model
+  opt = ora.make_opt('cvppp', 128, 160, 4)
+  P = ora.random_params(opt, 44)
+  m = full_model.get_model(opt).load_weights(P)
+  rng = np.random.RandomState(8)
+  sizes = [3, 2, 3, 3, 1, 3, 2]
+  feeds = [{'x': rng.rand(b, 128, 160, 3).astype(np.float32), 'phase_train': False} for b in sizes]
+  names = ['y_out', 's_out', 'x_patch']
+  lone = [m.run(names, f, as_numpy=True) for f in feeds]
+  for kw in (dict(), dict(to_host=True)):
+    pipe = m.pipeline(2, coalesce=2)
+    got = []
+    for f in feeds:
+      while pipe.full(f['x'].shape[0]):
+        got.append(pipe.collect(as_numpy=True))
+      pipe.submit(names, f, **kw)
+    assert len(pipe) == len(feeds) - len(got)
+    while len(pipe):
+      got.append(pipe.collect(as_numpy=True))
+    assert len(got) == len(lone) and sorted(pipe.free) == [0, 1] and not pipe.group
+    for a, b in zip(got, lone):
+      for u, v in zip(a, b):
+        assert u.shape == v.shape and np.abs(u - v).max() < 1e-6, np.abs(u - v).max()
+  # device tensors come back as copies: the slot's buffers are rewritten by its next launch
+  pipe = m.pipeline(1, coalesce=2)
+  pipe.submit('y_out', feeds[0])
+  pipe.submit('y_out', feeds[1])
+  y0 = pipe.collect()
+  y1 = pipe.collect()
+  pipe.submit('y_out', feeds[2])
+  pipe.submit('y_out', feeds[3])
+  pipe.drain()
+  assert np.abs(y0.cpu().numpy() - lone[0][0]).max() < 1e-6 and np.abs(y1.cpu().numpy() - lone[1][0]).max() < 1e-6
+  # another set of outputs closes the waiting group instead of joining it
+  pipe = m.pipeline(2, coalesce=2)
+  pipe.submit('y_out', feeds[0])
+  pipe.submit(['s_out'], feeds[1])
+  assert len(pipe.free) == 1 and len(pipe.group) == 1
+  a = pipe.collect(as_numpy=True)
+  b = pipe.collect(as_numpy=True)
+  assert np.abs(a - lone[0][0]).max() < 1e-6 and np.abs(b[0] - lone[1][1]).max() < 1e-6
+  # parts under coalescing: 3 + 3 images as three launches of 2
+  pipe = m.pipeline(3, max_images=2, coalesce=2)
+  pipe.submit(names, feeds[2])
+  pipe.submit(names, feeds[3])
+  assert len(pipe.free) == 0
+  for k in (2, 3):
+    r = pipe.collect(as_numpy=True)
+    for u, v in zip(r, lone[k]):
+      assert u.shape == v.shape and np.abs(u - v).max() < 1e-6
+  assert sorted(pipe.free) == [0, 1, 2]
 
 
 def test_decode_pipeline_matches_lone_run(cuda):
