@@ -28,6 +28,9 @@
 // stores — that the two workgroups of a CU pay in lockstep because every tile starts at once.
 #include "ra_common.h"
 
+#ifndef RA_PAIRW_SPLIT_OCC
+#define RA_PAIRW_SPLIT_OCC 3  // workgroups per CU of the fused L2+L3 pair's SPLIT form
+#endif
 namespace ra {
 namespace wino {
 
@@ -301,14 +304,36 @@ struct PWArgs {
   int xcd_map;
 };
 
-template <int TSY>
-__global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
+// SPLIT (round 5): layer A — the direct 8 -> 16 conv, 54 of the kernel's 86 MFMAs per wave and tile — on the BF16 matrix pipe at
+// float32 accuracy, as in conv_pair8_mfma's SPLIT form (ra_conv_pair.hip): the staged input window is kept as three bf16
+// tiles [pixel][8 channels] (the exact three-piece split of every float32 value, made once per staged element), a K = 32
+// block is four taps x 8 channels (three blocks for the nine taps), a lane's A operand of a block and piece is one
+// ds_read_b128, and six piece products per block replace eight float32 MFMAs.
+typedef short s16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+__device__ inline unsigned pk_bf16w(float lo, float hi) {
+  typedef __bf16 bf16x2c __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2c));
+}
+__device__ inline void split3_pairw(float a, float b, unsigned &H, unsigned &M, unsigned &L) {  // a = a_H + a_M + a_L exactly
+  H = pk_bf16w(a, b);
+  float ra = a - __builtin_bit_cast(float, H << 16), rb = b - __builtin_bit_cast(float, H & 0xffff0000u);
+  M = pk_bf16w(ra, rb);
+  ra -= __builtin_bit_cast(float, M << 16);
+  rb -= __builtin_bit_cast(float, M & 0xffff0000u);
+  L = pk_bf16w(ra, rb);
+}
+template <int TSY, bool SPLIT = false>
+__global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 2) void conv_pair_wino_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
   constexpr int CINA = 8, CMID = 16, KK = CMID / 4, S = CMID + 2, NMB = TSY / 4;
   constexpr int AWY = TSY + 2, IWY = TSY + 4, IWX = TS + 4;   // layer-A output window / input window (rows; 18 / 20 wide)
   constexpr int NPA = AWY * WS, NGA = (NPA + 15) / 16, GPW = (NGA + 3) / 4;
   constexpr int NPI = IWY * IWX, NIT = (NPI * 2 + 255) / 256;  // input items: (pixel, half of its 8 channels)
   constexpr int TEXP = 20;                   // exchange stride per tile for 16 output channels: 16 * ksub banks apart
-  constexpr int R0 = NPI * CINA > 8 * 16 * TEXP ? NPI * CINA : 8 * 16 * TEXP;
+  constexpr int PLB = NPI * 16;              // SPLIT: bytes of one bf16 input tile [pixel][8]
+  constexpr int INF = SPLIT ? 3 * PLB / 4 : NPI * CINA;  // floats of the staged input
+  constexpr int R0 = INF > 8 * 16 * TEXP ? INF : 8 * 16 * TEXP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tinp = lds;                         // [IWY][IWX][8]   records [ksub][cg]  (channel = 4 * cg + ksub)
   float *tex = lds;                          // [4 p][2 j][16 tiles][TEXP]: phase B only, when tinp is dead
@@ -320,11 +345,31 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
   const int per = tiles_x * tiles_y;
 
   // layer A: direct-form B operands (9 taps x 2 channel groups) and epilogue constants of column m
-  float bA[9][2];
+  float bA[SPLIT ? 1 : 9][2];
+  s16x8w wA[SPLIT ? 3 : 1][SPLIT ? 3 : 1];  // SPLIT: block blk, k-slot j = input channel j of tap 4 blk + ksub, column m, three pieces
+  if constexpr (SPLIT) {
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+    for (int blk = 0; blk < 3; ++blk) {
+      const int tap = 4 * blk + ksub;
+      const bool ok = tap < 9;
+      const int tp = ok ? tap : 0;
 #pragma unroll
-    for (int cg = 0; cg < 2; ++cg) bA[tap][cg] = a.wpA[(size_t)((tap * 2 + cg) * 4 + ksub) * a.CoutAP + m];
+      for (int j = 0; j < 8; j += 2) {
+        const float w0 = a.wpA[(size_t)((tp * 2 + (j >> 2)) * 4 + (j & 3)) * a.CoutAP + m];
+        const float w1 = a.wpA[(size_t)((tp * 2 + ((j + 1) >> 2)) * 4 + ((j + 1) & 3)) * a.CoutAP + m];
+        unsigned H, M, L;
+        split3_pairw(ok ? w0 : 0.f, ok ? w1 : 0.f, H, M, L);
+        wA[blk][0][j] = (short)(H & 0xffffu), wA[blk][0][j + 1] = (short)(H >> 16);
+        wA[blk][1][j] = (short)(M & 0xffffu), wA[blk][1][j + 1] = (short)(M >> 16);
+        wA[blk][2][j] = (short)(L & 0xffffu), wA[blk][2][j + 1] = (short)(L >> 16);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) bA[tap][cg] = a.wpA[(size_t)((tap * 2 + cg) * 4 + ksub) * a.CoutAP + m];
+  }
   const float scA = a.scA[m], shA = a.shA[m];
   const float loA = a.reluA ? 0.f : -__builtin_inff();
   // layer B: this wave's row p of the transformed filters (one block of 16 output channels)
@@ -348,7 +393,7 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
     int li = 16 * (p + 4 * s) + m;
     if (li >= NPA) li = NPA - 1;  // padding rows of the last group repeat a real pixel; their results go to the slack
     const int r = li / WS, c = li - r * WS;
-    ain[s] = (r * IWX + c) * CINA + 2 * ksub;
+    ain[s] = SPLIT ? (r * IWX + c) * 16 : (r * IWX + c) * CINA + 2 * ksub;  // SPLIT: byte offset of the pixel's 16-byte record
   }
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
@@ -377,6 +422,18 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int e = tid + 256 * i, cg = e & 1, pix = e >> 1;
+      if constexpr (SPLIT) {
+        unsigned H0, M0, L0, H1, M1, L1;  // channels 4 cg .. 4 cg + 3 of the pixel: 8 bytes of its record in each of the three tiles
+        split3_pairw(pre[i].x, pre[i].y, H0, M0, L0);
+        split3_pairw(pre[i].z, pre[i].w, H1, M1, L1);
+        if (e < NPI * 2) {
+          unsigned char *rec = reinterpret_cast<unsigned char *>(tinp) + pix * 16 + cg * 8;
+          *reinterpret_cast<u32x2w *>(rec) = u32x2w{H0, H1};
+          *reinterpret_cast<u32x2w *>(rec + PLB) = u32x2w{M0, M1};
+          *reinterpret_cast<u32x2w *>(rec + 2 * PLB) = u32x2w{L0, L1};
+        }
+        continue;
+      }
       if (e < NPI * 2) {
         float *rec = tinp + pix * CINA + cg;
 #pragma unroll
@@ -393,6 +450,24 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
       f32x4 acc[GPW];
 #pragma unroll
       for (int s = 0; s < GPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (SPLIT) {
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(tinp);
+        const int t0 = ksub, t1 = 4 + ksub, t2 = 8;  // this lane's tap of the three blocks (block 2: tap 8; its other k-slots carry zero weights)
+        const int toff[3] = {((t0 / 3) * IWX + t0 % 3) * 16, ((t1 / 3) * IWX + t1 % 3) * 16, ((t2 / 3) * IWX + t2 % 3) * 16};
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // six piece products, smallest first
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+          for (int s = 0; s < GPW; ++s) {
+            s16x8w av[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) av[pc] = *reinterpret_cast<const s16x8w *>(tb + ain[s] + toff[blk] + pc * PLB);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+              acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, av[PA[t]]), __builtin_bit_cast(bf16x8w, wA[blk][PB[t]]),
+                                                               acc[s], 0, 0, 0);
+          }
+      } else {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         f32x2 av[GPW];
@@ -403,6 +478,7 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
         for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
           for (int s = 0; s < GPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[tap][cg], acc[s], 0, 0, 0);
+      }
       }
 #pragma unroll
       for (int s = 0; s < GPW; ++s) {
@@ -473,10 +549,11 @@ __global__ __launch_bounds__(256, TSY == 8 ? 4 : 2) void conv_pair_wino_mfma(con
   }
 }
 
-template <int TSY>
+template <int TSY, bool SPLIT = false>
 int launch_pair(const PWArgs &a, hipStream_t st) {
-  auto kern = conv_pair_wino_mfma<TSY>;
-  constexpr int r0 = (TSY + 4) * (TS + 4) * 8 > 8 * 16 * 20 ? (TSY + 4) * (TS + 4) * 8 : 8 * 16 * 20;
+  auto kern = conv_pair_wino_mfma<TSY, SPLIT>;
+  constexpr int inf = SPLIT ? 3 * (TSY + 4) * (TS + 4) * 4 : (TSY + 4) * (TS + 4) * 8;
+  constexpr int r0 = inf > 8 * 16 * 20 ? inf : 8 * 16 * 20;
   constexpr size_t lds = (size_t)(r0 + ((TSY + 2) * WS + 16) * 18) * sizeof(float);
   static bool attr = false;
   static int cap = 0;
@@ -604,5 +681,11 @@ extern "C" int ra_conv_pair_wino_f32(const float *x, int B, int H, int W, const 
     const char *e = getenv("RA_PAIRW_TSY");
     tsy = (e && atoi(e) == 16) ? 16 : 8;  // 8-row tiles: 128 VGPRs and 24 KB of LDS, 4 workgroups per CU (39.1 vs 42.5 us)
   }
+  static int split = -1;  // RA_PAIRW_SPLIT=0: layer A on the float32 MFMA (rounds 2-4)
+  if (split < 0) {
+    const char *e = getenv("RA_PAIRW_SPLIT");
+    split = e ? atoi(e) : 1;
+  }
+  if (split && tsy == 8) return wino::launch_pair<8, true>(a, as_stream(stream));
   return tsy == 8 ? wino::launch_pair<8>(a, as_stream(stream)) : wino::launch_pair<16>(a, as_stream(stream));
 }
