@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 110
+#define RA_ABI_VERSION 111
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -169,6 +169,18 @@ int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsam
                      const float *wpA, const float *scaleA, const float *shiftA, int CoutA, int reluA,
                      const float *wpB, const float *scaleB, const float *shiftB, int CoutB, int reluB,
                      int poolB, const float *plane, int plane_chan, float *y, void *stream);
+
+/* K1s (round 5) — the same layer (conv3x3 SAME + folded BatchNorm + ReLU + max-pool, nnlib.py:229-253) as a DIRECT convolution
+ * on the BF16 matrix pipe at float32 accuracy: every float32 operand is the exact sum of three bf16 pieces, and six of the
+ * nine piece products (everything above 2^-24 of a product) run as v_mfma_f32_16x16x32_bf16 with float32 accumulation
+ * (csrc/ra_conv_split.hip).  Cin in {16, 32}, Cout % 32 == 0, pool 1 | 2, H and W multiples of 16
+ * (ra_conv_split_supported).  wpacked: ra_conv_split_packed_halfs() 16-bit words, the filter's three bf16 pieces in B-operand
+ * order, from the reference's [3,3,Cin,Cout] filter by ra_conv_split_pack_weights (host).  scale / shift as ra_conv3x3_f32. */
+int ra_conv_split_supported(int Cin, int Cout, int pool, int H, int W);
+size_t ra_conv_split_packed_halfs(int Cin, int Cout);
+int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, unsigned short *out);
+int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, const unsigned short *wpacked, const float *scale,
+                      const float *shift, int Cout, int relu, int pool, float *y, void *stream);
 
 /* K1w: conv3x3 SAME + folded BN + ReLU + optional 2x2 max-pool (nnlib.py:229-253) as Winograd F(2x2, 3x3)
  * on the f32 MFMA: 2.25x fewer matrix multiplies than ra_conv3x3_f32 for the same layer, results equal

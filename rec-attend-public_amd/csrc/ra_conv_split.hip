@@ -1,0 +1,332 @@
+// K1s — direct 3x3 convolution on the BF16 matrix pipe at float32 accuracy (round 5), for the mid-resolution layers of the
+// controller CNN (nnlib.cnn: conv3x3 SAME + b -> BatchNorm(eval, folded) -> ReLU -> max-pool, nnlib.py:229-253).
+//
+// Why: gfx950's bf16 MFMA does 16x the float32 MFMA's FLOPs per cycle, and a float32 value is EXACTLY the sum of three bf16
+// pieces (8 + 8 + 8 mantissa bits).  Products of bf16 numbers are exact in float32, and of the nine piece products of a * b
+// six carry everything above 2^-24 of it (hh, hm, mh, hl, lh, mm), so six v_mfma_f32_16x16x32_bf16 per K = 32 block compute
+// what eight v_mfma_f32_16x16x4_f32 compute, in 41 ns of a SIMD instead of 108 (tools/mfma_split_probe.hip,
+// profiles/r05_mfma_split_probe.txt; K = 576 dot products: 1.9e-7 of sum |a b| against 2.3e-7 for the float32 chain).  At that
+// rate the DIRECT form's nine taps cost less matrix time than Winograd F(2x2,3x3)'s four products on the float32 pipe
+// (9 / 2.67 = 3.4 against 4), without the transform adds, the LDS exchange and the two barriers per row block of K1w.
+//
+// Layout: a workgroup owns a 16 x 16 output tile (pre-pool) and 16 NB output channels (NB = 2; grid.y = cout slices).
+//   * the input window (18 x 18 pixels x Cin) is split ONCE per element on its way into LDS: three bf16 tiles
+//     [pixel][Cin], pixel stride 2 Cin + 16 bytes, row stride 20 pixels — with 4 x 4-pixel MFMA row groups the 16 lanes of a
+//     ds_read_b128 then hit 16 different bank quads;
+//   * the filter's three pieces, pre-split on the host in B-operand order, stay in LDS for the launch; a wave reads the
+//     3 NB operand vectors of a K-block once and uses them for its four pixel groups;
+//   * a K = 32 block is one tap x 32 channels (Cin = 16: two taps x 16); a lane's A operand of a block and piece is the 8
+//     consecutive channels of its pixel: ONE ds_read_b128; 3 reads feed 6 NB MFMAs;
+//   * MFMA rows m = 4 q + r = element r (dy, dx) of pooling window q of a 4 x 4-pixel group, so a lane's four accumulators
+//     are one 2x2 pooling window: pool = three v_max (as K1's non-SWAP form);
+//   * persistent workgroups; the next tile's window is fetched into registers behind the MFMA loop.
+// Results differ from K1 / K1w by summation order and the dropped 2^-24 terms only (tests/test_kernels_gpu.py).
+#include <cstring>
+
+#include "ra_common.h"
+
+namespace ra {
+namespace csplit {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 16, TW = 16;            // output tile (conv resolution)
+constexpr int WSY = TH + 2, WSX = TW + 2;  // staged window
+constexpr int WSP = 20;                    // LDS row stride in pixels (bank spread, see above)
+constexpr int NB = 2;                      // blocks of 16 output channels per workgroup
+
+struct SArgs {
+  const float *x;
+  const unsigned short *wp;
+  const float *scale, *shift;
+  float *y;
+  int B, H, W, Cout, relu;
+  int bytes_x, bytes_y;
+};
+
+template <int CIN>
+struct Geo {
+  static constexpr int NBLK = CIN >= 32 ? 9 * (CIN / 32) : 5;  // K = 32 blocks: tap x 32 channels; Cin = 16: two taps x 16
+  static constexpr int RS = 2 * CIN + 16;                      // bytes per staged pixel record
+  static constexpr int PLANE = WSY * WSP * RS;                 // bytes of one bf16 tile
+  static constexpr int WBYTES = NBLK * 3 * NB * 1024;          // one cout slice of the packed filter: [blk][piece][nb][kb][n][8] bf16
+  static constexpr int LDS = 3 * PLANE + WBYTES;
+};
+
+__device__ inline unsigned pk_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2c __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2c));
+}
+// (a, b) -> packed bf16 pairs H, M, L with a = a_H + a_M + a_L exactly (each difference is exact in float32)
+__device__ inline void split3_pair(float a, float b, unsigned &H, unsigned &M, unsigned &L) {
+  H = pk_bf16(a, b);
+  float ra = a - __builtin_bit_cast(float, H << 16), rb = b - __builtin_bit_cast(float, H & 0xffff0000u);
+  M = pk_bf16(ra, rb);
+  ra -= __builtin_bit_cast(float, M << 16);
+  rb -= __builtin_bit_cast(float, M & 0xffff0000u);
+  L = pk_bf16(ra, rb);
+}
+
+template <int CIN, int POOL>
+__global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int tiles_x, int tiles_y, int ntiles) {
+  using G = Geo<CIN>;
+  constexpr int RS = G::RS, PLANE = G::PLANE, NBLK = G::NBLK, C4 = CIN / 4;
+  constexpr int NITEMS = WSY * WSX * C4, NIT = (NITEMS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *tin = lds;               // three bf16 tiles [WSY][WSP][RS]
+  unsigned char *wl = lds + 3 * PLANE;    // the slice's filter pieces
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kb = lane >> 4;  // A side: row m, k-group kb;  B / D side: column n = m, D rows 4 kb + r
+  const int slice = blockIdx.y;
+
+  // A-operand byte offsets: the lane's pixel inside a 4 x 4 group (row m = 4 q + r: window q = (qy, qx), element r = (dy, dx))
+  // and, per K-block, its tap and channel octet
+  const int qy = m >> 3, qx = (m >> 2) & 1, dy = (m >> 1) & 1, dx = m & 1;
+  const int lane_pix = ((2 * qy + dy) * WSP + 2 * qx + dx) * RS;
+  int toff[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    int tap, ch;
+    if constexpr (CIN >= 32) {
+      tap = b / (CIN / 32);
+      ch = 32 * (b % (CIN / 32)) + 8 * kb;
+    } else {
+      tap = 2 * b + (kb >> 1);
+      tap = tap < 9 ? tap : 8;  // the tenth "tap" of the last block carries zero weights: any staged pixel will do
+      ch = 8 * (kb & 1);
+    }
+    toff[b] = ((tap / 3) * WSP + tap % 3) * RS + 2 * ch;
+  }
+  const int woff = (kb * 16 + m) * 16;
+  float sc[NB], sh[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    sc[nb] = a.scale[16 * (NB * slice + nb) + m];
+    sh[nb] = a.shift[16 * (NB * slice + nb) + m];
+  }
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  const int Ho = a.H / POOL, Wo = a.W / POOL;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.bytes_x, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes_y, 0x00020000);
+  const int per = tiles_x * tiles_y;
+
+  // staging items: (window pixel, channel quad); position inside the window is tile-invariant
+  int it_off[NIT], it_r[NIT], it_c[NIT], it_lds[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int e = tid + 256 * i;
+    const int c4 = e % C4, pix = e / C4;
+    it_r[i] = pix / WSX;
+    it_c[i] = pix - it_r[i] * WSX;
+    it_off[i] = ((it_r[i] * a.W + it_c[i]) * CIN + 4 * c4) * 4;
+    it_lds[i] = (it_r[i] * WSP + it_c[i]) * RS + 8 * c4;
+    if (e >= NITEMS) it_r[i] = -(1 << 20);  // never inside the image, never stored
+  }
+  f32x4 pre[NIT];
+  auto fetch = [&](int T) {
+    const int fb = T / per, fr = T - fb * per;
+    const int fy0 = (fr / tiles_x) * TH - 1, fx0 = (fr % tiles_x) * TW - 1;
+    const int base = ((fb * a.H + fy0) * a.W + fx0) * CIN * 4;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int Y = fy0 + it_r[i], X = fx0 + it_c[i];
+      const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+      pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? base + it_off[i] : 0x7fffffff, 0, 0));
+    }
+  };
+
+  {  // the filter: a straight 16-byte copy, once per workgroup (issued BEFORE the first window's loads: the other order — the
+     // window in flight across the copy — measured 0.5 us slower at cfg2's L5 / L6)
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(a.wp) + (size_t)slice * G::WBYTES);
+    for (int e = tid; e < G::WBYTES / 16; e += 256) reinterpret_cast<u32x4 *>(wl)[e] = src[e];
+  }
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / per, trem = tile - b * per;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    __syncthreads();  // the previous tile's operand reads are complete (and, first time round, the filter copy is issued)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      unsigned H0, M0, L0, H1, M1, L1;
+      split3_pair(pre[i].x, pre[i].y, H0, M0, L0);
+      split3_pair(pre[i].z, pre[i].w, H1, M1, L1);
+      if (it_r[i] >= 0) {
+        unsigned char *rec = tin + it_lds[i];
+        *reinterpret_cast<u32x2 *>(rec) = u32x2{H0, H1};
+        *reinterpret_cast<u32x2 *>(rec + PLANE) = u32x2{M0, M1};
+        *reinterpret_cast<u32x2 *>(rec + 2 * PLANE) = u32x2{L0, L1};
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight across the MFMA loop
+
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wave_pix = 4 * wave * WSP * RS + lane_pix;  // this wave's row of 4 x 4-pixel groups
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // six piece products per block, smallest first
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+      s16x8 wv[3][NB];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wv[pc][nb] = *reinterpret_cast<const s16x8 *>(wl + ((blk * 3 + pc) * NB + nb) * 1024 + woff);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s16x8 av[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) av[pc] = *reinterpret_cast<const s16x8 *>(tin + pc * PLANE + wave_pix + 4 * g * RS + toff[blk]);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[PA[t]]), __builtin_bit_cast(bf16x8, wv[PB[t]][nb]),
+                                                                 acc[g][nb], 0, 0, 0);
+      }
+    }
+    // epilogue: lane (column n = m, D rows 4 kb + r) holds the four elements r = (dy, dx) of pooling window kb = (wy, wx) of group g
+    const int wy = kb >> 1, wx = kb & 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int co = 16 * (NB * slice + nb) + m;
+        const f32x4 v = acc[g][nb] * sc[nb] + sh[nb];
+        if constexpr (POOL == 2) {
+          const float o = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), lo);
+          const int oy = ty * (TH / 2) + 2 * wave + wy, ox = tx * (TW / 2) + 2 * g + wx;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry, (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int oy = ty * TH + 4 * wave + 2 * wy + (r >> 1), ox = tx * TW + 4 * g + 2 * wx + (r & 1);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[r], lo)), ry,
+                                                  (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
+          }
+        }
+      }
+  }
+}
+
+inline int cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+template <int CIN, int POOL>
+int launch(const SArgs &a, hipStream_t st) {
+  auto kern = conv_split_kernel<CIN, POOL>;
+  constexpr int lds = Geo<CIN>::LDS;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / (16 * NB);
+  int gx = cu_count() / slices;  // one workgroup per CU (141 KB of LDS at Cin = 32)
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  return launch_status("ra_conv_split_f32");
+}
+
+inline unsigned short bf16_rne_host(float v) {
+  unsigned u;
+  memcpy(&u, &v, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+inline float bf16_to_float_host(unsigned short h) {
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+}  // namespace csplit
+}  // namespace ra
+
+using namespace ra;
+
+extern "C" int ra_conv_split_supported(int Cin, int Cout, int pool, int H, int W) {
+  return (Cin == 16 || Cin == 32) && Cout > 0 && Cout % (16 * csplit::NB) == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
+         H % csplit::TH == 0 && W % csplit::TW == 0;
+}
+
+extern "C" size_t ra_conv_split_packed_halfs(int Cin, int Cout) {
+  if (!(Cin == 16 || Cin == 32) || Cout <= 0 || Cout % (16 * csplit::NB)) return 0;
+  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5;
+  return (size_t)(Cout / (16 * csplit::NB)) * nblk * 3 * csplit::NB * 512;
+}
+
+// w: the reference's [3,3,Cin,Cout] filter (host) -> out[slice][blk][piece][nb][kb][n][8] bf16: the exact three-piece split of
+// W[tap][ci][cout] with (tap, ci) = K-slot (blk, kb, j) and cout = 16 (NB slice + nb) + n; slots beyond the nine taps are zero.
+extern "C" int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, unsigned short *out) {
+  const size_t n = ra_conv_split_packed_halfs(Cin, Cout);
+  if (!w || !out || !n) return fail(RA_E_SHAPE, "ra_conv_split_pack_weights: Cin=%d Cout=%d", Cin, Cout);
+  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, slices = Cout / (16 * csplit::NB);
+  for (int s = 0; s < slices; ++s)
+    for (int b = 0; b < nblk; ++b)
+      for (int nb = 0; nb < csplit::NB; ++nb)
+        for (int kb = 0; kb < 4; ++kb)
+          for (int nn = 0; nn < 16; ++nn)
+            for (int j = 0; j < 8; ++j) {
+              int tap, ci;
+              if (Cin >= 32) {
+                tap = b / (Cin / 32);
+                ci = 32 * (b % (Cin / 32)) + 8 * kb + j;
+              } else {
+                tap = 2 * b + (kb >> 1);
+                ci = 8 * (kb & 1) + j;
+              }
+              const int co = 16 * (csplit::NB * s + nb) + nn;
+              float v = tap < 9 ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
+              for (int pc = 0; pc < 3; ++pc) {
+                const unsigned short h = csplit::bf16_rne_host(v);
+                out[(((((size_t)s * nblk + b) * 3 + pc) * csplit::NB + nb) * 4 + kb) * 128 + nn * 8 + j] = h;
+                v -= csplit::bf16_to_float_host(h);
+              }
+            }
+  return 0;
+}
+
+extern "C" int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, const unsigned short *wpacked, const float *scale,
+                                 const float *shift, int Cout, int relu, int pool, float *y, void *stream) {
+  if (!x || !wpacked || !scale || !shift || !y || B <= 0) return fail(RA_E_INVALID, "ra_conv_split_f32: bad argument");
+  if (!ra_conv_split_supported(Cin, Cout, pool, H, W))
+    return fail(RA_E_SHAPE, "ra_conv_split_f32: Cin=%d Cout=%d pool=%d %dx%d", Cin, Cout, pool, H, W);
+  const size_t bx = (size_t)B * H * W * Cin * 4, by = (size_t)B * (H / pool) * (W / pool) * Cout * 4;
+  if (bx >= (1ull << 31) || by >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_split_f32: a tensor exceeds 2 GiB");
+  csplit::SArgs a;
+  a.x = x;
+  a.wp = wpacked;
+  a.scale = scale;
+  a.shift = shift;
+  a.y = y;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.Cout = Cout;
+  a.relu = relu;
+  a.bytes_x = (int)bx;
+  a.bytes_y = (int)by;
+  hipStream_t st = as_stream(stream);
+  if (Cin == 16) return pool == 2 ? csplit::launch<16, 2>(a, st) : csplit::launch<16, 1>(a, st);
+  return pool == 2 ? csplit::launch<32, 2>(a, st) : csplit::launch<32, 1>(a, st);
+}

@@ -55,6 +55,7 @@ class DecodeEngine(object):
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.prefill_ride = True  # the once-per-forward y_out prefill rides on the first controller-CNN launch
+    self.use_split = os.environ.get('RA_USE_SPLIT', '1') != '0'  # K1s: the mid-resolution controller-CNN layers as direct convs on the bf16 matrix pipe at float32 accuracy
     # extract + attention-CNN layer 0 as one launch (ra_extract_conv0_f32, round 5): built, parity-tested and MEASURED SLOWER than
     # the two launches it replaces (11.8 vs 7.1 + 3.5 us at cfg2, profiles/r05_attn_fusion_probe.txt) — off; RA_FUSE_EXTRACT_CONV0=1 runs it
     self.fuse_extract_conv0 = os.environ.get('RA_FUSE_EXTRACT_CONV0', '0') == '1'
@@ -104,7 +105,7 @@ class DecodeEngine(object):
     W = {}
     cmap_c, n_c = self._chan_map(d['ctrl_in'])
     assert n_c == d['ccnn_channels'][0]
-    W['ccnn'], W['ccnn_wino'] = [], []
+    W['ccnn'], W['ccnn_wino'], W['ccnn_split'] = [], [], []
     hh, ww = d['H'], d['W']
     for i in range(d['ccnn_nlayers']):
       cin, cout = d['ccnn_channels'][i], d['ccnn_channels'][i + 1]
@@ -117,6 +118,9 @@ class DecodeEngine(object):
       # mid-resolution layers also as Winograd F(2x2,3x3) filters (K1w: 2.25x fewer MFMAs), where the shape allows
       wino = i > 0 and self.use_wino and ops.conv_wino_supported(cin, cout, d['ccnn_pool'][i], hh, ww)
       W['ccnn_wino'].append(_dev(ops.pack_wino_weights(M['ctrl_cnn_w_%d' % i]), device) if wino else None)
+      # ... and as the exact three-piece bf16 split of the filter, for the direct form on the bf16 matrix pipe (K1s, round 5)
+      split = i > 0 and self.use_split and cin >= 32 and ops.conv_split_supported(cin, cout, d['ccnn_pool'][i], hh, ww)  # Cin = 16 (L4): no faster than K1w
+      W['ccnn_split'].append(torch.from_numpy(ops.pack_split_weights(M['ctrl_cnn_w_%d' % i])).to(device) if split else None)
       hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
     Cf = d['ccnn_channels'][-1]
     self.desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
@@ -519,7 +523,10 @@ class DecodeEngine(object):
         i = step[1]
         wp, sc, sh, cout, pool = layers[i]
         wino = self.W['ccnn_wino'][i] if (layers is self.W.get('ccnn') and pl is None and self.use_wino) else None
-        if wino is not None:
+        split = self.W['ccnn_split'][i] if (layers is self.W.get('ccnn') and pl is None and self.use_split) else None
+        if split is not None:
+          ops.conv_split(src, split, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i])
+        elif wino is not None:
           ops.conv_wino(src, wino, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i])
         else:
           ops.conv3x3(src, wp, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i], plane=pl,

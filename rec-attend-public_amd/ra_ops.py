@@ -210,6 +210,34 @@ def pack_wino_weights(w):
   return out
 
 
+def conv_split_supported(cin, cout, pool, H, W):
+  return bool(rn.lib().ra_conv_split_supported(int(cin), int(cout), int(pool), int(H), int(W)))
+
+
+def pack_split_weights(w):
+  """TF-layout [3,3,Cin,Cout] filter -> its exact three-piece bf16 split in K1s's B-operand order (numpy, host; bf16 pairs in float32 words)."""
+  w = _np32(w)
+  cin, cout = w.shape[2], w.shape[3]
+  n = rn.lib().ra_conv_split_packed_halfs(cin, cout)
+  if w.shape[0] != 3 or w.shape[1] != 3 or n == 0:
+    raise rn.RecAttendError('unsupported split-precision conv shape %r' % (w.shape,))
+  out = np.empty(n, dtype=np.int16)
+  check(rn.lib().ra_conv_split_pack_weights(ptr(w), cin, cout, ptr(out)), 'ra_conv_split_pack_weights')
+  return out.view(np.float32)  # carried as a float32 tensor like every other packed filter (two bf16 pieces per word)
+
+
+def conv_split(x, wp, scale, shift, cout, relu=True, pool=1, out=None):
+  """conv3x3 SAME + folded BN + ReLU + pool as a direct convolution on the bf16 matrix pipe at float32 accuracy
+  (ra_conv_split_f32: three bf16 pieces per operand, six piece products).  x [B,H,W,Cin]."""
+  _need_cuda(x, wp, scale, shift, out)
+  B, H, W, cin = x.shape
+  if out is None:
+    out = torch.empty((B, H // pool, W // pool, cout), dtype=torch.float32, device=x.device)
+  check(rn.lib().ra_conv_split_f32(ptr(x), B, H, W, cin, ptr(wp), ptr(scale), ptr(shift), int(cout), int(relu), int(pool),
+                                   ptr(out), rn.stream_ptr()), 'ra_conv_split_f32')
+  return out
+
+
 def conv_wino(x, wp, scale, shift, cout, relu=True, pool=1, out=None):
   """conv3x3 SAME + folded BN + ReLU + pool as Winograd F(2x2,3x3) (ra_conv_wino_f32).  x [B,H,W,Cin]."""
   _need_cuda(x, wp, scale, shift, out)

@@ -407,6 +407,35 @@ def test_dense_attention_operators(cuda, H, W, big):
   assert np.abs(pd.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('B,H,W,Ci,Co,pool,relu', [(2, 32, 48, 16, 32, 1, True), (1, 64, 32, 32, 32, 2, True), (3, 16, 16, 32, 64, 2, True),
+                                                    (2, 48, 32, 16, 64, 2, False), (8, 128, 128, 32, 32, 2, True)])
+def test_conv_split_precision(cuda, B, H, W, Ci, Co, pool, relu):
+  """K1s (ra_conv_split_f32, round 5): the direct 3x3 layer on the bf16 matrix pipe — every operand the exact sum of three bf16
+  pieces, six of the nine piece products — against the float64 oracle at the float32 kernels' bar (2e-5 of the output scale),
+  with operands of mixed magnitude (the dropped piece products are below 2^-24 of a product whatever the exponents), and
+  against K1 on the same inputs."""
+  rng = np.random.RandomState(B * 100 + H + Ci + Co)
+  x = (rng.randn(B, H, W, Ci) * np.exp(rng.uniform(-3, 3, (B, H, W, Ci)))).astype(np.float32)
+  w = (rng.randn(3, 3, Ci, Co) / np.sqrt(9 * Ci)).astype(np.float32)
+  b = (rng.randn(Co) * 0.1).astype(np.float32)
+  bn = (rng.randn(Co).astype(np.float32) * 0.1, rng.uniform(0.5, 1.5, Co).astype(np.float32), rng.randn(Co).astype(np.float32) * 0.1,
+        rng.uniform(0.5, 1.5, Co).astype(np.float32))
+  sc, sh = ops.fold_bn(b, Co, bn)
+  ref = (ora.conv2d(x.astype(np.float64), w.astype(np.float64))) * sc[:Co].astype(np.float64) + sh[:Co].astype(np.float64)
+  if relu:
+    ref = ora.relu(ref)
+  if pool == 2:
+    ref = ora.max_pool(ref, 2)
+  assert ops.conv_split_supported(Ci, Co, pool, H, W) and not ops.conv_split_supported(8, Co, pool, H, W)
+  wp = torch.from_numpy(ops.pack_split_weights(w)).to(cuda)
+  y = ops.conv_split(dev(x, cuda), wp, dev(sc, cuda), dev(sh, cuda), Co, relu=relu, pool=pool)
+  y1 = ops.conv3x3(dev(x, cuda), dev(ops.pack_conv_weights(w), cuda), dev(sc, cuda), dev(sh, cuda), Co, relu=relu, pool=pool)
+  torch.cuda.synchronize()
+  assert y.shape == ref.shape
+  e_split, e_k1 = relerr(y.cpu().numpy(), ref), relerr(y1.cpu().numpy(), ref)
+  assert e_split < 2e-5 and e_split < 4 * e_k1 + 1e-7, (e_split, e_k1)
+
+
 @pytest.mark.parametrize('H,W,big,cout,F', [(128, 128, False, 8, 48), (96, 160, True, 8, 48), (512, 512, False, 8, 48),
                                              (64, 96, False, 16, 48), (128, 128, True, 12, 32)])
 def test_extract_fused_with_first_attention_cnn_layer(cuda, H, W, big, cout, F):
