@@ -93,7 +93,7 @@ def seed_weights(model, seed):
   model['ctrl_mlp_b_0'].copy_(b)
 
 
-ROUNDS = ('r04', 'r03', 'r02', 'r01')
+ROUNDS = ('r05', 'r04', 'r03', 'r02', 'r01')
 
 
 def pmc_traffic(images, size, name='r03_pmc_encoder_traffic.json', want_source=False):
@@ -130,8 +130,8 @@ def mfma_busy():
     path = os.path.join(ROOT, 'profiles', rnd + '_pmc_sq_mfma_per_kernel.csv')
     if not os.path.exists(path):
       continue
-    rows = [r for r in csv.DictReader(open(path)) if any(k in r['kernel'] for k in ('ra::cpair::', 'ra::wino::', 'ra::conv::conv3x3_mfma<16, 1, 4, 2, 1, false'))
-            and 'conv_pair8_mfma<4, false>' not in r['kernel']]
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r['kernel'] for k in ('ra::cpair::', 'ra::wino::', 'ra::csplit::', 'ra::conv::conv3x3_mfma<16, 1, 4, 2, 1, false'))
+            and 'conv_pair8_mfma<4, false' not in r['kernel']]
     if not rows:
       continue
     base = min(int(r['dispatches']) for r in rows)

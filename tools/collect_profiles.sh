@@ -6,7 +6,7 @@
 # profiles/ by hand.  Every command runs under `timeout`.
 set -u
 OUT=gpurun_out/${1:-prof}
-R3=${2:-r04}
+R3=${2:-r05}
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
