@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 111
+#define RA_ABI_VERSION 112
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -569,6 +569,14 @@ int ra_postprocess_f32(const float *y_out, const float *s_out, int B, int T, int
                        float thresh, const float *fg, float *y_bin, float *s_hard,
                        float *union_out, void *stream);
 int ra_union_f32(const float *y, int B, int T, int HW, float *union_out, void *stream);
+/* The evaluator's cv2 steps as plain kernels on N = B*T planes (full_model_eval.py:112-118):
+ * ra_dilate_f32 — morph_single (postprocess.py:63-72): cv2.dilate(plane, ones(2 radius + 1)^2), out-of-image pixels ignored.
+ * ra_resize_linear_f32 + ra_bilateral5_f32 — upsample_single (postprocess.py:93-106): cv2.resize(..., INTER_LINEAR) (pixel
+ *   centres aligned, float32 two-tap weights) and cv2.bilateralFilter(b, 5, sigma_color, sigma_space) (circular radius-2
+ *   neighbourhood, BORDER_REFLECT_101, the exact exponential where cv2 interpolates a table).  out != y. */
+int ra_dilate_f32(const float *y, int N, int H, int W, int radius, float *out, void *stream);
+int ra_resize_linear_f32(const float *y, int N, int Hs, int Ws, int H, int W, float *out, void *stream);
+int ra_bilateral5_f32(const float *y, int N, int H, int W, float sigma_color, float sigma_space, float *out, void *stream);
 int ra_remove_tiny_f32(float *y_bin, const float *sizes, float *conf, int B, int T, int HW,
                        float threshold, void *stream);
 int ra_eval_metrics_f32(const float *inter, const float *sum_a, const float *sum_b,

@@ -461,6 +461,54 @@ def pp_apply_threshold(y_out, thresh):
   return (y_out > thresh).astype('float32')
 
 
+def pp_morph(y_out):
+  """postprocess.py:55-72: cv2.dilate(plane, ones((5, 5))) — the maximum over the 5 x 5 window, pixels outside the image
+  ignored (cv2's default border value for a dilation).  cv2 itself is not part of this stack: restated from its documented
+  behaviour."""
+  H, W = y_out.shape[-2:]
+  pad = np.pad(y_out, [(0, 0)] * (y_out.ndim - 2) + [(2, 2), (2, 2)], constant_values=-np.inf)
+  out = np.full(y_out.shape, -np.inf)
+  for dy in range(5):
+    for dx in range(5):
+      out = np.maximum(out, pad[..., dy:dy + H, dx:dx + W])
+  return out
+
+
+def pp_upsample(y_out, H, W, sigma_color=10.0, sigma_space=10.0):
+  """postprocess.py:75-106: cv2.resize(a, (W, H), INTER_LINEAR) (pixel centres aligned: source coordinate
+  (d + 0.5) * src / dst - 0.5 clamped to the image) then cv2.bilateralFilter(b, 5, 10, 10) (circular radius-2 neighbourhood,
+  BORDER_REFLECT_101; the exact exponentials).  Unpinned: cv2 is not part of this stack."""
+  Hs, Ws = y_out.shape[-2:]
+
+  def taps(n_src, n_dst):
+    f = (np.arange(n_dst) + 0.5) * (n_src / n_dst) - 0.5
+    i0 = np.floor(f).astype(int)
+    w = f - i0
+    lo = i0 < 0
+    hi = i0 >= n_src - 1
+    i0 = np.clip(i0, 0, n_src - 1)
+    w = np.where(lo | hi, 0.0, w)
+    return i0, np.minimum(i0 + 1, n_src - 1), w
+  y0, y1, wy = taps(Hs, H)
+  x0, x1, wx = taps(Ws, W)
+  a = y_out.astype(np.float64)
+  top = a[..., y0, :][..., :, x0] * (1 - wx) + a[..., y0, :][..., :, x1] * wx
+  bot = a[..., y1, :][..., :, x0] * (1 - wx) + a[..., y1, :][..., :, x1] * wx
+  b = top * (1 - wy)[:, None] + bot * wy[:, None]
+  ref = lambda i, n: np.abs(i) if n == 1 else (lambda j: np.where(j >= n, 2 * (n - 1) - j, j))(np.abs(i))
+  num, den = np.zeros_like(b), np.zeros_like(b)
+  rr, cc = np.arange(H), np.arange(W)
+  for dy in range(-2, 3):
+    for dx in range(-2, 3):
+      if dy * dy + dx * dx > 4:
+        continue
+      v = b[..., ref(rr + dy, H), :][..., :, ref(cc + dx, W)]
+      wgt = np.exp(-(dy * dy + dx * dx) / (2 * sigma_space ** 2) - (v - b) ** 2 / (2 * sigma_color ** 2))
+      num += wgt * v
+      den += wgt
+  return num / den
+
+
 def pp_remove_tiny(y_out, conf, threshold=200):
   """postprocess.py:109-136."""
   if threshold == 0:

@@ -68,6 +68,78 @@ __global__ __launch_bounds__(256) void union_kernel(const float *y, int T, int H
   *reinterpret_cast<f32x4 *>(uni + (size_t)b * HW + e) = m;
 }
 
+// morph_single (postprocess.py:63-72): cv2.dilate(plane, ones(5, 5)) = the maximum over the 5 x 5 window around every pixel,
+// border pixels outside the image ignored (cv2's default border value for a dilation behaves as -inf).  One thread per
+// pixel; the window's 25 loads hit L1 / L2 (the planes are small next to the caches).
+__global__ __launch_bounds__(256) void dilate_kernel(const float *y, int H, int W, int R, float *out) {
+  const int n = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= H * W) return;
+  const int r = e / W, c = e - r * W;
+  const float *p = y + (size_t)n * H * W;
+  float m = -__builtin_inff();
+  for (int dy = -R; dy <= R; ++dy) {
+    const int yy = r + dy;
+    if (yy < 0 || yy >= H) continue;
+    for (int dx = -R; dx <= R; ++dx) {
+      const int xx = c + dx;
+      if (xx >= 0 && xx < W) m = fmaxf(m, p[yy * W + xx]);
+    }
+  }
+  out[(size_t)n * H * W + e] = m;
+}
+
+// upsample_single (postprocess.py:93-106): cv2.resize(a, (W, H), INTER_LINEAR) then cv2.bilateralFilter(b, 5, 10, 10).
+//   resize: pixel centres aligned — source coordinate (d + 0.5) * (src / dst) - 0.5, clamped to the image, two-tap linear
+//   weights in float32 (cv2's float path; its 8-bit path uses fixed-point coefficients);
+//   bilateral: d = 5 -> radius 2, the CIRCULAR neighbourhood dy^2 + dx^2 <= 4 (13 pixels), weight
+//   exp(-(dy^2 + dx^2) / (2 * 10^2)) * exp(-(v - v0)^2 / (2 * 10^2)), borders reflected without the edge pixel
+//   (BORDER_REFLECT_101).  cv2 evaluates the colour weight from an interpolated table; this is the formula the table
+//   approximates (the two cannot be compared here: cv2 is not part of this stack).
+__global__ __launch_bounds__(256) void resize_linear_kernel(const float *y, int Hs, int Ws, int H, int W, float *out) {
+  const int n = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= H * W) return;
+  const int r = e / W, c = e - r * W;
+  const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+  float fy = ((float)r + 0.5f) * sy - 0.5f, fx = ((float)c + 0.5f) * sx - 0.5f;
+  int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+  fy -= (float)y0;
+  fx -= (float)x0;
+  if (y0 < 0) y0 = 0, fy = 0.f;
+  if (y0 >= Hs - 1) y0 = Hs - 1, fy = 0.f;
+  if (x0 < 0) x0 = 0, fx = 0.f;
+  if (x0 >= Ws - 1) x0 = Ws - 1, fx = 0.f;
+  const int y1 = y0 + 1 < Hs ? y0 + 1 : y0, x1 = x0 + 1 < Ws ? x0 + 1 : x0;
+  const float *p = y + (size_t)n * Hs * Ws;
+  const float top = p[y0 * Ws + x0] * (1.f - fx) + p[y0 * Ws + x1] * fx;
+  const float bot = p[y1 * Ws + x0] * (1.f - fx) + p[y1 * Ws + x1] * fx;
+  out[(size_t)n * H * W + e] = top * (1.f - fy) + bot * fy;
+}
+__device__ inline int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+__global__ __launch_bounds__(256) void bilateral5_kernel(const float *y, int H, int W, float sigma_color, float sigma_space, float *out) {
+  const int n = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= H * W) return;
+  const int r = e / W, c = e - r * W;
+  const float *p = y + (size_t)n * H * W;
+  const float v0 = p[e], gc = -0.5f / (sigma_color * sigma_color), gs = -0.5f / (sigma_space * sigma_space);
+  float num = 0.f, den = 0.f;
+  for (int dy = -2; dy <= 2; ++dy)
+    for (int dx = -2; dx <= 2; ++dx) {
+      if (dy * dy + dx * dx > 4) continue;
+      const float v = p[reflect101(r + dy, H) * W + reflect101(c + dx, W)];
+      const float w = expf((float)(dy * dy + dx * dx) * gs + (v - v0) * (v - v0) * gc);
+      num += w * v;
+      den += w;
+    }
+  out[(size_t)n * H * W + e] = num / den;
+}
+
 // remove_tiny_single (postprocess.py:126-136): planes of at most `threshold` pixels vanish
 __global__ __launch_bounds__(256) void remove_tiny_kernel(float *y_bin, const float *sizes, float *conf, int HW,
                                                            float threshold) {
@@ -202,6 +274,26 @@ extern "C" int ra_union_f32(const float *y, int B, int T, int HW, float *union_o
   hipLaunchKernelGGL(eval::union_kernel, dim3(ceil_div(HW, 1024), B), dim3(256), 0, as_stream(stream), y, T, HW,
                      union_out);
   return launch_status("ra_union_f32");
+}
+
+extern "C" int ra_dilate_f32(const float *y, int N, int H, int W, int radius, float *out, void *stream) {
+  if (!y || !out || y == out || N <= 0 || H <= 0 || W <= 0 || radius < 0 || radius > 16) return fail(RA_E_INVALID, "ra_dilate_f32: bad argument");
+  hipLaunchKernelGGL(eval::dilate_kernel, dim3(ceil_div(H * W, 256), N), dim3(256), 0, as_stream(stream), y, H, W, radius, out);
+  return launch_status("ra_dilate_f32");
+}
+
+extern "C" int ra_resize_linear_f32(const float *y, int N, int Hs, int Ws, int H, int W, float *out, void *stream) {
+  if (!y || !out || N <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return fail(RA_E_INVALID, "ra_resize_linear_f32: bad argument");
+  hipLaunchKernelGGL(eval::resize_linear_kernel, dim3(ceil_div(H * W, 256), N), dim3(256), 0, as_stream(stream), y, Hs, Ws, H, W, out);
+  return launch_status("ra_resize_linear_f32");
+}
+
+extern "C" int ra_bilateral5_f32(const float *y, int N, int H, int W, float sigma_color, float sigma_space, float *out, void *stream) {
+  if (!y || !out || y == out || N <= 0 || H <= 0 || W <= 0 || !(sigma_color > 0.f) || !(sigma_space > 0.f))
+    return fail(RA_E_INVALID, "ra_bilateral5_f32: bad argument");
+  hipLaunchKernelGGL(eval::bilateral5_kernel, dim3(ceil_div(H * W, 256), N), dim3(256), 0, as_stream(stream), y, H, W, sigma_color,
+                     sigma_space, out);
+  return launch_status("ra_bilateral5_f32");
 }
 
 extern "C" int ra_remove_tiny_f32(float *y_bin, const float *sizes, float *conf, int B, int T, int HW,

@@ -12,7 +12,8 @@ reference's write_log chain (full_model_eval.py:97-139) runs on the device for e
 --threshold_list (default 0.3, the reference CLI's default, :193-194): apply_confidence, apply_one_label,
 apply_threshold [, mask_foreground, remove_tiny] and the --analyzers (default list :201-205);
 the per-threshold means go to <output>/output_<split>/metrics_rank<r>.yaml.  The cv2 steps
-(upsample + bilateral filter, morph) are skipped: evaluation is at the network resolution."""
+(upsample + bilateral filter, morph) run as device kernels since round 5 (utils/postprocess.py): the resize when the labels'
+size differs from the network's, the dilation when a foreground mask is given and --no_morph is not."""
 import argparse
 import os
 import time
@@ -87,8 +88,26 @@ def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, anal
       gt = torch.as_tensor(np.asarray(data['y_gt'][b0:b1], dtype=np.float32)).to(dev)
       sg = torch.as_tensor(np.asarray(data['s_gt'][b0:b1], dtype=np.float32)).to(dev)
       fg = torch.as_tensor(np.asarray(data['fg'][b0:b1], dtype=np.float32)).to(dev) if 'fg' in data else None
+      # the reference's chain (full_model_eval.py:112-124): apply_confidence -> upsample to the labels' size -> [foreground given:
+      # morph unless --no_morph] -> apply_one_label -> per threshold: apply_threshold [-> mask_foreground -> remove_tiny].  Without
+      # a resize and a dilation it collapses into ONE fused pass (pp.postprocess)
+      resize = tuple(gt.shape[-2:]) != tuple(y_dev.shape[-2:])
+      dilate = fg is not None and not args.no_morph
+      if resize or dilate:
+        s2 = s_dev[:, :, 0].contiguous() if s_dev.dim() == 3 else s_dev   # multi-class: :108-110
+        yc, s_conf = pp.apply_confidence(y_dev, s2)
+        if resize:
+          yc = pp.upsample(yc, gt)
+        if dilate:
+          yc = pp.morph(yc)
+        one = pp.apply_one_label(yc)
       for th in thresholds:
-        y_bin, s_hard, _ = pp.postprocess(y_dev, s_dev, th, fg=fg, remove_tiny_threshold=args.remove_tiny)
+        if resize or dilate:
+          y_bin, s_hard = pp.apply_threshold(one, th), s_conf
+          if fg is not None:
+            y_bin, s_hard = pp.remove_tiny(pp.mask_foreground(y_bin, fg), s_hard, threshold=args.remove_tiny)
+        else:
+          y_bin, s_hard, _ = pp.postprocess(y_dev, s_dev, th, fg=fg, remove_tiny_threshold=args.remove_tiny)
         results = {'y_out': y_bin, 'y_gt': gt, 's_out': s_hard, 's_gt': sg}
         for n in names:
           acc[th][n].append(analysis.create_analyzer(n)(results).cpu().numpy())

@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 111  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 112  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -114,6 +114,9 @@ SIGNATURES = {
     'ra_loss_stats_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _Z, _P, _P]),
     'ra_postprocess_f32': (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     'ra_union_f32': (_I, [_P, _I, _I, _I, _P, _P]),
+    'ra_dilate_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    'ra_resize_linear_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'ra_bilateral5_f32': (_I, [_P, _I, _I, _I, _F, _F, _P, _P]),
     'ra_remove_tiny_f32': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     'ra_eval_metrics_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     'ra_random_transform_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

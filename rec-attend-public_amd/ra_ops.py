@@ -705,6 +705,38 @@ def union_over_instances(y):
   return out
 
 
+def dilate(y, radius=2):
+  """cv2.dilate(plane, ones((2 radius + 1,) * 2)) on every [H,W] plane of y [..., H, W] (postprocess.py:63-72)."""
+  y = y.contiguous()
+  _need_cuda(y)
+  H, W = y.shape[-2:]
+  out = torch.empty_like(y)
+  check(rn.lib().ra_dilate_f32(ptr(y), y.numel() // (H * W), H, W, int(radius), ptr(out), rn.stream_ptr()), 'ra_dilate_f32')
+  return out
+
+
+def resize_linear(y, H, W):
+  """cv2.resize(plane, (W, H), interpolation=INTER_LINEAR) on every plane of y [..., Hs, Ws] (postprocess.py:103-104)."""
+  y = y.contiguous()
+  _need_cuda(y)
+  Hs, Ws = y.shape[-2:]
+  out = torch.empty(y.shape[:-2] + (int(H), int(W)), dtype=torch.float32, device=y.device)
+  check(rn.lib().ra_resize_linear_f32(ptr(y), y.numel() // (Hs * Ws), Hs, Ws, int(H), int(W), ptr(out), rn.stream_ptr()),
+        'ra_resize_linear_f32')
+  return out
+
+
+def bilateral5(y, sigma_color=10.0, sigma_space=10.0):
+  """cv2.bilateralFilter(plane, 5, sigma_color, sigma_space) on every plane of y [..., H, W] (postprocess.py:105)."""
+  y = y.contiguous()
+  _need_cuda(y)
+  H, W = y.shape[-2:]
+  out = torch.empty_like(y)
+  check(rn.lib().ra_bilateral5_f32(ptr(y), y.numel() // (H * W), H, W, C.c_float(sigma_color), C.c_float(sigma_space), ptr(out),
+                                   rn.stream_ptr()), 'ra_bilateral5_f32')
+  return out
+
+
 def remove_tiny(y_bin, sizes, conf, threshold):
   """In place: instance planes of at most `threshold` pixels are zeroed, their conf too."""
   _need_cuda(y_bin, sizes, conf)

@@ -39,12 +39,17 @@ def remove_tiny(y_out, conf, threshold=200):
 
 
 def morph(y_out):
-  raise NotImplementedError('morph (postprocess.py:55-72) needs cv2.dilate; not built (SURVEY.md §8f rank 4)')
+  """postprocess.py:55-72: cv2.dilate of every instance plane with a 5 x 5 box (out-of-image pixels ignored)."""
+  return ops.dilate(y_out, 2)
 
 
 def upsample(y_out, y_gt):
-  raise NotImplementedError('upsample (postprocess.py:75-106) needs cv2.resize + bilateralFilter; not built '
-                            '(SURVEY.md §8f rank 4); evaluate at the network resolution')
+  """postprocess.py:75-106: every plane of y_out [B,T,H',W'] resized to y_gt's [H,W] (cv2.resize, INTER_LINEAR) and passed
+  through cv2.bilateralFilter(b, 5, 10, 10).  The resize is cv2's float32 arithmetic; the bilateral filter evaluates the
+  exponentials cv2 reads from an interpolated table (cv2 is not part of this stack, so the two have not been compared: the
+  step is optional in the evaluator and off by default)."""
+  H, W = (y_gt.shape[-2], y_gt.shape[-1]) if hasattr(y_gt, 'shape') else (int(y_gt[0]), int(y_gt[1]))
+  return ops.bilateral5(ops.resize_linear(y_out, H, W), 10.0, 10.0)
 
 
 def postprocess(y_out, s_out, thresh, fg=None, remove_tiny_threshold=0):

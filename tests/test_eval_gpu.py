@@ -65,8 +65,13 @@ def test_postprocess(cuda, B, T, H, W, thresh, use_fg, tiny):
   assert (rt_y.cpu().numpy() == o_y).all() and (rt_s.cpu().numpy() == o_s).all()
   if fg is not None:
     assert (pp.mask_foreground(thr, dev(fg, cuda)).cpu().numpy() == thr.cpu().numpy() * fg[:, None]).all()
-  with pytest.raises(NotImplementedError):
-    pp.upsample(thr, thr)
+  # the evaluator's cv2 steps (postprocess.py:55-106; round 5): 5 x 5 dilation — exact — and linear resize + bilateral filter
+  mo = pp.morph(thr)
+  assert (mo.cpu().numpy() == ora.pp_morph(thr.cpu().numpy().astype(np.float64))).all()
+  soft = yc[:, :, ::2, ::2].contiguous()
+  up = pp.upsample(soft, thr)
+  assert tuple(up.shape) == tuple(thr.shape)
+  assert np.abs(up.cpu().numpy() - ora.pp_upsample(soft.cpu().numpy(), thr.shape[2], thr.shape[3])).max() < 2e-6
 
 
 @pytest.mark.parametrize('B,T,H,W', [(3, 8, 64, 64), (2, 16, 48, 80), (2, 21, 32, 32)])
