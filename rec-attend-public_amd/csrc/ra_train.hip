@@ -1642,6 +1642,155 @@ __global__ __launch_bounds__(256) void wgrad8_kernel(const float *x, const float
     dstp[e] = (red[e] + red[e + 10 * 16 * CP]) + (red[e + 2 * 10 * 16 * CP] + red[e + 3 * 10 * 16 * CP]);
 }
 
+// ... and in the bf16 mode's stacked step (round 5: x of the 8 -> 8 layer and every dU are STORED as bf16, the first layer's x is
+// the float32 packed image): wgrad8b_kernel.  The bf16-operand wgrad_kernel these launches took stages float32 tiles through
+// registers and ran at 242 us (8 -> 8, 43 images) / 397 us (4 -> 8, 64 images) — the 4 -> 8 one slower than the float32 mode's
+// wgrad8_kernel.  Same scheme as wgrad8_kernel — both tiles HBM -> LDS directly (16 bytes per pixel each: 8 bf16 channels, or
+// the 4 float32 channels of the image), double-buffered, one barrier per tile, M rows = (tap, ci) pairs + the bias row — on
+// v_mfma_f32_16x16x32_bf16 with K = the 32 pixels of one tile row: a lane's operand is 8 consecutive pixels of ONE channel,
+// gathered from the pixel-major tile by 8 ds_read_b32 and 4 v_perm_b32 (bf16 tiles: the low or high half of each word) or 4
+// v_cvt_pk_bf16_f32 (the float32 image: rounded to nearest even, as every bf16 operand of this mode).  5 (3) MFMAs per 32
+// pixels instead of 40 (24) float32 ones, half the tile bytes.  Partial records as wgrad_kernel writes them.
+typedef short s16x8t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+template <int CIN>  // 8: x stored as bf16 (16 bytes per pixel); 4: x float32 (the packed image, 16 bytes per pixel)
+__global__ __launch_bounds__(256) void wgrad8b_kernel(const void *x, const void *du, int B, int Hs, int Ws, int H, int W, int tiles_x,
+                                                      int tiles_y, int ntiles, float *part, const void *const *xtab,
+                                                      const void *const *dutab, int Bseg, int CP) {
+  constexpr int NR = 9 * CIN + 1, NT = (NR + 15) / 16;
+  constexpr int NIX = WLH * WLW, NIU = WTH * WTW;            // 16-byte items: one per pixel in both tiles
+  constexpr int XB = (NIX + 63) / 64 * 1024, UB = NIU * 16;  // bytes of one x / dU tile in LDS (whole 64-lane pieces)
+  constexpr int NITX = (NIX + 255) / 256, NITU = NIU / 256;
+  constexpr int kOOB = 0x7fffffff;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];  // [2][XB + UB], then reused for the reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kb = lane >> 4;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // row R = 16 t + n of tile t: (tap, ci) -> byte offset of (pixel 8 kb of the row, channel ci) inside the x tile, and whether
+  // the bf16 element is the high half of its word
+  int aoff[NT];
+  unsigned asel[NT];
+  bool abias[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int R = 16 * t + n, Rc = R < 9 * CIN ? R : 0, tap = Rc / CIN, ci = Rc - tap * CIN;
+    const int pix = (tap / 3) * WLW + tap % 3 + 8 * kb;
+    aoff[t] = CIN == 8 ? pix * 16 + (ci >> 1) * 4 : pix * 16 + ci * 4;
+    asel[t] = (ci & 1) ? 0x07060302u : 0x05040100u;  // v_perm_b32(hi word, lo word): the two high / the two low halves
+    abias[t] = R == 9 * CIN;
+  }
+  const int co = n & 7;
+  const int boff = 8 * kb * 16 + (co >> 1) * 4;
+  const unsigned bsel = (co & 1) ? 0x07060302u : 0x05040100u;
+  const int per = tiles_x * tiles_y;
+  const size_t seg_imgs = xtab ? (size_t)Bseg : (size_t)B;
+  const int bytes_x = (int)(seg_imgs * Hs * Ws * 16), bytes_u = (int)(seg_imgs * H * W * 16);
+  auto load_tile = [&](int tile, int buf) {
+    int b = tile / per;
+    const int tr = tile - b * per;
+    const void *xb = x, *ub = du;
+    if (xtab) {
+      const int seg = b / Bseg;
+      xb = xtab[seg];
+      ub = dutab[seg];
+      b -= seg * Bseg;
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(xb), 0, bytes_x, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ub), 0, bytes_u, 0x00020000);
+    const int ty0 = (tr / tiles_x) * WTH, tx0 = (tr % tiles_x) * WTW;
+    unsigned char *dst = ldsb + buf * (XB + UB);
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      if (256 * it + 64 * wave >= NIX) continue;  // wave-uniform
+      const int e = tid + 256 * it;
+      const int r = e / WLW, c = e - r * WLW;
+      const int Y = ty0 + r - 1, X = tx0 + c - 1;
+      const bool ok = (e < NIX) & ((unsigned)Y < (unsigned)H) & ((unsigned)X < (unsigned)W);
+      const int off = ok ? ((b * Hs + Y) * Ws + X) * 16 : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void *)(dst + (256 * it + 64 * wave) * 16), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NITU; ++it) {
+      const int e = tid + 256 * it;
+      const int r = e / WTW, c = e - r * WTW;
+      const int Y = ty0 + r, X = tx0 + c;
+      const bool ok = (Y < H) & (X < W);
+      const int off = ok ? ((b * H + Y) * W + X) * 16 : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void *)(dst + XB + (256 * it + 64 * wave) * 16), 16, off, 0, 0, 0);
+    }
+  };
+  int buf = 0;
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x, 0);
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool has_next = tile + (int)gridDim.x < ntiles;
+    if (has_next) load_tile(tile + gridDim.x, buf ^ 1);  // in flight across the MFMAs; the barrier below waits for it
+    const unsigned char *xs = ldsb + buf * (XB + UB);
+    const unsigned char *us = xs + XB;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {  // this wave's rows 2 wave, 2 wave + 1: K = the row's 32 pixels
+      const int row = wave * 2 + g;
+      unsigned bw[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bw[j] = *reinterpret_cast<const unsigned *>(us + (row * WTW + j) * 16 + boff);
+      u32x4t bv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = __builtin_amdgcn_perm(bw[2 * j + 1], bw[2 * j], bsel);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        u32x4t av;
+        if constexpr (CIN == 8) {
+          unsigned aw[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) aw[j] = *reinterpret_cast<const unsigned *>(xs + (row * WLW + j) * 16 + aoff[t]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) av[j] = __builtin_amdgcn_perm(aw[2 * j + 1], aw[2 * j], asel[t]);
+        } else {
+          float af[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) af[j] = *reinterpret_cast<const float *>(xs + (row * WLW + j) * 16 + aoff[t]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            typedef float f32x2c __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2c __attribute__((ext_vector_type(2)));
+            av[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2c{af[2 * j], af[2 * j + 1]}, bf16x2c));
+          }
+        }
+        if (t == NT - 1 && abias[t]) av = u32x4t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};  // the bias row: A = 1
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8t, av), __builtin_bit_cast(bf16x8t, bv), acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // the next tile has landed (vmcnt(0)) and every wave is done reading this one
+    buf ^= 1;
+  }
+  float *red = reinterpret_cast<float *>(ldsb);  // [wave][tap (9 = bias)][16][CP]
+  for (int e = tid; e < 4 * 10 * 16 * CP; e += 256) red[e] = 0.f;
+  __syncthreads();
+  float *mine = red + wave * (10 * 16 * CP);
+  if (n < 8) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int R = 16 * t + 4 * kb + r;
+        int slot = -1;
+        if (R < 9 * CIN) {
+          const int tap = R / CIN;
+          slot = tap * 16 + (R - tap * CIN);
+        } else if (R == 9 * CIN) {
+          slot = 9 * 16;
+        }
+        if (slot >= 0) mine[slot * CP + n] = acc[t][r];
+      }
+  }
+  __syncthreads();
+  float *dstp = part + (size_t)blockIdx.x * (10 * 16 * CP);
+  for (int e = tid; e < 10 * 16 * CP; e += 256)
+    dstp[e] = (red[e] + red[e + 10 * 16 * CP]) + (red[e + 2 * 10 * 16 * CP] + red[e + 3 * 10 * 16 * CP]);
+}
+
 // dW[tap][ci][co] (= TF [3,3,Cin,Cout]) and db[co] from the partials, fixed order.
 __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *part, int nwg, int nchunks, int CP, int Cin, int Cout,
                                                           float *dw, float *db) {  // CP = couts per slice
@@ -1890,7 +2039,20 @@ int wgrad_impl(const float *x, int Cin, int B, int Hs, int Ws, int upsample, con
     t8_ok = e ? atoi(e) : 1;
   }
   const size_t seg_bytes = (size_t)(xtab ? Bseg : B) * H * W * 8 * 4;  // the larger of the two tensors of a segment
-  if (small && t8_ok && seg_bytes < (1ull << 31) && Hs == H && Ws == W) {
+  // bf16 mode, stacked step: dU stored as bf16 and x either stored as bf16 (8 channels) or the float32 packed image (4 channels)
+  const bool small_b = small_ok && t8_ok && bf16 && !ups && Cout == 8 && (fmt & 2) &&
+                       ((Cin == 8 && (fmt & 1)) || (Cin == 4 && !(fmt & 1))) && seg_bytes < (1ull << 31) && Hs == H && Ws == W;
+  if (small_b) {
+    const size_t lds_s = 2 * (size_t)(((WLH * WLW + 63) / 64) * 1024 + WTH * WTW * 16);
+    const size_t lds_8 = lds_s > 4 * lds_red ? lds_s : 4 * lds_red;
+    const void *const *xt = reinterpret_cast<const void *const *>(xtab), *const *ut = reinterpret_cast<const void *const *>(dutab);
+    if (Cin == 4)
+      hipLaunchKernelGGL(wgrad8b_kernel<4>, dim3(gx), dim3(256), lds_8, st, (const void *)x, (const void *)du, B, Hs, Ws, H, W, tiles_x, tiles_y,
+                         ntiles, ws, xt, ut, Bseg, per);
+    else
+      hipLaunchKernelGGL(wgrad8b_kernel<8>, dim3(gx), dim3(256), lds_8, st, (const void *)x, (const void *)du, B, Hs, Ws, H, W, tiles_x, tiles_y,
+                         ntiles, ws, xt, ut, Bseg, per);
+  } else if (small && t8_ok && seg_bytes < (1ull << 31) && Hs == H && Ws == W) {
     const size_t lds_s = 2 * (size_t)(((WLH * WLW * (Cin / 4) + 63) / 64) * 1024 + WTH * WTW * 32);
     const size_t lds_8 = lds_s > 4 * lds_red ? lds_s : 4 * lds_red;
     if (Cin == 4)

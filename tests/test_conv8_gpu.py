@@ -188,3 +188,38 @@ def test_full_resolution_layer_gradient_pin(cuda):
   print('8->8 layer at 512x512, B=8: dW %.1e dgamma %.1e dbeta %.1e | dx L2 %.1e, outliers %.1e' % (
       errs['dw'], errs['dgamma'], errs['dbeta'], l2, frac))
   assert l2 < 1e-4 and frac < 1e-5, (l2, frac)
+
+
+@pytest.mark.parametrize('cin', [4, 8])
+@pytest.mark.parametrize('table', [False, True])
+def test_wgrad8_bf16_storage_vs_float64(cuda, cin, table):
+  """wgrad8b_kernel (round 5): the bf16 mode's filter gradient of the two full-resolution layers — dU stored as bf16, x stored as
+  bf16 (8 -> 8) or the float32 packed image (4 -> 8, rounded to bf16 as an operand) — on v_mfma_f32_16x16x32_bf16 with K = 32
+  pixels, through ra_conv3x3_wgrad_acc_bf16_f32 and, with `table`, the stacked step's pointer-table call.  Against a float64
+  correlation of the SAME bf16 values (products of bf16 numbers are exact in float32: the bar is the float32 one), ragged shape,
+  sums ADDED to non-zero gw / gb."""
+  rng = np.random.RandomState(40 + cin + table)
+  nseg, Bseg, H, W, cout = (3, 2, 45, 70, 8) if table else (1, 3, 77, 150, 8)
+  x32 = [torch.tensor(rng.randn(Bseg, H, W, cin).astype(np.float32), device=cuda) for _ in range(nseg)]
+  xb = [t.to(torch.bfloat16) for t in x32]
+  du = [torch.tensor(rng.randn(Bseg, H, W, cout).astype(np.float32), device=cuda).to(torch.bfloat16) for _ in range(nseg)]
+  xs = xb if cin == 8 else x32        # 8 -> 8: the stored bf16 activation; 4 -> 8: the float32 image
+  fmt = (1 if cin == 8 else 0) | 2    # bit 0: x stored as bf16, bit 1: dU stored as bf16
+  lib = rn.lib()
+  nws = lib.ra_conv3x3_wgrad_workspace_floats(cin, cout, nseg * Bseg, H, W)
+  ws = torch.full((nws,), float('nan'), device=cuda)
+  g0w, g0b = rng.randn(3, 3, cin, cout).astype(np.float32), rng.randn(cout).astype(np.float32)
+  gw, gb = torch.tensor(g0w, device=cuda), torch.tensor(g0b, device=cuda)
+  if table:
+    tab = torch.zeros(128, dtype=torch.int64, device=cuda)
+    for off, ts in ((0, xs), (64, du)):
+      host = (C.c_void_p * nseg)(*[t.data_ptr() for t in ts])
+      rn.check(lib.ra_ptr_table(host, nseg, tab.data_ptr() + 8 * off, rn.stream_ptr()), 'ptr_table')
+    rn.check(lib.ra_conv3x3_wgrad_multi_acc_f32(tab.data_ptr(), tab.data_ptr() + 8 * 64, nseg, cin, Bseg, H, W, 0, cout, rn.ptr(ws), nws,
+                                                None, cin, 0, rn.ptr(gw), rn.ptr(gb), 1 | (fmt << 1), rn.stream_ptr()), 'wgrad_multi')
+  else:
+    rn.check(lib.ra_conv3x3_wgrad_acc_bf16_f32(rn.ptr(xs[0]), cin, Bseg, H, W, 0, rn.ptr(du[0]), cout, rn.ptr(ws), nws, None, cin, 0,
+                                               rn.ptr(gw), rn.ptr(gb), fmt, rn.stream_ptr()), 'wgrad_bf16')
+  rw, rb = _wgrad_ref(torch.cat([t.float() for t in xb]), torch.cat([t.float() for t in du]))
+  rw, rb = rw + torch.tensor(g0w, device=cuda).double(), rb + torch.tensor(g0b, device=cuda).double()
+  assert _rel(gw, rw) < 2e-5 and _rel(gb, rb) < 2e-5, (_rel(gw, rw), _rel(gb, rb))
