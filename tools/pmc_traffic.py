@@ -25,7 +25,7 @@ def build_stamp():
           'librecattend_sha16': sha(os.path.join(ROOT, 'rec-attend-public_amd', 'librecattend.so'))}
 
 
-KEYS = ['ra::conv::', 'ra::cpair::', 'ra::wino::']
+KEYS = ['ra::conv::', 'ra::cpair::', 'ra::wino::', 'ra::csplit::']
 
 
 def tail_sum(path, counter, reps):
