@@ -38,7 +38,7 @@ extern "C" {
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
  * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
  * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
-#define RA_ABI_VERSION 112
+#define RA_ABI_VERSION 113
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *ra_last_error_string(void);
@@ -173,12 +173,16 @@ int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsam
 /* K1s (round 5) — the same layer (conv3x3 SAME + folded BatchNorm + ReLU + max-pool, nnlib.py:229-253) as a DIRECT convolution
  * on the BF16 matrix pipe at float32 accuracy: every float32 operand is the exact sum of three bf16 pieces, and six of the
  * nine piece products (everything above 2^-24 of a product) run as v_mfma_f32_16x16x32_bf16 with float32 accumulation
- * (csrc/ra_conv_split.hip).  Cin in {16, 32}, Cout % 32 == 0, pool 1 | 2, H and W multiples of 16
+ * (csrc/ra_conv_split.hip).  Cin in {16, 32}, Cout % 16 == 0, pool 1 | 2, H and W multiples of 16
  * (ra_conv_split_supported).  wpacked: ra_conv_split_packed_halfs() 16-bit words, the filter's three bf16 pieces in B-operand
- * order, from the reference's [3,3,Cin,Cout] filter by ra_conv_split_pack_weights (host).  scale / shift as ra_conv3x3_f32. */
+ * order, from the reference's [3,3,Cin,Cout] filter by ra_conv_split_pack_weights (host) or ra_conv_split_pack_weights_dev
+ * (device pointers; transposed != 0: w is a conv2d_transpose filter [3,3,Cout,Cin] — taps flipped, in / out swapped, as
+ * RA_CONV_TRANSPOSED: the packing of a cnn layer's DATA GRADIENT, which the training step runs as this conv with scale 1,
+ * shift 0).  scale / shift as ra_conv3x3_f32. */
 int ra_conv_split_supported(int Cin, int Cout, int pool, int H, int W);
 size_t ra_conv_split_packed_halfs(int Cin, int Cout);
 int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, unsigned short *out);
+int ra_conv_split_pack_weights_dev(const float *w, int Cin, int Cout, int transposed, unsigned short *out, void *stream);
 int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, const unsigned short *wpacked, const float *scale,
                       const float *shift, int Cout, int relu, int pool, float *y, void *stream);
 

@@ -38,7 +38,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TH = 16, TW = 16;            // output tile (conv resolution)
 constexpr int WSY = TH + 2, WSX = TW + 2;  // staged window
 constexpr int WSP = 20;                    // LDS row stride in pixels (bank spread, see above)
-constexpr int NB = 2;                      // blocks of 16 output channels per workgroup
 
 struct SArgs {
   const float *x;
@@ -49,7 +48,7 @@ struct SArgs {
   int bytes_x, bytes_y;
 };
 
-template <int CIN>
+template <int CIN, int NB>  // NB: blocks of 16 output channels per workgroup (2; 1 where Cout is an odd multiple of 16)
 struct Geo {
   static constexpr int NBLK = CIN >= 32 ? 9 * (CIN / 32) : 5;  // K = 32 blocks: tap x 32 channels; Cin = 16: two taps x 16
   static constexpr int RS = 2 * CIN + 16;                      // bytes per staged pixel record
@@ -72,9 +71,9 @@ __device__ inline void split3_pair(float a, float b, unsigned &H, unsigned &M, u
   L = pk_bf16(ra, rb);
 }
 
-template <int CIN, int POOL>
+template <int CIN, int POOL, int NB>
 __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int tiles_x, int tiles_y, int ntiles) {
-  using G = Geo<CIN>;
+  using G = Geo<CIN, NB>;
   constexpr int RS = G::RS, PLANE = G::PLANE, NBLK = G::NBLK, C4 = CIN / 4;
   constexpr int NITEMS = WSY * WSX * C4, NIT = (NITEMS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -229,10 +228,10 @@ inline int cu_count() {
   return cus;
 }
 
-template <int CIN, int POOL>
+template <int CIN, int POOL, int NB>
 int launch(const SArgs &a, hipStream_t st) {
-  auto kern = conv_split_kernel<CIN, POOL>;
-  constexpr int lds = Geo<CIN>::LDS;
+  auto kern = conv_split_kernel<CIN, POOL, NB>;
+  constexpr int lds = Geo<CIN, NB>::LDS;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -265,14 +264,69 @@ inline float bf16_to_float_host(unsigned short h) {
 using namespace ra;
 
 extern "C" int ra_conv_split_supported(int Cin, int Cout, int pool, int H, int W) {
-  return (Cin == 16 || Cin == 32) && Cout > 0 && Cout % (16 * csplit::NB) == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
+  return (Cin == 16 || Cin == 32) && Cout > 0 && Cout % 16 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
          H % csplit::TH == 0 && W % csplit::TW == 0;
 }
 
 extern "C" size_t ra_conv_split_packed_halfs(int Cin, int Cout) {
-  if (!(Cin == 16 || Cin == 32) || Cout <= 0 || Cout % (16 * csplit::NB)) return 0;
+  if (!(Cin == 16 || Cin == 32) || Cout <= 0 || Cout % 16) return 0;
   const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5;
-  return (size_t)(Cout / (16 * csplit::NB)) * nblk * 3 * csplit::NB * 512;
+  return (size_t)(Cout / 16) * nblk * 3 * 512;
+}
+
+namespace ra {
+namespace csplit {
+// one packed 16-bit word: (slice, block, piece, nb, kb, n, j) -> (tap, ci, co) -> the piece of the filter value there.
+// transposed: w is a conv2d_transpose filter [3,3,Cout,Cin] (equivalently: the data gradient of a cnn layer whose filter is
+// [3,3,Cin_w = Cout,Cout_w = Cin]): taps flipped, in / out swapped, as ra_conv_pack_weights(RA_CONV_TRANSPOSED).
+__host__ __device__ inline void slot_of(size_t e, int Cin, int Cout, int nblk, int nbw, int &pc, int &tap, int &ci, int &co) {
+  const int j = (int)(e & 7), nn = (int)((e >> 3) & 15), kb = (int)((e >> 7) & 3);
+  size_t r = e >> 9;  // ((slice * nblk + b) * 3 + pc) * nbw + nb
+  const int nb = (int)(r % nbw);
+  r /= nbw;
+  pc = (int)(r % 3);
+  r /= 3;
+  const int b = (int)(r % nblk), s = (int)(r / nblk);
+  if (Cin >= 32) {
+    tap = b / (Cin / 32);
+    ci = 32 * (b % (Cin / 32)) + 8 * kb + j;
+  } else {
+    tap = 2 * b + (kb >> 1);
+    ci = 8 * (kb & 1) + j;
+  }
+  co = 16 * (nbw * s + nb) + nn;
+}
+__host__ __device__ inline float filter_at(const float *w, int Cin, int Cout, int transposed, int tap, int ci, int co) {
+  if (tap >= 9) return 0.f;
+  return transposed ? w[((size_t)(8 - tap) * Cout + co) * Cin + ci] : w[((size_t)tap * Cin + ci) * Cout + co];
+}
+__global__ __launch_bounds__(256) void pack_split_kernel(const float *w, int Cin, int Cout, int transposed, int nblk, int nbw, size_t n,
+                                                         unsigned short *out) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  int pc, tap, ci, co;
+  slot_of(e, Cin, Cout, nblk, nbw, pc, tap, ci, co);
+  float v = filter_at(w, Cin, Cout, transposed, tap, ci, co);
+  unsigned short h = 0;
+  for (int k = 0; k <= pc; ++k) {  // the pc-th piece: round, subtract, round ... (every difference exact)
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    h = (unsigned short)(u >> 16);
+    v -= __builtin_bit_cast(float, (unsigned)h << 16);
+  }
+  out[e] = h;
+}
+}  // namespace csplit
+}  // namespace ra
+
+// The same packing on device pointers (the training step's filters change every step).
+extern "C" int ra_conv_split_pack_weights_dev(const float *w, int Cin, int Cout, int transposed, unsigned short *out, void *stream) {
+  const size_t n = ra_conv_split_packed_halfs(Cin, Cout);
+  if (!w || !out || !n) return fail(RA_E_SHAPE, "ra_conv_split_pack_weights_dev: Cin=%d Cout=%d", Cin, Cout);
+  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0) ? 2 : 1;
+  hipLaunchKernelGGL(csplit::pack_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, Cin, Cout,
+                     transposed ? 1 : 0, nblk, nbw, n, out);
+  return launch_status("ra_conv_split_pack_weights_dev");
 }
 
 // w: the reference's [3,3,Cin,Cout] filter (host) -> out[slice][blk][piece][nb][kb][n][8] bf16: the exact three-piece split of
@@ -280,29 +334,18 @@ extern "C" size_t ra_conv_split_packed_halfs(int Cin, int Cout) {
 extern "C" int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, unsigned short *out) {
   const size_t n = ra_conv_split_packed_halfs(Cin, Cout);
   if (!w || !out || !n) return fail(RA_E_SHAPE, "ra_conv_split_pack_weights: Cin=%d Cout=%d", Cin, Cout);
-  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, slices = Cout / (16 * csplit::NB);
-  for (int s = 0; s < slices; ++s)
-    for (int b = 0; b < nblk; ++b)
-      for (int nb = 0; nb < csplit::NB; ++nb)
-        for (int kb = 0; kb < 4; ++kb)
-          for (int nn = 0; nn < 16; ++nn)
-            for (int j = 0; j < 8; ++j) {
-              int tap, ci;
-              if (Cin >= 32) {
-                tap = b / (Cin / 32);
-                ci = 32 * (b % (Cin / 32)) + 8 * kb + j;
-              } else {
-                tap = 2 * b + (kb >> 1);
-                ci = 8 * (kb & 1) + j;
-              }
-              const int co = 16 * (csplit::NB * s + nb) + nn;
-              float v = tap < 9 ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
-              for (int pc = 0; pc < 3; ++pc) {
-                const unsigned short h = csplit::bf16_rne_host(v);
-                out[(((((size_t)s * nblk + b) * 3 + pc) * csplit::NB + nb) * 4 + kb) * 128 + nn * 8 + j] = h;
-                v -= csplit::bf16_to_float_host(h);
-              }
-            }
+  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0) ? 2 : 1;
+  for (size_t e = 0; e < n; ++e) {
+    int pc, tap, ci, co;
+    csplit::slot_of(e, Cin, Cout, nblk, nbw, pc, tap, ci, co);
+    float v = csplit::filter_at(w, Cin, Cout, 0, tap, ci, co);
+    unsigned short h = 0;
+    for (int k = 0; k <= pc; ++k) {
+      h = csplit::bf16_rne_host(v);
+      v -= csplit::bf16_to_float_host(h);
+    }
+    out[e] = h;
+  }
   return 0;
 }
 
@@ -327,6 +370,10 @@ extern "C" int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, c
   a.bytes_x = (int)bx;
   a.bytes_y = (int)by;
   hipStream_t st = as_stream(stream);
-  if (Cin == 16) return pool == 2 ? csplit::launch<16, 2>(a, st) : csplit::launch<16, 1>(a, st);
-  return pool == 2 ? csplit::launch<32, 2>(a, st) : csplit::launch<32, 1>(a, st);
+  if (Cout % 32 == 0) {
+    if (Cin == 16) return pool == 2 ? csplit::launch<16, 2, 2>(a, st) : csplit::launch<16, 1, 2>(a, st);
+    return pool == 2 ? csplit::launch<32, 2, 2>(a, st) : csplit::launch<32, 1, 2>(a, st);
+  }
+  if (Cin == 16) return pool == 2 ? csplit::launch<16, 2, 1>(a, st) : csplit::launch<16, 1, 1>(a, st);
+  return pool == 2 ? csplit::launch<32, 2, 1>(a, st) : csplit::launch<32, 1, 1>(a, st);
 }

@@ -17,7 +17,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librecattend.so')
 
-RA_ABI_VERSION = 112  # include/recattend.h: RA_ABI_VERSION
+RA_ABI_VERSION = 113  # include/recattend.h: RA_ABI_VERSION
 RA_CONV_TRANSPOSED = 1
 RA_E_INVALID, RA_E_SHAPE, RA_E_WORKSPACE = -1, -2, -3  # include/recattend.h
 RA_ATTN_STRIDE = 16
@@ -141,6 +141,7 @@ SIGNATURES = {
     'ra_conv_split_supported': (_I, [_I, _I, _I, _I, _I]),
     'ra_conv_split_packed_halfs': (_Z, [_I, _I]),
     'ra_conv_split_pack_weights': (_I, [_P, _I, _I, _P]),
+    'ra_conv_split_pack_weights_dev': (_I, [_P, _I, _I, _I, _P, _P]),
     'ra_conv_split_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_conv_pair_wino_supported': (_I, [_I, _I, _I, _I, _I, _I]),
     'ra_conv_pair_wino_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),

@@ -226,6 +226,20 @@ def pack_split_weights(w):
   return out.view(np.float32)  # carried as a float32 tensor like every other packed filter (two bf16 pieces per word)
 
 
+def pack_split_weights_dev(w, cin, cout, transposed=False):
+  """The same packing from a DEVICE filter (the training step: the weights change every step).  cin / cout: the conv's input
+  / output channels; transposed: w is laid out [3,3,cout,cin] and the taps flip (a conv2d_transpose filter, or the filter of
+  a cnn layer whose data gradient this conv is)."""
+  _need_cuda(w)
+  n = rn.lib().ra_conv_split_packed_halfs(int(cin), int(cout))
+  if n == 0 or w.numel() != 9 * cin * cout:
+    raise rn.RecAttendError('unsupported split-precision conv shape Cin=%d Cout=%d' % (cin, cout))
+  out = torch.empty(n // 2, dtype=torch.float32, device=w.device)
+  check(rn.lib().ra_conv_split_pack_weights_dev(ptr(w.contiguous()), int(cin), int(cout), int(bool(transposed)), ptr(out),
+                                                rn.stream_ptr()), 'ra_conv_split_pack_weights_dev')
+  return out
+
+
 def conv_split(x, wp, scale, shift, cout, relu=True, pool=1, out=None):
   """conv3x3 SAME + folded BN + ReLU + pool as a direct convolution on the bf16 matrix pipe at float32 accuracy
   (ra_conv_split_f32: three bf16 pieces per operand, six piece products).  x [B,H,W,Cin]."""

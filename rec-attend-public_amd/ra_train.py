@@ -690,6 +690,9 @@ class BatchNormTrain(torch.autograd.Function):
     return dx, dgamma, dbeta
 
 
+SPLIT_DGRAD = {'on': os.environ.get('RA_SPLIT_DGRAD', '1') != '0'}  # tuning aid: 0 = every float32 data gradient on K1
+
+
 def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf, out_dtype=torch.float32):
   """Backward-data of ConvBNActPool's conv: the same MFMA conv kernel on the flipped / in-out-swapped packing.  In the bf16
   mode's stacked step du may be stored as bf16 and the result takes the input tensor's storage type (out_dtype)."""
@@ -698,11 +701,21 @@ def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf, out_dtype=to
     return _conv_dgrad_bf16(du, w, tr, stride, cmap, x_shape, cin_w, cache, out_dtype)
   B, Hs, Ws, Cx = x_shape
   cout = du.shape[3]
-  duc = _pad_channels(du)
-  cd = duc.shape[3]
   cpb = ops.cout_padded(cin_w)
   ones = _const('ones', cpb, dev, lambda: torch.ones(cpb, dtype=torch.float32, device=dev))
   zeros = _const('zeros', cpb, dev, lambda: torch.zeros(cpb, dtype=torch.float32, device=dev))
+  if (SPLIT_DGRAD['on'] and not bf and stride == 1 and cmap is None and Cx == cin_w and cout >= 32 and  # (16 channels: conv16_kernel is as fast)
+      ops.conv_split_supported(cout, cin_w, 1, du.shape[1], du.shape[2]) and du.numel() * 4 < (1 << 31)):
+    # round 5: the float32 data gradient of a 16- / 32-channel layer on the bf16 matrix pipe at float32 accuracy (K1s,
+    # csrc/ra_conv_split.hip: every operand the exact sum of three bf16 pieces, six piece products) — 32 -> 32 at 128 x 128 x
+    # 128 images: 2 x 292 -> 193 us in the cfg4 step.  The filter's pieces are packed on the device once per step (cache: per pack epoch).
+    key = ('split', w.data_ptr(), w._version, bool(tr))
+    hit = cache.get(key)
+    if hit is None:
+      hit = cache[key] = (w, ops.pack_split_weights_dev(w.detach(), cout, cin_w, transposed=not tr))
+    return ops.conv_split(du.contiguous(), hit[1], ones, zeros, cin_w, relu=False, pool=1)
+  duc = _pad_channels(du)
+  cd = duc.shape[3]
   wpb = _pack_dev(w.contiguous(), cout, cin_w, cd, _pad_map(cout, cd, dev), not tr, cache)
   dxr = ops.conv3x3(duc, wpb, ones, zeros, cin_w, relu=False, pool=1, bf16=bf)
   if stride == 2:

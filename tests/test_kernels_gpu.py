@@ -408,7 +408,8 @@ def test_dense_attention_operators(cuda, H, W, big):
 
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,pool,relu', [(2, 32, 48, 16, 32, 1, True), (1, 64, 32, 32, 32, 2, True), (3, 16, 16, 32, 64, 2, True),
-                                                    (2, 48, 32, 16, 64, 2, False), (8, 128, 128, 32, 32, 2, True)])
+                                                    (2, 48, 32, 16, 64, 2, False), (8, 128, 128, 32, 32, 2, True), (2, 32, 32, 32, 16, 1, False),
+                                                    (1, 16, 32, 16, 48, 2, True)])
 def test_conv_split_precision(cuda, B, H, W, Ci, Co, pool, relu):
   """K1s (ra_conv_split_f32, round 5): the direct 3x3 layer on the bf16 matrix pipe — every operand the exact sum of three bf16
   pieces, six of the nine piece products — against the float64 oracle at the float32 kernels' bar (2e-5 of the output scale),
@@ -434,6 +435,19 @@ def test_conv_split_precision(cuda, B, H, W, Ci, Co, pool, relu):
   assert y.shape == ref.shape
   e_split, e_k1 = relerr(y.cpu().numpy(), ref), relerr(y1.cpu().numpy(), ref)
   assert e_split < 2e-5 and e_split < 4 * e_k1 + 1e-7, (e_split, e_k1)
+  # the device packer (the training step's filters change every step) writes the same words as the host one ...
+  wd = ops.pack_split_weights_dev(dev(w, cuda), Ci, Co)
+  assert torch.equal(wd.view(torch.int32), wp.view(torch.int32))
+  # ... and, transposed, the packing of the layer's DATA GRADIENT: dx = conv(du, flip(w) with in / out swapped) (nnlib.py:229-253
+  # differentiated); K1s takes it when the layer's channel counts allow
+  if ops.conv_split_supported(Co, Ci, 1, H, W):
+    du = rng.randn(B, H, W, Co).astype(np.float32)
+    wt = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))  # [3,3,Co,Ci]: the equivalent direct filter
+    ref_dx = ora.conv2d(du.astype(np.float64), wt.astype(np.float64))
+    wpt = ops.pack_split_weights_dev(dev(w, cuda), Co, Ci, transposed=True)
+    cpi = ops.cout_padded(Ci)
+    dx = ops.conv_split(dev(du, cuda), wpt, torch.ones(cpi, device=cuda), torch.zeros(cpi, device=cuda), Ci, relu=False, pool=1)
+    assert relerr(dx.cpu().numpy(), ref_dx) < 2e-5
 
 
 @pytest.mark.parametrize('H,W,big,cout,F', [(128, 128, False, 8, 48), (96, 160, True, 8, 48), (512, 512, False, 8, 48),

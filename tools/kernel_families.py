@@ -12,7 +12,7 @@ def family(n):
   if 'ra::train::wgrad' in n: return 'wgrad'
   if 'hungarian' in n: return 'hungarian'
   if 'ra::train::bn' in n or 'chan_' in n or 'moments_from_partials' in n: return 'bn kernels'
-  if 'ra::conv' in n or 'ra::cpair' in n: return 'conv fwd/dgrad'
+  if 'ra::conv' in n or 'ra::cpair' in n or 'ra::csplit' in n: return 'conv fwd/dgrad'
   if 'ra::train' in n: return 'train other'
   if n.startswith('Cijk') or 'rocblas' in n: return 'rocBLAS gemm / gemv'
   if 'at::native' in n: return 'torch elementwise/reduce'
