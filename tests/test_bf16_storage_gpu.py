@@ -137,6 +137,12 @@ def test_wgrad_bf16_storage_equals_operand_kernel(cuda, cin, cout, ups):
   ref = run(xf, df, None)
   for fmt, x, du in ((3, xb, db_), (1, xb, df), (2, xf, db_), (0, xf, df)):
     got = run(x, du, fmt)
+    if cout == 8 and not ups and ((cin == 8 and fmt == 3) or (cin == 4 and fmt == 2)):
+      # round 5: these two storage combinations of the 8-output-channel layers run wgrad8b_kernel (K = 32 pixels per MFMA on the
+      # bf16 tiles as they lie in memory): the same exact products in another summation order — float32 round-off, not bit equality
+      for a_, b_ in zip(got, ref):
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(1.0, float(b_.abs().max())), fmt
+      continue
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), fmt
 
 
