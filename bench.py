@@ -597,7 +597,7 @@ def main():
                  'arch': 'cvppp', 'H': S, 'W': S, 'T': T, 'batch_per_gpu': B,
                  'global_batch': B * world, 'parallelism': 'batch-sharded x%d, no collective' % world,
                  'ranks_in_communicator': ra_dist.comm_size(),
-                 'hip_graph': bool(eng.use_graph), 'batches_in_flight': pipe.depth * coalesce, 'pipeline_slots': pipe.depth,
+                 'hip_graph': bool(eng.use_graph), 'tile_tickets': bool(eng.tile_tickets), 'batches_in_flight': pipe.depth * coalesce, 'pipeline_slots': pipe.depth,
                  'batches_per_launch': coalesce,
                  'pipeline_note': ('each of the %d pipeline slots decodes %d consecutively submitted batches of %d images as ONE forward '
                                    '(DecodePipeline(coalesce=%d): eval-mode images are independent, every batch is collected on its own); '
@@ -626,16 +626,25 @@ def main():
     Bs = sb['img'].shape[0]
     Fh, Fw = d['Fh'], d['Fw']
 
-    def graph_time_us(fn, reps=20, inner=8):
+    probe_tk = ops.tickets_alloc(256, sb['img'].device) if eng.tile_tickets else None
+    probe_fill = {}
+
+    def graph_time_us(fn, reps=20, inner=8, tickets=False):
       """Average duration of one `fn` launch group: `inner` copies are captured in one HIP graph
       (a replay has a fixed ~10 us cost that must not be charged to the kernels) and the graph is
-      replayed `reps` times between two HIP events on the launch stream."""
+      replayed `reps` times between two HIP events on the launch stream.  tickets: as in the engine's forward, the controller
+      CNN's persistent launches draw their tiles (one zeroing fill of the ticket scratch per replay, inside the graph)."""
       fn()
       torch.cuda.synchronize()
       g = torch.cuda.CUDAGraph()
       with torch.cuda.graph(g):
-        for _ in range(inner):
-          fn()
+        bound = tickets and probe_tk is not None and ops.tickets_bind(probe_tk)
+        try:
+          for _ in range(inner):
+            fn()
+        finally:
+          if bound:
+            ops.tickets_unbind()
       for _ in range(3):
         g.replay()
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -645,7 +654,14 @@ def main():
         g.replay()
       e1.record()
       torch.cuda.synchronize()
-      return 1e3 * e0.elapsed_time(e1) / (reps * inner)
+      us = 1e3 * e0.elapsed_time(e1) / (reps * inner)
+      if tickets and probe_tk is not None:
+        # the zeroing fill of the ticket scratch is one launch per FORWARD in the engine (16 timesteps x 6 launches) but one per
+        # `inner` groups here: its share is taken out again
+        if 'us' not in probe_fill:
+          probe_fill['us'] = graph_time_us(lambda: ops.fill(probe_tk, 0.0))
+        us -= probe_fill['us'] / inner
+      return us
 
     rides = (not eng.box) and (not d['disable_overwrite']) and eng._prefill_rides(sb)
 
@@ -658,11 +674,11 @@ def main():
     tot_f, per_f = encoder_flops_per_image(d)
     layers = []
     for step in eng.plan['ccnn']:
-      us = graph_time_us(lambda: enc_step(step))
+      us = graph_time_us(lambda: enc_step(step), tickets=True)
       fl = sum(per_f[i] for i in step[1:])
       layers.append({'layers': list(step[1:]), 'fused': step[0] == 'pair', 'avg_us': us,
                      'gflop': fl * Bs / 1e9, 'tflops': fl * Bs / (us * 1e-6) / 1e12})
-    enc_us = graph_time_us(lambda: [enc_step(st_) for st_ in eng.plan['ccnn']])
+    enc_us = graph_time_us(lambda: [enc_step(st_) for st_ in eng.plan['ccnn']], tickets=True)
     cache_us = 0.0
     if 'l0cache' in sb:
       # the cache is filled by the FIRST timestep's launch (un-cached kernel + cache stores, valid while
@@ -712,7 +728,7 @@ def main():
         for st_ in reng.plan['ccnn']:
           src_ = rsb['img'] if st_[1] == 0 else rsb['ccnn'][st_[1] - 1]
           reng._run_cnn([st_], reng.W['ccnn'], src_, rsb['ccnn'], 1, 'ctrl_cnn', plane=rsb['canvas'], cache=rsb.get('l0cache'))
-      us_l = graph_time_us(enc_launched) + cache_us * rB / Bs / T
+      us_l = graph_time_us(enc_launched, tickets=True) + cache_us * rB / Bs / T
       out['roofline']['as_launched'] = {
           'images_per_launch': rB, 'avg_us_per_launch_group': us_l, 'flop_per_launch_group': tot_f * rB,
           'achieved': tot_f * rB / (us_l * 1e-6) / 1e12, 'frac': tot_f * rB / (us_l * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,

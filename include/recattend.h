@@ -812,6 +812,22 @@ int ra_weighted_sum_multi_f32(const float *w, const float *bias, const float *y,
 int ra_weighted_sum_multi_strided_f32(const float *w, const float *bias, const float *y, int B, int N, int T, int HW,
                                       float *out, size_t o_img, size_t o_row, void *stream);
 
+/* Dynamic tile tickets for the persistent controller-CNN launches (no reference counterpart: nnlib.cnn, nnlib.py:229-253, is
+ * one TF op per layer and knows no tiles).  ra_conv_pair_cached_f32, ra_conv_pair_wino_f32, ra_conv_wino_f32 and
+ * ra_conv_split_f32 run persistent grids; by default a workgroup walks a fixed list of tiles, which is fastest when the
+ * launch owns the GPU and up to 2x slower when other work (another batch's controller in the decode pipeline, another
+ * process) keeps some of its workgroups from starting on time.  Between ra_tile_tickets_bind(scratch, slots) and
+ * ra_tile_tickets_bind(NULL, 0) every such launch issued by the CALLING THREAD takes the next slot(s) of `scratch` (one per
+ * output-channel slice) and its workgroups DRAW their tiles from per-XCD pools in it, so that a late workgroup costs only
+ * its share.  scratch: device memory, 128-byte aligned, slots * ra_tile_tickets_slot_bytes() bytes, ZERO when the first of
+ * those launches executes (e.g. ra_fill_f32 on the same stream), used by launches of ONE stream only, and re-zeroed before the
+ * slots are handed out again (the decode engine binds at the start of a forward: one fill per forward, also inside its
+ * captured graph).  Launches that find no slot left, or whose grid is too small to draw from all eight pools, keep the
+ * static walk.  Returns 1 if bound, 0 if unbound (NULL, or a device whose workgroups do not report exactly the XCC ids
+ * 0..7: the static walk stays), negative on error.  RA_TILE_TICKETS=0 disables it. */
+int ra_tile_tickets_bind(void *scratch, int slots);
+int ra_tile_tickets_slot_bytes(void);
+
 /* p[0..n) = value (p 16-byte aligned): the canvas reset `canvas = zeros` (full_model.py:239) and
  * the sigmoid(beta) prefill of y_out behind RA_PASTE_Y_PREFILLED, as a library launch so that the
  * captured forward holds no framework kernel. */

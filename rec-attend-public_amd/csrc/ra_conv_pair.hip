@@ -36,6 +36,7 @@ struct PArgs {
   float *rider_dst;
   int rider_quads;  // float4 groups to write (rider_dst 16-byte aligned, < 2 GiB)
   float rider_val;
+  unsigned *tickets;  // conv_pair8: this launch's slot of tile-ticket pools (ra_common.h), nullptr = the static tile walk
 };
 
 template <int CINA, int CMID, int NCB, int GX, int GYB>
@@ -616,6 +617,11 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
 
   const int tid = threadIdx.x, lane = tid & 63;
+  // dynamic tile tickets (a.tickets, ra_common.h): the workgroup draws its tiles from its XCD's pool instead of walking them
+  __shared__ unsigned tk_sh[2];
+  TicketWalk tk;
+  const bool dyn = a.tickets != nullptr;
+  if (dyn) tk.issue(a.tickets, ntiles);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, ksub = lane >> 4;  // A-operand side
   const int n = lane & 15, qo = lane >> 4;    // D side: column n = (p, co), rows 4*qo + r
@@ -805,8 +811,13 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
   for (int g = 0; g < 4; ++g) g_y[g] = ((g >> 1) * a.Wo + 8 * (g & 1)) * a.CoutB * 4;
 
   int tile = t_first;
-  TC cur = split(tile), nxt = cur;
-  if (tile < t_end) fetch(cur);
+  if (dyn) {
+    tk.begin(tk_sh);
+    tile = tk.cur;
+  }
+  bool have = dyn ? tile >= 0 : tile < t_end;
+  TC cur = split(have ? tile : 0), nxt = cur;
+  if (have) fetch(cur);
   RA_P8_DECL;
   // the padded groups read LDS this kernel never writes; whatever an earlier kernel left there
   // must not be NaN/Inf (their results are discarded, but keep the arithmetic clean)
@@ -823,7 +834,8 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
   const int my_tiles = t_end > t_first ? (t_end - t_first + nwx - 1) / nwx : 1;
   const int r_per_tile = (r_chunk + 256 * my_tiles - 1) / (256 * my_tiles);
   const u32x4r r_bits = __builtin_bit_cast(u32x4r, f32x4{a.rider_val, a.rider_val, a.rider_val, a.rider_val});
-  for (; tile < t_end; tile += nwx, cur = nxt) {
+  bool have_n = false;
+  for (; have; tile = dyn ? (tk.step(), tk.cur) : tile + nwx, cur = nxt, have = have_n) {
     const int b = cur.b, ty0 = cur.ty * G::TH, tx0 = cur.tx * G::TW;
 
     // ---------------- stage layer A's input window (prefetched registers -> LDS) ----------------
@@ -854,10 +866,19 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
         }
       }
     }
+    if (dyn) tk.publish(tk_sh);
     RA_P8_SYNC();
     RA_P8_AT(0);  // staged + barrier
-    nxt = advance(cur);
-    if (tile + nwx < t_end) fetch(nxt);  // the next tile's loads fly while this one is computed
+    if (dyn) {
+      tk.read_next(tk_sh);
+      tk.request();  // the draw for the tile after next: older than the prefetch loads below, in flight across this tile
+      have_n = tk.nxt >= 0;
+      nxt = split(have_n ? tk.nxt : 0);
+    } else {
+      have_n = tile + nwx < t_end;
+      nxt = advance(cur);
+    }
+    if (have_n) fetch(nxt);  // the next tile's loads fly while this one is computed
     if constexpr (!CACHED) {
       if (rider)
         for (int u = 0; u < r_per_tile; ++u, r_idx += 256)
@@ -1084,6 +1105,7 @@ int launch8(const PArgs &a_in, int B, hipStream_t st) {
   PArgs a2 = a;
   const int grid = ntiles < wgs ? ntiles : wgs;
   a2.xcd_map = (xcd && grid % 8 == 0 && grid >= 8) ? 1 : 0;
+  a2.tickets = (CACHED && ntiles >= kTicketMinTilesPerWg * grid) ? take_ticket_slots(1, grid) : nullptr;  // the steady-state form; bound scratch only
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a2, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_f32");
 }

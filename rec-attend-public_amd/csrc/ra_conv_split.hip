@@ -46,6 +46,7 @@ struct SArgs {
   float *y;
   int B, H, W, Cout, relu;
   int bytes_x, bytes_y;
+  unsigned *tickets;  // this launch's slots of tile-ticket pools, one per channel slice (ra_common.h); nullptr = the static walk
 };
 
 template <int CIN, int NB>  // NB: blocks of 16 output channels per workgroup (2; 1 where Cout is an odd multiple of 16)
@@ -80,6 +81,11 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
   unsigned char *tin = lds;               // three bf16 tiles [WSY][WSP][RS]
   unsigned char *wl = lds + 3 * PLANE;    // the slice's filter pieces
   const int tid = threadIdx.x, lane = tid & 63;
+  // dynamic tile tickets (a.tickets): tiles are drawn from this XCD's pool of the channel slice instead of walked
+  __shared__ unsigned tk_sh[2];
+  TicketWalk tk;
+  const bool dyn = a.tickets != nullptr;
+  if (dyn) tk.issue(a.tickets + blockIdx.y * kTicketSlotWords, ntiles);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kb = lane >> 4;  // A side: row m, k-group kb;  B / D side: column n = m, D rows 4 kb + r
   const int slice = blockIdx.y;
@@ -145,9 +151,13 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     const u32x4 *src = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(a.wp) + (size_t)slice * G::WBYTES);
     for (int e = tid; e < G::WBYTES / 16; e += 256) reinterpret_cast<u32x4 *>(wl)[e] = src[e];
   }
-  int tile = blockIdx.x;
+  int tile = blockIdx.x, tnext = 0;
+  if (dyn) {
+    tk.begin(tk_sh);
+    tile = tk.cur >= 0 ? tk.cur : ntiles;
+  }
   if (tile < ntiles) fetch(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile = tnext) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     __syncthreads();  // the previous tile's operand reads are complete (and, first time round, the filter copy is issued)
@@ -163,8 +173,17 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
         *reinterpret_cast<u32x2 *>(rec + 2 * PLANE) = u32x2{L0, L1};
       }
     }
+    if (dyn) tk.publish(tk_sh);
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight across the MFMA loop
+    if (dyn) {
+      tk.read_next(tk_sh);
+      tk.request();  // older than the prefetch loads below: consumed with them at the next tile's staging
+      tk.step();
+      tnext = tk.cur >= 0 ? tk.cur : ntiles;
+    } else {
+      tnext = tile + (int)gridDim.x;
+    }
+    if (tnext < ntiles) fetch(tnext);  // in flight across the MFMA loop
 
     f32x4 acc[4][NB];
 #pragma unroll
@@ -241,7 +260,9 @@ int launch(const SArgs &a, hipStream_t st) {
   int gx = cu_count() / slices;  // one workgroup per CU (141 KB of LDS at Cin = 32)
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  SArgs a2 = a;
+  a2.tickets = ntiles >= kTicketMinTilesPerWg * gx ? take_ticket_slots(slices, gx) : nullptr;  // several tiles per workgroup and a bound scratch: drawn tiles
+  hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a2, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_split_f32");
 }
 
@@ -356,7 +377,7 @@ extern "C" int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, c
     return fail(RA_E_SHAPE, "ra_conv_split_f32: Cin=%d Cout=%d pool=%d %dx%d", Cin, Cout, pool, H, W);
   const size_t bx = (size_t)B * H * W * Cin * 4, by = (size_t)B * (H / pool) * (W / pool) * Cout * 4;
   if (bx >= (1ull << 31) || by >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_split_f32: a tensor exceeds 2 GiB");
-  csplit::SArgs a;
+  csplit::SArgs a{};
   a.x = x;
   a.wp = wpacked;
   a.scale = scale;

@@ -47,6 +47,7 @@ struct WArgs {
   int B, H, W, Cout, relu;
   int bytes_x;
   int xcd_map;
+  unsigned *tickets;  // this launch's slots of tile-ticket pools, one per channel slice (ra_common.h); nullptr = the static walk
 };
 
 // XCD-contiguous tile walk (see conv_pair8_mfma): workgroups are dealt to the 8 XCDs round robin, so with
@@ -80,6 +81,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
   float *tin = lds;                  // [WSY][WS][S]
   float *tex = lds + WSY * WS * S;   // [4 p][2 j][16 tiles][TEX]
   const int tid = threadIdx.x, lane = tid & 63;
+  // dynamic tile tickets (a.tickets): tiles are drawn from this XCD's pool of the channel slice instead of walked
+  __shared__ unsigned tk_sh[2];
+  TicketWalk tk;
+  const bool dyn = a.tickets != nullptr;
+  if (dyn) tk.issue(a.tickets + blockIdx.y * kTicketSlotWords, ntiles);
   const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, ksub = lane >> 4;
   const int slice = blockIdx.y, NBT = a.Cout / 16;
@@ -132,7 +138,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
   };
 
   const TileWalk tw = tile_walk(ntiles, a.xcd_map);
-  for (int tile = tw.first; tile < tw.end; tile += tw.step) {
+  if (dyn) tk.begin(tk_sh);
+  const int t_end = dyn ? ntiles : tw.end;  // drawn tiles come from the pool of the XCD the workgroup is ON (not blockIdx % 8's chunk)
+  for (int tile = dyn ? (tk.cur >= 0 ? tk.cur : t_end) : tw.first; tile < t_end;
+       tile = dyn ? (tk.step(), tk.cur >= 0 ? tk.cur : t_end) : tile + tw.step) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy = ty * TSY - 1, ox = tx * TS - 1;
@@ -144,7 +153,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
 #pragma unroll
       for (int i = 0; i < N0; ++i) store_rows(0, 6, i, v0[i]);
     }
+    if (dyn) tk.publish(tk_sh);
     __syncthreads();
+    if (dyn) {
+      tk.read_next(tk_sh);
+      tk.request();
+    }
 
 #pragma unroll 1
     for (int mblk = 0; mblk < NMB; ++mblk) {
@@ -257,6 +271,7 @@ int launch(const WArgs &a, hipStream_t st) {
   if (gx > ntiles) gx = ntiles;
   WArgs a2 = a;  // XCD-contiguous tile walk when the grid's rows are whole rounds of the 8 XCDs
   a2.xcd_map = (gx % 8 == 0) ? 1 : 0;
+  a2.tickets = ntiles >= kTicketMinTilesPerWg * gx ? take_ticket_slots(slices, gx) : nullptr;  // several tiles per workgroup and a bound scratch: drawn tiles
   hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), lds, st, a2, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_wino_f32");
 }
@@ -302,6 +317,7 @@ struct PWArgs {
   int B, H, W, CoutAP, reluA, reluB;
   int bytes_x;
   int xcd_map;
+  unsigned *tickets;  // this launch's slot of tile-ticket pools (ra_common.h); nullptr = the static walk
 };
 
 // SPLIT (round 5): layer A — the direct 8 -> 16 conv, 54 of the kernel's 86 MFMAs per wave and tile — on the BF16 matrix pipe at
@@ -334,6 +350,11 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
   constexpr int PLB = NPI * 16;              // SPLIT: bytes of one bf16 input tile [pixel][8]
   constexpr int INF = SPLIT ? 3 * PLB / 4 : NPI * CINA;  // floats of the staged input
   constexpr int R0 = INF > 8 * 16 * TEXP ? INF : 8 * 16 * TEXP;
+  // dynamic tile tickets (a.tickets): tiles are drawn from this XCD's pool instead of walked (static: tile += tw.step)
+  __shared__ unsigned tk_sh[2];
+  TicketWalk tk;
+  const bool dyn = a.tickets != nullptr;
+  if (dyn) tk.issue(a.tickets, ntiles);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tinp = lds;                         // [IWY][IWX][8]   records [ksub][cg]  (channel = 4 * cg + ksub)
   float *tex = lds;                          // [4 p][2 j][16 tiles][TEXP]: phase B only, when tinp is dead
@@ -413,9 +434,14 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
   };
 
   const TileWalk tw = tile_walk(ntiles, a.xcd_map);
-  int tile = tw.first;
-  if (tile < tw.end) fetch(tile);
-  for (; tile < tw.end; tile += tw.step) {
+  int tile = tw.first, tnext = 0;
+  const int t_end = dyn ? ntiles : tw.end;  // drawn tiles come from the pool of the XCD the workgroup is ON (not blockIdx % 8's chunk)
+  if (dyn) {
+    tk.begin(tk_sh);
+    tile = tk.cur >= 0 ? tk.cur : t_end;
+  }
+  if (tile < t_end) fetch(tile);
+  for (; tile < t_end; tile = tnext) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     __syncthreads();  // the previous tile's phase B (exchange reads) is complete
@@ -440,8 +466,17 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
         for (int ks = 0; ks < 4; ++ks) rec[2 * ks] = pre[i][ks];
       }
     }
+    if (dyn) tk.publish(tk_sh);
     __syncthreads();
-    if (tile + tw.step < tw.end) fetch(tile + tw.step);
+    if (dyn) {
+      tk.read_next(tk_sh);
+      tk.request();  // older than the prefetch loads below: consumed with them at the next tile's staging
+      tk.step();
+      tnext = tk.cur >= 0 ? tk.cur : t_end;
+    } else {
+      tnext = tile + tw.step;
+    }
+    if (tnext < t_end) fetch(tnext);
 
     // ---------------- phase A: layer A on the window, BN + ReLU, -> tin ----------------
     {
@@ -575,6 +610,9 @@ int launch_pair(const PWArgs &a, hipStream_t st) {
   const int grid = ntiles < cap ? ntiles : cap;
   PWArgs a2 = a;
   a2.xcd_map = (xcd && grid % 8 == 0 && grid >= 8) ? 1 : 0;
+  // (this pair from 6 tiles per workgroup: at 4 — cfg2's batch of 8 alone — drawing costs it 2 us of 33, at 8 — the 16 images of a
+  // pipeline slot — 1.3 of 66 against 9-14 us saved next to another slot's tail)
+  a2.tickets = ntiles >= 2 * kTicketMinTilesPerWg * grid ? take_ticket_slots(1, grid) : nullptr;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a2, tiles_x, tiles_y, ntiles);
   return launch_status("ra_conv_pair_wino_f32");
 }
@@ -621,7 +659,7 @@ extern "C" int ra_conv_wino_f32(const float *x, int B, int H, int W, int Cin, co
     return fail(RA_E_SHAPE, "ra_conv_wino_f32: Cin=%d Cout=%d pool=%d %dx%d", Cin, Cout, pool, H, W);
   const size_t bytes = (size_t)B * H * W * Cin * sizeof(float);
   if (bytes >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_wino_f32: input exceeds 2 GiB");
-  wino::WArgs a;
+  wino::WArgs a{};
   a.x = x;
   a.wp = wpacked;
   a.scale = scale;
@@ -655,7 +693,7 @@ extern "C" int ra_conv_pair_wino_f32(const float *x, int B, int H, int W, const 
   if (!ra_conv_pair_wino_supported(8, 16, 16, 2, H, W)) return fail(RA_E_SHAPE, "ra_conv_pair_wino_f32: %dx%d", H, W);
   const size_t bytes = (size_t)B * H * W * 8 * sizeof(float);
   if (bytes >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_pair_wino_f32: input exceeds 2 GiB");
-  wino::PWArgs a;
+  wino::PWArgs a{};
   a.x = x;
   a.wpA = wpA;
   a.scA = scaleA;

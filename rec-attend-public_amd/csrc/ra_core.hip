@@ -27,6 +27,62 @@ int tail_prio(int kind) {  // read on every call (an int parse): tests and A/B p
 }
 }  // namespace ra
 
+// ---- dynamic tile tickets (ra_common.h): the calling thread's bound scratch and its cursor ----
+namespace ra {
+namespace {
+thread_local unsigned *g_tk_base = nullptr;
+thread_local int g_tk_slots = 0, g_tk_next = 0;
+__global__ __launch_bounds__(64) void xcc_census_kernel(int *seen) {
+  if (threadIdx.x == 0) atomicOr(seen, 1 << xcc_id());
+}
+// The pools are keyed by HW_REG_XCC_ID 0..7: a device (or partition mode) whose workgroups do not land on exactly those eight
+// XCDs would leave pools undrawn, so tickets are only handed out where a census launch has seen all eight and nothing else.
+int tickets_supported() {
+  static int ok = -1;
+  if (ok < 0) {
+    const char *e = getenv("RA_TILE_TICKETS");
+    if (e && atoi(e) == 0) return ok = 0;
+    int *seen = nullptr, h = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;  // decide outside a capture
+    if (hipMalloc(&seen, sizeof(int)) != hipSuccess) return ok = 0;
+    (void)hipMemset(seen, 0, sizeof(int));
+    hipLaunchKernelGGL(xcc_census_kernel, dim3(1024), dim3(64), 0, nullptr, seen);
+    const bool good = hipMemcpy(&h, seen, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(seen);
+    ok = (good && h == 0xff) ? 1 : 0;
+  }
+  return ok;
+}
+}  // namespace
+unsigned *take_ticket_slots(int n, int grid_x) {
+  // fewer than 8 workgroups per XCD: the static walk (a pool must never be left without a workgroup to draw from it)
+  if (!g_tk_base || n <= 0 || grid_x < 64 || g_tk_next + n > g_tk_slots) return nullptr;
+  unsigned *p = g_tk_base + (size_t)g_tk_next * kTicketSlotWords;
+  g_tk_next += n;
+  return p;
+}
+}  // namespace ra
+
+extern "C" int ra_tile_tickets_bind(void *scratch, int slots) {
+  if (!scratch || slots <= 0) {
+    ra::g_tk_base = nullptr;
+    ra::g_tk_slots = ra::g_tk_next = 0;
+    return 0;
+  }
+  if (reinterpret_cast<uintptr_t>(scratch) & 127) return ra::fail(RA_E_INVALID, "ra_tile_tickets_bind: the scratch must be 128-byte aligned");
+  if (!ra::tickets_supported()) {  // not an error: the launches keep their static tile walk
+    ra::g_tk_base = nullptr;
+    ra::g_tk_slots = ra::g_tk_next = 0;
+    return 0;
+  }
+  ra::g_tk_base = static_cast<unsigned *>(scratch);
+  ra::g_tk_slots = slots;
+  ra::g_tk_next = 0;
+  return 1;
+}
+extern "C" int ra_tile_tickets_slot_bytes(void) { return ra::kTicketSlotWords * (int)sizeof(unsigned); }
+
 extern "C" int ra_version(void) { return RA_ABI_VERSION; }
 extern "C" const char *ra_last_error_string(void) { return ra::g_err; }
 

@@ -52,6 +52,10 @@ class DecodeEngine(object):
     self.cache_first = True  # image part of the first controller-CNN layer cached once per forward
     self.fill_cache_inline = True  # ... by the first timestep's own launch (else: a separate kernel)
     self.co_resident = 1  # engines decoding concurrently on this GPU (set by full_model.DecodePipeline)
+    # drawn tiles in the controller CNN's persistent launches (ra_tile_tickets_bind): for a GPU this process does NOT own.  With
+    # another stream's controllers as company the launch group slows x1.12-1.21 instead of x1.37 (tools/contention_probe.py);
+    # inside our own decode pipeline it measured neutral (63.7k vs 64.0k: profiles/r05_tile_tickets.txt), hence off by default.
+    self.tile_tickets = os.environ.get('RA_ENGINE_TICKETS', '0') != '0'
     self.nsub = 0  # sub-batches decoded on parallel streams; 0 = one (see _launch_all)
     self.use_graph = True
     self.prefill_ride = True  # the once-per-forward y_out prefill rides on the first controller-CNN launch
@@ -270,6 +274,7 @@ class DecodeEngine(object):
       for i in range(d['ccnn_nlayers']):
         hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
         b['ccnn'].append(f(Bs, hh, ww, d['ccnn_channels'][i + 1]))
+      b['tickets'] = ops.tickets_alloc(16 * T, device)  # <= 16 ticketed launch slices per timestep
       b['h_last'] = f(T, Bs, d['hid'])
       b['ctrl_out'] = f(T, Bs, 9)
       b['gmaps'] = f(T, Bs, d['iters'], d['G'])
@@ -397,8 +402,15 @@ class DecodeEngine(object):
 
   def _launch_sub(self, b, want_box):
     self._launch_pack(b)
-    for tt in range(self.d['T']):
-      self._launch_tail(b, tt, want_box, self._launch_encoder(b, tt))
+    # the controller CNN's persistent launches draw their tiles (ra_tile_tickets_bind): another slot's controller or patch
+    # convs on the same GPU then cost them their share of the chip, not a second round (tools/contention_probe.py)
+    bound = self.tile_tickets and 'tickets' in b and ops.tickets_bind(b['tickets'])
+    try:
+      for tt in range(self.d['T']):
+        self._launch_tail(b, tt, want_box, self._launch_encoder(b, tt))
+    finally:
+      if bound:
+        ops.tickets_unbind()
 
   def _launch_encoder(self, b, tt):
     fill = b['y_out'] if (tt == 0 and b.pop('_fill_rider', False)) else None

@@ -122,6 +122,8 @@ SIGNATURES = {
     'ra_random_transform_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_weighted_sum_f32': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ra_fill_f32': (_I, [_P, _Z, _F, _P]),
+    'ra_tile_tickets_bind': (_I, [_P, _I]),
+    'ra_tile_tickets_slot_bytes': (_I, []),
     'ra_adam_step_f32': (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P]),
     'ra_adam_step_guarded_f32': (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
     'ra_bn_workspace_floats': (_Z, [_I]),

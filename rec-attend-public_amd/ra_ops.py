@@ -823,6 +823,28 @@ def fill(t, value):
   return t
 
 
+def tickets_alloc(slots, device):
+  """Scratch for `slots` ticketed launches (ra_tile_tickets_bind, include/recattend.h): zeroed by tickets_bind."""
+  n = slots * rn.lib().ra_tile_tickets_slot_bytes() // 4
+  return torch.zeros((n,), dtype=torch.float32, device=device)
+
+
+def tickets_bind(t):
+  """Zero the scratch on the current stream and make it current for this thread's persistent conv launches: their
+  workgroups draw tiles from per-XCD pools instead of walking a fixed list (robust against company on the GPU).
+  Returns True if bound; tickets_unbind() ends it.  The launches must all go to the current stream."""
+  _need_cuda(t)
+  fill(t, 0.0)
+  rc = rn.lib().ra_tile_tickets_bind(ptr(t), t.numel() * 4 // rn.lib().ra_tile_tickets_slot_bytes())
+  if rc < 0:
+    check(rc, 'ra_tile_tickets_bind')
+  return rc == 1
+
+
+def tickets_unbind():
+  rn.lib().ra_tile_tickets_bind(None, 0)
+
+
 def greedy_match(score, out=None):
   """modellib.f_greedy_match with matched == 0 (modellib.py:365-379): score [B,T] -> [B,T]."""
   score = score.contiguous()
