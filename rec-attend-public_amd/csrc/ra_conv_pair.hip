@@ -631,8 +631,17 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
   // BN scale is folded into the weights and the shift into the accumulator's initial value, so
   // the epilogue of a value is one v_max (ReLU); FP32 MFMA shares the FP32 VALU lanes on gfx950
   // (tools/mfma_valu.hip: their times add), so every VALU instruction here costs MFMA time.
-  const float scA = a.scA[co], shA = a.shA[co], scB = a.scB[co], shB = a.shB[co];
+  const float scA = a.scA[co], scB = a.scB[co], shB = a.shB[co];
   const float loA = a.reluA ? 0.f : -__builtin_inff(), loB = a.reluB ? 0.f : -__builtin_inff();
+  // Phase A runs its MFMAs with the operands SWAPPED (filter = A operand, pixels = B operand: the same lane contents, the other
+  // argument order), so its accumulators are D^T: lane (pixel mA = lane & 15, channel block g4 = lane >> 4) holds the FOUR
+  // channels 4 g4 .. 4 g4 + 3 of column n = (p, co), i.e. channels coA0 .. coA0 + 3 of ONE pixel (row qA of the group, column
+  // 2 rA + pA).  With pixels as rows a lane held one channel of four pixels and wrote the bf16 tiles of layer B with twelve
+  // 2-byte LDS stores per group; now it is three 8-byte stores (phase A was 45 % of a workgroup's life, issue-bound on them).
+  const int qA = m >> 2, rA = m & 3, pA = ksub >> 1, coA0 = 4 * (ksub & 1);
+  f32x4 scA4, shA4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) scA4[j] = a.scA[coA0 + j], shA4[j] = a.shA[coA0 + j];
   // W' of both layers, once per workgroup: one dword per (tap', cg) per lane, zero where the
   // tap misses pixel p
   // FILL (un-cached kernel with a cache pointer): the first timestep of a forward.  Its canvas is all
@@ -789,8 +798,6 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
                              : ((m >> 2) * G::LW + 2 * (m & 3)) * CINA + ksub * NCGA;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(a.cache ? a.cache : a.src), 0, a.cache ? a.bytes_c : 0, 0x00020000);
-  const int chpos = (co & 3) * 2 + (co >> 2);
-  const int lane_mid = (qo * G::AW + p) * 8 + chpos;
   const int lane_b = ((m & 1) * G::AW + 2 * (m >> 1) + 1) * 8 + ksub * 2;
   const int pg = a.plane_chan >> 2, slot = a.plane_chan & 3;
 
@@ -803,7 +810,7 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
     const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
     slot_c[s] = (4 * gr * a.cache_gx + gc) * 256;
   }
-  const int lane_c = (qo * a.cache_gx * 16 + n) * 16;
+  const int lane_c = qA * a.cache_gx * 256 + rA * 64 + ksub * 16;  // cell (row, column group): [pair r][n] floats, this lane's n = 4 g4 ..
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes_y, 0x00020000);
   const unsigned lane_y = co < a.CoutB ? (unsigned)(((2 * qo + p) * a.CoutB + co) * 4) : 0x80000000u;
   int g_y[4];
@@ -837,6 +844,16 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
   bool have_n = false;
   for (; have; tile = dyn ? (tk.step(), tk.cur) : tile + nwx, cur = nxt, have = have_n) {
     const int b = cur.b, ty0 = cur.ty * G::TH, tx0 = cur.tx * G::TW;
+    // CACHED: this tile's cached sums of layer A — 32 bytes per pixel, the launch's largest read — are requested HERE, a
+    // staging pass and a barrier ahead of their use (requested where phase A starts, their latency was 16 % of a workgroup's
+    // life: tools/pair8_probe.hip "cache arrived"); they need no registers that are live now — phase B's are dead
+    f32x4 cpre[CACHED ? G::GPW : 1];
+    if constexpr (CACHED) {
+      const int tile_c0 = ((b * a.cache_rows + ty0) * a.cache_gx + (tx0 >> 3)) * 256;
+#pragma unroll
+      for (int s = 0; s < G::GPW; ++s)
+        cpre[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, tile_c0 + slot_c[s] + lane_c, 0, 0));
+    }
 
     // ---------------- stage layer A's input window (prefetched registers -> LDS) ----------------
 #pragma unroll
@@ -888,7 +905,7 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
     // ---------------- phase A: layer A on the 18 x 36 region -> tmid ----------------
     {
       const bool interior = (ty0 >= 1) & (ty0 + G::TH + 1 <= a.H) & (tx0 >= 2) & (tx0 + G::TW + 1 <= a.W);
-      const int tile_c = ((b * a.cache_rows + ty0) * a.cache_gx + (tx0 >> 3)) * 256;
+      const int tile_c = ((b * a.cache_rows + ty0) * a.cache_gx + (tx0 >> 3)) * 256;  // (the FILL form's cache stores)
       f32x4 acc[G::GPW];
       int gin[G::GPW];
 #pragma unroll
@@ -898,15 +915,12 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
         const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
         gin[s] = (4 * gr * G::LW + 8 * gc) * RECA + lane_in;
         if constexpr (CACHED) {
-          // this lane's 4 partial sums (rows 4*qo + r of the group) are one float4 of the cache:
-          // [image][row ty0-1+4gr+qo (+1)][column group tx0/8+gc][n][r]
+          // this lane's 4 partial sums (columns n = 4 g4 .. + 3 of pixel mA of the group) are one float4 of the cache:
+          // [image][row ty0-1+4gr+qA (+1)][column group tx0/8+gc][pair rA][n]
           // (byte offset = tile part + slot part + lane part; only the first changes per tile)
-          const int off = tile_c + slot_c[s] + lane_c;
-          const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0));
-          acc[s] = c * scA + shA;
+          acc[s] = cpre[s] * scA4 + shA4;
         } else {
-          const float i0 = fill ? 0.f : shA;
-          acc[s] = f32x4{i0, i0, i0, i0};
+          acc[s] = fill ? f32x4{0.f, 0.f, 0.f, 0.f} : shA4;
         }
       }
       RA_P8_AT(1);  // layer A's cached sums have arrived (accumulators initialised)
@@ -918,7 +932,7 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
           for (int s = 0; s < G::GPW; ++s) av[s] = tin[gin[s] + ky * G::LW];
 #pragma unroll
           for (int s = 0; s < G::GPW; ++s)
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bAc[ky], acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(bAc[ky], av[s], acc[s], 0, 0, 0);  // D^T: rows = (p, co), columns = pixels
         }
       } else {
 #pragma unroll
@@ -933,7 +947,7 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
           for (int cg = 0; cg < NCGA; ++cg)
 #pragma unroll
             for (int s = 0; s < G::GPW; ++s)
-              acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[ky * 4 + kxp][cg], acc[s], 0, 0, 0);
+              acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(bA[ky * 4 + kxp][cg], av[s][cg], acc[s], 0, 0, 0);
         }
       }
       if (fill) {  // uniform: raw sums -> cache, then the folded scale / shift
@@ -946,50 +960,44 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
           // rows 0..17 (16 / 17 are computed identically by the tile below) and column groups 0..3;
           // group 4 (pairs 2, 3 reach past the staged window) belongs to the tile on the right, except
           // in the last tile column, where those pairs lie outside the image
-          const bool mine = (4 * gr + qo < G::AHS) & ((gc < 4) | (tx0 + G::TW >= a.W));
+          const bool mine = (4 * gr + qA < G::AHS) & ((gc < 4) | (tx0 + G::TW >= a.W));
           const int off = mine ? tile_c + slot_c[s] + lane_c : 0x7fffffff;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[s]), rc, off, 0, 0);
-          acc[s] = acc[s] * scA + shA;
+          acc[s] = acc[s] * scA4 + shA4;
         }
       }
 #pragma unroll
       for (int s = 0; s < G::GPW; ++s) {
         const int gi = wave + 4 * s;
         const int gr = gi / G::AGX, gc = gi - gr * G::AGX;
-        const bool live = (gi < G::NGA) & (4 * gr + qo < G::AHS);
-        float o[4];
+        const bool live = (gi < G::NGA) & (4 * gr + qA < G::AHS);
+        float o[4];  // channels coA0 .. coA0 + 3 of the pixel (row 4 gr + qA, column 8 gc + 2 rA + pA) of the region
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[s][r], loA);
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(acc[s][j], loA);
         if (!interior) {  // outside the image the intermediate is layer B's SAME padding: zero
-          const int Y = ty0 - 1 + 4 * gr + qo;
-          const bool yok = (Y >= 0) & (Y < a.H);
+          const int Y = ty0 - 1 + 4 * gr + qA, X = tx0 - 2 + 8 * gc + 2 * rA + pA;
+          const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int X = tx0 - 2 + 8 * gc + 2 * r + p;
-            o[r] = (yok & (X >= 0) & (X < a.W)) ? o[r] : 0.f;
-          }
+          for (int j = 0; j < 4; ++j) o[j] = ok ? o[j] : 0.f;
         }
+        const int pix = (4 * gr + qA) * G::AW + 8 * gc + 2 * rA + pA;
         if constexpr (SPLIT) {
-          // three bf16 tiles [pixel][channel]: this lane's four values are channel co of pixels (row qo, col 2 r + p)
+          // three bf16 tiles [pixel][channel]: the lane's four channels are 8 contiguous bytes of the pixel's record in each
           unsigned H01, M01, L01, H23, M23, L23;
           split3_pair(o[0], o[1], H01, M01, L01);
           split3_pair(o[2], o[3], H23, M23, L23);
           if (live) {
-            unsigned char *d0 = reinterpret_cast<unsigned char *>(tmid) + ((4 * gr + qo) * G::AW + 8 * gc + p) * 16 + co * 2;
-            const unsigned hs[4] = {H01 & 0xffffu, H01 >> 16, H23 & 0xffffu, H23 >> 16};
-            const unsigned ms[4] = {M01 & 0xffffu, M01 >> 16, M23 & 0xffffu, M23 >> 16};
-            const unsigned ls[4] = {L01 & 0xffffu, L01 >> 16, L23 & 0xffffu, L23 >> 16};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              *reinterpret_cast<unsigned short *>(d0 + r * 32) = (unsigned short)hs[r];
-              *reinterpret_cast<unsigned short *>(d0 + r * 32 + PLANE_B) = (unsigned short)ms[r];
-              *reinterpret_cast<unsigned short *>(d0 + r * 32 + 2 * PLANE_B) = (unsigned short)ls[r];
-            }
+            typedef unsigned u32x2t __attribute__((ext_vector_type(2)));
+            unsigned char *d0 = reinterpret_cast<unsigned char *>(tmid) + pix * 16 + coA0 * 2;
+            *reinterpret_cast<u32x2t *>(d0) = u32x2t{H01, H23};
+            *reinterpret_cast<u32x2t *>(d0 + PLANE_B) = u32x2t{M01, M23};
+            *reinterpret_cast<u32x2t *>(d0 + 2 * PLANE_B) = u32x2t{L01, L23};
           }
         } else if (live) {
-          float *dst = tmid + (4 * gr * G::AW + 8 * gc) * 8 + lane_mid;
+          // float32 tile, records [ksub][cg] (channel c at 2 (c & 3) + (c >> 2)): this lane's channels sit two floats apart
+          float *dst = tmid + pix * 8 + (ksub & 1);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[r * 16] = o[r];
+          for (int j = 0; j < 4; ++j) dst[2 * j] = o[j];
         }
       }
     }
@@ -1111,7 +1119,7 @@ int launch8(const PArgs &a_in, int B, hipStream_t st) {
 }
 
 // Timestep-invariant partial sums of the N-packed pair's layer A (see conv_pair8_mfma, CACHED):
-//   S[b][Y+1][gx][n = p*8 + co][r] = sum_{ky,kx} sum_{ci != plane_chan} x[b][Y+ky-1][X+kx-1][ci] * W[ky][kx][ci][co]
+//   S[b][Y+1][gx][r][n = p*8 + co] = sum_{ky,kx} sum_{ci != plane_chan} x[b][Y+ky-1][X+kx-1][ci] * W[ky][kx][ci][co]
 // with X = 8*gx - 2 + 2*r + p (SAME zero padding; 0 for pixels outside the image), i.e. exactly
 // the float4 a lane of phase A initialises its accumulator with.  The cache must be zero-filled when
 // allocated: entries outside the image are never written.
@@ -1151,14 +1159,14 @@ __global__ __launch_bounds__(256) void first_cache_kernel(const float *x, const 
   for (int co = 0; co < 8; ++co) sm[yl][xl][co] = acc[co];
   __syncthreads();
   for (int e = threadIdx.x; e < 4 * 8 * 16; e += 256) {
-    const int n = e & 15, g = (e >> 4) & 7, row = e >> 7;
-    const int p = n >> 3, co = n & 7;
+    const int n4 = e & 3, r = (e >> 2) & 3, g = (e >> 4) & 7, row = e >> 7;  // columns n = 4 n4 .. 4 n4 + 3 of pair r
+    const int p = n4 >> 1, co0 = 4 * (n4 & 1);
     const int Yo = blockIdx.y * 4 + row, gx = blockIdx.x * 8 + g;
     if (Yo < H && gx < ngx) {
       f32x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = sm[row][8 * g + 2 * r + p][co];
-      *reinterpret_cast<f32x4 *>(cache + ((((size_t)b * rows + (Yo + 1)) * ngx + gx) * 16 + n) * 4) = o;
+      for (int j = 0; j < 4; ++j) o[j] = sm[row][8 * g + 2 * r + p][co0 + j];
+      *reinterpret_cast<f32x4 *>(cache + (((size_t)b * rows + (Yo + 1)) * ngx + gx) * 64 + r * 16 + 4 * n4) = o;
     }
   }
 }

@@ -391,7 +391,12 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) bA[tap][cg] = a.wpA[(size_t)((tap * 2 + cg) * 4 + ksub) * a.CoutAP + m];
   }
-  const float scA = a.scA[m], shA = a.shA[m];
+  // Layer A's MFMAs run with the operands swapped (filter = A operand, window pixels = B operand: the same lane contents, the
+  // other argument order), so a lane's accumulator holds channels 4 ksub .. 4 ksub + 3 of ONE window pixel (16 g + m) instead of
+  // one channel of four pixels: two 8-byte LDS stores and one bounds check per group instead of four 4-byte stores and four checks
+  f32x4 scA4, shA4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) scA4[j] = a.scA[4 * ksub + j], shA4[j] = a.shA[4 * ksub + j];
   const float loA = a.reluA ? 0.f : -__builtin_inff();
   // layer B: this wave's row p of the transformed filters (one block of 16 output channels)
   float bw[4][KK];
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
             for (int pc = 0; pc < 3; ++pc) av[pc] = *reinterpret_cast<const s16x8w *>(tb + ain[s] + toff[blk] + pc * PLB);
 #pragma unroll
             for (int t = 0; t < 6; ++t)
-              acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, av[PA[t]]), __builtin_bit_cast(bf16x8w, wA[blk][PB[t]]),
+              acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, wA[blk][PB[t]]), __builtin_bit_cast(bf16x8w, av[PA[t]]),
                                                                acc[s], 0, 0, 0);
           }
       } else {
@@ -512,24 +517,27 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
 #pragma unroll
         for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
-          for (int s = 0; s < GPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][cg], bA[tap][cg], acc[s], 0, 0, 0);
+          for (int s = 0; s < GPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(bA[tap][cg], av[s][cg], acc[s], 0, 0, 0);
       }
       }
 #pragma unroll
       for (int s = 0; s < GPW; ++s) {
         const int g = p + 4 * s;
         if (g < NGA) {  // wave-uniform
+          const int li = 16 * g + m;  // D^T column m of the group = window pixel li; rows 4 ksub + j = its channels
+          f32x4 o = acc[s] * scA4 + shA4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int li = 16 * g + 4 * ksub + r;  // D row 4 * ksub + r of the group = window pixel li
-            float o = fmaxf(acc[s][r] * scA + shA, loA);
-            if (!interior) {
-              const int wr = li / WS, wc = li - wr * WS;
-              const int Y = oyA + wr, X = oxA + wc;
-              o = ((Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W)) ? o : 0.f;
-            }
-            tin[li * S + m] = o;  // li >= NPA: the slack behind the window
+          for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], loA);
+          if (!interior) {
+            const int wr = li / WS, wc = li - wr * WS;
+            const int Y = oyA + wr, X = oxA + wc;
+            const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = ok ? o[j] : 0.f;
           }
+          float *d = tin + li * S + 4 * ksub;  // li >= NPA: the slack behind the window; S = 18: 8-byte aligned
+          *reinterpret_cast<f32x2 *>(d) = f32x2{o[0], o[1]};
+          *reinterpret_cast<f32x2 *>(d + 2) = f32x2{o[2], o[3]};
         }
       }
     }

@@ -18,6 +18,7 @@ of the training graph (full_model.py:913-1097) is available as outputs too (`los
 `match`, ... — Model.LOSS_OUTPUTS; csrc/ra_loss.hip).  `train_step` (backward + Adam,
 full_model.py:1039-1057) lives in ra_train.py.
 """
+import os
 import numpy as np
 import torch
 
@@ -390,7 +391,9 @@ class DecodePipeline(object):
   def _make_slots(self):
     proto = self.model.engine
     self.slots = []
-    streams = [torch.cuda.Stream() for _ in range(self.streams)]
+    # RA_PIPE_PRIO: probing aid — "a,b,c,d" stream priorities (0 normal, -1 high) of the slots' streams
+    prios = [int(v) for v in os.environ.get('RA_PIPE_PRIO', '').split(',') if v.strip()]
+    streams = [torch.cuda.Stream(priority=prios[k % len(prios)]) if prios else torch.cuda.Stream() for k in range(self.streams)]
     for k in range(self.depth):
       eng = ra_engine.DecodeEngine(proto.d, self.model, box_model=proto.box)
       for flag in ('fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score',

@@ -1,9 +1,8 @@
-run() { echo "$1: $(eval "$2 timeout 300 python bench.py --steps 200 --warmup 8 --no-train-object --no-cpu-baseline $3" 2>gpurun_out/sw.err > gpurun_out/sw.json; python tools/bench_line.py gpurun_out/sw.json)"; }
-run "base t0" "RA_ENGINE_TICKETS=0" ""
-run "fuse-patch-pairs t0" "RA_ENGINE_TICKETS=0" "--fuse-patch-pairs"
-run "fuse-patch-pairs t1" "RA_ENGINE_TICKETS=1" "--fuse-patch-pairs"
-run "fuse extract conv0 t0" "RA_ENGINE_TICKETS=0 RA_FUSE_EXTRACT_CONV0=1" ""
-run "coalesce 4, in-flight 16, t0" "RA_ENGINE_TICKETS=0" "--coalesce 4 --in-flight 16"
-run "coalesce 4, in-flight 16, t1" "RA_ENGINE_TICKETS=1" "--coalesce 4 --in-flight 16"
-run "coalesce 3, in-flight 12, t1" "RA_ENGINE_TICKETS=1" "--coalesce 3 --in-flight 12"
-run "coalesce 2, in-flight 8, 3 streams t1" "RA_ENGINE_TICKETS=1" "--streams 3"
+run() { echo "$1: $(eval "$2 timeout 300 python bench.py --steps 240 --warmup 8 --no-train-object --no-cpu-baseline $3" 2>gpurun_out/sw.err > gpurun_out/sw.json; python tools/bench_line.py gpurun_out/sw.json 2>/dev/null || tail -2 gpurun_out/sw.err)"; }
+python -c "import torch; print(torch.cuda.Stream.priority_range())"
+run "base" "" ""
+run "prio -1,0,0,0" "RA_PIPE_PRIO=-1,0,0,0" ""
+run "prio -1,-1,0,0" "RA_PIPE_PRIO=-1,-1,0,0" ""
+run "prio -1,0,-1,0" "RA_PIPE_PRIO=-1,0,-1,0" ""
+run "prio -1 all" "RA_PIPE_PRIO=-1" ""
+run "prio -1,0,0,0 tickets" "RA_PIPE_PRIO=-1,0,0,0 RA_ENGINE_TICKETS=1" ""
