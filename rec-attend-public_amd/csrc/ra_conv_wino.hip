@@ -200,23 +200,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const WArgs a, int tile
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[q][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[q][kk][nb], acc[q][nb], 0, 0, 0);
+            acc[q][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[q][kk][nb], v[q], acc[q][nb], 0, 0, 0);  // D^T: rows = couts, columns = tiles
       }
       if (mblk + 1 < NMB) {
 #pragma unroll
         for (int i = 0; i < N1; ++i) store_rows(4 * mblk + 6, 4, i, vn[i]);
       }
-      // q half of A^T: T[p][0] = M0 + M1 + M2, T[p][1] = M1 - M2 - M3; D rows = tiles 4 * ksub + r, col = cout
+      // q half of A^T: T[p][0] = M0 + M1 + M2, T[p][1] = M1 - M2 - M3.  The MFMAs ran with the operands swapped (filter = A
+      // operand), so a lane holds couts 4 ksub .. 4 ksub + 3 of tile m: one 16-byte store per half instead of four 4-byte ones
       if (mblk) __syncthreads();  // the previous row block's exchange has been consumed
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const f32x4 t0 = acc[0][nb] + acc[1][nb] + acc[2][nb];
         const f32x4 t1 = acc[1][nb] - acc[2][nb] - acc[3][nb];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          tex[((p * 2 + 0) * 16 + 4 * ksub + r) * TEX + 16 * nb + m] = t0[r];
-          tex[((p * 2 + 1) * 16 + 4 * ksub + r) * TEX + 16 * nb + m] = t1[r];
-        }
+        *reinterpret_cast<f32x4 *>(&tex[((p * 2 + 0) * 16 + m) * TEX + 16 * nb + 4 * ksub]) = t0;
+        *reinterpret_cast<f32x4 *>(&tex[((p * 2 + 1) * 16 + m) * TEX + 16 * nb + 4 * ksub]) = t1;
       }
       __syncthreads();
       // p half of A^T + BN + ReLU + pool for the 16 x CO (tile, cout) pairs of the row block, NB per thread
@@ -340,6 +338,31 @@ __device__ inline void split3_pairw(float a, float b, unsigned &H, unsigned &M, 
   rb -= __builtin_bit_cast(float, M & 0xffff0000u);
   L = pk_bf16w(ra, rb);
 }
+// tools/pairw_probe.hip builds this file with -DRA_PROBEW: wave 0 of every workgroup accumulates the shader-clock time between a
+// few points of conv_pair_wino_mfma's tile loop and leaves the sums in ra_probew_buf[workgroup][8] (as RA_PROBE8 in ra_conv_pair.hip)
+#ifdef RA_PROBEW
+__device__ long long *ra_probew_buf;
+#define RA_PW_DECL long long pw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pw_t = (long long)__builtin_readcyclecounter(), pw_t0 = (long long)wall_clock64()
+#define RA_PW_AT(k)                                                \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const long long n_ = (long long)__builtin_readcyclecounter();  \
+    pw_acc[k] += n_ - pw_t;                                        \
+    pw_t = n_;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#define RA_PW_END                                                                    \
+  do {                                                                               \
+    if (threadIdx.x == 0 && ra_probew_buf) {                                         \
+      pw_acc[7] = (long long)wall_clock64() - pw_t0;                                 \
+      for (int k_ = 0; k_ < 8; ++k_) ra_probew_buf[(size_t)blockIdx.x * 8 + k_] = pw_acc[k_]; \
+    }                                                                                \
+  } while (0)
+#else
+#define RA_PW_DECL
+#define RA_PW_AT(k)
+#define RA_PW_END
+#endif
 template <int TSY, bool SPLIT = false>
 __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 2) void conv_pair_wino_mfma(const PWArgs a, int tiles_x, int tiles_y, int ntiles) {
   constexpr int CINA = 8, CMID = 16, KK = CMID / 4, S = CMID + 2, NMB = TSY / 4;
@@ -446,10 +469,12 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
     tile = tk.cur >= 0 ? tk.cur : t_end;
   }
   if (tile < t_end) fetch(tile);
+  RA_PW_DECL;
   for (; tile < t_end; tile = tnext) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     __syncthreads();  // the previous tile's phase B (exchange reads) is complete
+    RA_PW_AT(0);  // top barrier
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int e = tid + 256 * i, cg = e & 1, pix = e >> 1;
@@ -473,6 +498,7 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
     }
     if (dyn) tk.publish(tk_sh);
     __syncthreads();
+    RA_PW_AT(1);  // staged (split into three bf16 tiles) + barrier
     if (dyn) {
       tk.read_next(tk_sh);
       tk.request();  // older than the prefetch loads below: consumed with them at the next tile's staging
@@ -520,6 +546,7 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
           for (int s = 0; s < GPW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(bA[tap][cg], av[s][cg], acc[s], 0, 0, 0);
       }
       }
+      RA_PW_AT(2);  // layer A's MFMAs
 #pragma unroll
       for (int s = 0; s < GPW; ++s) {
         const int g = p + 4 * s;
@@ -541,7 +568,9 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
         }
       }
     }
+    RA_PW_AT(3);  // layer A's epilogue -> tin
     __syncthreads();
+    RA_PW_AT(4);  // barrier
 
     // ---------------- phase B: Winograd F(2x2, 3x3) out of tin (see conv_wino_mfma) ----------------
 #pragma unroll 1
@@ -559,17 +588,15 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
         for (int j = 0; j < 4; ++j) r[j] = pa[j * S + 4 * kk] + sg * pb[j * S + 4 * kk];
         const float v[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], bw[q][kk], acc[q], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[q][kk], v[q], acc[q], 0, 0, 0);  // D^T (see conv_wino_mfma)
       }
+      RA_PW_AT(5);  // phase B: input transform + 16 MFMAs of the row block
       if (mblk) __syncthreads();  // the previous row block's exchange has been consumed
       {
         const f32x4 t0 = acc[0] + acc[1] + acc[2];
         const f32x4 t1 = acc[1] - acc[2] - acc[3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          tex[((p * 2 + 0) * 16 + 4 * ksub + r) * TEXP + m] = t0[r];
-          tex[((p * 2 + 1) * 16 + 4 * ksub + r) * TEXP + m] = t1[r];
-        }
+        *reinterpret_cast<f32x4 *>(&tex[((p * 2 + 0) * 16 + m) * TEXP + 4 * ksub]) = t0;  // couts 4 ksub .. + 3 of tile m
+        *reinterpret_cast<f32x4 *>(&tex[((p * 2 + 1) * 16 + m) * TEXP + 4 * ksub]) = t1;
       }
       __syncthreads();
       {
@@ -588,8 +615,10 @@ __global__ __launch_bounds__(256, TSY == 8 ? (SPLIT ? RA_PAIRW_SPLIT_OCC : 4) : 
         const int oty = ty * (TSY / 2) + 2 * mblk + (tl >> 3), otx = tx * 8 + (tl & 7);
         a.y[((size_t)(b * Ho + oty) * Wo + otx) * 16 + eco] = best;
       }
+      RA_PW_AT(6);  // phase B: exchange, output transform, BN + ReLU + pool, store
     }
   }
+  RA_PW_END;
 }
 
 template <int TSY, bool SPLIT = false>
