@@ -297,7 +297,11 @@ int ra_controller_f32(const ra_ctrl_desc *d, const float *feat /*[B,G,Cf]*/, con
  * activation vectors through 8-byte {tag, value} granules in `ws` (device, must be zero-filled
  * ONCE when allocated; generation-tagged, so graph replays need no memset; one workspace per
  * concurrently running launch).  Same results up to float32 summation order.  B <= 14.
- * status_dev (nullable): set to 1 if a peer workgroup timed out. */
+ * status_dev (nullable): set to 1 if a peer workgroup timed out.  * Round 5: where the device's workgroups report the XCC ids 0..7, the launch is a 1-D grid whose workgroups draw their (image,
+ * slice) role from a per-XCD ticket (behind the images' granules in `ws`: ra_ctrl_split_workspace_bytes includes it), so that
+ * the 16 workgroups of an image share ONE XCD's L2 and exchange through plain stores and L1-bypassing loads instead of
+ * agent-scope atomics: 63 -> 57 us per launch at cfg2.  RA_CTRL_XCD=0 selects the grid (16, B) form.  Same results bit for bit.
+*/
 int ra_ctrl_split_supported(const ra_ctrl_desc *d);
 size_t ra_ctrl_split_packed_floats(const ra_ctrl_desc *d);
 size_t ra_ctrl_split_workspace_bytes(const ra_ctrl_desc *d, int B);

@@ -37,14 +37,13 @@ __global__ __launch_bounds__(64) void xcc_census_kernel(int *seen) {
 }
 // The pools are keyed by HW_REG_XCC_ID 0..7: a device (or partition mode) whose workgroups do not land on exactly those eight
 // XCDs would leave pools undrawn, so tickets are only handed out where a census launch has seen all eight and nothing else.
-int tickets_supported() {
+}  // namespace
+int xcc_census_ok() {
   static int ok = -1;
   if (ok < 0) {
-    const char *e = getenv("RA_TILE_TICKETS");
-    if (e && atoi(e) == 0) return ok = 0;
     int *seen = nullptr, h = 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;  // decide outside a capture
+    if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;  // decide outside a capture
     if (hipMalloc(&seen, sizeof(int)) != hipSuccess) return ok = 0;
     (void)hipMemset(seen, 0, sizeof(int));
     hipLaunchKernelGGL(xcc_census_kernel, dim3(1024), dim3(64), 0, nullptr, seen);
@@ -53,6 +52,12 @@ int tickets_supported() {
     ok = (good && h == 0xff) ? 1 : 0;
   }
   return ok;
+}
+namespace {
+int tickets_supported() {
+  const char *e = getenv("RA_TILE_TICKETS");
+  if (e && atoi(e) == 0) return 0;
+  return xcc_census_ok() == 1 ? 1 : 0;
 }
 }  // namespace
 unsigned *take_ticket_slots(int n, int grid_x) {

@@ -13,6 +13,8 @@
 // redundantly), the softmax is computed redundantly from the gathered logits.
 // Results are identical in structure to the single-workgroup kernel (same products, different
 // summation grouping; float32 round-off class).
+#include <cstdlib>
+
 #include "ra_common.h"
 
 namespace ra {
@@ -123,6 +125,32 @@ __device__ inline void gather(const u64 *g, int n, unsigned tag, float *dst, int
   __syncthreads();
 }
 
+// XCD-local exchange (the XL form of the per-image kernel): when the 16 workgroups of an image sit on ONE XCD, that XCD's L2 is
+// their coherence point — a granule is a plain 8-byte store (the vector L1 writes through) and a poll is a load that only
+// bypasses the CU's L1 (sc0), 0.3-0.5 us a round instead of the ~2.5 us of an agent-scope exchange through the memory fabric
+// (tools/xcd_barrier_probe.hip; the 13 gathers of a timestep were 37 of the launch's 63 us).
+typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
+__device__ inline void publish_l2(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, float v) {
+  __builtin_amdgcn_raw_buffer_store_b64(u32x2g{__float_as_uint(v), tag}, r, idx * 8, 0, 0);
+}
+__device__ inline void gather_l2(__amdgpu_buffer_rsrc_t r, int first, int n, unsigned tag, float *dst, int *err) {
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    unsigned spins = 0;
+    u32x2g x;
+    while (true) {
+      x = __builtin_amdgcn_raw_buffer_load_b64(r, (first + i) * 8, 0, (int)0x80000001u);  // sc0 (past the L1), volatile
+      if (x.y == tag) break;
+      if (++spins > kSpinLimit) {
+        *err = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    dst[i] = __uint_as_float(x.x);
+  }
+  __syncthreads();
+}
+
 __device__ inline float sigm(float z) { return 1.0f / (1.0f + expf(-z)); }
 
 __device__ float block_reduce(float v, bool is_max, float *red4) {
@@ -173,14 +201,31 @@ __device__ inline int any_gemv(const float *Wm, int n, const float *x, int K, fl
   return parts;
 }
 
-template <int FR>  // feature registers per thread = ceil(G*Cf / 256)
+// XL = false: grid (16, B), workgroup (p, b) = blockIdx; the image's workgroups are dealt over all eight XCDs and exchange
+// through agent-scope atomics.  XL = true: a 1-D grid of 128 * ceil(B / 8) workgroups (the dispatcher deals them to the XCDs
+// round robin: 16 * ceil(B / 8) each); a workgroup on XCD x draws a role from x's ticket counter (L2-local atomic; the
+// counter only ever counts up, roles are tickets modulo the XCD's share) and becomes slice p of image b = x + 8 j — every
+// image's team shares one L2.  Teams of images >= B leave at once.
+template <int FR, bool XL = false>  // FR: feature registers per thread = ceil(G*Cf / 256)
 __global__ __launch_bounds__(kThreads) void controller_split_kernel(
     const ra_ctrl_desc d, const float *feat, const float *__restrict__ wp, float *h_last,
-    float *ctrl_out, float *gmaps, float *attn, unsigned *ws, int *status, int prio) {
+    float *ctrl_out, float *gmaps, float *attn, unsigned *ws, int *status, int prio, int B, unsigned *tickets) {
   raise_prio(prio);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Layout L = layout(d);
-  const int t = threadIdx.x, p = blockIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x;
+  int p = blockIdx.x, b = blockIdx.y;
+  if constexpr (XL) {
+    unsigned *role_sh = reinterpret_cast<unsigned *>(smem);  // (dynamic LDS: the launch's 160 KB limit leaves no static word)
+    const int x = xcc_id(), share = kP * ((B + 7) >> 3);
+    if (t == 0) *role_sh = ticket_draw(tickets + x * kTicketPoolStride) % (unsigned)share;
+    __syncthreads();
+    const int role = (int)*role_sh;
+    __syncthreads();  // read by all before the weight slice overwrites it
+    p = role % kP;
+    b = x + 8 * (role / kP);
+    if (b >= B) return;  // (the whole team)
+  }
   const int G = d.G, Cf = d.Cf, hid = d.hid, us = L.us, gs = L.gs, K = L.K;
   const int Gx = kP * gs;  // logits exchanged (>= G; tail slices hold padding)
   // LDS carve
@@ -193,7 +238,16 @@ __global__ __launch_bounds__(kThreads) void controller_split_kernel(
   unsigned *wsb = ws + (size_t)b * ws_words_per_image(d);
   const unsigned tag = wsb[0] + 1u;
   u64 *gran = reinterpret_cast<u64 *>(wsb + 2);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gran, 0, (int)(granules_per_image(d) * 8), 0x00020000);
   int err = 0;
+  auto pub = [&](size_t idx, float v) {
+    if constexpr (XL) publish_l2(grs, (int)idx, tag, v);
+    else publish(gran + idx, tag, v);
+  };
+  auto gat = [&](size_t first, int n, float *dst) {
+    if constexpr (XL) gather_l2(grs, (int)first, n, tag, dst, &err);
+    else gather(gran + first, n, tag, dst, &err);
+  };
 
   {  // weight slice -> LDS (stays for the whole launch)
     // batches of 16 independent 16-byte loads per thread: the fill is latency-, not
@@ -267,9 +321,9 @@ __global__ __launch_bounds__(kThreads) void controller_split_kernel(
       }
       const float gi = sigm(pre[0]), gf = sigm(pre[1]), go = sigm(pre[2]), u = tanhf(pre[3]);
       cst = gf * cst + gi * u;
-      publish(gran + goff + p * us + t, tag, go * tanhf(cst));
+      pub(goff + p * us + t, go * tanhf(cst));
     }
-    gather(gran + goff, hid, tag, xh + Cf, &err);
+    gat(goff, hid, xh + Cf);
     goff += hid;
     if (it == d.iters - 1) break;
     // ---- glimpse MLP hidden layers (relu) ----
@@ -280,9 +334,9 @@ __global__ __launch_bounds__(kThreads) void controller_split_kernel(
         const int parts = kThreads / us;
         float a = W[L.gh_b[l] + t];
         for (int q = 0; q < parts; ++q) a += red[q * us + t];
-        publish(gran + goff + p * us + t, tag, fmaxf(a, 0.0f));
+        pub(goff + p * us + t, fmaxf(a, 0.0f));
       }
-      gather(gran + goff, hid, tag, va, &err);
+      gat(goff, hid, va);
       goff += hid;
       in = va;
     }
@@ -293,9 +347,9 @@ __global__ __launch_bounds__(kThreads) void controller_split_kernel(
       if (t < gs) {
         float a = W[L.gl_b + t];
         for (int q = 0; q < parts; ++q) a += red[q * ncol + t];
-        publish(gran + goff + p * gs + t, tag, a);
+        pub(goff + p * gs + t, a);
       }
-      gather(gran + goff, Gx, tag, gm, &err);
+      gat(goff, Gx, gm);
       goff += Gx;
       float mx = -3.0e38f;
       for (int g = t; g < G; g += kThreads) mx = fmaxf(mx, gm[g]);
@@ -371,15 +425,30 @@ template <int FR>
 int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, float *h_last,
            float *ctrl_out, float *gmaps, float *attn, unsigned *ws, int *status, size_t lds,
            hipStream_t st) {
-  auto kern = controller_split_kernel<FR>;
+  auto kern = controller_split_kernel<FR, false>;
+  auto kern_xl = controller_split_kernel<FR, true>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern_xl),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(kP, B), dim3(kThreads), lds, st, d, feat, wp, h_last, ctrl_out,
-                     gmaps, attn, ws, status, tail_prio(1));
+  // the XCD-local form wherever the device's workgroups report the XCC ids 0..7 (ra_core.hip's census); RA_CTRL_XCD=0: the old one
+  static int xl = -1;
+  if (xl < 0) {
+    const char *e = getenv("RA_CTRL_XCD");
+    if (e && atoi(e) == 0) xl = 0;
+    else if (const int c = xcc_census_ok(); c >= 0) xl = c;  // (-1: asked inside a stream capture — decide at the next launch)
+  }
+  unsigned *tickets = ws + (size_t)B * ws_words_per_image(d);  // 8 pools of kTicketPoolStride words behind the images' granules
+  if (xl == 1)
+    hipLaunchKernelGGL(kern_xl, dim3(8 * kP * ((B + 7) / 8)), dim3(kThreads), lds, st, d, feat, wp, h_last, ctrl_out, gmaps, attn, ws,
+                       status, tail_prio(1), B, tickets);
+  else
+    hipLaunchKernelGGL(kern, dim3(kP, B), dim3(kThreads), lds, st, d, feat, wp, h_last, ctrl_out,
+                       gmaps, attn, ws, status, tail_prio(1), B, tickets);
   return launch_status("ra_controller_split_f32");
 }
 
@@ -728,7 +797,7 @@ extern "C" size_t ra_ctrl_split_packed_floats(const ra_ctrl_desc *d) {
 
 extern "C" size_t ra_ctrl_split_workspace_bytes(const ra_ctrl_desc *d, int B) {
   if (!d || B <= 0 || !ctrl2::supported(*d)) return 0;
-  return (size_t)B * ctrl2::ws_words_per_image(*d) * 4;
+  return ((size_t)B * ctrl2::ws_words_per_image(*d) + 8 * kTicketPoolStride) * 4;  // + the XCD-local form's role tickets
 }
 
 extern "C" int ra_ctrl_split_pack_weights(const ra_ctrl_desc *d, const float *const *lstm_w,
