@@ -12,6 +12,7 @@
 
 namespace ra {
 void set_error(const char *, ...) {}
+int tail_prio(int) { return 0; }
 }  // namespace ra
 
 #define CK(x)                                                              \
@@ -98,7 +99,7 @@ int main(int argc, char **argv) {
     const int n_items = Fh * (Cp / 4) * B, chunk = (n_items + 7) / 8;
     run("extract_rows<4>", 8 * chunk, 4, [&] {
       hipLaunchKernelGGL((extract_rows_kernel<4>), dim3(8 * chunk), dim3(256), 0, 0, img, Ci, 0, canvas, 3, attn, H, W, Fh,
-                         Fw, Cp, 1, patch, n_items, chunk);
+                         Fw, Cp, 1, patch, n_items, chunk, 0);
     });
   }
   for (int flags : {3, 2, 0}) {
@@ -112,13 +113,13 @@ int main(int argc, char **argv) {
     size_t lds = (size_t)4 * 256 * 16 + (size_t)(4 * Fw + Fh * Fw + 16) * 4;
     run(nm, H / 4 * B, 5, [&] {
       hipLaunchKernelGGL((paste_win_kernel<0, 4>), dim3(H / 4, B), dim3(256), lds, 0, ypatch, attn, H, W, Fh, Fw, -5.0f, 0,
-                         canvas, yout, (size_t)2 * H * W, flags, ScoreArgs{});
+                         canvas, yout, (size_t)2 * H * W, flags, ScoreArgs{}, 0);
     });
     snprintf(nm, sizeof nm, "paste_win<0,8> flags=%d", flags);
     lds = (size_t)8 * 256 * 16 + (size_t)(8 * Fw + Fh * Fw + 16) * 4;
     run(nm, H / 8 * B, 5, [&] {
       hipLaunchKernelGGL((paste_win_kernel<0, 8>), dim3(H / 8, B), dim3(256), lds, 0, ypatch, attn, H, W, Fh, Fw, -5.0f, 0,
-                         canvas, yout, (size_t)2 * H * W, flags, ScoreArgs{});
+                         canvas, yout, (size_t)2 * H * W, flags, ScoreArgs{}, 0);
     });
   }
   return 0;

@@ -47,12 +47,16 @@ done
 timeout 900 python bench.py --config cfg3 > $OUT/${R3}_bench_cfg3.json 2>> $OUT/bench.err
 timeout 900 python bench.py --config cfg5 > $OUT/${R3}_bench_cfg5.json 2>> $OUT/bench.err
 timeout 120 tools/bin/attn_probe 8 > $OUT/${R3}_attn_probe.txt 2>&1
-timeout 120 tools/bin/pair8_probe 8 > $OUT/${R3}_pair8_probe.txt 2>&1
+{ timeout 120 tools/bin/pair8_probe 8; timeout 120 tools/bin/pair8_probe 16; [ -x tools/bin/pairw_probe ] && { timeout 120 tools/bin/pairw_probe 8; timeout 120 tools/bin/pairw_probe 16; }; } > $OUT/${R3}_pair_probes.txt 2>&1
 timeout 120 tools/bin/lat_probe 256 > $OUT/${R3}_lat_probe.txt 2>&1
 # round 4: K1 at the training step's full-resolution shapes, the Hungarian launch problem by problem, the one-XCD barrier
 { for shp in "8 8 512 512 8" "4 8 512 512 8" "16 16 256 256 8" "32 32 128 128 8"; do echo "== Cin Cout H W B = $shp"; timeout 120 python tools/conv_shape_bench.py $shp 2>&1 | grep " us "; done; } > $OUT/${R3}_conv_shape_bench.txt
 timeout 300 python tools/hungarian_step_probe.py 2>&1 | tail -3 > $OUT/${R3}_hungarian_step_probe.txt
 [ -x tools/bin/xcd_barrier_probe ] && { timeout 60 tools/bin/xcd_barrier_probe 48; timeout 60 tools/bin/xcd_barrier_probe 16; } > $OUT/${R3}_xcd_barrier_probe.txt 2>&1
 
+# round 5, second session: what the pipeline's slots do to each other (static tile walk / drawn tiles), per launch and as a group
+{ timeout 200 python tools/contention_probe.py 16; RA_ENGINE_TICKETS=1 timeout 200 python tools/contention_probe.py 16; timeout 250 python tools/contention_by_layer.py 16; } 2>&1 | grep -v amdgpu.ids > $OUT/${R3}_contention_probes.txt
+timeout 120 python tools/ctrl_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/${R3}_ctrl_bench.txt
+RA_CTRL_XCD=0 timeout 120 python tools/ctrl_bench.py 2>&1 | grep -v amdgpu.ids | sed 's/^/RA_CTRL_XCD=0  /' >> $OUT/${R3}_ctrl_bench.txt
 [ -x tools/bin/mfma_rate_probe ] && timeout 60 tools/bin/mfma_rate_probe > $OUT/${R3}_mfma_rate_probe.txt 2>&1
 ls -la $OUT
