@@ -146,10 +146,18 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     }
   };
 
-  {  // the filter: a straight 16-byte copy, once per workgroup (issued BEFORE the first window's loads: the other order — the
-     // window in flight across the copy — measured 0.5 us slower at cfg2's L5 / L6)
+  // the filter: a straight 16-byte copy, once per workgroup — ALL of a thread's loads (14 at Cin = 32) issued before its first
+  // LDS store, and the first window's loads behind them, before those stores (as a plain load / store loop the copy was a chain
+  // of dependent L2 round trips at the head of every launch: one workgroup per CU, nothing else to hide it)
+  constexpr int NWQ = G::WBYTES / 16, NWI = (NWQ + 255) / 256;
+  u32x4 wtmp[NWI];
+  {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(a.wp) + (size_t)slice * G::WBYTES);
-    for (int e = tid; e < G::WBYTES / 16; e += 256) reinterpret_cast<u32x4 *>(wl)[e] = src[e];
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int e = tid + 256 * i;
+      wtmp[i] = src[e < NWQ ? e : NWQ - 1];
+    }
   }
   int tile = blockIdx.x, tnext = 0;
   if (dyn) {
@@ -157,6 +165,11 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     tile = tk.cur >= 0 ? tk.cur : ntiles;
   }
   if (tile < ntiles) fetch(tile);
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) {
+    const int e = tid + 256 * i;
+    if (e < NWQ) reinterpret_cast<u32x4 *>(wl)[e] = wtmp[i];
+  }
   for (; tile < ntiles; tile = tnext) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
