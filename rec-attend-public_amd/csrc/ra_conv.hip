@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   int T = blockIdx.x, ch = 0, buf = 0;
   if (T >= ntiles) return;
   load_b(0);
+  load_item(T, 0);  // (ahead of pack_b: the bf16 form's packing waits for the weights — the first tile's loads fly meanwhile)
   pack_b();
-  load_item(T, 0);
   cur_b = org_b, cur_ty0 = org_ty0, cur_tx0 = org_tx0;
   store_item(0);
   zero_acc();
