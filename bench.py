@@ -843,6 +843,18 @@ def main():
                                               'touch the attention window only (traffic 0.26x algorithmic); not a roofline claim'}
     del m32, s32
     torch.cuda.empty_cache()
+    if coalesce > 1 and pipe.slots:
+      # ... and at the size the pipeline's slots launch it (config.batches_per_launch batches per forward)
+      reng_a = pipe.slots[0][0]
+      rsb_a = reng_a.subs[0]
+      rB_a = int(rsb_a['img'].shape[0])
+      rsb_a['attn'][0].copy_(sb['attn'][0][:1].expand(rB_a, -1))  # the bench model's box for every image of the slot
+      tl = attn_times(rsb_a, rB_a, reng_a.W)
+      byl = float(S * S * (d['acnn_channels'][0] + 3) * 4) * rB_a
+      out['roofline_attn']['as_launched'] = {
+          'images_per_launch': rB_a, 'extract_paste_us': tl['net'], 'frac_algorithmic': byl / (tl['net'] * 1e-6) / 1e9 / PEAK_HBM_GBS,
+          'note': 'the same two launches over the %d images of a pipeline slot; algorithmic bytes, as frac (the north star\'s bar '
+                  'is quoted at the configuration\'s B = 8: frac)' % rB_a}
     # the whole post-encoder tail of one timestep exactly as the forward issues it
     tail_us = graph_time_us(lambda: eng._launch_tail(sb, 1, False, sb['ccnn'][-1]))
     out['tail_us'] = tail_us
