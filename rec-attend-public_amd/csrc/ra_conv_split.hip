@@ -72,6 +72,31 @@ __device__ inline void split3_pair(float a, float b, unsigned &H, unsigned &M, u
   L = pk_bf16(ra, rb);
 }
 
+// tools/split_probe.hip builds this file with -DRA_PROBES: wave 0 of every workgroup accumulates the shader-clock time between
+// points of the tile loop (as RA_PROBE8 in ra_conv_pair.hip) and leaves the sums in ra_probes_buf[workgroup][8]
+#ifdef RA_PROBES
+__device__ long long *ra_probes_buf;
+#define RA_PS_DECL long long ps_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps_t = (long long)__builtin_readcyclecounter(), ps_t0 = (long long)wall_clock64()
+#define RA_PS_AT(k)                                                \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const long long n_ = (long long)__builtin_readcyclecounter();  \
+    ps_acc[k] += n_ - ps_t;                                        \
+    ps_t = n_;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#define RA_PS_END                                                                    \
+  do {                                                                               \
+    if (threadIdx.x == 0 && ra_probes_buf) {                                         \
+      ps_acc[7] = (long long)wall_clock64() - ps_t0;                                 \
+      for (int k_ = 0; k_ < 8; ++k_) ra_probes_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k_] = ps_acc[k_]; \
+    }                                                                                \
+  } while (0)
+#else
+#define RA_PS_DECL
+#define RA_PS_AT(k)
+#define RA_PS_END
+#endif
 template <int CIN, int POOL, int NB>
 __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = Geo<CIN, NB>;
@@ -81,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
   unsigned char *tin = lds;               // three bf16 tiles [WSY][WSP][RS]
   unsigned char *wl = lds + 3 * PLANE;    // the slice's filter pieces
   const int tid = threadIdx.x, lane = tid & 63;
+  RA_PS_DECL;
   // dynamic tile tickets (a.tickets): tiles are drawn from this XCD's pool of the channel slice instead of walked
   __shared__ unsigned tk_sh[2];
   TicketWalk tk;
@@ -170,10 +196,12 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     const int e = tid + 256 * i;
     if (e < NWQ) reinterpret_cast<u32x4 *>(wl)[e] = wtmp[i];
   }
+  RA_PS_AT(0);  // prologue: constants, filter copy, first window requested
   for (; tile < ntiles; tile = tnext) {
     const int b = tile / per, trem = tile - b * per;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     __syncthreads();  // the previous tile's operand reads are complete (and, first time round, the filter copy is issued)
+    RA_PS_AT(1);  // top barrier
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       unsigned H0, M0, L0, H1, M1, L1;
@@ -186,8 +214,10 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
         *reinterpret_cast<u32x2 *>(rec + 2 * PLANE) = u32x2{L0, L1};
       }
     }
+    RA_PS_AT(2);  // window arrived, split into three bf16 tiles, stored
     if (dyn) tk.publish(tk_sh);
     __syncthreads();
+    RA_PS_AT(3);  // staging barrier
     if (dyn) {
       tk.read_next(tk_sh);
       tk.request();  // older than the prefetch loads below: consumed with them at the next tile's staging
@@ -225,6 +255,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
                                                                  acc[g][nb], 0, 0, 0);
       }
     }
+    RA_PS_AT(4);  // next window requested + the k-loop (9 blocks x 4 groups x 6 products x NB)
     // epilogue: lane (column n = m, D rows 4 kb + r) holds the four elements r = (dy, dx) of pooling window kb = (wy, wx) of group g
     const int wy = kb >> 1, wx = kb & 1;
 #pragma unroll
@@ -246,7 +277,9 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
           }
         }
       }
+    RA_PS_AT(5);  // epilogue: scale / shift, pool, ReLU, stores issued
   }
+  RA_PS_END;
 }
 
 inline int cu_count() {
