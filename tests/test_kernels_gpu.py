@@ -275,19 +275,23 @@ def test_controller(cuda, arch, H, W, flags):
   assert relerr(a[:, 7], np.exp(co[:, 7])) < 1e-4
 
 
-@pytest.mark.parametrize('arch,H,W,flags', [
-    ('cvppp', 128, 128, {}),
-    ('cvppp', 224, 224, {'squash_ctrl_params': True}),   # G = 49 -> gs = 4, padded logits
-    ('kitti', 128, 448, {}),
-    ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2, 'num_glimpse_mlp_layers': 3}),
-    ('cvppp', 512, 512, {'num_glimpse_mlp_layers': 1}),
+@pytest.mark.parametrize('arch,H,W,flags,B', [
+    ('cvppp', 128, 128, {}, 5),
+    ('cvppp', 224, 224, {'squash_ctrl_params': True}, 5),   # G = 49 -> gs = 4, padded logits
+    ('kitti', 128, 448, {}, 5),
+    ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2, 'num_glimpse_mlp_layers': 3}, 5),
+    ('cvppp', 512, 512, {'num_glimpse_mlp_layers': 1}, 5),
+    ('cvppp', 512, 512, {}, 8),    # the XCD-local form: one team of 16 workgroups on every XCD
+    ('cvppp', 512, 512, {}, 11),   # ... two teams on three XCDs, one on five
+    ('cvppp', 128, 128, {}, 14),   # ... the residency limit: 224 workgroups of the 256 launched take a role
+    ('cvppp', 128, 128, {}, 1),
 ])
-def test_controller_split(cuda, arch, H, W, flags):
+def test_controller_split(cuda, arch, H, W, flags, B):
   """The 16-workgroup LDS-stationary controller: same maths, exchanged through tagged granules;
-  launched three times on the same workspace (generation tags, as under HIP-graph replay)."""
+  launched three times on the same workspace (generation tags, as under HIP-graph replay; the XCD-local form's role
+  tickets only ever count up)."""
   opt = ora.make_opt(arch, H, W, 2, **flags)
   d, P = _ctrl_setup(opt, 4)
-  B = 5
   Cf = d['ccnn_channels'][-1]
   desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
                             opt['ctrl_mlp_dim'], H, W, 48, 48, d['squash'], d['fixed_var'],
