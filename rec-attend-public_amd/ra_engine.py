@@ -573,7 +573,13 @@ class DecodeEngine(object):
         np.ascontiguousarray(a, dtype=np.float32))).to(device=device, dtype=torch.float32)
     x = as_t(x)
     B = x.shape[0]
-    self.prepare(device)
+    # The weights' stamp (data pointer and version of each of ~1 400 tensors: 0.5 ms of host time at cfg2) is compared AFTER
+    # the launch, while the GPU decodes: a forward that finds changed weights is prepared and launched again on the same
+    # stream before anything is returned (the stale run's outputs are overwritten in stream order).  Only the first forward
+    # and a forward after _stamp was reset prepare first.
+    late_check = self._stamp is not None
+    if not late_check:
+      self.prepare(device)
     self.alloc(B, device)
     b = self.glob
     b['x'].copy_(x)
@@ -592,6 +598,13 @@ class DecodeEngine(object):
         sb['noise'].copy_(b['noise'][:, k * Bs:(k + 1) * Bs])
         sb['box_gt'] = ops.gt_box(sb['y_gt'].contiguous(), float(self.d['attn_box_padding_ratio']), 10.0)[1]
     self._last_want_box = bool(want_box)
+    self._launch_forward(want_box)
+    if late_check and self._weights_stamp() != self._stamp:
+      self.prepare(device)  # new packed weights, graphs dropped
+      self._launch_forward(want_box)
+    return self
+
+  def _launch_forward(self, want_box):
     graphable = self.use_graph and self.timing is None
     if not graphable:
       self._launch_all(want_box)

@@ -143,6 +143,19 @@ def test_weights_reload_invalidates_packing(cuda):
     y = m.run('y_out', {'x': x, 'phase_train': False}, as_numpy=True)
     ref = ora.full_model_forward(opt, P, x)
     assert np.abs(y - ref['y_out']).max() < MASK_TOL
+  # the engine compares the weights' stamp AFTER it has launched (the host work hides behind the GPU) and launches again if it
+  # changed: an in-place edit of one tensor between two forwards — graph captured, same buffers — must show in the second one
+  key = 'ctrl_mlp_b_0'
+  P = dict(P)
+  b = np.array(P[key], copy=True)
+  b[0:2] += 0.3
+  P[key] = b
+  with torch.no_grad():
+    m[key].copy_(torch.as_tensor(b).to(m[key].device, m[key].dtype).reshape(m[key].shape))
+  y = m.run('y_out', {'x': x, 'phase_train': False}, as_numpy=True)
+  ref2 = ora.full_model_forward(opt, P, x)
+  assert np.abs(y - ref2['y_out']).max() < MASK_TOL
+  assert np.abs(ref2['y_out'] - ref['y_out']).max() > 10 * MASK_TOL  # (the edit does move the masks)
 
 
 def test_box_model(cuda):
