@@ -132,10 +132,46 @@ class Model(dict):
 
   def __init__(self, opt, dims, box_model=False):
     dict.__init__(self)
+    self._mut = 0
     self.opt = dict(opt)
     self.dims = dims
     self.box_model = box_model
     self.engine = None
+
+  # every change of the dict itself is counted (`_mut`): the decode engine re-packs its weights when an entry is replaced or a
+  # tensor is modified in place, and tells the two apart cheaply — this counter, and the sum of the tensors' version counters
+  def __setitem__(self, k, v):
+    self._mut += 1
+    dict.__setitem__(self, k, v)
+
+  def __delitem__(self, k):
+    self._mut += 1
+    dict.__delitem__(self, k)
+
+  def update(self, *a, **kw):
+    self._mut += 1
+    dict.update(self, *a, **kw)
+
+  def setdefault(self, k, default=None):
+    self._mut += 1
+    return dict.setdefault(self, k, default)
+
+  def pop(self, *a):
+    self._mut += 1
+    return dict.pop(self, *a)
+
+  def popitem(self):
+    self._mut += 1
+    return dict.popitem(self)
+
+  def clear(self):
+    self._mut += 1
+    dict.clear(self)
+
+  def __ior__(self, other):
+    self._mut += 1
+    dict.update(self, other)
+    return self
 
   def weight_keys(self):
     return sorted(k for k, v in self.items() if isinstance(v, torch.Tensor))
