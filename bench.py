@@ -248,9 +248,10 @@ def bench_other(args, rank, world, name):
   feed['y_gt'] = y_gt.cuda()
   per = args.part_images or B
   parts = -(-B // per)
-  depth = max(parts, max(1, args.in_flight) // len(models))
+  co = max(1, args.coalesce)  # submitted batches one slot decodes as ONE forward (DecodePipeline(coalesce=...))
+  depth = max(parts, max(1, args.in_flight) // len(models) // co)
   per_stage = max(1, args.streams // len(models)) if args.streams else None  # HIP streams per stage (default min(depth, 4))
-  pipes = [(st, m.pipeline(depth, max_images=per, co_resident=min(depth, per_stage or 4) * len(models), streams=per_stage))
+  pipes = [(st, m.pipeline(depth, max_images=per * co, co_resident=min(depth, per_stage or 4) * len(models), streams=per_stage, coalesce=co))
            for st, m in models]
 
   def step():
@@ -263,7 +264,7 @@ def bench_other(args, rank, world, name):
     for _, pipe in pipes:
       pipe.drain()
 
-  for _ in range(max(args.warmup, 2 * depth)):
+  for _ in range(max(args.warmup, 2 * depth * co)):
     step()
   drain()
   ra_dist.barrier()
@@ -284,7 +285,7 @@ def bench_other(args, rank, world, name):
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s' % (name, c['what']), 'arch': c['arch'], 'H': H, 'W': W, 'T': T,
                    'batch_per_gpu': B, 'stages': list(c['stages']), 'parts_per_batch': parts,
-                   'parts_in_flight': depth * len(pipes),
+                   'parts_in_flight': depth * len(pipes) * co, 'batches_per_launch': co,
                    'controller': ('group-shared (16 workgroups per %d images)' % ops_group(pipes[-1][1].slots[0][0]) if pipes[-1][1].slots[0][0].subs[0].get('ctrl_batch')
                                   else 'split (16 workgroups per image)' if 'ctrl_ws' in pipes[-1][1].slots[0][0].subs[0]
                                   else 'single workgroup per image')}}))
@@ -445,10 +446,10 @@ def main():
   ap.add_argument('--streams', type=int, default=0, help='HIP streams the in-flight batches share (default: min(in-flight, 4))')
   ap.add_argument('--in-flight', type=int, default=0,
                   help='batches decoding concurrently per GPU (DecodePipeline depth; 1 = one after the other; '
-                       'default: 8 at cfg2 (on 4 streams), 6 at cfg3 over its two stages, 2 at cfg5)')
+                       'default: 8 (at cfg2 on 4 streams; at cfg3 over its two stages))')
   ap.add_argument('--coalesce', type=int, default=0,
                   help='consecutively submitted batches one pipeline slot decodes as ONE forward (DecodePipeline(coalesce=...)); '
-                       'default: 2 at cfg2 (four slots of 2 x 8 images for the 8 batches in flight), 1 elsewhere')
+                       'default: 2 at cfg2 (four slots of 2 x 8 images for the 8 batches in flight), 2 at cfg3 (2 x 16), 4 at cfg5 (4 x 4)')
   ap.add_argument('--nsub', type=int, default=0, help='stream-parallel sub-batches (0 = auto)')
   ap.add_argument('--no-fuse-score', action='store_true', help='tuning aid: score MLP as its own launch')
   ap.add_argument('--host-output', action='store_true',
@@ -473,7 +474,11 @@ def main():
                        'data-parallel, one RCCL all-reduce of the gradient bucket per step); prints its own JSON line')
   args = ap.parse_args()
   if args.in_flight <= 0:
-    args.in_flight = {'cfg2': 8, 'cfg3': 6, 'cfg5': 2}[args.config]
+    args.in_flight = {'cfg2': 8, 'cfg3': 8, 'cfg5': 8}[args.config]  # eight submitted batches decoding, as at cfg2
+  if args.coalesce <= 0 and args.config != 'cfg2':
+    # cfg3 / cfg5 (round 5, second session): coalesced slots as at cfg2 — 2 x 16 images per forward at cfg3, 4 x 4 at cfg5
+    # (32.3k -> 38.2k and 17.9k -> 30.7k instance-timesteps/s; `--coalesce 1 --in-flight 6|2` = the protocol of rounds 2-5a)
+    args.coalesce = {'cfg3': 2, 'cfg5': 4}[args.config]
 
   import ra_dist
   if int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.gpus > 1:

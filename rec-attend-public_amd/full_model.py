@@ -612,7 +612,13 @@ class DecodePipeline(object):
 
   def drain(self):
     """Wait for every batch in flight without fetching anything (throughput measurement)."""
-    self._launch_group()
+    if self.group:
+      # batches still waiting for company need a slot: the launched ones are older — let them finish and give theirs back first
+      for _, stream in (self.slots or []):
+        stream.synchronize()
+      self.pending = [t for t in self.pending if t['launch'] is None]
+      self.free = list(range(self.depth))
+      self._launch_group()
     for _, stream in (self.slots or []):
       stream.synchronize()
     self.pending = []

@@ -601,3 +601,42 @@ def test_decode_pipeline_to_host(cuda):
   for a, b in zip(got, lone):
     for u, v in zip(a, b):
       assert isinstance(u, np.ndarray) and np.array_equal(u, v)
+
+
+def test_decode_pipeline_coalesces_box_model_batches_and_drains_a_waiting_group(cuda):
+  """box_model batches (y_gt and the [T, B, H, W] noise are fed per batch) through DecodePipeline(coalesce=2): each batch as a
+  lone run; and drain() with every slot busy AND a batch still waiting for company (it used to raise: the waiting batch needs a
+  slot that only the older, launched batches can give back)."""
+  import box_model
+  opt = ora.make_opt('cvppp', 96, 96, 3)
+  P = ora.random_params(opt, 7, box_model=True)
+  m = box_model.get_model(opt).load_weights(P)
+  rng = np.random.RandomState(9)
+  feeds = []
+  for b in (2, 3, 2, 1, 2):
+    y_gt = np.zeros((b, 3, 96, 96), np.float32)
+    y_gt[:, 0, 10:40, 15:50] = 1
+    y_gt[:, 1, 50:80, 40:90] = 1
+    feeds.append({'x': rng.rand(b, 96, 96, 3).astype(np.float32), 'y_gt': y_gt,
+                  'noise': rng.uniform(0, 0.3, (3, b, 96, 96)).astype(np.float32), 'phase_train': False})
+  names = ['s_out', 'attn_box', 'canvas']
+  lone = [m.run(names, f, as_numpy=True) for f in feeds]
+  pipe = m.pipeline(2, coalesce=2)
+  got = []
+  for f in feeds:
+    while pipe.full(f['x'].shape[0]):
+      got.append(pipe.collect(as_numpy=True))
+    pipe.submit(names, f)
+  while len(pipe):
+    got.append(pipe.collect(as_numpy=True))
+  assert len(got) == len(lone)
+  for a, b in zip(got, lone):
+    for u, v in zip(a, b):
+      assert u.shape == v.shape and np.abs(u - v).max() < 1e-6, np.abs(u - v).max()
+  # two slots busy with two batches each, a fifth batch waiting for company: drain() must not raise
+  pipe = m.pipeline(2, coalesce=2)
+  for f in feeds:
+    pipe.submit(names, f)
+  assert len(pipe.group) == 1 and not pipe.free
+  pipe.drain()
+  assert not pipe.group and not len(pipe) and sorted(pipe.free) == [0, 1]
