@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void controller_split_kernel(
 
 template <int FR>
 int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, float *h_last,
-           float *ctrl_out, float *gmaps, float *attn, unsigned *ws, int *status, size_t lds,
+           float *ctrl_out, float *gmaps, float *attn, unsigned *ws, size_t ws_bytes, int *status, size_t lds,
            hipStream_t st) {
   auto kern = controller_split_kernel<FR, false>;
   auto kern_xl = controller_split_kernel<FR, true>;
@@ -442,7 +442,9 @@ int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, flo
     if (e && atoi(e) == 0) xl = 0;
     else if (const int c = xcc_census_ok(); c >= 0) xl = c;  // (-1: asked inside a stream capture — decide at the next launch)
   }
-  unsigned *tickets = ws + (size_t)B * ws_words_per_image(d);  // 8 pools of kTicketPoolStride words behind the images' granules
+  // 8 pools of kTicketPoolStride words at the END of the caller's workspace (not behind THIS launch's images: a workspace sized for
+  // more images than it is launched with keeps its granules and its role tickets apart)
+  unsigned *tickets = ws + ws_bytes / 4 - 8 * kTicketPoolStride;
   if (xl == 1)
     hipLaunchKernelGGL(kern_xl, dim3(8 * kP * ((B + 7) / 8)), dim3(kThreads), lds, st, d, feat, wp, h_last, ctrl_out, gmaps, attn, ws,
                        status, tail_prio(1), B, tickets);
@@ -858,7 +860,7 @@ extern "C" int ra_controller_split_f32(const ra_ctrl_desc *d, const float *feat,
   const int fr = ceil_div(d->G * d->Cf, ctrl2::kThreads);
   hipStream_t st = as_stream(stream);
   unsigned *w = reinterpret_cast<unsigned *>(ws);
-#define RA_C2(FR) return ctrl2::launch<FR>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, status_dev, lds, st)
+#define RA_C2(FR) return ctrl2::launch<FR>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, ws_bytes, status_dev, lds, st)
   if (fr <= 4) RA_C2(4);
   if (fr <= 16) RA_C2(16);
   if (fr <= 32) RA_C2(32);
