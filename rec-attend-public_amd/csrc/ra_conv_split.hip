@@ -35,9 +35,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TH = 16, TW = 16;            // output tile (conv resolution)
-constexpr int WSY = TH + 2, WSX = TW + 2;  // staged window
+constexpr int TW = 16;                     // output tile width (conv resolution); its height TH is 16, or 8 at Cin = 64 (Geo)
+constexpr int WSX = TW + 2;                // staged window width
 constexpr int WSP = 20;                    // LDS row stride in pixels (bank spread, see above)
+constexpr int tile_rows(int cin) { return cin >= 64 ? 8 : 16; }  // Cin = 64: a 10-row window (3 x 28.8 KB) beside 54 KB of filter
 
 struct SArgs {
   const float *x;
@@ -51,6 +52,8 @@ struct SArgs {
 
 template <int CIN, int NB>  // NB: blocks of 16 output channels per workgroup (2; 1 where Cout is an odd multiple of 16)
 struct Geo {
+  static constexpr int TH = tile_rows(CIN), WSY = TH + 2;      // output tile height, staged window height
+  static constexpr int GPW = TH / 4;                           // 4 x 4-pixel groups per wave (TH / 4 rows of 4 groups over 4 waves)
   static constexpr int NBLK = CIN >= 32 ? 9 * (CIN / 32) : 5;  // K = 32 blocks: tap x 32 channels; Cin = 16: two taps x 16
   static constexpr int RS = 2 * CIN + 16;                      // bytes per staged pixel record
   static constexpr int PLANE = WSY * WSP * RS;                 // bytes of one bf16 tile
@@ -100,7 +103,7 @@ __device__ long long *ra_probes_buf;
 template <int CIN, int POOL, int NB>
 __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = Geo<CIN, NB>;
-  constexpr int RS = G::RS, PLANE = G::PLANE, NBLK = G::NBLK, C4 = CIN / 4;
+  constexpr int RS = G::RS, PLANE = G::PLANE, NBLK = G::NBLK, C4 = CIN / 4, TH = G::TH, WSY = G::WSY, GPW = G::GPW;
   constexpr int NITEMS = WSY * WSX * C4, NIT = (NITEMS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char *tin = lds;               // three bf16 tiles [WSY][WSP][RS]
@@ -228,12 +231,15 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     }
     if (tnext < ntiles) fetch(tnext);  // in flight across the MFMA loop
 
-    f32x4 acc[4][NB];
+    f32x4 acc[GPW][NB];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < GPW; ++g)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int wave_pix = 4 * wave * WSP * RS + lane_pix;  // this wave's row of 4 x 4-pixel groups
+    // this wave's 4 x 4-pixel groups: a whole row of four (TH = 16: row = wave) or half a row (TH = 8: row = wave / 2, groups
+    // 2 (wave & 1) and the next)
+    const int grow = GPW == 4 ? wave : wave >> 1, gx0 = GPW == 4 ? 0 : 2 * (wave & 1);
+    const int wave_pix = (4 * grow * WSP + 4 * gx0) * RS + lane_pix;
     constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // six piece products per block, smallest first
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) wv[pc][nb] = *reinterpret_cast<const s16x8 *>(wl + ((blk * 3 + pc) * NB + nb) * 1024 + woff);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < GPW; ++g) {
         s16x8 av[3];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) av[pc] = *reinterpret_cast<const s16x8 *>(tin + pc * PLANE + wave_pix + 4 * g * RS + toff[blk]);
@@ -259,19 +265,19 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     // epilogue: lane (column n = m, D rows 4 kb + r) holds the four elements r = (dy, dx) of pooling window kb = (wy, wx) of group g
     const int wy = kb >> 1, wx = kb & 1;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < GPW; ++g)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int co = 16 * (NB * slice + nb) + m;
         const f32x4 v = acc[g][nb] * sc[nb] + sh[nb];
         if constexpr (POOL == 2) {
           const float o = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), lo);
-          const int oy = ty * (TH / 2) + 2 * wave + wy, ox = tx * (TW / 2) + 2 * g + wx;
+          const int oy = ty * (TH / 2) + 2 * grow + wy, ox = tx * (TW / 2) + 2 * (gx0 + g) + wx;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry, (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int oy = ty * TH + 4 * wave + 2 * wy + (r >> 1), ox = tx * TW + 4 * g + 2 * wx + (r & 1);
+            const int oy = ty * TH + 4 * grow + 2 * wy + (r >> 1), ox = tx * TW + 4 * (gx0 + g) + 2 * wx + (r & 1);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[r], lo)), ry,
                                                   (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
           }
@@ -302,7 +308,7 @@ int launch(const SArgs &a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  const int tiles_x = a.W / TW, tiles_y = a.H / TH, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / (16 * NB);
+  const int tiles_x = a.W / TW, tiles_y = a.H / Geo<CIN, NB>::TH, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / (16 * NB);
   int gx = cu_count() / slices;  // one workgroup per CU (141 KB of LDS at Cin = 32)
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
@@ -331,12 +337,12 @@ inline float bf16_to_float_host(unsigned short h) {
 using namespace ra;
 
 extern "C" int ra_conv_split_supported(int Cin, int Cout, int pool, int H, int W) {
-  return (Cin == 16 || Cin == 32) && Cout > 0 && Cout % 16 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
-         H % csplit::TH == 0 && W % csplit::TW == 0;
+  return (Cin == 16 || Cin == 32 || Cin == 64) && Cout > 0 && Cout % 16 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
+         H % csplit::tile_rows(Cin) == 0 && W % csplit::TW == 0;
 }
 
 extern "C" size_t ra_conv_split_packed_halfs(int Cin, int Cout) {
-  if (!(Cin == 16 || Cin == 32) || Cout <= 0 || Cout % 16) return 0;
+  if (!(Cin == 16 || Cin == 32 || Cin == 64) || Cout <= 0 || Cout % 16) return 0;
   const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5;
   return (size_t)(Cout / 16) * nblk * 3 * 512;
 }
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *w, int Cin
 extern "C" int ra_conv_split_pack_weights_dev(const float *w, int Cin, int Cout, int transposed, unsigned short *out, void *stream) {
   const size_t n = ra_conv_split_packed_halfs(Cin, Cout);
   if (!w || !out || !n) return fail(RA_E_SHAPE, "ra_conv_split_pack_weights_dev: Cin=%d Cout=%d", Cin, Cout);
-  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0) ? 2 : 1;
+  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0 && Cin < 64) ? 2 : 1;  // Cin = 64: 16 couts per workgroup
   hipLaunchKernelGGL(csplit::pack_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, Cin, Cout,
                      transposed ? 1 : 0, nblk, nbw, n, out);
   return launch_status("ra_conv_split_pack_weights_dev");
@@ -401,7 +407,7 @@ extern "C" int ra_conv_split_pack_weights_dev(const float *w, int Cin, int Cout,
 extern "C" int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, unsigned short *out) {
   const size_t n = ra_conv_split_packed_halfs(Cin, Cout);
   if (!w || !out || !n) return fail(RA_E_SHAPE, "ra_conv_split_pack_weights: Cin=%d Cout=%d", Cin, Cout);
-  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0) ? 2 : 1;
+  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0 && Cin < 64) ? 2 : 1;  // Cin = 64: 16 couts per workgroup
   for (size_t e = 0; e < n; ++e) {
     int pc, tap, ci, co;
     csplit::slot_of(e, Cin, Cout, nblk, nbw, pc, tap, ci, co);
@@ -437,6 +443,7 @@ extern "C" int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, c
   a.bytes_x = (int)bx;
   a.bytes_y = (int)by;
   hipStream_t st = as_stream(stream);
+  if (Cin == 64) return pool == 2 ? csplit::launch<64, 2, 1>(a, st) : csplit::launch<64, 1, 1>(a, st);
   if (Cout % 32 == 0) {
     if (Cin == 16) return pool == 2 ? csplit::launch<16, 2, 2>(a, st) : csplit::launch<16, 1, 2>(a, st);
     return pool == 2 ? csplit::launch<32, 2, 2>(a, st) : csplit::launch<32, 1, 2>(a, st);

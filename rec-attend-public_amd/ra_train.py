@@ -704,7 +704,7 @@ def _conv_dgrad(du, w, tr, stride, cmap, x_shape, cin_w, cache, bf, out_dtype=to
   cpb = ops.cout_padded(cin_w)
   ones = _const('ones', cpb, dev, lambda: torch.ones(cpb, dtype=torch.float32, device=dev))
   zeros = _const('zeros', cpb, dev, lambda: torch.zeros(cpb, dtype=torch.float32, device=dev))
-  if (SPLIT_DGRAD['on'] and not bf and stride == 1 and cmap is None and Cx == cin_w and cout >= 32 and  # (16 channels: conv16_kernel is as fast)
+  if (SPLIT_DGRAD['on'] and not bf and stride == 1 and cmap is None and Cx == cin_w and cout == 32 and  # (16 channels: conv16_kernel is as fast; 64: K1s's 8-row form is the decode loop's, not measured here)
       ops.conv_split_supported(cout, cin_w, 1, du.shape[1], du.shape[2]) and du.numel() * 4 < (1 << 31)):
     # round 5: the float32 data gradient of a 16- / 32-channel layer on the bf16 matrix pipe at float32 accuracy (K1s,
     # csrc/ra_conv_split.hip: every operand the exact sum of three bf16 pieces, six piece products) — 32 -> 32 at 128 x 128 x

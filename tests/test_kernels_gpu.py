@@ -413,7 +413,9 @@ def test_dense_attention_operators(cuda, H, W, big):
 
 @pytest.mark.parametrize('B,H,W,Ci,Co,pool,relu', [(2, 32, 48, 16, 32, 1, True), (1, 64, 32, 32, 32, 2, True), (3, 16, 16, 32, 64, 2, True),
                                                     (2, 48, 32, 16, 64, 2, False), (8, 128, 128, 32, 32, 2, True), (2, 32, 32, 32, 16, 1, False),
-                                                    (1, 16, 32, 16, 48, 2, True)])
+                                                    (1, 16, 32, 16, 48, 2, True),
+                                                    (8, 32, 32, 64, 64, 2, True), (2, 8, 48, 64, 64, 1, True), (3, 24, 16, 64, 32, 2, False),
+                                                    (1, 40, 32, 64, 16, 1, True)])  # Cin = 64: 8-row tiles, 16 couts per workgroup
 def test_conv_split_precision(cuda, B, H, W, Ci, Co, pool, relu):
   """K1s (ra_conv_split_f32, round 5): the direct 3x3 layer on the bf16 matrix pipe — every operand the exact sum of three bf16
   pieces, six of the nine piece products — against the float64 oracle at the float32 kernels' bar (2e-5 of the output scale),
