@@ -139,7 +139,7 @@ class DecodeEngine(object):
       wino = i > 0 and self.use_wino and ops.conv_wino_supported(cin, cout, d['ccnn_pool'][i], hh, ww)
       W['ccnn_wino'].append(_dev(ops.pack_wino_weights(M['ctrl_cnn_w_%d' % i]), device) if wino else None)
       # ... and as the exact three-piece bf16 split of the filter, for the direct form on the bf16 matrix pipe (K1s, round 5)
-      split = i > 0 and self.use_split and cin >= 32 and ops.conv_split_supported(cin, cout, d['ccnn_pool'][i], hh, ww)  # Cin = 16 (L4): no faster than K1w
+      split = i > 0 and self.use_split and cin >= int(os.environ.get('RA_SPLIT_MIN_CIN', '32')) and ops.conv_split_supported(cin, cout, d['ccnn_pool'][i], hh, ww)  # Cin = 16 (L4): no faster than K1w
       W['ccnn_split'].append(torch.from_numpy(ops.pack_split_weights(M['ctrl_cnn_w_%d' % i])).to(device) if split else None)
       hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
     Cf = d['ccnn_channels'][-1]
