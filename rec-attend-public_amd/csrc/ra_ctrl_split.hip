@@ -436,16 +436,19 @@ int launch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, flo
     attr_set = true;
   }
   // the XCD-local form wherever the device's workgroups report the XCC ids 0..7 (ra_core.hip's census); RA_CTRL_XCD=0: the old one
-  static int xl = -1;
+  static int xl = -1, xl_all = 0;
   if (xl < 0) {
     const char *e = getenv("RA_CTRL_XCD");
+    xl_all = (e && atoi(e) == 2) ? 1 : 0;
     if (e && atoi(e) == 0) xl = 0;
     else if (const int c = xcc_census_ok(); c >= 0) xl = c;  // (-1: asked inside a stream capture — decide at the next launch)
   }
   // 8 pools of kTicketPoolStride words at the END of the caller's workspace (not behind THIS launch's images: a workspace sized for
   // more images than it is launched with keeps its granules and its role tickets apart)
   unsigned *tickets = ws + ws_bytes / 4 - 8 * kTicketPoolStride;
-  if (xl == 1)
+  // up to 8 images: one team per XCD, 16 of its 32 CUs — as much headroom as the grid (16, B) form has on the whole chip.  9-14
+  // images would put two teams on some XCDs and need ALL their CUs: those launches keep the grid (16, B) form (RA_CTRL_XCD=2: both)
+  if (xl == 1 && (B <= 8 || xl_all))
     hipLaunchKernelGGL(kern_xl, dim3(8 * kP * ((B + 7) / 8)), dim3(kThreads), lds, st, d, feat, wp, h_last, ctrl_out, gmaps, attn, ws,
                        status, tail_prio(1), B, tickets);
   else

@@ -282,7 +282,7 @@ def test_controller(cuda, arch, H, W, flags):
     ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2, 'num_glimpse_mlp_layers': 3}, 5),
     ('cvppp', 512, 512, {'num_glimpse_mlp_layers': 1}, 5),
     ('cvppp', 512, 512, {}, 8),    # the XCD-local form: one team of 16 workgroups on every XCD
-    ('cvppp', 512, 512, {}, 11),   # ... two teams on three XCDs, one on five
+    ('cvppp', 512, 512, {}, 11),   # 9-14 images: the grid (16, B) form by default (RA_CTRL_XCD=2: two teams on three XCDs, one on five)
     ('cvppp', 128, 128, {}, 14),   # ... the residency limit: 224 workgroups of the 256 launched take a role
     ('cvppp', 128, 128, {}, 1),
 ])
