@@ -173,8 +173,8 @@ int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsam
 /* K1s (round 5) — the same layer (conv3x3 SAME + folded BatchNorm + ReLU + max-pool, nnlib.py:229-253) as a DIRECT convolution
  * on the BF16 matrix pipe at float32 accuracy: every float32 operand is the exact sum of three bf16 pieces, and six of the
  * nine piece products (everything above 2^-24 of a product) run as v_mfma_f32_16x16x32_bf16 with float32 accumulation
- * (csrc/ra_conv_split.hip).  Cin in {16, 32}, Cout % 16 == 0, pool 1 | 2, H and W multiples of 16
- * (ra_conv_split_supported).  wpacked: ra_conv_split_packed_halfs() 16-bit words, the filter's three bf16 pieces in B-operand
+ * (csrc/ra_conv_split.hip).  Cin in {16, 32, 64}, Cout % 16 == 0, pool 1 | 2, W a multiple of 16, H a multiple of 16 (of 8 at
+ * Cin = 64: 8-row tiles) (ra_conv_split_supported).  wpacked: ra_conv_split_packed_halfs() 16-bit words, the filter's three bf16 pieces in B-operand
  * order, from the reference's [3,3,Cin,Cout] filter by ra_conv_split_pack_weights (host) or ra_conv_split_pack_weights_dev
  * (device pointers; transposed != 0: w is a conv2d_transpose filter [3,3,Cout,Cin] — taps flipped, in / out swapped, as
  * RA_CONV_TRANSPOSED: the packing of a cnn layer's DATA GRADIENT, which the training step runs as this conv with scale 1,
