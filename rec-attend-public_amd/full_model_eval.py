@@ -119,8 +119,11 @@ def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, anal
   # results copied to the host ride on the slot's stream: a batch queued behind one would wait for its copy, so that
   # mode keeps one batch per stream (33.8k vs 29.0k instance-timesteps/s at cfg2)
   depth = max(1, args.in_flight) if analyze else max(1, min(args.in_flight, 4))
-  # small batches travel two to a slot (DecodePipeline(coalesce=2), round 5: +15 % at cfg2 with the same images in flight)
-  coalesce = 2 if (args.batch_size <= 8 and depth >= 2 and analyze) else 1
+  # small batches travel together, about 16 images to a slot and forward (DecodePipeline(coalesce=...), round 5: two batches of 8
+  # +15 % at cfg2, four batches of 4 +70 % at cfg5 with the same images in flight), as long as at least two slots remain
+  coalesce = 1
+  if analyze and depth >= 2 and args.batch_size <= 8:
+    coalesce = max(1, min(16 // max(1, args.batch_size), depth // 2))
   pipe, spans = model.pipeline(max(1, depth // coalesce), coalesce=coalesce), []
   for b0 in range(lo, hi, args.batch_size):
     b1 = min(hi, b0 + args.batch_size)
