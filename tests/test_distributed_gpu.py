@@ -112,7 +112,9 @@ def test_two_ranks_on_one_gpu_through_the_train_cli(cuda, tmp_path):
     bad4 += int((d > 1e-4).sum())
     tot += d.size
   print('sync_bn two ranks vs one process after 1 step of 1e-3: %d of %d weights differ by > 1e-5 (%.3f %%), %d by > 1e-4' % (bad5, tot, 100.0 * bad5 / tot, bad4))
-  assert bad5 <= 1e-3 * tot and bad4 == 0, (bad5, bad4, tot)  # measured: 0 of 381 530
+  # measured: 0 of 381 530 in most runs; 8 / 4 (> 1e-5 / > 1e-4) in two of fourteen runs of the whole suite — elements whose gradient
+  # is round-off in both runs and lands on the other side of zero (the amplification described above), hence a handful is allowed
+  assert bad5 <= 1e-3 * tot and bad4 <= 2e-5 * tot, (bad5, bad4, tot)
 
 
 def test_two_ranks_reach_the_bench_line(cuda):
