@@ -256,3 +256,35 @@ def test_deferred_status_check_raises_on_flush():
   s._status_pending = (Ev(), other, 16, 1)
   with pytest.raises(rn.RecAttendError):
     s.flush_status()
+
+
+def test_weights_stamp_sees_every_kind_of_change():
+  """DecodeEngine._weights_stamp (compared after every launch): full_model.Model counts the mutations of the dict itself, in-place
+  edits show in the tensors' version counters; a plain dict as the model falls back to the (key, pointer, version) tuple."""
+  import torch
+  import full_model
+  import ra_engine
+  sys_opt = ora.make_opt('cvppp', 64, 64, 2)
+  m = full_model.get_model(sys_opt)
+  e = m.engine
+  s0 = e._weights_stamp()
+  assert e._weights_stamp() == s0
+  k = m.weight_keys()[0]
+  with torch.no_grad():
+    m[k].add_(1.0)  # in place: the version counter
+  s1 = e._weights_stamp()
+  assert s1 != s0
+  m[k] = m[k].clone()  # the entry replaced: the dict's mutation counter (the new tensor's version starts at 0 again)
+  s2 = e._weights_stamp()
+  assert s2 != s1 and s2[0] == s1[0] + 1
+  for mutate in (lambda: m.update({k: m[k]}), lambda: m.setdefault('zz_probe', torch.zeros(1)), lambda: m.pop('zz_probe'),
+                 lambda: m.__ior__({})):
+    before = m._mut
+    mutate()
+    assert m._mut == before + 1
+  plain = ra_engine.DecodeEngine(m.dims, dict(m))
+  p0 = plain._weights_stamp()
+  assert isinstance(p0, tuple) and len(p0) == len(m.weight_keys()) and plain._weights_stamp() == p0
+  with torch.no_grad():
+    m[k].add_(1.0)
+  assert plain._weights_stamp() != p0
