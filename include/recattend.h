@@ -36,8 +36,9 @@ extern "C" {
 #define RA_E_HUNG_EQUALIZE (-15) /* hungarian.cc:446-450 */
 
 /* ABI version: bumped whenever an entry point of this header is removed or changes its signature (additions do not
- * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102 =
- * this round.  ra_native.py refuses a library whose version differs from the header it was written against. */
+ * bump it).  101 = round 3's removal of the table-form attention entry points and the phase-fused patch net; 102-113 =
+ * rounds 3-5 (signature changes of the controller / conv entry points as the kernels were rebuilt; `git log -p
+ * include/recattend.h` has each).  ra_native.py refuses a library whose version differs from the header it was written against. */
 #define RA_ABI_VERSION 113
 int ra_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
@@ -46,6 +47,12 @@ const char *ra_last_error_string(void);
 /* Test aid (no reference counterpart): fills the LDS of every CU with NaN, so a kernel that
  * reads shared memory it never wrote fails the parity tests deterministically. */
 int ra_debug_poison_lds(void *stream);
+/* Test aid (no reference counterpart): parks `n_wg` workgroups of `lds_bytes` dynamic LDS each (<= 160 KB; above 80 KB that is
+ * one per CU) on XCD `xcd` (HW_REG_XCC_ID) for `millis` ms of wall clock (s_memrealtime, capped at 20 s): a launch of 8 * n_wg
+ * workgroups whose members on any other XCD leave at once.  resident[0] (device int, zeroed by the caller, may be NULL) counts
+ * the parked workgroups as they start.  For tests of what a launch that relies on co-residency (ra_controller_split_f32) does
+ * when part of an XCD is taken: tests/test_full_model_gpu.py. */
+int ra_debug_park_xcd(int xcd, int n_wg, int lds_bytes, int millis, int *resident, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Hungarian matching — replaces the TF custom op

@@ -70,8 +70,8 @@ constexpr int kTicketSlotWords = 8 * kTicketPoolStride;    // one slot = the 8 X
 // four upwards the launch is as fast or faster alone (L0+L1 79.5 -> 72.1 us back to back: the pools also even out the XCDs)
 // and loses 3-8 % instead of 13-50 % to another slot's controller (tools/contention_by_layer.py).
 constexpr int kTicketMinTilesPerWg = 3;
-unsigned *take_ticket_slots(int n, int grid_x);
-int xcc_census_ok();  // ra_core.hip: 1 = this device's workgroups report exactly the XCC ids 0..7, 0 = not, -1 = cannot tell now (stream capture)            // ra_core.hip: n consecutive slots of the bound scratch, or nullptr
+unsigned *take_ticket_slots(int n, int grid_x);  // ra_core.hip: n consecutive slots of the bound scratch, or nullptr
+int xcc_census_ok();  // ra_core.hip: 1 = this device's workgroups report exactly the XCC ids 0..7, 0 = not, -1 = cannot tell now (stream capture)
 
 __device__ __forceinline__ int xcc_id() {
   unsigned id;

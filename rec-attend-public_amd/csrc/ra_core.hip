@@ -117,6 +117,39 @@ extern "C" int ra_debug_poison_lds(void *stream) {
   return ra::launch_status("ra_debug_poison_lds");
 }
 
+// Test aid: hold part of ONE XCD's CUs for a while (see recattend.h).
+namespace ra {
+namespace {
+__global__ __launch_bounds__(64) void park_xcd_kernel(int xcd, unsigned long long ticks, int *resident) {
+  extern __shared__ float sh[];
+  if (xcc_id() != xcd) return;
+  if (threadIdx.x == 0) {
+    sh[0] = 1.0f;  // (the dynamic LDS is what keeps a second workgroup off this CU)
+    if (resident) atomicAdd(resident, 1);
+    const unsigned long long t0 = wall_clock64();  // 100 MHz, constant
+    for (unsigned n = 0; n < 400000000u; ++n) {    // bounded whatever the clock does
+      if (wall_clock64() - t0 >= ticks) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+  }
+}
+}  // namespace
+}  // namespace ra
+
+extern "C" int ra_debug_park_xcd(int xcd, int n_wg, int lds_bytes, int millis, int *resident, void *stream) {
+  if (xcd < 0 || xcd > 7 || n_wg <= 0 || n_wg > 64 || lds_bytes < 0 || lds_bytes > 160 * 1024 || millis < 0)
+    return ra::fail(RA_E_INVALID, "ra_debug_park_xcd: bad argument");
+  if (millis > 20000) millis = 20000;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra::park_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(ra::park_xcd_kernel, dim3(8 * n_wg), dim3(64), (size_t)lds_bytes, ra::as_stream(stream), xcd,
+                     (unsigned long long)millis * 100000ull, resident);
+  return ra::launch_status("ra_debug_park_xcd");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Small utilities of the decode loop that must not cost a framework kernel inside the HIP graph.
 namespace ra {

@@ -534,7 +534,12 @@ class DecodePipeline(object):
         ev.record(stream)
       used.append(k)
       events.append((ev, host))
-    rec = dict(used=used, events=events, bounds=bounds, refs=len(members), names=names, res=None, checked=False)
+    # `feed` (for a group: fresh concatenations made on the CURRENT stream; for a lone batch: the caller's tensors, which the
+    # caller may drop as soon as submit() returns) is read by the engines' input copies on the slots' side streams, possibly
+    # milliseconds from now (a slot queued behind another on its stream): the launch record keeps the tensors alive until the
+    # launch has been waited for, so the caching allocator cannot hand their blocks to the next group's concatenation or to a
+    # consumer's uploads while the copy is still queued
+    rec = dict(used=used, events=events, bounds=bounds, refs=len(members), names=names, res=None, checked=False, feed=feed)
     lo = 0
     for m in members:
       m['launch'], m['lo'], m['hi'] = rec, lo, lo + m['B']
@@ -548,6 +553,7 @@ class DecodePipeline(object):
     for k, (ev, host) in zip(rec['used'], rec['events']):
       eng, stream = self.slots[k]
       ev.synchronize()
+      rec['feed'] = None  # the engines' input copies have run
       redone = eng.check_status()
       if host is not None and redone:  # the pinned copies were taken from the starved forward: copy the re-decoded outputs over them
         for h, n in zip(host, rec['names']):
@@ -608,6 +614,7 @@ class DecodePipeline(object):
     t = self.pending.pop(0)
     for ev, _ in t['launch']['events']:
       ev.synchronize()
+    t['launch']['feed'] = None
     self._release(t['launch'])
 
   def drain(self):

@@ -12,8 +12,11 @@ reference's write_log chain (full_model_eval.py:97-139) runs on the device for e
 --threshold_list (default 0.3, the reference CLI's default, :193-194): apply_confidence, apply_one_label,
 apply_threshold [, mask_foreground, remove_tiny] and the --analyzers (default list :201-205);
 the per-threshold means go to <output>/output_<split>/metrics_rank<r>.yaml.  The cv2 steps
-(upsample + bilateral filter, morph) run as device kernels since round 5 (utils/postprocess.py): the resize when the labels'
-size differs from the network's, the dilation when a foreground mask is given and --no_morph is not."""
+(upsample + bilateral filter, morph) run as device kernels (utils/postprocess.py).  As in the reference, pp.upsample — cv2.resize
+to the labels' size, then bilateralFilter(5, 10, 10), which on [0, 1] maps is close to a radius-2 blur — ALWAYS runs, also when
+the labels already have the network's size (full_model_eval.py:114), and the dilation runs when a foreground mask is given and
+--no_morph is not.  --fused_postprocess (not a reference flag) skips the bilateral step when no resize is needed: the chain
+then collapses into one fused device pass; masks and metrics near the threshold differ from the reference's in that mode."""
 import argparse
 import os
 import time
@@ -32,6 +35,9 @@ def build_parser():
     cap.add_flags(p, table)
   p.add_argument('--input', default=None, help='.npz with x [N,H,W,3] (+ d_in, y_in)')
   p.add_argument('--num_synthetic', type=int, default=8)
+  p.add_argument('--fused_postprocess', action='store_true',
+                 help='not a reference flag: skip upsample\'s bilateral filter when the labels have the network\'s size (one fused '
+                      'post-processing pass; results near the threshold differ from the reference chain)')
   p.add_argument('--in_flight', type=int, default=8, help='batches submitted to one GPU at a time (four decode concurrently, the rest queue behind them)')
   return p
 
@@ -88,10 +94,11 @@ def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, anal
       gt = torch.as_tensor(np.asarray(data['y_gt'][b0:b1], dtype=np.float32)).to(dev)
       sg = torch.as_tensor(np.asarray(data['s_gt'][b0:b1], dtype=np.float32)).to(dev)
       fg = torch.as_tensor(np.asarray(data['fg'][b0:b1], dtype=np.float32)).to(dev) if 'fg' in data else None
-      # the reference's chain (full_model_eval.py:112-124): apply_confidence -> upsample to the labels' size -> [foreground given:
-      # morph unless --no_morph] -> apply_one_label -> per threshold: apply_threshold [-> mask_foreground -> remove_tiny].  Without
-      # a resize and a dilation it collapses into ONE fused pass (pp.postprocess)
-      resize = tuple(gt.shape[-2:]) != tuple(y_dev.shape[-2:])
+      # the reference's chain (full_model_eval.py:112-124): apply_confidence -> upsample to the labels' size (ALWAYS: resize +
+      # bilateral filter, also at equal size) -> [foreground given: morph unless --no_morph] -> apply_one_label -> per threshold:
+      # apply_threshold [-> mask_foreground -> remove_tiny].  --fused_postprocess: without a resize and a dilation the chain
+      # collapses into ONE fused pass (pp.postprocess) that leaves the bilateral step out
+      resize = tuple(gt.shape[-2:]) != tuple(y_dev.shape[-2:]) or not getattr(args, 'fused_postprocess', False)
       dilate = fg is not None and not args.no_morph
       if resize or dilate:
         s2 = s_dev[:, :, 0].contiguous() if s_dev.dim() == 3 else s_dev   # multi-class: :108-110

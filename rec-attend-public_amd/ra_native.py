@@ -44,6 +44,7 @@ SIGNATURES = {
     'ra_version': (_I, []),
     'ra_last_error_string': (C.c_char_p, []),
     'ra_debug_poison_lds': (_I, [_P]),
+    'ra_debug_park_xcd': (_I, [_I, _I, _I, _I, _P, _P]),
     'ra_gather_f32': (_I, [_P, _P, _Z, _P, _P]),
     'ra_gemm_tn_acc_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     'ra_conv3x3_bf16_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P, _I, _P]),

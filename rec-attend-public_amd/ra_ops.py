@@ -283,6 +283,12 @@ def poison_lds():
   check(rn.lib().ra_debug_poison_lds(rn.stream_ptr()), 'ra_debug_poison_lds')
 
 
+def park_xcd(xcd, n_wg, lds_bytes=100 * 1024, millis=100, resident=None, stream=None):
+  """Test aid: hold n_wg CUs' worth of LDS on one XCD for `millis` ms (ra_debug_park_xcd); resident: int32 device counter."""
+  check(rn.lib().ra_debug_park_xcd(int(xcd), int(n_wg), int(lds_bytes), int(millis), ptr(resident) if resident is not None else None,
+                                   rn.stream_ptr() if stream is None else stream.cuda_stream), 'ra_debug_park_xcd')
+
+
 def conv_pair_supported(cin, cout_a, cout_b):
   return bool(rn.lib().ra_conv_pair_supported(int(cin), int(cout_a), int(cout_b)))
 

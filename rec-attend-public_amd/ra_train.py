@@ -256,7 +256,42 @@ def _side_stream(device, which=0):
   return _SIDE[k]
 
 
-_PACK = {}  # the pack cache of callers outside a TrainStep (tests, one-off layer calls); a TrainStep owns its own
+class _LatestVersionPack(dict):
+  """The pack cache of callers OUTSIDE a TrainStep (the train-mode nnlib closures, tests, one-off layer calls).  Keys carry the
+  source tensor's data pointer AND version — (ptr, version, geometry...), ('shift', ptr, version, cp), ('split', ptr, version,
+  transposed) — so an in-place optimizer step makes every entry of that weight stale; a plain dict kept them all and an
+  ordinary training loop over the closures grew by one set of packed filters per layer, direction and step (~1 MB
+  per step at the CVPPP arch).  Here a new version of the same (tensor, geometry) REPLACES the old entry, and the whole cache
+  is capped (oldest first) for callers that keep creating tensors."""
+  CAP = 2048
+
+  def __init__(self):
+    super().__init__()
+    self._latest = {}
+
+  @staticmethod
+  def _identity(key):
+    return (key[0], key[1]) + tuple(key[3:]) if isinstance(key[0], str) else (key[0],) + tuple(key[2:])
+
+  def __setitem__(self, key, value):
+    ident = self._identity(key)
+    old = self._latest.get(ident)
+    if old is not None and old != key:
+      super().pop(old, None)
+    self._latest[ident] = key
+    super().__setitem__(key, value)
+    while len(self) > self.CAP:
+      k0 = next(iter(self))
+      super().pop(k0)
+      self._latest.pop(self._identity(k0), None)
+
+  def clear(self):
+    super().clear()
+    self._latest.clear()
+
+
+_PACK = _LatestVersionPack()
+# A TrainStep owns its own cache
 # (TrainStep._pack, handed to the layer functions through meta['cache']): per step, (weight storage, geometry) -> packed
 # filter — the filters are shared by the T timesteps.  forward_loss() clears the trainer's dict (the optimizer writes the
 # weights through raw pointers); an entry keeps its source tensor alive and carries the tensor's version, so a caller
@@ -2153,33 +2188,57 @@ class TrainStep(object):
 
   def _check_status(self, rec):
     """The status words of one finished step, on the host.  The guarded optimizer kernel has already refused that step's
-    update if any of them was non-zero, so nothing here repairs weights: a failed MATCHING raises (the reference aborts
-    there, hungarian.cc LOG(FATAL)); a controller TIME-OUT (the 16-workgroup form found a peer not resident: something else
-    on the GPU) switches the sequential phase to the one-workgroup controller for good, gives the skipped step's number
-    back and warns; another RANK's failure raises here too, so that no rank walks into the next collective alone."""
-    ev, host, n_match, n_ctrl = rec
+    update if any of them was non-zero, so nothing here repairs weights.  The record is
+      [n_match matching codes | n_ctrl controller words | n_forced "skipped on purpose" | world > 1: 2 all-reduced flags]
+    and the decision is COLLECTIVE: the two trailing flags — "a matching failed on some rank", "a controller
+    timed out (or the step was skipped on purpose) on some rank" — rode on the gradient bucket's all-reduce, so every rank
+    reads the same two words and takes the same branch:
+      * a failed MATCHING anywhere raises on every rank (the reference aborts there, hungarian.cc LOG(FATAL));
+      * a controller TIME-OUT anywhere (the 16-workgroup form found a peer not resident: something else on the GPU) makes
+        every rank switch its sequential phase to the one-workgroup controller for good, give the skipped step's number back
+        and warn — no rank walks into the next collective alone, global_step and the learn-rate schedule stay equal;
+      * a step that run() skipped on purpose (the one already queued behind a timed-out step: it ran on the exchange
+        workspace that step left behind) only gives its number back.
+    Returns True when a recovery ran (run() then forces the skip of the step it has just launched)."""
+    ev, host, n_match, n_ctrl = rec[:4]
+    n_forced = rec[4] if len(rec) > 4 else 0
+    n_world = rec[5] if len(rec) > 5 else max(0, int(host.numel()) - n_match - n_ctrl - n_forced)
     ev.synchronize()
     h = host.clone()
+    o = n_match + n_ctrl
+    if n_forced and int(h[o:o + n_forced].abs().max()) != 0:  # set together on every rank (the decision that set it was collective)
+      self.bucket.global_step = max(0, self.bucket.global_step - 1)
+      self.model['global_step'] = float(self.bucket.global_step)
+      self.skipped_steps = getattr(self, 'skipped_steps', 0) + 1
+      return False
+    w = h[o + n_forced:o + n_forced + n_world]
+    own_ctrl = bool(n_ctrl and int(h[n_match:o].abs().max()) != 0)
     if n_match:
-      ops.check_match_status(h[:n_match], 'f_segm_match')
-    if n_ctrl and int(h[n_match:n_match + n_ctrl].abs().max()) != 0:  # a controller workgroup timed out on its peers
+      ops.check_match_status(h[:n_match], 'f_segm_match')  # raises with the solver's own code
+    if n_world >= 2:
+      any_match, any_ctrl = int(w[0]) != 0, int(w[1]) != 0
+    else:  # one process — or a record from before the flags were split: any foreign flag is a failure we cannot name
+      any_match, any_ctrl = bool(n_world and int(w.abs().max()) != 0), False
+    if any_match:
+      raise rn.RecAttendError('training step: another rank reported a failed matching for this step; the update was skipped '
+                              'on every rank')
+    if own_ctrl or any_ctrl:  # a controller workgroup timed out on its peers, here or on another rank
       sc = getattr(self, '_seqc', None)
       if sc is not None and sc.get('status') is not None:
         sc['status'].zero_()
       import warnings
       warnings.warn('controller_split (sequential phase of the training step): a workgroup waited for a peer that never became '
-                    'resident — is another process using this GPU?  That step\'s update was not applied; the trainer runs the '
-                    'one-workgroup controller from now on (RA_TRAIN_CTRL_SPLIT=0 selects it from the start)')
+                    'resident%s — is another process using this GPU?  That step\'s update was not applied on any rank; the '
+                    'trainer runs the one-workgroup controller from now on (RA_TRAIN_CTRL_SPLIT=0 selects it from the start)'
+                    % ('' if own_ctrl else ' on another rank'))
       self.seq_ctrl_split = False
       self._seqc = None
       self._drop_captured_steps()
       self.bucket.global_step = max(0, self.bucket.global_step - 1)  # the skipped step is taken again
       self.model['global_step'] = float(self.bucket.global_step)
       self.skipped_steps = getattr(self, 'skipped_steps', 0) + 1
-      return
-    if h.numel() > n_match + n_ctrl and int(h[n_match + n_ctrl:].abs().max()) != 0:
-      raise rn.RecAttendError('training step: another rank reported a failed matching / controller time-out for this step; the '
-                              'update was skipped on every rank')
+      return True
+    return False
 
   def flush_status(self):
     """Check the solver / controller statuses of the LAST step now (run() checks each step's record one step late)."""
@@ -2325,25 +2384,41 @@ class TrainStep(object):
     n_match = sum(int(t.numel()) for t in sts)
     n_ctrl = 0
     if sc is not None and sc.get('ok'):
-      sts.append(sc['status'].reshape(-1).to(torch.int32))
+      # a SNAPSHOT, taken on the stream behind this step's launches: .reshape / .to(int32) of an int32 tensor alias the
+      # controller's sticky status word itself, which the check of the PREVIOUS step below may zero
+      sts.append(sc['status'].reshape(-1).to(torch.int32).clone())
       n_ctrl = int(sts[-1].numel())
     inject = getattr(self, '_inject_status', None)  # test hook: a status word forced for ONE step
     if inject is not None and sts:
       self._inject_status = None
       sts[0] = sts[0] + int(inject)
+    inject_c = getattr(self, '_inject_ctrl_status', None)  # test hook: "this step's controller timed out"
+    if inject_c is not None and n_ctrl:
+      self._inject_ctrl_status = None
+      sts[-1] = sts[-1] + int(inject_c)
     prev = getattr(self, '_status_pending', None)
     self._status_pending = None
+    recovered = False
     if prev is not None:
-      self._check_status(prev)  # also before its pinned buffer is overwritten by this step's copy
+      recovered = bool(self._check_status(prev))  # also before its pinned buffer is overwritten by this step's copy
+    n_forced = 0
+    if recovered and sts:
+      # the step just launched was queued behind the timed-out one: it ran the 16-workgroup controller on the exchange
+      # workspace that step left behind (generation tags half advanced), so its gradients are not to be trusted either —
+      # its update is refused on the device like its predecessor's and its step number is given back at its own check
+      sts.append(torch.ones(1, dtype=torch.int32, device=sts[0].device))
+      n_forced = 1
     dev_st = None
     if sts:
       dev_st = (torch.cat(sts) if len(sts) > 1 else sts[0]).contiguous()
-      if self.world > 1:  # every rank must skip the update if ANY rank failed: the flag rides on the bucket's all-reduce
-        failed = (dev_st[:n_match] < 0).any() | (dev_st[n_match:] != 0).any()
-        self.bucket.grad_full[self.bucket.n] = failed.to(torch.float32)
+      if self.world > 1:  # every rank must take the same decision: two flags ride on the bucket's all-reduce (sums over ranks)
+        self.bucket.grad_full[self.bucket.n] = (dev_st[:n_match] < 0).any().to(torch.float32) if n_match else 0.0
+        self.bucket.grad_full[self.bucket.n + 1] = (dev_st[n_match:] != 0).any().to(torch.float32) if dev_st.numel() > n_match else 0.0
     world = self.bucket.allreduce()
+    n_world = 0
     if dev_st is not None and world > 1:
-      dev_st = torch.cat([dev_st, self.bucket.grad_full[self.bucket.n:self.bucket.n + 1].view(torch.int32)])
+      dev_st = torch.cat([dev_st, self.bucket.grad_full[self.bucket.n:self.bucket.n + 2].view(torch.int32)])
+      n_world = 2
     lr = self.bucket.step(world=world, status=dev_st, n_solver=n_match)
     if dev_st is not None:
       host = getattr(self, '_status_host', None)
@@ -2352,7 +2427,7 @@ class TrainStep(object):
       ev = torch.cuda.Event()
       host.copy_(dev_st, non_blocking=True)
       ev.record()
-      self._status_pending = (ev, host, n_match, n_ctrl)
+      self._status_pending = (ev, host, n_match, n_ctrl, n_forced, n_world)
     wd = float(self.opt.get('weight_decay', 0.0) or 0.0)
     if self.use_graph:  # the graph's output tensors are rewritten by the next replay: hand out copies of the small ones
       out = {k: (v.clone() if isinstance(v, torch.Tensor) and v.numel() <= 4096 else v) for k, v in out.items()}

@@ -164,10 +164,19 @@ def test_eval_driver_writes_predictions_and_metrics(cuda, tmp_path):
     opt = yaml.safe_load(f)
   m = full_model.get_model(opt).load_weights(dict(np.load(str(tmp_path / 'results' / 'm0' / 'weights.npz'))))
   y, s = m.run(['y_out', 's_out'], {'x': x, 'phase_train': False})
-  y_bin, s_hard, _ = pp.postprocess(y, s, 0.5)
+  # the reference's chain (full_model_eval.py:112-124): pp.upsample — resize + bilateral filter — runs even at equal size
+  yc, s_hard = pp.apply_confidence(y, s)
+  y_bin = pp.apply_threshold(pp.apply_one_label(pp.upsample(yc, dev(y_gt, cuda))), 0.5)
   r = {'y_out': y_bin, 'y_gt': dev(y_gt, cuda), 's_out': s_hard, 's_gt': dev(s_gt, cuda)}
   assert abs(summary['0.50']['sbd']['mean'] - float(analysis.f_symmetric_best_dice(r).mean())) < 1e-6
   assert summary['0.50']['dic']['count'] == 3
+  # --fused_postprocess (not a reference flag): no bilateral step at equal size, one fused pass
+  full_model_eval.main(['--model_id', 'm0', '--results', res, '--input', inp, '--batch_size', '2', '--fused_postprocess',
+                        '--threshold_list', '0.5', '--analyzers', 'sbd'])
+  summary = yaml.safe_load(open(str(out_dir / 'metrics_rank0.yaml')))
+  y_bin, s_hard, _ = pp.postprocess(y, s, 0.5)
+  r = {'y_out': y_bin, 'y_gt': dev(y_gt, cuda), 's_out': s_hard, 's_gt': dev(s_gt, cuda)}
+  assert abs(summary['0.50']['sbd']['mean'] - float(analysis.f_symmetric_best_dice(r).mean())) < 1e-6
 
 
 @pytest.mark.parametrize('H,W,C,pad', [(32, 32, 3, 8), (24, 40, 8, 5), (16, 16, 1, 0)])

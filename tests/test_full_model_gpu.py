@@ -290,40 +290,157 @@ def test_cfg2_full_size_vs_oracle(cuda):
   print('cfg2 full size: max |dy| = %.2e' % np.abs(out['y_out'] - ref['y_out']).max())
 
 
-def test_cfg2_pipelined_operating_point_vs_oracle(cuda):
-  """The operating point bench.py times — cfg2 (512x512, T=16) at B = 8 through the DecodePipeline with 8 batches
-  submitted on 4 streams (group-shared controller K2b in groups of 4, the pair kernels at their pipeline occupancy,
-  the y_out prefill riding on the first controller-CNN launch) — against the float64 oracle on two images of one of
-  the batches, and bit-identical results for every batch that carries the same images."""
+_CFG2_OP = {}
+
+
+def _cfg2_operating_point_case():
+  """cfg2 weights tuned to non-trivial masks + the float64 oracle on two images (computed once per session)."""
+  if not _CFG2_OP:
+    opt = ora.make_opt('cvppp', 512, 512, 16)
+    P = dict(ora.random_params(opt, 101))
+    b = P['ctrl_mlp_b_0'].copy()
+    b[0:2], b[2:4] = [0.1, -0.2], np.log(0.3)
+    P['ctrl_mlp_b_0'] = b
+    for t in range(16):
+      P['attn_dcnn_6_%d_beta' % t] = P['attn_dcnn_6_%d_beta' % t] + 12.0
+    x2, _, _ = _inputs(opt, 2, 102)
+    _CFG2_OP.update(opt=opt, P=P, x2=x2, ref=ora.full_model_forward(opt, P, x2, None, None))
+  return _CFG2_OP
+
+
+@pytest.mark.parametrize('depth,coalesce', [(4, 2), (8, 1)], ids=['bench_default_4_slots_of_2x8', 'one_batch_per_slot'])
+def test_cfg2_pipelined_operating_point_vs_oracle(cuda, depth, coalesce):
+  """The operating point bench.py times, built exactly as bench.py builds it (`model.pipeline(in_flight // coalesce,
+  coalesce=coalesce)` with --in-flight 8, --coalesce 2: four slots on four streams, each decoding TWO consecutively submitted
+  batches of 8 as ONE 16-image forward — K2b in groups of 8, every controller-CNN kernel at twice the tile count, the y_out
+  prefill rider over 16 images) — cfg2 (512x512, T=16), eight batches of 8 submitted, against the float64 oracle: the oracle's
+  two images sit at positions 2 and 5 of EVERY batch, so both halves of a slot's 16-image launch are checked.  The
+  one-batch-per-slot case (rounds 2-4's protocol: K2b in groups of 4) stays beside it."""
   import full_model
-  opt = ora.make_opt('cvppp', 512, 512, 16)
-  P = dict(ora.random_params(opt, 101))
-  b = P['ctrl_mlp_b_0'].copy()
-  b[0:2], b[2:4] = [0.1, -0.2], np.log(0.3)
-  P['ctrl_mlp_b_0'] = b
-  for t in range(16):
-    P['attn_dcnn_6_%d_beta' % t] = P['attn_dcnn_6_%d_beta' % t] + 12.0
-  x2, _, _ = _inputs(opt, 2, 102)
-  ref = ora.full_model_forward(opt, P, x2, None, None)
+  c = _cfg2_operating_point_case()
+  ref = c['ref']
   rng = np.random.RandomState(7)
-  x8 = rng.rand(8, 512, 512, 3).astype(np.float32)
-  x8[2], x8[5] = x2[0], x2[1]  # the oracle's two images sit at positions 2 and 5 of every batch
+  feeds = []
+  for k in range(2):  # two different batches alternate, so that a slot's two members differ in their other six images
+    x8 = rng.rand(8, 512, 512, 3).astype(np.float32)
+    x8[2], x8[5] = c['x2'][0], c['x2'][1]
+    feeds.append({'x': torch.as_tensor(x8).cuda(), 'phase_train': False})
+  m = full_model.get_model(c['opt']).load_weights(c['P'])
+  pipe = m.pipeline(max(1, 8 // coalesce), coalesce=coalesce)  # bench.py: model.pipeline(in_flight // coalesce, coalesce=coalesce)
+  assert pipe.streams == 4 and pipe.depth == depth
+  for k in range(8):
+    assert not pipe.full()
+    pipe.submit(['y_out', 's_out'], feeds[k % 2])
+  assert not pipe.free and not pipe.group  # every slot busy, nothing waiting for company
+  outs = []
+  while len(pipe):
+    outs.append(pipe.collect(as_numpy=True))
+  sb = pipe.slots[0][0].subs[0]
+  assert sb.get('ctrl_batch')  # the slots run the group-shared controller
+  assert int(sb['img'].shape[0]) == 8 * coalesce  # ... over the images of `coalesce` batches
+  for k, (y, s) in enumerate(outs):
+    y0, s0 = outs[k % 2]
+    assert (y == y0).all() and (s == s0).all()  # the same batch in another slot / the other half of a launch: bit-identical
+    for j, pos in enumerate((2, 5)):
+      assert np.abs(y[pos] - ref['y_out'][j]).max() < MASK_TOL and np.abs(s[pos] - ref['s_out'][j]).max() < MASK_TOL
+  assert ref['y_out'].max() > 0.9
+
+
+def _bench_pipeline(m, stages, in_flight, coalesce, B):
+  """The DecodePipeline bench.py --config cfg3|cfg5 builds for one stage (bench.bench_other: no --part-images, default streams)."""
+  depth = max(1, in_flight // stages // coalesce)
+  return m.pipeline(depth, max_images=B * coalesce, co_resident=min(depth, 4) * stages, streams=None, coalesce=coalesce)
+
+
+def test_cfg3_coalesced_operating_point_vs_oracle(cuda):
+  """bench.py --config cfg3 as it runs by default (--in-flight 8 --coalesce 2): KITTI arch 128x448, T = 20, both stages, every
+  slot decoding TWO batches of 16 as one 32-image forward (more images than any multi-workgroup controller form takes at this
+  co-residency: whatever form the engine picks is the one checked).  Four batches per stage; the oracle's two images sit at
+  positions 3 and 12 of every batch — float64 oracle masks within 1e-3 for full_model, boxes and scores for box_model."""
+  import box_model
+  import full_model
+  opt = ora.make_opt('kitti', 128, 448, 20)
+  B, T, H, W = 16, 20, 128, 448
+  x2, d2, y2 = _inputs(opt, 2, 62)
+  rng = np.random.RandomState(11)
+  xb, db, yb = _inputs(opt, B, 63)
+  for k, pos in enumerate((3, 12)):
+    xb[pos], db[pos], yb[pos] = x2[k], d2[k], y2[k]
+  # stage 2: full_model
+  P = ora.random_params(opt, 61)
+  ref = ora.full_model_forward(opt, P, x2, d2, y2)
   m = full_model.get_model(opt).load_weights(P)
-  pipe = m.pipeline(8)
-  assert pipe.streams == 4
-  feed = {'x': torch.as_tensor(x8).cuda(), 'phase_train': False}
-  for _ in range(8):
+  pipe = _bench_pipeline(m, 2, 8, 2, B)
+  assert pipe.depth == 2 and pipe.coalesce == 2
+  feed = {'x': torch.as_tensor(xb).cuda(), 'd_in': torch.as_tensor(db).cuda(), 'y_in': torch.as_tensor(yb).cuda(), 'phase_train': False}
+  for _ in range(4):
+    assert not pipe.full(B)
     pipe.submit(['y_out', 's_out'], feed)
   outs = []
   while len(pipe):
     outs.append(pipe.collect(as_numpy=True))
-  assert pipe.slots[0][0].subs[0].get('ctrl_batch')  # the slots run the group-shared controller
-  y0, s0 = outs[0]
-  for y, s in outs[1:]:
-    assert (y == y0).all() and (s == s0).all()
-  for k, pos in enumerate((2, 5)):
-    assert np.abs(y0[pos] - ref['y_out'][k]).max() < MASK_TOL and np.abs(s0[pos] - ref['s_out'][k]).max() < MASK_TOL
-  assert ref['y_out'].max() > 0.9
+  assert int(pipe.slots[0][0].subs[0]['img'].shape[0]) == 32
+  for y, s in outs:
+    for k, pos in enumerate((3, 12)):
+      assert np.abs(y[pos] - ref['y_out'][k]).max() < MASK_TOL and np.abs(s[pos] - ref['s_out'][k]).max() < MASK_TOL
+  print('cfg3 full_model slot controller:', 'K2b' if pipe.slots[0][0].subs[0].get('ctrl_batch') else
+        'split' if 'ctrl_ws' in pipe.slots[0][0].subs[0] else 'one workgroup per image')
+  del pipe, m
+  # stage 1: box_model (teacher-forced canvas from y_gt and the fed noise)
+  Pb = ora.random_params(opt, 64, box_model=True)
+  y_gt2 = np.zeros((2, T, H, W), np.float32)
+  for b in range(2):
+    for t in range(3):
+      y0, x0 = rng.randint(0, H // 2), rng.randint(0, W // 2)
+      y_gt2[b, t, y0:y0 + rng.randint(8, H // 2), x0:x0 + rng.randint(8, W // 2)] = 1
+  noise2 = rng.uniform(0, 0.3, (T, 2, H, W, 1)).astype(np.float32)
+  refb = ora.box_model_forward(opt, Pb, x2, y_gt2, noise2, d_in=d2, y_in=y2)
+  y_gtb = np.zeros((B, T, H, W), np.float32)
+  y_gtb[:, 0, 10:60, 20:200] = 1
+  noiseb = rng.uniform(0, 0.3, (T, B, H, W)).astype(np.float32)
+  for k, pos in enumerate((3, 12)):
+    y_gtb[pos], noiseb[:, pos] = y_gt2[k], noise2[:, k, :, :, 0]
+  mb = box_model.get_model(opt).load_weights(Pb)
+  pipe = _bench_pipeline(mb, 2, 8, 2, B)
+  feedb = dict(feed, y_gt=torch.as_tensor(y_gtb).cuda(), noise=torch.as_tensor(noiseb).cuda())
+  for _ in range(4):
+    pipe.submit(['attn_box', 's_out'], feedb)
+  while len(pipe):
+    ab, sc = pipe.collect(as_numpy=True)
+    for k, pos in enumerate((3, 12)):
+      assert np.abs(ab[pos] - refb['attn_box'][k]).max() < MASK_TOL and np.abs(sc[pos] - refb['s_out'][k]).max() < MASK_TOL
+  assert int(pipe.slots[0][0].subs[0]['img'].shape[0]) == 32
+
+
+def test_cfg5_coalesced_operating_point_vs_oracle(cuda):
+  """bench.py --config cfg5 as it runs by default (--in-flight 8 --coalesce 4): Cityscapes arch 256x512, T = 20, batches of 4,
+  every slot decoding FOUR batches as one 16-image forward; the oracle's two images at positions 1 and 2 of every batch."""
+  import full_model
+  opt = ora.make_opt('cityscapes', 256, 512, 20)
+  B = 4
+  P = ora.random_params(opt, 71)
+  x2, d2, y2 = _inputs(opt, 2, 72)
+  ref = ora.full_model_forward(opt, P, x2, d2, y2)
+  m = full_model.get_model(opt).load_weights(P)
+  pipe = _bench_pipeline(m, 1, 8, 4, B)
+  assert pipe.depth == 2 and pipe.coalesce == 4
+  feeds = []
+  for k in range(2):
+    xb, db, yb = _inputs(opt, B, 73 + k)
+    for j, pos in enumerate((1, 2)):
+      xb[pos], db[pos], yb[pos] = x2[j], d2[j], y2[j]
+    feeds.append({'x': torch.as_tensor(xb).cuda(), 'd_in': torch.as_tensor(db).cuda(), 'y_in': torch.as_tensor(yb).cuda(), 'phase_train': False})
+  for k in range(8):
+    assert not pipe.full(B)
+    pipe.submit(['y_out', 's_out'], feeds[k % 2])
+  assert not pipe.free
+  n = 0
+  while len(pipe):
+    y, s = pipe.collect(as_numpy=True)
+    n += 1
+    for j, pos in enumerate((1, 2)):
+      assert np.abs(y[pos] - ref['y_out'][j]).max() < MASK_TOL and np.abs(s[pos] - ref['s_out'][j]).max() < MASK_TOL
+  assert n == 8 and int(pipe.slots[0][0].subs[0]['img'].shape[0]) == 16
 
 
 def test_cfg5_cityscapes_t32(cuda):
@@ -411,6 +528,56 @@ def test_starved_split_controller_recovers_on_one_workgroup_form(cuda):
     warnings.simplefilter('always')
     y3, s3 = pipe.collect()
   assert isinstance(y3, np.ndarray) and np.abs(y3 - good[0]).max() < 1e-4 and np.abs(s3 - good[1]).max() < 1e-4
+
+
+def test_xcd_local_controller_with_part_of_its_xcd_taken(cuda):
+  """The XCD-local controller (ra_ctrl_split.hip, XL form: the 16 workgroups of image b run on XCD b % 8 and exchange through
+  that XCD's L2; roles are per-XCD tickets) under a REAL uneven deal instead of a simulated status word: a parked kernel
+  (ra_debug_park_xcd) holds 24 of XCD 0's 32 CUs — 100 KB of LDS each, so none of them can take a 112 KB controller workgroup —
+  for longer than the controller's spin limit.  Image 0's team then cannot be resident together: whether the dispatcher holds
+  its other workgroups back (the residents time out on their peers) or deals them to other XCDs (tickets beyond an XCD's share
+  wrap onto roles that exist; XCD 0's team stays short), the launch must flag its status word, model.run must decode the batch
+  again on the one-workgroup controller, and the masks must be the oracle's."""
+  import time
+  import warnings
+  import full_model
+  import ra_ops as ops
+  opt = ora.make_opt('cvppp', 128, 128, 2)
+  P = ora.random_params(opt, 47)
+  x = np.random.RandomState(12).rand(2, 128, 128, 3).astype(np.float32)
+  ref = ora.full_model_forward(opt, P, x, None, None)
+  m = full_model.get_model(opt).load_weights(P)
+  feed = {'x': x, 'phase_train': False}
+  good = m.run(['y_out', 's_out'], feed, as_numpy=True)
+  eng = m.engine
+  sb = eng.subs[0]
+  if 'ctrl_ws' not in sb or sb.get('ctrl_batch'):
+    pytest.skip('the per-image split controller is not what this engine runs')
+  assert np.abs(good[0] - ref['y_out']).max() < MASK_TOL
+  resident = torch.zeros(1, dtype=torch.int32, device=cuda)
+  side = torch.cuda.Stream()
+  torch.cuda.synchronize()
+  ops.park_xcd(0, 24, lds_bytes=100 * 1024, millis=12000, resident=resident, stream=side)
+  t0 = time.time()
+  while int(resident.item()) < 24 and time.time() - t0 < 5.0:  # (.item() runs on the default stream: it does not wait for `side`)
+    time.sleep(0.01)
+  n_parked = int(resident.item())
+  assert n_parked == 24, 'parked workgroups resident on XCD 0: %d' % n_parked
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    t0 = time.time()
+    y, s = m.run(['y_out', 's_out'], feed, as_numpy=True)
+    dt = time.time() - t0
+  torch.cuda.synchronize()
+  timed_out = any('one-workgroup controller' in str(x_.message) for x_ in w)
+  print('run with 24 CUs of XCD 0 parked: %.2f s, timed out and re-decoded: %s' % (dt, timed_out))
+  # 8 free CUs on XCD 0 < 16 workgroups: the team could not have been resident together
+  assert timed_out and eng.ctrl_split is False and 'ctrl_ws' not in eng.subs[0]
+  assert np.abs(y - ref['y_out']).max() < MASK_TOL and np.abs(s - ref['s_out']).max() < MASK_TOL
+  assert np.abs(y - good[0]).max() < 1e-4
+  # the engine stays on the one-workgroup form and stays right
+  y2 = m.run('y_out', feed, as_numpy=True)
+  assert np.array_equal(y2, y)
 
 
 def test_decode_pipeline_coalesced_batches_match_lone_runs(cuda):

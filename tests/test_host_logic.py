@@ -256,6 +256,27 @@ def test_deferred_status_check_raises_on_flush():
   s._status_pending = (Ev(), other, 16, 1)
   with pytest.raises(rn.RecAttendError):
     s.flush_status()
+  # the record of a data-parallel step: [16 matching | 1 controller | 0 forced | 2 all-reduced flags] — the decision is the same
+  # on every rank: ANOTHER rank's controller time-out makes this rank recover too instead of raising ...
+  s2 = Stub()
+  rec = torch.zeros(19, dtype=torch.int32)
+  rec[18] = 0x3f800000  # flag 1: "a controller timed out on some rank" (this rank's own word, [16], is clean)
+  s2._status_pending = (Ev(), rec, 16, 1, 0, 2)
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    assert s2._check_status(s2._status_pending) is True
+  assert any('on another rank' in str(x.message) for x in w)
+  assert s2.seq_ctrl_split is False and s2.dropped == 1 and s2.bucket.global_step == 6 and s2.skipped_steps == 1
+  # ... another rank's failed MATCHING raises here as it does there ...
+  rec = torch.zeros(19, dtype=torch.int32)
+  rec[17] = 0x40000000  # two ranks' matchings failed
+  with pytest.raises(rn.RecAttendError):
+    s2._check_status((Ev(), rec, 16, 1, 0, 2))
+  # ... and a step skipped on purpose (queued behind a timed-out one) only gives its number back, whatever else it says
+  rec = torch.zeros(20, dtype=torch.int32)
+  rec[16], rec[17], rec[19] = 1, 1, 0x3f800000
+  assert s2._check_status((Ev(), rec, 16, 1, 1, 2)) is False
+  assert s2.bucket.global_step == 5 and s2.skipped_steps == 2 and s2.dropped == 1
 
 
 def test_weights_stamp_sees_every_kind_of_change():
@@ -288,3 +309,28 @@ def test_weights_stamp_sees_every_kind_of_change():
   with torch.no_grad():
     m[k].add_(1.0)
   assert plain._weights_stamp() != p0
+
+
+def test_global_pack_cache_keeps_only_the_latest_version_of_a_weight():
+  """the train-mode nnlib closures pack their filters into ra_train._PACK, whose keys carry the weight's version; an
+  in-place optimizer step used to leave one dead set of packs per step behind.  A newer version of the same (tensor, geometry)
+  replaces the entry, other geometries of the tensor stay, and the cache is capped."""
+  import ra_train as rt
+  c = rt._LatestVersionPack()
+  c[(100, 0, 3, 8, 4, 0, False)] = ('w', 'p0')
+  c[(100, 1, 3, 8, 4, 0, False)] = ('w', 'p1')     # the weight moved in place: replaces p0
+  c[(100, 1, 3, 8, 8, 0, False)] = ('w', 'q1')     # another geometry of the same weight: kept beside it
+  c[('shift', 200, 0, 16)] = ('b', 's0')
+  c[('shift', 200, 5, 16)] = ('b', 's5')
+  c[('split', 100, 1, True)] = ('w', 1)
+  c[('split', 100, 2, True)] = ('w', 2)
+  assert sorted(map(str, c)) == sorted(map(str, [(100, 1, 3, 8, 4, 0, False), (100, 1, 3, 8, 8, 0, False), ('shift', 200, 5, 16),
+                                                 ('split', 100, 2, True)]))
+  assert c.get((100, 0, 3, 8, 4, 0, False)) is None and c[(100, 1, 3, 8, 4, 0, False)][1] == 'p1'
+  for i in range(c.CAP + 500):
+    c[(1000 + i, 0, 1)] = i
+  assert len(c) == c.CAP and len(c._latest) == c.CAP
+  c.clear()
+  assert not c and not c._latest
+  assert isinstance(rt._PACK, rt._LatestVersionPack)
+

@@ -327,6 +327,9 @@ def test_controller_split(cuda, arch, H, W, flags, B):
     ('kitti', 128, 448, {}, 16),                             # full groups only
     ('cvppp', 512, 512, {'fixed_var': True, 'num_ctrl_mlp_layers': 2}, 11),  # full groups + a ragged one
     ('cvppp', 512, 512, {'num_glimpse_mlp_layers': 1}, 1),
+    ('cvppp', 512, 512, {}, 16),       # the headline's launch: a pipeline slot of two batches of 8 (bench.py, coalesce = 2)
+    ('cityscapes', 256, 512, {}, 16),  # cfg5's slot: four batches of 4
+    ('kitti', 128, 448, {}, 32),       # cfg3's slot: two batches of 16
 ])
 def test_controller_batch(cuda, arch, H, W, flags, B):
   """K2b, the split controller with its weight slices shared by groups of 4 images (8 for launches of more than 8): the oracle's recurrence,

@@ -1526,3 +1526,40 @@ def test_failed_status_never_reaches_the_weights(cuda):
     loss, _ = m.run(['loss', 'train_step'], feed)  # goes on, on the one-workgroup controller
     tr.flush_status()
     assert np.isfinite(float(loss)) and not torch.equal(tr.bucket.param, snap2[0]) and tr.bucket.global_step == snap2[1] + 1
+
+
+def test_controller_time_out_noticed_one_step_late(cuda):
+  """full_model_train's loop never flushes, so a controller time-out of step k is noticed inside step k+1's run() —
+  AFTER step k+1's graph has been launched on the 16-workgroup controller over the workspace step k left behind.  The check must
+  not erase step k+1's own status (the words are snapshots, not aliases of the controller's sticky word), step k+1's update
+  must be refused as well (a forced status word), both step numbers are given back, and the trainer goes on on the
+  one-workgroup controller with a healthy step k+2."""
+  import warnings
+  import full_model
+  opt, P, x, y_gt, s_gt = _case(T=2, wmul=0.6)
+  feed = {'x': x, 'y_gt': y_gt, 's_gt': s_gt, 'phase_train': True, 'aug': False}
+  m = full_model.get_model(opt).load_weights(P)
+  for _ in range(2):
+    m.run(['loss', 'train_step'], feed)
+  tr = m.trainer
+  tr.flush_status()
+  if getattr(tr, '_seqc', None) is None or not tr._seqc.get('ok'):
+    pytest.skip('the sequential phase does not run the 16-workgroup controller here')
+  torch.cuda.synchronize()
+  snap = (tr.bucket.param.clone(), tr.bucket.m.clone(), tr.bucket.global_step)
+  tr._inject_ctrl_status = 1  # step 3: "a controller workgroup timed out"
+  m.run(['loss', 'train_step'], feed)
+  assert tr._status_pending is not None and tr._status_pending[3] >= 1
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    m.run(['loss', 'train_step'], feed)  # step 4: launched, THEN step 3's record is read
+  assert any('one-workgroup controller' in str(x_.message) for x_ in w)
+  assert tr.seq_ctrl_split is False and tr._status_pending is not None and tr._status_pending[4] == 1  # step 4 carries the forced word
+  torch.cuda.synchronize()
+  assert torch.equal(tr.bucket.param, snap[0]) and torch.equal(tr.bucket.m, snap[1])  # neither step 3 nor step 4 reached the weights
+  loss, _ = m.run(['loss', 'train_step'], feed)  # step 5 = the third step taken again, on the one-workgroup controller
+  tr.flush_status()
+  torch.cuda.synchronize()
+  assert np.isfinite(float(loss)) and not torch.equal(tr.bucket.param, snap[0])
+  assert tr.bucket.global_step == snap[2] + 1 and tr.skipped_steps == 2
+
