@@ -93,10 +93,10 @@ def seed_weights(model, seed):
   model['ctrl_mlp_b_0'].copy_(b)
 
 
-ROUNDS = ('r05', 'r04', 'r03', 'r02', 'r01')
+ROUNDS = ('r06', 'r05', 'r04', 'r03', 'r02', 'r01')
 
 
-def pmc_traffic(images, size, name='r03_pmc_encoder_traffic.json', want_source=False):
+def pmc_traffic(images, size, name='rNN_pmc_encoder_traffic.json', want_source=False):
   """HBM bytes per launch group measured with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE
   passes over `bench.py --pmc-group REPS [--pmc-which attn]`, summarised by tools/pmc_traffic.py);
   the newest committed round's file that matches this shape.  want_source: also which file, and whether the library
@@ -143,6 +143,50 @@ def mfma_busy():
   return None
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_16x16x32_bf16: 16 384 FLOP in 16 cycles of a SIMD)
+MFMA_CLOCK_GHZ = 2.4
+
+
+def mfma_executed(enc_us=None):
+  """What the matrix pipes EXECUTED in the controller-CNN launch group, from the newest committed SQ counter pass that holds
+  SQ_INSTS_VALU_MFMA_MOPS_F32 / _BF16 (rocprofv3: add-or-multiply operations / 512, per dispatch): the time the group's MFMA
+  instructions occupy their pipe at its dense peak — float32 ops at 157.3 TFLOP/s plus bf16 ops at 2 500 TFLOP/s (= MFMA
+  instructions issued x cycles each / (1024 SIMDs x clock)) — over the group's duration.  Unlike roofline.frac (ALGORITHMIC FLOPs
+  over the float32 peak, which the six-piece bf16 forms and Winograd can push past 1) this cannot exceed 1: it is the fraction
+  of the launch group's time during which the matrix pipes had work."""
+  import csv
+  for rnd in ROUNDS:
+    path = os.path.join(ROOT, 'profiles', rnd + '_pmc_sq_mfma_per_kernel.csv')
+    if not os.path.exists(path):
+      continue
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r['kernel'] for k in ('ra::cpair::', 'ra::wino::', 'ra::csplit::', 'ra::conv::conv3x3_mfma<16, 1, 4, 2, 1, false'))
+            and 'conv_pair8_mfma<4, false' not in r['kernel']]
+    if not rows or 'SQ_INSTS_VALU_MFMA_MOPS_BF16' not in rows[0]:
+      continue
+    base = min(int(r['dispatches']) for r in rows)
+    per, tot_s, tot_cyc = {}, 0.0, 0.0
+    for r in rows:
+      w = round(int(r['dispatches']) / base)
+      f32, b16 = 512.0 * float(r['SQ_INSTS_VALU_MFMA_MOPS_F32']), 512.0 * float(r['SQ_INSTS_VALU_MFMA_MOPS_BF16'])
+      pipe_s = f32 / (PEAK_F32_MFMA_TFLOPS * 1e12) + b16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+      cyc = float(r['GRBM_GUI_ACTIVE']) / 8.0
+      per[r['kernel'].split('(')[0].replace('void ', '')] = {
+          'launches_per_timestep': w, 'gflop_f32_pipe': f32 / 1e9, 'gflop_bf16_pipe': b16 / 1e9, 'pipe_us_at_peak': pipe_s * 1e6,
+          'frac_of_its_own_duration': pipe_s * MFMA_CLOCK_GHZ * 1e9 / cyc}
+      tot_s += w * pipe_s
+      tot_cyc += w * cyc
+    out = {'pipe_us_at_peak_per_launch_group': tot_s * 1e6, 'frac_counter_clock': tot_s * MFMA_CLOCK_GHZ * 1e9 / tot_cyc,
+           'peaks': {'f32_mfma_tflops': PEAK_F32_MFMA_TFLOPS, 'bf16_mfma_tflops': PEAK_BF16_MFMA_TFLOPS},
+           'source': 'profiles/%s_pmc_sq_mfma_per_kernel.csv' % rnd, 'per_kernel': per,
+           'note': 'executed matrix work: SQ_INSTS_VALU_MFMA_MOPS_{F32,BF16} x 512 FLOP each at the dense peak of its own pipe, over '
+                   'the launch time (frac: this run\'s HIP-event time of the group; frac_counter_clock: the counter pass\'s own '
+                   'GRBM_GUI_ACTIVE at %.1f GHz); bounded by 1, unlike roofline.frac' % MFMA_CLOCK_GHZ}
+    if enc_us:
+      out['frac'] = tot_s * 1e6 / enc_us
+    return out
+  return None
+
+
 def _cgroup_cpus():
   """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a
   container often sees every host core in os.cpu_count() but is scheduled on far fewer)."""
@@ -156,7 +200,19 @@ def _cgroup_cpus():
   return max(1, n)
 
 
-def cpu_baseline(opt, seed, budget_s=12.0, batch=2, steps=4):
+def _cpu_feeds(opt, rng, n):
+  """x [, d_in, y_in] for the CPU restatement (SURVEY 8d's synthetic inputs)."""
+  H, W = opt['inp_height'], opt['inp_width']
+  x = rng.rand(n, H, W, 3).astype(np.float32)
+  if not opt.get('add_d_out'):
+    return x, None, None
+  d_in = np.eye(8, dtype=np.float32)[rng.randint(0, 8, (n, H, W))]
+  lg = rng.randn(n, H, W, opt['num_semantic_classes']).astype(np.float32)
+  e = np.exp(lg - lg.max(-1, keepdims=True))
+  return x, d_in, (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+
+def cpu_baseline(opt, seed, budget_s=12.0, batch=2, steps=4, arch='CVPPP'):
   """CPU stand-in baseline as BASELINE.md §3 / SURVEY.md §8(d) define it: the PyTorch-CPU
   restatement of the same graph (oracle/ra_oracle_torch.py: F.conv2d / conv_transpose2d /
   max_pool2d / matmul, i.e. oneDNN + BLAS), float32, on a bounded sample of the same workload —
@@ -178,23 +234,23 @@ def cpu_baseline(opt, seed, budget_s=12.0, batch=2, steps=4):
       o1 = dict(opt)
       o1['timespan'] = 1
       P1 = ora.random_params(o1, seed)
-      x1 = rng.rand(1, H, W, 3).astype(np.float32)
+      x1, d1, y1 = _cpu_feeds(opt, rng, 1)
       probe = {}
       for nt in sorted({usable, min(usable, 32)}, reverse=True):
         torch.set_num_threads(nt)
-        ort.forward(o1, P1, x1)  # warm-up: thread pool, oneDNN primitive cache
+        ort.forward(o1, P1, x1, d1, y1)  # warm-up: thread pool, oneDNN primitive cache
         t0 = time.perf_counter()
-        ort.forward(o1, P1, x1)
+        ort.forward(o1, P1, x1, d1, y1)
         probe[nt] = time.perf_counter() - t0
       threads = min(probe, key=probe.get)
       torch.set_num_threads(threads)
       o2 = dict(opt)
       o2['timespan'] = steps
       P2 = ora.random_params(o2, seed)
-      x2 = rng.rand(batch, H, W, 3).astype(np.float32)
+      x2, d2, y2 = _cpu_feeds(opt, rng, batch)
       n, t0 = 0, time.perf_counter()
       while True:
-        ort.forward(o2, P2, x2)
+        ort.forward(o2, P2, x2, d2, y2)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 128:  # bounded sample
@@ -205,10 +261,102 @@ def cpu_baseline(opt, seed, budget_s=12.0, batch=2, steps=4):
           'kind': 'port', 'label': 'CPU stand-in (PyTorch-CPU restatement, float32), %d threads of %d usable '
                                    'cores' % (threads, usable),
           'sample': 'PyTorch-CPU (oneDNN/BLAS) float32 restatement, %d forwards of B=%d x T=%d of the same '
-                    '%dx%d CVPPP-arch graph in %.1f s on %d threads (one image-timestep probe: %s); stand-in '
+                    '%dx%d %s-arch full_model graph in %.1f s on %d threads (one image-timestep probe: %s); stand-in '
                     'for the TF-0.12 CPU path, which cannot run here'
-                    % (n, batch, steps, H, W, el, threads,
+                    % (n, batch, steps, H, W, arch, el, threads,
                        ', '.join('%d threads %.2f s' % kv for kv in sorted(probe.items())))}
+
+
+def graph_time_us_plain(fn, reps=20, inner=8):
+  """Average duration of one `fn` launch group: `inner` copies captured in one HIP graph (a replay's fixed ~10 us must not
+  be charged to the kernels), replayed `reps` times between two HIP events on the launch stream."""
+  fn()
+  torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    for _ in range(inner):
+      fn()
+  for _ in range(3):
+    g.replay()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize()
+  e0.record()
+  for _ in range(reps):
+    g.replay()
+  e1.record()
+  torch.cuda.synchronize()
+  return 1e3 * e0.elapsed_time(e1) / (reps * inner)
+
+
+def other_rooflines(model, feed, T, H, W, slot_eng=None):
+  """`roofline` (controller-CNN launch group, MFMA), `roofline_attn` (extract + paste, HBM), tail and controller times of a
+  full_model stage at cfg3 / cfg5, in the protocol of the cfg2 line: each group exactly as the engine issues it for ONE batch,
+  captured alone in a HIP graph and timed with HIP events on the launch stream; `as_launched` = the same groups over the images
+  a pipeline slot decodes per forward.  FLOPs / bytes: SURVEY 8(d) (2*9*Cin*Cout per conv output pixel; H*W*(C0+3)*4 B per
+  image-timestep for the resample)."""
+  import ra_ops as ops
+  eng, d = model.engine, model.dims
+  eng.forward(feed['x'], d_in=feed.get('d_in'), y_in=feed.get('y_in'))
+  torch.cuda.synchronize()
+  tot_f, per_f = encoder_flops_per_image(d)
+  Fh, Fw = d['Fh'], d['Fw']
+  pflags = (0 if d['disable_overwrite'] else ops.PASTE_Y_PREFILLED) | ops.PASTE_CANVAS_FLOORED
+
+  def groups(e):
+    sb, Wt = e.subs[0], e.W
+    n = int(sb['img'].shape[0])
+
+    def enc_step(step):
+      src = sb['img'] if step[1] == 0 else sb['ccnn'][step[1] - 1]
+      e._run_cnn([step], Wt['ccnn'], src, sb['ccnn'], 1, 'ctrl_cnn', plane=sb['canvas'], cache=sb.get('l0cache'))
+
+    def attn_group():
+      ops.extract_direct(sb['img'], 0, sb['attn'][0], Fh, Fw, d['C0p'], True, sb['x_patch'][0], canvas=sb['canvas'], canvas_chan=d['D'])
+      ops.paste_direct(sb['y_out_patch'][0], 0, sb['attn'][0], -5.0, d['disable_overwrite'], sb['y_out'].data_ptr(), T * H * W, H, W,
+                       canvas=sb['canvas'], flags=pflags)
+    return sb, n, enc_step, attn_group
+
+  sb, n, enc_step, attn_group = groups(eng)
+  layers = []
+  for step in eng.plan['ccnn']:
+    us = graph_time_us_plain(lambda: enc_step(step))
+    fl = sum(per_f[i] for i in step[1:])
+    kind = ('pair' if step[0] == 'pair' else 'K1s' if eng.W['ccnn_split'][step[1]] is not None else
+            'K1w' if eng.W['ccnn_wino'][step[1]] is not None and step[1] > 0 else 'K1')
+    layers.append({'layers': list(step[1:]), 'kernel': kind, 'avg_us': us, 'gflop': fl * n / 1e9, 'tflops': fl * n / (us * 1e-6) / 1e12})
+  enc_us = graph_time_us_plain(lambda: [enc_step(st_) for st_ in eng.plan['ccnn']])
+  enc_bytes = 4.0 * sb['canvas'].numel()
+  for st_ in eng.plan['ccnn']:
+    src_ = sb['img'] if st_[1] == 0 else sb['ccnn'][st_[1] - 1]
+    enc_bytes += 4.0 * (src_.numel() + sb['ccnn'][st_[-1]].numel())
+  ach = tot_f * n / (enc_us * 1e-6) / 1e12
+  roof = {'kernel': 'controller CNN: %d layers in %d launches per timestep per batch of %d images (%s)'
+                    % (d['ccnn_nlayers'], len(eng.plan['ccnn']), n, ', '.join('L%s %s' % ('+'.join(map(str, l['layers'])), l['kernel']) for l in layers)),
+          'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+          'traffic': None, 'algorithmic_bytes_per_launch_group': enc_bytes, 'flop_per_launch_group': tot_f * n,
+          'flop_per_image_timestep': tot_f, 'avg_us_per_launch_group': enc_us, 'layers': layers,
+          'peak_note': 'algorithmic FLOPs (SURVEY 8d) over the dense f32-input MFMA peak; the K1s / K1w / split-pair launches do their '
+                       'multiplies on the bf16 pipe as six piece products or as Winograd, so this is a speed relative to a '
+                       'float32-MFMA-bound kernel, not a bounded fraction'}
+  attn_us = graph_time_us_plain(attn_group)
+  abytes = float(H * W * (d['acnn_channels'][0] + 3) * 4)
+  roof_a = {'kernel': 'ra::attnd::extract_rows_kernel + paste_win_kernel, one batch of %d images' % n, 'bound': 'hbm',
+            'achieved': abytes * n / (attn_us * 1e-6) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': abytes * n / (attn_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 'traffic': None, 'bytes_per_launch_group': abytes * n,
+            'bytes_per_image_timestep': abytes, 'avg_us_per_launch_group': attn_us,
+            'note': 'algorithmic bytes (SURVEY 8d: H*W*(C0+3)*4 per image-timestep) over the two dependent launches; the kernels are '
+                    'window-only, so the bytes really moved are a fraction of that (cfg2: 0.26x, profiles/r05_pmc_attn_traffic.json)'}
+  extra = {'tail_us': graph_time_us_plain(lambda: eng._launch_tail(sb, 1, False, sb['ccnn'][-1]))}
+  if slot_eng is not None and slot_eng.subs:
+    sb2, n2, enc2, attn2 = groups(slot_eng)
+    us2 = graph_time_us_plain(lambda: [enc2(st_) for st_ in slot_eng.plan['ccnn']])
+    roof['as_launched'] = {'images_per_launch': n2, 'avg_us_per_launch_group': us2, 'achieved': tot_f * n2 / (us2 * 1e-6) / 1e12,
+                           'frac': tot_f * n2 / (us2 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    sb2['attn'][0].copy_(sb['attn'][0][:1].expand(n2, -1))
+    ua2 = graph_time_us_plain(attn2)
+    roof_a['as_launched'] = {'images_per_launch': n2, 'extract_paste_us': ua2, 'frac_algorithmic': abytes * n2 / (ua2 * 1e-6) / 1e9 / PEAK_HBM_GBS}
+    extra['tail_us_as_launched'] = graph_time_us_plain(lambda: slot_eng._launch_tail(sb2, 1, False, sb2['ccnn'][-1]))
+  return roof, roof_a, extra
 
 
 OTHER_CONFIGS = {  # BASELINE.json configs[2] / configs[4] at the sizes the reference feeds the model (SURVEY.md §8)
@@ -278,7 +426,10 @@ def bench_other(args, rank, world, name):
     for eng_k, _ in pipe.slots:
       eng_k.check_status(recover=False)
   if rank == 0:
-    print(json.dumps({
+    fm = [m for st, m in models if st == 'full_model'][0]
+    fpipe = [p for st, p in pipes if st == 'full_model'][0]
+    roof, roof_a, extra = other_rooflines(fm, feed, T, H, W, slot_eng=fpipe.slots[0][0] if fpipe.slots else None)
+    line = {
         'metric': 'instance-timesteps/sec, %s (whole job)' % name, 'value': world * B * T * args.steps / elapsed,
         'unit': 'instance-timesteps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -288,7 +439,13 @@ def bench_other(args, rank, world, name):
                    'parts_in_flight': depth * len(pipes) * co, 'batches_per_launch': co,
                    'controller': ('group-shared (16 workgroups per %d images)' % ops_group(pipes[-1][1].slots[0][0]) if pipes[-1][1].slots[0][0].subs[0].get('ctrl_batch')
                                   else 'split (16 workgroups per image)' if 'ctrl_ws' in pipes[-1][1].slots[0][0].subs[0]
-                                  else 'single workgroup per image')}}))
+                                  else 'single workgroup per image')},
+        'roofline': roof, 'roofline_attn': roof_a}
+    line.update(extra)
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline(opt, 1234, arch=c['arch'])
+      line['cpu_baseline']['note'] = 'full_model stage only (the restatement of box_model\'s teacher-forced loop is not timed)' if len(models) > 1 else 'full_model'
+    print(json.dumps(line))
   if world > 1:
     ra_dist.barrier()
     torch.distributed.destroy_process_group()
@@ -706,6 +863,7 @@ def main():
                                                                        len(eng.plan['ccnn']), Bs),
         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': enc_traffic, 'traffic_source': enc_traffic_src, 'mfma_busy': mfma_busy(),
+        'executed': mfma_executed(enc_us),
         'traffic_note': 'HBM bytes per launch group from committed rocprofv3 --pmc passes '
                         '(profiles/r0x_pmc_encoder_traffic.json; FETCH_SIZE x2 gfx950 correction + '
                         'WRITE_SIZE); null if no pass matches this shape',
@@ -749,10 +907,11 @@ def main():
       ops.paste_direct(bb['y_out_patch'][0][:n], 0, bb['attn'][0][:n], -5.0, d['disable_overwrite'],
                        bb['y_out'].data_ptr(), T * S * S, S, S, canvas=bb['canvas'][:n], flags=pflags)
 
-    # round 5: the forward issues the extract FUSED with layer 0 of the attention CNN (ra_extract_conv0_f32: one launch for
-    # what were two).  The attention resample's time is then what that launch costs beyond the conv layer it absorbed:
-    #   group = (extract+conv0 launch) + (paste launch) - (the conv0 launch alone, as rounds 1-4 issued it)
-    # all three measured here, in the same graphs-of-8 protocol; `unfused` = extract + paste as separate launches.
+    # The forward issues extract and paste as TWO launches (ra_engine.fuse_extract_conv0 is off by default: the fused
+    # extract + attention-CNN layer 0 launch, ra_extract_conv0_f32, was built in round 5, is parity-tested and measured SLOWER —
+    # profiles/r05_attn_fusion_probe.txt).  Only with RA_FUSE_EXTRACT_CONV0=1 does the accounting below switch to
+    #   group = (extract+conv0 launch) + (paste launch) - (the conv0 launch alone)
+    # all three measured in the same graphs-of-8 protocol; `unfused` = extract + paste as separate launches = what runs.
     fused_attn = bool(eng.fuse_extract_conv0 and 'acnn0_plain' in Wt and eng.plan['acnn'][0] == ('single', 0))
 
     def fused_group(bb=sb, n=Bs, W_=None):
@@ -805,7 +964,7 @@ def main():
     fill_us = graph_time_us(prefill, reps=10, inner=2) if (prefilled and not rides) else 0.0
     group_us = attn_us + fill_us / T
     attn_bytes = float(S * S * (d['acnn_channels'][0] + 3) * 4) * Bs
-    attn_traffic, attn_traffic_src = pmc_traffic(Bs, S, 'r03_pmc_attn_traffic.json', want_source=True)
+    attn_traffic, attn_traffic_src = pmc_traffic(Bs, S, 'rNN_pmc_attn_traffic.json', want_source=True)
     out['roofline_attn'] = {
         'kernel': 'ra::attnd::extract_rows_kernel + paste_win_kernel (+ 1/T of the per-forward fills) — attention '
                   'resample, one sub-batch of %d images' % Bs, 'bound': 'hbm',
@@ -815,7 +974,7 @@ def main():
         'bytes_per_launch_group': attn_bytes, 'avg_us_per_launch_group': group_us,
         'extract_paste_us': attn_us, 'fills_us_per_forward': fill_us,
         'launches_us': attn_t,
-        'accounting': ('round 5: the extract runs FUSED with layer 0 of the attention CNN (one launch instead of two); the '
+        'accounting': ('RA_FUSE_EXTRACT_CONV0=1: the extract runs FUSED with layer 0 of the attention CNN (one launch instead of two); the '
                        "group's time = (extract+conv0 launch + paste launch) - (the conv0 launch alone) = launches_us.fused - "
                        'launches_us.conv0; launches_us.unfused = extract + paste as the two separate launches of rounds 1-4, '
                        'frac_unfused the fraction on that time') if fused_attn else 'extract + paste, two launches',
@@ -827,7 +986,7 @@ def main():
         'launch_floor_us': graph_time_us(lambda: ops.fill(sb['attn'][0][:1, :4], 0.0)),
         'note': 'achieved = ALGORITHMIC bytes (SURVEY 8d: read the attention input once, write y_out, '
                 'read+write the canvas = H*W*(C0+3)*4 B per image-timestep) / time of the two dependent launches.  The '
-                'kernels are window-only: `traffic` (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_attn_traffic.json) is '
+                'kernels are window-only: `traffic` (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, the file traffic_source names) is '
                 'what they really move and achieved_traffic = traffic / time.  launch_floor_us = one dependent launch of a '
                 '4-float fill in the same graph: two of them are the part of the group no kernel design can remove'}
     # the same group at a large batch, where the fixed latencies amortise

@@ -180,8 +180,9 @@ int ra_conv_pair_f32(const float *src, int Cin, int B, int Hs, int Ws, int upsam
 /* K1s (round 5) — the same layer (conv3x3 SAME + folded BatchNorm + ReLU + max-pool, nnlib.py:229-253) as a DIRECT convolution
  * on the BF16 matrix pipe at float32 accuracy: every float32 operand is the exact sum of three bf16 pieces, and six of the
  * nine piece products (everything above 2^-24 of a product) run as v_mfma_f32_16x16x32_bf16 with float32 accumulation
- * (csrc/ra_conv_split.hip).  Cin in {16, 32, 64}, Cout % 16 == 0, pool 1 | 2, W a multiple of 16, H a multiple of 16 (of 8 at
- * Cin = 64: 8-row tiles) (ra_conv_split_supported).  wpacked: ra_conv_split_packed_halfs() 16-bit words, the filter's three bf16 pieces in B-operand
+ * (csrc/ra_conv_split.hip).  Cin in {16, 24, 32, 64}, Cout % 16 == 0, pool 1 | 2, H and W multiples of 4 (round 6: the 16 x 16
+ * tiles — 8 rows at Cin = 64 — may be ragged at the right and bottom edges: KITTI's 56- and 28-pixel maps, the 24- and 12-pixel
+ * patch maps) (ra_conv_split_supported).  wpacked: ra_conv_split_packed_halfs() 16-bit words, the filter's three bf16 pieces in B-operand
  * order, from the reference's [3,3,Cin,Cout] filter by ra_conv_split_pack_weights (host) or ra_conv_split_pack_weights_dev
  * (device pointers; transposed != 0: w is a conv2d_transpose filter [3,3,Cout,Cin] — taps flipped, in / out swapped, as
  * RA_CONV_TRANSPOSED: the packing of a cnn layer's DATA GRADIENT, which the training step runs as this conv with scale 1,
@@ -192,6 +193,12 @@ int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, unsigned short
 int ra_conv_split_pack_weights_dev(const float *w, int Cin, int Cout, int transposed, unsigned short *out, void *stream);
 int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, const unsigned short *wpacked, const float *scale,
                       const float *shift, int Cout, int relu, int pool, float *y, void *stream);
+/* ... with channel plane_chan of x taken from the plane [B,H,W] instead (round 6; Cin 16 | 24 | 32): the FIRST controller-CNN
+ * layer of the KITTI / Cityscapes architectures, whose packed input concat(x, canvas, d_in, y_in) (full_model.py:640-661; 13 / 21
+ * channels packed to 16 / 24) keeps the canvas in its own plane (as ra_conv3x3_f32's plane / plane_chan). */
+int ra_conv_split_plane_f32(const float *x, int B, int H, int W, int Cin, const float *plane, int plane_chan,
+                            const unsigned short *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool,
+                            float *y, void *stream);
 
 /* K1w: conv3x3 SAME + folded BN + ReLU + optional 2x2 max-pool (nnlib.py:229-253) as Winograd F(2x2, 3x3)
  * on the f32 MFMA: 2.25x fewer matrix multiplies than ra_conv3x3_f32 for the same layer, results equal

@@ -38,7 +38,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TW = 16;                     // output tile width (conv resolution); its height TH is 16, or 8 at Cin = 64 (Geo)
 constexpr int WSX = TW + 2;                // staged window width
 constexpr int WSP = 20;                    // LDS row stride in pixels (bank spread, see above)
-constexpr int tile_rows(int cin) { return cin >= 64 ? 8 : 16; }  // Cin = 64: a 10-row window (3 x 28.8 KB) beside 54 KB of filter
+constexpr int tile_rows(int cin) { return (cin >= 64 || cin == 24) ? 8 : 16; }  // Cin = 64: a 10-row window (3 x 28.8 KB) beside 54 KB of filter; 24: two workgroups per CU (below)
+// bytes per staged pixel record: 2 Cin + 16, an ODD number of 16-byte units (48, 80, 144), so that the 16 lanes of a ds_read_b128
+// hit 16 different bank quads; Cin = 24 would give 64 (four-way conflicts) and takes 80
+constexpr int rec_stride(int cin) { return cin == 24 ? 80 : 2 * cin + 16; }
+// K = 32 blocks: the 9 Cin / 8 channel octets of a pixel's 3 x 3 neighbourhood in (tap, octet) order, four to a block — octet
+// o = 4 blk + kb is channels 8 (o % (Cin / 8)) .. + 8 of tap o / (Cin / 8); the last block's spare octets carry zero weights.
+// (Cin = 32: one tap per block; 64: half a tap; 16: two taps; 24, round 6: one and a third.)
+constexpr int k_blocks(int cin) { return (9 * (cin / 8) + 3) / 4; }
 
 struct SArgs {
   const float *x;
@@ -48,17 +55,25 @@ struct SArgs {
   int B, H, W, Cout, relu;
   int bytes_x, bytes_y;
   unsigned *tickets;  // this launch's slots of tile-ticket pools, one per channel slice (ra_common.h); nullptr = the static walk
+  const float *plane;  // PL: a [B,H,W] plane standing in for channel plane_chan of x (the canvas)
+  int plane_chan, bytes_p;
 };
 
 template <int CIN, int NB>  // NB: blocks of 16 output channels per workgroup (2; 1 where Cout is an odd multiple of 16)
 struct Geo {
   static constexpr int TH = tile_rows(CIN), WSY = TH + 2;      // output tile height, staged window height
   static constexpr int GPW = TH / 4;                           // 4 x 4-pixel groups per wave (TH / 4 rows of 4 groups over 4 waves)
-  static constexpr int NBLK = CIN >= 32 ? 9 * (CIN / 32) : 5;  // K = 32 blocks: tap x 32 channels; Cin = 16: two taps x 16
-  static constexpr int RS = 2 * CIN + 16;                      // bytes per staged pixel record
+  static constexpr int NBLK = k_blocks(CIN);
+  static constexpr int RS = rec_stride(CIN);                   // bytes per staged pixel record
   static constexpr int PLANE = WSY * WSP * RS;                 // bytes of one bf16 tile
   static constexpr int WBYTES = NBLK * 3 * NB * 1024;          // one cout slice of the packed filter: [blk][piece][nb][kb][n][8] bf16
   static constexpr int LDS = 3 * PLANE + WBYTES;
+  // Workgroups per CU (round 6).  A layer with few input channels has a SHORT k-loop (Cin = 16, 16 couts: 120 MFMAs per wave and
+  // tile, 0.8 us) — too short to cover the next window's trip from HBM, which is issued behind the staging barrier: with one
+  // workgroup per CU the KITTI architectures' first layer (13 -> 16 channels at full resolution) ran at 4.5 us per tile, slower
+  // than the float32-MFMA K1.  Where two workgroups' LDS fits a CU (Cin = 16 / 24 with 16 couts: 67 / 70 KB each) the grid is
+  // two per CU and one's window fetch, split and barriers hide under the other's k-loop.
+  static constexpr int OCC = 2 * (LDS + 64) <= 160 * 1024 ? 2 : 1;
 };
 
 __device__ inline unsigned pk_bf16(float lo, float hi) {
@@ -100,8 +115,8 @@ __device__ long long *ra_probes_buf;
 #define RA_PS_AT(k)
 #define RA_PS_END
 #endif
-template <int CIN, int POOL, int NB>
-__global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int tiles_x, int tiles_y, int ntiles) {
+template <int CIN, int POOL, int NB, bool PL = false>  // PL: channel a.plane_chan of x comes from the plane a.plane (the first layer's canvas)
+__global__ __launch_bounds__(256, (Geo<CIN, NB>::OCC)) void conv_split_kernel(const SArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = Geo<CIN, NB>;
   constexpr int RS = G::RS, PLANE = G::PLANE, NBLK = G::NBLK, C4 = CIN / 4, TH = G::TH, WSY = G::WSY, GPW = G::GPW;
   constexpr int NITEMS = WSY * WSX * C4, NIT = (NITEMS + 255) / 256;
@@ -126,15 +141,11 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
   int toff[NBLK];
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) {
-    int tap, ch;
-    if constexpr (CIN >= 32) {
-      tap = b / (CIN / 32);
-      ch = 32 * (b % (CIN / 32)) + 8 * kb;
-    } else {
-      tap = 2 * b + (kb >> 1);
-      tap = tap < 9 ? tap : 8;  // the tenth "tap" of the last block carries zero weights: any staged pixel will do
-      ch = 8 * (kb & 1);
-    }
+    constexpr int OPT = CIN / 8;
+    const int o = 4 * b + kb;
+    int tap = o / OPT;
+    const int ch = 8 * (o % OPT);
+    tap = tap < 9 ? tap : 8;  // a spare octet of the last block carries zero weights: any staged pixel will do
     toff[b] = ((tap / 3) * WSP + tap % 3) * RS + 2 * ch;
   }
   const int woff = (kb * 16 + m) * 16;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
   const int per = tiles_x * tiles_y;
 
   // staging items: (window pixel, channel quad); position inside the window is tile-invariant
-  int it_off[NIT], it_r[NIT], it_c[NIT], it_lds[NIT];
+  int it_off[NIT], it_r[NIT], it_c[NIT], it_lds[NIT], it_pl[PL ? NIT : 1];
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int e = tid + 256 * i;
@@ -161,9 +172,16 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     it_off[i] = ((it_r[i] * a.W + it_c[i]) * CIN + 4 * c4) * 4;
     it_lds[i] = (it_r[i] * WSP + it_c[i]) * RS + 8 * c4;
     if (e >= NITEMS) it_r[i] = -(1 << 20);  // never inside the image, never stored
+    if constexpr (PL) it_pl[i] = (c4 == (a.plane_chan >> 2)) ? (it_r[i] * a.W + it_c[i]) * 4 : -1;
   }
-  f32x4 pre[NIT];
-  auto fetch = [&](int T) {
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(PL ? a.plane : a.x), 0, PL ? a.bytes_p : 0, 0x00020000);
+  const int pl_lane = a.plane_chan & 3;
+  // Two windows in flight (round 6): the static walk requests the window of the tile AFTER next while a tile is computed, so a
+  // request has a whole tile period to come back (one tile ahead left a short k-loop — Cin = 16 / 24: under a microsecond —
+  // waiting for HBM at every tile).  Drawn tiles (a.tickets) keep one window in flight: the ticket walk knows one tile ahead.
+  f32x4 preA[NIT], preB[NIT];
+  float plA[PL ? NIT : 1], plB[PL ? NIT : 1];  // PL: the plane's values travel beside the window and are merged at the split
+  auto fetch = [&](int T, f32x4(&pre)[NIT], float(&ppl)[PL ? NIT : 1]) {
     const int fb = T / per, fr = T - fb * per;
     const int fy0 = (fr / tiles_x) * TH - 1, fx0 = (fr % tiles_x) * TW - 1;
     const int base = ((fb * a.H + fy0) * a.W + fx0) * CIN * 4;
@@ -172,6 +190,15 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
       const int Y = fy0 + it_r[i], X = fx0 + it_c[i];
       const bool ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
       pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? base + it_off[i] : 0x7fffffff, 0, 0));
+    }
+    if constexpr (PL) {  // the quad that holds the plane's channel: that component comes from the plane (zero outside the image)
+      const int pbase = ((fb * a.H + fy0) * a.W + fx0) * 4;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int Y = fy0 + it_r[i], X = fx0 + it_c[i];
+        const bool ok = (it_pl[i] >= 0) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+        ppl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ok ? pbase + it_pl[i] : 0x7fffffff, 0, 0));
+      }
     }
   };
 
@@ -189,27 +216,38 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     }
   }
   int tile = blockIdx.x, tnext = 0;
+  const int gstep = (int)gridDim.x;
   if (dyn) {
     tk.begin(tk_sh);
     tile = tk.cur >= 0 ? tk.cur : ntiles;
   }
-  if (tile < ntiles) fetch(tile);
+  if (tile < ntiles) fetch(tile, preA, plA);
+  if (!dyn && tile + gstep < ntiles) fetch(tile + gstep, preB, plB);
 #pragma unroll
   for (int i = 0; i < NWI; ++i) {
     const int e = tid + 256 * i;
     if (e < NWQ) reinterpret_cast<u32x4 *>(wl)[e] = wtmp[i];
   }
-  RA_PS_AT(0);  // prologue: constants, filter copy, first window requested
-  for (; tile < ntiles; tile = tnext) {
-    const int b = tile / per, trem = tile - b * per;
-    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  RA_PS_AT(0);  // prologue: constants, filter copy, first window(s) requested
+
+  // a window's registers -> three bf16 tiles in LDS, between the tile loop's two barriers
+  auto stage = [&](f32x4(&pre)[NIT], float(&ppl)[PL ? NIT : 1]) {
     __syncthreads();  // the previous tile's operand reads are complete (and, first time round, the filter copy is issued)
     RA_PS_AT(1);  // top barrier
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
+      f32x4 v = pre[i];
+      if constexpr (PL) {
+        if (it_pl[i] >= 0) {
+          v.x = pl_lane == 0 ? ppl[i] : v.x;
+          v.y = pl_lane == 1 ? ppl[i] : v.y;
+          v.z = pl_lane == 2 ? ppl[i] : v.z;
+          v.w = pl_lane == 3 ? ppl[i] : v.w;
+        }
+      }
       unsigned H0, M0, L0, H1, M1, L1;
-      split3_pair(pre[i].x, pre[i].y, H0, M0, L0);
-      split3_pair(pre[i].z, pre[i].w, H1, M1, L1);
+      split3_pair(v.x, v.y, H0, M0, L0);
+      split3_pair(v.z, v.w, H1, M1, L1);
       if (it_r[i] >= 0) {
         unsigned char *rec = tin + it_lds[i];
         *reinterpret_cast<u32x2 *>(rec) = u32x2{H0, H1};
@@ -221,16 +259,12 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
     if (dyn) tk.publish(tk_sh);
     __syncthreads();
     RA_PS_AT(3);  // staging barrier
-    if (dyn) {
-      tk.read_next(tk_sh);
-      tk.request();  // older than the prefetch loads below: consumed with them at the next tile's staging
-      tk.step();
-      tnext = tk.cur >= 0 ? tk.cur : ntiles;
-    } else {
-      tnext = tile + (int)gridDim.x;
-    }
-    if (tnext < ntiles) fetch(tnext);  // in flight across the MFMA loop
+  };
 
+  // the k-loop and the epilogue of one staged tile
+  auto compute = [&](int T) {
+    const int b = T / per, trem = T - b * per;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     f32x4 acc[GPW][NB];
 #pragma unroll
     for (int g = 0; g < GPW; ++g)
@@ -273,17 +307,41 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel(const SArgs a, int t
         if constexpr (POOL == 2) {
           const float o = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), lo);
           const int oy = ty * (TH / 2) + 2 * grow + wy, ox = tx * (TW / 2) + 2 * (gx0 + g) + wx;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry, (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
+          if ((ox < Wo) & (oy < Ho))  // (ragged last tiles: a width that is not a multiple of 16, a height that is not one of TH)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry, (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int oy = ty * TH + 4 * grow + 2 * wy + (r >> 1), ox = tx * TW + 4 * (gx0 + g) + 2 * wx + (r & 1);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[r], lo)), ry,
-                                                  (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
+            if ((ox < Wo) & (oy < Ho))
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v[r], lo)), ry,
+                                                    (((b * Ho + oy) * Wo + ox) * a.Cout + co) * 4, 0, 0);
           }
         }
       }
     RA_PS_AT(5);  // epilogue: scale / shift, pool, ReLU, stores issued
+  };
+
+  if (dyn) {
+    for (; tile < ntiles; tile = tnext) {
+      stage(preA, plA);
+      tk.read_next(tk_sh);
+      tk.request();  // older than the prefetch loads below: consumed with them at the next tile's staging
+      tk.step();
+      tnext = tk.cur >= 0 ? tk.cur : ntiles;
+      if (tnext < ntiles) fetch(tnext, preA, plA);  // in flight across the MFMA loop
+      compute(tile);
+    }
+  } else {
+    for (; tile < ntiles; tile += 2 * gstep) {
+      stage(preA, plA);
+      if (tile + 2 * gstep < ntiles) fetch(tile + 2 * gstep, preA, plA);  // in flight across two tiles
+      compute(tile);
+      if (tile + gstep >= ntiles) break;
+      stage(preB, plB);
+      if (tile + 3 * gstep < ntiles) fetch(tile + 3 * gstep, preB, plB);
+      compute(tile + gstep);
+    }
   }
   RA_PS_END;
 }
@@ -299,17 +357,17 @@ inline int cu_count() {
   return cus;
 }
 
-template <int CIN, int POOL, int NB>
+template <int CIN, int POOL, int NB, bool PL = false>
 int launch(const SArgs &a, hipStream_t st) {
-  auto kern = conv_split_kernel<CIN, POOL, NB>;
+  auto kern = conv_split_kernel<CIN, POOL, NB, PL>;
   constexpr int lds = Geo<CIN, NB>::LDS;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  const int tiles_x = a.W / TW, tiles_y = a.H / Geo<CIN, NB>::TH, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / (16 * NB);
-  int gx = cu_count() / slices;  // one workgroup per CU (141 KB of LDS at Cin = 32)
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + Geo<CIN, NB>::TH - 1) / Geo<CIN, NB>::TH, ntiles = tiles_x * tiles_y * a.B, slices = a.Cout / (16 * NB);
+  int gx = Geo<CIN, NB>::OCC * cu_count() / slices;  // one workgroup per CU (141 KB of LDS at Cin = 32), two where their LDS fits (Geo::OCC)
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   SArgs a2 = a;
@@ -337,14 +395,13 @@ inline float bf16_to_float_host(unsigned short h) {
 using namespace ra;
 
 extern "C" int ra_conv_split_supported(int Cin, int Cout, int pool, int H, int W) {
-  return (Cin == 16 || Cin == 32 || Cin == 64) && Cout > 0 && Cout % 16 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
-         H % csplit::tile_rows(Cin) == 0 && W % csplit::TW == 0;
+  return (Cin == 16 || Cin == 24 || Cin == 32 || Cin == 64) && Cout > 0 && Cout % 16 == 0 && (pool == 1 || pool == 2) && H > 0 && W > 0 &&
+         H % 4 == 0 && W % 4 == 0;  // (whole 4 x 4-pixel groups: the last tile of a row / column may be ragged — round 6)
 }
 
 extern "C" size_t ra_conv_split_packed_halfs(int Cin, int Cout) {
-  if (!(Cin == 16 || Cin == 32 || Cin == 64) || Cout <= 0 || Cout % 16) return 0;
-  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5;
-  return (size_t)(Cout / 16) * nblk * 3 * 512;
+  if (!(Cin == 16 || Cin == 24 || Cin == 32 || Cin == 64) || Cout <= 0 || Cout % 16) return 0;
+  return (size_t)(Cout / 16) * csplit::k_blocks(Cin) * 3 * 512;
 }
 
 namespace ra {
@@ -360,13 +417,9 @@ __host__ __device__ inline void slot_of(size_t e, int Cin, int Cout, int nblk, i
   pc = (int)(r % 3);
   r /= 3;
   const int b = (int)(r % nblk), s = (int)(r / nblk);
-  if (Cin >= 32) {
-    tap = b / (Cin / 32);
-    ci = 32 * (b % (Cin / 32)) + 8 * kb + j;
-  } else {
-    tap = 2 * b + (kb >> 1);
-    ci = 8 * (kb & 1) + j;
-  }
+  const int o = 4 * b + kb, opt = Cin / 8;  // (k_blocks: octet o of the pixel's neighbourhood)
+  tap = o / opt;
+  ci = 8 * (o % opt) + j;
   co = 16 * (nbw * s + nb) + nn;
 }
 __host__ __device__ inline float filter_at(const float *w, int Cin, int Cout, int transposed, int tap, int ci, int co) {
@@ -396,7 +449,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *w, int Cin
 extern "C" int ra_conv_split_pack_weights_dev(const float *w, int Cin, int Cout, int transposed, unsigned short *out, void *stream) {
   const size_t n = ra_conv_split_packed_halfs(Cin, Cout);
   if (!w || !out || !n) return fail(RA_E_SHAPE, "ra_conv_split_pack_weights_dev: Cin=%d Cout=%d", Cin, Cout);
-  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0 && Cin < 64) ? 2 : 1;  // Cin = 64: 16 couts per workgroup
+  const int nblk = csplit::k_blocks(Cin), nbw = (Cout % 32 == 0 && Cin < 64) ? 2 : 1;  // Cin = 64: 16 couts per workgroup
   hipLaunchKernelGGL(csplit::pack_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, Cin, Cout,
                      transposed ? 1 : 0, nblk, nbw, n, out);
   return launch_status("ra_conv_split_pack_weights_dev");
@@ -407,7 +460,7 @@ extern "C" int ra_conv_split_pack_weights_dev(const float *w, int Cin, int Cout,
 extern "C" int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, unsigned short *out) {
   const size_t n = ra_conv_split_packed_halfs(Cin, Cout);
   if (!w || !out || !n) return fail(RA_E_SHAPE, "ra_conv_split_pack_weights: Cin=%d Cout=%d", Cin, Cout);
-  const int nblk = Cin >= 32 ? 9 * (Cin / 32) : 5, nbw = (Cout % 32 == 0 && Cin < 64) ? 2 : 1;  // Cin = 64: 16 couts per workgroup
+  const int nblk = csplit::k_blocks(Cin), nbw = (Cout % 32 == 0 && Cin < 64) ? 2 : 1;  // Cin = 64: 16 couts per workgroup
   for (size_t e = 0; e < n; ++e) {
     int pc, tap, ci, co;
     csplit::slot_of(e, Cin, Cout, nblk, nbw, pc, tap, ci, co);
@@ -422,14 +475,17 @@ extern "C" int ra_conv_split_pack_weights(const float *w, int Cin, int Cout, uns
   return 0;
 }
 
-extern "C" int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, const unsigned short *wpacked, const float *scale,
-                                 const float *shift, int Cout, int relu, int pool, float *y, void *stream) {
-  if (!x || !wpacked || !scale || !shift || !y || B <= 0) return fail(RA_E_INVALID, "ra_conv_split_f32: bad argument");
+namespace ra {
+namespace csplit {
+int run(const float *x, int B, int H, int W, int Cin, const float *plane, int plane_chan, const unsigned short *wpacked, const float *scale,
+        const float *shift, int Cout, int relu, int pool, float *y, void *stream, const char *who) {
+  if (!x || !wpacked || !scale || !shift || !y || B <= 0) return fail(RA_E_INVALID, "%s: bad argument", who);
   if (!ra_conv_split_supported(Cin, Cout, pool, H, W))
-    return fail(RA_E_SHAPE, "ra_conv_split_f32: Cin=%d Cout=%d pool=%d %dx%d", Cin, Cout, pool, H, W);
+    return fail(RA_E_SHAPE, "%s: Cin=%d Cout=%d pool=%d %dx%d", who, Cin, Cout, pool, H, W);
+  if (plane && (plane_chan < 0 || plane_chan >= Cin)) return fail(RA_E_INVALID, "%s: plane_chan %d outside [0, %d)", who, plane_chan, Cin);
   const size_t bx = (size_t)B * H * W * Cin * 4, by = (size_t)B * (H / pool) * (W / pool) * Cout * 4;
-  if (bx >= (1ull << 31) || by >= (1ull << 31)) return fail(RA_E_SHAPE, "ra_conv_split_f32: a tensor exceeds 2 GiB");
-  csplit::SArgs a{};
+  if (bx >= (1ull << 31) || by >= (1ull << 31)) return fail(RA_E_SHAPE, "%s: a tensor exceeds 2 GiB", who);
+  SArgs a{};
   a.x = x;
   a.wp = wpacked;
   a.scale = scale;
@@ -442,12 +498,38 @@ extern "C" int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, c
   a.relu = relu;
   a.bytes_x = (int)bx;
   a.bytes_y = (int)by;
+  a.plane = plane;
+  a.plane_chan = plane ? plane_chan : 0;
+  a.bytes_p = (int)((size_t)B * H * W * 4);
   hipStream_t st = as_stream(stream);
-  if (Cin == 64) return pool == 2 ? csplit::launch<64, 2, 1>(a, st) : csplit::launch<64, 1, 1>(a, st);
-  if (Cout % 32 == 0) {
-    if (Cin == 16) return pool == 2 ? csplit::launch<16, 2, 2>(a, st) : csplit::launch<16, 1, 2>(a, st);
-    return pool == 2 ? csplit::launch<32, 2, 2>(a, st) : csplit::launch<32, 1, 2>(a, st);
+  const bool two = Cout % 32 == 0 && Cin < 64;  // 32 output channels per workgroup (Cin = 64: 16, its filter slice is 54 KB)
+#define RA_CS(CIN_)                                                                                             \
+  if (Cin == CIN_) {                                                                                            \
+    if (plane) {                                                                                                \
+      if (two) return pool == 2 ? launch<CIN_, 2, 2, true>(a, st) : launch<CIN_, 1, 2, true>(a, st);            \
+      return pool == 2 ? launch<CIN_, 2, 1, true>(a, st) : launch<CIN_, 1, 1, true>(a, st);                     \
+    }                                                                                                           \
+    if (two) return pool == 2 ? launch<CIN_, 2, 2>(a, st) : launch<CIN_, 1, 2>(a, st);                          \
+    return pool == 2 ? launch<CIN_, 2, 1>(a, st) : launch<CIN_, 1, 1>(a, st);                                   \
   }
-  if (Cin == 16) return pool == 2 ? csplit::launch<16, 2, 1>(a, st) : csplit::launch<16, 1, 1>(a, st);
-  return pool == 2 ? csplit::launch<32, 2, 1>(a, st) : csplit::launch<32, 1, 1>(a, st);
+  RA_CS(16)
+  RA_CS(24)
+  RA_CS(32)
+#undef RA_CS
+  if (plane) return fail(RA_E_SHAPE, "%s: the plane form is built for Cin 16 / 24 / 32", who);
+  return pool == 2 ? launch<64, 2, 1>(a, st) : launch<64, 1, 1>(a, st);
+}
+}  // namespace csplit
+}  // namespace ra
+
+extern "C" int ra_conv_split_f32(const float *x, int B, int H, int W, int Cin, const unsigned short *wpacked, const float *scale,
+                                 const float *shift, int Cout, int relu, int pool, float *y, void *stream) {
+  return csplit::run(x, B, H, W, Cin, nullptr, 0, wpacked, scale, shift, Cout, relu, pool, y, stream, "ra_conv_split_f32");
+}
+
+extern "C" int ra_conv_split_plane_f32(const float *x, int B, int H, int W, int Cin, const float *plane, int plane_chan,
+                                       const unsigned short *wpacked, const float *scale, const float *shift, int Cout, int relu, int pool,
+                                       float *y, void *stream) {
+  if (!plane) return fail(RA_E_INVALID, "ra_conv_split_plane_f32: null plane");
+  return csplit::run(x, B, H, W, Cin, plane, plane_chan, wpacked, scale, shift, Cout, relu, pool, y, stream, "ra_conv_split_plane_f32");
 }

@@ -65,6 +65,13 @@ class DecodeEngine(object):
     self.use_graph = True
     self.prefill_ride = True  # the once-per-forward y_out prefill rides on the first controller-CNN launch
     self.use_split = os.environ.get('RA_USE_SPLIT', '1') != '0'  # K1s: the mid-resolution controller-CNN layers as direct convs on the bf16 matrix pipe at float32 accuracy
+    # round 6: K1s also as the FIRST controller-CNN layer where no image-part cache applies (the KITTI / Cityscapes architectures:
+    # 13 / 21 channels packed to 16 / 24, the canvas as a plane — ra_conv_split_plane_f32) ...
+    self.split_first = os.environ.get('RA_SPLIT_FIRST', '1') != '0'
+    # ... and in the attention CNN on the 48 x 48 patch (single-source layers with 16 / 24 / 32 / 64 input channels; ragged 24- and
+    # 12-pixel maps).  'auto': where a layer has >= RA_SPLIT_PATCH_MIN_MF MFLOP per launch (the KITTI-sized nets: 16 images x 5-40
+    # MFLOP), not the CVPPP net's sub-MFLOP layers, which are launch-latency-bound and lose to K1s's filter copy
+    self.split_patch = os.environ.get('RA_SPLIT_PATCH', 'auto')
     # extract + attention-CNN layer 0 as one launch (ra_extract_conv0_f32, round 5): built, parity-tested and MEASURED SLOWER than
     # the two launches it replaces (11.8 vs 7.1 + 3.5 us at cfg2, profiles/r05_attn_fusion_probe.txt) — off; RA_FUSE_EXTRACT_CONV0=1 runs it
     self.fuse_extract_conv0 = os.environ.get('RA_FUSE_EXTRACT_CONV0', '0') == '1'
@@ -139,8 +146,14 @@ class DecodeEngine(object):
       wino = i > 0 and self.use_wino and ops.conv_wino_supported(cin, cout, d['ccnn_pool'][i], hh, ww)
       W['ccnn_wino'].append(_dev(ops.pack_wino_weights(M['ctrl_cnn_w_%d' % i]), device) if wino else None)
       # ... and as the exact three-piece bf16 split of the filter, for the direct form on the bf16 matrix pipe (K1s, round 5)
-      split = i > 0 and self.use_split and cin >= int(os.environ.get('RA_SPLIT_MIN_CIN', '32')) and ops.conv_split_supported(cin, cout, d['ccnn_pool'][i], hh, ww)  # Cin = 16 (L4): no faster than K1w
-      W['ccnn_split'].append(torch.from_numpy(ops.pack_split_weights(M['ctrl_cnn_w_%d' % i])).to(device) if split else None)
+      # (Cin = 16 where Winograd takes the layer — cfg2's L4 —: K1s is no faster than K1w; where it does not — KITTI's 16 -> 16 pool-2
+      #  layer — K1s replaces the float32-MFMA K1)
+      split = (i > 0 and self.use_split and (cin >= int(os.environ.get('RA_SPLIT_MIN_CIN', '32')) or not wino) and
+               ops.conv_split_supported(_r4(cin), cout, d['ccnn_pool'][i], hh, ww))
+      if i == 0 and self.use_split and self.split_first and d['C0p'] != 4 and ops.conv_split_supported(d['C0p'], cout, d['ccnn_pool'][0], hh, ww):
+        W['ccnn_split'].append(torch.from_numpy(ops.pack_split_weights(M['ctrl_cnn_w_0'], cin_kernel=d['C0p'], chan_map=cmap_c)).to(device))
+      else:
+        W['ccnn_split'].append(torch.from_numpy(ops.pack_split_weights(M['ctrl_cnn_w_%d' % i])).to(device) if split else None)
       hh, ww = hh // d['ccnn_pool'][i], ww // d['ccnn_pool'][i]
     Cf = d['ccnn_channels'][-1]
     self.desc = ops.make_ctrl_desc(d['G'], Cf, d['hid'], d['iters'], d['n_gmlp'], d['n_cmlp'],
@@ -161,7 +174,8 @@ class DecodeEngine(object):
       cmap_a, n_a = self._chan_map(d['attn_in'])
       assert n_a == d['acnn_channels'][0]
       self.attn_sel = [c for c, m in enumerate(cmap_a) if m >= 0]
-      W['acnn'] = []
+      W['acnn'], W['acnn_split'] = [], []
+      ph, pw = d['Fh'], d['Fw']
       for i in range(d['acnn_nlayers']):
         cin, cout = d['acnn_channels'][i], d['acnn_channels'][i + 1]
         if i == 0:
@@ -170,6 +184,14 @@ class DecodeEngine(object):
           wp = ops.pack_conv_weights(M['attn_cnn_w_%d' % i], cin_kernel=_r4(cin))
         sc, sh = fold_all('attn_cnn', i, cout)
         W['acnn'].append((_dev(wp, device), sc, sh, cout, d['acnn_pool'][i]))
+        ck = d['C0p'] if i == 0 else _r4(cin)
+        sp = None
+        if self.use_split and self.split_patch != '0' and ops.conv_split_supported(ck, cout, d['acnn_pool'][i], ph, pw):
+          mf = 2e-6 * 9 * cin * cout * ph * pw  # MFLOP per image
+          if self.split_patch == '1' or mf >= float(os.environ.get('RA_SPLIT_PATCH_MIN_MF', '4')):
+            sp = torch.from_numpy(ops.pack_split_weights(M['attn_cnn_w_%d' % i], cin_kernel=ck, chan_map=cmap_a if i == 0 else None)).to(device)
+        W['acnn_split'].append(sp)
+        ph, pw = ph // d['acnn_pool'][i], pw // d['acnn_pool'][i]
         if i == 0 and ops.extract_conv0_supported(d['C0p'], d['Fh'], d['Fw'], cout, d['acnn_pool'][0]):
           # the layer's filter in the PACKED input's channel order, for the launch that fuses it into the extract
           w0 = M['attn_cnn_w_0'].detach().cpu().numpy().astype(np.float32)
@@ -551,9 +573,13 @@ class DecodeEngine(object):
         i = step[1]
         wp, sc, sh, cout, pool = layers[i]
         wino = self.W['ccnn_wino'][i] if (layers is self.W.get('ccnn') and pl is None and self.use_wino) else None
-        split = self.W['ccnn_split'][i] if (layers is self.W.get('ccnn') and pl is None and self.use_split) else None
+        split = None
+        if self.use_split and layers is self.W.get('ccnn') and (pl is None or i == 0):
+          split = self.W['ccnn_split'][i]
+        elif self.use_split and layers is self.W.get('acnn'):
+          split = self.W['acnn_split'][i]
         if split is not None:
-          ops.conv_split(src, split, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i])
+          ops.conv_split(src, split, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i], plane=pl, plane_chan=pc if pl is not None else -1)
         elif wino is not None:
           ops.conv_wino(src, wino, sc[tt], sh[tt], cout, relu=True, pool=pool, out=bufs[i])
         else:

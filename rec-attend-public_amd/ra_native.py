@@ -146,6 +146,7 @@ SIGNATURES = {
     'ra_conv_split_pack_weights': (_I, [_P, _I, _I, _P]),
     'ra_conv_split_pack_weights_dev': (_I, [_P, _I, _I, _I, _P, _P]),
     'ra_conv_split_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'ra_conv_split_plane_f32': (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_conv_pair_wino_supported': (_I, [_I, _I, _I, _I, _I, _I]),
     'ra_conv_pair_wino_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     'ra_gauss_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),

@@ -214,9 +214,19 @@ def conv_split_supported(cin, cout, pool, H, W):
   return bool(rn.lib().ra_conv_split_supported(int(cin), int(cout), int(pool), int(H), int(W)))
 
 
-def pack_split_weights(w):
-  """TF-layout [3,3,Cin,Cout] filter -> its exact three-piece bf16 split in K1s's B-operand order (numpy, host; bf16 pairs in float32 words)."""
+def pack_split_weights(w, cin_kernel=None, chan_map=None):
+  """TF-layout [3,3,Cin,Cout] filter -> its exact three-piece bf16 split in K1s's B-operand order (numpy, host; bf16 pairs in float32 words).
+  cin_kernel / chan_map (as pack_conv_weights): the kernel's input has cin_kernel channels, channel c of it is the filter's input
+  channel chan_map[c] (-1: a channel the filter does not read — zero rows)."""
   w = _np32(w)
+  if cin_kernel is not None or chan_map is not None:
+    ck = int(cin_kernel if cin_kernel is not None else len(chan_map))
+    cm = list(chan_map) if chan_map is not None else list(range(w.shape[2])) + [-1] * (ck - w.shape[2])
+    wk = np.zeros((3, 3, ck, w.shape[3]), np.float32)
+    for c, m_ in enumerate(cm[:ck]):
+      if m_ >= 0:
+        wk[:, :, c, :] = w[:, :, m_, :]
+    w = wk
   cin, cout = w.shape[2], w.shape[3]
   n = rn.lib().ra_conv_split_packed_halfs(cin, cout)
   if w.shape[0] != 3 or w.shape[1] != 3 or n == 0:
@@ -240,13 +250,18 @@ def pack_split_weights_dev(w, cin, cout, transposed=False):
   return out
 
 
-def conv_split(x, wp, scale, shift, cout, relu=True, pool=1, out=None):
+def conv_split(x, wp, scale, shift, cout, relu=True, pool=1, out=None, plane=None, plane_chan=-1):
   """conv3x3 SAME + folded BN + ReLU + pool as a direct convolution on the bf16 matrix pipe at float32 accuracy
-  (ra_conv_split_f32: three bf16 pieces per operand, six piece products).  x [B,H,W,Cin]."""
-  _need_cuda(x, wp, scale, shift, out)
+  (ra_conv_split_f32: three bf16 pieces per operand, six piece products).  x [B,H,W,Cin]; plane [B,H,W]: stands in for channel
+  plane_chan of x (ra_conv_split_plane_f32)."""
+  _need_cuda(x, wp, scale, shift, out, plane)
   B, H, W, cin = x.shape
   if out is None:
     out = torch.empty((B, H // pool, W // pool, cout), dtype=torch.float32, device=x.device)
+  if plane is not None:
+    check(rn.lib().ra_conv_split_plane_f32(ptr(x), B, H, W, cin, ptr(plane), int(plane_chan), ptr(wp), ptr(scale), ptr(shift), int(cout),
+                                           int(relu), int(pool), ptr(out), rn.stream_ptr()), 'ra_conv_split_plane_f32')
+    return out
   check(rn.lib().ra_conv_split_f32(ptr(x), B, H, W, cin, ptr(wp), ptr(scale), ptr(shift), int(cout), int(relu), int(pool),
                                    ptr(out), rn.stream_ptr()), 'ra_conv_split_f32')
   return out

@@ -418,7 +418,11 @@ def test_dense_attention_operators(cuda, H, W, big):
                                                     (2, 48, 32, 16, 64, 2, False), (8, 128, 128, 32, 32, 2, True), (2, 32, 32, 32, 16, 1, False),
                                                     (1, 16, 32, 16, 48, 2, True),
                                                     (8, 32, 32, 64, 64, 2, True), (2, 8, 48, 64, 64, 1, True), (3, 24, 16, 64, 32, 2, False),
-                                                    (1, 40, 32, 64, 16, 1, True)])  # Cin = 64: 8-row tiles, 16 couts per workgroup
+                                                    (1, 40, 32, 64, 16, 1, True),  # Cin = 64: 8-row tiles, 16 couts per workgroup
+                                                    # round 6: ragged last tiles (KITTI's 56- / 28-pixel maps, the 24- / 12-pixel patch maps), Cin = 24
+                                                    (2, 16, 56, 32, 64, 1, True), (3, 16, 56, 64, 64, 2, True), (2, 8, 28, 64, 64, 2, False),
+                                                    (2, 24, 24, 16, 32, 2, True), (3, 12, 12, 64, 96, 2, True), (2, 48, 48, 16, 16, 1, True),
+                                                    (2, 64, 112, 16, 16, 2, True), (2, 32, 48, 24, 16, 2, True), (1, 20, 36, 24, 32, 1, False)])
 def test_conv_split_precision(cuda, B, H, W, Ci, Co, pool, relu):
   """K1s (ra_conv_split_f32, round 5): the direct 3x3 layer on the bf16 matrix pipe — every operand the exact sum of three bf16
   pieces, six of the nine piece products — against the float64 oracle at the float32 kernels' bar (2e-5 of the output scale),
@@ -457,6 +461,41 @@ def test_conv_split_precision(cuda, B, H, W, Ci, Co, pool, relu):
     cpi = ops.cout_padded(Ci)
     dx = ops.conv_split(dev(du, cuda), wpt, torch.ones(cpi, device=cuda), torch.zeros(cpi, device=cuda), Ci, relu=False, pool=1)
     assert relerr(dx.cpu().numpy(), ref_dx) < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W,real,Ck,Co,pool', [(2, 64, 96, 13, 16, 16, 2), (2, 32, 64, 21, 24, 16, 2), (1, 128, 448, 13, 16, 16, 2),
+                                                    (3, 16, 40, 21, 24, 32, 1), (2, 32, 32, 30, 32, 16, 2)])
+def test_conv_split_first_layer_with_canvas_plane(cuda, B, H, W, real, Ck, Co, pool):
+  """ra_conv_split_plane_f32 (round 6): K1s as the FIRST controller-CNN layer of the KITTI / Cityscapes architectures — the packed
+  input concat(x, canvas, d_in, y_in) (full_model.py:640-661: 13 / 21 real channels in 16 / 24, the rest zero pad with garbage
+  allowed) with the canvas in its own plane, the filter's rows found through the channel map — against the float64 oracle on the
+  reference's concatenated input, and against K1 with the same plane."""
+  rng = np.random.RandomState(B + H + W + real)
+  D = 3
+  img = rng.rand(B, H, W, Ck).astype(np.float32)
+  img[..., D] = 777.0          # the canvas slot of the packed image is never read
+  img[..., real:] = 555.0      # ... nor are the pad channels (their filter rows are zero)
+  canvas = rng.rand(B, H, W).astype(np.float32)
+  w = (rng.randn(3, 3, real, Co) / np.sqrt(9 * real)).astype(np.float32)
+  b = (rng.randn(Co) * 0.1).astype(np.float32)
+  bn = (rng.randn(Co).astype(np.float32) * 0.1, rng.uniform(0.5, 1.5, Co).astype(np.float32), rng.randn(Co).astype(np.float32) * 0.1,
+        rng.uniform(0.5, 1.5, Co).astype(np.float32))
+  sc, sh = ops.fold_bn(b, Co, bn)
+  cmap = list(range(real)) + [-1] * (Ck - real)
+  xin = img[..., :real].astype(np.float64).copy()
+  xin[..., D] = canvas
+  ref = ora.relu(ora.conv2d(xin, w.astype(np.float64)) * sc[:Co].astype(np.float64) + sh[:Co].astype(np.float64))
+  if pool == 2:
+    ref = ora.max_pool(ref, 2)
+  assert ops.conv_split_supported(Ck, Co, pool, H, W)
+  wp = torch.from_numpy(ops.pack_split_weights(w, cin_kernel=Ck, chan_map=cmap)).to(cuda)
+  y = ops.conv_split(dev(img, cuda), wp, dev(sc, cuda), dev(sh, cuda), Co, relu=True, pool=pool, plane=dev(canvas, cuda), plane_chan=D)
+  y1 = ops.conv3x3(dev(img, cuda), dev(ops.pack_conv_weights(w, cin_kernel=Ck, chan_map=cmap), cuda), dev(sc, cuda), dev(sh, cuda), Co,
+                   relu=True, pool=pool, plane=dev(canvas, cuda), plane_chan=D)
+  torch.cuda.synchronize()
+  assert y.shape == ref.shape
+  e_split, e_k1 = relerr(y.cpu().numpy(), ref), relerr(y1.cpu().numpy(), ref)
+  assert e_split < 2e-5 and e_split < 4 * e_k1 + 1e-7, (e_split, e_k1)
 
 
 @pytest.mark.parametrize('H,W,big,cout,F', [(128, 128, False, 8, 48), (96, 160, True, 8, 48), (512, 512, False, 8, 48),

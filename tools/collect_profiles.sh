@@ -6,7 +6,7 @@
 # profiles/ by hand.  Every command runs under `timeout`.
 set -u
 OUT=gpurun_out/${1:-prof}
-R3=${2:-r05}
+R3=${2:-r06}
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
@@ -21,7 +21,7 @@ for which in enc attn; do
   $R --pmc FETCH_SIZE -d $OUT/pmc_${which}_f -o f -- python bench.py --pmc-group 10 --pmc-which $which > $OUT/pmc_${which}_f.json 2> $OUT/pmc_${which}_f.log
   $R --pmc WRITE_SIZE -d $OUT/pmc_${which}_w -o w -- python bench.py --pmc-group 10 --pmc-which $which > $OUT/pmc_${which}_w.json 2> $OUT/pmc_${which}_w.log
 done
-$R --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o s -- python bench.py --pmc-group 10 --pmc-which enc > $OUT/pmc_sq.json 2> $OUT/pmc_sq.log
+$R --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $OUT/pmc_sq -o s -- python bench.py --pmc-group 10 --pmc-which enc > $OUT/pmc_sq.json 2> $OUT/pmc_sq.log
 F=$(find $OUT/pmc_enc_f -name '*counter_collection.csv' | head -1); W=$(find $OUT/pmc_enc_w -name '*counter_collection.csv' | head -1)
 timeout 60 python tools/pmc_traffic.py $F $W 10 8 512 $OUT/${R3}_pmc_encoder_traffic.json > $OUT/traffic_enc.txt 2>&1
 F=$(find $OUT/pmc_attn_f -name '*counter_collection.csv' | head -1); W=$(find $OUT/pmc_attn_w -name '*counter_collection.csv' | head -1)
