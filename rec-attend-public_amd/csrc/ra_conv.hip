@@ -657,6 +657,18 @@ int dispatch_geo(const Args &a, int B, hipStream_t st) {
     if (wgs(4, 1) >= want) return launch<CK, NC, WN, 4, 1>(a, B, st);
   }
   if (wgs(2, 2) >= want) return launch<CK, NC, WN, 2, 2>(a, B, st);
+#if RA_K1_PART == 0
+  // round 6: ONE pixel group per wave (8-column tiles) where even the smallest two-group geometry leaves most of the chip
+  // without a workgroup — the patch-sized layers with many channels (KITTI's attention DCNN: 128 -> 64 at 12 x 12 is 288
+  // dependent k-steps per pixel group; two groups per wave and 96 workgroups made it 16.5 us whatever the batch).  RA_CONV_TINY_WGS:
+  // the workgroup count of the (2, 1) geometry below which the (1, 1) form is taken (0 = never).
+  static int tiny = -1;
+  if (tiny < 0) {
+    const char *e = getenv("RA_CONV_TINY_WGS");
+    tiny = e ? atoi(e) : 200;
+  }
+  if (force == 11 || (!force && wgs(2, 1) < tiny)) return launch<CK, NC, WN, 1, 1>(a, B, st);
+#endif
   return launch<CK, NC, WN, 2, 1>(a, B, st);
 }
 

@@ -146,9 +146,11 @@ class DecodeEngine(object):
       wino = i > 0 and self.use_wino and ops.conv_wino_supported(cin, cout, d['ccnn_pool'][i], hh, ww)
       W['ccnn_wino'].append(_dev(ops.pack_wino_weights(M['ctrl_cnn_w_%d' % i]), device) if wino else None)
       # ... and as the exact three-piece bf16 split of the filter, for the direct form on the bf16 matrix pipe (K1s, round 5)
-      # (Cin = 16 where Winograd takes the layer — cfg2's L4 —: K1s is no faster than K1w; where it does not — KITTI's 16 -> 16 pool-2
-      #  layer — K1s replaces the float32-MFMA K1)
-      split = (i > 0 and self.use_split and (cin >= int(os.environ.get('RA_SPLIT_MIN_CIN', '32')) or not wino) and
+      # Cin >= 32: always.  Cin = 16: where Winograd does not take the layer; and, round 6, where the layer has 16 output channels —
+      # K1s then runs two workgroups per CU (Geo::OCC) with two windows in flight and beats K1w (KITTI's L1, 16 -> 16 pool 2:
+      # 12.4 -> 10.1 us at cfg3, 8.1 -> 6.8 at cfg5); 16 -> 32 stays with K1w (cfg2's L4 12.3 vs 12.9 us, cfg5's L2 6.0 vs 7.1:
+      # profiles/r06_k1s_sweep.txt)
+      split = (i > 0 and self.use_split and (cin >= int(os.environ.get('RA_SPLIT_MIN_CIN', '32')) or not wino or cout == 16) and
                ops.conv_split_supported(_r4(cin), cout, d['ccnn_pool'][i], hh, ww))
       if i == 0 and self.use_split and self.split_first and d['C0p'] != 4 and ops.conv_split_supported(d['C0p'], cout, d['ccnn_pool'][0], hh, ww):
         W['ccnn_split'].append(torch.from_numpy(ops.pack_split_weights(M['ctrl_cnn_w_0'], cin_kernel=d['C0p'], chan_map=cmap_c)).to(device))
