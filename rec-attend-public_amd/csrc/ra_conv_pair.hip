@@ -536,6 +536,13 @@ struct NGeo {
   static constexpr int MID_FLOATS = AHS * AW * 8;
 };
 
+// Round 6, measured and NOT kept (-DRA_PAIR8_CACHE_AHEAD=1 builds it): the NEXT tile's cached sums requested at the start of phase B,
+// a whole phase ahead.  Their 28 registers stay live across phase B: at three workgroups per CU (168 VGPRs) the compiler spills 16
+// (L0+L1 32.7 -> 38.6 us at cfg2, B = 8), at two per CU without spills 37.3 us (512 workgroups) / 44.4 (768): the occupancy is worth
+// more than the 14 % wait it removes (profiles/r06_encoder_levers.txt).
+#ifndef RA_PAIR8_CACHE_AHEAD
+#define RA_PAIR8_CACHE_AHEAD 0
+#endif
 #ifndef RA_PAIR8_OCC
 #define RA_PAIR8_OCC 3  // workgroups per CU: 3 x 38.7 KB LDS, <= 168 VGPRs (4 spills)
 #endif
@@ -601,7 +608,7 @@ __device__ inline void split3_pair(float a, float b, unsigned &H, unsigned &M, u
   L = pk_bf16(ra, rb);
 }
 template <int CINA, bool CACHED, bool SPLIT = false>
-__global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, CACHED ? (SPLIT ? (RA_PAIR8_CACHE_AHEAD ? 2 : 3) : 4) : RA_PAIR8_OCC) void conv_pair8_mfma(const PArgs a, int tiles_x, int tiles_y, int ntiles) {
   using G = NGeo<CINA>;
   constexpr int NCGA = G::NCGA;
   static_assert(!CACHED || CINA == 4, "cached form: 4 input channels");
@@ -842,18 +849,26 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
   const int r_per_tile = (r_chunk + 256 * my_tiles - 1) / (256 * my_tiles);
   const u32x4r r_bits = __builtin_bit_cast(u32x4r, f32x4{a.rider_val, a.rider_val, a.rider_val, a.rider_val});
   bool have_n = false;
+  f32x4 cpre[CACHED ? G::GPW : 1];
+  auto load_cache = [&](const TC &tc) {
+    const int tile_c0 = ((tc.b * a.cache_rows + tc.ty * G::TH) * a.cache_gx + ((tc.tx * G::TW) >> 3)) * 256;
+#pragma unroll
+    for (int s = 0; s < (CACHED ? G::GPW : 1); ++s)
+      cpre[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, tile_c0 + slot_c[s] + lane_c, 0, 0));
+  };
+#if RA_PAIR8_CACHE_AHEAD
+  if constexpr (CACHED) {
+    if (have) load_cache(cur);
+  }
+#endif
   for (; have; tile = dyn ? (tk.step(), tk.cur) : tile + nwx, cur = nxt, have = have_n) {
     const int b = cur.b, ty0 = cur.ty * G::TH, tx0 = cur.tx * G::TW;
-    // CACHED: this tile's cached sums of layer A — 32 bytes per pixel, the launch's largest read — are requested HERE, a
-    // staging pass and a barrier ahead of their use (requested where phase A starts, their latency was 16 % of a workgroup's
-    // life: tools/pair8_probe.hip "cache arrived"); they need no registers that are live now — phase B's are dead
-    f32x4 cpre[CACHED ? G::GPW : 1];
-    if constexpr (CACHED) {
-      const int tile_c0 = ((b * a.cache_rows + ty0) * a.cache_gx + (tx0 >> 3)) * 256;
-#pragma unroll
-      for (int s = 0; s < G::GPW; ++s)
-        cpre[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, tile_c0 + slot_c[s] + lane_c, 0, 0));
-    }
+    // CACHED: this tile's cached sums of layer A — 32 bytes per pixel, the launch's largest read — were requested a whole
+    // phase B ahead (round 6; RA_PAIR8_CACHE_AHEAD=0 at build time: at the top of the tile, one staging pass and a barrier ahead
+    // of their use, as in round 5 — the probe's "waiting for the cached sums 14 %")
+#if !RA_PAIR8_CACHE_AHEAD
+    if constexpr (CACHED) load_cache(cur);
+#endif
 
     // ---------------- stage layer A's input window (prefetched registers -> LDS) ----------------
 #pragma unroll
@@ -1006,6 +1021,11 @@ __global__ __launch_bounds__(256, CACHED ? (SPLIT ? 3 : 4) : RA_PAIR8_OCC) void 
     RA_P8_AT(3);  // barrier
 
     // ---------------- phase B: layer B out of tmid, BN + ReLU + 2x2 max-pool -> global ----------------
+#if RA_PAIR8_CACHE_AHEAD
+    if constexpr (CACHED) {
+      if (have_n) load_cache(nxt);  // phase A has consumed cpre; the next tile's sums fly across phase B and the next staging
+    }
+#endif
     {
       f32x4 acc[4];
       int gmid[4];

@@ -33,7 +33,7 @@ cp $(find $OUT/trace4 -name '*kernel_stats.csv' | head -1) $OUT/${R3}_bench_kern
 # keep the merge small: the raw traces are not needed
 rm -rf $OUT/trace $OUT/trace4 $OUT/pmc_*_f $OUT/pmc_*_w $OUT/pmc_sq
 # the traffic files must be in profiles/ for the bench line to pick them up
-cp $OUT/${R3}_pmc_encoder_traffic.json $OUT/${R3}_pmc_attn_traffic.json profiles/ 2>/dev/null
+cp $OUT/${R3}_pmc_encoder_traffic.json $OUT/${R3}_pmc_attn_traffic.json $OUT/${R3}_pmc_sq_mfma_per_kernel.csv profiles/ 2>/dev/null  # (roofline.traffic / mfma_busy / executed read them)
 timeout 900 python bench.py > $OUT/${R3}_bench_n1.json 2> $OUT/bench.err
 for DT in f32 bf16; do
   SUF=""; [ $DT = bf16 ] && SUF="_bf16"
