@@ -446,19 +446,28 @@ class DecodePipeline(object):
     """How many slots a launch of B images takes."""
     return 1 if not self.max_images else max(1, -(-int(B) // int(self.max_images)))
 
-  def full(self, B=None):
+  def _ends_soon(self, remaining):
+    """The caller has told how many batches follow (`remaining`), and what is left — the waiting group, the batch at hand and
+    those — fits the slots one batch each: near the end of a finite stream batches stop waiting for company, so that the last
+    ones keep ALL streams busy instead of filling half the slots twice as full (20 batches through four slots of two: the
+    last four go out as 4 x 1, not 2 x 2)."""
+    return (remaining is not None and self.coalesce > 1 and len(self.group) + 1 + int(remaining) <= self.depth and
+            os.environ.get('RA_PIPE_ENDGAME', '0') == '1')
+
+  def full(self, B=None, remaining=None):
     """The next submit() (of a batch of B images; default: one that takes one slot) would have to launch, and there is no
-    slot for it: collect() / retire() first.  A batch that only joins the waiting group needs no slot."""
-    if len(self.group) + 1 < self.coalesce:
+    slot for it: collect() / retire() first.  A batch that only joins the waiting group needs no slot.  remaining: as submit()."""
+    if len(self.group) + 1 < self.coalesce and not self._ends_soon(remaining):
       return False
     waiting = sum(t['B'] for t in self.group)
     return len(self.free) < self.parts(waiting + (B if B is not None else 1))
 
-  def submit(self, outputs, feed, to_host=False):
+  def submit(self, outputs, feed, to_host=False, remaining=None):
     """Start decoding one batch (eval outputs only); returns immediately.  to_host: the outputs are also
     copied to pinned host memory on the slot's stream (asynchronously, under the other batches' compute —
     y_out of a cfg2 batch is 134 MB, 2.7 ms of PCIe); collect() then returns NumPy arrays without a
-    further copy."""
+    further copy.  remaining (round 6, optional): how many more batches the caller will submit after this one — an evaluator
+    knows; see _ends_soon()."""
     if not torch.cuda.is_available():
       raise RecAttendError('the decode loop needs an MI355X (HIP device); no CPU fallback')
     single = isinstance(outputs, str)
@@ -474,7 +483,8 @@ class DecodePipeline(object):
     if nparts > self.depth:
       raise RecAttendError('a batch of %d images needs %d slots of <= %d images; the pipeline has %d' %
                            (waiting + B, nparts, self.max_images, self.depth))
-    launches = len(self.group) + 1 >= self.coalesce
+    ends = self._ends_soon(remaining)
+    launches = len(self.group) + 1 >= self.coalesce or ends
     if launches and nparts > len(self.free):
       raise RecAttendError('%d of %d slots busy: collect() a batch before the next submit()' %
                            (self.depth - len(self.free), self.depth))
@@ -485,7 +495,7 @@ class DecodePipeline(object):
     t = dict(names=names, single=single, feed=feed, to_host=to_host, B=B, launch=None, lo=0, hi=B)
     self.group.append(t)
     self.pending.append(t)
-    if len(self.group) >= self.coalesce:
+    if len(self.group) >= self.coalesce or ends:
       self._launch_group()
 
   def _launch_group(self):

@@ -136,9 +136,10 @@ def _run_shard(args, model, data, lo, hi, rank, restore, thresholds, names, anal
     b1 = min(hi, b0 + args.batch_size)
     feed = {k: v[b0:b1] for k, v in data.items() if k in ('x', 'd_in', 'y_in')}
     feed['phase_train'] = False
-    while pipe.full(b1 - b0):
+    left = -(-(hi - b1) // args.batch_size)  # batches still to come: the last few go out one per slot (DecodePipeline._ends_soon)
+    while pipe.full(b1 - b0, remaining=left):
       consume(*(spans.pop(0) + tuple(pipe.collect())))
-    pipe.submit(['y_out', 's_out'], feed, to_host=not analyze)
+    pipe.submit(['y_out', 's_out'], feed, to_host=not analyze, remaining=left)
     spans.append((b0, b1))
   while len(pipe):
     consume(*(spans.pop(0) + tuple(pipe.collect())))

@@ -239,13 +239,34 @@ def f_dic(s_out, s_gt, abs=False):
 
 
 def get_gt_box(y_gt, padding_ratio=0.0, center_shift_ratio=0.0, min_padding=10.0):
-  """modellib.py:663-701 -> top_left [B,T,2], bot_right [B,T,2], box [B,T,H,W]."""
-  if not isinstance(center_shift_ratio, (int, float)) or center_shift_ratio != 0.0 or \
-      not isinstance(padding_ratio, (int, float)):
-    raise NotImplementedError('noisy GT boxes (tensor padding / centre shift, full_model.py:567-577) '
-                              'belong to the training step (SURVEY.md §8f rank 2)')
-  params, box = ops.gt_box(y_gt, float(padding_ratio), float(min_padding))
-  return params[:, :, 0:2].contiguous(), params[:, :, 2:4].contiguous(), box
+  """modellib.py:663-701 -> top_left [B,T,2], bot_right [B,T,2], box [B,T,H,W].  padding_ratio / center_shift_ratio: numbers, or
+  tensors broadcastable to [B,T,1] or [B,T,2] — the noisy ground-truth boxes of the training graph (full_model.py:567-577 draws
+  them per instance).  Scalars run as one fused launch (ra_gt_box_f32); tensors take the reduction from the same kernel and do
+  the [B,T]-sized corner algebra and the box fill (get_filled_box_idx, modellib.py:731-748) as device tensor ops."""
+  scalar = isinstance(padding_ratio, (int, float)) and isinstance(center_shift_ratio, (int, float))
+  if scalar and center_shift_ratio == 0.0:
+    params, box = ops.gt_box(y_gt, float(padding_ratio), float(min_padding))
+    return params[:, :, 0:2].contiguous(), params[:, :, 2:4].contiguous(), box
+  B, T, H, W = y_gt.shape
+  dev = y_gt.device
+  as_t = lambda v: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v, dtype=torch.float32)).to(device=dev, dtype=torch.float32)
+  pr, cs = as_t(padding_ratio), as_t(center_shift_ratio)
+  raw, _ = ops.gt_box(y_gt, 0.0, 0.0, want_box=False)  # the reductions of :679-683 with the empty instances already fixed to 0
+  nz = (ops.pair_stats(y_gt, y_gt, want=('sum_b',))['sum_b'] > 0).to(torch.float32)[:, :, None]
+  # an empty instance reduces to (H W, H W) / (0, 0) in the reference (idx + (1 - 0) * H W; idx * 0): its box comes out empty
+  top_left = raw[:, :, 0:2] * nz + (1.0 - nz) * float(H * W)
+  bot_right = raw[:, :, 2:4] * nz
+  size = bot_right - top_left
+  pad = torch.clamp(pr * size, min=float(min_padding))
+  top_left = top_left + cs * size - pad
+  bot_right = bot_right + cs * size + pad
+  yy = torch.arange(H, dtype=torch.float32, device=dev).view(1, 1, H, 1)
+  xx = torch.arange(W, dtype=torch.float32, device=dev).view(1, 1, 1, W)
+  tl, br = top_left[:, :, :, None, None], bot_right[:, :, :, None, None]
+  box = ((yy >= tl[:, :, 0]) & (xx >= tl[:, :, 1]) & (yy <= br[:, :, 0]) & (xx <= br[:, :, 1])).to(torch.float32)
+  top_left = top_left * nz
+  bot_right = nz * bot_right + (1.0 - nz) * (2.0 * float(min_padding))
+  return top_left.contiguous(), bot_right.contiguous(), box
 
 
 def get_gt_attn(y_gt, filter_height, filter_width, padding_ratio=0.0, center_shift_ratio=0.0,

@@ -234,6 +234,8 @@ class DecodeEngine(object):
     self.plan = self._make_plan(W)
     self._stamp = stamp
     self._graphs = {}
+    for k, (g_, s_, st_, _) in list(self.__dict__.get('_states', {}).items()):  # the parked sizes' graphs hold the old packs too
+      self._states[k] = (g_, s_, st_, {})
 
   def _make_plan(self, W):
     """Greedy pairing of consecutive conv layers into fused launches (ra_conv_pair_f32): A must
@@ -286,6 +288,19 @@ class DecodeEngine(object):
     if B % nsub:
       nsub = 1
     if self._B == (B, nsub):
+      return
+    # a few batch sizes stay allocated (buffers AND captured graphs): a pipeline slot that decodes 2 x 8 images in the steady
+    # state and lone batches of 8 at the end of a stream (DecodePipeline._ends_soon), or an evaluator's ragged last batch, must
+    # not re-allocate and re-capture at every change of size
+    states = self.__dict__.setdefault('_states', {})
+    if self._B is not None:
+      states[self._B] = (self.glob, self.subs, self.streams, self._graphs)
+      while len(states) > 3:
+        states.pop(next(iter(states)))
+    hit = states.pop((B, nsub), None)
+    if hit is not None:
+      self.glob, self.subs, self.streams, self._graphs = hit
+      self._B = (B, nsub)
       return
     d, T = self.d, self.d['T']
     f = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
@@ -399,6 +414,7 @@ class DecodeEngine(object):
     self.ctrl_split = False
     self._stamp = None   # prepare() again: split_ok becomes False
     self._B = None       # alloc() again: no exchange workspace, so _launch_tail takes ra_controller_f32
+    self._states = {}
     self._graphs = {}
     self.forward(keep['x'], d_in=keep.get('d_in'), y_in=keep.get('y_in'), y_gt=keep.get('y_gt'), noise=keep.get('noise'),
                  want_box=want_box)

@@ -580,7 +580,7 @@ def test_xcd_local_controller_with_part_of_its_xcd_taken(cuda):
   assert np.array_equal(y2, y)
 
 
-def test_decode_pipeline_coalesced_batches_match_lone_runs(cuda):
+def test_decode_pipeline_coalesced_batches_match_lone_runs(cuda, monkeypatch):
   """DecodePipeline(coalesce=2) (round 5): two consecutively submitted batches are decoded by ONE slot as one forward over
   their images, and collect() still returns them one at a time — each exactly what a lone model.run of that batch returns
   (eval-mode images are independent).  Ragged batch sizes, an odd batch count (the last one is launched alone by collect()),
@@ -626,6 +626,31 @@ def test_decode_pipeline_coalesced_batches_match_lone_runs(cuda):
   a = pipe.collect(as_numpy=True)
   b = pipe.collect(as_numpy=True)
   assert np.abs(a - lone[0][0]).max() < 1e-6 and np.abs(b[0] - lone[1][1]).max() < 1e-6
+  # the end of a finite stream (round 6): with `remaining` told, the last batches stop waiting for company once what is left fits
+  # the slots one batch each — 7 batches through 2 slots of 2: (0,1) (2,3) (4,5) then 6 alone as soon as a slot is free — and a
+  # slot switches between its 2-batch and 1-batch sizes without losing either's buffers or graphs
+  monkeypatch.setenv('RA_PIPE_ENDGAME', '1')  # (opt-in: measured slower at cfg2)
+  pipe = m.pipeline(2, coalesce=2)
+  got, launched_alone = [], 0
+  for k, f in enumerate(feeds):
+    left = len(feeds) - 1 - k
+    while pipe.full(f['x'].shape[0], remaining=left):
+      got.append(pipe.collect(as_numpy=True))
+    before = len(pipe.group)
+    pipe.submit(names, f, remaining=left)
+    launched_alone += int(before == 0 and not pipe.group and left + 1 <= pipe.depth)
+  while len(pipe):
+    got.append(pipe.collect(as_numpy=True))
+  assert launched_alone >= 1 and len(got) == len(lone)
+  for a, b in zip(got, lone):
+    for u, v in zip(a, b):
+      assert u.shape == v.shape and np.abs(u - v).max() < 1e-6
+  for f, l in zip(feeds[:2], lone[:2]):  # the same pipeline again: sizes it has seen come back from the engines' parked states
+    pipe.submit(names, f, remaining=None)
+  for l in lone[:2]:
+    for u, v in zip(pipe.collect(as_numpy=True), l):
+      assert np.abs(u - v).max() < 1e-6
+  monkeypatch.setenv('RA_PIPE_ENDGAME', '0')
   # parts under coalescing: 3 + 3 images as three launches of 2
   pipe = m.pipeline(3, max_images=2, coalesce=2)
   pipe.submit(names, feeds[2])

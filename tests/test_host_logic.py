@@ -334,3 +334,24 @@ def test_global_pack_cache_keeps_only_the_latest_version_of_a_weight():
   assert not c and not c._latest
   assert isinstance(rt._PACK, rt._LatestVersionPack)
 
+
+
+
+def test_pipeline_end_of_stream_rule(monkeypatch):
+  """DecodePipeline._ends_soon (round 6): batches stop waiting for company only when the caller has said how many follow and
+  everything left fits the slots one batch each."""
+  import full_model
+  monkeypatch.setenv('RA_PIPE_ENDGAME', '1')  # (off by default: measured slower at cfg2, profiles/r06_pipeline_endgame.txt)
+
+  class M:
+    OUTPUTS = ()
+  p = full_model.DecodePipeline(M(), depth=4, coalesce=2)
+  assert not p._ends_soon(None) and not p._ends_soon(4) and p._ends_soon(3) and p._ends_soon(0)
+  p.group = [dict(B=8)]
+  assert not p._ends_soon(3) and p._ends_soon(2)
+  assert not p.full(remaining=None) and not p.full(remaining=5)  # joining a waiting group needs no slot
+  p.free = []
+  assert p.full(remaining=2)  # ... but going out alone does
+  assert not full_model.DecodePipeline(M(), depth=4, coalesce=1)._ends_soon(0)
+  monkeypatch.setenv('RA_PIPE_ENDGAME', '0')
+  assert not full_model.DecodePipeline(M(), depth=4, coalesce=2)._ends_soon(0)

@@ -90,8 +90,18 @@ def test_gt_box(cuda, H, W, pad_ratio, min_pad):
                                                                     min_padding=min_pad)
   assert np.abs(ctr.cpu().numpy() - (tl + br) / 2).max() < 1e-4
   assert np.abs(size.cpu().numpy() - (br - tl)).max() < 1e-4
-  with pytest.raises(NotImplementedError):
-    modellib.get_gt_box(dev(y_gt, cuda), padding_ratio=0.2, center_shift_ratio=0.1)
+  # noisy ground-truth boxes as the training graph draws them (full_model.py:567-577): per-instance padding / centre shift tensors
+  pr = (pad_ratio + rng.uniform(-0.1, 0.1, (3, 6, 1))).astype(np.float32)
+  cs = rng.uniform(-0.05, 0.05, (3, 6, 2)).astype(np.float32)
+  tl, br, box = ora.get_gt_box(y_gt.astype(np.float64), padding_ratio=pr.astype(np.float64), center_shift_ratio=cs.astype(np.float64),
+                               min_padding=min_pad)
+  gtl, gbr, gbox = modellib.get_gt_box(dev(y_gt, cuda), padding_ratio=dev(pr, cuda), center_shift_ratio=dev(cs, cuda), min_padding=min_pad)
+  assert np.abs(gtl.cpu().numpy() - tl).max() < 1e-3 and np.abs(gbr.cpu().numpy() - br).max() < 1e-3
+  assert (gbox.cpu().numpy() != box).mean() < 1e-3  # (a corner within round-off of a pixel index may fall either way)
+  tl2, br2, box2 = modellib.get_gt_box(dev(y_gt, cuda), padding_ratio=0.2, center_shift_ratio=0.1, min_padding=min_pad)  # scalar shift
+  rtl, rbr, rbox = ora.get_gt_box(y_gt.astype(np.float64), padding_ratio=0.2, center_shift_ratio=0.1, min_padding=min_pad)
+  assert np.abs(tl2.cpu().numpy() - rtl).max() < 1e-3 and np.abs(br2.cpu().numpy() - rbr).max() < 1e-3
+  assert (box2.cpu().numpy() != rbox).mean() < 1e-3
 
 
 @pytest.mark.parametrize('B,T', [(4, 5), (3, 16), (2, 21)])
