@@ -712,24 +712,18 @@ def main():
   coalesce = args.coalesce if args.coalesce > 0 else (2 if (args.in_flight >= 2 and B <= 8) else 1)
   pipe = model.pipeline(max(1, args.in_flight // coalesce), streams=args.streams or None, coalesce=coalesce)
 
-  def step(remaining=None):
-    # remaining: the evaluator's loop knows how many batches follow (full_model_eval.py passes it too): the last few then
-    # go out one per slot instead of waiting for company (DecodePipeline._ends_soon)
-    while pipe.full(remaining=remaining):
+  def step():
+    while pipe.full():
       pipe.retire()
-    pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output, remaining=remaining)
+    pipe.submit(['y_out', 's_out'], feed, to_host=args.host_output)
 
   for _ in range(max(args.warmup, 2 * pipe.depth * coalesce)):  # every slot allocates + captures its graph
     step()
   pipe.drain()
-  if coalesce > 1:  # the one-batch graphs of the end game are captured in the warm-up too, not inside the timed region
-    for k in range(pipe.depth):
-      step(remaining=pipe.depth - 1 - k)
-    pipe.drain()
   barrier()
   t0 = time.perf_counter()
-  for k in range(args.steps):
-    step(remaining=args.steps - 1 - k)
+  for _ in range(args.steps):
+    step()
   pipe.drain()
   barrier()
   elapsed = ra_dist.max_over_ranks(time.perf_counter() - t0)

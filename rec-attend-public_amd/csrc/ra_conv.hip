@@ -142,9 +142,16 @@ __device__ inline bf16x4 pack_bf16(float v0, float v1, float v2, float v3) {
 // output of that channel — and the wave leaves one record {n, S1, S2, pivot} per channel in a.mom_part
 // [(workgroup * WM + wave row)][CoutP][4].  tf.nn.moments of the layer (nnlib.py:98) then costs one small finishing
 // launch (ra_bn_moments_from_partials_f32: the records re-based onto one reference in float64) instead of two more passes over u.
-template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false>
+// UPS = true (round 6; SWAP layers on the (2, 2) geometry): the SUB-PIXEL form of a stride-2 transposed conv.  The staged tile is
+// still the zero-stuffed image U[2i+1, 2j+1] = x[i, j], but a wave's four pixel groups are no longer four 8 x 2 blocks of its
+// 16 x 4 region: group g = (py, px) is the region's 16 pixels of ONE parity class (rows 2 dy + py, columns 2 (2 q + dx) + px).
+// Tile origins are even, so for such a pixel only the taps with ky = py and kx = px (mod 2) meet stuffed data — 4, 2, 2 and 1
+// taps for the four classes, 9 per 64 pixels instead of 36: a quarter of the MFMAs and of the A-operand reads, same results
+// (the skipped products are exact zeros).
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false, bool UPS = false>
 __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(const Args a, int tiles_x, int tiles_y, int ntiles) {
   static_assert(!MOM || SWAP, "batch moments ride on the channel-vector epilogue");
+  static_assert(!UPS || (SWAP && GX == 2 && GY == 2 && !BF16 && !MOM), "sub-pixel form: float32 SWAP layers on the (2, 2) geometry");
   raise_prio(a.prio);
   using G = Geo<CK, NC, WN, GX, GY>;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // 2 * G::LDS_FLOATS
@@ -163,7 +170,8 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   // A-operand lane geometry: m = lane & 15 -> (q, dy, dx); ksub = lane >> 4.
   const int m = lane & 15, ksub = lane >> 4;
   const int q = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
-  const int a_base = ((wm * G::WR + dy) * G::LW + 2 * q + dx) * G::PIX + ksub * G::NCG;  // floats
+  const int a_base = UPS ? ((wm * G::WR + 2 * dy) * G::LW + 2 * (2 * q + dx)) * G::PIX + ksub * G::NCG
+                         : ((wm * G::WR + dy) * G::LW + 2 * q + dx) * G::PIX + ksub * G::NCG;  // floats
   const int co_lane = lane & 15;
   const int qo = lane >> 4;  // D rows 4*qo + r -> pooled x position qo, window element r
 
@@ -414,14 +422,22 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
 #pragma unroll
       for (int g = 0; g < G::PM; ++g) {
         const int gx = g % GX, gy = g / GX;
-        av[g] = *reinterpret_cast<const avec *>(
-            &tb[a_base + ((2 * gy + ky) * G::LW + 8 * gx + kx) * G::PIX]);
+        if constexpr (UPS) {  // g = parity class (py, px) = (gy, gx): only its own taps touch stuffed data
+          if (((ky ^ gy) & 1) | ((kx ^ gx) & 1)) continue;
+          av[g] = *reinterpret_cast<const avec *>(&tb[a_base + ((gy + ky) * G::LW + gx + kx) * G::PIX]);
+        } else {
+          av[g] = *reinterpret_cast<const avec *>(
+              &tb[a_base + ((2 * gy + ky) * G::LW + 8 * gx + kx) * G::PIX]);
+        }
       }
 #pragma unroll
       for (int cg = 0; cg < G::NCG; ++cg) {
         const int s = tap * G::NCG + cg;
 #pragma unroll
         for (int g = 0; g < G::PM; ++g) {
+          if constexpr (UPS) {
+            if (((ky ^ (g / GX)) & 1) | ((kx ^ (g % GX)) & 1)) continue;
+          }
           const float aval = av[g][cg];
 #pragma unroll
           for (int n = 0; n < NC; ++n)
@@ -492,8 +508,9 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
     // SWAP layers never pool and always have Cout % 4 == 0 (the dispatch's condition for this form): one 16- or 8-byte
     // store per lane and pixel group, no window maximum, no division by the pool size (a run-time divisor cost two integer
     // divisions per pixel group here: a third of the epilogue's instructions)
-    const int lrow = ty0 + wm * G::WR + dy;  // conv row / col of this lane's pixel in group 0
-    const int lcol = tx0 + 2 * q + dx;
+    const int lrow = ty0 + wm * G::WR + (UPS ? 2 * dy : dy);  // conv row / col of this lane's pixel in group 0
+    const int lcol = tx0 + (UPS ? 2 * (2 * q + dx) : 2 * q + dx);
+    constexpr int GDY = UPS ? 1 : 2, GDX = UPS ? 1 : 8;  // a group's row / column offset from group 0 (UPS: its parity class)
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       const int co0 = 16 * (wn * NC + n) + 4 * ksub;
@@ -503,7 +520,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
       for (int g = 0; g < G::PM; ++g) {
         const int gx = g % GX, gy = g / GX;
         f32x4 v = acc[g][n] * sc4[n] + sh4[n];
-        const bool okp = (lrow + 2 * gy < a.H) & (lcol + 8 * gx < a.W);
+        const bool okp = (lrow + GDY * gy < a.H) & (lcol + GDX * gx < a.W);
         if constexpr (MOM) {
           if (g == 0 && !mhave) {  // pivot: this wave's first output of the channel (pixel lane 0 of the 16)
 #pragma unroll
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
-        const int off = obase + (2 * gy * a.Wo + 8 * gx) * a.Cout;
+        const int off = obase + (GDY * gy * a.Wo + GDX * gx) * a.Cout;
         if (BF16 && a.out_bf16) {  // four channels = 8 bytes (RNE, as the operand rounding)
           const int boff = (okp & co_ok) ? off * 2 : kOOB;
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, pack_bf16(v[0], v[1], v[2], v[3])), rsy, boff, 0, 0);
@@ -590,10 +607,10 @@ __global__ __launch_bounds__(256, (GX * GY * NC > 8) ? 1 : 2) void conv3x3_mfma(
   }
 }
 
-template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false>
+template <int CK, int NC, int WN, int GX, int GY, bool SWAP, bool BF16 = false, bool MOM = false, bool UPS = false>
 int launch_s(const Args &a, int B, hipStream_t st) {
   using G = Geo<CK, NC, WN, GX, GY>;
-  auto kern = conv3x3_mfma<CK, NC, WN, GX, GY, SWAP, BF16, MOM>;
+  auto kern = conv3x3_mfma<CK, NC, WN, GX, GY, SWAP, BF16, MOM, UPS>;
   constexpr size_t lds = 2 * G::LDS_FLOATS * sizeof(float);
   static int wgs_per_cu = 0;  // idempotent lazy init
   if (!wgs_per_cu) {
@@ -613,6 +630,14 @@ int launch_s(const Args &a, int B, hipStream_t st) {
 }
 
 namespace {  // the dispatch chain differs between the parts of this file (RA_K1_PART): internal linkage, one per part
+inline bool ups_subpixel() {  // RA_CONV_UPS_SUBPIXEL=0: the zero-stuffed form of rounds 1-5 (A/B aid)
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("RA_CONV_UPS_SUBPIXEL");
+    on = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return on == 1;
+}
 template <int CK, int NC, int WN, int GX, int GY>
 int launch(const Args &a, int B, hipStream_t st) {
   // channel-vector stores pay off when there is no pooling and the channel count allows float4
@@ -628,7 +653,12 @@ int launch(const Args &a, int B, hipStream_t st) {
 #elif RA_K1_PART == 2  // float32 + batch moments
   return launch_s<CK, NC, WN, GX, GY, true, false, true>(a, B, st);
 #else
-  if (swap) return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
+  if (swap) {
+    if constexpr (GX == 2 && GY == 2) {
+      if (a.ups && ups_subpixel()) return launch_s<CK, NC, WN, GX, GY, true, false, false, true>(a, B, st);
+    }
+    return launch_s<CK, NC, WN, GX, GY, true>(a, B, st);
+  }
   return launch_s<CK, NC, WN, GX, GY, false>(a, B, st);
 #endif
 }
@@ -648,6 +678,18 @@ int dispatch_geo(const Args &a, int B, hipStream_t st) {
     const char *e = getenv("RA_CONV_GEO");
     force = e ? atoi(e) : 0;
   }
+#if RA_K1_PART == 0
+  // a stride-2 transposed conv without pooling runs its sub-pixel form (UPS), which lives on the (2, 2) geometry
+  // ... where that geometry still yields enough workgroups: with few (a lone batch of 8 CVPPP patches: 16-72) the zero-stuffed
+  // form on one-group tiles has 4 x the workgroups at the same chain length per wave and wins (RA_CONV_UPS_MIN_WGS, profiles/r06_k1s_sweep.txt)
+  static int ups_min = -1;
+  if (ups_min < 0) {
+    const char *e = getenv("RA_CONV_UPS_MIN_WGS");
+    ups_min = e ? atoi(e) : 96;
+  }
+  if (!force && a.ups && a.pool == 1 && (a.Cout & 3) == 0 && !a.mom_part && ups_subpixel() && wgs(2, 2) >= ups_min)
+    return launch<CK, NC, WN, 2, 2>(a, B, st);
+#endif
   if (force == 42) return launch<CK, NC, WN, 4, 2>(a, B, st);
   if (force == 41) return launch<CK, NC, WN, 4, 1>(a, B, st);
   if (force == 22) return launch<CK, NC, WN, 2, 2>(a, B, st);
