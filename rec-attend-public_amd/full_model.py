@@ -434,7 +434,7 @@ class DecodePipeline(object):
       eng = ra_engine.DecodeEngine(proto.d, self.model, box_model=proto.box)
       for flag in ('fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score',
                    'cache_first', 'fill_cache_inline', 'nsub', 'use_graph', 'use_wino', 'wino_unfuse', 'pair_wino', 'prefill_ride',
-                   'fuse_extract_conv0', 'use_split', 'split_first', 'split_patch'):
+                   'fuse_extract_conv0', 'use_split', 'split_first', 'split_patch', 'box_iou_rects'):
         setattr(eng, flag, getattr(proto, flag))
       eng.co_resident = self.co_resident
       self.slots.append((eng, streams[k % self.streams]))

@@ -68,6 +68,7 @@ class DecodeEngine(object):
     # round 6: K1s also as the FIRST controller-CNN layer where no image-part cache applies (the KITTI / Cityscapes architectures:
     # 13 / 21 channels packed to 16 / 24, the canvas as a plane — ra_conv_split_plane_f32) ...
     self.split_first = os.environ.get('RA_SPLIT_FIRST', '1') != '0'
+    self.box_iou_rects = os.environ.get('RA_BOX_IOU_RECTS', '1') != '0'  # box_model: IoU of the step's box against the GT boxes from their corners
     # ... and in the attention CNN on the 48 x 48 patch (single-source layers with 16 / 24 / 32 / 64 input channels; ragged 24- and
     # 12-pixel maps).  'auto': where a layer has >= RA_SPLIT_PATCH_MIN_MF MFLOP per launch (the KITTI-sized nets: 16 images x 5-40
     # MFLOP), not the CVPPP net's sub-MFLOP layers, which are launch-latency-bound and lose to K1s's filter copy
@@ -614,7 +615,13 @@ class DecodeEngine(object):
     [B,T]-sized bookkeeping."""
     d, T = self.d, self.d['T']
     box = b['box1']
-    iou = ops.pair_stats(box, b['box_gt'], want=('iou_soft',))['iou_soft']  # f_inter / f_union, [B,1,T]
+    if self.box_iou_rects and 'gt_params' in b and d['W'] % 4 == 0 and T <= 32:
+      # round 6: the GT boxes are filled rectangles, so the soft IoU row needs their corners, not their T planes
+      # (ra_box_iou_rects_f32, the training graph's kernel): one read of the box instead of T x H x W x 4 bytes per image —
+      # 63 -> 8 us per timestep at cfg3's 32 images
+      iou = ops.box_iou_rects(box.view(box.shape[0], d['H'], d['W']), b['gt_params'])  # [B,T]
+    else:
+      iou = ops.pair_stats(box, b['box_gt'], want=('iou_soft',))['iou_soft']  # f_inter / f_union, [B,1,T]
     ops.greedy_match(iou.view(iou.shape[0], T), out=b['match'])  # matched = 0, modellib.py:365-379
     ops.weighted_sum(b['match'], b['y_gt'], b['ysel'])
     ops.canvas_max(b['canvas'].view(b['canvas'].shape + (1,)), 0, b['ysel'], b['noise'][tt])
@@ -656,7 +663,7 @@ class DecodeEngine(object):
       Bs = B // len(self.subs)
       for k, sb in enumerate(self.subs):
         sb['noise'].copy_(b['noise'][:, k * Bs:(k + 1) * Bs])
-        sb['box_gt'] = ops.gt_box(sb['y_gt'].contiguous(), float(self.d['attn_box_padding_ratio']), 10.0)[1]
+        sb['gt_params'], sb['box_gt'] = ops.gt_box(sb['y_gt'].contiguous(), float(self.d['attn_box_padding_ratio']), 10.0)
     self._last_want_box = bool(want_box)
     self._launch_forward(want_box)
     if late_check and self._weights_stamp() != self._stamp:
@@ -674,8 +681,11 @@ class DecodeEngine(object):
       for sb in self.subs:
         if 'box_gt_buf' not in sb:
           sb['box_gt_buf'] = torch.empty_like(sb['box_gt'])
+          sb['gt_params_buf'] = torch.empty_like(sb['gt_params'])
         sb['box_gt_buf'].copy_(sb['box_gt'])
         sb['box_gt'] = sb['box_gt_buf']
+        sb['gt_params_buf'].copy_(sb['gt_params'])
+        sb['gt_params'] = sb['gt_params_buf']
     g = self._graphs.get(key)
     if g is None:
       self._launch_all(want_box)  # warm-up (also sets kernel attributes)
