@@ -1085,7 +1085,22 @@ def main():
         return 1e6 * (time.perf_counter() - t1) / reps
       launch = hung_us(step_w)
       single = [hung_us(step_w[k:k + 1].contiguous(), 3) for k in range(n_p)]
+      fxz = np.load(fx)
+      host_us = None
+      if 'iou' in fxz and 's_gt' in fxz:  # the same problems through the training step's default path: host cores, a stream host function
+        h_iou, h_s = torch.as_tensor(fxz['iou']).cuda(), torch.as_tensor(fxz['s_gt']).cuda()
+        _, _, blk = ops.segm_match_host(h_iou, h_s, None, threads=min(32, _cgroup_cpus()))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+          ops.segm_match_host(h_iou, h_s, blk, threads=min(32, _cgroup_cpus()))
+        torch.cuda.synchronize()
+        host_us = 1e6 * (time.perf_counter() - t1) / 5
       out['hungarian_cfg4_step'] = {
+          'host_node_us': host_us,
+          'host_node_note': 'ra_segm_match_host_f32 (round 6, the training step\'s default): precondition kernel, D2H, ra_hungarian_f32 on host '
+                            'threads side by side as a host function of the stream, H2D, re-mask — the whole f_segm_match of the %d problems; '
+                            'launch_us is the device solver alone' % n_p,
           'problems': n_p, 'shape': list(step_w.shape[1:]), 'launch_us': launch, 'us_per_problem_in_launch': launch / n_p,
           'us_per_problem_alone_median': float(np.median(single)), 'us_per_problem_alone_max': float(np.max(single)),
           'note': 'one wave per problem, all problems of the step in ONE launch (its duration = the slowest problem, '

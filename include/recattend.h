@@ -555,6 +555,16 @@ int ra_knob_setup_f32(const float *gt_box_ws, int B, int T, const float *pad, co
 size_t ra_segm_match_workspace_bytes(int B, int N);
 int ra_segm_match_f32(const float *iou, const float *s_gt, int B, int N, void *ws, size_t ws_bytes,
                       float *match, int *status, void *stream);
+/* ... with the B problems solved on HOST cores (ra_hungarian_f32 on up to `threads` threads) as a host function of the stream — a host
+ * node of the graph when the stream is capturing (round 6): precondition kernel -> D2H copy into `pinned` -> host solve -> H2D ->
+ * re-mask.  The device solver's launch lasts as long as its slowest problem (1.7 ms for a cfg4 step's 16 x 16 problems, on the
+ * step's critical path); a host core needs ~0.5 ms per problem and the problems run side by side.  w_dev: B N N floats of device
+ * scratch; pinned: page-locked host memory of ra_segm_match_host_block_bytes() (16-byte aligned) that carries the host function's
+ * arguments and staging — it must stay allocated, and unused by anyone else, as long as a graph that captured the call lives.
+ * match / status: device outputs as ra_segm_match_f32's (status[b]: ra_hungarian_f32's return code for problem b). */
+size_t ra_segm_match_host_block_bytes(int B, int N);
+int ra_segm_match_host_f32(const float *iou, const float *s_gt, int B, int N, float *w_dev, void *pinned, size_t pinned_bytes,
+                           int threads, float *match, int *status, void *stream);
 int ra_loss_stats_f32(const float *iou_soft, const float *iou_hard, const float *dice,
                       const float *match_real, const float *iou_box, const float *match_box,
                       const float *s_out, const float *s_gt, const float *sum_gt, int B, int T,

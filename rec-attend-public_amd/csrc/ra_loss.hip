@@ -13,6 +13,8 @@
 //   K10 segm_match pre/post-processing around the device Hungarian solver, and the scalar
 //       statistics (coverage, matched IoU, DICE, confidence loss, counting) in one workgroup.
 #include <cmath>
+#include <thread>
+#include <vector>
 
 #include "ra_common.h"
 
@@ -784,6 +786,83 @@ extern "C" int ra_segm_match_f32(const float *iou, const float *s_gt, int B, int
   if (rc) return rc;
   hipLaunchKernelGGL(loss::match_post_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, match, s_gt, N, total);
   return launch_status("ra_segm_match_f32");
+}
+
+// ---- f_segm_match with the solver on HOST cores, as a host node of the stream / captured graph (round 6) --------------------
+// The device solver runs one wave per problem and a launch lasts as long as its slowest problem: 1.7 ms for the 16 x 16 problems
+// of a cfg4 training step, serial on the step's critical path (every gradient waits for the matching), where one host core
+// needs ~0.5 ms per problem (hungarian.cc's control flow is serial and branchy: a CPU core runs it 3 x faster than a wave).
+// Here the B problems go to host threads in parallel: precondition kernel -> D2H copy into the caller's PINNED block -> host
+// function (hipLaunchHostFunc: a host node when the stream is capturing) -> H2D copy -> re-mask kernel.  Results are those of
+// ra_hungarian_f32 — the same source as the device solver (RA_HUNG solve()), bit-identical by construction and by test.
+// The pinned block: [ctl: 64 bytes | w: B N N floats | match: B N N floats | status: B ints]; it carries the host function's
+// arguments, so it must stay allocated (and untouched by the caller) for as long as a graph that captured the call lives.
+namespace ra {
+namespace loss {
+struct HostMatchCtl {
+  int B, N, threads, pad;
+  float *w, *match;
+  int *status;
+};
+static_assert(sizeof(HostMatchCtl) <= 64, "control block");
+static void host_match_fn(void *p) {
+  const HostMatchCtl c = *static_cast<const HostMatchCtl *>(p);
+  const int nthr = c.threads < 1 ? 1 : (c.threads > c.B ? c.B : c.threads);
+  auto work = [&c, nthr](int t0) {
+    std::vector<float> cx(c.N), cy(c.N);
+    for (int b = t0; b < c.B; b += nthr) {
+      const size_t o = (size_t)b * c.N * c.N;
+      c.status[b] = ra_hungarian_f32(c.w + o, 1, c.N, c.N, c.match + o, cx.data(), cy.data());
+    }
+  };
+  if (nthr == 1) {
+    work(0);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nthr - 1);
+  for (int t = 1; t < nthr; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &t : th) t.join();
+}
+}  // namespace loss
+}  // namespace ra
+
+extern "C" size_t ra_segm_match_host_block_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return 64 + (size_t)B * N * N * 8 + (size_t)B * 4;
+}
+
+extern "C" int ra_segm_match_host_f32(const float *iou, const float *s_gt, int B, int N, float *w_dev, void *pinned, size_t pinned_bytes,
+                                      int threads, float *match, int *status, void *stream) {
+  if (!iou || !s_gt || !w_dev || !pinned || !match || !status || B <= 0 || N <= 0)
+    return fail(RA_E_INVALID, "ra_segm_match_host_f32: bad argument");
+  if (pinned_bytes < ra_segm_match_host_block_bytes(B, N) || (reinterpret_cast<uintptr_t>(pinned) & 15))
+    return fail(RA_E_WORKSPACE, "ra_segm_match_host_f32: pinned block of %zu bytes (16-byte aligned), need %zu", pinned_bytes,
+                ra_segm_match_host_block_bytes(B, N));
+  hipStream_t st = as_stream(stream);
+  const int total = B * N * N;
+  char *blk = static_cast<char *>(pinned);
+  loss::HostMatchCtl *ctl = reinterpret_cast<loss::HostMatchCtl *>(blk);
+  float *hw = reinterpret_cast<float *>(blk + 64), *hm = hw + total;
+  int *hs = reinterpret_cast<int *>(hm + total);
+  // (written at enqueue time: a graph that captured an earlier call on this block replays with the same values)
+  ctl->B = B;
+  ctl->N = N;
+  ctl->threads = threads;
+  ctl->w = hw;
+  ctl->match = hm;
+  ctl->status = hs;
+  hipLaunchKernelGGL(loss::match_pre_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, iou, s_gt, N, total, w_dev);
+  int rc = launch_status("ra_segm_match_host_f32");
+  if (rc) return rc;
+  hipError_t e = hipMemcpyAsync(hw, w_dev, (size_t)total * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipLaunchHostFunc(st, loss::host_match_fn, ctl);
+  if (e == hipSuccess) e = hipMemcpyAsync(match, hm, (size_t)total * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(status, hs, (size_t)B * 4, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return fail((int)e, "ra_segm_match_host_f32: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(loss::match_post_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, match, s_gt, N, total);
+  return launch_status("ra_segm_match_host_f32");
 }
 
 extern "C" size_t ra_loss_stats_workspace_floats(int B) { return B > 0 ? (size_t)B * loss::kNTerms : 0; }

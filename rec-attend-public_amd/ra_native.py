@@ -111,6 +111,8 @@ SIGNATURES = {
     'ra_knob_setup_f32': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     'ra_segm_match_workspace_bytes': (_Z, [_I, _I]),
     'ra_segm_match_f32': (_I, [_P, _P, _I, _I, _P, _Z, _P, _P, _P]),
+    'ra_segm_match_host_block_bytes': (_Z, [_I, _I]),
+    'ra_segm_match_host_f32': (_I, [_P, _P, _I, _I, _P, _P, _Z, _I, _P, _P, _P]),
     'ra_loss_stats_workspace_floats': (_Z, [_I]),
     'ra_loss_stats_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _Z, _P, _P]),
     'ra_postprocess_f32': (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),

@@ -689,6 +689,23 @@ def segm_match(iou, s_gt):
   return match, status
 
 
+def segm_match_host(iou, s_gt, block=None, threads=16):
+  """modellib.f_segm_match with the Hungarian problems solved on HOST cores, side by side, as a host function of the current stream
+  (a host node under graph capture): ra_segm_match_host_f32.  block: (pinned uint8 host tensor, device float scratch) kept by the
+  caller for as long as a captured graph may replay the call (None: a fresh one is made and returned).  -> (match, status, block)."""
+  iou, s_gt = iou.contiguous(), s_gt.contiguous()
+  _need_cuda(iou, s_gt)
+  B, N, _ = iou.shape
+  nb = rn.lib().ra_segm_match_host_block_bytes(B, N)
+  if block is None or block[0].numel() < nb or block[1].numel() < B * N * N:
+    block = (torch.empty((nb,), dtype=torch.uint8).pin_memory(), torch.empty((B * N * N,), dtype=torch.float32, device=iou.device))
+  match = torch.empty_like(iou)
+  status = torch.zeros((B,), dtype=torch.int32, device=iou.device)
+  check(rn.lib().ra_segm_match_host_f32(ptr(iou), ptr(s_gt), B, N, ptr(block[1]), block[0].data_ptr(), block[0].numel(), int(threads),
+                                        ptr(match), ptr(status), rn.stream_ptr()), 'ra_segm_match_host_f32')
+  return match, status, block
+
+
 def loss_stats(iou_soft, iou_hard, dice, match_real, iou_box, match_box, s_out, s_gt, sum_gt,
                fixed_order=False, segm_loss_fn='iou', loss_mix_ratio=1.0):
   """Every scalar of full_model.py:941-1081 -> float32 [len(STAT_NAMES)] on the device."""

@@ -2096,7 +2096,7 @@ class TrainStep(object):
         if st is not None:
           statuses.append(st)
       else:
-        m, st = ops.segm_match(iou.detach(), s_gt)
+        m, st = self._segm_match(iou.detach(), s_gt, 'lone')
         statuses.append(st)  # checked by the caller once the step has run (no host sync in here)
       cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
       if fixed:  # f_iou(pairwise=False) summed over ALL T, unmasked, over the identity match's count (full_model.py:922-945,985-1007)
@@ -2116,7 +2116,7 @@ class TrainStep(object):
       y_gt_c, box_gt_c = y_gt.contiguous(), box_gt.contiguous()
       st_s = ops.pair_stats(y_out.detach(), y_gt_c, want=want, a_tmajor=tm)
       st_b = ops.pair_stats(attn_box.detach(), box_gt_c, want=want, a_tmajor=tm)
-      m2, st2 = ops.segm_match(torch.cat([st_s['iou_soft'], st_b['iou_soft']], dim=0), torch.cat([s_gt, s_gt], dim=0))
+      m2, st2 = self._segm_match(torch.cat([st_s['iou_soft'], st_b['iou_soft']], dim=0), torch.cat([s_gt, s_gt], dim=0), 'head')
       m, m_box = m2[:B], m2[B:]
       loss, pv = LossHead.apply(y_out, attn_box, s_out, y_gt_c, box_gt_c, st_s, st_b, m, m_box, tm, float(opt.get('loss_mix_ratio', 1.0)))
       pieces = {'loss': loss, 'box_loss': pv[0], 'segm_loss': pv[1], 'conf_loss': pv[2], 'iou_soft': pv[3], 'iou_soft_box': pv[4],
@@ -2129,7 +2129,7 @@ class TrainStep(object):
       # from the sequential phase's masks on a side stream, under the stacked forward, loses to the fork it needs: 31.1,
       # and a second fork makes the graph replay 1.5x slower: 47.9 ms)
       i_soft, i_box = PairIoU.apply(y_out, y_gt, tm), PairIoU.apply(attn_box, box_gt, tm)
-      m2, st2 = ops.segm_match(torch.cat([i_soft.detach(), i_box.detach()], dim=0), torch.cat([s_gt, s_gt], dim=0))
+      m2, st2 = self._segm_match(torch.cat([i_soft.detach(), i_box.detach()], dim=0), torch.cat([s_gt, s_gt], dim=0), 'merged')
       iou_box, m_box = matched_iou(attn_box, box_gt, i_box, (m2[B:], None))
       iou_soft, m = matched_iou(y_out, y_gt, i_soft, (m2[:B], st2))
     elif self.match_side_stream:
@@ -2185,6 +2185,23 @@ class TrainStep(object):
           self.model[key + '_ema_mean'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * mean)
           self.model[key + '_ema_var'].mul_(EMA_DECAY).add_((1 - EMA_DECAY) * var)
     return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in pieces.items()}
+
+  # f_segm_match's Hungarian problems on host cores, side by side, as a host node of the captured step (round 6): the device
+  # solver's launch lasts as long as its slowest problem — 1.7 ms of a cfg4 step, with every gradient waiting for it — where a
+  # host core needs ~0.5 ms per problem.  RA_HUNG_HOST=0: the device solver (ra_segm_match_f32)
+  host_match = os.environ.get('RA_HUNG_HOST', '1') != '0'
+
+  def _segm_match(self, iou, s_gt, site):
+    if not self.host_match:
+      return ops.segm_match(iou, s_gt)
+    blocks = self.__dict__.setdefault('_match_blocks', {})
+    key = (site, tuple(iou.shape))
+    threads = getattr(self, '_match_threads', None)
+    if threads is None:
+      n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+      threads = self._match_threads = max(1, min(32, n))
+    m, st, blocks[key] = ops.segm_match_host(iou, s_gt, blocks.get(key), threads)  # the block lives as long as the trainer (and its graphs)
+    return m, st
 
   def _check_status(self, rec):
     """The status words of one finished step, on the host.  The guarded optimizer kernel has already refused that step's
@@ -2522,7 +2539,7 @@ class BoxTrainStep(TrainStep):
     if fixed:
       m = torch.eye(T, device=dev)[None] * s_gt[:, None, :] * s_gt[:, :, None]
     else:
-      m, st = ops.segm_match(iou.detach(), s_gt)
+      m, st = self._segm_match(iou.detach(), s_gt, 'box')
       statuses.append(st)
     cnt = torch.clamp(m.sum(dim=(1, 2)), min=1.0)
     iou_box = ((iou * m).sum(dim=(1, 2)) / cnt).sum() / B

@@ -225,3 +225,54 @@ def test_cfg4_step_matrices_device(cuda):
   assert (Md.cpu().numpy() == m).all() and (cxd.cpu().numpy()[..., 0] == cx).all() and (cyd.cpu().numpy()[:, 0, :] == cy).all()
   match, status = ops.segm_match(torch.from_numpy(STEP['iou']).to(cuda), torch.from_numpy(STEP['s_gt']).to(cuda))
   assert int(status.abs().max()) == 0 and (match.cpu().numpy() == STEP['match']).all()
+
+
+@pytest.mark.gpu
+def test_segm_match_on_host_cores_as_a_stream_host_function(cuda):
+  """ra_segm_match_host_f32 (round 6): f_segm_match with the Hungarian problems solved by ra_hungarian_f32 on host threads, side by
+  side, as a host function of the stream — precondition kernel, D2H into the caller's pinned block, host solve, H2D, re-mask.  The
+  cfg4 step's matrices against the committed answer, random ragged problems against the device solver (bit for bit, statuses
+  included), the same pinned block reused, and the call captured in a HIP graph and replayed on new inputs (the training step's use)."""
+  import time
+  import torch
+  iou = torch.from_numpy(STEP['iou']).to(cuda)
+  s_gt = torch.from_numpy(STEP['s_gt']).to(cuda)
+  match, status, block = ops.segm_match_host(iou, s_gt, None, threads=16)
+  torch.cuda.synchronize()
+  assert int(status.abs().max()) == 0 and (match.cpu().numpy() == STEP['match']).all()
+  rng = np.random.RandomState(11)
+  for B, N in ((16, 16), (5, 21), (32, 16), (3, 32)):
+    iou_r = rng.rand(B, N, N).astype(np.float32) * (rng.rand(B, N, N) < 0.7)
+    s_r = (np.arange(N)[None, :] < rng.randint(1, N + 1, (B, 1))).astype(np.float32)
+    a, b = torch.from_numpy(iou_r).to(cuda), torch.from_numpy(s_r).to(cuda)
+    md, sd = ops.segm_match(a, b)
+    mh, sh, blk = ops.segm_match_host(a, b, None, threads=3)
+    mh2, sh2, blk2 = ops.segm_match_host(a, b, blk, threads=64)  # the block reused, more threads than problems
+    torch.cuda.synchronize()
+    assert blk2 is blk and torch.equal(md, mh) and torch.equal(sd, sh) and torch.equal(md, mh2) and torch.equal(sd, sh2)
+  # under graph capture: static inputs, new values before every replay
+  st_iou, st_s = iou.clone(), s_gt.clone()
+  ops.segm_match_host(st_iou, st_s, block, threads=16)
+  torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    gm, gs, gb = ops.segm_match_host(st_iou, st_s, block, threads=16)
+  for k in range(3):
+    perm = torch.randperm(16, generator=torch.Generator().manual_seed(k)).to(cuda)
+    st_iou.copy_(iou[perm])
+    st_s.copy_(s_gt[perm])
+    g.replay()
+    torch.cuda.synchronize()
+    assert (gm.cpu().numpy() == STEP['match'][perm.cpu().numpy()]).all() and int(gs.abs().max()) == 0
+  t0 = time.perf_counter()
+  for _ in range(5):
+    g.replay()
+  torch.cuda.synchronize()
+  t_host = (time.perf_counter() - t0) / 5
+  ops.segm_match(iou, s_gt)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(5):
+    ops.segm_match(iou, s_gt)
+  torch.cuda.synchronize()
+  print('cfg4 step matchings: host node %.2f ms, device solver %.2f ms' % (1e3 * t_host, 1e3 * (time.perf_counter() - t0) / 5))

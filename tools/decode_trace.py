@@ -17,6 +17,8 @@ def run(cfg, images):
   import torch
   import bench
   import full_model
+  box = cfg.endswith('box')
+  cfg = cfg[:-3] if box else cfg
   if cfg == 'cfg2':
     arch, H, W, T, B = 'cvppp', 512, 512, 16, 8
   else:
@@ -24,7 +26,11 @@ def run(cfg, images):
     arch, H, W, T, B = c['arch'], c['H'], c['W'], c['T'], c['B']
   B = images or B
   opt = bench.make_opt(arch, H, W, T)
-  m = full_model.get_model(opt, is_training=False)
+  if box:
+    import box_model
+    m = box_model.get_model(opt)
+  else:
+    m = full_model.get_model(opt, is_training=False)
   bench.seed_weights(m, 1234)
   g = torch.Generator().manual_seed(1234)
   x = torch.rand((B, H, W, 3), generator=g).cuda()
@@ -32,6 +38,12 @@ def run(cfg, images):
   if opt['add_d_out']:
     kw['d_in'] = torch.nn.functional.one_hot(torch.randint(0, 8, (B, H, W), generator=g), 8).float().cuda()
     kw['y_in'] = torch.softmax(torch.randn((B, H, W, opt['num_semantic_classes']), generator=g), dim=-1).cuda()
+  if box:
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    y_gt = torch.zeros((B, T, H, W))
+    for t in range(min(T, 6)):
+      y_gt[:, t] = (((yy - (20 + 15 * t) % H) ** 2 / 400.0 + (xx - (30 + 60 * t) % W) ** 2 / 900.0) <= 1).float()
+    kw['y_gt'] = y_gt.cuda()
   for _ in range(4):
     m.engine.forward(x, **kw)
     torch.cuda.synchronize()
@@ -60,7 +72,7 @@ def show(path, which=None):
     t_prev_end = en
     if first_enc is None and ('cpair' in s or 'conv3x3' in s or 'csplit' in s or 'wino' in s):
       first_enc = s
-    if s == first_enc and cur and any('paste' in c[0] for c in cur):
+    if s == first_enc and cur and any(('paste' in c[0] or 'canvas_max' in c[0]) for c in cur):
       steps.append(cur)
       cur = []
     cur.append(item)
