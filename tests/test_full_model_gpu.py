@@ -25,13 +25,14 @@ def _inputs(opt, B, seed):
   return x, d_in, y_in
 
 
-def _check(opt, B, seed, use_graph, tune=None):
+def _check(opt, B, seed, use_graph, tune=None, ref=None):
   import full_model
   P = ora.random_params(opt, seed)
   if tune is not None:
     P = tune(P)
   x, d_in, y_in = _inputs(opt, B, seed + 1)
-  ref = ora.full_model_forward(opt, P, x, d_in, y_in)
+  if ref is None:
+    ref = ora.full_model_forward(opt, P, x, d_in, y_in)
   m = full_model.get_model(opt).load_weights(P)
   m.engine.use_graph = use_graph
   feed = {'x': x, 'phase_train': False, 'd_in': d_in, 'y_in': y_in}
@@ -270,22 +271,11 @@ def test_full_size_properties(cuda):
 
 def test_cfg2_full_size_vs_oracle(cuda):
   """BASELINE.json configs[1] at FULL size — CVPPP arch, 512x512, T=16 — against the float64
-  oracle with oracle-style weights (non-trivial masks), B=2; masks within 1e-3."""
-  opt = ora.make_opt('cvppp', 512, 512, 16)
-
-  def tune(P):
-    """At 512 px the seeded weights leave every mask at sigmoid(-5): give the box a plausible size
-    (as bench.seed_weights does) and the decoder's last BN a positive offset, so that the masks
-    are non-trivial and the comparison exercises the whole range."""
-    P = dict(P)
-    b = P['ctrl_mlp_b_0'].copy()
-    b[0:2], b[2:4] = [0.1, -0.2], np.log(0.3)
-    P['ctrl_mlp_b_0'] = b
-    for t in range(16):
-      P['attn_dcnn_6_%d_beta' % t] = P['attn_dcnn_6_%d_beta' % t] + 12.0
-    return P
-
-  out, ref = _check(opt, 2, 101, use_graph=True, tune=tune)
+  oracle with oracle-style weights (non-trivial masks), B=2; masks within 1e-3.  (Weights, images and the oracle's answer are those
+  of the pipelined operating-point test below: at 512 px the seeded weights leave every mask at sigmoid(-5), so the box gets a
+  plausible size and the decoder's last BN a positive offset; the float64 forward is computed once per session.)"""
+  c = _cfg2_operating_point_case()
+  out, ref = _check(c['opt'], 2, 101, use_graph=True, tune=lambda P: c['P'], ref=c['ref'])
   assert ref['y_out'].max() > 0.9 and (ref['y_out'] > 0.5).mean() > 0.01
   print('cfg2 full size: max |dy| = %.2e' % np.abs(out['y_out'] - ref['y_out']).max())
 

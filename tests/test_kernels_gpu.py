@@ -707,16 +707,23 @@ def test_first_layer_cache_vs_plain_pair(cuda, shape):
     assert (out3.cpu().numpy() == out0.cpu().numpy()).all() and (cache3.cpu().numpy() == cache2.cpu().numpy()).all()
 
 
-def test_pack_input_zeroes_canvas_plane(cuda):
-  """pack_input with the decode loop's separate canvas plane: packed record as before, plane = 0."""
-  rng = np.random.RandomState(5)
+@pytest.mark.parametrize('Dd,Dy,Cp', [(8, 2, 16), (8, 9, 24), (0, 0, 4), (8, 1, 16)])
+def test_pack_input_zeroes_canvas_plane(cuda, Dd, Dy, Cp):
+  """pack_input with the decode loop's separate canvas plane: the packed record [x | 0 | d_in | y_in | 0-pad] (full_model.py:640-661
+  order, canvas slot zero) for the KITTI (13 in 16), Cityscapes (21 in 24) and CVPPP (3 + 1 in 4) inputs, plane = 0 (round 6: one
+  thread per channel quad, 16-byte stores)."""
+  rng = np.random.RandomState(5 + Cp)
   B, H, W = 2, 12, 20
-  x, d_in, y_in = rng.rand(B, H, W, 3), rng.rand(B, H, W, 8), rng.rand(B, H, W, 2)
-  packed = torch.full((B, H, W, 16), -1.0, dtype=torch.float32, device=cuda)
+  x = rng.rand(B, H, W, 3)
+  d_in = rng.rand(B, H, W, Dd) if Dd else None
+  y_in = rng.rand(B, H, W, Dy) if Dy else None
+  packed = torch.full((B, H, W, Cp), -1.0, dtype=torch.float32, device=cuda)
   plane = torch.full((B, H, W), 3.0, dtype=torch.float32, device=cuda)
-  ops.pack_input(dev(x, cuda), dev(d_in, cuda), dev(y_in, cuda), 16, packed, canvas_plane=plane)
+  ops.pack_input(dev(x, cuda), None if d_in is None else dev(d_in, cuda), None if y_in is None else dev(y_in, cuda), Cp, packed, canvas_plane=plane)
   got = packed.cpu().numpy()
-  want = np.concatenate([x, np.zeros((B, H, W, 1)), d_in, y_in, np.zeros((B, H, W, 2))], axis=-1).astype(np.float32)
+  parts = [x, np.zeros((B, H, W, 1))] + ([d_in] if Dd else []) + ([y_in] if Dy else [])
+  parts.append(np.zeros((B, H, W, Cp - 4 - Dd - Dy)))
+  want = np.concatenate(parts, axis=-1).astype(np.float32)
   assert (got == want).all() and (plane.cpu().numpy() == 0).all()
 
 
