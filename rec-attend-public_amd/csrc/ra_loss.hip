@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void gt_box_fill_kernel(const float *params, i
 constexpr int kRectBlocks = 64;  // workgroups per image in the first stage
 template <int TM>  // the unrolled rectangle count: the smallest of 8 / 16 / 32 that holds T (the loop body is predicated, not skipped)
 __global__ __launch_bounds__(256) void box_iou_rects_kernel(const float *box, const float *params, int T, int H, int W,
-                                                            float *part) {
+                                                            float *part, int nblk) {
   __shared__ float red[4][kMaxT + 1];
   __shared__ float rect[kMaxT][4];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void box_iou_rects_kernel(const float *box, co
   float acc[TM + 1];
 #pragma unroll
   for (int t = 0; t <= TM; ++t) acc[t] = 0.f;
-  for (int e = (blockIdx.x * 256 + tid) * 4; e < H * W; e += kRectBlocks * 1024) {  // W % 4 == 0: four pixels of one row
+  for (int e = (blockIdx.x * 256 + tid) * 4; e < H * W; e += nblk * 1024) {  // W % 4 == 0: four pixels of one row
     const f32x4 v = *reinterpret_cast<const f32x4 *>(a + e);
     const int yy = e / W, xx = e - yy * W;
     acc[TM] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -348,11 +348,11 @@ __global__ __launch_bounds__(256) void box_iou_rects_kernel(const float *box, co
 }
 
 __global__ __launch_bounds__(64) void box_iou_rects_finish_kernel(const float *part, const float *params, int T, int H, int W,
-                                                                  float *iou) {
+                                                                  float *iou, int nblk) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (t >= T) return;
   float is = 0.f, sa = 0.f;
-  for (int k = 0; k < kRectBlocks; ++k) {  // fixed order
+  for (int k = 0; k < nblk; ++k) {  // fixed order
     is += part[((size_t)b * kRectBlocks + k) * (kMaxT + 1) + t];
     sa += part[((size_t)b * kRectBlocks + k) * (kMaxT + 1) + kMaxT];
   }
@@ -749,13 +749,17 @@ extern "C" int ra_box_iou_rects_f32(const float *box, const float *params, int B
     return fail(RA_E_SHAPE, "ra_box_iou_rects_f32: T <= %d, W %% 4 == 0 and a 16-byte aligned map required", loss::kMaxT);
   if (ws_floats < ra_box_iou_rects_workspace_floats(B)) return fail(RA_E_WORKSPACE, "ra_box_iou_rects_f32: workspace too small");
   hipStream_t st = as_stream(stream);
+  // workgroups per image: about four 16-byte loads per thread — a workgroup's fixed cost is its T + 1 cross-wave reductions, and 64
+  // workgroups on a 128 x 448 map (box_model at KITTI size: under one load per thread) made the launch 38 us for 7 MB (round 6)
+  int nblk = ceil_div(H * W / 4, 256 * 4);
+  nblk = nblk < 1 ? 1 : (nblk > loss::kRectBlocks ? loss::kRectBlocks : nblk);
   if (T <= 8)
-    hipLaunchKernelGGL(loss::box_iou_rects_kernel<8>, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
+    hipLaunchKernelGGL(loss::box_iou_rects_kernel<8>, dim3(nblk, B), dim3(256), 0, st, box, params, T, H, W, ws, nblk);
   else if (T <= 16)
-    hipLaunchKernelGGL(loss::box_iou_rects_kernel<16>, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
+    hipLaunchKernelGGL(loss::box_iou_rects_kernel<16>, dim3(nblk, B), dim3(256), 0, st, box, params, T, H, W, ws, nblk);
   else
-    hipLaunchKernelGGL(loss::box_iou_rects_kernel<32>, dim3(loss::kRectBlocks, B), dim3(256), 0, st, box, params, T, H, W, ws);
-  hipLaunchKernelGGL(loss::box_iou_rects_finish_kernel, dim3(B), dim3(64), 0, st, ws, params, T, H, W, iou);
+    hipLaunchKernelGGL(loss::box_iou_rects_kernel<32>, dim3(nblk, B), dim3(256), 0, st, box, params, T, H, W, ws, nblk);
+  hipLaunchKernelGGL(loss::box_iou_rects_finish_kernel, dim3(B), dim3(64), 0, st, ws, params, T, H, W, iou, nblk);
   return launch_status("ra_box_iou_rects_f32");
 }
 

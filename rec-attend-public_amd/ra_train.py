@@ -2195,7 +2195,9 @@ class TrainStep(object):
     if not self.host_match:
       return ops.segm_match(iou, s_gt)
     blocks = self.__dict__.setdefault('_match_blocks', {})
-    key = (site, tuple(iou.shape))
+    # one block per (call site, shape, STREAM): the box matching may run on a side stream under the mask matching (match_side_stream)
+    # — two calls in flight at once must not share the staging block and its control words
+    key = (site, tuple(iou.shape), torch.cuda.current_stream().cuda_stream)
     threads = getattr(self, '_match_threads', None)
     if threads is None:
       n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
