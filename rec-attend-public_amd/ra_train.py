@@ -1943,6 +1943,7 @@ class TrainStep(object):
     Cityscapes architectures (full_model.py:165-194)."""
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    self._match_seq = 0  # (_segm_match's staging blocks are keyed by the call's position in the step)
     self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
     self._pack.refresh()  # this step's packed filters and padded biases: one gather over the parameter bucket
     self._wgrad_parts.reset()
@@ -2195,9 +2196,13 @@ class TrainStep(object):
     if not self.host_match:
       return ops.segm_match(iou, s_gt)
     blocks = self.__dict__.setdefault('_match_blocks', {})
-    # one block per (call site, shape, STREAM): the box matching may run on a side stream under the mask matching (match_side_stream)
-    # — two calls in flight at once must not share the staging block and its control words
-    key = (site, tuple(iou.shape), torch.cuda.current_stream().cuda_stream)
+    # one block per (call site, shape, position in the step): the box matching may run on a side stream under the mask matching
+    # (match_side_stream) — two calls in flight at once must not share the staging block and its control words.  The position
+    # counts the step's matching calls (forward_loss resets it), so the eager first step and the captured one find the same
+    # blocks (a block made DURING capture would pin memory inside it and invalidate the capture)
+    seq = self.__dict__.get('_match_seq', 0)
+    self._match_seq = seq + 1
+    key = (site, tuple(iou.shape), seq)
     threads = getattr(self, '_match_threads', None)
     if threads is None:
       n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -2491,6 +2496,7 @@ class BoxTrainStep(TrainStep):
   def forward_loss(self, x, y_gt, s_gt, knobs=None, generator=None, d_in=None, y_in=None):
     P, d, opt = self.leaves, self.d, self.opt
     self._pack.clear()  # the optimizer wrote new weights since the last step
+    self._match_seq = 0  # (_segm_match's staging blocks are keyed by the call's position in the step)
     self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
     self._pack.refresh()
     self._wgrad_parts.reset()
