@@ -337,6 +337,14 @@ size_t ra_ctrl_batch_workspace_bytes(const ra_ctrl_desc *d, int B);
 int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
                             float *h_last, float *ctrl_out, float *glimpse_maps, float *attn, void *ws,
                             size_t ws_bytes, int *status_dev, void *stream);
+/* ... on the XCD-local exchange (round 6): group g's 16 workgroups run on XCD (g + xcd_offset) mod 8 and exchange through that XCD's
+ * L2 (as ra_controller_split_f32's XCD-local form) instead of agent-scope atomics.  At most 8 groups per launch; the CALLER vouches that
+ * launches which can run at the same time use offsets that keep their groups on different XCDs (DecodePipeline: slot k of 4 streams with 2
+ * groups each -> offset 2 k).  xcd_offset < 0, more than 8 groups, RA_CTRL_XCD=0 or a device whose workgroups do not report XCC ids 0..7:
+ * the agent-scope form (= ra_controller_batch_f32).  Same workspace (ra_ctrl_batch_workspace_bytes holds the role tickets). */
+int ra_controller_batch_xcd_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
+                                float *h_last, float *ctrl_out, float *glimpse_maps, float *attn, void *ws,
+                                size_t ws_bytes, int *status_dev, int xcd_offset, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * K3/K5  Gaussian attention.  Replaces modellib.get_gaussian_filter (modellib.py:581-612),

@@ -533,6 +533,42 @@ __device__ inline void gather_multi(const u64 *g, int n, int nimg, unsigned tag,
   __syncthreads();
 }
 
+// ... the same through the XCD's L2 (the XL form of K2b, round 6): granules are plain 8-byte stores of the producer, polled
+// with loads that bypass this CU's L1 — as gather_l2 above, eight in flight per thread.
+__device__ inline void gather_multi_l2(__amdgpu_buffer_rsrc_t r, size_t first, int n, int nimg, unsigned tag, float *dst, int stride, int *err) {
+  const int total = n * nimg;
+  for (int base = 0; base < total; base += kThreads * 8) {
+    unsigned pending = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (base + threadIdx.x + kThreads * j < total) pending |= 1u << j;
+    unsigned spins = 0;
+    while (pending) {
+      u32x2g x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (pending & (1u << j))
+          x[j] = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(first + base + threadIdx.x + kThreads * j) * 8, 0, (int)0x80000001u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((pending & (1u << j)) && x[j].y == tag) {
+          const int e = base + threadIdx.x + kThreads * j;
+          const int i = e / n, c = e - i * n;
+          dst[i * stride + c] = __uint_as_float(x[j].x);
+          pending &= ~(1u << j);
+        }
+      if (pending) {
+        if (++spins > kSpinLimit) {
+          *err = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // out[i][col] = sum_k x[i][k] * W[k][col] for the images of the group; ncol a power of two <= 64, n real columns;
 // threads = (col, k-part), a part walks quads of consecutive k (one 16-byte LDS read of x per image and quad);
 // xs and K multiples of 4 (K: the tail is zero-padded by the caller's layout or handled below);
@@ -568,15 +604,30 @@ __device__ inline int gemv_multi(const float *W, int n, int ncol, const float *x
   return parts;
 }
 
-template <int FR, int NI>
+// XL = true (round 6): the XCD-local form, as controller_split_kernel's — a 1-D grid of 128 workgroups, 16 per XCD; a workgroup
+// on XCD x draws its slice p from x's role tickets and serves group (x - xcd_off) mod 8, so a group's 16 workgroups share one
+// L2 and exchange through it (plain stores, L1-bypassing polls) instead of agent-scope atomics; XCDs without a group leave at
+// once.  At most 8 groups per launch; concurrent launches are given different xcd_off by the caller (one team per XCD).
+template <int FR, int NI, bool XL = false>
 __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctrl_desc d, const float *feat,
                                                                     const float *__restrict__ wp, int B, float *h_last,
                                                                     float *ctrl_out, float *gmaps, float *attn,
-                                                                    unsigned *ws, int *status, int prio) {
+                                                                    unsigned *ws, int *status, int prio, unsigned *tickets, int xcd_off) {
   raise_prio(prio);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Layout L = layout(d);
-  const int t = threadIdx.x, p = blockIdx.x, grp = blockIdx.y;
+  const int t = threadIdx.x;
+  int p = blockIdx.x, grp = blockIdx.y;
+  if constexpr (XL) {
+    unsigned *role_sh = reinterpret_cast<unsigned *>(smem);
+    const int x = xcc_id();
+    if (t == 0) *role_sh = ticket_draw(tickets + x * kTicketPoolStride) % (unsigned)kP;
+    __syncthreads();
+    p = (int)*role_sh;
+    __syncthreads();  // read by all before the weight slice overwrites it
+    grp = (x - xcd_off) & 7;
+    if (grp * NI >= B) return;  // (the whole team)
+  }
   const int G = d.G, Cf = d.Cf, hid = d.hid, us = L.us, gs = L.gs, K = L.K;
   const int Gx = kP * gs, Kp = round_up(K, 4), Gxp = round_up(Gx, 4);
   const int b0 = grp * NI, nimg = (B - b0 < NI) ? B - b0 : NI;
@@ -588,7 +639,16 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
   unsigned *wsg = ws + (size_t)grp * ws_words_per_group<NI>(d);
   const unsigned tag = wsg[0] + 1u;
   u64 *gran = reinterpret_cast<u64 *>(wsg + 2);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gran, 0, (int)(granules_per_group<NI>(d) * 8), 0x00020000);
   int err = 0;
+  auto publish = [&](u64 *g, unsigned tg, float v) {  // (shadows the agent-scope helper: g is an address inside `gran`)
+    if constexpr (XL) publish_l2(grs, (int)(g - gran), tg, v);
+    else ctrl2::publish(g, tg, v);
+  };
+  auto gather_multi = [&](const u64 *g, int n, int nimg_, unsigned tg, float *dst, int stride, int *e) {
+    if constexpr (XL) gather_multi_l2(grs, (size_t)(g - gran), n, nimg_, tg, dst, stride, e);
+    else ctrl2::gather_multi(g, n, nimg_, tg, dst, stride, e);
+  };
 
   {  // weight slice -> LDS (stays for the whole launch)
     const f32x4 *src = reinterpret_cast<const f32x4 *>(wp + (size_t)p * L.slice);
@@ -773,15 +833,30 @@ __global__ __launch_bounds__(kThreads) void controller_batch_kernel(const ra_ctr
 
 template <int FR, int NI>
 int launch_batch(const ra_ctrl_desc &d, const float *feat, const float *wp, int B, float *h_last, float *ctrl_out,
-                 float *gmaps, float *attn, unsigned *ws, int *status, size_t lds, hipStream_t st) {
-  auto kern = controller_batch_kernel<FR, NI>;
+                 float *gmaps, float *attn, unsigned *ws, size_t ws_bytes, int *status, size_t lds, int xcd_off, hipStream_t st) {
+  auto kern = controller_batch_kernel<FR, NI, false>;
+  auto kern_xl = controller_batch_kernel<FR, NI, true>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern_xl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(kP, ceil_div(B, NI)), dim3(kThreads), lds, st, d, feat, wp, B, h_last, ctrl_out, gmaps,
-                     attn, ws, status, tail_prio(1));
+  // the XCD-local form: only when the caller names an XCD offset (xcd_off >= 0: it vouches that concurrent launches use others),
+  // the launch has at most 8 groups, and the device's workgroups report the XCC ids 0..7 (RA_CTRL_XCD=0: never)
+  static int xl = -1;
+  if (xl < 0) {
+    const char *e = getenv("RA_CTRL_XCD");
+    if (e && atoi(e) == 0) xl = 0;
+    else if (const int c = xcc_census_ok(); c >= 0) xl = c;
+  }
+  unsigned *tickets = ws + ws_bytes / 4 - 8 * kTicketPoolStride;
+  if (xl == 1 && xcd_off >= 0 && ceil_div(B, NI) <= 8)
+    hipLaunchKernelGGL(kern_xl, dim3(8 * kP), dim3(kThreads), lds, st, d, feat, wp, B, h_last, ctrl_out, gmaps, attn, ws, status,
+                       tail_prio(1), tickets, xcd_off & 7);
+  else
+    hipLaunchKernelGGL(kern, dim3(kP, ceil_div(B, NI)), dim3(kThreads), lds, st, d, feat, wp, B, h_last, ctrl_out, gmaps,
+                       attn, ws, status, tail_prio(1), tickets, 0);
   return launch_status("ra_controller_batch_f32");
 }
 
@@ -883,12 +958,19 @@ extern "C" int ra_ctrl_batch_group_images(const ra_ctrl_desc *d, int B) {
 extern "C" size_t ra_ctrl_batch_workspace_bytes(const ra_ctrl_desc *d, int B) {
   if (!d || B <= 0 || !ctrl2::batch_supported<4>(*d)) return 0;
   const int g = ctrl2::group_images(*d, B);
-  return (size_t)ceil_div(B, g) * (g == 8 ? ctrl2::ws_words_per_group<8>(*d) : ctrl2::ws_words_per_group<4>(*d)) * 4;
+  // (+ the role tickets of the XCD-local form, at the end: 8 pools of one 128-byte line)
+  return ((size_t)ceil_div(B, g) * (g == 8 ? ctrl2::ws_words_per_group<8>(*d) : ctrl2::ws_words_per_group<4>(*d)) + 8 * kTicketPoolStride) * 4;
 }
 
 extern "C" int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
                                        float *h_last, float *ctrl_out, float *glimpse_maps, float *attn, void *ws,
                                        size_t ws_bytes, int *status_dev, void *stream) {
+  return ra_controller_batch_xcd_f32(d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, ws, ws_bytes, status_dev, -1, stream);
+}
+
+extern "C" int ra_controller_batch_xcd_f32(const ra_ctrl_desc *d, const float *feat, const float *wpacked, int B,
+                                           float *h_last, float *ctrl_out, float *glimpse_maps, float *attn, void *ws,
+                                           size_t ws_bytes, int *status_dev, int xcd_offset, void *stream) {
   if (!d || !feat || !wpacked || !ws || B <= 0) return fail(RA_E_INVALID, "ra_controller_batch_f32: bad argument");
   if (!ctrl2::batch_supported<4>(*d)) return fail(RA_E_SHAPE, "ra_controller_batch_f32: unsupported descriptor");
   const int g = ctrl2::group_images(*d, B);
@@ -900,8 +982,8 @@ extern "C" int ra_controller_batch_f32(const ra_ctrl_desc *d, const float *feat,
   hipStream_t st = as_stream(stream);
   unsigned *w = reinterpret_cast<unsigned *>(ws);
 #define RA_C3(FR)                                                                                                        \
-  return g == 8 ? ctrl2::launch_batch<FR, 8>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, status_dev, lds, st) \
-                : ctrl2::launch_batch<FR, 4>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, status_dev, lds, st)
+  return g == 8 ? ctrl2::launch_batch<FR, 8>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, ws_bytes, status_dev, lds, xcd_offset, st) \
+                : ctrl2::launch_batch<FR, 4>(*d, feat, wpacked, B, h_last, ctrl_out, glimpse_maps, attn, w, ws_bytes, status_dev, lds, xcd_offset, st)
   if (fr <= 4) RA_C3(4);
   if (fr <= 16) RA_C3(16);
   if (fr <= 32) RA_C3(32);

@@ -434,9 +434,12 @@ class DecodePipeline(object):
       eng = ra_engine.DecodeEngine(proto.d, self.model, box_model=proto.box)
       for flag in ('fuse_pairs', 'fuse_patch_pairs', 'ctrl_split', 'fuse_score',
                    'cache_first', 'fill_cache_inline', 'nsub', 'use_graph', 'use_wino', 'wino_unfuse', 'pair_wino', 'prefill_ride',
-                   'fuse_extract_conv0', 'use_split', 'split_first', 'split_patch', 'box_iou_rects'):
+                   'fuse_extract_conv0', 'use_split', 'split_first', 'split_patch', 'box_iou_rects', 'ctrl_batch_xcd'):
         setattr(eng, flag, getattr(proto, flag))
       eng.co_resident = self.co_resident
+      # slots on the same stream never run at the same time; with other pipelines beside this one (co_resident > streams) the
+      # company is not ours to place: K2b then keeps its agent-scope exchange
+      eng.xcd_slot, eng.xcd_slots = k % self.streams, (self.streams if self.co_resident <= self.streams else 0)
       self.slots.append((eng, streams[k % self.streams]))
 
   def __len__(self):

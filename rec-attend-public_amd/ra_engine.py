@@ -68,6 +68,8 @@ class DecodeEngine(object):
     # round 6: K1s also as the FIRST controller-CNN layer where no image-part cache applies (the KITTI / Cityscapes architectures:
     # 13 / 21 channels packed to 16 / 24, the canvas as a plane — ra_conv_split_plane_f32) ...
     self.split_first = os.environ.get('RA_SPLIT_FIRST', '1') != '0'
+    self.ctrl_batch_xcd = os.environ.get('RA_CTRL_BATCH_XCD', '1') != '0'  # K2b's groups each on an XCD of their own, exchanging through its L2
+    self.xcd_slot, self.xcd_slots = 0, 1  # this engine's place among the launches that can run at the same time (set by DecodePipeline; 0 slots: unknown company -> agent scope)
     self.box_iou_rects = os.environ.get('RA_BOX_IOU_RECTS', '1') != '0'  # box_model: IoU of the step's box against the GT boxes from their corners
     # ... and in the attention CNN on the 48 x 48 patch (single-source layers with 16 / 24 / 32 / 64 input channels; ragged 24- and
     # 12-pixel maps).  'auto': where a layer has >= RA_SPLIT_PATCH_MIN_MF MFLOP per launch (the KITTI-sized nets: 16 images x 5-40
@@ -349,6 +351,15 @@ class DecodeEngine(object):
         # more than 14 images, or launches that overlap: the group-shared form (K2b, 16 workgroups per group of images)
         b['ctrl_ws'], b['ctrl_status'] = ops.ctrl_batch_workspace(self.desc, Bs, device)
         b['ctrl_batch'] = True
+        # round 6: K2b on the XCD-local exchange where every group of every launch that can run at the same time gets an XCD
+        # of its own: `xcd_slot` of `xcd_slots` concurrent launches (DecodePipeline: stream k of its streams; a lone engine: 0 of 1)
+        ng = -(-Bs // ops.ctrl_batch_group(self.desc, Bs))
+        # ... and the teams in flight take at most half of the XCDs (RA_CTRL_BATCH_XCD_MAX_TEAMS, default 4).  Measured: cfg5's two
+        # slots of two groups 42.5k -> 45.5k instance-timesteps/s (the tail as launched 284 -> 279 us and, more, 16 CUs of ONE XCD
+        # per team instead of 4 on each of the eight); cfg2's four slots of two groups 68.0k -> 65.6k: with a team on every XCD the
+        # controller CNN's XCD-contiguous tile walks each wait for a half-occupied XCD somewhere (profiles/r06_k1s_sweep.txt)
+        if self.ctrl_batch_xcd and self.xcd_slots >= 1 and self.xcd_slots * ng <= int(os.environ.get('RA_CTRL_BATCH_XCD_MAX_TEAMS', '4')):
+          b['ctrl_xcd_off'] = (self.xcd_slot % self.xcd_slots) * ng
       if self.box:
         b['noise'] = f(T, Bs, H, W)
         b['ysel'] = f(Bs, H, W)
@@ -502,8 +513,11 @@ class DecodeEngine(object):
   def _launch_tail(self, b, tt, want_box, src):
     d, Wt, T = self.d, self.W, self.d['T']
     H, W, Fh, Fw = d['H'], d['W'], d['Fh'], d['Fw']
-    if 'ctrl_ws' in b:
-      (ops.controller_batch if b.get('ctrl_batch') else ops.controller_split)(
+    if 'ctrl_ws' in b and b.get('ctrl_batch'):
+      ops.controller_batch(self.desc, src, Wt['ctrl_split'], b['h_last'][tt], b['ctrl_out'][tt], b['gmaps'][tt], b['attn'][tt],
+                           b['ctrl_ws'], b['ctrl_status'], xcd_offset=b.get('ctrl_xcd_off', -1))
+    elif 'ctrl_ws' in b:
+      ops.controller_split(
           self.desc, src, Wt['ctrl_split'], b['h_last'][tt], b['ctrl_out'][tt], b['gmaps'][tt], b['attn'][tt],
           b['ctrl_ws'], b['ctrl_status'])
     else:

@@ -80,6 +80,7 @@ SIGNATURES = {
     'ra_ctrl_batch_supported': (_I, [C.POINTER(CtrlDesc)]),
     'ra_ctrl_batch_workspace_bytes': (_Z, [C.POINTER(CtrlDesc), _I]),
     'ra_controller_batch_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    'ra_controller_batch_xcd_f32': (_I, [C.POINTER(CtrlDesc), _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     'ra_gaussian_filter_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'ra_extract_direct_f32': (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'ra_extract_conv0_supported': (_I, [_I, _I, _I, _I, _I]),

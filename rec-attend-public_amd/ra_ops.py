@@ -165,12 +165,14 @@ def ctrl_batch_workspace(desc, B, device):
           torch.zeros(1, dtype=torch.int32, device=device))
 
 
-def controller_batch(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status):
-  """K2b: ra_controller_split_f32's recurrence with the weight slices shared by groups of ctrl_batch_group(desc, B) images."""
+def controller_batch(desc, feat, wp, h_last, ctrl_out, gmaps, attn, ws, status, xcd_offset=-1):
+  """K2b: ra_controller_split_f32's recurrence with the weight slices shared by groups of ctrl_batch_group(desc, B) images.
+  xcd_offset >= 0: the XCD-local exchange, group g on XCD (g + xcd_offset) % 8 (ra_controller_batch_xcd_f32: the caller keeps
+  concurrent launches on different XCDs); -1: agent-scope atomics."""
   _need_cuda(feat, wp, h_last, ctrl_out, gmaps, attn)
-  check(rn.lib().ra_controller_batch_f32(C.byref(desc), ptr(feat), ptr(wp), feat.shape[0], ptr(h_last), ptr(ctrl_out),
-                                         ptr(gmaps), ptr(attn), ptr(ws), ws.numel() * 8, ptr(status), rn.stream_ptr()),
-        'ra_controller_batch_f32')
+  check(rn.lib().ra_controller_batch_xcd_f32(C.byref(desc), ptr(feat), ptr(wp), feat.shape[0], ptr(h_last), ptr(ctrl_out),
+                                             ptr(gmaps), ptr(attn), ptr(ws), ws.numel() * 8, ptr(status), int(xcd_offset), rn.stream_ptr()),
+        'ra_controller_batch_xcd_f32')
 
 
 # ---------------------------------------------------------------------------- device ops

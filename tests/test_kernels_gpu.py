@@ -361,7 +361,9 @@ def test_controller_batch(cuda, arch, H, W, flags, B):
     h, co, gm = ora._controller(d, P64, feat.astype(np.float64), np.dtype(np.float64))
     cn, ls, ctr, size, lv = ora._decode_ctrl(d, co, np.dtype(np.float64))
     h_last, ctrl_out, gmaps, attn = z(B, d['hid']), z(B, 9), z(B, d['iters'], d['G']), z(B, 16)
-    ops.controller_batch(desc, dev(feat, cuda), wp, h_last, ctrl_out, gmaps, attn, ws, status)
+    # launch 0: agent-scope exchange; launches 1, 2: the XCD-local form (round 6), group g on XCD (g + offset) % 8 — the same
+    # workspace (generation tags and role tickets only ever count up)
+    ops.controller_batch(desc, dev(feat, cuda), wp, h_last, ctrl_out, gmaps, attn, ws, status, xcd_offset=(-1, 0, 5)[rep])
     torch.cuda.synchronize()
     assert int(status.item()) == 0
     assert relerr(h_last.cpu().numpy(), h) < 5e-5
